@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py -- ConvVAE train-step throughput on MI355X (driver contract).
+
+A "step" = one pass of the hot path over one synthetic batch that is already resident
+in HBM: forward + backward (vaenpvc_train_fwd_bwd) [+ RCCL all-reduce of the flat
+gradient buffer when N > 1] + fused TF-Adam.  Workload at N = 1 (BASELINE.json
+configs[1], north_star "batch 256 x [1,513,128]"): 256*128 = 32768 independent 513-bin
+frames per step per GPU (weak scaling: fixed per-GPU work).  The literal F = 256 reading
+is reported in `config.literal_batch256`.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'vae-npvc_amd'))
+sys.path.insert(0, ROOT)
+
+# SURVEY 8(d) / BASELINE.md section 4: algorithmic figures per frame
+FLOP_PER_FRAME_TRAIN = 28.85e6          # 3 x effective forward MACs x 2
+BYTES_PER_FRAME_TRAIN = 300752.0        # layer-materialised model, fp32 activations
+BYTES_PER_STEP_PARAMS = 37.57e6         # weights fwd+bwd, grads, Adam state
+HBM_PEAK = 8.0e12
+FP32_PEAK = 157.3e12
+# dominant kernel family: the last decoder layer (1025-tap conv_transpose = dense Toeplitz GEMM
+# [F,4104] x [4104,513]); algorithmic flops per frame for one pass (fwd, or dgrad, or wgrad)
+DEC3_FLOP_PER_FRAME = 2.0 * 8 * 513 * 513
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--frames', type=int, default=256 * 128, help='frames per step PER GPU')
+    p.add_argument('--impl', default='auto', choices=['auto', 'generic'])
+    p.add_argument('--timer-tag', default='dec3_fwd', help='kernel site timed with HIP events for the roofline')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-seconds', type=float, default=15.0)
+    p.add_argument('--no-literal', action='store_true', help='skip the extra F=256 measurement')
+    return p.parse_args()
+
+
+def cpu_baseline(arch, seconds):
+    """The oracle's PyTorch-CPU fp32 restatement (CPU stand-in for the TF1 reference path,
+    which cannot run here): full train step (fwd + autograd bwd + TF-Adam), F = 256
+    frames per step, all host cores, as many steps as fit in `seconds`."""
+    import numpy as np
+    import torch
+    from oracle import convvae_oracle as O
+    F = 256
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    P = O.torch_params(O.init_params(arch, 0), torch.float32, requires_grad=True)
+    x, y, eps = O.make_inputs(arch, F, 0)
+    xt, yt, et = torch.tensor(x), torch.tensor(y), torch.tensor(eps)
+    m = {k: torch.zeros_like(v) for k, v in P.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in P.items()}
+
+    def step(t):
+        for p in P.values():
+            p.grad = None
+        O.torch_loss(arch, P, xt, yt, et)['G'].backward()
+        lr_t = 1e-4 * (1 - 0.999 ** t) ** 0.5 / (1 - 0.5 ** t)
+        with torch.no_grad():
+            for k, p in P.items():
+                g = p.grad
+                m[k].mul_(0.5).add_(g, alpha=0.5)
+                v2[k].mul_(0.999).addcmul_(g, g, value=0.001)
+                p.sub_(lr_t * m[k] / (v2[k].sqrt() + 1e-8))
+    step(1)
+    times, t0, t = [], time.perf_counter(), 2
+    while time.perf_counter() - t0 < seconds and len(times) < 200:
+        a = time.perf_counter()
+        step(t)
+        times.append(time.perf_counter() - a)
+        t += 1
+    med = float(np.median(times))
+    return {'value': F / med, 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+            'sample': 'oracle torch-CPU fp32 train step (fwd+bwd+TF-Adam), F=256 frames/step, %d steps, median' % len(times),
+            'ms_per_step': med * 1e3}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from hipvae import Engine
+    from hipvae import lib as L
+    from hipvae.dp import Stepper
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    with open(os.path.join(ROOT, 'vae-npvc_amd', 'architecture-vae-vcc2016.json')) as fp:
+        arch = json.load(fp)
+    t = arch['training']
+    eng = Engine(arch, impl=args.impl)
+    eng.init_params(seed=0)
+    st = Stepper(eng, t['lr'], t['beta1'], t['beta2'])
+    st.broadcast_params()
+    lib = L.load_library()
+
+    def make_batch(F, seed):
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        x = (torch.rand(F, 513, generator=g) * 2 - 1).to(eng.device)
+        y = torch.randint(0, 10, (F,), generator=g, dtype=torch.int64).to(eng.device)
+        eps = torch.randn(F, 128, generator=g).to(eng.device)
+        return x, y, eps
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(F, steps, warmup, tag=None):
+        x, y, eps = make_batch(F, 1234 + rank)
+        for _ in range(warmup):
+            st.step(x, y, eps)
+        barrier()
+        if tag:
+            lib.vaenpvc_timer_select(tag.encode())
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st.step(x, y, eps)
+        barrier()
+        dt = time.perf_counter() - t0
+        kern = None
+        if tag:
+            import ctypes as C
+            ms, n = C.c_double(), C.c_int64()
+            lib.vaenpvc_timer_read(C.byref(ms), C.byref(n))
+            lib.vaenpvc_timer_select(None)
+            if n.value:
+                kern = (ms.value / n.value, n.value)
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, kern
+
+    F = args.frames
+    dt, kern = timed(F, args.steps, args.warmup, args.timer_tag)
+    frames_per_s = world * F * args.steps / dt
+    steps_per_s = args.steps / dt
+    out = {
+        'metric': 'SP frames/sec (train step: fwd+bwd+Adam%s)' % ('+RCCL all-reduce' if world > 1 else ''),
+        'value': frames_per_s, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic (x~U(-1,1), y~randint(10), eps~N(0,1) injected, resident in HBM; random-init weights)',
+        'config': {'workload': 'ConvVAE architecture-vae-vcc2016 train step, 256x[1,513,128] = %d frames/step/GPU' % F,
+                   'frames_per_step_per_gpu': F, 'global_frames_per_step': F * world, 'impl': args.impl,
+                   'parallelism': 'dp%d' % world},
+        'step_fraction_of_rooflines': {
+            'hbm_model_B': (frames_per_s / world * BYTES_PER_FRAME_TRAIN + steps_per_s * BYTES_PER_STEP_PARAMS) / HBM_PEAK,
+            'fp32_flops': frames_per_s / world * FLOP_PER_FRAME_TRAIN / FP32_PEAK},
+    }
+    if kern:
+        avg_ms, n = kern
+        ach = DEC3_FLOP_PER_FRAME * F / (avg_ms * 1e-3) / 1e12
+        out['roofline'] = {'bound': 'mfma', 'kernel': args.timer_tag, 'achieved': ach, 'peak': FP32_PEAK / 1e12,
+                           'unit': 'TFLOP/s', 'frac': ach / (FP32_PEAK / 1e12), 'traffic': None,
+                           'avg_kernel_ms': avg_ms, 'launches': n,
+                           'algorithmic_flops_per_launch': DEC3_FLOP_PER_FRAME * F}
+    if not args.no_literal:
+        dt2, _ = timed(256, 50, 5)
+        out['config']['literal_batch256'] = {'frames_per_s': world * 256 * 50 / dt2, 'ms_per_step': dt2 / 50 * 1e3}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(arch, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,159 @@
+/*
+ * vaenpvc.h -- C-ABI of the MI355X-native ConvVAE hot path (libvaenpvc_hip.so).
+ *
+ * The reference (JeremyCCHsu/vae-npvc) has NO foreign-function interface: its hot
+ * path is a TensorFlow-1 graph executed by `sess.run`.  This header is therefore the
+ * boundary a maintainer would bind instead of building that graph; each entry point
+ * cites the reference code whose arithmetic it replaces (paths relative to the
+ * reference repository root).  See INTEGRATION.md for the ctypes stub.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer owned by the caller, contiguous,
+ *     16-byte aligned; nothing is allocated or freed behind the ABI;
+ *   - all work is enqueued on the caller's `hipStream_t` (passed as void*), nothing
+ *     synchronises the host;
+ *   - return value: 0 = ok, <0 = error (see VAENPVC_E_*); `vaenpvc_last_error()`
+ *     returns a thread-local message; no C++ exception crosses the ABI;
+ *   - frames are rows: x is [F, H] float32 (the reference's [F,1,H,1] NCHW tensor,
+ *     analyzer.py:116-122), y is int64 [F] (analyzer.py:127), H = 513.
+ */
+#ifndef VAENPVC_H_
+#define VAENPVC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAENPVC_MAX_LAYERS 8
+
+#define VAENPVC_OK 0
+#define VAENPVC_E_ARG (-1)       /* bad argument / malformed architecture */
+#define VAENPVC_E_WORKSPACE (-2) /* workspace too small */
+#define VAENPVC_E_HIP (-3)       /* a HIP runtime call failed */
+#define VAENPVC_E_UNSUPPORTED (-4)
+
+/* implementation selector (vaenpvc_set_impl) */
+#define VAENPVC_IMPL_AUTO 0 /* tuned gfx950 kernels where the geometry matches, generic otherwise */
+#define VAENPVC_IMPL_GENERIC 1 /* geometry-generic HIP kernels only (cross-check path) */
+
+/* workspace modes */
+#define VAENPVC_MODE_INFER 0
+#define VAENPVC_MODE_TRAIN 1
+
+/* Architecture description = the keys model/vae.py actually reads from
+ * architecture-*.json (model/vae.py:22-23,39,74,80-81,86,95).  Kernels are [k,1],
+ * strides [s,1] (W = 1 everywhere). */
+typedef struct vaenpvc_arch {
+  int32_t H;     /* arch["hwc"][0] : bins per frame (513) */
+  int32_t z_dim; /* arch["z_dim"] ; also the speaker-embedding width (model/vae.py:21-24) */
+  int32_t y_dim; /* arch["y_dim"] : number of speakers */
+  int32_t n_enc;
+  int32_t enc_kernel[VAENPVC_MAX_LAYERS];
+  int32_t enc_stride[VAENPVC_MAX_LAYERS];
+  int32_t enc_output[VAENPVC_MAX_LAYERS];
+  int32_t gen_h; /* arch["generator"]["hwc"] = [h, w(=1), c] */
+  int32_t gen_c;
+  int32_t n_dec;
+  int32_t dec_kernel[VAENPVC_MAX_LAYERS];
+  int32_t dec_stride[VAENPVC_MAX_LAYERS];
+  int32_t dec_output[VAENPVC_MAX_LAYERS];
+} vaenpvc_arch;
+
+typedef struct vaenpvc_ctx vaenpvc_ctx;
+
+/* ABI version of this header; bumped on any signature change. */
+int vaenpvc_abi_version(void);
+const char* vaenpvc_last_error(void);
+
+/* Replaces ConvVAE.__init__ / _sanity_check (model/vae.py:9-39): validates the
+ * architecture (AssertionError analogue = VAENPVC_E_ARG) and derives the TF 'SAME'
+ * shape chain. Holds no device memory. */
+int vaenpvc_ctx_create(const vaenpvc_arch* arch, vaenpvc_ctx** out);
+void vaenpvc_ctx_destroy(vaenpvc_ctx* ctx);
+int vaenpvc_set_impl(vaenpvc_ctx* ctx, int impl);
+
+/* Trainable-tensor table = tf.trainable_variables() of the reference in creation
+ * order (model/vae.py:20-24,72-103; util/layers.py:33-64): 44 tensors for the
+ * VCC2016 architecture, stored back to back in ONE flat float32 buffer in TF layouts
+ * (conv [k,1,Cin,Cout]; conv_transpose [k,1,Cout,Cin]; dense [in,out]). */
+int vaenpvc_param_count(const vaenpvc_ctx* ctx);
+int64_t vaenpvc_param_floats(const vaenpvc_ctx* ctx);
+/* name: caller buffer of name_cap bytes; shape: int64[4]; returns 0 / VAENPVC_E_ARG */
+int vaenpvc_param_info(const vaenpvc_ctx* ctx, int index, char* name, int name_cap,
+                       int64_t* offset_floats, int32_t* ndim, int64_t* shape);
+
+/* Workspace (activations kept for backward, per-frame statistics, gradient
+ * scratch).  `vaenpvc_ws_find` exposes named regions (float offsets into d_ws) so
+ * that tests can inspect every intermediate the reference graph would hold:
+ *   enc_a<i>, enc_st<i>, z_mu, z_lv, z, h, dec_a<i>, dec_st<i>, xh,
+ *   kl_f, nll_f, d_enc_a<i>, d_z_mu, d_z_lv, d_z, d_h, d_dec_a<i>, d_xh        */
+int64_t vaenpvc_workspace_bytes(const vaenpvc_ctx* ctx, int64_t F, int mode);
+int vaenpvc_ws_find(const vaenpvc_ctx* ctx, int64_t F, int mode, const char* name,
+                    int64_t* offset_floats, int64_t* count_floats);
+
+/* ConvVAE.encode (model/vae.py:139-141 -> _encoder 72-82; util/layers.py:47-66):
+ * d_z_mu [F,z_dim]; d_z_lv may be NULL (convert.py:85 only uses z_mu). */
+int vaenpvc_encode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, int64_t F,
+                       float* d_z_mu, float* d_z_lv, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ConvVAE.decode / generate (model/vae.py:143-145 -> _generator 84-103, _merge 51-61;
+ * util/image.py:4-5 NHWC transpose is a no-op on memory since W = 1):
+ * d_z [F,z_dim], d_y int64 [F] -> d_xh [F,H]. */
+int vaenpvc_decode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_z,
+                       const int64_t* d_y, int64_t F, float* d_xh, void* d_ws, size_t ws_bytes,
+                       void* stream);
+
+/* ConvVAE.loss (model/vae.py:106-137; util/layers.py:152-183) + the gradient half of
+ * `optimizer.minimize(loss['G'])` (trainer/vae.py:19-24).
+ * d_eps [F,z_dim] is the N(0,1) draw of GaussianSampleLayer, injected by the caller
+ * (the reference's tf.random_normal is unseeded).
+ * d_grads: flat float32 buffer, same layout as d_params, OVERWRITTEN with
+ *          d loss['G'] / d params for the LOCAL mean over these F frames.
+ * d_loss3: float[3] = { G, D_KL, logP } (model/vae.py:127-130). */
+int vaenpvc_train_fwd_bwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_x,
+                          const int64_t* d_y, const float* d_eps, int64_t F, float* d_grads,
+                          float* d_loss3, void* d_ws, size_t ws_bytes, void* stream);
+
+/* Forward + losses only (VAETrainer._refresh_status fetch, trainer/vae.py:31-36). */
+int vaenpvc_loss_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_x,
+                     const int64_t* d_y, const float* d_eps, int64_t F, float* d_loss3,
+                     void* d_ws, size_t ws_bytes, void* stream);
+
+/* tf.train.AdamOptimizer apply for all trainables as ONE fused pass over the flat
+ * buffers (trainer/vae.py:16-24; TF-flavour: p -= lr_t * m / (sqrt(v) + eps),
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t), t = step, 1-based).  grad_scale multiplies the
+ * gradient first (1/world_size after an all-reduce SUM). */
+int vaenpvc_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n,
+                      int64_t step, float lr, float beta1, float beta2, float eps,
+                      float grad_scale, void* stream);
+
+/* Tanhize.forward_process / backward_process (analyzer.py:82-87), per bin:
+ * fwd: clip((x-xmin)/(xmax-xmin),0,1)*2-1 ; bwd: (x*.5+.5)*(xmax-xmin)+xmin.
+ * d_xmin/d_xmax: float32 [H]. In-place allowed. */
+int vaenpvc_tanhize_fwd(const float* d_sp, const float* d_xmin, const float* d_xmax, float* d_x,
+                        int64_t F, int32_t H, void* stream);
+int vaenpvc_tanhize_bwd(const float* d_x, const float* d_xmin, const float* d_xmax, float* d_sp,
+                        int64_t F, int32_t H, void* stream);
+
+/* analyzer.read record slicing (analyzer.py:113-127): rows of `rec_floats` float32
+ * (1029) -> x = Tanhize(row[0:H]) and y = int64(row[rec_floats-1]) (bit-exact cast). */
+int vaenpvc_unpack_records(const float* d_records, int64_t F, int32_t rec_floats, int32_t H,
+                           const float* d_xmin, const float* d_xmax, float* d_x, int64_t* d_y,
+                           void* stream);
+
+/* Measurement hook (no reference counterpart): brackets every launch of ONE tagged
+ * kernel with a hipEvent pair on the launch stream, so bench.py can report that
+ * kernel's average duration over the timed region.  Tags are the kernel-site names
+ * listed in DESIGN.md (e.g. "dec3_fwd").  NULL or "" disables.  Process-global. */
+int vaenpvc_timer_select(const char* tag);
+/* Synchronises the recorded events, returns the summed milliseconds and the number of
+ * launches since the last read, and resets the accumulator. */
+int vaenpvc_timer_read(double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAENPVC_H_ */

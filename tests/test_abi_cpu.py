@@ -1,0 +1,123 @@
+"""CPU-side checks of the C-ABI library: it loads without a GPU, exports every symbol
+the header declares, and its host-side tables agree with the oracle's layout."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, SMALL_ARCH
+from hipvae import lib as L
+from hipvae.engine import arch_to_struct, glorot_init
+from oracle import convvae_oracle as O
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, 'include', 'vaenpvc.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(vaenpvc_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_loads_and_exports_every_header_symbol():
+    lib = L.load_library()
+    names = header_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), 'missing export %s' % n
+        assert n in L.SIGNATURES, 'binding table lacks %s' % n
+    assert lib.vaenpvc_abi_version() == L.ABI_VERSION
+
+
+def make_ctx(arch):
+    lib = L.load_library()
+    a = arch_to_struct(arch)
+    ctx = C.c_void_p()
+    rc = lib.vaenpvc_ctx_create(C.byref(a), C.byref(ctx))
+    return lib, ctx, rc
+
+
+@pytest.mark.parametrize('which', ['vcc', 'small'])
+def test_param_table_matches_oracle_layout(arch, which):
+    arch = arch if which == 'vcc' else SMALL_ARCH
+    lib, ctx, rc = make_ctx(arch)
+    assert rc == 0
+    want = O.param_layout(arch)
+    assert lib.vaenpvc_param_count(ctx) == len(want)
+    buf = C.create_string_buffer(128)
+    off, nd, shp = C.c_int64(), C.c_int32(), (C.c_int64 * 4)()
+    pos = 0
+    for i, (name, shape) in enumerate(want.items()):
+        assert lib.vaenpvc_param_info(ctx, i, buf, 128, C.byref(off), C.byref(nd), shp) == 0
+        assert buf.value.decode() == name
+        assert tuple(shp[k] for k in range(nd.value)) == tuple(shape)
+        assert off.value == pos
+        pos += int(np.prod(shape))
+    assert lib.vaenpvc_param_floats(ctx) == pos
+    assert lib.vaenpvc_param_info(ctx, len(want), buf, 128, None, None, None) == L.MODE_INFER - 1  # E_ARG
+    lib.vaenpvc_ctx_destroy(ctx)
+
+
+def test_workspace_queries(arch):
+    lib, ctx, rc = make_ctx(arch)
+    assert rc == 0
+    b_inf = lib.vaenpvc_workspace_bytes(ctx, 16, L.MODE_INFER)
+    b_trn = lib.vaenpvc_workspace_bytes(ctx, 16, L.MODE_TRAIN)
+    assert 0 < b_inf < b_trn
+    off, cnt = C.c_int64(), C.c_int64()
+    assert lib.vaenpvc_ws_find(ctx, 16, L.MODE_TRAIN, b'enc_a4', C.byref(off), C.byref(cnt)) == 0
+    assert cnt.value == 16 * 768 and off.value % 64 == 0
+    assert lib.vaenpvc_ws_find(ctx, 16, L.MODE_TRAIN, b'd_dec_a2', C.byref(off), C.byref(cnt)) == 0
+    assert cnt.value == 16 * 4104
+    assert lib.vaenpvc_ws_find(ctx, 16, L.MODE_INFER, b'd_xh', C.byref(off), C.byref(cnt)) < 0
+    assert b'no workspace region' in lib.vaenpvc_last_error()
+    # the INFER layout is a prefix of the TRAIN layout (same offsets)
+    o2 = C.c_int64()
+    for nm in (b'enc_a0', b'z_mu', b'h', b'dec_a2', b'xh', b'nll_f'):
+        lib.vaenpvc_ws_find(ctx, 16, L.MODE_INFER, nm, C.byref(off), None)
+        lib.vaenpvc_ws_find(ctx, 16, L.MODE_TRAIN, nm, C.byref(o2), None)
+        assert off.value == o2.value
+    lib.vaenpvc_ctx_destroy(ctx)
+
+
+def test_malformed_architecture_is_rejected(arch):
+    import copy
+    bad = copy.deepcopy(arch)
+    bad['generator']['output'] = [32, 16, 8]          # len mismatch -> AssertionError (vae.py:37-39)
+    with pytest.raises(AssertionError):
+        arch_to_struct(bad)
+    bad = copy.deepcopy(arch)
+    bad['generator']['stride'][-1] = [2, 1]           # output 1026 bins != 513
+    lib, ctx, rc = make_ctx(bad)
+    assert rc == -1 and b'generator output' in lib.vaenpvc_last_error()
+    bad = copy.deepcopy(arch)
+    bad['encoder']['kernel'][0] = [7, 3]
+    with pytest.raises(ValueError):
+        arch_to_struct(bad)
+
+
+def test_null_and_range_arguments_return_errors(arch):
+    lib, ctx, rc = make_ctx(arch)
+    assert lib.vaenpvc_encode_fwd(ctx, None, None, 4, None, None, None, 0, None) == -1
+    assert lib.vaenpvc_adam_step(None, None, None, None, 10, 1, 1e-4, .5, .999, 1e-8, 1.0, None) == -1
+    assert lib.vaenpvc_workspace_bytes(ctx, 0, L.MODE_TRAIN) < 0
+    lib.vaenpvc_ctx_destroy(ctx)
+
+
+def test_glorot_init_matches_tf_defaults(arch):
+    lib, ctx, rc = make_ctx(arch)
+    from collections import OrderedDict
+    layout, pos = OrderedDict(), 0
+    for name, shape in O.param_layout(arch).items():
+        layout[name] = (pos, tuple(shape)); pos += int(np.prod(shape))
+    flat = glorot_init(layout, seed=0).numpy()
+    P = O.unflatten_params(arch, flat)
+    k = P['Encoder/Conv2d-4/kernel']
+    lim = np.sqrt(6.0 / (7 * 128 + 7 * 256))
+    assert np.abs(k).max() <= lim and np.abs(k).max() > 0.95 * lim
+    assert np.all(P['Encoder/Conv2d-4/bias'] == 0) and np.all(P['Generator/ConvT-LN1.scale'] == 1)
+    assert np.all(P['Generator/ConvT-LN1.offset'] == 0)
+    e = P['y_embedding/y_emb']
+    assert np.abs(e).max() <= np.sqrt(6.0 / 138) + 1e-7
+    assert np.array_equal(flat, glorot_init(layout, seed=0).numpy())
+    lib.vaenpvc_ctx_destroy(ctx)

@@ -1,0 +1,272 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle.
+
+Bars: integer plumbing bit-exact; activations / losses / converted frames
+<= 1e-4 relative (||a-b||_inf / max(||b||_inf, 1e-6)) against the float64 oracle;
+gradients and Adam trajectories <= 2e-4 (fp32 summation over the batch).
+Every measured error is appended to gpurun_out/parity_report.txt.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, ROOT, SMALL_ARCH, load_arch, rel_err, sample_idx
+from oracle import convvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_ACT = 1e-4
+TOL_GRAD = 2e-4
+REPORT = os.path.join(ROOT, 'gpurun_out', 'parity_report.txt')
+
+
+def report(tag, err, tol):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, 'a') as fp:
+        fp.write('%-70s err=%.3e tol=%.1e %s\n' % (tag, err, tol, 'OK' if err <= tol else 'FAIL'))
+
+
+def check(tag, got, want, tol, fails):
+    e = rel_err(got, want)
+    report(tag, e, tol)
+    if not (e <= tol):
+        fails.append('%s: %.3e > %.1e' % (tag, e, tol))
+
+
+ARCHS = {'vcc': load_arch(), 'small': SMALL_ARCH}
+
+
+def make_engine(which, impl):
+    from hipvae import Engine
+    return Engine(ARCHS[which], impl=impl)
+
+
+def upload(eng, P, x, y, eps):
+    eng.load_flat(O.flatten_params(P))
+    dev = eng.device
+    return (torch.tensor(x, device=dev), torch.tensor(y, device=dev), torch.tensor(eps, device=dev))
+
+
+def run_train(eng, P, x, y, eps):
+    xt, yt, et = upload(eng, P, x, y, eps)
+    grads = torch.full((eng.n_params,), float('nan'), device=eng.device)
+    l3 = eng.train_fwd_bwd(xt, yt, et, grads).clone()
+    torch.cuda.synchronize()
+    return l3.cpu().numpy(), grads.cpu().numpy()
+
+
+CASES = [('small', 'generic', 5, 1), ('vcc', 'generic', 4, 0), ('vcc', 'auto', 4, 0), ('vcc', 'auto', 37, 5),
+         ('small', 'auto', 5, 1)]
+
+
+@pytest.mark.parametrize('which,impl,F,seed', CASES)
+def test_forward_intermediates_and_losses(which, impl, F, seed):
+    from hipvae import lib as L
+    arch = ARCHS[which]
+    eng = make_engine(which, impl)
+    P = O.init_params(arch, seed)
+    x, y, eps = O.make_inputs(arch, F, seed)
+    l3, _ = run_train(eng, P, x, y, eps)
+    R = O.np_forward(arch, P, x, y, eps)
+    g = O.geometry(arch)
+    fails = []
+    tag = '%s/%s/F%d ' % (which, impl, F)
+
+    def region(name):
+        return eng.ws_region(F, L.MODE_TRAIN, name).cpu().numpy()
+    for i, l in enumerate(g['enc']):
+        a = R['enc_a%d' % i]
+        check(tag + 'enc_a%d' % i, region('enc_a%d' % i).reshape(a.shape), a, TOL_ACT, fails)
+        st = region('enc_st%d' % i).reshape(F, 2)
+        mu = a.mean(axis=(1, 2)); rstd = 1 / np.sqrt(a.var(axis=(1, 2)) + 1e-5)
+        # the mean is compared on the scale of the activations (it may legitimately be ~0)
+        check(tag + 'enc_mean%d' % i, st[:, 0] / np.abs(a).max(), mu / np.abs(a).max(), TOL_ACT, fails)
+        check(tag + 'enc_rstd%d' % i, st[:, 1], rstd, TOL_ACT, fails)
+    for k in ('z_mu', 'z_lv', 'z', 'h'):
+        check(tag + k, region(k).reshape(R[k].shape), R[k], TOL_ACT, fails)
+    for i in range(len(g['dec']) - 1):
+        a = R['dec_a%d' % i]
+        check(tag + 'dec_a%d' % i, region('dec_a%d' % i).reshape(a.shape), a, TOL_ACT, fails)
+        st = region('dec_st%d' % i).reshape(F, 2)
+        check(tag + 'dec_rstd%d' % i, st[:, 1], 1 / np.sqrt(a.var(axis=(1, 2)) + 1e-5), TOL_ACT, fails)
+    check(tag + 'xh', region('xh').reshape(R['xh'].shape), R['xh'], TOL_ACT, fails)
+    check(tag + 'loss3', l3, np.array([R['G'], R['D_KL'], R['logP']]), TOL_ACT, fails)
+    report(tag + 'recon-L1 mean|xh-xh_ref|', float(np.abs(region('xh').reshape(R['xh'].shape) - R['xh']).mean()), 1.0)
+    assert not fails, '\n'.join(fails)
+
+
+@pytest.mark.parametrize('which,impl,F,seed', CASES + [('vcc', 'auto', 256, 2)])
+def test_gradients(which, impl, F, seed):
+    arch = ARCHS[which]
+    eng = make_engine(which, impl)
+    P = O.init_params(arch, seed)
+    x, y, eps = O.make_inputs(arch, F, seed)
+    l3, grads = run_train(eng, P, x, y, eps)
+    assert np.isfinite(grads).all(), 'some gradient entries were never written'
+    L, G = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64)
+    fails = []
+    tag = '%s/%s/F%d grad ' % (which, impl, F)
+    for name, (off, shape) in eng.layout.items():
+        n = int(np.prod(shape))
+        check(tag + name, grads[off:off + n].reshape(shape), G[name], TOL_GRAD, fails)
+    check(tag + 'loss3', l3, np.array([L['G'], L['D_KL'], L['logP']]), TOL_ACT, fails)
+    assert not fails, '\n'.join(fails)
+
+
+@pytest.mark.parametrize('which,impl,fixture,F,seed', [('vcc', 'generic', 'vcc2016_F4_seed0.npz', 4, 0),
+                                                        ('vcc', 'auto', 'vcc2016_F4_seed0.npz', 4, 0),
+                                                        ('small', 'generic', 'small_F5_seed1.npz', 5, 1)])
+def test_against_committed_golden_vectors(which, impl, fixture, F, seed):
+    arch = ARCHS[which]
+    gold = np.load(os.path.join(GOLDEN, fixture))
+    eng = make_engine(which, impl)
+    P = O.init_params(arch, seed)
+    x, y, eps = O.make_inputs(arch, F, seed)
+    fails = []
+    tag = 'golden %s/%s ' % (which, impl)
+    xt, yt, et = upload(eng, P, x, y, eps)
+    from hipvae.dp import Stepper
+    st = Stepper(eng, 1e-4, 0.5, 0.999)
+    idx = sample_idx(eng.n_params, 64)
+    p0 = eng.params.cpu().numpy().astype(np.float64)[idx]
+    for t in (1, 2, 3):
+        l3 = st.step(xt, yt, et).clone()
+        if t == 1:
+            from hipvae import lib as L
+            check(tag + 'loss3', l3.cpu().numpy(), gold['loss3'], TOL_ACT, fails)
+            for k in ('z_mu', 'z_lv', 'xh'):
+                got = eng.ws_region(F, L.MODE_TRAIN, k).cpu().numpy().reshape(gold[k].shape)
+                check(tag + k, got, gold[k], TOL_ACT, fails)
+            g = st.grads.cpu().numpy()
+            for i, (name, (off, shape)) in enumerate(eng.layout.items()):
+                n = int(np.prod(shape))
+                l2 = np.sqrt((g[off:off + n].astype(np.float64) ** 2).sum())
+                e = abs(l2 - gold['grad_l2'][i]) / max(gold['grad_l2'][i], 1e-6)
+                report(tag + 'grad_l2 ' + name, e, TOL_GRAD)
+                if e > TOL_GRAD:
+                    fails.append('grad_l2 %s %.3e' % (name, e))
+                k = min(8, n)
+                e = np.abs(g[off:off + n][sample_idx(n)] - gold['grad_samples'][i][:k]).max() / max(gold['grad_absmax'][i], 1e-6)
+                report(tag + 'grad_samples ' + name, e, TOL_GRAD)
+                if e > TOL_GRAD:
+                    fails.append('grad_samples %s %.3e' % (name, e))
+        # Adam trajectory: compare the UPDATE (p_t - p_0), which is what the optimiser computes
+        got = eng.params.cpu().numpy().astype(np.float64)[idx] - p0
+        want = gold['adam_p%d' % t] - p0
+        e = np.abs(got - want).max() / np.abs(want).max()
+        report(tag + 'adam step %d (delta)' % t, e, 2e-3)
+        if e > 2e-3:
+            fails.append('adam step %d: %.3e' % (t, e))
+    assert not fails, '\n'.join(fails)
+
+
+@pytest.mark.parametrize('which,impl,F', [('vcc', 'generic', 9), ('vcc', 'auto', 9), ('vcc', 'auto', 1),
+                                          ('vcc', 'auto', 700), ('small', 'generic', 3)])
+def test_encode_decode_conversion_path(which, impl, F):
+    """convert.py:79-89: x -> encode (z_mu) -> decode(target id)."""
+    arch = ARCHS[which]
+    eng = make_engine(which, impl)
+    P = O.init_params(arch, 7)
+    x, y, _ = O.make_inputs(arch, F, 7)
+    eng.load_flat(O.flatten_params(P))
+    xt = torch.tensor(x, device=eng.device)
+    z_mu, z_lv = eng.encode(xt.view(F, 1, -1, 1), want_lv=True)
+    trg = arch['y_dim'] - 1
+    yt = torch.full((F,), trg, dtype=torch.int64, device=eng.device)
+    xh = eng.decode(z_mu, yt)
+    R = O.np_forward(arch, P, x, np.full(F, trg), None)
+    fails = []
+    tag = 'convert %s/%s/F%d ' % (which, impl, F)
+    check(tag + 'z_mu', z_mu.cpu().numpy(), R['z_mu'], TOL_ACT, fails)
+    check(tag + 'z_lv', z_lv.cpu().numpy(), R['z_lv'], TOL_ACT, fails)
+    check(tag + 'xh', xh.cpu().numpy(), R['xh'], TOL_ACT, fails)
+    assert not fails, '\n'.join(fails)
+
+
+def test_data_plane_kernels(arch):
+    """Tanhize fwd/bwd (analyzer.py:82-87) and record unpacking with the bit-exact
+    float32 -> int64 speaker cast (analyzer.py:127)."""
+    eng = make_engine('vcc', 'auto')
+    rng = np.random.default_rng(0)
+    xmin = rng.uniform(-12, -8, 513).astype(np.float32)
+    xmax = xmin + rng.uniform(2, 6, 513).astype(np.float32)
+    N = 1000
+    rec = rng.standard_normal((N, 1029)).astype(np.float32)
+    rec[:, :513] = rng.uniform(-14, -2, (N, 513))
+    spk = rng.integers(0, 10, N)
+    rec[:, -1] = spk.astype(np.float32)
+    dev = eng.device
+    tmin, tmax = torch.tensor(xmin, device=dev), torch.tensor(xmax, device=dev)
+    x, y = eng.unpack_records(torch.tensor(rec, device=dev), tmin, tmax)
+    assert y.dtype == torch.int64 and np.array_equal(y.cpu().numpy(), spk.astype(np.int64))
+    want = O.tanhize_forward(rec[:, :513].astype(np.float64), xmin.astype(np.float64), xmax.astype(np.float64))
+    assert np.abs(x.cpu().numpy() - want).max() < 2e-6
+    assert x.min().item() >= -1.0 and x.max().item() <= 1.0
+    back = eng.tanhize(x, tmin, tmax, forward=False).cpu().numpy()
+    wantb = O.tanhize_backward(want, xmin.astype(np.float64), xmax.astype(np.float64))
+    assert rel_err(back, wantb) < 1e-6
+    fw = eng.tanhize(torch.tensor(rec[:, :513], device=dev), tmin, tmax, forward=True)
+    assert torch.equal(fw, x)
+
+
+@pytest.mark.parametrize('impl', ['generic', 'auto'])
+def test_properties_at_full_batch(arch, impl):
+    """Size-independent properties at the metric's batch (F = 256)."""
+    eng = make_engine('vcc', impl)
+    F = 256
+    P = O.init_params(arch, 11)
+    x, y, eps = O.make_inputs(arch, F, 11)
+    l3, g = run_train(eng, P, x, y, eps)
+    # (1) data-parallel identity: grads of the full batch == mean of the grads of the two halves
+    h = F // 2
+    la, ga = run_train(eng, P, x[:h], y[:h], eps[:h])
+    lb, gb = run_train(eng, P, x[h:], y[h:], eps[h:])
+    assert rel_err(0.5 * (ga + gb), g) < 1e-4
+    assert np.allclose(0.5 * (la + lb), l3, rtol=1e-5)
+    # (2) frame independence: permuting frames permutes outputs
+    perm = np.random.default_rng(0).permutation(F)
+    xt = torch.tensor(x, device=eng.device)
+    z = eng.encode(xt).cpu().numpy()
+    zp = eng.encode(torch.tensor(x[perm], device=eng.device)).cpu().numpy()
+    assert rel_err(zp, z[perm]) < 1e-6
+    # (3) decode(z, y) depends on the embedding only through row y
+    zt = torch.tensor(z, device=eng.device)
+    y3 = torch.full((F,), 3, dtype=torch.int64, device=eng.device)
+    base = eng.decode(zt, y3).clone()
+    views = eng.param_views()
+    views['y_embedding/y_emb'][[0, 1, 2, 4, 5, 6, 7, 8, 9]] += 1.0
+    assert torch.equal(eng.decode(zt, y3), base)
+    views['y_embedding/y_emb'][3] += 1.0
+    assert not torch.equal(eng.decode(zt, y3), base)
+    # (4) all-zero weights -> xh = 0 and closed-form logP
+    eng.params.zero_()
+    for name, v in eng.param_views().items():
+        if name.endswith('.scale'):
+            v.fill_(1.0)
+    et = torch.tensor(eps, device=eng.device)
+    yt = torch.tensor(y, device=eng.device)
+    l3z = eng.loss_fwd(xt, yt, et).cpu().numpy()
+    want = -0.5 * (513 * O.LOG_2PI + (x.astype(np.float64) ** 2).sum(1).mean() / (1 + 1e-6))
+    assert abs(l3z[2] - want) < 1e-4 * abs(want)
+    assert abs(l3z[1] - 128 * 0.5 * (1 / (1 + 1e-6) - 1)) < 1e-6
+
+
+def test_argument_errors(arch):
+    from hipvae import HipVaeError
+    eng = make_engine('vcc', 'auto')
+    x = torch.zeros(4, 513, device=eng.device)
+    with pytest.raises(TypeError):
+        eng.encode(x.double())
+    with pytest.raises(ValueError):
+        eng.encode(torch.zeros(4, 512, device=eng.device))
+    with pytest.raises(TypeError):
+        eng.decode(torch.zeros(4, 128, device=eng.device), torch.zeros(4, dtype=torch.int32, device=eng.device))
+    # workspace too small -> VAENPVC_E_WORKSPACE through the ABI
+    import ctypes as C
+    from hipvae import lib as L
+    z = torch.zeros(4, 128, device=eng.device)
+    ws = torch.zeros(1024, dtype=torch.uint8, device=eng.device)
+    rc = eng.lib.vaenpvc_encode_fwd(eng.ctx, eng.params.data_ptr(), x.data_ptr(), 4, z.data_ptr(), None,
+                                    ws.data_ptr(), 1024, None)
+    assert rc == -2 and b'workspace too small' in eng.lib.vaenpvc_last_error()

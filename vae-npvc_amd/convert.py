@@ -1,0 +1,116 @@
+"""Conversion CLI with the reference's flag names (convert.py:14-30):
+
+    python convert.py --src SF1 --trg TM3 --model ConvVAE \
+        --checkpoint logdir/train/<stamp>/model.ckpt-<N>
+
+Device path per utterance (convert.py:79-89): Tanhize -> encode (z_mu) -> decode with the
+target speaker id -> inverse Tanhize.  The log-F0 transform (convert.py:51-57) runs on the
+host.  WORLD synthesis needs pyworld (absent here): when it is importable a wav is written,
+otherwise the converted features are saved as `<src>-<trg>-<basename>.npz`.
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+from datetime import datetime
+from importlib import import_module
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+FS = 16000
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument('--checkpoint', default=None, help='root of log dir')
+    p.add_argument('--src', default='SF1', help='source speaker [SF1 - TM3]')
+    p.add_argument('--trg', default='TM3', help='target speaker [SF1 - TM3]')
+    p.add_argument('--output_dir', default='./logdir', help='root of output dir')
+    p.add_argument('--module', default='model.vae', help='Module')
+    p.add_argument('--model', default=None, help='Model')
+    p.add_argument('--file_pattern', default='./dataset/vcc2016/bin/Testing Set/{}/*.bin', help='file pattern')
+    args = p.parse_args(argv)
+    if args.model is None:                                               # convert.py:23-27
+        raise ValueError('\n  You MUST specify `model`.'
+                         '\n    Use `python convert.py --help` to see applicable options.')
+    return args
+
+
+def make_output_name(output_dir, filename, src, trg, ext):              # convert.py:35-43
+    basename = os.path.splitext(os.path.split(str(filename, 'utf8'))[-1])[0]
+    print('Processing {}'.format(basename))
+    return os.path.join(output_dir, '{}-{}-{}.{}'.format(src, trg, basename, ext))
+
+
+def get_default_output(logdir_root):                                     # convert.py:45-49
+    stamp = datetime.now().strftime('%m%d-%H%M-%S-%Y')
+    logdir = os.path.join(logdir_root, 'output', stamp)
+    print('Using default logdir: {}'.format(logdir))
+    return logdir
+
+
+def convert_f0(f0, src, trg, etc_dir='./etc'):
+    """convert.py:51-57 -- note the thresholds apply to the TRANSFORMED value (quirk kept)."""
+    mu_s, std_s = np.fromfile(os.path.join(etc_dir, '{}.npf'.format(src)), np.float32)
+    mu_t, std_t = np.fromfile(os.path.join(etc_dir, '{}.npf'.format(trg)), np.float32)
+    f0 = np.asarray(f0, np.float32)
+    lf0 = np.where(f0 > 1., np.log(np.where(f0 > 1., f0, 1.)), f0).astype(np.float32)
+    lf0 = np.where(lf0 > 1., (lf0 - mu_s) / std_s * std_t + mu_t, lf0).astype(np.float32)
+    lf0 = np.where(lf0 > 1., np.exp(lf0), lf0).astype(np.float32)
+    return lf0
+
+
+def convert_utterance(machine, normalizer, sp, trg_id):
+    """The device tensor path of convert.py:79-89 for one utterance: sp [N,513] -> converted sp."""
+    import torch
+    x = normalizer.forward_process(sp)                                    # [N,513] in [-1,1]
+    x = x.view(x.shape[0], 1, x.shape[1], 1)                              # nh_to_nchw (convert.py:60-63)
+    y_t = torch.full((x.shape[0],), int(trg_id), dtype=torch.int64, device=x.device)
+    z = machine.encode(x)
+    x_t = machine.decode(z, y_t)                                          # NHWC [N,513,1,1]
+    x_t = x_t.reshape(x_t.shape[0], -1)                                   # tf.squeeze
+    return normalizer.backward_process(x_t)
+
+
+def main(argv=None):
+    from analyzer import read_whole_features, SPEAKERS, Tanhize, load_npf
+    from util.wrapper import load
+
+    args = parse_args(argv)
+    MODEL = getattr(import_module(args.module), args.model)
+    logdir, ckpt = os.path.split(args.checkpoint)
+    arch_file = glob.glob(os.path.join(logdir, 'architecture*.json'))[0]  # should only be 1 file
+    with open(arch_file) as fp:
+        arch = json.load(fp)
+    normalizer = Tanhize(xmax=load_npf('./etc/xmax.npf'), xmin=load_npf('./etc/xmin.npf'))
+    machine = MODEL(arch)
+    load(machine.engine, logdir, ckpt=ckpt)
+    output_dir = get_default_output(args.output_dir)
+    os.makedirs(output_dir, exist_ok=True)
+    trg_id = SPEAKERS.index(args.trg)
+    try:
+        import pyworld as pw
+        import soundfile as sf
+    except ImportError:
+        pw = sf = None
+    for feat in read_whole_features(args.file_pattern.format(args.src)):
+        sp = convert_utterance(machine, normalizer, feat['sp'], trg_id).cpu().numpy()
+        f0 = convert_f0(feat['f0'], args.src, args.trg)
+        feat.update({'sp': sp, 'f0': f0})
+        if pw is not None:
+            # analyzer.pw2wav (analyzer.py:162-173): sp_lin = 10^sp * en, float64 C-contiguous
+            en = feat['en'].reshape(-1, 1).astype(np.float64)
+            sp_lin = np.ascontiguousarray(np.power(10., sp.astype(np.float64)) * en)
+            y = pw.synthesize(np.ascontiguousarray(f0.astype(np.float64)), sp_lin,
+                              np.ascontiguousarray(feat['ap'].astype(np.float64)), FS)
+            sf.write(make_output_name(output_dir, feat['filename'], args.src, args.trg, 'wav'), y, FS)
+        else:
+            np.savez(make_output_name(output_dir, feat['filename'], args.src, args.trg, 'npz'),
+                     sp=sp, f0=f0, ap=feat['ap'], en=feat['en'])
+
+
+if __name__ == '__main__':
+    main()

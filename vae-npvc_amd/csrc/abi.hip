@@ -1,0 +1,292 @@
+// abi.hip -- the extern "C" surface declared in include/vaenpvc.h.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+#include "kernels.h"
+
+using namespace vaenpvc;
+
+struct vaenpvc_ctx {
+  Model m;
+  int impl = VAENPVC_IMPL_AUTO;
+  std::mutex mu;
+  std::map<std::pair<int64_t, int>, std::pair<std::vector<Region>, int64_t>> ws_cache;
+};
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* f, ...) {
+  va_list ap;
+  va_start(ap, f);
+  vsnprintf(g_err, sizeof g_err, f, ap);
+  va_end(ap);
+  return code;
+}
+
+static const std::pair<std::vector<Region>, int64_t>& layout_of(vaenpvc_ctx* c, int64_t F, int mode) {
+  std::lock_guard<std::mutex> lk(c->mu);
+  auto key = std::make_pair(F, mode);
+  auto it = c->ws_cache.find(key);
+  if (it == c->ws_cache.end()) {
+    if (c->ws_cache.size() > 64) c->ws_cache.clear();
+    int64_t total = 0;
+    auto regs = workspace_layout(c->m, F, mode, &total);
+    it = c->ws_cache.emplace(key, std::make_pair(std::move(regs), total)).first;
+  }
+  return it->second;
+}
+
+static int resolve(vaenpvc_ctx* c, int64_t F, int mode, void* d_ws, size_t ws_bytes, Ws* w) {
+  if (F < 1) return fail(VAENPVC_E_ARG, "F must be >= 1 (got %lld)", (long long)F);
+  if (F > (1LL << 24)) return fail(VAENPVC_E_ARG, "F too large (%lld)", (long long)F);
+  const auto& lay = layout_of(c, F, mode);
+  if (d_ws == nullptr || ws_bytes < (size_t)lay.second * 4)
+    return fail(VAENPVC_E_WORKSPACE, "workspace too small: need %lld bytes, got %lld", (long long)lay.second * 4,
+                (long long)ws_bytes);
+  if (((uintptr_t)d_ws & 15) != 0) return fail(VAENPVC_E_ARG, "workspace must be 16-byte aligned");
+  float* base = (float*)d_ws;
+  memset(w, 0, sizeof *w);
+  for (const Region& r : lay.first) {
+    float* p = base + r.offset;
+    const std::string& n = r.name;
+    auto idx = [&](size_t pre) { return atoi(n.c_str() + pre); };
+    if (n.rfind("enc_a", 0) == 0) w->enc_a[idx(5)] = p;
+    else if (n.rfind("enc_st", 0) == 0) w->enc_st[idx(6)] = p;
+    else if (n.rfind("dec_a", 0) == 0) w->dec_a[idx(5)] = p;
+    else if (n.rfind("dec_st", 0) == 0) w->dec_st[idx(6)] = p;
+    else if (n.rfind("d_enc_a", 0) == 0) w->d_enc_a[idx(7)] = p;
+    else if (n.rfind("d_dec_a", 0) == 0) w->d_dec_a[idx(7)] = p;
+    else if (n == "z_mu") w->z_mu = p;
+    else if (n == "z_lv") w->z_lv = p;
+    else if (n == "z") w->z = p;
+    else if (n == "h") w->h = p;
+    else if (n == "xh") w->xh = p;
+    else if (n == "kl_f") w->kl_f = p;
+    else if (n == "nll_f") w->nll_f = p;
+    else if (n == "d_xh") w->d_xh = p;
+    else if (n == "d_h") w->d_h = p;
+    else if (n == "d_z") w->d_z = p;
+    else if (n == "d_e") w->d_e = p;
+    else if (n == "d_z_mu") w->d_z_mu = p;
+    else if (n == "d_z_lv") w->d_z_lv = p;
+    else if (n == "dy_tmp") w->dy_tmp = p;
+    else if (n == "scratch") { w->scratch = p; w->scratch_floats = r.count; }
+  }
+  return 0;
+}
+
+static int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(VAENPVC_E_HIP, "%s: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+static bool use_tuned(const vaenpvc_ctx* c) {
+  return c->impl == VAENPVC_IMPL_AUTO && c->m.is_vcc2016 && tuned::available();
+}
+
+// ---- single-kernel event timer ---------------------------------------------------
+namespace vaenpvc {
+static std::string g_tag;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
+static size_t g_used = 0;
+static const size_t kPoolMax = 16384;
+bool timer_match(const char* tag) { return !g_tag.empty() && g_tag == tag; }
+void timer_begin(hipStream_t s) {
+  if (g_used >= kPoolMax) return;
+  if (g_used >= g_pool.size()) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    g_pool.emplace_back(a, b);
+  }
+  hipEventRecord(g_pool[g_used].first, s);
+}
+void timer_end(hipStream_t s) {
+  if (g_used >= kPoolMax || g_used >= g_pool.size()) return;
+  hipEventRecord(g_pool[g_used].second, s);
+  ++g_used;
+}
+}  // namespace vaenpvc
+
+extern "C" {
+
+int vaenpvc_timer_select(const char* tag) {
+  g_tag = tag ? tag : "";
+  g_used = 0;
+  return 0;
+}
+
+int vaenpvc_timer_read(double* total_ms, int64_t* launches) {
+  double tot = 0.0;
+  for (size_t i = 0; i < g_used; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_pool[i].second) != hipSuccess) return fail(VAENPVC_E_HIP, "timer sync");
+    if (hipEventElapsedTime(&ms, g_pool[i].first, g_pool[i].second) != hipSuccess) return fail(VAENPVC_E_HIP, "timer elapsed");
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (int64_t)g_used;
+  g_used = 0;
+  return 0;
+}
+
+int vaenpvc_abi_version(void) { return 1; }
+const char* vaenpvc_last_error(void) { return g_err; }
+
+int vaenpvc_ctx_create(const vaenpvc_arch* arch, vaenpvc_ctx** out) {
+  if (!arch || !out) return fail(VAENPVC_E_ARG, "null argument");
+  vaenpvc_ctx* c = new (std::nothrow) vaenpvc_ctx();
+  if (!c) return fail(VAENPVC_E_ARG, "out of host memory");
+  std::string err = build_model(*arch, &c->m);
+  if (!err.empty()) {
+    delete c;
+    return fail(VAENPVC_E_ARG, "architecture: %s", err.c_str());
+  }
+  const char* env = getenv("VAENPVC_IMPL");
+  if (env && strcmp(env, "generic") == 0) c->impl = VAENPVC_IMPL_GENERIC;
+  *out = c;
+  return 0;
+}
+
+void vaenpvc_ctx_destroy(vaenpvc_ctx* ctx) { delete ctx; }
+
+int vaenpvc_set_impl(vaenpvc_ctx* ctx, int impl) {
+  if (!ctx || (impl != VAENPVC_IMPL_AUTO && impl != VAENPVC_IMPL_GENERIC)) return fail(VAENPVC_E_ARG, "bad impl");
+  ctx->impl = impl;
+  return 0;
+}
+
+int vaenpvc_param_count(const vaenpvc_ctx* ctx) { return ctx ? (int)ctx->m.table.size() : VAENPVC_E_ARG; }
+int64_t vaenpvc_param_floats(const vaenpvc_ctx* ctx) { return ctx ? ctx->m.n_params : VAENPVC_E_ARG; }
+
+int vaenpvc_param_info(const vaenpvc_ctx* ctx, int index, char* name, int name_cap, int64_t* offset_floats,
+                       int32_t* ndim, int64_t* shape) {
+  if (!ctx || index < 0 || index >= (int)ctx->m.table.size()) return fail(VAENPVC_E_ARG, "bad parameter index");
+  const ParamInfo& p = ctx->m.table[index];
+  if (name && name_cap > 0) {
+    strncpy(name, p.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (offset_floats) *offset_floats = p.offset;
+  if (ndim) *ndim = p.ndim;
+  if (shape)
+    for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+  return 0;
+}
+
+int64_t vaenpvc_workspace_bytes(const vaenpvc_ctx* ctx, int64_t F, int mode) {
+  if (!ctx || F < 1 || (mode != VAENPVC_MODE_INFER && mode != VAENPVC_MODE_TRAIN)) return fail(VAENPVC_E_ARG, "bad argument");
+  return layout_of(const_cast<vaenpvc_ctx*>(ctx), F, mode).second * 4;
+}
+
+int vaenpvc_ws_find(const vaenpvc_ctx* ctx, int64_t F, int mode, const char* name, int64_t* offset_floats,
+                    int64_t* count_floats) {
+  if (!ctx || !name || F < 1) return fail(VAENPVC_E_ARG, "bad argument");
+  const auto& lay = layout_of(const_cast<vaenpvc_ctx*>(ctx), F, mode);
+  for (const Region& r : lay.first)
+    if (r.name == name) {
+      if (offset_floats) *offset_floats = r.offset;
+      if (count_floats) *count_floats = r.count;
+      return 0;
+    }
+  return fail(VAENPVC_E_ARG, "no workspace region named '%s'", name);
+}
+
+int vaenpvc_encode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, int64_t F, float* d_z_mu,
+                       float* d_z_lv, void* d_ws, size_t ws_bytes, void* stream) {
+  if (!ctx || !d_params || !d_x || !d_z_mu) return fail(VAENPVC_E_ARG, "null argument");
+  Ws w;
+  int rc = resolve(ctx, F, VAENPVC_MODE_INFER, d_ws, ws_bytes, &w);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (use_tuned(ctx)) tuned::encoder_fwd(ctx->m, d_params, d_x, F, w, s);
+  else generic::encoder_fwd(ctx->m, d_params, d_x, F, w, s);
+  size_t nb = (size_t)F * ctx->m.z * 4;
+  if (hipMemcpyAsync(d_z_mu, w.z_mu, nb, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(VAENPVC_E_HIP, "copy z_mu");
+  if (d_z_lv && hipMemcpyAsync(d_z_lv, w.z_lv, nb, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(VAENPVC_E_HIP, "copy z_lv");
+  return check_launch("encode_fwd");
+}
+
+int vaenpvc_decode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_z, const int64_t* d_y, int64_t F,
+                       float* d_xh, void* d_ws, size_t ws_bytes, void* stream) {
+  if (!ctx || !d_params || !d_z || !d_y || !d_xh) return fail(VAENPVC_E_ARG, "null argument");
+  Ws w;
+  int rc = resolve(ctx, F, VAENPVC_MODE_INFER, d_ws, ws_bytes, &w);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (use_tuned(ctx)) tuned::decoder_fwd(ctx->m, d_params, d_z, d_y, F, w, d_xh, s);
+  else generic::decoder_fwd(ctx->m, d_params, d_z, d_y, F, w, d_xh, s);
+  return check_launch("decode_fwd");
+}
+
+static int fwd_all(vaenpvc_ctx* ctx, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F,
+                   const Ws& w, bool want_grad, float* loss3, hipStream_t s) {
+  if (use_tuned(ctx)) tuned::encoder_fwd(ctx->m, P, x, F, w, s);
+  else generic::encoder_fwd(ctx->m, P, x, F, w, s);
+  generic::reparam_fwd(ctx->m, eps, F, w, s);
+  if (use_tuned(ctx)) tuned::decoder_fwd(ctx->m, P, w.z, y, F, w, w.xh, s);
+  else generic::decoder_fwd(ctx->m, P, w.z, y, F, w, w.xh, s);
+  generic::loss_fwd(ctx->m, x, F, w, want_grad, loss3, s);
+  return 0;
+}
+
+int vaenpvc_loss_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, const int64_t* d_y,
+                     const float* d_eps, int64_t F, float* d_loss3, void* d_ws, size_t ws_bytes, void* stream) {
+  if (!ctx || !d_params || !d_x || !d_y || !d_eps || !d_loss3) return fail(VAENPVC_E_ARG, "null argument");
+  Ws w;
+  int rc = resolve(ctx, F, VAENPVC_MODE_INFER, d_ws, ws_bytes, &w);
+  if (rc) return rc;
+  fwd_all(ctx, d_params, d_x, d_y, d_eps, F, w, false, d_loss3, (hipStream_t)stream);
+  return check_launch("loss_fwd");
+}
+
+int vaenpvc_train_fwd_bwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, const int64_t* d_y,
+                          const float* d_eps, int64_t F, float* d_grads, float* d_loss3, void* d_ws,
+                          size_t ws_bytes, void* stream) {
+  if (!ctx || !d_params || !d_x || !d_y || !d_eps || !d_grads || !d_loss3) return fail(VAENPVC_E_ARG, "null argument");
+  Ws w;
+  int rc = resolve(ctx, F, VAENPVC_MODE_TRAIN, d_ws, ws_bytes, &w);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  fwd_all(ctx, d_params, d_x, d_y, d_eps, F, w, true, d_loss3, s);
+  if (use_tuned(ctx)) tuned::backward(ctx->m, d_params, d_x, d_y, d_eps, F, w, d_grads, s);
+  else generic::backward(ctx->m, d_params, d_x, d_y, d_eps, F, w, d_grads, s);
+  return check_launch("train_fwd_bwd");
+}
+
+int vaenpvc_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n, int64_t step,
+                      float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  if (!d_params || !d_grads || !d_m || !d_v || n < 1 || step < 1) return fail(VAENPVC_E_ARG, "bad argument");
+  double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)step)) /
+                (1.0 - std::pow((double)beta1, (double)step));
+  launch_adam(d_params, d_grads, d_m, d_v, n, (float)lr_t, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
+  return check_launch("adam_step");
+}
+
+int vaenpvc_tanhize_fwd(const float* d_sp, const float* d_xmin, const float* d_xmax, float* d_x, int64_t F,
+                        int32_t H, void* stream) {
+  if (!d_sp || !d_xmin || !d_xmax || !d_x || F < 1 || H < 1) return fail(VAENPVC_E_ARG, "bad argument");
+  launch_tanhize(d_sp, d_xmin, d_xmax, d_x, F, H, true, (hipStream_t)stream);
+  return check_launch("tanhize_fwd");
+}
+
+int vaenpvc_tanhize_bwd(const float* d_x, const float* d_xmin, const float* d_xmax, float* d_sp, int64_t F,
+                        int32_t H, void* stream) {
+  if (!d_x || !d_xmin || !d_xmax || !d_sp || F < 1 || H < 1) return fail(VAENPVC_E_ARG, "bad argument");
+  launch_tanhize(d_x, d_xmin, d_xmax, d_sp, F, H, false, (hipStream_t)stream);
+  return check_launch("tanhize_bwd");
+}
+
+int vaenpvc_unpack_records(const float* d_records, int64_t F, int32_t rec_floats, int32_t H, const float* d_xmin,
+                           const float* d_xmax, float* d_x, int64_t* d_y, void* stream) {
+  if (!d_records || !d_xmin || !d_xmax || !d_x || !d_y || F < 1 || H < 1 || rec_floats < H + 1)
+    return fail(VAENPVC_E_ARG, "bad argument");
+  launch_unpack(d_records, F, rec_floats, H, d_xmin, d_xmax, d_x, d_y, (hipStream_t)stream);
+  return check_launch("unpack_records");
+}
+
+}  // extern "C"

@@ -1,0 +1,584 @@
+// generic_kernels.hip -- geometry-generic HIP kernels for the ConvVAE hot path.
+//
+// One thread per output element, sequential (deterministic) inner loops.  These
+// kernels accept ANY architecture JSON the reference accepts; the tuned gfx950
+// kernels (gfx950_*.hip) replace them for the VCC2016 geometry and are cross-checked
+// against them on the GPU.  Conventions shared by both families:
+//   * activations are frames-major [F, C, H] float32 (NCHW with W = 1);
+//   * for every conv+LayerNorm+lrelu layer the tensor kept in HBM is the PRE-LN conv
+//     output `a` plus per-frame (mean, rstd); consumers apply
+//     y = lrelu(gamma_c*(a-mean)*rstd + beta_c) when they load it ("LN on load"),
+//     so each inter-layer tensor is written once and read once per pass.
+// Reference arithmetic: util/layers.py:10-66,147-183 ; model/vae.py:51-137.
+#include <cstdio>
+
+#include "kernels.h"
+
+namespace vaenpvc {
+namespace generic {
+
+#define LN_EPS 1e-5f
+#define LEAK 0.02f
+#define EPSILON 1e-6f
+#define LOG_2PI 1.8378770664093453f
+
+struct G {  // device copy of ConvL geometry
+  int cin, hin, cout, hout, k, s, pad;
+};
+static G mk(const ConvL& l) { return G{l.cin, l.hin, l.cout, l.hout, l.k, l.s, l.pad}; }
+
+struct Act {  // LN-on-load descriptor; st == nullptr -> identity
+  const float* st;
+  const float* gamma;
+  const float* beta;
+};
+
+__device__ __forceinline__ float lnact(float v, const Act& a, int64_t f, int c) {
+  if (a.st == nullptr) return v;
+  float n = (v - a.st[2 * f]) * a.st[2 * f + 1] * a.gamma[c] + a.beta[c];
+  return fmaxf(n, LEAK * n);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// all threads receive the block total; blockDim.x must be a multiple of 64, <= 1024
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sm[i];
+  return r;
+}
+
+static inline dim3 grid1(int64_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+// ------------------------------------------------------------------ forward
+// util/layers.py:56-64 : a[f,o,j] = b[o] + sum_c sum_t W[t,c,o] * y_in[f,c,s*j-pad+t]
+__global__ void k_conv_fwd(const float* __restrict__ in, Act ai, const float* __restrict__ W,
+                           const float* __restrict__ b, float* __restrict__ out, int64_t F, G g) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t N = F * g.cout * g.hout;
+  if (idx >= N) return;
+  int j = (int)(idx % g.hout);
+  int o = (int)((idx / g.hout) % g.cout);
+  int64_t f = idx / ((int64_t)g.hout * g.cout);
+  float acc = b[o];
+  for (int c = 0; c < g.cin; ++c) {
+    const float* row = in + (f * g.cin + c) * g.hin;
+    for (int t = 0; t < g.k; ++t) {
+      int i = g.s * j - g.pad + t;
+      if (i < 0 || i >= g.hin) continue;
+      acc += lnact(row[i], ai, f, c) * W[((int64_t)t * g.cin + c) * g.cout + o];
+    }
+  }
+  out[idx] = acc;
+}
+
+// util/layers.py:32 : per-frame mean and biased variance over all C*H -> (mean, rstd)
+__global__ void k_ln_stats(const float* __restrict__ a, float* __restrict__ st, int n) {
+  __shared__ float sm[16];
+  int64_t f = blockIdx.x;
+  const float* p = a + f * n;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += p[i];
+  float mean = block_sum(s, sm) / n;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float d = p[i] - mean;
+    q += d * d;
+  }
+  float var = block_sum(q, sm) / n;
+  if (threadIdx.x == 0) {
+    st[2 * f] = mean;
+    st[2 * f + 1] = 1.0f / sqrtf(var + LN_EPS);
+  }
+}
+
+// model/vae.py:79-81 : z_mu, z_lv = dense(flatten(y_last)) ; flatten is C-major = memory order
+__global__ void k_heads_fwd(const float* __restrict__ a, Act ai, int hlast, const float* __restrict__ Wmu,
+                            const float* __restrict__ bmu, const float* __restrict__ Wlv,
+                            const float* __restrict__ blv, float* __restrict__ zmu, float* __restrict__ zlv,
+                            int64_t F, int flat, int z) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= F * 2 * z) return;
+  int n = (int)(idx % (2 * z));
+  int64_t f = idx / (2 * z);
+  const float* W = n < z ? Wmu : Wlv;
+  int nn = n < z ? n : n - z;
+  float acc = n < z ? bmu[nn] : blv[nn];
+  const float* row = a + f * flat;
+  for (int k = 0; k < flat; ++k) acc += lnact(row[k], ai, f, k / hlast) * W[(int64_t)k * z + nn];
+  (n < z ? zmu : zlv)[f * z + nn] = acc;
+}
+
+// util/layers.py:152-156 sampler and 170-183 KL (mu2 = lv2 = 0), one block per frame
+__global__ void k_reparam(const float* __restrict__ zmu, const float* __restrict__ zlv,
+                          const float* __restrict__ eps, float* __restrict__ z, float* __restrict__ kl_f, int zd) {
+  __shared__ float sm[16];
+  int64_t f = blockIdx.x;
+  float kl = 0.f;
+  for (int d = threadIdx.x; d < zd; d += blockDim.x) {
+    float mu = zmu[f * zd + d], lv = zlv[f * zd + d];
+    float v = expf(lv);
+    z[f * zd + d] = eps ? mu + eps[f * zd + d] * sqrtf(v) : mu;
+    kl += 0.5f * ((0.f - lv) + (v + mu * mu) / (1.0f + EPSILON) - 1.0f);
+  }
+  kl = block_sum(kl, sm);
+  if (threadIdx.x == 0) kl_f[f] = kl;
+}
+
+// model/vae.py:51-61,89 : h = z*Wz + bz + E[y]*Wy + by + b
+__global__ void k_merge_fwd(const float* __restrict__ z, const int64_t* __restrict__ y,
+                            const float* __restrict__ emb, const float* __restrict__ Wz,
+                            const float* __restrict__ bz, const float* __restrict__ Wy,
+                            const float* __restrict__ by, const float* __restrict__ bm, float* __restrict__ h,
+                            int64_t F, int zd, int M) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= F * M) return;
+  int n = (int)(idx % M);
+  int64_t f = idx / M;
+  const float* zr = z + f * zd;
+  const float* er = emb + y[f] * zd;
+  float a1 = bz[n], a2 = by[n];
+  for (int k = 0; k < zd; ++k) {
+    a1 += zr[k] * Wz[(int64_t)k * M + n];
+    a2 += er[k] * Wy[(int64_t)k * M + n];
+  }
+  h[idx] = (a1 + a2) + bm[n];
+}
+
+// model/vae.py:96-99 : a[f,o,p] = b[o] + sum_c sum_j W[p+pad-s*j, o, c] * y_in[f,c,j]
+__global__ void k_convT_fwd(const float* __restrict__ in, Act ai, const float* __restrict__ W,
+                            const float* __restrict__ b, float* __restrict__ out, int64_t F, G g) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t N = F * g.cout * g.hout;
+  if (idx >= N) return;
+  int p = (int)(idx % g.hout);
+  int o = (int)((idx / g.hout) % g.cout);
+  int64_t f = idx / ((int64_t)g.hout * g.cout);
+  float acc = b[o];
+  for (int j = 0; j < g.hin; ++j) {
+    int t = p + g.pad - g.s * j;
+    if (t < 0 || t >= g.k) continue;
+    const float* wr = W + ((int64_t)t * g.cout + o) * g.cin;
+    for (int c = 0; c < g.cin; ++c) acc += lnact(in[(f * g.cin + c) * g.hin + j], ai, f, c) * wr[c];
+  }
+  out[idx] = acc;
+}
+
+// util/layers.py:159-167 with log_var = 0 ; d G / d xh = (xh - x) / ((1+1e-6) F)
+__global__ void k_nll(const float* __restrict__ x, const float* __restrict__ xh, float* __restrict__ nll_f,
+                      float* __restrict__ dxh, int H, float invF) {
+  __shared__ float sm[16];
+  int64_t f = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < H; i += blockDim.x) {
+    float d = x[f * H + i] - xh[f * H + i];
+    s += -0.5f * (LOG_2PI + (d * d) / (1.0f + EPSILON));
+    if (dxh) dxh[f * H + i] = -d / (1.0f + EPSILON) * invF;
+  }
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) nll_f[f] = s;
+}
+
+// model/vae.py:112-128 batch means -> {G, D_KL, logP}; single block, deterministic
+__global__ void k_loss_reduce(const float* __restrict__ kl_f, const float* __restrict__ nll_f, int64_t F,
+                              float* __restrict__ loss3) {
+  __shared__ float sm[16];
+  float a = 0.f, b = 0.f;
+  for (int64_t i = threadIdx.x; i < F; i += blockDim.x) {
+    a += kl_f[i];
+    b += nll_f[i];
+  }
+  a = block_sum(a, sm);
+  b = block_sum(b, sm);
+  if (threadIdx.x == 0) {
+    float kl = a / (float)F, lp = b / (float)F;
+    loss3[0] = -lp + kl;
+    loss3[1] = kl;
+    loss3[2] = lp;
+  }
+}
+
+// ------------------------------------------------------------------ backward
+// dY_in[f,c,j] = sum_o sum_t W[t,o,c] * dOut[f,o,s*j-pad+t]     (convT input gradient)
+__global__ void k_convT_bwd_data(const float* __restrict__ dout, const float* __restrict__ W,
+                                 float* __restrict__ din, int64_t F, G g) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= F * g.cin * g.hin) return;
+  int j = (int)(idx % g.hin);
+  int c = (int)((idx / g.hin) % g.cin);
+  int64_t f = idx / ((int64_t)g.hin * g.cin);
+  float acc = 0.f;
+  for (int o = 0; o < g.cout; ++o) {
+    const float* dr = dout + (f * g.cout + o) * g.hout;
+    for (int t = 0; t < g.k; ++t) {
+      int p = g.s * j - g.pad + t;
+      if (p < 0 || p >= g.hout) continue;
+      acc += W[((int64_t)t * g.cout + o) * g.cin + c] * dr[p];
+    }
+  }
+  din[idx] = acc;
+}
+
+// dW[t,o,c] = sum_f sum_j y_in[f,c,j] * dOut[f,o,s*j-pad+t]
+__global__ void k_convT_bwd_w(const float* __restrict__ in, Act ai, const float* __restrict__ dout,
+                              float* __restrict__ dW, int64_t F, G g) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)g.k * g.cout * g.cin) return;
+  int c = (int)(idx % g.cin);
+  int o = (int)((idx / g.cin) % g.cout);
+  int t = (int)(idx / ((int64_t)g.cin * g.cout));
+  float acc = 0.f;
+  for (int64_t f = 0; f < F; ++f) {
+    const float* ir = in + (f * g.cin + c) * g.hin;
+    const float* dr = dout + (f * g.cout + o) * g.hout;
+    for (int j = 0; j < g.hin; ++j) {
+      int p = g.s * j - g.pad + t;
+      if (p < 0 || p >= g.hout) continue;
+      acc += lnact(ir[j], ai, f, c) * dr[p];
+    }
+  }
+  dW[idx] = acc;
+}
+
+// db[o] = sum_f sum_h d[f,o,h] ; one block per channel
+__global__ void k_bias_grad(const float* __restrict__ d, float* __restrict__ db, int64_t F, int C, int H) {
+  __shared__ float sm[16];
+  int o = blockIdx.x;
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < F * H; i += blockDim.x) {
+    int64_t f = i / H;
+    int h = (int)(i % H);
+    s += d[(f * C + o) * H + h];
+  }
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) db[o] = s;
+}
+
+// LayerNorm + lrelu backward (autodiff of util/layers.py:32-44,149); one block per frame.
+//   n = gamma*xhat+beta ; dn = dy*(n>=0 ? 1 : leak) ; dxh = dn*gamma
+//   da = rstd*(dxh - mean(dxh) - xhat*mean(dxh*xhat))
+__global__ void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ a, const float* __restrict__ st,
+                         const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ da,
+                         int C, int H) {
+  __shared__ float sm[16];
+  int64_t f = blockIdx.x;
+  int n = C * H;
+  float mean = st[2 * f], rstd = st[2 * f + 1];
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int c = i / H;
+    float xh = (a[f * n + i] - mean) * rstd;
+    float nn = xh * gamma[c] + beta[c];
+    float dn = dy[f * n + i] * (nn >= 0.f ? 1.0f : LEAK);
+    float dx = dn * gamma[c];
+    s1 += dx;
+    s2 += dx * xh;
+  }
+  s1 = block_sum(s1, sm) / n;
+  s2 = block_sum(s2, sm) / n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int c = i / H;
+    float xh = (a[f * n + i] - mean) * rstd;
+    float nn = xh * gamma[c] + beta[c];
+    float dn = dy[f * n + i] * (nn >= 0.f ? 1.0f : LEAK);
+    float dx = dn * gamma[c];
+    da[f * n + i] = rstd * (dx - s1 - xh * s2);
+  }
+}
+
+// dgamma[c] = sum_{f,h} dn*xhat ; dbeta[c] = sum_{f,h} dn ; one block per channel
+__global__ void k_ln_param_grad(const float* __restrict__ dy, const float* __restrict__ a,
+                                const float* __restrict__ st, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* __restrict__ dgamma,
+                                float* __restrict__ dbeta, int64_t F, int C, int H) {
+  __shared__ float sm[16];
+  int c = blockIdx.x;
+  float g = gamma[c], b = beta[c];
+  float sg = 0.f, sb = 0.f;
+  for (int64_t i = threadIdx.x; i < F * H; i += blockDim.x) {
+    int64_t f = i / H;
+    int h = (int)(i % H);
+    int64_t e = (f * C + c) * H + h;
+    float xh = (a[e] - st[2 * f]) * st[2 * f + 1];
+    float nn = xh * g + b;
+    float dn = dy[e] * (nn >= 0.f ? 1.0f : LEAK);
+    sg += dn * xh;
+    sb += dn;
+  }
+  sg = block_sum(sg, sm);
+  sb = block_sum(sb, sm);
+  if (threadIdx.x == 0) {
+    dgamma[c] = sg;
+    dbeta[c] = sb;
+  }
+}
+
+// dY_in[f,c,i] = sum_o sum_t W[t,c,o] * da[f,o,j], s*j-pad+t = i       (conv input gradient)
+__global__ void k_conv_bwd_data(const float* __restrict__ da, const float* __restrict__ W,
+                                float* __restrict__ din, int64_t F, G g) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= F * g.cin * g.hin) return;
+  int i = (int)(idx % g.hin);
+  int c = (int)((idx / g.hin) % g.cin);
+  int64_t f = idx / ((int64_t)g.hin * g.cin);
+  float acc = 0.f;
+  for (int t = 0; t < g.k; ++t) {
+    int u = i + g.pad - t;
+    if (u < 0 || u % g.s != 0) continue;
+    int j = u / g.s;
+    if (j >= g.hout) continue;
+    const float* wr = W + ((int64_t)t * g.cin + c) * g.cout;
+    for (int o = 0; o < g.cout; ++o) acc += wr[o] * da[(f * g.cout + o) * g.hout + j];
+  }
+  din[idx] = acc;
+}
+
+// dW[t,c,o] = sum_f sum_j y_in[f,c,s*j-pad+t] * da[f,o,j]
+__global__ void k_conv_bwd_w(const float* __restrict__ in, Act ai, const float* __restrict__ da,
+                             float* __restrict__ dW, int64_t F, G g) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)g.k * g.cin * g.cout) return;
+  int o = (int)(idx % g.cout);
+  int c = (int)((idx / g.cout) % g.cin);
+  int t = (int)(idx / ((int64_t)g.cout * g.cin));
+  float acc = 0.f;
+  for (int64_t f = 0; f < F; ++f) {
+    const float* ir = in + (f * g.cin + c) * g.hin;
+    const float* dr = da + (f * g.cout + o) * g.hout;
+    for (int j = 0; j < g.hout; ++j) {
+      int i = g.s * j - g.pad + t;
+      if (i < 0 || i >= g.hin) continue;
+      acc += lnact(ir[i], ai, f, c) * dr[j];
+    }
+  }
+  dW[idx] = acc;
+}
+
+// dflat[f,k] = sum_n dzmu[f,n] Wmu[k,n] + dzlv[f,n] Wlv[k,n]
+__global__ void k_heads_bwd_data(const float* __restrict__ dzmu, const float* __restrict__ dzlv,
+                                 const float* __restrict__ Wmu, const float* __restrict__ Wlv,
+                                 float* __restrict__ dy, int64_t F, int flat, int z) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= F * flat) return;
+  int k = (int)(idx % flat);
+  int64_t f = idx / flat;
+  float acc = 0.f;
+  for (int n = 0; n < z; ++n)
+    acc += dzmu[f * z + n] * Wmu[(int64_t)k * z + n] + dzlv[f * z + n] * Wlv[(int64_t)k * z + n];
+  dy[idx] = acc;
+}
+
+// dW[k,n] = sum_f y_last[f,k] * dz[f,n]   (both heads)
+__global__ void k_heads_bwd_w(const float* __restrict__ a, Act ai, int hlast, const float* __restrict__ dzmu,
+                              const float* __restrict__ dzlv, float* __restrict__ dWmu,
+                              float* __restrict__ dWlv, int64_t F, int flat, int z) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)flat * z) return;
+  int n = (int)(idx % z);
+  int k = (int)(idx / z);
+  float a1 = 0.f, a2 = 0.f;
+  for (int64_t f = 0; f < F; ++f) {
+    float v = lnact(a[f * flat + k], ai, f, k / hlast);
+    a1 += v * dzmu[f * z + n];
+    a2 += v * dzlv[f * z + n];
+  }
+  dWmu[idx] = a1;
+  dWlv[idx] = a2;
+}
+
+// column sums of a [F, N] matrix written to up to three destinations
+__global__ void k_colsum(const float* __restrict__ d, int64_t F, int N, float* o1, float* o2, float* o3) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int64_t f = 0; f < F; ++f) s += d[f * N + n];
+  o1[n] = s;
+  if (o2) o2[n] = s;
+  if (o3) o3[n] = s;
+}
+
+// autodiff of the sampler + KL: dmu = dz + mu/((1+eps)F) ; dlv = dz*0.5*eps*sqrt(e^lv) + 0.5(e^lv/(1+eps) - 1)/F
+__global__ void k_reparam_bwd(const float* __restrict__ dz, const float* __restrict__ zmu,
+                              const float* __restrict__ zlv, const float* __restrict__ eps,
+                              float* __restrict__ dzmu, float* __restrict__ dzlv, int64_t N, float invF) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float mu = zmu[i], lv = zlv[i], v = expf(lv), g = dz[i];
+  dzmu[i] = g + mu / (1.0f + EPSILON) * invF;
+  dzlv[i] = g * (0.5f * eps[i] * sqrtf(v)) + 0.5f * (v / (1.0f + EPSILON) - 1.0f) * invF;
+}
+
+// dz[f,k] = sum_n dh[f,n] Wz[k,n] ; de[f,k] = sum_n dh[f,n] Wy[k,n]
+__global__ void k_merge_bwd_data(const float* __restrict__ dh, const float* __restrict__ Wz,
+                                 const float* __restrict__ Wy, float* __restrict__ dz, float* __restrict__ de,
+                                 int64_t F, int zd, int M) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= F * zd) return;
+  int k = (int)(idx % zd);
+  int64_t f = idx / zd;
+  float a1 = 0.f, a2 = 0.f;
+  for (int n = 0; n < M; ++n) {
+    float g = dh[f * M + n];
+    a1 += g * Wz[(int64_t)k * M + n];
+    a2 += g * Wy[(int64_t)k * M + n];
+  }
+  dz[idx] = a1;
+  de[idx] = a2;
+}
+
+// dWz[k,n] = sum_f z[f,k] dh[f,n] ; dWy[k,n] = sum_f E[y_f,k] dh[f,n]
+__global__ void k_merge_bwd_w(const float* __restrict__ z, const int64_t* __restrict__ y,
+                              const float* __restrict__ emb, const float* __restrict__ dh,
+                              float* __restrict__ dWz, float* __restrict__ dWy, int64_t F, int zd, int M) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)zd * M) return;
+  int n = (int)(idx % M);
+  int k = (int)(idx / M);
+  float a1 = 0.f, a2 = 0.f;
+  for (int64_t f = 0; f < F; ++f) {
+    float g = dh[f * M + n];
+    a1 += z[f * zd + k] * g;
+    a2 += emb[y[f] * zd + k] * g;
+  }
+  dWz[idx] = a1;
+  dWy[idx] = a2;
+}
+
+// dE[spk,k] = sum_{f : y_f == spk} de[f,k]   (tf IndexedSlices gradient, densified)
+__global__ void k_emb_grad(const float* __restrict__ de, const int64_t* __restrict__ y, float* __restrict__ dE,
+                           int64_t F, int zd, int ny) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ny * zd) return;
+  int k = idx % zd;
+  int spk = idx / zd;
+  float s = 0.f;
+  for (int64_t f = 0; f < F; ++f)
+    if (y[f] == spk) s += de[f * zd + k];
+  dE[idx] = s;
+}
+
+// ------------------------------------------------------------------ host drivers
+static Act act_of(const ConvL& l, const float* P, const float* st) {
+  return Act{st, P + l.gamma_off, P + l.beta_off};
+}
+
+void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F, const Ws& w, hipStream_t s) {
+  const float* in = x;
+  Act ai{nullptr, nullptr, nullptr};
+  for (int i = 0; i < m.n_enc; ++i) {
+    const ConvL& l = m.enc[i];
+    int64_t N = F * l.cout * l.hout;
+    hipLaunchKernelGGL(k_conv_fwd, grid1(N), dim3(256), 0, s, in, ai, P + l.w_off, P + l.b_off, w.enc_a[i], F, mk(l));
+    hipLaunchKernelGGL(k_ln_stats, dim3((unsigned)F), dim3(256), 0, s, w.enc_a[i], w.enc_st[i], l.cout * l.hout);
+    in = w.enc_a[i];
+    ai = act_of(l, P, w.enc_st[i]);
+  }
+  const ConvL& last = m.enc[m.n_enc - 1];
+  hipLaunchKernelGGL(k_heads_fwd, grid1(F * 2 * m.z), dim3(256), 0, s, in, ai, last.hout, P + m.wmu_off,
+                     P + m.bmu_off, P + m.wlv_off, P + m.blv_off, w.z_mu, w.z_lv, F, m.flat, m.z);
+}
+
+void reparam_fwd(const Model& m, const float* eps, int64_t F, const Ws& w, hipStream_t s) {
+  hipLaunchKernelGGL(k_reparam, dim3((unsigned)F), dim3(128), 0, s, w.z_mu, w.z_lv, eps, w.z, w.kl_f, m.z);
+}
+
+void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* y, int64_t F, const Ws& w,
+                 float* xh_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_merge_fwd, grid1(F * m.merge), dim3(256), 0, s, z, y, P + m.emb_off, P + m.wz_off,
+                     P + m.bz_off, P + m.wy_off, P + m.by_off, P + m.bm_off, w.h, F, m.z, m.merge);
+  const float* in = w.h;
+  Act ai{nullptr, nullptr, nullptr};
+  for (int i = 0; i < m.n_dec; ++i) {
+    const ConvL& l = m.dec[i];
+    float* out = l.has_ln ? w.dec_a[i] : xh_out;
+    int64_t N = F * l.cout * l.hout;
+    char tag[32];
+    snprintf(tag, sizeof tag, "dec%d_fwd", i);
+    VAENPVC_TIMED(tag, s, hipLaunchKernelGGL(k_convT_fwd, grid1(N), dim3(256), 0, s, in, ai, P + l.w_off, P + l.b_off, out, F, mk(l)));
+    if (l.has_ln) {
+      hipLaunchKernelGGL(k_ln_stats, dim3((unsigned)F), dim3(256), 0, s, out, w.dec_st[i], l.cout * l.hout);
+      in = out;
+      ai = act_of(l, P, w.dec_st[i]);
+    }
+  }
+}
+
+void loss_fwd(const Model& m, const float* x, int64_t F, const Ws& w, bool want_grad, float* loss3, hipStream_t s) {
+  hipLaunchKernelGGL(k_nll, dim3((unsigned)F), dim3(256), 0, s, x, w.xh, w.nll_f, want_grad ? w.d_xh : nullptr, m.H,
+                     1.0f / (float)F);
+  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, s, w.kl_f, w.nll_f, F, loss3);
+}
+
+void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F,
+              const Ws& w, float* G, hipStream_t s) {
+  const float invF = 1.0f / (float)F;
+  // ---- decoder, last layer first; `dout` = gradient w.r.t. the layer's pre-LN output
+  const float* dout = w.d_xh;
+  for (int i = m.n_dec - 1; i >= 0; --i) {
+    const ConvL& l = m.dec[i];
+    const float* in = i == 0 ? w.h : w.dec_a[i - 1];
+    Act ai{nullptr, nullptr, nullptr};
+    if (i > 0) ai = act_of(m.dec[i - 1], P, w.dec_st[i - 1]);
+    hipLaunchKernelGGL(k_convT_bwd_w, grid1((int64_t)l.k * l.cout * l.cin), dim3(256), 0, s, in, ai, dout,
+                       G + l.w_off, F, mk(l));
+    hipLaunchKernelGGL(k_bias_grad, dim3(l.cout), dim3(256), 0, s, dout, G + l.b_off, F, l.cout, l.hout);
+    if (i == 0) {
+      hipLaunchKernelGGL(k_convT_bwd_data, grid1(F * l.cin * l.hin), dim3(256), 0, s, dout, P + l.w_off, w.d_h, F, mk(l));
+    } else {
+      const ConvL& pl = m.dec[i - 1];
+      hipLaunchKernelGGL(k_convT_bwd_data, grid1(F * l.cin * l.hin), dim3(256), 0, s, dout, P + l.w_off, w.dy_tmp, F, mk(l));
+      hipLaunchKernelGGL(k_ln_param_grad, dim3(pl.cout), dim3(256), 0, s, w.dy_tmp, w.dec_a[i - 1], w.dec_st[i - 1],
+                         P + pl.gamma_off, P + pl.beta_off, G + pl.gamma_off, G + pl.beta_off, F, pl.cout, pl.hout);
+      hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)F), dim3(256), 0, s, w.dy_tmp, w.dec_a[i - 1], w.dec_st[i - 1],
+                         P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[i - 1], pl.cout, pl.hout);
+      dout = w.d_dec_a[i - 1];
+    }
+  }
+  // ---- merge + embedding
+  hipLaunchKernelGGL(k_merge_bwd_w, grid1((int64_t)m.z * m.merge), dim3(256), 0, s, w.z, y, P + m.emb_off, w.d_h,
+                     G + m.wz_off, G + m.wy_off, F, m.z, m.merge);
+  hipLaunchKernelGGL(k_colsum, grid1(m.merge), dim3(256), 0, s, w.d_h, F, m.merge, G + m.bz_off, G + m.by_off,
+                     G + m.bm_off);
+  hipLaunchKernelGGL(k_merge_bwd_data, grid1(F * m.z), dim3(256), 0, s, w.d_h, P + m.wz_off, P + m.wy_off, w.d_z,
+                     w.d_e, F, m.z, m.merge);
+  hipLaunchKernelGGL(k_emb_grad, grid1(m.ny * m.z), dim3(256), 0, s, w.d_e, y, G + m.emb_off, F, m.z, m.ny);
+  // ---- sampler + KL
+  hipLaunchKernelGGL(k_reparam_bwd, grid1(F * m.z), dim3(256), 0, s, w.d_z, w.z_mu, w.z_lv, eps, w.d_z_mu, w.d_z_lv,
+                     F * m.z, invF);
+  // ---- heads
+  const ConvL& last = m.enc[m.n_enc - 1];
+  Act alast = act_of(last, P, w.enc_st[m.n_enc - 1]);
+  hipLaunchKernelGGL(k_heads_bwd_w, grid1((int64_t)m.flat * m.z), dim3(256), 0, s, w.enc_a[m.n_enc - 1], alast,
+                     last.hout, w.d_z_mu, w.d_z_lv, G + m.wmu_off, G + m.wlv_off, F, m.flat, m.z);
+  hipLaunchKernelGGL(k_colsum, grid1(m.z), dim3(256), 0, s, w.d_z_mu, F, m.z, G + m.bmu_off, nullptr, nullptr);
+  hipLaunchKernelGGL(k_colsum, grid1(m.z), dim3(256), 0, s, w.d_z_lv, F, m.z, G + m.blv_off, nullptr, nullptr);
+  hipLaunchKernelGGL(k_heads_bwd_data, grid1(F * m.flat), dim3(256), 0, s, w.d_z_mu, w.d_z_lv, P + m.wmu_off,
+                     P + m.wlv_off, w.dy_tmp, F, m.flat, m.z);
+  // ---- encoder: dy_tmp holds the gradient w.r.t. the post-activation output of layer i
+  for (int i = m.n_enc - 1; i >= 0; --i) {
+    const ConvL& l = m.enc[i];
+    hipLaunchKernelGGL(k_ln_param_grad, dim3(l.cout), dim3(256), 0, s, w.dy_tmp, w.enc_a[i], w.enc_st[i],
+                       P + l.gamma_off, P + l.beta_off, G + l.gamma_off, G + l.beta_off, F, l.cout, l.hout);
+    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)F), dim3(256), 0, s, w.dy_tmp, w.enc_a[i], w.enc_st[i], P + l.gamma_off,
+                       P + l.beta_off, w.d_enc_a[i], l.cout, l.hout);
+    const float* in = i == 0 ? x : w.enc_a[i - 1];
+    Act ai{nullptr, nullptr, nullptr};
+    if (i > 0) ai = act_of(m.enc[i - 1], P, w.enc_st[i - 1]);
+    hipLaunchKernelGGL(k_conv_bwd_w, grid1((int64_t)l.k * l.cin * l.cout), dim3(256), 0, s, in, ai, w.d_enc_a[i],
+                       G + l.w_off, F, mk(l));
+    hipLaunchKernelGGL(k_bias_grad, dim3(l.cout), dim3(256), 0, s, w.d_enc_a[i], G + l.b_off, F, l.cout, l.hout);
+    if (i > 0)
+      hipLaunchKernelGGL(k_conv_bwd_data, grid1(F * l.cin * l.hin), dim3(256), 0, s, w.d_enc_a[i], P + l.w_off,
+                         w.dy_tmp, F, mk(l));
+  }
+}
+
+}  // namespace generic
+}  // namespace vaenpvc

@@ -1,0 +1,71 @@
+// kernels.h -- host-callable launchers shared between the ABI layer and the kernel
+// translation units.  Everything enqueues on `stream`; nothing synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "model.h"
+
+namespace vaenpvc {
+
+struct Ws {  // resolved workspace pointers (see workspace_layout)
+  float* enc_a[VAENPVC_MAX_LAYERS];
+  float* enc_st[VAENPVC_MAX_LAYERS];
+  float *z_mu, *z_lv, *z, *h;
+  float* dec_a[VAENPVC_MAX_LAYERS];
+  float* dec_st[VAENPVC_MAX_LAYERS];
+  float *xh, *kl_f, *nll_f;
+  // train only
+  float* d_xh;
+  float* d_dec_a[VAENPVC_MAX_LAYERS];
+  float *d_h, *d_z, *d_e, *d_z_mu, *d_z_lv;
+  float* d_enc_a[VAENPVC_MAX_LAYERS];
+  float* dy_tmp;
+  float* scratch;
+  int64_t scratch_floats;
+};
+
+// ---- single-kernel event timer (abi.hip) ----------------------------------------
+bool timer_match(const char* tag);
+void timer_begin(hipStream_t s);
+void timer_end(hipStream_t s);
+#define VAENPVC_TIMED(tag, stream, stmt)        \
+  do {                                          \
+    bool _tm = ::vaenpvc::timer_match(tag);     \
+    if (_tm) ::vaenpvc::timer_begin(stream);    \
+    stmt;                                       \
+    if (_tm) ::vaenpvc::timer_end(stream);      \
+  } while (0)
+
+// ---- geometry-generic HIP kernels (generic_kernels.hip) -------------------------
+namespace generic {
+void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F, const Ws& w, hipStream_t s);
+// z = z_mu + eps*sqrt(exp(z_lv)) (eps may be null -> z = z_mu); also per-frame KL
+void reparam_fwd(const Model& m, const float* eps, int64_t F, const Ws& w, hipStream_t s);
+// decoder from z (w.z or external) and y -> xh_out
+void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* y, int64_t F, const Ws& w,
+                 float* xh_out, hipStream_t s);
+// per-frame log-density, optional d_xh, then {G, D_KL, logP}
+void loss_fwd(const Model& m, const float* x, int64_t F, const Ws& w, bool want_grad, float* loss3, hipStream_t s);
+void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F,
+              const Ws& w, float* G, hipStream_t s);
+}  // namespace generic
+
+// ---- elementwise / optimiser kernels (misc_kernels.hip) -------------------------
+void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
+                 float eps, float gscale, hipStream_t s);
+void launch_tanhize(const float* in, const float* xmin, const float* xmax, float* out, int64_t F, int H,
+                    bool forward, hipStream_t s);
+void launch_unpack(const float* rec, int64_t F, int rec_floats, int H, const float* xmin, const float* xmax,
+                   float* x, int64_t* y, hipStream_t s);
+
+// ---- tuned gfx950 kernels for the VCC2016 geometry (gfx950_*.hip) ----------------
+namespace tuned {
+bool available();
+void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F, const Ws& w, hipStream_t s);
+void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* y, int64_t F, const Ws& w,
+                 float* xh_out, hipStream_t s);
+void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F,
+              const Ws& w, float* G, hipStream_t s);
+}  // namespace tuned
+
+}  // namespace vaenpvc

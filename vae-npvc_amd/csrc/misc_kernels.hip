@@ -1,0 +1,89 @@
+// misc_kernels.hip -- optimiser and data-plane kernels (HBM-bound, float4 streams).
+#include "kernels.h"
+
+namespace vaenpvc {
+
+// tf.train.AdamOptimizer apply (trainer/vae.py:16-24): ONE pass over the
+// flat buffers; reads g,p,m,v and writes p,m,v (28 B/param).
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, int64_t n, float lr_t, float b1, float b2, float eps, float gs) {
+  int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 + 3 < n) {
+    float4 pp = *(float4*)(p + i4), gg = *(const float4*)(g + i4), mm = *(float4*)(m + i4), vv = *(float4*)(v + i4);
+    float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ga[4] = {gg.x, gg.y, gg.z, gg.w};
+    float ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gk = ga[k] * gs;
+      ma[k] = b1 * ma[k] + (1.0f - b1) * gk;
+      va[k] = b2 * va[k] + (1.0f - b2) * gk * gk;
+      pa[k] = pa[k] - lr_t * ma[k] / (sqrtf(va[k]) + eps);
+    }
+    *(float4*)(p + i4) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    *(float4*)(m + i4) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+    *(float4*)(v + i4) = make_float4(va[0], va[1], va[2], va[3]);
+  } else {
+    for (int64_t i = i4; i < n; ++i) {
+      float gk = g[i] * gs;
+      float mk = b1 * m[i] + (1.0f - b1) * gk;
+      float vk = b2 * v[i] + (1.0f - b2) * gk * gk;
+      m[i] = mk;
+      v[i] = vk;
+      p[i] = p[i] - lr_t * mk / (sqrtf(vk) + eps);
+    }
+  }
+}
+
+void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
+                 float eps, float gscale, hipStream_t s) {
+  int64_t nt = (n + 3) / 4;
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2, eps,
+                     gscale);
+}
+
+// Tanhize (analyzer.py:77-87)
+__global__ void k_tanhize(const float* __restrict__ in, const float* __restrict__ xmin,
+                          const float* __restrict__ xmax, float* __restrict__ out, int64_t N, int H, bool fwd) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int b = (int)(i % H);
+  float lo = xmin[b], sc = xmax[b] - lo, v = in[i];
+  if (fwd) {
+    float u = (v - lo) / sc;
+    u = fminf(fmaxf(u, 0.f), 1.f);
+    out[i] = u * 2.f - 1.f;
+  } else {
+    out[i] = (v * .5f + .5f) * sc + lo;
+  }
+}
+
+void launch_tanhize(const float* in, const float* xmin, const float* xmax, float* out, int64_t F, int H,
+                    bool forward, hipStream_t s) {
+  int64_t N = F * H;
+  hipLaunchKernelGGL(k_tanhize, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, in, xmin, xmax, out, N, H, forward);
+}
+
+// analyzer.py:113-127: x = Tanhize(record[:H]) ; y = int64(record[-1])
+__global__ void k_unpack(const float* __restrict__ rec, int64_t F, int R, int H, const float* __restrict__ xmin,
+                         const float* __restrict__ xmax, float* __restrict__ x, int64_t* __restrict__ y) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F * (H + 1)) return;
+  int b = (int)(i % (H + 1));
+  int64_t f = i / (H + 1);
+  if (b == H) {
+    y[f] = (int64_t)rec[f * R + R - 1];  // tf.cast(float32 -> int64): truncation toward zero
+  } else {
+    float lo = xmin[b], sc = xmax[b] - lo;
+    float u = (rec[f * R + b] - lo) / sc;
+    u = fminf(fmaxf(u, 0.f), 1.f);
+    x[f * H + b] = u * 2.f - 1.f;
+  }
+}
+
+void launch_unpack(const float* rec, int64_t F, int rec_floats, int H, const float* xmin, const float* xmax,
+                   float* x, int64_t* y, hipStream_t s) {
+  int64_t N = F * (H + 1);
+  hipLaunchKernelGGL(k_unpack, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rec, F, rec_floats, H, xmin, xmax, x, y);
+}
+
+}  // namespace vaenpvc

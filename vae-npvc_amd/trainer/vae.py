@@ -1,0 +1,84 @@
+"""`--trainer_module trainer.vae --trainer VAETrainer` plugin (drop-in for the
+reference's trainer/vae.py:9-111 + the GANTrainer base ctor trainer/gan.py:13-23).
+
+Adam(lr, beta1, beta2 from arch['training']) over ALL trainables as one fused HIP
+kernel; data-parallel over torch.distributed when WORLD_SIZE > 1.
+"""
+import logging
+import os
+import time
+
+import torch
+
+from hipvae.dp import Stepper
+
+
+class VAETrainer(object):
+    def __init__(self, loss, arch, args, dirs):          # trainer/gan.py:14-23
+        self.loss = loss
+        self.arch = arch
+        self.args = args
+        self.dirs = dirs
+        self.opt = self._optimize()
+        os.makedirs(dirs['logdir'], exist_ok=True)
+        logging.basicConfig(level=logging.INFO, filename=os.path.join(dirs['logdir'], 'training.log'))
+
+    def _optimize(self):                                  # trainer/vae.py:10-28
+        t = self.arch['training']
+        machine = getattr(self.loss, 'machine', None)
+        if machine is None:
+            raise ValueError('loss must come from ConvVAE.loss (it carries the machine)')
+        stepper = Stepper(machine.engine, t['lr'], t['beta1'], t['beta2'])
+        return {'g': stepper, 'global_step': lambda: stepper.step_count}
+
+    def _status_message(self, step, logP, D_KL):          # trainer/vae.py:47-50
+        msg = 'Iter {:05d}: '.format(step)
+        msg += 'log P(x|z, y) = {:.3e} '.format(logP)
+        msg += 'D_KL(z) = {:.3e} '.format(D_KL)
+        return msg
+
+    def _refresh_status(self, l3):                        # trainer/vae.py:31-52
+        st = self.opt['g']
+        l3 = st.mean_losses(l3).cpu()
+        msg = self._status_message(st.step_count, float(l3[2]), float(l3[1]))
+        if st.rank == 0:
+            print('\r{}'.format(msg), end='', flush=True)
+            logging.info(msg)
+        return msg
+
+    def save(self, step=None):
+        st = self.opt['g']
+        if st.rank != 0:
+            return None
+        path = os.path.join(self.dirs['logdir'], 'model.ckpt-{}'.format(st.step_count if step is None else step))
+        sd = st.state_dict()
+        sd['layout'] = list(st.backend.layout.items()) if hasattr(st.backend, 'layout') else None
+        torch.save(sd, path)
+        return path
+
+    def train(self, nIter, machine=None, summary_op=None, status_secs=60, save_secs=300):
+        """trainer/vae.py:73-99.  Like the reference, the iteration count comes from
+        arch['training']['max_iter'] (nIter is ignored, trap T7)."""
+        st = self.opt['g']
+        machine = machine or self.loss.machine
+        source = self.loss.source
+        if source is None:
+            raise ValueError('loss was not built from analyzer.read() handles')
+        st.broadcast_params()
+        max_iter = self.arch['training']['max_iter']
+        t_status = t_save = time.time()
+        l3 = None
+        for step in range(max_iter):
+            x, y = source.next_batch()                    # analyzer.read dequeue
+            eps = machine._draw_eps(x.shape[0])           # GaussianSampleLayer draw
+            l3 = st.step(x, y, eps)                       # sess.run(self.opt['g'])
+            now = time.time()
+            if now - t_status >= status_secs:
+                self._refresh_status(l3)
+                t_status = now
+            if now - t_save >= save_secs:                 # Supervisor save_model_secs=300
+                self.save()
+                t_save = now
+        if l3 is not None:
+            self._refresh_status(l3)
+        return self.save()

@@ -1,0 +1,43 @@
+"""Log-dir and checkpoint helpers (behavioural counterpart of the reference's
+util/wrapper.py:32-62,99-132; TF Saver replaced by a flat-buffer checkpoint)."""
+import os
+import re
+from datetime import datetime
+
+import torch
+
+
+def validate_log_dirs(args):
+    """logdir = <logdir_root>/train/<MMDD-HHMM-SS-YYYY> (wrapper.py:99-132).  Unlike the
+    reference (which crashes on --logdir/--logdir_root) explicit values work."""
+    logdir_root = getattr(args, 'logdir_root', None)
+    logdir = getattr(args, 'logdir', None)
+    restore_from = getattr(args, 'restore_from', None)
+    if logdir and restore_from:
+        raise ValueError('You can only specify one of the following: --logdir and --restore_from')
+    if logdir and logdir_root:
+        raise ValueError('You can only specify either --logdir or --logdir_root')
+    if logdir_root is None:
+        logdir_root = 'logdir'
+    if logdir is None:
+        stamp = datetime.now().strftime('%m%d-%H%M-%S-%Y')
+        logdir = os.path.join(logdir_root, 'train', stamp)
+        print('Using default logdir: {}'.format(logdir))
+    if restore_from is None:
+        restore_from = logdir
+    return {'logdir': logdir, 'logdir_root': logdir_root, 'restore_from': restore_from}
+
+
+def load(engine, logdir, ckpt=None):
+    """Restore parameters from `<logdir>/<ckpt>` or the newest model.ckpt-N
+    (wrapper.py:32-62); returns the global step parsed from the -N suffix."""
+    if ckpt is None:
+        cands = [f for f in os.listdir(logdir) if re.match(r'model\.ckpt-\d+$', f)]
+        if not cands:
+            raise FileNotFoundError('no model.ckpt-N under %s' % logdir)
+        ckpt = max(cands, key=lambda f: int(f.rsplit('-', 1)[1]))
+    path = os.path.join(logdir, ckpt)
+    sd = torch.load(path, map_location='cpu')
+    engine.load_flat(sd['params'])
+    m = re.search(r'-(\d+)$', ckpt)
+    return int(m.group(1)) if m else int(sd.get('step', 0))
