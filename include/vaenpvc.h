@@ -144,6 +144,13 @@ int vaenpvc_unpack_records(const float* d_records, int64_t F, int32_t rec_floats
                            const float* d_xmin, const float* d_xmax, float* d_x, int64_t* d_y,
                            void* stream);
 
+/* Debug/validation hook (no reference counterpart): per-step selection between the tuned
+ * gfx950 kernel (bit set) and the geometry-generic kernel (bit clear) when the context
+ * runs in VAENPVC_IMPL_AUTO on the VCC2016 geometry.  Bits 0..4 = encoder conv i,
+ * 5 = heads, 6 = merge, 7..10 = decoder layer i; one mask for forward steps, one for
+ * backward steps.  Default: all ones.  Process-global. */
+int vaenpvc_set_tuned_masks(uint32_t fwd_mask, uint32_t bwd_mask);
+
 /* Measurement hook (no reference counterpart): brackets every launch of ONE tagged
  * kernel with a hipEvent pair on the launch stream, so bench.py can report that
  * kernel's average duration over the timed region.  Tags are the kernel-site names

@@ -114,6 +114,11 @@ void timer_end(hipStream_t s) {
 
 extern "C" {
 
+int vaenpvc_set_tuned_masks(uint32_t fwd_mask, uint32_t bwd_mask) {
+  tuned::set_masks(fwd_mask, bwd_mask);
+  return 0;
+}
+
 int vaenpvc_timer_select(const char* tag) {
   g_tag = tag ? tag : "";
   g_used = 0;

@@ -468,46 +468,54 @@ __global__ void k_emb_grad(const float* __restrict__ de, const int64_t* __restri
 static Act act_of(const ConvL& l, const float* P, const float* st) {
   return Act{st, P + l.gamma_off, P + l.beta_off};
 }
+static const Act kNoAct{nullptr, nullptr, nullptr};
+
+void enc_layer_fwd(const Model& m, const float* P, const float* x, int64_t F, const Ws& w, hipStream_t s, int i) {
+  const ConvL& l = m.enc[i];
+  const float* in = i == 0 ? x : w.enc_a[i - 1];
+  Act ai = i == 0 ? kNoAct : act_of(m.enc[i - 1], P, w.enc_st[i - 1]);
+  int64_t N = F * l.cout * l.hout;
+  hipLaunchKernelGGL(k_conv_fwd, grid1(N), dim3(256), 0, s, in, ai, P + l.w_off, P + l.b_off, w.enc_a[i], F, mk(l));
+  hipLaunchKernelGGL(k_ln_stats, dim3((unsigned)F), dim3(256), 0, s, w.enc_a[i], w.enc_st[i], l.cout * l.hout);
+}
+
+void heads_fwd(const Model& m, const float* P, int64_t F, const Ws& w, hipStream_t s) {
+  const ConvL& last = m.enc[m.n_enc - 1];
+  Act ai = act_of(last, P, w.enc_st[m.n_enc - 1]);
+  hipLaunchKernelGGL(k_heads_fwd, grid1(F * 2 * m.z), dim3(256), 0, s, w.enc_a[m.n_enc - 1], ai, last.hout,
+                     P + m.wmu_off, P + m.bmu_off, P + m.wlv_off, P + m.blv_off, w.z_mu, w.z_lv, F, m.flat, m.z);
+}
 
 void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F, const Ws& w, hipStream_t s) {
-  const float* in = x;
-  Act ai{nullptr, nullptr, nullptr};
-  for (int i = 0; i < m.n_enc; ++i) {
-    const ConvL& l = m.enc[i];
-    int64_t N = F * l.cout * l.hout;
-    hipLaunchKernelGGL(k_conv_fwd, grid1(N), dim3(256), 0, s, in, ai, P + l.w_off, P + l.b_off, w.enc_a[i], F, mk(l));
-    hipLaunchKernelGGL(k_ln_stats, dim3((unsigned)F), dim3(256), 0, s, w.enc_a[i], w.enc_st[i], l.cout * l.hout);
-    in = w.enc_a[i];
-    ai = act_of(l, P, w.enc_st[i]);
-  }
-  const ConvL& last = m.enc[m.n_enc - 1];
-  hipLaunchKernelGGL(k_heads_fwd, grid1(F * 2 * m.z), dim3(256), 0, s, in, ai, last.hout, P + m.wmu_off,
-                     P + m.bmu_off, P + m.wlv_off, P + m.blv_off, w.z_mu, w.z_lv, F, m.flat, m.z);
+  for (int i = 0; i < m.n_enc; ++i) enc_layer_fwd(m, P, x, F, w, s, i);
+  heads_fwd(m, P, F, w, s);
 }
 
 void reparam_fwd(const Model& m, const float* eps, int64_t F, const Ws& w, hipStream_t s) {
   hipLaunchKernelGGL(k_reparam, dim3((unsigned)F), dim3(128), 0, s, w.z_mu, w.z_lv, eps, w.z, w.kl_f, m.z);
 }
 
-void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* y, int64_t F, const Ws& w,
-                 float* xh_out, hipStream_t s) {
+void merge_fwd(const Model& m, const float* P, const float* z, const int64_t* y, int64_t F, const Ws& w, hipStream_t s) {
   hipLaunchKernelGGL(k_merge_fwd, grid1(F * m.merge), dim3(256), 0, s, z, y, P + m.emb_off, P + m.wz_off,
                      P + m.bz_off, P + m.wy_off, P + m.by_off, P + m.bm_off, w.h, F, m.z, m.merge);
-  const float* in = w.h;
-  Act ai{nullptr, nullptr, nullptr};
-  for (int i = 0; i < m.n_dec; ++i) {
-    const ConvL& l = m.dec[i];
-    float* out = l.has_ln ? w.dec_a[i] : xh_out;
-    int64_t N = F * l.cout * l.hout;
-    char tag[32];
-    snprintf(tag, sizeof tag, "dec%d_fwd", i);
-    VAENPVC_TIMED(tag, s, hipLaunchKernelGGL(k_convT_fwd, grid1(N), dim3(256), 0, s, in, ai, P + l.w_off, P + l.b_off, out, F, mk(l)));
-    if (l.has_ln) {
-      hipLaunchKernelGGL(k_ln_stats, dim3((unsigned)F), dim3(256), 0, s, out, w.dec_st[i], l.cout * l.hout);
-      in = out;
-      ai = act_of(l, P, w.dec_st[i]);
-    }
-  }
+}
+
+void dec_layer_fwd(const Model& m, const float* P, int64_t F, const Ws& w, float* xh_out, hipStream_t s, int i) {
+  const ConvL& l = m.dec[i];
+  const float* in = i == 0 ? w.h : w.dec_a[i - 1];
+  Act ai = i == 0 ? kNoAct : act_of(m.dec[i - 1], P, w.dec_st[i - 1]);
+  float* out = l.has_ln ? w.dec_a[i] : xh_out;
+  int64_t N = F * l.cout * l.hout;
+  char tag[32];
+  snprintf(tag, sizeof tag, "dec%d_fwd", i);
+  VAENPVC_TIMED(tag, s, hipLaunchKernelGGL(k_convT_fwd, grid1(N), dim3(256), 0, s, in, ai, P + l.w_off, P + l.b_off, out, F, mk(l)));
+  if (l.has_ln) hipLaunchKernelGGL(k_ln_stats, dim3((unsigned)F), dim3(256), 0, s, out, w.dec_st[i], l.cout * l.hout);
+}
+
+void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* y, int64_t F, const Ws& w,
+                 float* xh_out, hipStream_t s) {
+  merge_fwd(m, P, z, y, F, w, s);
+  for (int i = 0; i < m.n_dec; ++i) dec_layer_fwd(m, P, F, w, xh_out, s, i);
 }
 
 void loss_fwd(const Model& m, const float* x, int64_t F, const Ws& w, bool want_grad, float* loss3, hipStream_t s) {
@@ -516,32 +524,34 @@ void loss_fwd(const Model& m, const float* x, int64_t F, const Ws& w, bool want_
   hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, s, w.kl_f, w.nll_f, F, loss3);
 }
 
-void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F,
-              const Ws& w, float* G, hipStream_t s) {
-  const float invF = 1.0f / (float)F;
-  // ---- decoder, last layer first; `dout` = gradient w.r.t. the layer's pre-LN output
-  const float* dout = w.d_xh;
-  for (int i = m.n_dec - 1; i >= 0; --i) {
-    const ConvL& l = m.dec[i];
-    const float* in = i == 0 ? w.h : w.dec_a[i - 1];
-    Act ai{nullptr, nullptr, nullptr};
-    if (i > 0) ai = act_of(m.dec[i - 1], P, w.dec_st[i - 1]);
-    hipLaunchKernelGGL(k_convT_bwd_w, grid1((int64_t)l.k * l.cout * l.cin), dim3(256), 0, s, in, ai, dout,
-                       G + l.w_off, F, mk(l));
-    hipLaunchKernelGGL(k_bias_grad, dim3(l.cout), dim3(256), 0, s, dout, G + l.b_off, F, l.cout, l.hout);
-    if (i == 0) {
-      hipLaunchKernelGGL(k_convT_bwd_data, grid1(F * l.cin * l.hin), dim3(256), 0, s, dout, P + l.w_off, w.d_h, F, mk(l));
-    } else {
-      const ConvL& pl = m.dec[i - 1];
-      hipLaunchKernelGGL(k_convT_bwd_data, grid1(F * l.cin * l.hin), dim3(256), 0, s, dout, P + l.w_off, w.dy_tmp, F, mk(l));
-      hipLaunchKernelGGL(k_ln_param_grad, dim3(pl.cout), dim3(256), 0, s, w.dy_tmp, w.dec_a[i - 1], w.dec_st[i - 1],
-                         P + pl.gamma_off, P + pl.beta_off, G + pl.gamma_off, G + pl.beta_off, F, pl.cout, pl.hout);
-      hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)F), dim3(256), 0, s, w.dy_tmp, w.dec_a[i - 1], w.dec_st[i - 1],
-                         P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[i - 1], pl.cout, pl.hout);
-      dout = w.d_dec_a[i - 1];
-    }
+// ---- backward, one function per step.  Convention: a step for layer i consumes the
+// gradient w.r.t. the layer's PRE-LN output (d_dec_a[i] / d_xh / d_enc_a[i]) and produces
+// the gradient w.r.t. the previous layer's pre-LN output.
+void bias_grad(const float* d, float* db, int64_t F, int C, int H, hipStream_t s) {
+  hipLaunchKernelGGL(k_bias_grad, dim3(C), dim3(256), 0, s, d, db, F, C, H);
+}
+
+void bwd_dec_layer(const Model& m, const float* P, int64_t F, const Ws& w, float* G, hipStream_t s, int i) {
+  const ConvL& l = m.dec[i];
+  const float* dout = l.has_ln ? w.d_dec_a[i] : w.d_xh;
+  const float* in = i == 0 ? w.h : w.dec_a[i - 1];
+  Act ai = i == 0 ? kNoAct : act_of(m.dec[i - 1], P, w.dec_st[i - 1]);
+  hipLaunchKernelGGL(k_convT_bwd_w, grid1((int64_t)l.k * l.cout * l.cin), dim3(256), 0, s, in, ai, dout,
+                     G + l.w_off, F, mk(l));
+  bias_grad(dout, G + l.b_off, F, l.cout, l.hout, s);
+  if (i == 0) {
+    hipLaunchKernelGGL(k_convT_bwd_data, grid1(F * l.cin * l.hin), dim3(256), 0, s, dout, P + l.w_off, w.d_h, F, mk(l));
+  } else {
+    const ConvL& pl = m.dec[i - 1];
+    hipLaunchKernelGGL(k_convT_bwd_data, grid1(F * l.cin * l.hin), dim3(256), 0, s, dout, P + l.w_off, w.dy_tmp, F, mk(l));
+    hipLaunchKernelGGL(k_ln_param_grad, dim3(pl.cout), dim3(256), 0, s, w.dy_tmp, w.dec_a[i - 1], w.dec_st[i - 1],
+                       P + pl.gamma_off, P + pl.beta_off, G + pl.gamma_off, G + pl.beta_off, F, pl.cout, pl.hout);
+    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)F), dim3(256), 0, s, w.dy_tmp, w.dec_a[i - 1], w.dec_st[i - 1],
+                       P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[i - 1], pl.cout, pl.hout);
   }
-  // ---- merge + embedding
+}
+
+void bwd_merge(const Model& m, const float* P, const int64_t* y, int64_t F, const Ws& w, float* G, hipStream_t s) {
   hipLaunchKernelGGL(k_merge_bwd_w, grid1((int64_t)m.z * m.merge), dim3(256), 0, s, w.z, y, P + m.emb_off, w.d_h,
                      G + m.wz_off, G + m.wy_off, F, m.z, m.merge);
   hipLaunchKernelGGL(k_colsum, grid1(m.merge), dim3(256), 0, s, w.d_h, F, m.merge, G + m.bz_off, G + m.by_off,
@@ -549,35 +559,55 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   hipLaunchKernelGGL(k_merge_bwd_data, grid1(F * m.z), dim3(256), 0, s, w.d_h, P + m.wz_off, P + m.wy_off, w.d_z,
                      w.d_e, F, m.z, m.merge);
   hipLaunchKernelGGL(k_emb_grad, grid1(m.ny * m.z), dim3(256), 0, s, w.d_e, y, G + m.emb_off, F, m.z, m.ny);
-  // ---- sampler + KL
+}
+
+void bwd_reparam(const Model& m, const float* eps, int64_t F, const Ws& w, hipStream_t s) {
   hipLaunchKernelGGL(k_reparam_bwd, grid1(F * m.z), dim3(256), 0, s, w.d_z, w.z_mu, w.z_lv, eps, w.d_z_mu, w.d_z_lv,
-                     F * m.z, invF);
-  // ---- heads
-  const ConvL& last = m.enc[m.n_enc - 1];
-  Act alast = act_of(last, P, w.enc_st[m.n_enc - 1]);
-  hipLaunchKernelGGL(k_heads_bwd_w, grid1((int64_t)m.flat * m.z), dim3(256), 0, s, w.enc_a[m.n_enc - 1], alast,
-                     last.hout, w.d_z_mu, w.d_z_lv, G + m.wmu_off, G + m.wlv_off, F, m.flat, m.z);
+                     F * m.z, 1.0f / (float)F);
+}
+
+// heads: weight/bias gradients, then d(pre-LN output of the last encoder layer)
+void bwd_heads(const Model& m, const float* P, int64_t F, const Ws& w, float* G, hipStream_t s) {
+  const int li = m.n_enc - 1;
+  const ConvL& last = m.enc[li];
+  Act alast = act_of(last, P, w.enc_st[li]);
+  hipLaunchKernelGGL(k_heads_bwd_w, grid1((int64_t)m.flat * m.z), dim3(256), 0, s, w.enc_a[li], alast, last.hout,
+                     w.d_z_mu, w.d_z_lv, G + m.wmu_off, G + m.wlv_off, F, m.flat, m.z);
   hipLaunchKernelGGL(k_colsum, grid1(m.z), dim3(256), 0, s, w.d_z_mu, F, m.z, G + m.bmu_off, nullptr, nullptr);
   hipLaunchKernelGGL(k_colsum, grid1(m.z), dim3(256), 0, s, w.d_z_lv, F, m.z, G + m.blv_off, nullptr, nullptr);
   hipLaunchKernelGGL(k_heads_bwd_data, grid1(F * m.flat), dim3(256), 0, s, w.d_z_mu, w.d_z_lv, P + m.wmu_off,
                      P + m.wlv_off, w.dy_tmp, F, m.flat, m.z);
-  // ---- encoder: dy_tmp holds the gradient w.r.t. the post-activation output of layer i
-  for (int i = m.n_enc - 1; i >= 0; --i) {
-    const ConvL& l = m.enc[i];
-    hipLaunchKernelGGL(k_ln_param_grad, dim3(l.cout), dim3(256), 0, s, w.dy_tmp, w.enc_a[i], w.enc_st[i],
-                       P + l.gamma_off, P + l.beta_off, G + l.gamma_off, G + l.beta_off, F, l.cout, l.hout);
-    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)F), dim3(256), 0, s, w.dy_tmp, w.enc_a[i], w.enc_st[i], P + l.gamma_off,
-                       P + l.beta_off, w.d_enc_a[i], l.cout, l.hout);
-    const float* in = i == 0 ? x : w.enc_a[i - 1];
-    Act ai{nullptr, nullptr, nullptr};
-    if (i > 0) ai = act_of(m.enc[i - 1], P, w.enc_st[i - 1]);
-    hipLaunchKernelGGL(k_conv_bwd_w, grid1((int64_t)l.k * l.cin * l.cout), dim3(256), 0, s, in, ai, w.d_enc_a[i],
-                       G + l.w_off, F, mk(l));
-    hipLaunchKernelGGL(k_bias_grad, dim3(l.cout), dim3(256), 0, s, w.d_enc_a[i], G + l.b_off, F, l.cout, l.hout);
-    if (i > 0)
-      hipLaunchKernelGGL(k_conv_bwd_data, grid1(F * l.cin * l.hin), dim3(256), 0, s, w.d_enc_a[i], P + l.w_off,
-                         w.dy_tmp, F, mk(l));
+  hipLaunchKernelGGL(k_ln_param_grad, dim3(last.cout), dim3(256), 0, s, w.dy_tmp, w.enc_a[li], w.enc_st[li],
+                     P + last.gamma_off, P + last.beta_off, G + last.gamma_off, G + last.beta_off, F, last.cout, last.hout);
+  hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)F), dim3(256), 0, s, w.dy_tmp, w.enc_a[li], w.enc_st[li],
+                     P + last.gamma_off, P + last.beta_off, w.d_enc_a[li], last.cout, last.hout);
+}
+
+void bwd_enc_layer(const Model& m, const float* P, const float* x, int64_t F, const Ws& w, float* G, hipStream_t s, int i) {
+  const ConvL& l = m.enc[i];
+  const float* in = i == 0 ? x : w.enc_a[i - 1];
+  Act ai = i == 0 ? kNoAct : act_of(m.enc[i - 1], P, w.enc_st[i - 1]);
+  hipLaunchKernelGGL(k_conv_bwd_w, grid1((int64_t)l.k * l.cin * l.cout), dim3(256), 0, s, in, ai, w.d_enc_a[i],
+                     G + l.w_off, F, mk(l));
+  bias_grad(w.d_enc_a[i], G + l.b_off, F, l.cout, l.hout, s);
+  if (i > 0) {
+    const ConvL& pl = m.enc[i - 1];
+    hipLaunchKernelGGL(k_conv_bwd_data, grid1(F * l.cin * l.hin), dim3(256), 0, s, w.d_enc_a[i], P + l.w_off,
+                       w.dy_tmp, F, mk(l));
+    hipLaunchKernelGGL(k_ln_param_grad, dim3(pl.cout), dim3(256), 0, s, w.dy_tmp, w.enc_a[i - 1], w.enc_st[i - 1],
+                       P + pl.gamma_off, P + pl.beta_off, G + pl.gamma_off, G + pl.beta_off, F, pl.cout, pl.hout);
+    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)F), dim3(256), 0, s, w.dy_tmp, w.enc_a[i - 1], w.enc_st[i - 1],
+                       P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[i - 1], pl.cout, pl.hout);
   }
+}
+
+void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F,
+              const Ws& w, float* G, hipStream_t s) {
+  for (int i = m.n_dec - 1; i >= 0; --i) bwd_dec_layer(m, P, F, w, G, s, i);
+  bwd_merge(m, P, y, F, w, G, s);
+  bwd_reparam(m, eps, F, w, s);
+  bwd_heads(m, P, F, w, G, s);
+  for (int i = m.n_enc - 1; i >= 0; --i) bwd_enc_layer(m, P, x, F, w, G, s, i);
 }
 
 }  // namespace generic

@@ -1,0 +1,55 @@
+// gfx950_common.h -- device helpers shared by the tuned CDNA4 kernels.
+//
+// MFMA used throughout: v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles/SIMD, 157 TF chip
+// peak).  Operand maps (guides/cdna_hip_programming.md section 3):
+//   A: lane l holds A[i = l&31][k = l>>5]        B: lane l holds B[k = l>>5][j = l&31]
+//   C/D (16 regs): col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace vaenpvc {
+namespace tuned {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LN_EPS 1e-5f
+#define LEAK 0.02f
+#define EPSILON 1e-6f
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+// row of accumulator register `reg` for this lane inside a 32x32 tile
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// make LDS writes of this wave visible to its own later LDS reads (cross-lane)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float lnact_v(float v, float mean, float rstd, float g, float b) {
+  float n = (v - mean) * rstd * g + b;
+  return fmaxf(n, LEAK * n);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+constexpr int rup(int a, int b) { return cdiv(a, b) * b; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int cmin_(int a, int b) { return a < b ? a : b; }
+
+}  // namespace tuned
+}  // namespace vaenpvc

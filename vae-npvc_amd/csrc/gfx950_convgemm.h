@@ -1,0 +1,234 @@
+// gfx950_convgemm.h -- implicit-GEMM engine for every 1-D conv / conv_transpose /
+// dense layer of the ConvVAE in forward and input-gradient direction.
+//
+//   out[f, n, pos_out(r)] = bias[n] + sum_{tau, k} B[tau][k][n] * in'[f, k, pos_in(r, tau)]
+//
+//   S-type (strided correlation; conv forward, conv_transpose input-gradient, dense):
+//        rows r = output positions j ; pos_in = S*j - PAD + tau ; pos_out = j
+//   P-type (transposed, stride S, split into S phases; conv_transpose forward, conv
+//        input-gradient): phase ph covers outputs p = S*q + ph - PAD, taps t = ph + S*tau,
+//        pos_in = q - tau ; pos_out = p
+//
+// GEMM view per phase: M = (frame, r) rows, N = out channels, K = (tau, k).
+//   * one workgroup owns TF whole frames: their input tile is staged ONCE into LDS
+//     (coalesced HBM read, LN+lrelu applied on load, zero halos so the k-loop has no
+//     bounds checks); A fragments are gathered from LDS with im2col addressing
+//     (ds_read_b32, stride-RS rows -> conflict free);
+//   * B (weights, pre-packed [K][NP] by gfx950_prep) is streamed from L2 straight into
+//     the MFMA operand register: lanes 0..31 read 128 contiguous bytes; software
+//     prefetch one U-step chunk ahead;
+//   * v_mfma_f32_32x32x2_f32, MB x NB register blocking per wave;
+//   * epilogue: accumulators are transposed through a per-wave LDS buffer so that global
+//     stores run along the position axis.
+#pragma once
+#include "gfx950_common.h"
+
+namespace vaenpvc {
+namespace tuned {
+
+enum { IN_PLAIN = 0, IN_LN = 1, IN_CONCAT2 = 2 };
+
+template <int KC_, int HIN_, int N_, int HOUT_, int T_, int S_, int PAD_, bool TYPEP_, int TF_, int INKIND_,
+          int LNDIV_, int MB_, int NB_>
+struct ConvCfg {
+  static constexpr int KC = KC_, HIN = HIN_, N = N_, HOUT = HOUT_, T = T_, S = S_, PAD = PAD_, TF = TF_;
+  static constexpr bool TYPEP = TYPEP_;
+  static constexpr int INKIND = INKIND_, LNDIV = LNDIV_, MB = MB_, NB = NB_;
+  static constexpr int NW = 4;  // waves per workgroup
+  static constexpr int U = 8;   // k-steps (of 2) per B prefetch chunk
+  static constexpr int KCP = rup(KC, 2), KH = KCP / 2;
+  static constexpr int NP = rup(N, 32), NT = NP / 32;
+  static constexpr int NPH = TYPEP ? S : 1;
+  static constexpr int ntaps(int ph) { return TYPEP ? (T - ph + S - 1) / S : T; }
+  static constexpr int kt(int ph) { return ntaps(ph) * KH; }
+  static constexpr int ktp(int ph) { return rup(kt(ph), U); }
+  static constexpr int q0(int ph) { return TYPEP ? (PAD - ph > 0 ? cdiv(PAD - ph, S) : 0) : 0; }
+  static constexpr int q1(int ph) { return TYPEP ? (HOUT - 1 + PAD - ph) / S : HOUT - 1; }
+  static constexpr int rows(int ph) { return q1(ph) - q0(ph) + 1; }
+  static constexpr int boff(int ph) {
+    int o = 0;
+    for (int p = 0; p < ph; ++p) o += ktp(p) * 2 * NP;
+    return o;
+  }
+  static constexpr int BTOTAL = boff(NPH);  // floats of packed B
+  static constexpr int HLO = TYPEP ? (cdiv(T, S) - 1) : PAD;
+  static constexpr int HHI = TYPEP ? cmax(0, (HOUT - 1 + PAD) / S - (HIN - 1)) : cmax(0, S * (HOUT - 1) - PAD + T - 1 - (HIN - 1));
+  static constexpr int CSTR = HLO + HIN + HHI;
+  static constexpr int FSTR = (KCP * CSTR) | 1;  // odd: rows of different frames hit different banks
+  static constexpr int TILE = rup(TF * FSTR, 4);
+  static constexpr int RS = TYPEP ? 1 : S, TS = TYPEP ? -1 : 1, OFF = TYPEP ? 0 : -PAD;
+  static constexpr int LDS_BYTES = (TILE + NW * 32 * 33) * 4;
+  static_assert(!TYPEP || T > S - 1, "every phase needs a tap");
+};
+
+struct ConvArgs {
+  const float* in;     // [F][KC][HIN]   (IN_CONCAT2: first half  [F][KC/2])
+  const float* in2;    // IN_CONCAT2: second half rows [*][KC/2]
+  const int64_t* idx;  // IN_CONCAT2: optional row gather for in2 (speaker id)
+  const float* st;     // IN_LN: per-frame (mean, rstd)
+  const float* gamma;  // IN_LN: per channel (k / LNDIV)
+  const float* beta;
+  const float* Bp;    // packed weights, see ConvCfg
+  const float* bias;  // [N] or nullptr
+  float* out;         // [F][N][HOUT]
+  int F;
+};
+
+template <class C>
+__device__ __forceinline__ void conv_stage(const ConvArgs& a, float* tile, int f0) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < C::TILE / 4; i += 256) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  constexpr int PER = C::KC * C::HIN;
+  const int nfr = min(C::TF, a.F - f0);
+  const int total = nfr * PER;
+  for (int e = tid; e < total; e += 256) {
+    int f = e / PER;
+    int rem = e - f * PER;
+    int k = rem / C::HIN;
+    int i = rem - k * C::HIN;
+    float v;
+    if constexpr (C::INKIND == IN_CONCAT2) {
+      constexpr int HALF = C::KC / 2;
+      if (k < HALF) {
+        v = a.in[(int64_t)(f0 + f) * HALF + k];
+      } else {
+        int64_t g = a.idx ? a.idx[f0 + f] : (int64_t)(f0 + f);
+        v = a.in2[g * HALF + (k - HALF)];
+      }
+    } else {
+      v = a.in[(int64_t)f0 * PER + e];
+      if constexpr (C::INKIND == IN_LN) {
+        int ch = k / C::LNDIV;
+        v = lnact_v(v, a.st[2 * (f0 + f)], a.st[2 * (f0 + f) + 1], a.gamma[ch], a.beta[ch]);
+      }
+    }
+    tile[f * C::FSTR + k * C::CSTR + C::HLO + i] = v;
+  }
+  __syncthreads();
+}
+
+template <class C, int PH>
+__device__ __forceinline__ void conv_phase(const ConvArgs& a, const float* tile, float* tbuf, int f0, int nblk0,
+                                           int nblk1) {
+  constexpr int R = C::rows(PH), Q0 = C::q0(PH);
+  constexpr int KT = C::kt(PH), NCH = C::ktp(PH) / C::U;
+  constexpr int MTILES = cdiv(C::TF * R, 32), MBLK = cdiv(MTILES, C::MB);
+  constexpr int U = C::U, MB = C::MB, NB = C::NB, NP = C::NP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int nblks = nblk1 - nblk0;
+  const int items = MBLK * nblks;
+  for (int it = wave; it < items; it += C::NW) {
+    const int mblk = it / nblks;
+    const int nblk = nblk0 + (it - mblk * nblks);
+    const int nbase = nblk * NB * 32;
+    int baseA[MB], rowf[MB], rowq[MB];
+    bool rowok[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      int rf = (mblk * MB + mb) * 32 + l31;
+      bool ok = rf < C::TF * R;
+      int rr = ok ? rf : 0;
+      int f = rr / R;
+      int q = Q0 + (rr - f * R);
+      rowf[mb] = f;
+      rowq[mb] = q;
+      rowok[mb] = ok && (f0 + f) < a.F;
+      baseA[mb] = f * C::FSTR + lh * C::CSTR + C::HLO + q * C::RS + C::OFF;
+    }
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = zero16();
+
+    const float* bp = a.Bp + C::boff(PH) + lh * NP + nbase + l31;
+    float bcur[U][NB], bnxt[U][NB];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bcur[u][nb] = (nbase + nb * 32 < NP) ? bp[u * 2 * NP + nb * 32] : 0.f;
+    for (int c = 0; c < NCH; ++c) {
+      if (c + 1 < NCH) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            bnxt[u][nb] = (nbase + nb * 32 < NP) ? bp[((c + 1) * U + u) * 2 * NP + nb * 32] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int s = c * U + u;
+        s = s < KT ? s : KT - 1;  // padded B rows are zero; keep the LDS address in range
+        int tau = s / C::KH;
+        int kk = s - tau * C::KH;
+        int aoff = kk * 2 * C::CSTR + tau * C::TS;
+        float av[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[mb] = tile[baseA[mb] + aoff];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma32(av[mb], bcur[u][nb], acc[mb][nb]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bcur[u][nb] = bnxt[u][nb];
+    }
+    // ---- epilogue: transpose through LDS, store along the position axis
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      if ((mblk * MB + mb) >= MTILES) continue;  // wave-uniform
+      const int opos = C::TYPEP ? (C::S * rowq[mb] + PH - C::PAD) : rowq[mb];
+      const int64_t obase = (int64_t)(f0 + rowf[mb]) * C::N * C::HOUT + opos;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        if (nbase + nb * 32 >= NP) continue;  // wave-uniform
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) tbuf[l31 * 33 + acc_row(reg, lane)] = acc[mb][nb][reg];
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          int nl = 2 * i + lh;
+          int n = nbase + nb * 32 + nl;
+          float v = tbuf[nl * 33 + l31];
+          if (rowok[mb] && n < C::N) a.out[obase + (int64_t)n * C::HOUT] = v + (a.bias ? a.bias[n] : 0.f);
+        }
+        wave_lds_sync();
+      }
+    }
+  }
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_convgemm(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* tile = lds;
+  float* tbuf = lds + C::TILE + (threadIdx.x >> 6) * (32 * 33);
+  const int f0 = blockIdx.x * C::TF;
+  conv_stage<C>(a, tile, f0);
+  constexpr int NBLK = cdiv(C::NT, C::NB);
+  const int nblk0 = (int)((int64_t)NBLK * blockIdx.y / gridDim.y);
+  const int nblk1 = (int)((int64_t)NBLK * (blockIdx.y + 1) / gridDim.y);
+  conv_phase<C, 0>(a, tile, tbuf, f0, nblk0, nblk1);
+  if constexpr (C::NPH > 1) conv_phase<C, 1>(a, tile, tbuf, f0, nblk0, nblk1);
+  if constexpr (C::NPH > 2) conv_phase<C, 2>(a, tile, tbuf, f0, nblk0, nblk1);
+  static_assert(C::NPH <= 3, "stride > 3 not instantiated");
+}
+
+template <class C>
+inline void launch_convgemm(const ConvArgs& a, int nsplit, hipStream_t s) {
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convgemm<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              C::LDS_BYTES);
+    once = true;
+  }
+  dim3 grid((unsigned)cdiv(a.F, C::TF), (unsigned)nsplit);
+  hipLaunchKernelGGL(k_convgemm<C>, grid, dim3(256), C::LDS_BYTES, s, a);
+}
+
+}  // namespace tuned
+}  // namespace vaenpvc

@@ -1,0 +1,153 @@
+// gfx950_convwgrad.h -- weight gradients of the strided conv / conv_transpose layers.
+//
+//   dW[m = (t, xc)][n] += sum_f sum_r X'[f, xc, S*r - PAD + t] * Y'[f, n, r]
+//
+//   conv (encoder):   X = layer input (LN+lrelu on load), Y = d(pre-LN output)   -> dW[t][cin][cout]
+//   conv_transpose:   X = d(pre-LN output),               Y = layer input        -> dW[t][cout][cin]
+// i.e. in both cases the result lands directly in the TF kernel layout of the flat
+// gradient buffer.  GEMM view: M = T*XC, N = YC, K = (frame, r).  Both operand tiles of TF
+// frames are staged in LDS (coalesced HBM reads, zero halos); fragments are gathered with
+// lane <-> channel (odd channel stride -> conflict free), k-step = the same position r of two
+// consecutive frames.  Waves split M (and K when M is small); partial sums over frame
+// chunks are combined with fp32 global atomics.
+#pragma once
+#include "gfx950_common.h"
+
+namespace vaenpvc {
+namespace tuned {
+
+constexpr int odd_up(int v) { return v | 1; }
+
+template <int XC_, int XH_, int YC_, int YH_, int T_, int S_, int PAD_, bool XLN_, bool YLN_, int TF_, int NTW_>
+struct WgCfg {
+  static constexpr int XC = XC_, XH = XH_, YC = YC_, YH = YH_, T = T_, S = S_, PAD = PAD_, TF = TF_, NTW = NTW_;
+  static constexpr bool XLN = XLN_, YLN = YLN_;
+  static constexpr int M = T * XC, MTL = cdiv(M, 32);
+  static constexpr int NTL = cdiv(YC, 32), NSPLIT = cdiv(NTL, NTW);
+  static constexpr int WM = MTL >= 4 ? 4 : (MTL >= 2 ? 2 : 1), WK = 4 / WM, MTW = cdiv(MTL, WM);
+  static constexpr int HLO = PAD, HHI = cmax(0, S * (YH - 1) - PAD + T - 1 - (XH - 1));
+  static constexpr int CSTRX = odd_up(HLO + XH + HHI), CSTRY = odd_up(YH);
+  static constexpr int FSTRX = XC * CSTRX, FSTRY = NTW * 32 * CSTRY;
+  static constexpr int XT = rup(TF * FSTRX, 4), YT = rup(TF * FSTRY, 4);
+  static constexpr int LDS_BYTES = (XT + YT) * 4;
+  static_assert(TF % 2 == 0, "k-steps pair two frames");
+};
+
+struct WgArgs {
+  const float* X;
+  const float* xst;  // LN of X (XLN)
+  const float* xg;
+  const float* xb;
+  const float* Y;
+  const float* yst;  // LN of Y (YLN)
+  const float* yg;
+  const float* yb;
+  float* dW;  // [M][YC] atomicAdd
+  int F;
+  int fchunk;  // frames per blockIdx.x (multiple of TF)
+};
+
+template <class C>
+__global__ void __launch_bounds__(256) k_convwgrad(WgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* tX = lds;
+  float* tY = lds + C::XT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int wm = wave % C::WM, wk = wave / C::WM;
+  const int nc0 = blockIdx.y * C::NTW * 32;  // first Y channel of this workgroup
+  for (int i = tid; i < (C::XT + C::YT) / 4; i += 256) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  int baseA[C::MTW];
+  bool aok[C::MTW];
+#pragma unroll
+  for (int i = 0; i < C::MTW; ++i) {
+    int m = (wm + i * C::WM) * 32 + l31;
+    aok[i] = m < C::M;
+    int mm = aok[i] ? m : 0;
+    int t = mm / C::XC, xc = mm - t * C::XC;
+    baseA[i] = lh * C::FSTRX + xc * C::CSTRX + C::HLO - C::PAD + t;
+  }
+  int baseB[C::NTW];
+#pragma unroll
+  for (int j = 0; j < C::NTW; ++j) baseB[j] = lh * C::FSTRY + (j * 32 + l31) * C::CSTRY;
+  f32x16 acc[C::MTW][C::NTW];
+#pragma unroll
+  for (int i = 0; i < C::MTW; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j) acc[i][j] = zero16();
+
+  const int fb = blockIdx.x * a.fchunk;
+  const int fe = min(a.F, fb + a.fchunk);
+  constexpr int XPER = C::XC * C::XH, YPER = C::NTW * 32 * C::YH;
+  for (int f0 = fb; f0 < fe; f0 += C::TF) {
+    __syncthreads();  // previous sub-tile consumed (first pass: zero fill done)
+    for (int e = tid; e < C::TF * XPER; e += 256) {
+      int f = e / XPER, rem = e - f * XPER;
+      int xc = rem / C::XH, i = rem - xc * C::XH;
+      float v = 0.f;
+      if (f0 + f < fe) {
+        v = a.X[(int64_t)(f0 + f) * XPER + rem];
+        if constexpr (C::XLN) v = lnact_v(v, a.xst[2 * (f0 + f)], a.xst[2 * (f0 + f) + 1], a.xg[xc], a.xb[xc]);
+      }
+      tX[f * C::FSTRX + xc * C::CSTRX + C::HLO + i] = v;
+    }
+    for (int e = tid; e < C::TF * YPER; e += 256) {
+      int f = e / YPER, rem = e - f * YPER;
+      int nl = rem / C::YH, r = rem - nl * C::YH;
+      int n = nc0 + nl;
+      float v = 0.f;
+      if (f0 + f < fe && n < C::YC) {
+        v = a.Y[((int64_t)(f0 + f) * C::YC + n) * C::YH + r];
+        if constexpr (C::YLN) v = lnact_v(v, a.yst[2 * (f0 + f)], a.yst[2 * (f0 + f) + 1], a.yg[n], a.yb[n]);
+      }
+      tY[f * C::FSTRY + nl * C::CSTRY + r] = v;
+    }
+    __syncthreads();
+    constexpr int HP = C::TF / 2, KS = C::YH * HP;
+    for (int ks = wk; ks < KS; ks += C::WK) {
+      int r = ks / HP, fp = ks - r * HP;
+      int ao = fp * 2 * C::FSTRX + C::S * r;
+      int bo = fp * 2 * C::FSTRY + r;
+      float av[C::MTW], bv[C::NTW];
+#pragma unroll
+      for (int i = 0; i < C::MTW; ++i) {
+        float v = tX[baseA[i] + ao];
+        av[i] = aok[i] ? v : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < C::NTW; ++j) bv[j] = tY[baseB[j] + bo];
+#pragma unroll
+      for (int i = 0; i < C::MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < C::NTW; ++j) acc[i][j] = mfma32(av[i], bv[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < C::MTW; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        int m = (wm + i * C::WM) * 32 + acc_row(reg, lane);
+        int n = nc0 + j * 32 + l31;
+        if (m < C::M && n < C::YC) atomicAdd(a.dW + (int64_t)m * C::YC + n, acc[i][j][reg]);
+      }
+}
+
+template <class C>
+inline void launch_convwgrad(const WgArgs& a0, int target_wgs, hipStream_t s) {
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convwgrad<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              C::LDS_BYTES);
+    once = true;
+  }
+  WgArgs a = a0;
+  int chunks = cmax(1, target_wgs / C::NSPLIT);
+  a.fchunk = rup(cmax(1, cdiv(a.F, chunks)), C::TF);
+  dim3 grid((unsigned)cdiv(a.F, a.fchunk), (unsigned)C::NSPLIT);
+  hipLaunchKernelGGL(k_convwgrad<C>, grid, dim3(256), C::LDS_BYTES, s, a);
+}
+
+}  // namespace tuned
+}  // namespace vaenpvc

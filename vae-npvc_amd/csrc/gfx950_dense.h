@@ -1,0 +1,142 @@
+// gfx950_dense.h -- dense layers (encoder heads, speaker/latent merge) forward and
+// input-gradient:  out[f][n] = bias[n] + sum_k A'[f][k] * B[k][n]
+//
+// One workgroup = 32 frames (one MFMA row tile) x up to 4*NBW column tiles.  A' is staged
+// through LDS in K-chunks of KCH (coalesced HBM reads; LN+lrelu on load, or the
+// [z | E[y]] / [dz_mu | dz_lv] concatenation), B (packed [KP][NP] by gfx950_prep) streams
+// from L2 into the MFMA operand register (128 contiguous bytes per half-wave).  The
+// accumulator layout has lanes along n, so results are stored straight from registers.
+#pragma once
+#include "gfx950_common.h"
+#include "gfx950_convgemm.h"  // IN_* kinds
+
+namespace vaenpvc {
+namespace tuned {
+
+struct DenseArgs {
+  const float* in;     // [F][K]  (IN_CONCAT2: first half [F][K/2])
+  const float* in2;    // IN_CONCAT2: second half rows
+  const int64_t* idx;  // IN_CONCAT2: optional row gather of in2
+  const float* st;     // IN_LN
+  const float* gamma;
+  const float* beta;
+  const float* Bp;  // packed [KP][NP], zero padded
+  const float* bias;
+  float* out;   // [F][ldo]            (columns n <  split)
+  float* out2;  // [F][ldo] or nullptr  (columns n >= split, stored at n - split)
+  int split;
+  int ldo;
+  int F;
+};
+
+template <int K_, int N_, int KCH_, int NBW_, int INKIND_, int LNDIV_>
+struct DenseCfg {
+  static constexpr int K = K_, N = N_, KCH = KCH_, NBW = NBW_, INKIND = INKIND_, LNDIV = LNDIV_;
+  static constexpr int NP = rup(N, 32), NT = NP / 32;
+  static constexpr int NCHUNK = cdiv(K, KCH);
+  static constexpr int KP = NCHUNK * KCH;  // packed B rows (zero padded)
+  static constexpr int ASTR = KCH + 1;     // odd -> conflict-free gathers (lane <-> frame)
+  static constexpr int NSPLIT = cdiv(NT, 4 * NBW);
+  static constexpr int LDS_BYTES = 32 * ASTR * 4;
+  static_assert(KCH % 16 == 0, "chunk = multiple of the prefetch depth");
+};
+
+template <class C>
+__global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float tA[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int f0 = blockIdx.x * 32;
+  const int nt0 = (blockIdx.y * 4 + wave) * C::NBW;  // first column tile of this wave
+  f32x16 acc[C::NBW];
+#pragma unroll
+  for (int nb = 0; nb < C::NBW; ++nb) acc[nb] = zero16();
+  const float* ap = tA + l31 * C::ASTR + lh;
+  constexpr int U = 8;
+  for (int ch = 0; ch < C::NCHUNK; ++ch) {
+    const int kc0 = ch * C::KCH;
+    __syncthreads();
+    for (int e = tid; e < 32 * C::KCH; e += 256) {
+      int fl = e / C::KCH, kk = e - fl * C::KCH;
+      int k = kc0 + kk, f = f0 + fl;
+      float v = 0.f;
+      if (k < C::K && f < a.F) {
+        if constexpr (C::INKIND == IN_CONCAT2) {
+          constexpr int HALF = C::K / 2;
+          if (k < HALF) {
+            v = a.in[(int64_t)f * HALF + k];
+          } else {
+            int64_t g = a.idx ? a.idx[f] : (int64_t)f;
+            v = a.in2[g * HALF + (k - HALF)];
+          }
+        } else {
+          v = a.in[(int64_t)f * C::K + k];
+          if constexpr (C::INKIND == IN_LN) {
+            int c = k / C::LNDIV;
+            v = lnact_v(v, a.st[2 * f], a.st[2 * f + 1], a.gamma[c], a.beta[c]);
+          }
+        }
+      }
+      tA[fl * C::ASTR + kk] = v;
+    }
+    __syncthreads();
+    if (nt0 < C::NT) {  // wave-uniform
+      const float* bp = a.Bp + (int64_t)(kc0 + lh) * C::NP + nt0 * 32 + l31;
+      float bcur[U][C::NBW], bnxt[U][C::NBW];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int nb = 0; nb < C::NBW; ++nb) bcur[u][nb] = (nt0 + nb < C::NT) ? bp[u * 2 * C::NP + nb * 32] : 0.f;
+      for (int c8 = 0; c8 < C::KCH / (2 * U); ++c8) {
+        if (c8 + 1 < C::KCH / (2 * U)) {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int nb = 0; nb < C::NBW; ++nb)
+              bnxt[u][nb] = (nt0 + nb < C::NT) ? bp[((c8 + 1) * U + u) * 2 * C::NP + nb * 32] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float av = ap[(c8 * U + u) * 2];
+#pragma unroll
+          for (int nb = 0; nb < C::NBW; ++nb) acc[nb] = mfma32(av, bcur[u][nb], acc[nb]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int nb = 0; nb < C::NBW; ++nb) bcur[u][nb] = bnxt[u][nb];
+      }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < C::NBW; ++nb) {
+    int n = (nt0 + nb) * 32 + l31;
+    if (nt0 + nb < C::NT && n < C::N) {
+      float bb = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        int f = f0 + acc_row(reg, lane);
+        if (f < a.F) {
+          if (a.out2 && n >= a.split)
+            a.out2[(int64_t)f * a.ldo + (n - a.split)] = acc[nb][reg] + bb;
+          else
+            a.out[(int64_t)f * a.ldo + n] = acc[nb][reg] + bb;
+        }
+      }
+    }
+  }
+}
+
+template <class C>
+inline void launch_densegemm(const DenseArgs& a, hipStream_t s) {
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_densegemm<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              C::LDS_BYTES);
+    once = true;
+  }
+  dim3 grid((unsigned)cdiv(a.F, 32), (unsigned)C::NSPLIT);
+  hipLaunchKernelGGL(k_densegemm<C>, grid, dim3(256), C::LDS_BYTES, s, a);
+}
+
+}  // namespace tuned
+}  // namespace vaenpvc

@@ -1,0 +1,303 @@
+// gfx950_elem.h -- HBM-bound kernels of the tuned path: LayerNorm statistics, the fused
+// LayerNorm+lrelu backward (input gradient + d gamma / d beta / d bias in one pass over the
+// tensors), column / total reductions, the speaker-embedding gradient and weight packing.
+#pragma once
+#include "gfx950_common.h"
+
+namespace vaenpvc {
+namespace tuned {
+
+// ---------------------------------------------------------------- LayerNorm statistics
+// util/layers.py:32 -- one wave per frame, the frame (N floats, N % 4 == 0) is read ONCE
+// with 16-byte loads and kept in registers for the two-pass (mean, then centred variance).
+template <int N>
+__global__ void __launch_bounds__(256) k_ln_stats_fast(const float* __restrict__ a, float* __restrict__ st, int F) {
+  static_assert(N % 4 == 0, "frame size must be a multiple of 4 floats");
+  constexpr int NV = N / 4, PER = cdiv(NV, 64);
+  const int lane = threadIdx.x & 63;
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= F) return;
+  const float4* p = reinterpret_cast<const float4*>(a + (int64_t)f * N);
+  float4 v[PER];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    int idx = lane + 64 * i;
+    v[i] = idx < NV ? p[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / N;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    if (lane + 64 * i < NV) {
+      float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float var = wave_sum(q) / N;
+  if (lane == 0) {
+    st[2 * f] = mean;
+    st[2 * f + 1] = 1.0f / sqrtf(var + LN_EPS);
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm + lrelu backward
+// autodiff of util/layers.py:32-44,149 for one layer with C channels x H positions:
+//   n = gamma*xhat+beta ; dn = dy*(n>=0 ? 1 : leak) ; dxh = dn*gamma
+//   da = rstd*(dxh - mean(dxh) - xhat*mean(dxh*xhat))
+//   d gamma[c] += sum dn*xhat ; d beta[c] += sum dn ; d bias[c] += sum da
+// A workgroup walks `fchunk` frames in sub-tiles of TF frames held in LDS (dn, xhat), so
+// dy and a are read once and da written once; the per-channel sums are carried in registers
+// per element across the whole chunk and reduced once at the end (3*C global atomics).
+template <int C_, int H_, int TF_>
+struct LnbCfg {
+  static constexpr int C = C_, H = H_, TF = TF_, N = C * H;
+  static constexpr int EPT = cdiv(N, 256);
+  static constexpr int LDS_FLOATS = cmax(2 * TF * N, 3 * N) + 4 * TF;
+  static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+};
+
+template <class L>
+__global__ void __launch_bounds__(256) k_ln_bwd_fused(const float* __restrict__ dy, const float* __restrict__ a,
+                                                      const float* __restrict__ st, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ da,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      float* __restrict__ dbias, int F, int fchunk) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int N = L::N, TF = L::TF, H = L::H, C = L::C, EPT = L::EPT;
+  float* dnL = lds;
+  float* xhL = lds + TF * N;
+  float* sS = lds + cmax(2 * TF * N, 3 * N);  // [TF][4]: mean(dxh), mean(dxh*xhat), rstd
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fb = blockIdx.x * fchunk, fe = min(F, fb + fchunk);
+  float su[EPT], sw[EPT], sd[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) su[k] = sw[k] = sd[k] = 0.f;
+  for (int f0 = fb; f0 < fe; f0 += TF) {
+    __syncthreads();
+    const int nfr = min(TF, fe - f0);
+    for (int e = tid; e < nfr * N; e += 256) {
+      int f = e / N, i = e - f * N;
+      int c = i / H;
+      float mean = st[2 * (f0 + f)], rstd = st[2 * (f0 + f) + 1];
+      float xh = (a[(int64_t)f0 * N + e] - mean) * rstd;
+      float nn = xh * gamma[c] + beta[c];
+      dnL[e] = dy[(int64_t)f0 * N + e] * (nn >= 0.f ? 1.0f : LEAK);
+      xhL[e] = xh;
+    }
+    __syncthreads();
+    for (int f = wave; f < nfr; f += 4) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int i = lane; i < N; i += 64) {
+        float dx = dnL[f * N + i] * gamma[i / H];
+        s1 += dx;
+        s2 += dx * xhL[f * N + i];
+      }
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      if (lane == 0) {
+        sS[4 * f] = s1 / N;
+        sS[4 * f + 1] = s2 / N;
+        sS[4 * f + 2] = st[2 * (f0 + f) + 1];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      int i = tid + 256 * k;
+      if (i < N) {
+        float g = gamma[i / H];
+        for (int f = 0; f < nfr; ++f) {
+          float dn = dnL[f * N + i], xh = xhL[f * N + i];
+          float d = sS[4 * f + 2] * (dn * g - sS[4 * f] - xh * sS[4 * f + 1]);
+          da[(int64_t)(f0 + f) * N + i] = d;
+          su[k] += dn * xh;
+          sw[k] += dn;
+          sd[k] += d;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* eU = lds;
+  float* eW = lds + N;
+  float* eD = lds + 2 * N;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    int i = tid + 256 * k;
+    if (i < N) {
+      eU[i] = su[k];
+      eW[i] = sw[k];
+      eD[i] = sd[k];
+    }
+  }
+  __syncthreads();
+  if constexpr (H >= 32) {
+    for (int c = wave; c < C; c += 4) {
+      float u = 0.f, w = 0.f, d = 0.f;
+      for (int h = lane; h < H; h += 64) {
+        u += eU[c * H + h];
+        w += eW[c * H + h];
+        d += eD[c * H + h];
+      }
+      u = wave_sum(u);
+      w = wave_sum(w);
+      d = wave_sum(d);
+      if (lane == 0) {
+        atomicAdd(dgamma + c, u);
+        atomicAdd(dbeta + c, w);
+        atomicAdd(dbias + c, d);
+      }
+    }
+  } else {
+    for (int c = tid; c < C; c += 256) {
+      float u = 0.f, w = 0.f, d = 0.f;
+      for (int h = 0; h < H; ++h) {
+        u += eU[c * H + h];
+        w += eW[c * H + h];
+        d += eD[c * H + h];
+      }
+      atomicAdd(dgamma + c, u);
+      atomicAdd(dbeta + c, w);
+      atomicAdd(dbias + c, d);
+    }
+  }
+}
+
+template <class L>
+inline void launch_ln_bwd(const float* dy, const float* a, const float* st, const float* gamma, const float* beta,
+                          float* da, float* dgamma, float* dbeta, float* dbias, int F, int target_wgs, hipStream_t s) {
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_bwd_fused<L>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES);
+    once = true;
+  }
+  int fchunk = rup(cmax(1, cdiv(F, target_wgs)), L::TF);
+  hipLaunchKernelGGL(k_ln_bwd_fused<L>, dim3((unsigned)cdiv(F, fchunk)), dim3(256), L::LDS_BYTES, s, dy, a, st, gamma,
+                     beta, da, dgamma, dbeta, dbias, F, fchunk);
+}
+
+// ---------------------------------------------------------------- reductions
+// o[n] += sum_f d[f*ld + n] ; grid (ceil(N/256), frame chunks); up to three destinations
+__global__ void __launch_bounds__(256) k_colsum_atomic(const float* __restrict__ d, int ld, int N, int F, int fchunk,
+                                                       float* o1, float* o2, float* o3) {
+  int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  int fb = blockIdx.y * fchunk, fe = min(F, fb + fchunk);
+  float s = 0.f;
+  for (int f = fb; f < fe; ++f) s += d[(int64_t)f * ld + n];
+  atomicAdd(o1 + n, s);
+  if (o2) atomicAdd(o2 + n, s);
+  if (o3) atomicAdd(o3 + n, s);
+}
+
+// out[0] += sum of all `count` floats
+__global__ void __launch_bounds__(256) k_sum_all_atomic(const float* __restrict__ d, int64_t count, float* out) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) s += d[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (sm[0] + sm[1]) + (sm[2] + sm[3]));
+}
+
+// dE[y_f][k] += de[f][k] (de = columns [off, off+zd) of a [F][ld] buffer); LDS accumulation
+// per frame chunk, then ny*zd global atomics per workgroup.
+__global__ void __launch_bounds__(256) k_emb_grad_fast(const float* __restrict__ de, int ld, int off,
+                                                       const int64_t* __restrict__ y, float* __restrict__ dE, int F,
+                                                       int fchunk, int zd, int ny) {
+  extern __shared__ float sm[];
+  for (int i = threadIdx.x; i < ny * zd; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  int fb = blockIdx.x * fchunk, fe = min(F, fb + fchunk);
+  for (int64_t e = (int64_t)fb * zd + threadIdx.x; e < (int64_t)fe * zd; e += 256) {
+    int f = (int)(e / zd), k = (int)(e - (int64_t)f * zd);
+    atomicAdd(&sm[y[f] * zd + k], de[(int64_t)f * ld + off + k]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ny * zd; i += 256) {
+    float v = sm[i];
+    if (v != 0.f) atomicAdd(dE + i, v);
+  }
+}
+
+// autodiff of the sampler + KL (see generic k_reparam_bwd); dz read with a row stride
+__global__ void __launch_bounds__(256) k_reparam_bwd_ld(const float* __restrict__ dz, int ld,
+                                                        const float* __restrict__ zmu, const float* __restrict__ zlv,
+                                                        const float* __restrict__ eps, float* __restrict__ dzmu,
+                                                        float* __restrict__ dzlv, int64_t N, int zd, float invF) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  int64_t f = i / zd;
+  int k = (int)(i - f * zd);
+  float mu = zmu[i], lv = zlv[i], v = expf(lv), g = dz[f * ld + k];
+  dzmu[i] = g + mu / (1.0f + EPSILON) * invF;
+  dzlv[i] = g * (0.5f * eps[i] * sqrtf(v)) + 0.5f * (v / (1.0f + EPSILON) - 1.0f) * invF;
+}
+
+// ---------------------------------------------------------------- weight packing
+template <class Fn>
+__global__ void __launch_bounds__(256) k_pack(Fn fn, float* __restrict__ dst, int count) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < count) dst[i] = fn(i);
+}
+template <class Fn>
+inline void launch_pack(Fn fn, float* dst, int count, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack<Fn>, dim3((unsigned)cdiv(count, 256)), dim3(256), 0, s, fn, dst, count);
+}
+
+// packed B of a ConvCfg from a TF kernel tensor.
+//   transposed == false: src[(t*KC + k)*N + n]     transposed == true: src[(t*N + n)*KC + k]
+template <class C>
+struct PackConv {
+  const float* src;
+  bool transposed;
+  __device__ float operator()(int i) const {
+    int ph = 0;
+    if (C::NPH > 1 && i >= C::boff(1)) ph = 1;
+    if (C::NPH > 2 && i >= C::boff(2)) ph = 2;
+    int r = i - (ph == 0 ? 0 : (ph == 1 ? C::boff(1) : C::boff(2)));
+    int row = r / C::NP, n = r - row * C::NP;
+    int tau = row / C::KCP, k = row - tau * C::KCP;
+    int t = C::TYPEP ? ph + C::S * tau : tau;
+    if (t >= C::T || k >= C::KC || n >= C::N) return 0.f;
+    return transposed ? src[((int64_t)t * C::N + n) * C::KC + k] : src[((int64_t)t * C::KC + k) * C::N + n];
+  }
+};
+
+// packed B [KP][NP] of a dense layer built from two row- or column-stacked matrices
+//   colcat : B[k][n] = n <  n1 ? s1[k*n1 + n] : s2[k*n2 + (n-n1)]          (k < K)
+//   rowcat : B[k][n] = k <  k1 ? s1[k*N + n]  : s2[(k-k1)*N + n]           (n < N)
+//   colcatT: B[k][n] = transpose of colcat(K'=N, N'=K): k <  n1 ? s1[n*n1 + k] : s2[n*n2 + (k-n1)]
+//   rowcatT: B[k][n] = transpose of rowcat: n < k1 ? s1[n*Nsrc + k] : s2[(n-k1)*Nsrc + k]
+struct PackDense {
+  const float* s1;
+  const float* s2;
+  int mode;  // 0 colcat, 1 rowcat, 2 colcatT, 3 rowcatT
+  int K, N, NP, split, n2;  // logical K x N of the packed matrix; split = n1 or k1
+  __device__ float operator()(int i) const {
+    int k = i / NP, n = i - k * NP;
+    if (k >= K || n >= N) return 0.f;
+    switch (mode) {
+      case 0: return n < split ? s1[(int64_t)k * split + n] : s2[(int64_t)k * n2 + (n - split)];
+      case 1: return k < split ? s1[(int64_t)k * N + n] : s2[(int64_t)(k - split) * N + n];
+      case 2: return k < split ? s1[(int64_t)n * split + k] : s2[(int64_t)n * n2 + (k - split)];
+      default: return n < split ? s1[(int64_t)n * K + k] : s2[(int64_t)(n - split) * K + k];
+    }
+  }
+};
+
+// channel-major, zero padded copy of the 1025-tap kernel: Wc[c][4 + t] = W[t][c]
+struct PackToep {
+  const float* src;
+  __device__ float operator()(int i) const {
+    int c = i / 1032, r = i - c * 1032 - 4;
+    return (r >= 0 && r < 1025) ? src[r * 8 + c] : 0.f;
+  }
+};
+
+}  // namespace tuned
+}  // namespace vaenpvc

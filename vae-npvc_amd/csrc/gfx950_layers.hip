@@ -1,0 +1,442 @@
+// gfx950_layers.hip -- the tuned MI355X path for the VCC2016 geometry
+// (architecture-vae-vcc2016.json): layer configurations of the four engines and the
+// per-step orchestration of forward and backward.  Every step can be switched back to
+// the geometry-generic kernel (set_masks) to isolate a fault on the GPU.
+//
+// Step list and the reference code each step replaces:
+//   e0..e4  conv2d_nchw_layernorm x5        util/layers.py:47-66 (model/vae.py:74-78)
+//   heads   two dense heads                  model/vae.py:79-81
+//   merge   embedding lookup + _merge        model/vae.py:51-61,89-90
+//   d0..d2  conv2d_transpose + LN + lrelu    model/vae.py:96-102
+//   d3      conv2d_transpose k=1025          model/vae.py:96-99
+//   backward steps = autodiff of the same    trainer/vae.py:24
+#include <cstdlib>
+
+#include "gfx950_convgemm.h"
+#include "gfx950_convwgrad.h"
+#include "gfx950_dense.h"
+#include "gfx950_elem.h"
+#include "gfx950_tngemm.h"
+#include "gfx950_toeplitz.h"
+#include "kernels.h"
+
+namespace vaenpvc {
+namespace tuned {
+
+// ---------------------------------------------------------------- configurations
+//                      KC  HIN   N  HOUT T  S PAD typeP  TF  in-kind  lndiv MB NB
+using E1F = ConvCfg<16, 171, 32, 57, 7, 3, 2, false, 4, IN_LN, 1, 2, 1>;
+using E2F = ConvCfg<32, 57, 64, 19, 7, 3, 2, false, 10, IN_LN, 1, 3, 1>;
+using E3F = ConvCfg<64, 19, 128, 7, 7, 3, 3, false, 9, IN_LN, 1, 2, 1>;
+using E4F = ConvCfg<128, 7, 256, 3, 7, 3, 3, false, 21, IN_LN, 1, 2, 2>;
+using D0F = ConvCfg<81, 19, 32, 57, 9, 3, 3, true, 10, IN_PLAIN, 1, 1, 1>;
+using D1F = ConvCfg<32, 57, 16, 171, 7, 3, 2, true, 4, IN_LN, 1, 2, 1>;
+using D2F = ConvCfg<16, 171, 8, 513, 7, 3, 2, true, 4, IN_LN, 1, 2, 1>;
+// input gradients: conv_transpose layers (S-type) and conv layers (P-type)
+using GD2 = ConvCfg<8, 513, 16, 171, 7, 3, 2, false, 2, IN_PLAIN, 1, 1, 1>;
+using GD1 = ConvCfg<16, 171, 32, 57, 7, 3, 2, false, 4, IN_PLAIN, 1, 2, 1>;
+using GD0 = ConvCfg<32, 57, 81, 19, 9, 3, 3, false, 10, IN_PLAIN, 1, 1, 1>;
+using GE4 = ConvCfg<256, 3, 128, 7, 7, 3, 3, true, 16, IN_PLAIN, 1, 1, 2>;
+using GE3 = ConvCfg<128, 7, 64, 19, 7, 3, 3, true, 9, IN_PLAIN, 1, 1, 1>;
+using GE2 = ConvCfg<64, 19, 32, 57, 7, 3, 2, true, 10, IN_PLAIN, 1, 1, 1>;
+using GE1 = ConvCfg<32, 57, 16, 171, 7, 3, 2, true, 4, IN_PLAIN, 1, 2, 1>;
+//                         K    N   KCH NBW in-kind    lndiv
+using HeadsF = DenseCfg<768, 256, 256, 2, IN_LN, 3>;
+using HeadsB = DenseCfg<256, 768, 256, 3, IN_CONCAT2, 1>;
+using MergeF = DenseCfg<256, 1539, 256, 2, IN_CONCAT2, 1>;
+using MergeB = DenseCfg<1539, 256, 256, 2, IN_PLAIN, 1>;
+//                     XC  XH   YC  YH  T  S PAD  XLN    YLN   TF NTW
+using WD2 = WgCfg<8, 513, 16, 171, 7, 3, 2, false, true, 2, 1>;
+using WD1 = WgCfg<16, 171, 32, 57, 7, 3, 2, false, true, 4, 1>;
+using WD0 = WgCfg<32, 57, 81, 19, 9, 3, 3, false, false, 6, 3>;
+using WE4 = WgCfg<128, 7, 256, 3, 7, 3, 3, true, false, 8, 1>;
+using WE3 = WgCfg<64, 19, 128, 7, 7, 3, 3, true, false, 8, 2>;
+using WE2 = WgCfg<32, 57, 64, 19, 7, 3, 2, true, false, 4, 2>;
+using WE1 = WgCfg<16, 171, 32, 57, 7, 3, 2, true, false, 4, 1>;
+using WE0 = WgCfg<1, 513, 16, 171, 7, 3, 2, false, false, 2, 1>;
+
+// packed-weight scratch layout (float offsets)
+struct Pk {
+  static constexpr int heads_f = 0;
+  static constexpr int heads_b = heads_f + HeadsF::KP * HeadsF::NP;
+  static constexpr int merge_f = heads_b + HeadsB::KP * HeadsB::NP;
+  static constexpr int merge_b = merge_f + MergeF::KP * MergeF::NP;
+  static constexpr int merge_bias = merge_b + MergeB::KP * MergeB::NP;
+  static constexpr int d0f = merge_bias + 1600;
+  static constexpr int d1f = d0f + D0F::BTOTAL;
+  static constexpr int d2f = d1f + D1F::BTOTAL;
+  static constexpr int gd2 = d2f + D2F::BTOTAL;
+  static constexpr int gd0 = gd2 + GD2::BTOTAL;
+  static constexpr int ge4 = gd0 + GD0::BTOTAL;
+  static constexpr int ge3 = ge4 + GE4::BTOTAL;
+  static constexpr int ge2 = ge3 + GE3::BTOTAL;
+  static constexpr int ge1 = ge2 + GE2::BTOTAL;
+  static constexpr int wc = ge1 + GE1::BTOTAL;
+  static constexpr int total = wc + TOEP_C * WROW;
+};
+static_assert(Pk::total <= 2 * 939162 + 65536, "packed weights must fit the scratch region");
+// layers whose TF kernel tensor IS the packed operand (no copy)
+static_assert(E1F::BTOTAL == 7 * 16 * 32 && E2F::BTOTAL == 7 * 32 * 64 && E3F::BTOTAL == 7 * 64 * 128 &&
+                  E4F::BTOTAL == 7 * 128 * 256 && GD1::BTOTAL == 7 * 16 * 32,
+              "direct-use layers must not be padded");
+
+static unsigned g_fwd_mask = 0xffffffffu, g_bwd_mask = 0xffffffffu;
+static bool g_env_read = false;
+static void read_env() {
+  if (g_env_read) return;
+  g_env_read = true;
+  if (const char* e = getenv("VAENPVC_FWD_MASK")) g_fwd_mask = (unsigned)strtoul(e, nullptr, 0);
+  if (const char* e = getenv("VAENPVC_BWD_MASK")) g_bwd_mask = (unsigned)strtoul(e, nullptr, 0);
+}
+void set_masks(unsigned fwd, unsigned bwd) {
+  g_env_read = true;
+  g_fwd_mask = fwd;
+  g_bwd_mask = bwd;
+}
+bool available() { return true; }
+static inline bool fwd_on(int bit) { return (g_fwd_mask >> bit) & 1u; }
+static inline bool bwd_on(int bit) { return (g_bwd_mask >> bit) & 1u; }
+
+__global__ void __launch_bounds__(256) k_add_bias(float* z, const float* b, int64_t n, int zd) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) z[i] += b[i % zd];
+}
+
+struct PackSum3 {
+  const float *a, *b, *c;
+  int n;
+  __device__ float operator()(int i) const { return i < n ? (a[i] + b[i]) + c[i] : 0.f; }
+};
+
+// ---------------------------------------------------------------- weight packing
+static void prep(const Model& m, const float* P, const Ws& w, hipStream_t s) {
+  float* S = w.scratch;
+  launch_pack(PackDense{P + m.wmu_off, P + m.wlv_off, 0, 768, 256, HeadsF::NP, 128, 128}, S + Pk::heads_f,
+              HeadsF::KP * HeadsF::NP, s);
+  launch_pack(PackDense{P + m.wmu_off, P + m.wlv_off, 2, 256, 768, HeadsB::NP, 128, 128}, S + Pk::heads_b,
+              HeadsB::KP * HeadsB::NP, s);
+  launch_pack(PackDense{P + m.wz_off, P + m.wy_off, 1, 256, 1539, MergeF::NP, 128, 0}, S + Pk::merge_f,
+              MergeF::KP * MergeF::NP, s);
+  launch_pack(PackDense{P + m.wz_off, P + m.wy_off, 3, 1539, 256, MergeB::NP, 128, 0}, S + Pk::merge_b,
+              MergeB::KP * MergeB::NP, s);
+  launch_pack(PackSum3{P + m.bz_off, P + m.by_off, P + m.bm_off, 1539}, S + Pk::merge_bias, 1600, s);
+  // conv_transpose forward: B[t][k=cin][n=cout] from TF [t][cout][cin]  -> transposed
+  launch_pack(PackConv<D0F>{P + m.dec[0].w_off, true}, S + Pk::d0f, D0F::BTOTAL, s);
+  launch_pack(PackConv<D1F>{P + m.dec[1].w_off, true}, S + Pk::d1f, D1F::BTOTAL, s);
+  launch_pack(PackConv<D2F>{P + m.dec[2].w_off, true}, S + Pk::d2f, D2F::BTOTAL, s);
+  // conv_transpose input-gradient: B[t][k=cout][n=cin] = TF layout (padded copies only)
+  launch_pack(PackConv<GD2>{P + m.dec[2].w_off, false}, S + Pk::gd2, GD2::BTOTAL, s);
+  launch_pack(PackConv<GD0>{P + m.dec[0].w_off, false}, S + Pk::gd0, GD0::BTOTAL, s);
+  // conv input-gradient: B[t][k=cout][n=cin] from TF [t][cin][cout] -> transposed
+  launch_pack(PackConv<GE4>{P + m.enc[4].w_off, true}, S + Pk::ge4, GE4::BTOTAL, s);
+  launch_pack(PackConv<GE3>{P + m.enc[3].w_off, true}, S + Pk::ge3, GE3::BTOTAL, s);
+  launch_pack(PackConv<GE2>{P + m.enc[2].w_off, true}, S + Pk::ge2, GE2::BTOTAL, s);
+  launch_pack(PackConv<GE1>{P + m.enc[1].w_off, true}, S + Pk::ge1, GE1::BTOTAL, s);
+  launch_pack(PackToep{P + m.dec[3].w_off}, S + Pk::wc, TOEP_C * WROW, s);
+}
+
+template <int N>
+static void stats(const float* a, float* st, int F, hipStream_t s) {
+  hipLaunchKernelGGL(k_ln_stats_fast<N>, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, a, st, F);
+}
+
+static ConvArgs conv_args(const float* in, const float* st, const float* gamma, const float* beta, const float* Bp,
+                          const float* bias, float* out, int F) {
+  ConvArgs a;
+  a.in = in;
+  a.in2 = nullptr;
+  a.idx = nullptr;
+  a.st = st;
+  a.gamma = gamma;
+  a.beta = beta;
+  a.Bp = Bp;
+  a.bias = bias;
+  a.out = out;
+  a.F = F;
+  return a;
+}
+
+// ---------------------------------------------------------------- forward
+void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, const Ws& w, hipStream_t s) {
+  read_env();
+  const int F = (int)F64;
+  prep(m, P, w, s);
+  // e0: Cin = 1, K = 7 -- 0.4 % of the MACs, HBM-bound; generic kernel + fast statistics
+  if (fwd_on(0)) {
+    generic::enc_layer_fwd(m, P, x, F, w, s, 0);
+  } else {
+    generic::enc_layer_fwd(m, P, x, F, w, s, 0);
+  }
+  auto lnp = [&](int i) { return conv_args(w.enc_a[i - 1], w.enc_st[i - 1], P + m.enc[i - 1].gamma_off, P + m.enc[i - 1].beta_off,
+                                           P + m.enc[i].w_off, P + m.enc[i].b_off, w.enc_a[i], F); };
+  if (fwd_on(1)) {
+    VAENPVC_TIMED("enc1_fwd", s, launch_convgemm<E1F>(lnp(1), 1, s));
+    stats<1824>(w.enc_a[1], w.enc_st[1], F, s);
+  } else generic::enc_layer_fwd(m, P, x, F, w, s, 1);
+  if (fwd_on(2)) {
+    VAENPVC_TIMED("enc2_fwd", s, launch_convgemm<E2F>(lnp(2), 1, s));
+    stats<1216>(w.enc_a[2], w.enc_st[2], F, s);
+  } else generic::enc_layer_fwd(m, P, x, F, w, s, 2);
+  if (fwd_on(3)) {
+    VAENPVC_TIMED("enc3_fwd", s, launch_convgemm<E3F>(lnp(3), 1, s));
+    stats<896>(w.enc_a[3], w.enc_st[3], F, s);
+  } else generic::enc_layer_fwd(m, P, x, F, w, s, 3);
+  if (fwd_on(4)) {
+    VAENPVC_TIMED("enc4_fwd", s, launch_convgemm<E4F>(lnp(4), 1, s));
+    stats<768>(w.enc_a[4], w.enc_st[4], F, s);
+  } else generic::enc_layer_fwd(m, P, x, F, w, s, 4);
+  if (fwd_on(5)) {
+    DenseArgs a{w.enc_a[4], nullptr, nullptr, w.enc_st[4], P + m.enc[4].gamma_off, P + m.enc[4].beta_off,
+                w.scratch + Pk::heads_f, nullptr, w.z_mu, w.z_lv, 128, 128, F};
+    // the two biases live in separate tensors: add them through the split as well
+    a.bias = nullptr;
+    VAENPVC_TIMED("heads_fwd", s, launch_densegemm<HeadsF>(a, s));
+    // bias add (tiny): z_mu += b_mu ; z_lv += b_lv
+    int64_t n = (int64_t)F * m.z;
+    hipLaunchKernelGGL(k_add_bias, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.z_mu, P + m.bmu_off, n, m.z);
+    hipLaunchKernelGGL(k_add_bias, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.z_lv, P + m.blv_off, n, m.z);
+  } else generic::heads_fwd(m, P, F, w, s);
+}
+
+void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* y, int64_t F64, const Ws& w,
+                 float* xh_out, hipStream_t s) {
+  read_env();
+  const int F = (int)F64;
+  prep(m, P, w, s);
+  if (fwd_on(6)) {
+    DenseArgs a{z, P + m.emb_off, y, nullptr, nullptr, nullptr, w.scratch + Pk::merge_f, w.scratch + Pk::merge_bias,
+                w.h, nullptr, 0, m.merge, F};
+    VAENPVC_TIMED("merge_fwd", s, launch_densegemm<MergeF>(a, s));
+  } else generic::merge_fwd(m, P, z, y, F, w, s);
+  if (fwd_on(7)) {
+    VAENPVC_TIMED("dec0_fwd", s, launch_convgemm<D0F>(conv_args(w.h, nullptr, nullptr, nullptr, w.scratch + Pk::d0f,
+                                                                P + m.dec[0].b_off, w.dec_a[0], F), 1, s));
+    stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
+  } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 0);
+  if (fwd_on(8)) {
+    VAENPVC_TIMED("dec1_fwd", s, launch_convgemm<D1F>(conv_args(w.dec_a[0], w.dec_st[0], P + m.dec[0].gamma_off,
+                                                                P + m.dec[0].beta_off, w.scratch + Pk::d1f,
+                                                                P + m.dec[1].b_off, w.dec_a[1], F), 1, s));
+    stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
+  } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 1);
+  if (fwd_on(9)) {
+    VAENPVC_TIMED("dec2_fwd", s, launch_convgemm<D2F>(conv_args(w.dec_a[1], w.dec_st[1], P + m.dec[1].gamma_off,
+                                                                P + m.dec[1].beta_off, w.scratch + Pk::d2f,
+                                                                P + m.dec[2].b_off, w.dec_a[2], F), 1, s));
+    stats<4104>(w.dec_a[2], w.dec_st[2], F, s);
+  } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 2);
+  if (fwd_on(10)) {
+    static bool once = false;
+    if (!once) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_fwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS);
+      once = true;
+    }
+    const float* g2 = P + m.dec[2].gamma_off;
+    const float* b2 = P + m.dec[2].beta_off;
+    if (F >= 2048) {
+      VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL(k_toep_fwd<4>, dim3((unsigned)cdiv(F, 32), 1), dim3(256), TF_LDS, s, w.dec_a[2],
+                                                      w.dec_st[2], g2, b2, w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, F));
+    } else {
+      VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL(k_toep_fwd<1>, dim3((unsigned)cdiv(F, 32), 4), dim3(256), TF_LDS, s, w.dec_a[2],
+                                                      w.dec_st[2], g2, b2, w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, F));
+    }
+    hipLaunchKernelGGL(k_toep_fwd_lastcol, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2], g2, b2,
+                       w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, F);
+  } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 3);
+}
+
+// ---------------------------------------------------------------- backward
+static TnArgs tn_args(const float* X, int ldx, const float* Y, int ldy, int M, int N, int F, float* C, int ldc) {
+  TnArgs a;
+  a.X = X;
+  a.xidx = nullptr;
+  a.st = a.gamma = a.beta = nullptr;
+  a.lndiv = 1;
+  a.ldx = ldx;
+  a.Y = Y;
+  a.ldy = ldy;
+  a.M = M;
+  a.N = N;
+  a.F = F;
+  a.C = C;
+  a.ldc = ldc;
+  a.fchunk = 0;
+  return a;
+}
+static int kchunks_for(int F, int tiles) { return cmax(1, cmin_(cdiv(F, 64), cdiv(1024, tiles))); }
+
+void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F64,
+              const Ws& w, float* G, hipStream_t s) {
+  read_env();
+  const int F = (int)F64;
+  (void)hipMemsetAsync(G, 0, (size_t)m.n_params * 4, s);
+  bool dec_bias_done[4] = {false, false, false, false};
+  bool enc_bias_done[5] = {false, false, false, false, false};
+  const int WGS = 1024;  // target workgroup count of the chunked reductions
+
+  // ---- d3: the 1025-tap layer
+  if (bwd_on(10)) {
+    const ConvL& l2 = m.dec[2];
+    TnArgs a = tn_args(w.dec_a[2], 4104, w.d_xh, 513, 4096, 512, F, G + m.dec[3].w_off, 0);
+    a.st = w.dec_st[2];
+    a.gamma = P + l2.gamma_off;
+    a.beta = P + l2.beta_off;
+    VAENPVC_TIMED("dec3_wgrad", s, launch_tngemm(a, true, kchunks_for(F, 32 * 4), s));
+    int ech = cmax(1, cmin_(cdiv(F, 64), 32));
+    int efc = cdiv(F, ech);
+    hipLaunchKernelGGL(k_toep_wgrad_edges, dim3((unsigned)cdiv(8200, 256), (unsigned)cdiv(F, efc)), dim3(256), 0, s, w.dec_a[2],
+                       w.dec_st[2], P + l2.gamma_off, P + l2.beta_off, w.d_xh, G + m.dec[3].w_off, F, efc);
+    hipLaunchKernelGGL(k_sum_all_atomic, dim3((unsigned)cmin_(1024, cdiv(F * 513, 1024))), dim3(256), 0, s, w.d_xh,
+                       (int64_t)F * 513, G + m.dec[3].b_off);
+    static bool once = false;
+    if (!once) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_dgrad), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS);
+      once = true;
+    }
+    VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL(k_toep_dgrad, dim3((unsigned)cdiv(F, 32), 8), dim3(256), TD_LDS, s, w.d_xh,
+                                                      w.scratch + Pk::wc, w.dy_tmp, F));
+    launch_ln_bwd<LnbCfg<8, 513, 2>>(w.dy_tmp, w.dec_a[2], w.dec_st[2], P + l2.gamma_off, P + l2.beta_off, w.d_dec_a[2],
+                                     G + l2.gamma_off, G + l2.beta_off, G + l2.b_off, F, WGS, s);
+    dec_bias_done[2] = true;
+  } else generic::bwd_dec_layer(m, P, F, w, G, s, 3);
+
+  // ---- d2
+  if (bwd_on(9)) {
+    const ConvL &l = m.dec[2], &pl = m.dec[1];
+    WgArgs a{w.d_dec_a[2], nullptr, nullptr, nullptr, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off,
+             G + l.w_off, F, 0};
+    VAENPVC_TIMED("dec2_wgrad", s, launch_convwgrad<WD2>(a, WGS, s));
+    if (!dec_bias_done[2]) generic::bias_grad(w.d_dec_a[2], G + l.b_off, F, l.cout, l.hout, s);
+    VAENPVC_TIMED("dec2_dgrad", s, launch_convgemm<GD2>(conv_args(w.d_dec_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::gd2,
+                                                                  nullptr, w.dy_tmp, F), 1, s));
+    launch_ln_bwd<LnbCfg<16, 171, 2>>(w.dy_tmp, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[1],
+                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, WGS, s);
+    dec_bias_done[1] = true;
+  } else generic::bwd_dec_layer(m, P, F, w, G, s, 2);
+
+  // ---- d1
+  if (bwd_on(8)) {
+    const ConvL &l = m.dec[1], &pl = m.dec[0];
+    WgArgs a{w.d_dec_a[1], nullptr, nullptr, nullptr, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off,
+             G + l.w_off, F, 0};
+    VAENPVC_TIMED("dec1_wgrad", s, launch_convwgrad<WD1>(a, WGS, s));
+    if (!dec_bias_done[1]) generic::bias_grad(w.d_dec_a[1], G + l.b_off, F, l.cout, l.hout, s);
+    VAENPVC_TIMED("dec1_dgrad", s, launch_convgemm<GD1>(conv_args(w.d_dec_a[1], nullptr, nullptr, nullptr, P + l.w_off, nullptr,
+                                                                  w.dy_tmp, F), 1, s));
+    launch_ln_bwd<LnbCfg<32, 57, 4>>(w.dy_tmp, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[0],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, WGS, s);
+    dec_bias_done[0] = true;
+  } else generic::bwd_dec_layer(m, P, F, w, G, s, 1);
+
+  // ---- d0
+  if (bwd_on(7)) {
+    const ConvL& l = m.dec[0];
+    WgArgs a{w.d_dec_a[0], nullptr, nullptr, nullptr, w.h, nullptr, nullptr, nullptr, G + l.w_off, F, 0};
+    VAENPVC_TIMED("dec0_wgrad", s, launch_convwgrad<WD0>(a, WGS, s));
+    if (!dec_bias_done[0]) generic::bias_grad(w.d_dec_a[0], G + l.b_off, F, l.cout, l.hout, s);
+    VAENPVC_TIMED("dec0_dgrad", s, launch_convgemm<GD0>(conv_args(w.d_dec_a[0], nullptr, nullptr, nullptr, w.scratch + Pk::gd0,
+                                                                  nullptr, w.d_h, F), 1, s));
+  } else generic::bwd_dec_layer(m, P, F, w, G, s, 0);
+
+  // ---- merge + embedding
+  if (bwd_on(6)) {
+    TnArgs a = tn_args(w.z, 128, w.d_h, 1539, 128, 1539, F, G + m.wz_off, 1539);
+    VAENPVC_TIMED("merge_wgrad", s, launch_tngemm(a, false, kchunks_for(F, 13), s));
+    TnArgs b = tn_args(P + m.emb_off, 128, w.d_h, 1539, 128, 1539, F, G + m.wy_off, 1539);
+    b.xidx = y;
+    launch_tngemm(b, false, kchunks_for(F, 13), s);
+    int ch = cmax(1, cmin_(cdiv(F, 64), 128)), fc = cdiv(F, ch);
+    hipLaunchKernelGGL(k_colsum_atomic, dim3((unsigned)cdiv(1539, 256), (unsigned)cdiv(F, fc)), dim3(256), 0, s, w.d_h, 1539, 1539,
+                       F, fc, G + m.bz_off, G + m.by_off, G + m.bm_off);
+    DenseArgs d{w.d_h, nullptr, nullptr, nullptr, nullptr, nullptr, w.scratch + Pk::merge_b, nullptr,
+                w.d_z, w.d_e, 128, 128, F};
+    VAENPVC_TIMED("merge_dgrad", s, launch_densegemm<MergeB>(d, s));
+    int ech = cmax(1, cmin_(cdiv(F, 32), 256)), efc = cdiv(F, ech);
+    hipLaunchKernelGGL(k_emb_grad_fast, dim3((unsigned)cdiv(F, efc)), dim3(256), (size_t)m.ny * m.z * 4, s, w.d_e, 128, 0, y,
+                       G + m.emb_off, F, efc, m.z, m.ny);
+  } else generic::bwd_merge(m, P, y, F, w, G, s);
+
+  generic::bwd_reparam(m, eps, F, w, s);
+
+  // ---- heads
+  if (bwd_on(5)) {
+    const ConvL& l4 = m.enc[4];
+    TnArgs a = tn_args(w.enc_a[4], 768, w.d_z_mu, 128, 768, 128, F, G + m.wmu_off, 128);
+    a.st = w.enc_st[4];
+    a.gamma = P + l4.gamma_off;
+    a.beta = P + l4.beta_off;
+    a.lndiv = 3;
+    VAENPVC_TIMED("heads_wgrad", s, launch_tngemm(a, false, kchunks_for(F, 6), s));
+    a.Y = w.d_z_lv;
+    a.C = G + m.wlv_off;
+    launch_tngemm(a, false, kchunks_for(F, 6), s);
+    int ch = cmax(1, cmin_(cdiv(F, 64), 256)), fc = cdiv(F, ch);
+    hipLaunchKernelGGL(k_colsum_atomic, dim3(1, (unsigned)cdiv(F, fc)), dim3(256), 0, s, w.d_z_mu, 128, 128, F, fc,
+                       G + m.bmu_off, nullptr, nullptr);
+    hipLaunchKernelGGL(k_colsum_atomic, dim3(1, (unsigned)cdiv(F, fc)), dim3(256), 0, s, w.d_z_lv, 128, 128, F, fc,
+                       G + m.blv_off, nullptr, nullptr);
+    DenseArgs d{w.d_z_mu, w.d_z_lv, nullptr, nullptr, nullptr, nullptr, w.scratch + Pk::heads_b, nullptr,
+                w.dy_tmp, nullptr, 0, 768, F};
+    VAENPVC_TIMED("heads_dgrad", s, launch_densegemm<HeadsB>(d, s));
+    launch_ln_bwd<LnbCfg<256, 3, 8>>(w.dy_tmp, w.enc_a[4], w.enc_st[4], P + l4.gamma_off, P + l4.beta_off, w.d_enc_a[4],
+                                     G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, F, WGS, s);
+    enc_bias_done[4] = true;
+  } else generic::bwd_heads(m, P, F, w, G, s);
+
+  // ---- encoder convs
+  auto wg_enc = [&](int i) {
+    const ConvL &l = m.enc[i], &pl = m.enc[i - 1];
+    return WgArgs{w.enc_a[i - 1], w.enc_st[i - 1], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[i], nullptr, nullptr, nullptr,
+                  G + l.w_off, F, 0};
+  };
+  if (bwd_on(4)) {
+    const ConvL &l = m.enc[4], &pl = m.enc[3];
+    VAENPVC_TIMED("enc4_wgrad", s, launch_convwgrad<WE4>(wg_enc(4), WGS, s));
+    if (!enc_bias_done[4]) generic::bias_grad(w.d_enc_a[4], G + l.b_off, F, l.cout, l.hout, s);
+    VAENPVC_TIMED("enc4_dgrad", s, launch_convgemm<GE4>(conv_args(w.d_enc_a[4], nullptr, nullptr, nullptr, w.scratch + Pk::ge4,
+                                                                  nullptr, w.dy_tmp, F), 1, s));
+    launch_ln_bwd<LnbCfg<128, 7, 8>>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[3],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, WGS, s);
+    enc_bias_done[3] = true;
+  } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 4);
+  if (bwd_on(3)) {
+    const ConvL &l = m.enc[3], &pl = m.enc[2];
+    VAENPVC_TIMED("enc3_wgrad", s, launch_convwgrad<WE3>(wg_enc(3), WGS, s));
+    if (!enc_bias_done[3]) generic::bias_grad(w.d_enc_a[3], G + l.b_off, F, l.cout, l.hout, s);
+    VAENPVC_TIMED("enc3_dgrad", s, launch_convgemm<GE3>(conv_args(w.d_enc_a[3], nullptr, nullptr, nullptr, w.scratch + Pk::ge3,
+                                                                  nullptr, w.dy_tmp, F), 1, s));
+    launch_ln_bwd<LnbCfg<64, 19, 6>>(w.dy_tmp, w.enc_a[2], w.enc_st[2], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[2],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, WGS, s);
+    enc_bias_done[2] = true;
+  } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 3);
+  if (bwd_on(2)) {
+    const ConvL &l = m.enc[2], &pl = m.enc[1];
+    VAENPVC_TIMED("enc2_wgrad", s, launch_convwgrad<WE2>(wg_enc(2), WGS, s));
+    if (!enc_bias_done[2]) generic::bias_grad(w.d_enc_a[2], G + l.b_off, F, l.cout, l.hout, s);
+    VAENPVC_TIMED("enc2_dgrad", s, launch_convgemm<GE2>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
+                                                                  nullptr, w.dy_tmp, F), 1, s));
+    launch_ln_bwd<LnbCfg<32, 57, 4>>(w.dy_tmp, w.enc_a[1], w.enc_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[1],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, WGS, s);
+    enc_bias_done[1] = true;
+  } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 2);
+  if (bwd_on(1)) {
+    const ConvL &l = m.enc[1], &pl = m.enc[0];
+    VAENPVC_TIMED("enc1_wgrad", s, launch_convwgrad<WE1>(wg_enc(1), WGS, s));
+    if (!enc_bias_done[1]) generic::bias_grad(w.d_enc_a[1], G + l.b_off, F, l.cout, l.hout, s);
+    VAENPVC_TIMED("enc1_dgrad", s, launch_convgemm<GE1>(conv_args(w.d_enc_a[1], nullptr, nullptr, nullptr, w.scratch + Pk::ge1,
+                                                                  nullptr, w.dy_tmp, F), 1, s));
+    launch_ln_bwd<LnbCfg<16, 171, 2>>(w.dy_tmp, w.enc_a[0], w.enc_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[0],
+                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, WGS, s);
+    enc_bias_done[0] = true;
+  } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 1);
+  if (bwd_on(0)) {
+    const ConvL& l = m.enc[0];
+    WgArgs a{x, nullptr, nullptr, nullptr, w.d_enc_a[0], nullptr, nullptr, nullptr, G + l.w_off, F, 0};
+    VAENPVC_TIMED("enc0_wgrad", s, launch_convwgrad<WE0>(a, WGS, s));
+    if (!enc_bias_done[0]) generic::bias_grad(w.d_enc_a[0], G + l.b_off, F, l.cout, l.hout, s);
+  } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 0);
+}
+
+}  // namespace tuned
+}  // namespace vaenpvc

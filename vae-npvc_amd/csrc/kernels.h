@@ -48,6 +48,17 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
 void loss_fwd(const Model& m, const float* x, int64_t F, const Ws& w, bool want_grad, float* loss3, hipStream_t s);
 void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F,
               const Ws& w, float* G, hipStream_t s);
+// per-step entry points (the tuned path can fall back to any of them, per layer)
+void enc_layer_fwd(const Model& m, const float* P, const float* x, int64_t F, const Ws& w, hipStream_t s, int i);
+void heads_fwd(const Model& m, const float* P, int64_t F, const Ws& w, hipStream_t s);
+void merge_fwd(const Model& m, const float* P, const float* z, const int64_t* y, int64_t F, const Ws& w, hipStream_t s);
+void dec_layer_fwd(const Model& m, const float* P, int64_t F, const Ws& w, float* xh_out, hipStream_t s, int i);
+void bias_grad(const float* d, float* db, int64_t F, int C, int H, hipStream_t s);
+void bwd_dec_layer(const Model& m, const float* P, int64_t F, const Ws& w, float* G, hipStream_t s, int i);
+void bwd_merge(const Model& m, const float* P, const int64_t* y, int64_t F, const Ws& w, float* G, hipStream_t s);
+void bwd_reparam(const Model& m, const float* eps, int64_t F, const Ws& w, hipStream_t s);
+void bwd_heads(const Model& m, const float* P, int64_t F, const Ws& w, float* G, hipStream_t s);
+void bwd_enc_layer(const Model& m, const float* P, const float* x, int64_t F, const Ws& w, float* G, hipStream_t s, int i);
 }  // namespace generic
 
 // ---- elementwise / optimiser kernels (misc_kernels.hip) -------------------------
@@ -60,6 +71,10 @@ void launch_unpack(const float* rec, int64_t F, int rec_floats, int H, const flo
 
 // ---- tuned gfx950 kernels for the VCC2016 geometry (gfx950_*.hip) ----------------
 namespace tuned {
+// step masks: bit set = use the tuned kernel for that step, clear = generic kernel.
+//   forward  bits: 0..4 encoder conv i | 5 heads | 6 merge | 7..10 decoder layer i
+//   backward bits: 0..4 encoder conv i | 5 heads | 6 merge | 7..10 decoder layer i
+void set_masks(unsigned fwd, unsigned bwd);
 bool available();
 void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F, const Ws& w, hipStream_t s);
 void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* y, int64_t F, const Ws& w,

@@ -144,6 +144,8 @@ std::vector<Region> workspace_layout(const Model& m, int64_t F, int mode, int64_
   add("xh", F * m.H);
   add("kl_f", F);
   add("nll_f", F);
+  // packed / transposed weight copies of the tuned kernels (F-independent)
+  add("scratch", 2 * m.n_params + 65536);
   if (mode == VAENPVC_MODE_TRAIN) {
     add("d_xh", F * m.H);
     for (int i = m.n_dec - 2; i >= 0; --i) add("d_dec_a" + std::to_string(i), F * m.dec[i].cout * m.dec[i].hout);
@@ -154,8 +156,6 @@ std::vector<Region> workspace_layout(const Model& m, int64_t F, int mode, int64_
     add("d_z_lv", F * m.z);
     for (int i = m.n_enc - 1; i >= 0; --i) add("d_enc_a" + std::to_string(i), F * m.enc[i].cout * m.enc[i].hout);
     add("dy_tmp", F * maxact);
-    // scratch for split reductions of the tuned weight-gradient kernels
-    add("scratch", 4 * m.n_params + 65536);
   }
   *total_floats = off;
   return r;

@@ -52,6 +52,7 @@ SIGNATURES = {
     'vaenpvc_adam_step': (C.c_int, [_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _P]),
     'vaenpvc_tanhize_fwd': (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P]),
     'vaenpvc_tanhize_bwd': (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P]),
+    'vaenpvc_set_tuned_masks': (C.c_int, [C.c_uint32, C.c_uint32]),
     'vaenpvc_timer_select': (C.c_int, [C.c_char_p]),
     'vaenpvc_timer_read': (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64)]),
     'vaenpvc_unpack_records': (C.c_int, [_P, _I64, _I32, _I32, _P, _P, _P, _P, _P]),
