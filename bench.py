@@ -56,7 +56,7 @@ def cpu_baseline(arch, seconds):
     import torch
     from oracle import convvae_oracle as O
     F = 256
-    threads = os.cpu_count() or 1
+    threads = int(os.environ.get('VAENPVC_CPU_THREADS', min(os.cpu_count() or 1, 32)))   # more threads oversubscribe this small model
     torch.set_num_threads(threads)
     P = O.torch_params(O.init_params(arch, 0), torch.float32, requires_grad=True)
     x, y, eps = O.make_inputs(arch, F, 0)

@@ -82,28 +82,32 @@ __device__ __forceinline__ void conv_stage(const ConvArgs& a, float* tile, int f
   constexpr int PER = C::KC * C::HIN;
   const int nfr = min(C::TF, a.F - f0);
   const int total = nfr * PER;
-  for (int e = tid; e < total; e += 256) {
-    int f = e / PER;
-    int rem = e - f * PER;
-    int k = rem / C::HIN;
-    int i = rem - k * C::HIN;
-    float v;
-    if constexpr (C::INKIND == IN_CONCAT2) {
-      constexpr int HALF = C::KC / 2;
+  if constexpr (C::INKIND == IN_CONCAT2) {
+    constexpr int HALF = C::KC / 2;
+    for (int e = tid; e < total; e += 256) {
+      int f = e / PER, k = e - f * PER;
+      float v;
       if (k < HALF) {
         v = a.in[(int64_t)(f0 + f) * HALF + k];
       } else {
         int64_t g = a.idx ? a.idx[f0 + f] : (int64_t)(f0 + f);
         v = a.in2[g * HALF + (k - HALF)];
       }
-    } else {
-      v = a.in[(int64_t)f0 * PER + e];
+      tile[f * C::FSTR + k * C::CSTR + C::HLO] = v;
+    }
+  } else {
+    auto put = [&](int e, float v) {
+      int f = e / PER;
+      int rem = e - f * PER;
+      int k = rem / C::HIN;
+      int i = rem - k * C::HIN;
       if constexpr (C::INKIND == IN_LN) {
         int ch = k / C::LNDIV;
         v = lnact_v(v, a.st[2 * (f0 + f)], a.st[2 * (f0 + f) + 1], a.gamma[ch], a.beta[ch]);
       }
-    }
-    tile[f * C::FSTR + k * C::CSTR + C::HLO + i] = v;
+      tile[f * C::FSTR + k * C::CSTR + C::HLO + i] = v;
+    };
+    stage_range<(PER % 4 == 0) ? 4 : 1, (PER % 4 == 0) ? 4 : 8>(a.in + (int64_t)f0 * PER, total, put);
   }
   __syncthreads();
 }

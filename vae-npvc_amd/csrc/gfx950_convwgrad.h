@@ -81,26 +81,50 @@ __global__ void __launch_bounds__(256) k_convwgrad(WgArgs a) {
   constexpr int XPER = C::XC * C::XH, YPER = C::NTW * 32 * C::YH;
   for (int f0 = fb; f0 < fe; f0 += C::TF) {
     __syncthreads();  // previous sub-tile consumed (first pass: zero fill done)
-    for (int e = tid; e < C::TF * XPER; e += 256) {
-      int f = e / XPER, rem = e - f * XPER;
-      int xc = rem / C::XH, i = rem - xc * C::XH;
-      float v = 0.f;
-      if (f0 + f < fe) {
-        v = a.X[(int64_t)(f0 + f) * XPER + rem];
+    const int nfr = min(C::TF, fe - f0);
+    {  // X tile: nfr whole frames are one contiguous HBM range
+      auto putx = [&](int e, float v) {
+        int f = e / XPER, rem = e - f * XPER;
+        int xc = rem / C::XH, i = rem - xc * C::XH;
         if constexpr (C::XLN) v = lnact_v(v, a.xst[2 * (f0 + f)], a.xst[2 * (f0 + f) + 1], a.xg[xc], a.xb[xc]);
-      }
-      tX[f * C::FSTRX + xc * C::CSTRX + C::HLO + i] = v;
+        tX[f * C::FSTRX + xc * C::CSTRX + C::HLO + i] = v;
+      };
+      stage_range<(XPER % 4 == 0) ? 4 : 1, 4>(a.X + (int64_t)f0 * XPER, nfr * XPER, putx);
+      if (nfr < C::TF)  // tail of the chunk: frames beyond it must read as zero
+        for (int e = nfr * XPER + tid; e < C::TF * XPER; e += 256) {
+          int f = e / XPER, rem = e - f * XPER;
+          int xc = rem / C::XH, i = rem - xc * C::XH;
+          tX[f * C::FSTRX + xc * C::CSTRX + C::HLO + i] = 0.f;
+        }
     }
-    for (int e = tid; e < C::TF * YPER; e += 256) {
-      int f = e / YPER, rem = e - f * YPER;
-      int nl = rem / C::YH, r = rem - nl * C::YH;
-      int n = nc0 + nl;
-      float v = 0.f;
-      if (f0 + f < fe && n < C::YC) {
-        v = a.Y[((int64_t)(f0 + f) * C::YC + n) * C::YH + r];
-        if constexpr (C::YLN) v = lnact_v(v, a.yst[2 * (f0 + f)], a.yst[2 * (f0 + f) + 1], a.yg[n], a.yb[n]);
+    {  // Y tile: per frame the valid channels of this workgroup are one contiguous run
+      constexpr int YFR = C::YC * C::YH;              // floats per frame of Y
+      const int ych = min(C::NTW * 32, C::YC - nc0);  // valid channels
+      const int yper = ych * C::YH;
+      const int ytot = C::TF * yper;
+      constexpr int BT = 8;
+      for (int e0 = tid; e0 < ytot; e0 += 256 * BT) {
+        float v[BT];
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+          int e = e0 + 256 * b;
+          int f = e / yper, rem = e - f * yper;
+          v[b] = (e < ytot && f < nfr) ? a.Y[(int64_t)(f0 + f) * YFR + (int64_t)nc0 * C::YH + rem] : 0.f;
+        }
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+          int e = e0 + 256 * b;
+          if (e < ytot) {
+            int f = e / yper, rem = e - f * yper;
+            int nl = rem / C::YH, r = rem - nl * C::YH;
+            float x = v[b];
+            if constexpr (C::YLN) {
+              if (f < nfr) x = lnact_v(x, a.yst[2 * (f0 + f)], a.yst[2 * (f0 + f) + 1], a.yg[nc0 + nl], a.yb[nc0 + nl]);
+            }
+            tY[f * C::FSTRY + nl * C::CSTRY + r] = x;
+          }
+        }
       }
-      tY[f * C::FSTRY + nl * C::CSTRY + r] = v;
     }
     __syncthreads();
     constexpr int HP = C::TF / 2, KS = C::YH * HP;

@@ -38,7 +38,7 @@ struct DenseCfg {
   static constexpr int ASTR = KCH + 1;     // odd -> conflict-free gathers (lane <-> frame)
   static constexpr int NSPLIT = cdiv(NT, 4 * NBW);
   static constexpr int LDS_BYTES = 32 * ASTR * 4;
-  static_assert(KCH % 16 == 0, "chunk = multiple of the prefetch depth");
+  static_assert(KCH % 64 == 0, "chunk = multiple of the prefetch depth and of the staging batch");
 };
 
 template <class C>
@@ -55,28 +55,43 @@ __global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
   for (int ch = 0; ch < C::NCHUNK; ++ch) {
     const int kc0 = ch * C::KCH;
     __syncthreads();
-    for (int e = tid; e < 32 * C::KCH; e += 256) {
-      int fl = e / C::KCH, kk = e - fl * C::KCH;
-      int k = kc0 + kk, f = f0 + fl;
-      float v = 0.f;
-      if (k < C::K && f < a.F) {
-        if constexpr (C::INKIND == IN_CONCAT2) {
-          constexpr int HALF = C::K / 2;
-          if (k < HALF) {
-            v = a.in[(int64_t)f * HALF + k];
+    constexpr int BT = 8;
+    for (int e0 = tid; e0 < 32 * C::KCH; e0 += 256 * BT) {
+      float v[BT];
+#pragma unroll
+      for (int b = 0; b < BT; ++b) {
+        int e = e0 + 256 * b;
+        int fl = e / C::KCH, kk = e - fl * C::KCH;
+        int k = kc0 + kk, f = f0 + fl;
+        v[b] = 0.f;
+        if (k < C::K && f < a.F) {
+          if constexpr (C::INKIND == IN_CONCAT2) {
+            constexpr int HALF = C::K / 2;
+            if (k < HALF) {
+              v[b] = a.in[(int64_t)f * HALF + k];
+            } else {
+              int64_t g = a.idx ? a.idx[f] : (int64_t)f;
+              v[b] = a.in2[g * HALF + (k - HALF)];
+            }
           } else {
-            int64_t g = a.idx ? a.idx[f] : (int64_t)f;
-            v = a.in2[g * HALF + (k - HALF)];
-          }
-        } else {
-          v = a.in[(int64_t)f * C::K + k];
-          if constexpr (C::INKIND == IN_LN) {
-            int c = k / C::LNDIV;
-            v = lnact_v(v, a.st[2 * f], a.st[2 * f + 1], a.gamma[c], a.beta[c]);
+            v[b] = a.in[(int64_t)f * C::K + k];
           }
         }
       }
-      tA[fl * C::ASTR + kk] = v;
+#pragma unroll
+      for (int b = 0; b < BT; ++b) {
+        int e = e0 + 256 * b;
+        int fl = e / C::KCH, kk = e - fl * C::KCH;
+        int k = kc0 + kk, f = f0 + fl;
+        float x = v[b];
+        if constexpr (C::INKIND == IN_LN) {
+          if (k < C::K && f < a.F) {
+            int c = k / C::LNDIV;
+            x = lnact_v(x, a.st[2 * f], a.st[2 * f + 1], a.gamma[c], a.beta[c]);
+          }
+        }
+        tA[fl * C::ASTR + kk] = x;
+      }
     }
     __syncthreads();
     if (nt0 < C::NT) {  // wave-uniform

@@ -42,20 +42,78 @@ __global__ void __launch_bounds__(256) k_ln_stats_fast(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------- encoder layer 0
+// conv k=7 s=3 pad=2, 1 -> 16 channels, 513 -> 171 bins (util/layers.py:56-64) fused with its
+// LayerNorm statistics: K = 7 is far too small for MFMA (0.4 % of the MACs), the layer is
+// HBM-bound (reads 2 KB, writes 10.9 KB per frame).  One workgroup walks a chunk of frames;
+// the input row sits in LDS, every thread produces the outputs idx = tid + 256k (coalesced
+// stores) and the whole frame is reduced in-block for (mean, rstd).
+__global__ void __launch_bounds__(256) k_enc0_fwd(const float* __restrict__ x, const float* __restrict__ W,
+                                                  const float* __restrict__ bias, float* __restrict__ a,
+                                                  float* __restrict__ st, int F, int fchunk) {
+  constexpr int H = 513, HO = 171, CO = 16, N = CO * HO, EPT = cdiv(N, 256);
+  __shared__ float xs[H + 8];
+  __shared__ float wl[7 * CO + CO];
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 7 * CO; i += 256) wl[i] = W[i];
+  if (tid < CO) wl[7 * CO + tid] = bias[tid];
+  if (tid < 8) xs[tid < 2 ? tid : H + tid] = 0.f;  // zero halos: xs[0..1], xs[H+2..H+7]
+  const int fb = blockIdx.x * fchunk, fe = min(F, fb + fchunk);
+  for (int f = fb; f < fe; ++f) {
+    __syncthreads();
+    for (int i = tid; i < H; i += 256) xs[2 + i] = x[(int64_t)f * H + i];
+    __syncthreads();
+    float v[EPT];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      int idx = tid + 256 * k;
+      v[k] = 0.f;
+      if (idx < N) {
+        int o = idx / HO, j = idx - o * HO;
+        float acc = wl[7 * CO + o];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) acc += wl[t * CO + o] * xs[3 * j + t];
+        v[k] = acc;
+        a[(int64_t)f * N + idx] = acc;
+        s += acc;
+      }
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[0][wave] = s;
+    __syncthreads();
+    const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * (1.0f / N);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k)
+      if (tid + 256 * k < N) q += (v[k] - mean) * (v[k] - mean);
+    q = wave_sum(q);
+    if (lane == 0) red[1][wave] = q;
+    __syncthreads();
+    if (tid == 0) {
+      float var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * (1.0f / N);
+      st[2 * f] = mean;
+      st[2 * f + 1] = 1.0f / sqrtf(var + LN_EPS);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- LayerNorm + lrelu backward
 // autodiff of util/layers.py:32-44,149 for one layer with C channels x H positions:
 //   n = gamma*xhat+beta ; dn = dy*(n>=0 ? 1 : leak) ; dxh = dn*gamma
 //   da = rstd*(dxh - mean(dxh) - xhat*mean(dxh*xhat))
 //   d gamma[c] += sum dn*xhat ; d beta[c] += sum dn ; d bias[c] += sum da
-// A workgroup walks `fchunk` frames in sub-tiles of TF frames held in LDS (dn, xhat), so
-// dy and a are read once and da written once; the per-channel sums are carried in registers
-// per element across the whole chunk and reduced once at the end (3*C global atomics).
-template <int C_, int H_, int TF_>
+// HBM-bound: dy and a are read ONCE, da written ONCE.  A workgroup walks `fchunk` frames; each
+// thread owns the element slots i = tid + 256k of every frame (coalesced rows), keeps dn and
+// xhat of the current frame in registers across the one block reduction per frame, and carries
+// the three per-element sums in registers over the whole chunk; they are reduced per channel
+// through LDS once at the end (3*C global atomics per workgroup).
+template <int C_, int H_>
 struct LnbCfg {
-  static constexpr int C = C_, H = H_, TF = TF_, N = C * H;
+  static constexpr int C = C_, H = H_, N = C * H;
   static constexpr int EPT = cdiv(N, 256);
-  static constexpr int LDS_FLOATS = cmax(2 * TF * N, 3 * N) + 4 * TF;
-  static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+  static constexpr int LDS_BYTES = 3 * N * 4;
 };
 
 template <class L>
@@ -65,61 +123,63 @@ __global__ void __launch_bounds__(256) k_ln_bwd_fused(const float* __restrict__ 
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                       float* __restrict__ dbias, int F, int fchunk) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int N = L::N, TF = L::TF, H = L::H, C = L::C, EPT = L::EPT;
-  float* dnL = lds;
-  float* xhL = lds + TF * N;
-  float* sS = lds + cmax(2 * TF * N, 3 * N);  // [TF][4]: mean(dxh), mean(dxh*xhat), rstd
+  __shared__ float red[2][4][2];
+  constexpr int N = L::N, H = L::H, C = L::C, EPT = L::EPT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fb = blockIdx.x * fchunk, fe = min(F, fb + fchunk);
-  float su[EPT], sw[EPT], sd[EPT];
+  float g[EPT], bt[EPT], su[EPT], sw[EPT], sd[EPT];
 #pragma unroll
-  for (int k = 0; k < EPT; ++k) su[k] = sw[k] = sd[k] = 0.f;
-  for (int f0 = fb; f0 < fe; f0 += TF) {
-    __syncthreads();
-    const int nfr = min(TF, fe - f0);
-    for (int e = tid; e < nfr * N; e += 256) {
-      int f = e / N, i = e - f * N;
-      int c = i / H;
-      float mean = st[2 * (f0 + f)], rstd = st[2 * (f0 + f) + 1];
-      float xh = (a[(int64_t)f0 * N + e] - mean) * rstd;
-      float nn = xh * gamma[c] + beta[c];
-      dnL[e] = dy[(int64_t)f0 * N + e] * (nn >= 0.f ? 1.0f : LEAK);
-      xhL[e] = xh;
-    }
-    __syncthreads();
-    for (int f = wave; f < nfr; f += 4) {
-      float s1 = 0.f, s2 = 0.f;
-      for (int i = lane; i < N; i += 64) {
-        float dx = dnL[f * N + i] * gamma[i / H];
-        s1 += dx;
-        s2 += dx * xhL[f * N + i];
-      }
-      s1 = wave_sum(s1);
-      s2 = wave_sum(s2);
-      if (lane == 0) {
-        sS[4 * f] = s1 / N;
-        sS[4 * f + 1] = s2 / N;
-        sS[4 * f + 2] = st[2 * (f0 + f) + 1];
-      }
-    }
-    __syncthreads();
+  for (int k = 0; k < EPT; ++k) {
+    int i = tid + 256 * k;
+    int c = i < N ? i / H : 0;
+    g[k] = gamma[c];
+    bt[k] = beta[c];
+    su[k] = sw[k] = sd[k] = 0.f;
+  }
+  for (int f = fb; f < fe; ++f) {
+    const float mean = st[2 * f], rstd = st[2 * f + 1];
+    const float* pd = dy + (int64_t)f * N;
+    const float* pa = a + (int64_t)f * N;
+    float dn[EPT], xh[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       int i = tid + 256 * k;
+      dn[k] = i < N ? pd[i] : 0.f;
+      xh[k] = i < N ? pa[i] : mean;
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      xh[k] = (xh[k] - mean) * rstd;
+      float nn = xh[k] * g[k] + bt[k];
+      dn[k] = dn[k] * (nn >= 0.f ? 1.0f : LEAK);
+      float dx = dn[k] * g[k];
+      s1 += dx;
+      s2 += dx * xh[k];
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int par = f & 1;
+    if (lane == 0) {
+      red[par][wave][0] = s1;
+      red[par][wave][1] = s2;
+    }
+    __syncthreads();
+    s1 = ((red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0])) * (1.0f / N);
+    s2 = ((red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1])) * (1.0f / N);
+    float* po = da + (int64_t)f * N;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      int i = tid + 256 * k;
+      float d = rstd * (dn[k] * g[k] - s1 - xh[k] * s2);
       if (i < N) {
-        float g = gamma[i / H];
-        for (int f = 0; f < nfr; ++f) {
-          float dn = dnL[f * N + i], xh = xhL[f * N + i];
-          float d = sS[4 * f + 2] * (dn * g - sS[4 * f] - xh * sS[4 * f + 1]);
-          da[(int64_t)(f0 + f) * N + i] = d;
-          su[k] += dn * xh;
-          sw[k] += dn;
-          sd[k] += d;
-        }
+        po[i] = d;
+        su[k] += dn[k] * xh[k];
+        sw[k] += dn[k];
+        sd[k] += d;
       }
     }
   }
-  __syncthreads();
   float* eU = lds;
   float* eW = lds + N;
   float* eD = lds + 2 * N;
@@ -174,7 +234,7 @@ inline void launch_ln_bwd(const float* dy, const float* a, const float* st, cons
                               hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES);
     once = true;
   }
-  int fchunk = rup(cmax(1, cdiv(F, target_wgs)), L::TF);
+  int fchunk = cmax(1, cdiv(F, target_wgs));
   hipLaunchKernelGGL(k_ln_bwd_fused<L>, dim3((unsigned)cdiv(F, fchunk)), dim3(256), L::LDS_BYTES, s, dy, a, st, gamma,
                      beta, da, dgamma, dbeta, dbias, F, fchunk);
 }

@@ -161,9 +161,11 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
   read_env();
   const int F = (int)F64;
   prep(m, P, w, s);
-  // e0: Cin = 1, K = 7 -- 0.4 % of the MACs, HBM-bound; generic kernel + fast statistics
+  // e0: Cin = 1, K = 7 -- 0.4 % of the MACs, HBM-bound: VALU conv fused with its LN statistics
   if (fwd_on(0)) {
-    generic::enc_layer_fwd(m, P, x, F, w, s, 0);
+    int fch = cmax(1, cdiv(F, 4096));
+    VAENPVC_TIMED("enc0_fwd", s, hipLaunchKernelGGL(k_enc0_fwd, dim3((unsigned)cdiv(F, fch)), dim3(256), 0, s, x, P + m.enc[0].w_off,
+                                                    P + m.enc[0].b_off, w.enc_a[0], w.enc_st[0], F, fch));
   } else {
     generic::enc_layer_fwd(m, P, x, F, w, s, 0);
   }
@@ -273,7 +275,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   (void)hipMemsetAsync(G, 0, (size_t)m.n_params * 4, s);
   bool dec_bias_done[4] = {false, false, false, false};
   bool enc_bias_done[5] = {false, false, false, false, false};
-  const int WGS = 1024;  // target workgroup count of the chunked reductions
+  const int WGS = 1024;   // target workgroup count of the chunked reductions
+  const int LWGS = 2048;  // ... of the HBM-bound LayerNorm backward
 
   // ---- d3: the 1025-tap layer
   if (bwd_on(10)) {
@@ -283,7 +286,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     a.gamma = P + l2.gamma_off;
     a.beta = P + l2.beta_off;
     VAENPVC_TIMED("dec3_wgrad", s, launch_tngemm(a, true, kchunks_for(F, 32 * 4), s));
-    int ech = cmax(1, cmin_(cdiv(F, 64), 32));
+    int ech = cmax(1, cmin_(cdiv(F, 64), 256));
     int efc = cdiv(F, ech);
     hipLaunchKernelGGL(k_toep_wgrad_edges, dim3((unsigned)cdiv(8200, 256), (unsigned)cdiv(F, efc)), dim3(256), 0, s, w.dec_a[2],
                        w.dec_st[2], P + l2.gamma_off, P + l2.beta_off, w.d_xh, G + m.dec[3].w_off, F, efc);
@@ -296,8 +299,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     }
     VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL(k_toep_dgrad, dim3((unsigned)cdiv(F, 32), 8), dim3(256), TD_LDS, s, w.d_xh,
                                                       w.scratch + Pk::wc, w.dy_tmp, F));
-    launch_ln_bwd<LnbCfg<8, 513, 2>>(w.dy_tmp, w.dec_a[2], w.dec_st[2], P + l2.gamma_off, P + l2.beta_off, w.d_dec_a[2],
-                                     G + l2.gamma_off, G + l2.beta_off, G + l2.b_off, F, WGS, s);
+    launch_ln_bwd<LnbCfg<8, 513>>(w.dy_tmp, w.dec_a[2], w.dec_st[2], P + l2.gamma_off, P + l2.beta_off, w.d_dec_a[2],
+                                     G + l2.gamma_off, G + l2.beta_off, G + l2.b_off, F, LWGS, s);
     dec_bias_done[2] = true;
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 3);
 
@@ -310,8 +313,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     if (!dec_bias_done[2]) generic::bias_grad(w.d_dec_a[2], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("dec2_dgrad", s, launch_convgemm<GD2>(conv_args(w.d_dec_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::gd2,
                                                                   nullptr, w.dy_tmp, F), 1, s));
-    launch_ln_bwd<LnbCfg<16, 171, 2>>(w.dy_tmp, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[1],
-                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, WGS, s);
+    launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[1],
+                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, LWGS, s);
     dec_bias_done[1] = true;
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 2);
 
@@ -324,8 +327,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     if (!dec_bias_done[1]) generic::bias_grad(w.d_dec_a[1], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("dec1_dgrad", s, launch_convgemm<GD1>(conv_args(w.d_dec_a[1], nullptr, nullptr, nullptr, P + l.w_off, nullptr,
                                                                   w.dy_tmp, F), 1, s));
-    launch_ln_bwd<LnbCfg<32, 57, 4>>(w.dy_tmp, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[0],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, WGS, s);
+    launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[0],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, LWGS, s);
     dec_bias_done[0] = true;
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 1);
 
@@ -379,8 +382,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     DenseArgs d{w.d_z_mu, w.d_z_lv, nullptr, nullptr, nullptr, nullptr, w.scratch + Pk::heads_b, nullptr,
                 w.dy_tmp, nullptr, 0, 768, F};
     VAENPVC_TIMED("heads_dgrad", s, launch_densegemm<HeadsB>(d, s));
-    launch_ln_bwd<LnbCfg<256, 3, 8>>(w.dy_tmp, w.enc_a[4], w.enc_st[4], P + l4.gamma_off, P + l4.beta_off, w.d_enc_a[4],
-                                     G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, F, WGS, s);
+    launch_ln_bwd<LnbCfg<256, 3>>(w.dy_tmp, w.enc_a[4], w.enc_st[4], P + l4.gamma_off, P + l4.beta_off, w.d_enc_a[4],
+                                     G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, F, LWGS, s);
     enc_bias_done[4] = true;
   } else generic::bwd_heads(m, P, F, w, G, s);
 
@@ -396,8 +399,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     if (!enc_bias_done[4]) generic::bias_grad(w.d_enc_a[4], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("enc4_dgrad", s, launch_convgemm<GE4>(conv_args(w.d_enc_a[4], nullptr, nullptr, nullptr, w.scratch + Pk::ge4,
                                                                   nullptr, w.dy_tmp, F), 1, s));
-    launch_ln_bwd<LnbCfg<128, 7, 8>>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[3],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, WGS, s);
+    launch_ln_bwd<LnbCfg<128, 7>>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[3],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, LWGS, s);
     enc_bias_done[3] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 4);
   if (bwd_on(3)) {
@@ -406,8 +409,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     if (!enc_bias_done[3]) generic::bias_grad(w.d_enc_a[3], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("enc3_dgrad", s, launch_convgemm<GE3>(conv_args(w.d_enc_a[3], nullptr, nullptr, nullptr, w.scratch + Pk::ge3,
                                                                   nullptr, w.dy_tmp, F), 1, s));
-    launch_ln_bwd<LnbCfg<64, 19, 6>>(w.dy_tmp, w.enc_a[2], w.enc_st[2], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[2],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, WGS, s);
+    launch_ln_bwd<LnbCfg<64, 19>>(w.dy_tmp, w.enc_a[2], w.enc_st[2], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[2],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, LWGS, s);
     enc_bias_done[2] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 3);
   if (bwd_on(2)) {
@@ -416,8 +419,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     if (!enc_bias_done[2]) generic::bias_grad(w.d_enc_a[2], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("enc2_dgrad", s, launch_convgemm<GE2>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
                                                                   nullptr, w.dy_tmp, F), 1, s));
-    launch_ln_bwd<LnbCfg<32, 57, 4>>(w.dy_tmp, w.enc_a[1], w.enc_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[1],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, WGS, s);
+    launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.enc_a[1], w.enc_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[1],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, LWGS, s);
     enc_bias_done[1] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 2);
   if (bwd_on(1)) {
@@ -426,8 +429,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     if (!enc_bias_done[1]) generic::bias_grad(w.d_enc_a[1], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("enc1_dgrad", s, launch_convgemm<GE1>(conv_args(w.d_enc_a[1], nullptr, nullptr, nullptr, w.scratch + Pk::ge1,
                                                                   nullptr, w.dy_tmp, F), 1, s));
-    launch_ln_bwd<LnbCfg<16, 171, 2>>(w.dy_tmp, w.enc_a[0], w.enc_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[0],
-                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, WGS, s);
+    launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.enc_a[0], w.enc_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[0],
+                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, LWGS, s);
     enc_bias_done[0] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 1);
   if (bwd_on(0)) {

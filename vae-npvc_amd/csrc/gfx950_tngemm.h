@@ -67,35 +67,61 @@ __global__ void __launch_bounds__(256) k_tngemm(TnArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
 
+  // operand loads run one chunk (U k-steps = 2U frames) ahead of the MFMAs
   constexpr int U = 4;
-  for (int f = fb; f < fe; f += 2 * U) {
-    float xa[U][2], yb[U][2];
+  float xr[U][2], yr[U][2], mr[U], rr[U];
+  float xn[U][2], yn[U][2], mn[U], rn[U];
+  auto load_chunk = [&](int f, float (&x)[U][2], float (&y)[U][2], float (&mm)[U], float (&rs)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int ff = f + 2 * u + lh;
-      bool fok = ff < fe;
-      int fc = fok ? ff : fb;
-      int64_t xr = a.xidx ? a.xidx[fc] : (int64_t)fc;
-      float mean = 0.f, rstd = 1.f;
+      int fc = ff < fe ? ff : fb;
+      int64_t xr_ = a.xidx ? a.xidx[fc] : (int64_t)fc;
+      mm[u] = 0.f;
+      rs[u] = 1.f;
       if (a.st) {
-        mean = a.st[2 * fc];
-        rstd = a.st[2 * fc + 1];
+        mm[u] = a.st[2 * fc];
+        rs[u] = a.st[2 * fc + 1];
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        float v = a.X[xr * a.ldx + xoff[i]];
-        if (a.st) v = lnact_v(v, mean, rstd, g[i], b[i]);
-        xa[u][i] = (fok && mok[i]) ? v : 0.f;
-        float w = a.Y[(int64_t)fc * a.ldy + noff[i]];
-        yb[u][i] = (fok && nok[i]) ? w : 0.f;
+        x[u][i] = a.X[xr_ * a.ldx + xoff[i]];
+        y[u][i] = a.Y[(int64_t)fc * a.ldy + noff[i]];
       }
     }
+  };
+  load_chunk(fb, xr, yr, mr, rr);
+  for (int f = fb; f < fe; f += 2 * U) {
+    const bool more = f + 2 * U < fe;
+    if (more) load_chunk(f + 2 * U, xn, yn, mn, rn);
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u) {
+      const bool fok = f + 2 * u + lh < fe;
+      float xa[2], yb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float v = xr[u][i];
+        if (a.st) v = lnact_v(v, mr[u], rr[u], g[i], b[i]);
+        xa[i] = (fok && mok[i]) ? v : 0.f;
+        yb[i] = (fok && nok[i]) ? yr[u][i] : 0.f;
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(xa[u][i], yb[u][j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(xa[i], yb[j], acc[i][j]);
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        mr[u] = mn[u];
+        rr[u] = rn[u];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          xr[u][i] = xn[u][i];
+          yr[u][i] = yn[u][i];
+        }
+      }
+    }
   }
 
   if constexpr (!TOEP) {
@@ -161,8 +187,20 @@ __global__ void __launch_bounds__(256) k_toep_wgrad_edges(const float* __restric
   const float g = gamma[c], b = beta[c];
   int fb = blockIdx.y * fchunk, fe = min(F, fb + fchunk);
   float s = 0.f;
-  for (int f = fb; f < fe; ++f)
-    s += lnact_v(a2[(int64_t)f * 4104 + c * 513 + j], st[2 * f], st[2 * f + 1], g, b) * dxh[(int64_t)f * 513 + q];
+  for (int f = fb; f < fe; f += 4) {
+    float x[4], d[4], m4[4], r4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int ff = f + u < fe ? f + u : fb;
+      x[u] = a2[(int64_t)ff * 4104 + c * 513 + j];
+      d[u] = dxh[(int64_t)ff * 513 + q];
+      m4[u] = st[2 * ff];
+      r4[u] = st[2 * ff + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (f + u < fe) s += lnact_v(x[u], m4[u], r4[u], g, b) * d[u];
+  }
   atomicAdd(dW + idx, s);
 }
 

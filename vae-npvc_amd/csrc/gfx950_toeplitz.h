@@ -44,12 +44,23 @@ __global__ void __launch_bounds__(256) k_toep_fwd(const float* __restrict__ a2, 
     const float g = gamma[c], b = beta[c];
     for (int jc0 = 0; jc0 < 2 * TF_JC; jc0 += TF_JC) {
       __syncthreads();  // previous chunk fully consumed (also covers the tW fill)
-      for (int e = tid; e < 32 * TF_JC; e += 256) {
-        int fl = e / TF_JC, jj = e - fl * TF_JC;
-        int j = jc0 + jj, f = f0 + fl;
-        float v = 0.f;
-        if (j < TOEP_H && f < F) v = lnact_v(a2[(int64_t)f * (TOEP_C * TOEP_H) + c * TOEP_H + j], st[2 * f], st[2 * f + 1], g, b);
-        tA[fl * TF_ASTR + jj] = v;
+      constexpr int BT = 8;
+      for (int e0 = tid; e0 < 32 * TF_JC; e0 += 256 * BT) {
+        float v[BT];
+#pragma unroll
+        for (int bb = 0; bb < BT; ++bb) {
+          int e = e0 + 256 * bb;
+          int fl = e / TF_JC, jj = e - fl * TF_JC;
+          int j = jc0 + jj, f = f0 + fl;
+          v[bb] = (e < 32 * TF_JC && j < TOEP_H && f < F) ? a2[(int64_t)f * (TOEP_C * TOEP_H) + c * TOEP_H + j] : 0.f;
+        }
+#pragma unroll
+        for (int bb = 0; bb < BT; ++bb) {
+          int e = e0 + 256 * bb;
+          int fl = e / TF_JC, jj = e - fl * TF_JC;
+          int j = jc0 + jj, f = f0 + fl;
+          if (e < 32 * TF_JC) tA[fl * TF_ASTR + jj] = (j < TOEP_H && f < F) ? lnact_v(v[bb], st[2 * f], st[2 * f + 1], g, b) : 0.f;
+        }
       }
       __syncthreads();
       const float* ap = tA + l31 * TF_ASTR + lh;
@@ -106,11 +117,22 @@ __global__ void __launch_bounds__(256) k_toep_dgrad(const float* __restrict__ dx
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int f0 = blockIdx.x * 32, c = blockIdx.y;
   for (int i = tid; i < WROW; i += 256) tW[i] = Wc[c * WROW + i];
-  for (int e = tid; e < 32 * TD_ASTR; e += 256) {
-    int fl = e / TD_ASTR, p = e - fl * TD_ASTR;
-    float v = 0.f;
-    if (p < TOEP_H && f0 + fl < F) v = dxh[(int64_t)(f0 + fl) * TOEP_H + p];
-    tA[e] = v;
+  {
+    constexpr int BT = 8;
+    for (int e0 = tid; e0 < 32 * TD_ASTR; e0 += 256 * BT) {
+      float v[BT];
+#pragma unroll
+      for (int bb = 0; bb < BT; ++bb) {
+        int e = e0 + 256 * bb;
+        int fl = e / TD_ASTR, p = e - fl * TD_ASTR;
+        v[bb] = (e < 32 * TD_ASTR && p < TOEP_H && f0 + fl < F) ? dxh[(int64_t)(f0 + fl) * TOEP_H + p] : 0.f;
+      }
+#pragma unroll
+      for (int bb = 0; bb < BT; ++bb) {
+        int e = e0 + 256 * bb;
+        if (e < 32 * TD_ASTR) tA[e] = v[bb];
+      }
+    }
   }
   __syncthreads();
   f32x16 acc[4];

@@ -21,7 +21,12 @@ class VAETrainer(object):
         self.dirs = dirs
         self.opt = self._optimize()
         os.makedirs(dirs['logdir'], exist_ok=True)
-        logging.basicConfig(level=logging.INFO, filename=os.path.join(dirs['logdir'], 'training.log'))
+        # trainer/gan.py:20-23 uses logging.basicConfig(filename=...); a dedicated handler does the
+        # same job but also works when the root logger is already configured by the host program
+        self.log = logging.getLogger('vaenpvc.train.%x' % id(self))
+        self.log.setLevel(logging.INFO)
+        self.log.propagate = False
+        self.log.addHandler(logging.FileHandler(os.path.join(dirs['logdir'], 'training.log')))
 
     def _optimize(self):                                  # trainer/vae.py:10-28
         t = self.arch['training']
@@ -43,7 +48,7 @@ class VAETrainer(object):
         msg = self._status_message(st.step_count, float(l3[2]), float(l3[1]))
         if st.rank == 0:
             print('\r{}'.format(msg), end='', flush=True)
-            logging.info(msg)
+            self.log.info(msg)
         return msg
 
     def save(self, step=None):
