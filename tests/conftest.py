@@ -3,6 +3,9 @@ import os
 import sys
 
 import pytest
+import torch
+
+torch.set_num_threads(min(8, os.cpu_count() or 1))
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, 'vae-npvc_amd')

@@ -49,22 +49,22 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Cooperative, latency-tolerant copy of `total` contiguous floats HBM -> (functor): every
 // thread first issues BATCH independent 16-byte (VEC = 4, base 16-byte aligned, total % 4 == 0)
 // or 4-byte loads, then hands the values to put(element_index, value).
-template <int VEC, int BATCH, class Put>
+template <int VEC, int BATCH, int NTHR = 256, class Put>
 __device__ __forceinline__ void stage_range(const float* __restrict__ src, int total, Put&& put) {
   const int tid = threadIdx.x;
   if constexpr (VEC == 4) {
     const float4* s4 = reinterpret_cast<const float4*>(src);
     const int n4 = total >> 2;
-    for (int i0 = tid; i0 < n4; i0 += 256 * BATCH) {
+    for (int i0 = tid; i0 < n4; i0 += NTHR * BATCH) {
       float4 v[BATCH];
 #pragma unroll
       for (int b = 0; b < BATCH; ++b) {
-        int i = i0 + 256 * b;
+        int i = i0 + NTHR * b;
         v[b] = i < n4 ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int b = 0; b < BATCH; ++b) {
-        int i = i0 + 256 * b;
+        int i = i0 + NTHR * b;
         if (i < n4) {
           put(4 * i, v[b].x);
           put(4 * i + 1, v[b].y);
@@ -74,16 +74,16 @@ __device__ __forceinline__ void stage_range(const float* __restrict__ src, int t
       }
     }
   } else {
-    for (int i0 = tid; i0 < total; i0 += 256 * BATCH) {
+    for (int i0 = tid; i0 < total; i0 += NTHR * BATCH) {
       float v[BATCH];
 #pragma unroll
       for (int b = 0; b < BATCH; ++b) {
-        int i = i0 + 256 * b;
+        int i = i0 + NTHR * b;
         v[b] = i < total ? src[i] : 0.f;
       }
 #pragma unroll
       for (int b = 0; b < BATCH; ++b) {
-        int i = i0 + 256 * b;
+        int i = i0 + NTHR * b;
         if (i < total) put(i, v[b]);
       }
     }

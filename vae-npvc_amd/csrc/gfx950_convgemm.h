@@ -34,7 +34,9 @@ struct ConvCfg {
   static constexpr int KC = KC_, HIN = HIN_, N = N_, HOUT = HOUT_, T = T_, S = S_, PAD = PAD_, TF = TF_;
   static constexpr bool TYPEP = TYPEP_;
   static constexpr int INKIND = INKIND_, LNDIV = LNDIV_, MB = MB_, NB = NB_;
-  static constexpr int NW = 4;  // waves per workgroup
+  static constexpr int NW = 8;  // waves per workgroup (2 per SIMD)
+  static constexpr int NTHR = NW * 64;
+  static constexpr int TBUF = 32 * 17;  // per-wave transpose buffer (16 rows x 32 columns, padded)
   static constexpr int U = 8;   // k-steps (of 2) per B prefetch chunk
   static constexpr int KCP = rup(KC, 2), KH = KCP / 2;
   static constexpr int NP = rup(N, 32), NT = NP / 32;
@@ -57,7 +59,9 @@ struct ConvCfg {
   static constexpr int FSTR = (KCP * CSTR) | 1;  // odd: rows of different frames hit different banks
   static constexpr int TILE = rup(TF * FSTR, 4);
   static constexpr int RS = TYPEP ? 1 : S, TS = TYPEP ? -1 : 1, OFF = TYPEP ? 0 : -PAD;
-  static constexpr int LDS_BYTES = (TILE + NW * 32 * 33) * 4;
+  static constexpr int LDS_BYTES = (TILE + NW * TBUF) * 4;
+  static constexpr int mtiles(int ph) { return cdiv(TF * rows(ph), 32); }
+  static constexpr int mblk(int ph) { return cdiv(mtiles(ph), MB); }
   static_assert(!TYPEP || T > S - 1, "every phase needs a tap");
 };
 
@@ -77,14 +81,14 @@ struct ConvArgs {
 template <class C>
 __device__ __forceinline__ void conv_stage(const ConvArgs& a, float* tile, int f0) {
   const int tid = threadIdx.x;
-  for (int i = tid; i < C::TILE / 4; i += 256) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < C::TILE / 4; i += C::NTHR) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   constexpr int PER = C::KC * C::HIN;
   const int nfr = min(C::TF, a.F - f0);
   const int total = nfr * PER;
   if constexpr (C::INKIND == IN_CONCAT2) {
     constexpr int HALF = C::KC / 2;
-    for (int e = tid; e < total; e += 256) {
+    for (int e = tid; e < total; e += C::NTHR) {
       int f = e / PER, k = e - f * PER;
       float v;
       if (k < HALF) {
@@ -107,25 +111,36 @@ __device__ __forceinline__ void conv_stage(const ConvArgs& a, float* tile, int f
       }
       tile[f * C::FSTR + k * C::CSTR + C::HLO + i] = v;
     };
-    stage_range<(PER % 4 == 0) ? 4 : 1, (PER % 4 == 0) ? 4 : 8>(a.in + (int64_t)f0 * PER, total, put);
+    stage_range<(PER % 4 == 0) ? 4 : 1, (PER % 4 == 0) ? 4 : 8, C::NTHR>(a.in + (int64_t)f0 * PER, total, put);
   }
   __syncthreads();
 }
 
-template <class C, int PH>
-__device__ __forceinline__ void conv_phase(const ConvArgs& a, const float* tile, float* tbuf, int f0, int nblk0,
+// One work item = (phase, block of MB row tiles, block of NB column tiles); the items of ALL
+// phases form one list that is dealt round-robin to the 8 waves.
+template <class C>
+__device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile, float* tbuf, int f0, int nblk0,
                                            int nblk1) {
-  constexpr int R = C::rows(PH), Q0 = C::q0(PH);
-  constexpr int KT = C::kt(PH), NCH = C::ktp(PH) / C::U;
-  constexpr int MTILES = cdiv(C::TF * R, 32), MBLK = cdiv(MTILES, C::MB);
   constexpr int U = C::U, MB = C::MB, NB = C::NB, NP = C::NP;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int nblks = nblk1 - nblk0;
-  const int items = MBLK * nblks;
+  const int it1 = C::mblk(0) * nblks;
+  const int it2 = it1 + (C::NPH > 1 ? C::mblk(1) * nblks : 0);
+  const int items = it2 + (C::NPH > 2 ? C::mblk(2) * nblks : 0);
   for (int it = wave; it < items; it += C::NW) {
-    const int mblk = it / nblks;
-    const int nblk = nblk0 + (it - mblk * nblks);
+    // ---- phase parameters (wave-uniform)
+    int ph = 0, local = it;
+    if (C::NPH > 1 && it >= it1) { ph = 1; local = it - it1; }
+    if (C::NPH > 2 && it >= it2) { ph = 2; local = it - it2; }
+    const int R = ph == 0 ? C::rows(0) : (ph == 1 ? C::rows(C::NPH > 1 ? 1 : 0) : C::rows(C::NPH > 2 ? 2 : 0));
+    const int Q0 = ph == 0 ? C::q0(0) : (ph == 1 ? C::q0(C::NPH > 1 ? 1 : 0) : C::q0(C::NPH > 2 ? 2 : 0));
+    const int KT = ph == 0 ? C::kt(0) : (ph == 1 ? C::kt(C::NPH > 1 ? 1 : 0) : C::kt(C::NPH > 2 ? 2 : 0));
+    const int NCH = ph == 0 ? C::ktp(0) / U : (ph == 1 ? C::ktp(C::NPH > 1 ? 1 : 0) / U : C::ktp(C::NPH > 2 ? 2 : 0) / U);
+    const int BOFF = ph == 0 ? 0 : (ph == 1 ? C::boff(C::NPH > 1 ? 1 : 0) : C::boff(C::NPH > 2 ? 2 : 0));
+    const int MTILES = ph == 0 ? C::mtiles(0) : (ph == 1 ? C::mtiles(C::NPH > 1 ? 1 : 0) : C::mtiles(C::NPH > 2 ? 2 : 0));
+    const int mblk = local / nblks;
+    const int nblk = nblk0 + (local - mblk * nblks);
     const int nbase = nblk * NB * 32;
     int baseA[MB], rowf[MB], rowq[MB];
     bool rowok[MB];
@@ -147,7 +162,7 @@ __device__ __forceinline__ void conv_phase(const ConvArgs& a, const float* tile,
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = zero16();
 
-    const float* bp = a.Bp + C::boff(PH) + lh * NP + nbase + l31;
+    const float* bp = a.Bp + BOFF + lh * NP + nbase + l31;
     float bcur[U][NB], bnxt[U][NB];
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -181,44 +196,57 @@ __device__ __forceinline__ void conv_phase(const ConvArgs& a, const float* tile,
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) bcur[u][nb] = bnxt[u][nb];
     }
-    // ---- epilogue: transpose through LDS, store along the position axis
+    // ---- epilogue: 16-row halves of each 32x32 tile are transposed through LDS so that
+    //      16 consecutive positions of one channel are stored by 16 consecutive lanes
+    const int l15 = lane & 15, lq = lane >> 4;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       if ((mblk * MB + mb) >= MTILES) continue;  // wave-uniform
-      const int opos = C::TYPEP ? (C::S * rowq[mb] + PH - C::PAD) : rowq[mb];
-      const int64_t obase = (int64_t)(f0 + rowf[mb]) * C::N * C::HOUT + opos;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        if (nbase + nb * 32 >= NP) continue;  // wave-uniform
+      for (int half = 0; half < 2; ++half) {
+        // reader lane <-> row (half*16 + l15) of the tile
+        int rf = (mblk * MB + mb) * 32 + half * 16 + l15;
+        bool ok = rf < C::TF * R;
+        int rr = ok ? rf : 0;
+        int fr = rr / R;
+        int qr = Q0 + (rr - fr * R);
+        ok = ok && (f0 + fr) < a.F;
+        const int opos = C::TYPEP ? (C::S * qr + ph - C::PAD) : qr;
+        const int64_t obase = (int64_t)(f0 + fr) * C::N * C::HOUT + opos;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) tbuf[l31 * 33 + acc_row(reg, lane)] = acc[mb][nb][reg];
-        wave_lds_sync();
+        for (int nb = 0; nb < NB; ++nb) {
+          if (nbase + nb * 32 >= NP) continue;  // wave-uniform
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          int nl = 2 * i + lh;
-          int n = nbase + nb * 32 + nl;
-          float v = tbuf[nl * 33 + l31];
-          if (rowok[mb] && n < C::N) a.out[obase + (int64_t)n * C::HOUT] = v + (a.bias ? a.bias[n] : 0.f);
+          for (int r8 = 0; r8 < 8; ++r8) {
+            int reg = half * 8 + r8;
+            tbuf[l31 * 17 + (acc_row(reg, lane) - half * 16)] = acc[mb][nb][reg];
+          }
+          wave_lds_sync();
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            int nl = 4 * i + lq;
+            int n = nbase + nb * 32 + nl;
+            float v = tbuf[nl * 17 + l15];
+            if (ok && n < C::N) a.out[obase + (int64_t)n * C::HOUT] = v + (a.bias ? a.bias[n] : 0.f);
+          }
+          wave_lds_sync();
         }
-        wave_lds_sync();
       }
     }
   }
 }
 
 template <class C>
-__global__ void __launch_bounds__(256) k_convgemm(ConvArgs a) {
+__global__ void __launch_bounds__(C::NTHR) k_convgemm(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* tile = lds;
-  float* tbuf = lds + C::TILE + (threadIdx.x >> 6) * (32 * 33);
+  float* tbuf = lds + C::TILE + (threadIdx.x >> 6) * C::TBUF;
   const int f0 = blockIdx.x * C::TF;
   conv_stage<C>(a, tile, f0);
   constexpr int NBLK = cdiv(C::NT, C::NB);
   const int nblk0 = (int)((int64_t)NBLK * blockIdx.y / gridDim.y);
   const int nblk1 = (int)((int64_t)NBLK * (blockIdx.y + 1) / gridDim.y);
-  conv_phase<C, 0>(a, tile, tbuf, f0, nblk0, nblk1);
-  if constexpr (C::NPH > 1) conv_phase<C, 1>(a, tile, tbuf, f0, nblk0, nblk1);
-  if constexpr (C::NPH > 2) conv_phase<C, 2>(a, tile, tbuf, f0, nblk0, nblk1);
+  conv_items<C>(a, tile, tbuf, f0, nblk0, nblk1);
   static_assert(C::NPH <= 3, "stride > 3 not instantiated");
 }
 
@@ -231,7 +259,7 @@ inline void launch_convgemm(const ConvArgs& a, int nsplit, hipStream_t s) {
     once = true;
   }
   dim3 grid((unsigned)cdiv(a.F, C::TF), (unsigned)nsplit);
-  hipLaunchKernelGGL(k_convgemm<C>, grid, dim3(256), C::LDS_BYTES, s, a);
+  hipLaunchKernelGGL(k_convgemm<C>, grid, dim3(C::NTHR), C::LDS_BYTES, s, a);
 }
 
 }  // namespace tuned

@@ -120,8 +120,7 @@ template <class L>
 __global__ void __launch_bounds__(256) k_ln_bwd_fused(const float* __restrict__ dy, const float* __restrict__ a,
                                                       const float* __restrict__ st, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float* __restrict__ da,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                      float* __restrict__ dbias, int F, int fchunk) {
+                                                      float* __restrict__ part, int F, int fchunk) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[2][4][2];
   constexpr int N = L::N, H = L::H, C = L::C, EPT = L::EPT;
@@ -205,9 +204,10 @@ __global__ void __launch_bounds__(256) k_ln_bwd_fused(const float* __restrict__ 
       w = wave_sum(w);
       d = wave_sum(d);
       if (lane == 0) {
-        atomicAdd(dgamma + c, u);
-        atomicAdd(dbeta + c, w);
-        atomicAdd(dbias + c, d);
+        float* pp = part + (int64_t)blockIdx.x * (3 * C);
+        pp[c] = u;
+        pp[C + c] = w;
+        pp[2 * C + c] = d;
       }
     }
   } else {
@@ -218,16 +218,36 @@ __global__ void __launch_bounds__(256) k_ln_bwd_fused(const float* __restrict__ 
         w += eW[c * H + h];
         d += eD[c * H + h];
       }
-      atomicAdd(dgamma + c, u);
-      atomicAdd(dbeta + c, w);
-      atomicAdd(dbias + c, d);
+      float* pp = part + (int64_t)blockIdx.x * (3 * C);
+      pp[c] = u;
+      pp[C + c] = w;
+      pp[2 * C + c] = d;
     }
+  }
+}
+
+// second stage: out{0,1,2}[c] += sum over workgroups of part[wg][{0,1,2}][c]
+__global__ void __launch_bounds__(256) k_ln_bwd_reduce(const float* __restrict__ part, int nwg, int C,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                       float* __restrict__ dbias) {
+  __shared__ float sm[4];
+  const int col = blockIdx.x;  // 0 .. 3C-1
+  float s = 0.f;
+  for (int w = threadIdx.x; w < nwg; w += 256) s += part[(int64_t)w * (3 * C) + col];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    float* o = col < C ? dgamma + col : (col < 2 * C ? dbeta + (col - C) : dbias + (col - 2 * C));
+    atomicAdd(o, t);
   }
 }
 
 template <class L>
 inline void launch_ln_bwd(const float* dy, const float* a, const float* st, const float* gamma, const float* beta,
-                          float* da, float* dgamma, float* dbeta, float* dbias, int F, int target_wgs, hipStream_t s) {
+                          float* da, float* dgamma, float* dbeta, float* dbias, float* part, int F, int target_wgs,
+                          hipStream_t s) {
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_bwd_fused<L>),
@@ -235,8 +255,10 @@ inline void launch_ln_bwd(const float* dy, const float* a, const float* st, cons
     once = true;
   }
   int fchunk = cmax(1, cdiv(F, target_wgs));
-  hipLaunchKernelGGL(k_ln_bwd_fused<L>, dim3((unsigned)cdiv(F, fchunk)), dim3(256), L::LDS_BYTES, s, dy, a, st, gamma,
-                     beta, da, dgamma, dbeta, dbias, F, fchunk);
+  int nwg = cdiv(F, fchunk);
+  hipLaunchKernelGGL(k_ln_bwd_fused<L>, dim3((unsigned)nwg), dim3(256), L::LDS_BYTES, s, dy, a, st, gamma, beta, da, part, F,
+                     fchunk);
+  hipLaunchKernelGGL(k_ln_bwd_reduce, dim3(3 * L::C), dim3(256), 0, s, part, nwg, L::C, dgamma, dbeta, dbias);
 }
 
 // ---------------------------------------------------------------- reductions

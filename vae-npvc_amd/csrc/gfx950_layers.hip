@@ -25,21 +25,21 @@ namespace tuned {
 
 // ---------------------------------------------------------------- configurations
 //                      KC  HIN   N  HOUT T  S PAD typeP  TF  in-kind  lndiv MB NB
-using E1F = ConvCfg<16, 171, 32, 57, 7, 3, 2, false, 4, IN_LN, 1, 2, 1>;
-using E2F = ConvCfg<32, 57, 64, 19, 7, 3, 2, false, 10, IN_LN, 1, 3, 1>;
-using E3F = ConvCfg<64, 19, 128, 7, 7, 3, 3, false, 9, IN_LN, 1, 2, 1>;
-using E4F = ConvCfg<128, 7, 256, 3, 7, 3, 3, false, 21, IN_LN, 1, 2, 2>;
-using D0F = ConvCfg<81, 19, 32, 57, 9, 3, 3, true, 10, IN_PLAIN, 1, 1, 1>;
-using D1F = ConvCfg<32, 57, 16, 171, 7, 3, 2, true, 4, IN_LN, 1, 2, 1>;
-using D2F = ConvCfg<16, 171, 8, 513, 7, 3, 2, true, 4, IN_LN, 1, 2, 1>;
+using E1F = ConvCfg<16, 171, 32, 57, 7, 3, 2, false, 4, IN_LN, 1, 1, 1>;
+using E2F = ConvCfg<32, 57, 64, 19, 7, 3, 2, false, 12, IN_LN, 1, 2, 1>;
+using E3F = ConvCfg<64, 19, 128, 7, 7, 3, 3, false, 9, IN_LN, 1, 1, 1>;
+using E4F = ConvCfg<128, 7, 256, 3, 7, 3, 3, false, 21, IN_LN, 1, 2, 1>;
+using D0F = ConvCfg<81, 19, 32, 57, 9, 3, 3, true, 8, IN_PLAIN, 1, 1, 1>;
+using D1F = ConvCfg<32, 57, 16, 171, 7, 3, 2, true, 4, IN_LN, 1, 1, 1>;
+using D2F = ConvCfg<16, 171, 8, 513, 7, 3, 2, true, 4, IN_LN, 1, 1, 1>;
 // input gradients: conv_transpose layers (S-type) and conv layers (P-type)
-using GD2 = ConvCfg<8, 513, 16, 171, 7, 3, 2, false, 2, IN_PLAIN, 1, 1, 1>;
-using GD1 = ConvCfg<16, 171, 32, 57, 7, 3, 2, false, 4, IN_PLAIN, 1, 2, 1>;
-using GD0 = ConvCfg<32, 57, 81, 19, 9, 3, 3, false, 10, IN_PLAIN, 1, 1, 1>;
-using GE4 = ConvCfg<256, 3, 128, 7, 7, 3, 3, true, 16, IN_PLAIN, 1, 1, 2>;
-using GE3 = ConvCfg<128, 7, 64, 19, 7, 3, 3, true, 9, IN_PLAIN, 1, 1, 1>;
-using GE2 = ConvCfg<64, 19, 32, 57, 7, 3, 2, true, 10, IN_PLAIN, 1, 1, 1>;
-using GE1 = ConvCfg<32, 57, 16, 171, 7, 3, 2, true, 4, IN_PLAIN, 1, 2, 1>;
+using GD2 = ConvCfg<8, 513, 16, 171, 7, 3, 2, false, 4, IN_PLAIN, 1, 1, 1>;
+using GD1 = ConvCfg<16, 171, 32, 57, 7, 3, 2, false, 4, IN_PLAIN, 1, 1, 1>;
+using GD0 = ConvCfg<32, 57, 81, 19, 9, 3, 3, false, 8, IN_PLAIN, 1, 1, 1>;
+using GE4 = ConvCfg<256, 3, 128, 7, 7, 3, 3, true, 16, IN_PLAIN, 1, 1, 1>;
+using GE3 = ConvCfg<128, 7, 64, 19, 7, 3, 3, true, 18, IN_PLAIN, 1, 1, 1>;
+using GE2 = ConvCfg<64, 19, 32, 57, 7, 3, 2, true, 8, IN_PLAIN, 1, 1, 1>;
+using GE1 = ConvCfg<32, 57, 16, 171, 7, 3, 2, true, 4, IN_PLAIN, 1, 1, 1>;
 //                         K    N   KCH NBW in-kind    lndiv
 using HeadsF = DenseCfg<768, 256, 256, 2, IN_LN, 3>;
 using HeadsB = DenseCfg<256, 768, 256, 3, IN_CONCAT2, 1>;
@@ -72,9 +72,10 @@ struct Pk {
   static constexpr int ge2 = ge3 + GE3::BTOTAL;
   static constexpr int ge1 = ge2 + GE2::BTOTAL;
   static constexpr int wc = ge1 + GE1::BTOTAL;
-  static constexpr int total = wc + TOEP_C * WROW;
+  static constexpr int lnpart = wc + TOEP_C * WROW;  // [LWGS][3][C] partial sums of the LN backward
+  static constexpr int total = lnpart + 2048 * 3 * 256;
 };
-static_assert(Pk::total <= 2 * 939162 + 65536, "packed weights must fit the scratch region");
+static_assert(Pk::total <= 4 * 939162 + 65536, "packed weights must fit the scratch region");
 // layers whose TF kernel tensor IS the packed operand (no copy)
 static_assert(E1F::BTOTAL == 7 * 16 * 32 && E2F::BTOTAL == 7 * 32 * 64 && E3F::BTOTAL == 7 * 64 * 128 &&
                   E4F::BTOTAL == 7 * 128 * 256 && GD1::BTOTAL == 7 * 16 * 32,
@@ -266,7 +267,7 @@ static TnArgs tn_args(const float* X, int ldx, const float* Y, int ldy, int M, i
   a.fchunk = 0;
   return a;
 }
-static int kchunks_for(int F, int tiles) { return cmax(1, cmin_(cdiv(F, 64), cdiv(1024, tiles))); }
+static int kchunks_for(int F, int tiles) { return cmax(1, cmin_(cdiv(F, 64), 768 / tiles)); }
 
 void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F64,
               const Ws& w, float* G, hipStream_t s) {
@@ -300,7 +301,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL(k_toep_dgrad, dim3((unsigned)cdiv(F, 32), 8), dim3(256), TD_LDS, s, w.d_xh,
                                                       w.scratch + Pk::wc, w.dy_tmp, F));
     launch_ln_bwd<LnbCfg<8, 513>>(w.dy_tmp, w.dec_a[2], w.dec_st[2], P + l2.gamma_off, P + l2.beta_off, w.d_dec_a[2],
-                                     G + l2.gamma_off, G + l2.beta_off, G + l2.b_off, F, LWGS, s);
+                                     G + l2.gamma_off, G + l2.beta_off, G + l2.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     dec_bias_done[2] = true;
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 3);
 
@@ -314,7 +315,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("dec2_dgrad", s, launch_convgemm<GD2>(conv_args(w.d_dec_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::gd2,
                                                                   nullptr, w.dy_tmp, F), 1, s));
     launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[1],
-                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, LWGS, s);
+                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     dec_bias_done[1] = true;
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 2);
 
@@ -328,7 +329,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("dec1_dgrad", s, launch_convgemm<GD1>(conv_args(w.d_dec_a[1], nullptr, nullptr, nullptr, P + l.w_off, nullptr,
                                                                   w.dy_tmp, F), 1, s));
     launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[0],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, LWGS, s);
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     dec_bias_done[0] = true;
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 1);
 
@@ -383,7 +384,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
                 w.dy_tmp, nullptr, 0, 768, F};
     VAENPVC_TIMED("heads_dgrad", s, launch_densegemm<HeadsB>(d, s));
     launch_ln_bwd<LnbCfg<256, 3>>(w.dy_tmp, w.enc_a[4], w.enc_st[4], P + l4.gamma_off, P + l4.beta_off, w.d_enc_a[4],
-                                     G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, F, LWGS, s);
+                                     G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     enc_bias_done[4] = true;
   } else generic::bwd_heads(m, P, F, w, G, s);
 
@@ -400,7 +401,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc4_dgrad", s, launch_convgemm<GE4>(conv_args(w.d_enc_a[4], nullptr, nullptr, nullptr, w.scratch + Pk::ge4,
                                                                   nullptr, w.dy_tmp, F), 1, s));
     launch_ln_bwd<LnbCfg<128, 7>>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[3],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, LWGS, s);
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     enc_bias_done[3] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 4);
   if (bwd_on(3)) {
@@ -410,7 +411,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc3_dgrad", s, launch_convgemm<GE3>(conv_args(w.d_enc_a[3], nullptr, nullptr, nullptr, w.scratch + Pk::ge3,
                                                                   nullptr, w.dy_tmp, F), 1, s));
     launch_ln_bwd<LnbCfg<64, 19>>(w.dy_tmp, w.enc_a[2], w.enc_st[2], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[2],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, LWGS, s);
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     enc_bias_done[2] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 3);
   if (bwd_on(2)) {
@@ -420,7 +421,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc2_dgrad", s, launch_convgemm<GE2>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
                                                                   nullptr, w.dy_tmp, F), 1, s));
     launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.enc_a[1], w.enc_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[1],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, LWGS, s);
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     enc_bias_done[1] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 2);
   if (bwd_on(1)) {
@@ -430,7 +431,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc1_dgrad", s, launch_convgemm<GE1>(conv_args(w.d_enc_a[1], nullptr, nullptr, nullptr, w.scratch + Pk::ge1,
                                                                   nullptr, w.dy_tmp, F), 1, s));
     launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.enc_a[0], w.enc_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[0],
-                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, F, LWGS, s);
+                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     enc_bias_done[0] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 1);
   if (bwd_on(0)) {

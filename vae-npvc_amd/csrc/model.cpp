@@ -145,7 +145,7 @@ std::vector<Region> workspace_layout(const Model& m, int64_t F, int mode, int64_
   add("kl_f", F);
   add("nll_f", F);
   // packed / transposed weight copies of the tuned kernels (F-independent)
-  add("scratch", 2 * m.n_params + 65536);
+  add("scratch", 4 * m.n_params + 65536);
   if (mode == VAENPVC_MODE_TRAIN) {
     add("d_xh", F * m.H);
     for (int i = m.n_dec - 2; i >= 0; --i) add("d_dec_a" + std::to_string(i), F * m.dec[i].cout * m.dec[i].hout);
