@@ -41,7 +41,7 @@ static const std::pair<std::vector<Region>, int64_t>& layout_of(vaenpvc_ctx* c, 
 
 static int resolve(vaenpvc_ctx* c, int64_t F, int mode, void* d_ws, size_t ws_bytes, Ws* w) {
   if (F < 1) return fail(VAENPVC_E_ARG, "F must be >= 1 (got %lld)", (long long)F);
-  if (F > (1LL << 24)) return fail(VAENPVC_E_ARG, "F too large (%lld)", (long long)F);
+  if (F > (1LL << 18)) return fail(VAENPVC_E_ARG, "F too large (%lld > 262144 frames per call)", (long long)F);
   const auto& lay = layout_of(c, F, mode);
   if (d_ws == nullptr || ws_bytes < (size_t)lay.second * 4)
     return fail(VAENPVC_E_WORKSPACE, "workspace too small: need %lld bytes, got %lld", (long long)lay.second * 4,
@@ -64,6 +64,7 @@ static int resolve(vaenpvc_ctx* c, int64_t F, int mode, void* d_ws, size_t ws_by
     else if (n == "z") w->z = p;
     else if (n == "h") w->h = p;
     else if (n == "xh") w->xh = p;
+    else if (n == "dec_y") w->dec_y = p;
     else if (n == "kl_f") w->kl_f = p;
     else if (n == "nll_f") w->nll_f = p;
     else if (n == "d_xh") w->d_xh = p;

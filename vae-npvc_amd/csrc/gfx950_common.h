@@ -94,6 +94,8 @@ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int rup(int a, int b) { return cdiv(a, b) * b; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int cmin_(int a, int b) { return a < b ? a : b; }
+// smallest value >= v that is congruent to r modulo 32 (LDS bank period for 4-byte accesses)
+constexpr int next_mod32(int v, int r) { return v + ((r - v) % 32 + 32) % 32; }
 
 }  // namespace tuned
 }  // namespace vaenpvc

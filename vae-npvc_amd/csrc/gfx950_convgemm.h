@@ -56,7 +56,10 @@ struct ConvCfg {
   static constexpr int HLO = TYPEP ? (cdiv(T, S) - 1) : PAD;
   static constexpr int HHI = TYPEP ? cmax(0, (HOUT - 1 + PAD) / S - (HIN - 1)) : cmax(0, S * (HOUT - 1) - PAD + T - 1 - (HIN - 1));
   static constexpr int CSTR = HLO + HIN + HHI;
-  static constexpr int FSTR = (KCP * CSTR) | 1;  // odd: rows of different frames hit different banks
+  // A gathers: lane l of a fragment reads row l = (frame, r) at f*FSTR + r*RS.  Choosing
+  // FSTR == rows-per-frame * RS (mod 32) makes the 32 lane addresses one arithmetic progression
+  // of step RS (1 or 3, coprime with 32 banks) across frame boundaries: conflict-free.
+  static constexpr int FSTR = next_mod32(KCP * CSTR, (rows(0) * (TYPEP ? 1 : S)) % 32);
   static constexpr int TILE = rup(TF * FSTR, 4);
   static constexpr int RS = TYPEP ? 1 : S, TS = TYPEP ? -1 : 1, OFF = TYPEP ? 0 : -PAD;
   static constexpr int LDS_BYTES = (TILE + NW * TBUF) * 4;

@@ -26,7 +26,10 @@ struct WgCfg {
   static constexpr int NTL = cdiv(YC, 32), NSPLIT = cdiv(NTL, NTW);
   static constexpr int WM = MTL >= 4 ? 4 : (MTL >= 2 ? 2 : 1), WK = 4 / WM, MTW = cdiv(MTL, WM);
   static constexpr int HLO = PAD, HHI = cmax(0, S * (YH - 1) - PAD + T - 1 - (XH - 1));
-  static constexpr int CSTRX = odd_up(HLO + XH + HHI), CSTRY = odd_up(YH);
+  // A gathers: lane <-> m = (t, xc) reads xc*CSTRX + t.  XC >= 32: one tap per fragment, odd
+  // stride.  XC < 32: a fragment spans 32/XC taps, stride == 32/XC (mod 32) keeps all 32 banks distinct.
+  static constexpr int CSTRX = XC >= 32 ? odd_up(HLO + XH + HHI) : next_mod32(HLO + XH + HHI, 32 / XC);
+  static constexpr int CSTRY = odd_up(YH);
   static constexpr int FSTRX = XC * CSTRX, FSTRY = NTW * 32 * CSTRY;
   static constexpr int XT = rup(TF * FSTRX, 4), YT = rup(TF * FSTRY, 4);
   static constexpr int LDS_BYTES = (XT + YT) * 4;

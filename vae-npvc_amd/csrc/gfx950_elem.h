@@ -42,6 +42,68 @@ __global__ void __launch_bounds__(256) k_ln_stats_fast(const float* __restrict__
   }
 }
 
+// Same, and additionally writes y = lrelu(gamma_c*(a-mean)*rstd + beta_c) ([C][H] per frame).
+// Used for the decoder layer in front of the 1025-tap layer, whose activated output is read
+// by three GEMM kernels (forward, weight gradient, edges).
+template <int N, int H>
+__global__ void __launch_bounds__(256) k_ln_stats_act(const float* __restrict__ a, float* __restrict__ st,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ y, int F) {
+  static_assert(N % 4 == 0, "frame size must be a multiple of 4 floats");
+  constexpr int NV = N / 4, PER = cdiv(NV, 64);
+  const int lane = threadIdx.x & 63;
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= F) return;
+  const float4* p = reinterpret_cast<const float4*>(a + (int64_t)f * N);
+  float4 v[PER];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    int idx = lane + 64 * i;
+    v[i] = idx < NV ? p[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / N;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    if (lane + 64 * i < NV) {
+      float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / N + LN_EPS);
+  if (lane == 0) {
+    st[2 * f] = mean;
+    st[2 * f + 1] = rstd;
+  }
+  float4* py = reinterpret_cast<float4*>(y + (int64_t)f * N);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    int idx = lane + 64 * i;
+    if (idx < NV) {
+      int e = 4 * idx;
+      float4 o;
+      o.x = lnact_v(v[i].x, mean, rstd, gamma[e / H], beta[e / H]);
+      o.y = lnact_v(v[i].y, mean, rstd, gamma[(e + 1) / H], beta[(e + 1) / H]);
+      o.z = lnact_v(v[i].z, mean, rstd, gamma[(e + 2) / H], beta[(e + 2) / H]);
+      o.w = lnact_v(v[i].w, mean, rstd, gamma[(e + 3) / H], beta[(e + 3) / H]);
+      py[idx] = o;
+    }
+  }
+}
+
+// y = lrelu(LN(a)) from existing statistics (used when the producing step ran the generic kernel)
+__global__ void __launch_bounds__(256) k_act_from_stats(const float* __restrict__ a, const float* __restrict__ st,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ y, int64_t total, int N, int H) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int64_t f = i / N;
+  int c = (int)(i - f * N) / H;
+  y[i] = lnact_v(a[i], st[2 * f], st[2 * f + 1], gamma[c], beta[c]);
+}
+
 // ---------------------------------------------------------------- encoder layer 0
 // conv k=7 s=3 pad=2, 1 -> 16 channels, 513 -> 171 bins (util/layers.py:56-64) fused with its
 // LayerNorm statistics: K = 7 is far too small for MFMA (0.4 % of the MACs), the layer is

@@ -226,8 +226,14 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     VAENPVC_TIMED("dec2_fwd", s, launch_convgemm<D2F>(conv_args(w.dec_a[1], w.dec_st[1], P + m.dec[1].gamma_off,
                                                                 P + m.dec[1].beta_off, w.scratch + Pk::d2f,
                                                                 P + m.dec[2].b_off, w.dec_a[2], F), 1, s));
-    stats<4104>(w.dec_a[2], w.dec_st[2], F, s);
-  } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 2);
+    hipLaunchKernelGGL((k_ln_stats_act<4104, 513>), dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
+                       P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, F);
+  } else {
+    generic::dec_layer_fwd(m, P, F, w, xh_out, s, 2);
+    int64_t tot = (int64_t)F * 4104;
+    hipLaunchKernelGGL(k_act_from_stats, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
+                       P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, tot, 4104, 513);
+  }
   if (fwd_on(10)) {
     static bool once = false;
     if (!once) {
@@ -235,17 +241,15 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS);
       once = true;
     }
-    const float* g2 = P + m.dec[2].gamma_off;
-    const float* b2 = P + m.dec[2].beta_off;
     if (F >= 2048) {
-      VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL(k_toep_fwd<4>, dim3((unsigned)cdiv(F, 32), 1), dim3(256), TF_LDS, s, w.dec_a[2],
-                                                      w.dec_st[2], g2, b2, w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, F));
+      VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL(k_toep_fwd<4>, dim3((unsigned)cdiv(F, 32), 1), dim3(256), TF_LDS, s, w.dec_y,
+                                                      w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, F));
     } else {
-      VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL(k_toep_fwd<1>, dim3((unsigned)cdiv(F, 32), 4), dim3(256), TF_LDS, s, w.dec_a[2],
-                                                      w.dec_st[2], g2, b2, w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, F));
+      VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL(k_toep_fwd<1>, dim3((unsigned)cdiv(F, 32), 4), dim3(256), TF_LDS, s, w.dec_y,
+                                                      w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, F));
     }
-    hipLaunchKernelGGL(k_toep_fwd_lastcol, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2], g2, b2,
-                       w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, F);
+    hipLaunchKernelGGL(k_toep_fwd_lastcol, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_y, w.scratch + Pk::wc,
+                       P + m.dec[3].b_off, xh_out, F);
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 3);
 }
 
@@ -282,15 +286,12 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   // ---- d3: the 1025-tap layer
   if (bwd_on(10)) {
     const ConvL& l2 = m.dec[2];
-    TnArgs a = tn_args(w.dec_a[2], 4104, w.d_xh, 513, 4096, 512, F, G + m.dec[3].w_off, 0);
-    a.st = w.dec_st[2];
-    a.gamma = P + l2.gamma_off;
-    a.beta = P + l2.beta_off;
+    TnArgs a = tn_args(w.dec_y, 4104, w.d_xh, 513, 4096, 512, F, G + m.dec[3].w_off, 0);
     VAENPVC_TIMED("dec3_wgrad", s, launch_tngemm(a, true, kchunks_for(F, 32 * 4), s));
     int ech = cmax(1, cmin_(cdiv(F, 64), 256));
     int efc = cdiv(F, ech);
-    hipLaunchKernelGGL(k_toep_wgrad_edges, dim3((unsigned)cdiv(8200, 256), (unsigned)cdiv(F, efc)), dim3(256), 0, s, w.dec_a[2],
-                       w.dec_st[2], P + l2.gamma_off, P + l2.beta_off, w.d_xh, G + m.dec[3].w_off, F, efc);
+    hipLaunchKernelGGL(k_toep_wgrad_edges, dim3((unsigned)cdiv(8200, 256), (unsigned)cdiv(F, efc)), dim3(256), 0, s, w.dec_y, w.d_xh,
+                       G + m.dec[3].w_off, F, efc);
     hipLaunchKernelGGL(k_sum_all_atomic, dim3((unsigned)cmin_(1024, cdiv(F * 513, 1024))), dim3(256), 0, s, w.d_xh,
                        (int64_t)F * 513, G + m.dec[3].b_off);
     static bool once = false;

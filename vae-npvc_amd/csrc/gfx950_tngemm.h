@@ -35,7 +35,12 @@ struct TnArgs {
 };
 
 // 256 threads = 2x2 waves, wave tile 64x64 (2x2 MFMA tiles), workgroup tile 128x128.
-template <bool TOEP>
+//   TOEP   : X = y2 (activated dec-2 output, [F][4104]), rows m = (c, j<512); diagonal epilogue
+//   EDGE   : M, N or the frame count are not multiples of the tile -> guarded operands
+//   LN     : LayerNorm+lrelu applied to X on load (heads: X = pre-LN output of encoder layer 4)
+//   GATHER : X rows gathered through xidx (speaker-embedding rows)
+// Operand loads run one chunk (U k-steps = 2U frames) ahead of the MFMAs, ping-pong register sets.
+template <bool TOEP, bool EDGE, bool LN, bool GATHER>
 __global__ void __launch_bounds__(256) k_tngemm(TnArgs a) {
   __shared__ float diag[4][128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -52,8 +57,8 @@ __global__ void __launch_bounds__(256) k_tngemm(TnArgs a) {
     mok[i] = m < a.M;
     int mm = mok[i] ? m : 0;
     xoff[i] = TOEP ? mm + (mm >> 9) : mm;  // (c, j<512) -> c*513 + j
-    if (a.st) {
-      int ch = TOEP ? (mm >> 9) : mm / a.lndiv;
+    if constexpr (LN) {
+      int ch = mm / a.lndiv;
       g[i] = a.gamma[ch];
       b[i] = a.beta[ch];
     }
@@ -67,61 +72,65 @@ __global__ void __launch_bounds__(256) k_tngemm(TnArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
 
-  // operand loads run one chunk (U k-steps = 2U frames) ahead of the MFMAs
   constexpr int U = 4;
-  float xr[U][2], yr[U][2], mr[U], rr[U];
-  float xn[U][2], yn[U][2], mn[U], rn[U];
-  auto load_chunk = [&](int f, float (&x)[U][2], float (&y)[U][2], float (&mm)[U], float (&rs)[U]) {
+  struct Chunk {
+    float x[U][2], y[U][2], mean[U], rstd[U];
+  };
+  const float* __restrict__ X = a.X;
+  const float* __restrict__ Y = a.Y;
+  auto load = [&](int f, Chunk& c) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int ff = f + 2 * u + lh;
-      int fc = ff < fe ? ff : fb;
-      int64_t xr_ = a.xidx ? a.xidx[fc] : (int64_t)fc;
-      mm[u] = 0.f;
-      rs[u] = 1.f;
-      if (a.st) {
-        mm[u] = a.st[2 * fc];
-        rs[u] = a.st[2 * fc + 1];
+      if constexpr (EDGE) ff = ff < fe ? ff : fb;
+      int xrow = ff;
+      if constexpr (GATHER) xrow = (int)a.xidx[ff];
+      if constexpr (LN) {
+        c.mean[u] = a.st[2 * ff];
+        c.rstd[u] = a.st[2 * ff + 1];
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        x[u][i] = a.X[xr_ * a.ldx + xoff[i]];
-        y[u][i] = a.Y[(int64_t)fc * a.ldy + noff[i]];
+        c.x[u][i] = X[xrow * a.ldx + xoff[i]];
+        c.y[u][i] = Y[ff * a.ldy + noff[i]];
       }
     }
   };
-  load_chunk(fb, xr, yr, mr, rr);
-  for (int f = fb; f < fe; f += 2 * U) {
-    const bool more = f + 2 * U < fe;
-    if (more) load_chunk(f + 2 * U, xn, yn, mn, rn);
+  auto compute = [&](int f, const Chunk& c) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool fok = f + 2 * u + lh < fe;
       float xa[2], yb[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        float v = xr[u][i];
-        if (a.st) v = lnact_v(v, mr[u], rr[u], g[i], b[i]);
-        xa[i] = (fok && mok[i]) ? v : 0.f;
-        yb[i] = (fok && nok[i]) ? yr[u][i] : 0.f;
+        float v = c.x[u][i];
+        if constexpr (LN) v = lnact_v(v, c.mean[u], c.rstd[u], g[i], b[i]);
+        float w = c.y[u][i];
+        if constexpr (EDGE) {
+          const bool fok = f + 2 * u + lh < fe;
+          v = (fok && mok[i]) ? v : 0.f;
+          w = (fok && nok[i]) ? w : 0.f;
+        }
+        xa[i] = v;
+        yb[i] = w;
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(xa[i], yb[j], acc[i][j]);
     }
-    if (more) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        mr[u] = mn[u];
-        rr[u] = rn[u];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          xr[u][i] = xn[u][i];
-          yr[u][i] = yn[u][i];
-        }
-      }
-    }
+  };
+  Chunk c0, c1;
+  load(fb, c0);
+  int f = fb;
+  while (true) {
+    if (f + 2 * U < fe) load(f + 2 * U, c1);
+    compute(f, c0);
+    f += 2 * U;
+    if (f >= fe) break;
+    if (f + 2 * U < fe) load(f + 2 * U, c0);
+    compute(f, c1);
+    f += 2 * U;
+    if (f >= fe) break;
   }
 
   if constexpr (!TOEP) {
@@ -164,42 +173,45 @@ inline void launch_tngemm(const TnArgs& a, bool toep, int kchunks, hipStream_t s
   TnArgs b = a;
   b.fchunk = ((a.F + kchunks - 1) / kchunks + 7) / 8 * 8;
   dim3 grid((unsigned)cdiv(a.M, 128), (unsigned)cdiv(a.N, 128), (unsigned)cdiv(a.F, b.fchunk));
-  if (toep)
-    hipLaunchKernelGGL(k_tngemm<true>, grid, dim3(256), 0, s, b);
-  else
-    hipLaunchKernelGGL(k_tngemm<false>, grid, dim3(256), 0, s, b);
+  const bool edge = (a.M % 128) || (a.N % 128) || (a.F % 8);
+  const bool ln = a.st != nullptr, gather = a.xidx != nullptr;
+#define VAENPVC_TN(T, E, L, G) hipLaunchKernelGGL((k_tngemm<T, E, L, G>), grid, dim3(256), 0, s, b)
+  if (toep) {
+    if (edge) VAENPVC_TN(true, true, false, false); else VAENPVC_TN(true, false, false, false);
+  } else if (gather) {
+    VAENPVC_TN(false, true, false, true);
+  } else if (ln) {
+    if (edge) VAENPVC_TN(false, true, true, false); else VAENPVC_TN(false, false, true, false);
+  } else {
+    if (edge) VAENPVC_TN(false, true, false, false); else VAENPVC_TN(false, false, false, false);
+  }
+#undef VAENPVC_TN
 }
 
 // Edge terms of the Toeplitz weight gradient not covered by the 512x512 MFMA part:
 //   t <= 512 : dW[t][c] += sum_f y2[f,c,512] * dxh[f,t]        (row j = 512, all q)
 //   t >  512 : dW[t][c] += sum_f y2[f,c,1024-t] * dxh[f,512]   (column q = 512, j < 512)
 // One thread per (t, c); grid (ceil(8200/256), frame chunks).
-__global__ void __launch_bounds__(256) k_toep_wgrad_edges(const float* __restrict__ a2, const float* __restrict__ st,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta,
-                                                          const float* __restrict__ dxh, float* __restrict__ dW,
-                                                          int F, int fchunk) {
+__global__ void __launch_bounds__(256) k_toep_wgrad_edges(const float* __restrict__ y2, const float* __restrict__ dxh,
+                                                          float* __restrict__ dW, int F, int fchunk) {
   int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= 1025 * 8) return;
   int t = idx >> 3, c = idx & 7;
   int j = t <= 512 ? 512 : 1024 - t;
   int q = t <= 512 ? t : 512;
-  const float g = gamma[c], b = beta[c];
   int fb = blockIdx.y * fchunk, fe = min(F, fb + fchunk);
   float s = 0.f;
   for (int f = fb; f < fe; f += 4) {
-    float x[4], d[4], m4[4], r4[4];
+    float x[4], d[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       int ff = f + u < fe ? f + u : fb;
-      x[u] = a2[(int64_t)ff * 4104 + c * 513 + j];
+      x[u] = y2[(int64_t)ff * 4104 + c * 513 + j];
       d[u] = dxh[(int64_t)ff * 513 + q];
-      m4[u] = st[2 * ff];
-      r4[u] = st[2 * ff + 1];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (f + u < fe) s += lnact_v(x[u], m4[u], r4[u], g, b) * d[u];
+      if (f + u < fe) s += x[u] * d[u];
   }
   atomicAdd(dW + idx, s);
 }

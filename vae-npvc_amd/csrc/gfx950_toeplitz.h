@@ -5,7 +5,8 @@
 // operand is never materialised -- a fragment is ONE contiguous ds_read_b32 from the
 // channel-major weight copy Wc[c][t] held in LDS.
 //
-//   forward : xh[f][p]     = b + sum_c sum_j Wc[c][p-j+512] * y2[f][c][j]   (p < 512 here)
+//   forward : xh[f][p]     = b + sum_c sum_j Wc[c][p-j+512] * y2[f][c][j]   (p < 512 here;
+//             y2 = lrelu(LN(a2)) is materialised once by the LN-statistics kernel of layer 2)
 //   dgrad   : dy2[f][c][j] =     sum_p     Wc[c][p-j+512] * dxh[f][p]       (all j)
 // 513 = 16*32 + 1: the MFMA part covers 512 columns; forward column p = 512 is a side
 // kernel (k_toep_fwd_lastcol), dgrad column j = 512 is a wave reduction inside the kernel.
@@ -26,10 +27,8 @@ constexpr int TF_ASTR = TF_JC + 1;   // odd row stride -> conflict-free A gather
 constexpr int TF_LDS = (32 * TF_ASTR + TOEP_C * WROW) * 4;
 
 template <int NBW>  // column tiles per wave (4 -> NSPLIT 1, 2 -> NSPLIT 2, 1 -> NSPLIT 4)
-__global__ void __launch_bounds__(256) k_toep_fwd(const float* __restrict__ a2, const float* __restrict__ st,
-                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  const float* __restrict__ Wc, const float* __restrict__ bias,
-                                                  float* __restrict__ xh, int F) {
+__global__ void __launch_bounds__(256) k_toep_fwd(const float* __restrict__ y2, const float* __restrict__ Wc,
+                                                  const float* __restrict__ bias, float* __restrict__ xh, int F) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* tA = lds;
   float* tW = lds + 32 * TF_ASTR;
@@ -41,7 +40,6 @@ __global__ void __launch_bounds__(256) k_toep_fwd(const float* __restrict__ a2, 
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) acc[nb] = zero16();
   for (int c = 0; c < TOEP_C; ++c) {
-    const float g = gamma[c], b = beta[c];
     for (int jc0 = 0; jc0 < 2 * TF_JC; jc0 += TF_JC) {
       __syncthreads();  // previous chunk fully consumed (also covers the tW fill)
       constexpr int BT = 8;
@@ -52,14 +50,13 @@ __global__ void __launch_bounds__(256) k_toep_fwd(const float* __restrict__ a2, 
           int e = e0 + 256 * bb;
           int fl = e / TF_JC, jj = e - fl * TF_JC;
           int j = jc0 + jj, f = f0 + fl;
-          v[bb] = (e < 32 * TF_JC && j < TOEP_H && f < F) ? a2[(int64_t)f * (TOEP_C * TOEP_H) + c * TOEP_H + j] : 0.f;
+          v[bb] = (e < 32 * TF_JC && j < TOEP_H && f < F) ? y2[(int64_t)f * (TOEP_C * TOEP_H) + c * TOEP_H + j] : 0.f;
         }
 #pragma unroll
         for (int bb = 0; bb < BT; ++bb) {
           int e = e0 + 256 * bb;
           int fl = e / TF_JC, jj = e - fl * TF_JC;
-          int j = jc0 + jj, f = f0 + fl;
-          if (e < 32 * TF_JC) tA[fl * TF_ASTR + jj] = (j < TOEP_H && f < F) ? lnact_v(v[bb], st[2 * f], st[2 * f + 1], g, b) : 0.f;
+          if (e < 32 * TF_JC) tA[fl * TF_ASTR + jj] = v[bb];
         }
       }
       __syncthreads();
@@ -85,20 +82,16 @@ __global__ void __launch_bounds__(256) k_toep_fwd(const float* __restrict__ a2, 
 }
 
 // forward column p = 512: xh[f][512] = b + sum_{c,j} Wc[c][1024-j] * y2[f][c][j]; one wave per frame
-__global__ void __launch_bounds__(256) k_toep_fwd_lastcol(const float* __restrict__ a2, const float* __restrict__ st,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, const float* __restrict__ Wc,
+__global__ void __launch_bounds__(256) k_toep_fwd_lastcol(const float* __restrict__ y2, const float* __restrict__ Wc,
                                                           const float* __restrict__ bias, float* __restrict__ xh, int F) {
   const int lane = threadIdx.x & 63;
   const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (f >= F) return;
-  const float mean = st[2 * f], rstd = st[2 * f + 1];
   float s = 0.f;
   for (int c = 0; c < TOEP_C; ++c) {
-    const float g = gamma[c], b = beta[c];
-    const float* row = a2 + (int64_t)f * (TOEP_C * TOEP_H) + c * TOEP_H;
+    const float* row = y2 + (int64_t)f * (TOEP_C * TOEP_H) + c * TOEP_H;
     const float* w = Wc + c * WROW + WPRE + 1024;
-    for (int j = lane; j < TOEP_H; j += 64) s += lnact_v(row[j], mean, rstd, g, b) * w[-j];
+    for (int j = lane; j < TOEP_H; j += 64) s += row[j] * w[-j];
   }
   s = wave_sum(s);
   if (lane == 0) xh[(int64_t)f * TOEP_H + 512] = s + bias[0];

@@ -14,6 +14,7 @@ struct Ws {  // resolved workspace pointers (see workspace_layout)
   float* dec_a[VAENPVC_MAX_LAYERS];
   float* dec_st[VAENPVC_MAX_LAYERS];
   float *xh, *kl_f, *nll_f;
+  float* dec_y;  // lrelu(LN(dec_a[n_dec-2]))
   // train only
   float* d_xh;
   float* d_dec_a[VAENPVC_MAX_LAYERS];

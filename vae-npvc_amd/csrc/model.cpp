@@ -141,6 +141,8 @@ std::vector<Region> workspace_layout(const Model& m, int64_t F, int mode, int64_
     add("dec_st" + std::to_string(i), F * 2);
     maxact = std::max<int64_t>(maxact, (int64_t)m.dec[i].cout * m.dec[i].hout);
   }
+  // activated output of the last LN layer of the decoder (operand of the final layer's GEMMs)
+  if (m.n_dec >= 2) add("dec_y", F * m.dec[m.n_dec - 2].cout * m.dec[m.n_dec - 2].hout);
   add("xh", F * m.H);
   add("kl_f", F);
   add("nll_f", F);
