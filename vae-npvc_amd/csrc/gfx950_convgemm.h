@@ -37,13 +37,15 @@ struct ConvCfg {
   static constexpr int NW = 8;  // waves per workgroup (2 per SIMD)
   static constexpr int NTHR = NW * 64;
   static constexpr int TBUF = 32 * 17;  // per-wave transpose buffer (16 rows x 32 columns, padded)
-  static constexpr int U = 8;   // k-steps (of 2) per B prefetch chunk
-  static constexpr int KCP = rup(KC, 2), KH = KCP / 2;
+  // K per tap is padded so that KH = KCP/2 k-steps split into uniform chunks of U steps
+  static constexpr int KCP = KC % 16 == 0 ? KC : rup(KC, 8), KH = KCP / 2;
+  static constexpr int U = KH % 8 == 0 ? 8 : 4;  // k-steps (of 2) per B prefetch chunk
+  static constexpr int CPT = KH / U;             // chunks per tap
   static constexpr int NP = rup(N, 32), NT = NP / 32;
   static constexpr int NPH = TYPEP ? S : 1;
   static constexpr int ntaps(int ph) { return TYPEP ? (T - ph + S - 1) / S : T; }
   static constexpr int kt(int ph) { return ntaps(ph) * KH; }
-  static constexpr int ktp(int ph) { return rup(kt(ph), U); }
+  static constexpr int ktp(int ph) { return kt(ph); }  // already a multiple of U
   static constexpr int q0(int ph) { return TYPEP ? (PAD - ph > 0 ? cdiv(PAD - ph, S) : 0) : 0; }
   static constexpr int q1(int ph) { return TYPEP ? (HOUT - 1 + PAD - ph) / S : HOUT - 1; }
   static constexpr int rows(int ph) { return q1(ph) - q0(ph) + 1; }
@@ -139,7 +141,6 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
     const int R = ph == 0 ? C::rows(0) : (ph == 1 ? C::rows(C::NPH > 1 ? 1 : 0) : C::rows(C::NPH > 2 ? 2 : 0));
     const int Q0 = ph == 0 ? C::q0(0) : (ph == 1 ? C::q0(C::NPH > 1 ? 1 : 0) : C::q0(C::NPH > 2 ? 2 : 0));
     const int KT = ph == 0 ? C::kt(0) : (ph == 1 ? C::kt(C::NPH > 1 ? 1 : 0) : C::kt(C::NPH > 2 ? 2 : 0));
-    const int NCH = ph == 0 ? C::ktp(0) / U : (ph == 1 ? C::ktp(C::NPH > 1 ? 1 : 0) / U : C::ktp(C::NPH > 2 ? 2 : 0) / U);
     const int BOFF = ph == 0 ? 0 : (ph == 1 ? C::boff(C::NPH > 1 ? 1 : 0) : C::boff(C::NPH > 2 ? 2 : 0));
     const int MTILES = ph == 0 ? C::mtiles(0) : (ph == 1 ? C::mtiles(C::NPH > 1 ? 1 : 0) : C::mtiles(C::NPH > 2 ? 2 : 0));
     const int mblk = local / nblks;
@@ -165,39 +166,46 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = zero16();
 
-    const float* bp = a.Bp + BOFF + lh * NP + nbase + l31;
-    float bcur[U][NB], bnxt[U][NB];
+    // K loop over chunks of U k-steps.  B (weights) streams from L2 into two ping-pong register
+    // sets, always one chunk ahead of the MFMAs that consume it (no register copies, so the
+    // compiler's s_waitcnt for a chunk sits a full chunk of MFMAs after its loads were issued).
+    // (loads are unconditional: columns of a partial last block are clamped to the last valid
+    //  tile and never stored; the prefetch may run up to two chunks past the phase's rows, which
+    //  is still inside the packed-weight / parameter buffer)
+    int ncol[NB];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) bcur[u][nb] = (nbase + nb * 32 < NP) ? bp[u * 2 * NP + nb * 32] : 0.f;
-    for (int c = 0; c < NCH; ++c) {
-      if (c + 1 < NCH) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            bnxt[u][nb] = (nbase + nb * 32 < NP) ? bp[((c + 1) * U + u) * 2 * NP + nb * 32] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        int s = c * U + u;
-        s = s < KT ? s : KT - 1;  // padded B rows are zero; keep the LDS address in range
-        int tau = s / C::KH;
-        int kk = s - tau * C::KH;
-        int aoff = kk * 2 * C::CSTR + tau * C::TS;
-        float av[MB];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) av[mb] = tile[baseA[mb] + aoff];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma32(av[mb], bcur[u][nb], acc[mb][nb]);
-      }
+    for (int nb = 0; nb < NB; ++nb) ncol[nb] = (nbase + nb * 32 < NP ? nbase + nb * 32 : NP - 32) + l31;
+    const float* bp0 = a.Bp + BOFF + lh * NP;
+    const int nchunks = (KT / C::KH) * C::CPT;
+    auto loadB = [&](float (&b)[U][NB], int chunk) {
+      const float* p = bp0 + chunk * (U * 2 * NP);
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bcur[u][nb] = bnxt[u][nb];
+        for (int nb = 0; nb < NB; ++nb) b[u][nb] = p[u * 2 * NP + ncol[nb]];
+    };
+    auto compute = [&](const float (&b)[U][NB], int chunk) {
+      const int tau = chunk / C::CPT, c = chunk - tau * C::CPT;
+      const int aoff = tau * C::TS + c * (U * 2 * C::CSTR);
+      float av[U][MB];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[u][mb] = tile[baseA[mb] + aoff + u * 2 * C::CSTR];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma32(av[u][mb], b[u][nb], acc[mb][nb]);
+    };
+    float b0[U][NB], b1[U][NB];
+    loadB(b0, 0);
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+      loadB(b1, chunk + 1);
+      compute(b0, chunk);
+      loadB(b0, chunk + 2);
+      if (chunk + 1 < nchunks) compute(b1, chunk + 1);
     }
     // ---- epilogue: 16-row halves of each 32x32 tile are transposed through LDS so that
     //      16 consecutive positions of one channel are stored by 16 consecutive lanes

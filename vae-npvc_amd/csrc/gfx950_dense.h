@@ -95,30 +95,39 @@ __global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
     }
     __syncthreads();
     if (nt0 < C::NT) {  // wave-uniform
-      const float* bp = a.Bp + (int64_t)(kc0 + lh) * C::NP + nt0 * 32 + l31;
-      float bcur[U][C::NBW], bnxt[U][C::NBW];
+      // B streams from L2 into two ping-pong register sets, one sub-chunk (U k-steps) ahead
+      // (unconditional loads: column tiles beyond NT are clamped and never stored; the last
+      //  prefetch of the last chunk over-reads into the zero padding / next packed matrix)
+      int ncol[C::NBW];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int nb = 0; nb < C::NBW; ++nb) bcur[u][nb] = (nt0 + nb < C::NT) ? bp[u * 2 * C::NP + nb * 32] : 0.f;
-      for (int c8 = 0; c8 < C::KCH / (2 * U); ++c8) {
-        if (c8 + 1 < C::KCH / (2 * U)) {
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int nb = 0; nb < C::NBW; ++nb)
-              bnxt[u][nb] = (nt0 + nb < C::NT) ? bp[((c8 + 1) * U + u) * 2 * C::NP + nb * 32] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          float av = ap[(c8 * U + u) * 2];
-#pragma unroll
-          for (int nb = 0; nb < C::NBW; ++nb) acc[nb] = mfma32(av, bcur[u][nb], acc[nb]);
-        }
+      for (int nb = 0; nb < C::NBW; ++nb) ncol[nb] = (nt0 + nb < C::NT ? nt0 + nb : C::NT - 1) * 32 + l31;
+      const float* bp = a.Bp + (kc0 + lh) * C::NP;
+      constexpr int NSUB = C::KCH / (2 * U);
+      auto loadB = [&](float (&b)[U][C::NBW], int c8) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-          for (int nb = 0; nb < C::NBW; ++nb) bcur[u][nb] = bnxt[u][nb];
+          for (int nb = 0; nb < C::NBW; ++nb) b[u][nb] = bp[(c8 * U + u) * 2 * C::NP + ncol[nb]];
+      };
+      auto compute = [&](const float (&b)[U][C::NBW], int c8) {
+        float av[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) av[u] = ap[(c8 * U + u) * 2];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int nb = 0; nb < C::NBW; ++nb) acc[nb] = mfma32(av[u], b[u][nb], acc[nb]);
+      };
+      float b0[U][C::NBW], b1[U][C::NBW];
+      loadB(b0, 0);
+#pragma unroll
+      for (int c8 = 0; c8 < NSUB; c8 += 2) {
+        if (c8 + 1 < NSUB) loadB(b1, c8 + 1);
+        compute(b0, c8);
+        if (c8 + 1 < NSUB) {
+          if (c8 + 2 < NSUB) loadB(b0, c8 + 2);
+          compute(b1, c8 + 1);
+        }
       }
     }
   }

@@ -36,7 +36,7 @@ using D2F = ConvCfg<16, 171, 8, 513, 7, 3, 2, true, 4, IN_LN, 1, 1, 1>;
 using GD2 = ConvCfg<8, 513, 16, 171, 7, 3, 2, false, 4, IN_PLAIN, 1, 1, 1>;
 using GD1 = ConvCfg<16, 171, 32, 57, 7, 3, 2, false, 4, IN_PLAIN, 1, 1, 1>;
 using GD0 = ConvCfg<32, 57, 81, 19, 9, 3, 3, false, 8, IN_PLAIN, 1, 1, 1>;
-using GE4 = ConvCfg<256, 3, 128, 7, 7, 3, 3, true, 16, IN_PLAIN, 1, 1, 1>;
+using GE4 = ConvCfg<256, 3, 128, 7, 7, 3, 3, true, 16, IN_PLAIN, 1, 1, 2>;
 using GE3 = ConvCfg<128, 7, 64, 19, 7, 3, 3, true, 18, IN_PLAIN, 1, 1, 1>;
 using GE2 = ConvCfg<64, 19, 32, 57, 7, 3, 2, true, 8, IN_PLAIN, 1, 1, 1>;
 using GE1 = ConvCfg<32, 57, 16, 171, 7, 3, 2, true, 4, IN_PLAIN, 1, 1, 1>;
