@@ -203,9 +203,13 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
     loadB(b0, 0);
     for (int chunk = 0; chunk < nchunks; chunk += 2) {
       loadB(b1, chunk + 1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch AHEAD of the MFMAs it overlaps
       compute(b0, chunk);
+      __builtin_amdgcn_sched_barrier(0);
       loadB(b0, chunk + 2);
+      __builtin_amdgcn_sched_barrier(0);
       if (chunk + 1 < nchunks) compute(b1, chunk + 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // ---- epilogue: 16-row halves of each 32x32 tile are transposed through LDS so that
     //      16 consecutive positions of one channel are stored by 16 consecutive lanes

@@ -123,10 +123,14 @@ __global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
 #pragma unroll
       for (int c8 = 0; c8 < NSUB; c8 += 2) {
         if (c8 + 1 < NSUB) loadB(b1, c8 + 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch AHEAD of the MFMAs it overlaps
         compute(b0, c8);
+        __builtin_amdgcn_sched_barrier(0);
         if (c8 + 1 < NSUB) {
           if (c8 + 2 < NSUB) loadB(b0, c8 + 2);
+          __builtin_amdgcn_sched_barrier(0);
           compute(b1, c8 + 1);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
