@@ -130,23 +130,28 @@ __global__ void __launch_bounds__(256) k_convwgrad(WgArgs a) {
       }
     }
     __syncthreads();
-    constexpr int HP = C::TF / 2, KS = C::YH * HP;
-    for (int ks = wk; ks < KS; ks += C::WK) {
-      int r = ks / HP, fp = ks - r * HP;
-      int ao = fp * 2 * C::FSTRX + C::S * r;
-      int bo = fp * 2 * C::FSTRY + r;
-      float av[C::MTW], bv[C::NTW];
+    // k-steps: position r (outer) x frame pair fp (inner, unrolled); the WK waves that share
+    // an M range take interleaved positions r.  Fragment reads of one r are all issued before
+    // its MFMAs (addresses differ only by compile-time offsets).
+    constexpr int HP = C::TF / 2;
+    for (int r = wk; r < C::YH; r += C::WK) {
+      float av[HP][C::MTW], bv[HP][C::NTW];
 #pragma unroll
-      for (int i = 0; i < C::MTW; ++i) {
-        float v = tX[baseA[i] + ao];
-        av[i] = aok[i] ? v : 0.f;
+      for (int fp = 0; fp < HP; ++fp) {
+#pragma unroll
+        for (int i = 0; i < C::MTW; ++i) {
+          float v = tX[baseA[i] + C::S * r + fp * 2 * C::FSTRX];
+          av[fp][i] = aok[i] ? v : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < C::NTW; ++j) bv[fp][j] = tY[baseB[j] + r + fp * 2 * C::FSTRY];
       }
 #pragma unroll
-      for (int j = 0; j < C::NTW; ++j) bv[j] = tY[baseB[j] + bo];
+      for (int fp = 0; fp < HP; ++fp)
 #pragma unroll
-      for (int i = 0; i < C::MTW; ++i)
+        for (int i = 0; i < C::MTW; ++i)
 #pragma unroll
-        for (int j = 0; j < C::NTW; ++j) acc[i][j] = mfma32(av[i], bv[j], acc[i][j]);
+          for (int j = 0; j < C::NTW; ++j) acc[i][j] = mfma32(av[fp][i], bv[fp][j], acc[i][j]);
     }
   }
 #pragma unroll

@@ -271,7 +271,7 @@ static TnArgs tn_args(const float* X, int ldx, const float* Y, int ldy, int M, i
   a.fchunk = 0;
   return a;
 }
-static int kchunks_for(int F, int tiles) { return cmax(1, cmin_(cdiv(F, 64), 768 / tiles)); }
+static int kchunks_for(int F, int tiles) { return cmax(1, cmin_(cdiv(F, 64), 512 / tiles)); }  // 2 workgroups (64 KB LDS) per CU
 
 void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F64,
               const Ws& w, float* G, hipStream_t s) {

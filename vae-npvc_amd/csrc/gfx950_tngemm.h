@@ -36,103 +36,115 @@ struct TnArgs {
 
 // 256 threads = 2x2 waves, wave tile 64x64 (2x2 MFMA tiles), workgroup tile 128x128.
 //   TOEP   : X = y2 (activated dec-2 output, [F][4104]), rows m = (c, j<512); diagonal epilogue
-//   EDGE   : M, N or the frame count are not multiples of the tile -> guarded operands
-//   LN     : LayerNorm+lrelu applied to X on load (heads: X = pre-LN output of encoder layer 4)
+//   LN     : LayerNorm+lrelu applied to X while staging (heads: X = pre-LN output of enc layer 4)
 //   GATHER : X rows gathered through xidx (speaker-embedding rows)
-// Operand loads run one chunk (U k-steps = 2U frames) ahead of the MFMAs, ping-pong register sets.
-template <bool TOEP, bool EDGE, bool LN, bool GATHER>
+// The reduction runs over chunks of KF frames.  Each chunk's 128 X columns and 128 Y columns
+// are read ONCE per workgroup (coalesced 512-byte rows) into registers while the MFMAs consume
+// the previous chunk from LDS, then written to the other LDS buffer (one barrier per chunk).
+// Fragments: lanes 0..31 read 32 consecutive floats of frame k, lanes 32..63 of frame k+1.
+constexpr int TN_KF = 32;                       // frames per chunk
+constexpr int TN_BUF = 2 * TN_KF * 128;         // floats per buffer: X[KF][128] then Y[KF][128]
+constexpr int TN_EPT = TN_KF * 128 / 256;       // staged elements per thread and operand
+
+template <bool TOEP, bool LN, bool GATHER>
 __global__ void __launch_bounds__(256) k_tngemm(TnArgs a) {
-  __shared__ float diag[4][128];
+  __shared__ __attribute__((aligned(16))) float lds[2 * TN_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * 128 + (wave >> 1) * 64;
-  const int n0 = blockIdx.y * 128 + (wave & 1) * 64;
+  const int mb0 = blockIdx.x * 128, nb0 = blockIdx.y * 128;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int fb = blockIdx.z * a.fchunk;
   const int fe = min(a.F, fb + a.fchunk);
-  int xoff[2], noff[2];
-  bool mok[2], nok[2];
-  float g[2] = {1.f, 1.f}, b[2] = {0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int m = m0 + i * 32 + l31;
-    mok[i] = m < a.M;
-    int mm = mok[i] ? m : 0;
-    xoff[i] = TOEP ? mm + (mm >> 9) : mm;  // (c, j<512) -> c*513 + j
-    if constexpr (LN) {
-      int ch = mm / a.lndiv;
-      g[i] = a.gamma[ch];
-      b[i] = a.beta[ch];
-    }
-    int n = n0 + i * 32 + l31;
-    nok[i] = n < a.N;
-    noff[i] = nok[i] ? n : 0;
+  // staging: thread -> column (tid & 127), rows (tid >> 7) + 2k
+  const int col = tid & 127, row0 = tid >> 7;
+  const int m = mb0 + col, n = nb0 + col;
+  const bool mok = m < a.M, nok = n < a.N;
+  const int mm = mok ? m : 0, nn = nok ? n : 0;
+  const int xoff = TOEP ? mm + (mm >> 9) : mm;  // (c, j<512) -> c*513 + j
+  float g = 1.f, b = 0.f;
+  if constexpr (LN) {
+    g = a.gamma[mm / a.lndiv];
+    b = a.beta[mm / a.lndiv];
   }
+  float rx[TN_EPT], ry[TN_EPT];
+  const float* __restrict__ X = a.X;
+  const float* __restrict__ Y = a.Y;
+  const int ldx = a.ldx, ldy = a.ldy;
+  const bool tile_full = (mb0 + 128 <= a.M) && (nb0 + 128 <= a.N);
+  // fast path: whole chunk inside [fb, fe) and a full 128x128 tile -> no guards, offsets advance
+  // by a constant (one add per load); guarded path only for edge tiles / the chunk tail
+  auto gload = [&](int f0) {
+    if (!GATHER && tile_full && f0 + TN_KF <= fe) {
+      int ox = (f0 + row0) * ldx + xoff, oy = (f0 + row0) * ldy + nn;
+#pragma unroll
+      for (int k = 0; k < TN_EPT; ++k) {
+        float v = X[ox];
+        if constexpr (LN) {
+          int f = f0 + row0 + 2 * k;
+          v = lnact_v(v, a.st[2 * f], a.st[2 * f + 1], g, b);
+        }
+        rx[k] = v;
+        ry[k] = Y[oy];
+        ox += 2 * ldx;
+        oy += 2 * ldy;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < TN_EPT; ++k) {
+        int f = f0 + row0 + 2 * k;
+        bool fok = f < fe;
+        int ff = fok ? f : fb;
+        int xrow = ff;
+        if constexpr (GATHER) xrow = (int)a.xidx[ff];
+        float v = X[xrow * ldx + xoff];
+        if constexpr (LN) v = lnact_v(v, a.st[2 * ff], a.st[2 * ff + 1], g, b);
+        rx[k] = (fok && mok) ? v : 0.f;
+        float w = Y[ff * ldy + nn];
+        ry[k] = (fok && nok) ? w : 0.f;
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* px = lds + buf * TN_BUF;
+    float* py = px + TN_KF * 128;
+#pragma unroll
+    for (int k = 0; k < TN_EPT; ++k) {
+      px[(row0 + 2 * k) * 128 + col] = rx[k];
+      py[(row0 + 2 * k) * 128 + col] = ry[k];
+    }
+  };
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
 
-  constexpr int U = 4;
-  struct Chunk {
-    float x[U][2], y[U][2], mean[U], rstd[U];
-  };
-  const float* __restrict__ X = a.X;
-  const float* __restrict__ Y = a.Y;
-  auto load = [&](int f, Chunk& c) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int ff = f + 2 * u + lh;
-      if constexpr (EDGE) ff = ff < fe ? ff : fb;
-      int xrow = ff;
-      if constexpr (GATHER) xrow = (int)a.xidx[ff];
-      if constexpr (LN) {
-        c.mean[u] = a.st[2 * ff];
-        c.rstd[u] = a.st[2 * ff + 1];
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        c.x[u][i] = X[xrow * a.ldx + xoff[i]];
-        c.y[u][i] = Y[ff * a.ldy + noff[i]];
+  gload(fb);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int f0 = fb; f0 < fe; f0 += TN_KF, buf ^= 1) {
+    const bool more = f0 + TN_KF < fe;
+    if (more) gload(f0 + TN_KF);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const float* px = lds + buf * TN_BUF + lh * 128 + wm + l31;
+      const float* py = lds + buf * TN_BUF + TN_KF * 128 + lh * 128 + wn + l31;
+#pragma unroll 4
+      for (int k = 0; k < TN_KF / 2; ++k) {
+        float x0 = px[k * 256], x1 = px[k * 256 + 32];
+        float y0 = py[k * 256], y1 = py[k * 256 + 32];
+        acc[0][0] = mfma32(x0, y0, acc[0][0]);
+        acc[0][1] = mfma32(x0, y1, acc[0][1]);
+        acc[1][0] = mfma32(x1, y0, acc[1][0]);
+        acc[1][1] = mfma32(x1, y1, acc[1][1]);
       }
     }
-  };
-  auto compute = [&](int f, const Chunk& c) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float xa[2], yb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float v = c.x[u][i];
-        if constexpr (LN) v = lnact_v(v, c.mean[u], c.rstd[u], g[i], b[i]);
-        float w = c.y[u][i];
-        if constexpr (EDGE) {
-          const bool fok = f + 2 * u + lh < fe;
-          v = (fok && mok[i]) ? v : 0.f;
-          w = (fok && nok[i]) ? w : 0.f;
-        }
-        xa[i] = v;
-        yb[i] = w;
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(xa[i], yb[j], acc[i][j]);
-    }
-  };
-  Chunk c0, c1;
-  load(fb, c0);
-  int f = fb;
-  while (true) {
-    if (f + 2 * U < fe) load(f + 2 * U, c1);
-    compute(f, c0);
-    f += 2 * U;
-    if (f >= fe) break;
-    if (f + 2 * U < fe) load(f + 2 * U, c0);
-    compute(f, c1);
-    f += 2 * U;
-    if (f >= fe) break;
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
   }
 
+  const int m0 = mb0 + wm, n0 = nb0 + wn;
   if constexpr (!TOEP) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -140,13 +152,14 @@ __global__ void __launch_bounds__(256) k_tngemm(TnArgs a) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-          int m = m0 + i * 32 + acc_row(reg, lane);
-          int n = n0 + j * 32 + l31;
-          if (m < a.M && n < a.N) atomicAdd(a.C + (int64_t)m * a.ldc + n, acc[i][j][reg]);
+          int mo = m0 + i * 32 + acc_row(reg, lane);
+          int no = n0 + j * 32 + l31;
+          if (mo < a.M && no < a.N) atomicAdd(a.C + (int64_t)mo * a.ldc + no, acc[i][j][reg]);
         }
   } else {
     // wave tile rows m0..m0+63 lie in ONE channel (512 % 64 == 0); diagonal d = col - row
-    float* dg = diag[wave];
+    __syncthreads();
+    float* dg = lds + wave * 128;
     dg[lane] = 0.f;
     dg[lane + 64] = 0.f;
     wave_lds_sync();
@@ -157,8 +170,8 @@ __global__ void __launch_bounds__(256) k_tngemm(TnArgs a) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           int row = i * 32 + acc_row(reg, lane);
-          int col = j * 32 + l31;
-          atomicAdd(&dg[col - row + 63], acc[i][j][reg]);
+          int cl = j * 32 + l31;
+          atomicAdd(&dg[cl - row + 63], acc[i][j][reg]);
         }
     wave_lds_sync();
     const int c = m0 >> 9, j0 = m0 & 511;
@@ -171,21 +184,17 @@ __global__ void __launch_bounds__(256) k_tngemm(TnArgs a) {
 
 inline void launch_tngemm(const TnArgs& a, bool toep, int kchunks, hipStream_t s) {
   TnArgs b = a;
-  b.fchunk = ((a.F + kchunks - 1) / kchunks + 7) / 8 * 8;
+  b.fchunk = ((a.F + kchunks - 1) / kchunks + TN_KF - 1) / TN_KF * TN_KF;
   dim3 grid((unsigned)cdiv(a.M, 128), (unsigned)cdiv(a.N, 128), (unsigned)cdiv(a.F, b.fchunk));
-  const bool edge = (a.M % 128) || (a.N % 128) || (a.F % 8);
   const bool ln = a.st != nullptr, gather = a.xidx != nullptr;
-#define VAENPVC_TN(T, E, L, G) hipLaunchKernelGGL((k_tngemm<T, E, L, G>), grid, dim3(256), 0, s, b)
-  if (toep) {
-    if (edge) VAENPVC_TN(true, true, false, false); else VAENPVC_TN(true, false, false, false);
-  } else if (gather) {
-    VAENPVC_TN(false, true, false, true);
-  } else if (ln) {
-    if (edge) VAENPVC_TN(false, true, true, false); else VAENPVC_TN(false, false, true, false);
-  } else {
-    if (edge) VAENPVC_TN(false, true, false, false); else VAENPVC_TN(false, false, false, false);
-  }
-#undef VAENPVC_TN
+  if (toep)
+    hipLaunchKernelGGL((k_tngemm<true, false, false>), grid, dim3(256), 0, s, b);
+  else if (gather)
+    hipLaunchKernelGGL((k_tngemm<false, false, true>), grid, dim3(256), 0, s, b);
+  else if (ln)
+    hipLaunchKernelGGL((k_tngemm<false, true, false>), grid, dim3(256), 0, s, b);
+  else
+    hipLaunchKernelGGL((k_tngemm<false, false, false>), grid, dim3(256), 0, s, b);
 }
 
 // Edge terms of the Toeplitz weight gradient not covered by the 512x512 MFMA part:

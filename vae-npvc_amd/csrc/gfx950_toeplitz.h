@@ -22,47 +22,71 @@ constexpr int WPRE = 4;
 
 // ---------------------------------------------------------------- forward
 // grid (ceil(F/32), NSPLIT); 256 threads; each wave owns 16/NSPLIT/4 column tiles.
-constexpr int TF_JC = 258;           // j-chunk staged in LDS (2 chunks cover 516 >= 513)
+// K = (channel c, j) is walked in 16 chunks (8 channels x 2 halves of 258 j).  Double buffered:
+// while the MFMAs consume chunk i from LDS buffer i&1, the global loads of chunk i+1 are in
+// flight into registers; they are written to the other buffer after the MFMA block, one
+// __syncthreads per chunk.  The 1032-float weight row of the chunk's channel travels with it.
+constexpr int TF_JC = 258;           // j-chunk (2 chunks cover 516 >= 513)
 constexpr int TF_ASTR = TF_JC + 1;   // odd row stride -> conflict-free A gathers
-constexpr int TF_LDS = (32 * TF_ASTR + TOEP_C * WROW) * 4;
+constexpr int TF_BUF = 32 * TF_ASTR + WROW;   // floats per buffer: A chunk + weight row
+constexpr int TF_LDS = 2 * TF_BUF * 4;
+constexpr int TF_EPT = (32 * TF_JC + 255) / 256;  // staged A elements per thread
+constexpr int TF_WPT = (WROW + 255) / 256;
 
 template <int NBW>  // column tiles per wave (4 -> NSPLIT 1, 2 -> NSPLIT 2, 1 -> NSPLIT 4)
 __global__ void __launch_bounds__(256) k_toep_fwd(const float* __restrict__ y2, const float* __restrict__ Wc,
                                                   const float* __restrict__ bias, float* __restrict__ xh, int F) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* tA = lds;
-  float* tW = lds + 32 * TF_ASTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int f0 = blockIdx.x * 32;
-  for (int i = tid; i < TOEP_C * WROW; i += 256) tW[i] = Wc[i];
   const int p0 = (blockIdx.y * 4 + wave) * NBW * 32;
   f32x16 acc[NBW];
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) acc[nb] = zero16();
-  for (int c = 0; c < TOEP_C; ++c) {
-    for (int jc0 = 0; jc0 < 2 * TF_JC; jc0 += TF_JC) {
-      __syncthreads();  // previous chunk fully consumed (also covers the tW fill)
-      constexpr int BT = 8;
-      for (int e0 = tid; e0 < 32 * TF_JC; e0 += 256 * BT) {
-        float v[BT];
+  float ra[TF_EPT], rw[TF_WPT];
+  auto gload = [&](int chunk) {
+    const int c = chunk >> 1, jc0 = (chunk & 1) * TF_JC;
 #pragma unroll
-        for (int bb = 0; bb < BT; ++bb) {
-          int e = e0 + 256 * bb;
-          int fl = e / TF_JC, jj = e - fl * TF_JC;
-          int j = jc0 + jj, f = f0 + fl;
-          v[bb] = (e < 32 * TF_JC && j < TOEP_H && f < F) ? y2[(int64_t)f * (TOEP_C * TOEP_H) + c * TOEP_H + j] : 0.f;
-        }
+    for (int k = 0; k < TF_EPT; ++k) {
+      int e = tid + 256 * k;
+      int fl = e / TF_JC, jj = e - fl * TF_JC;
+      int j = jc0 + jj, f = f0 + fl;
+      ra[k] = (e < 32 * TF_JC && j < TOEP_H && f < F) ? y2[(int64_t)f * (TOEP_C * TOEP_H) + c * TOEP_H + j] : 0.f;
+    }
 #pragma unroll
-        for (int bb = 0; bb < BT; ++bb) {
-          int e = e0 + 256 * bb;
-          int fl = e / TF_JC, jj = e - fl * TF_JC;
-          if (e < 32 * TF_JC) tA[fl * TF_ASTR + jj] = v[bb];
-        }
-      }
-      __syncthreads();
+    for (int k = 0; k < TF_WPT; ++k) {
+      int i = tid + 256 * k;
+      rw[k] = i < WROW ? Wc[c * WROW + i] : 0.f;
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* tA = lds + buf * TF_BUF;
+    float* tW = tA + 32 * TF_ASTR;
+#pragma unroll
+    for (int k = 0; k < TF_EPT; ++k) {
+      int e = tid + 256 * k;
+      int fl = e / TF_JC, jj = e - fl * TF_JC;
+      if (e < 32 * TF_JC) tA[fl * TF_ASTR + jj] = ra[k];
+    }
+#pragma unroll
+    for (int k = 0; k < TF_WPT; ++k) {
+      int i = tid + 256 * k;
+      if (i < WROW) tW[i] = rw[k];
+    }
+  };
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int chunk = 0; chunk < 2 * TOEP_C; ++chunk) {
+    if (chunk + 1 < 2 * TOEP_C) gload(chunk + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const float* tA = lds + (chunk & 1) * TF_BUF;
+      const float* tW = tA + 32 * TF_ASTR;
+      const int jc0 = (chunk & 1) * TF_JC;
       const float* ap = tA + l31 * TF_ASTR + lh;
       // B index: Wc[c][p - j + 512], p = p0 + nb*32 + l31, j = jc0 + 2*s + lh
-      const float* wp = tW + c * WROW + WPRE + 512 + p0 + l31 - lh - jc0;
+      const float* wp = tW + WPRE + 512 + p0 + l31 - lh - jc0;
 #pragma unroll 3
       for (int s = 0; s < TF_JC / 2; ++s) {
         float av = ap[2 * s];
@@ -70,6 +94,9 @@ __global__ void __launch_bounds__(256) k_toep_fwd(const float* __restrict__ y2, 
         for (int nb = 0; nb < NBW; ++nb) acc[nb] = mfma32(av, wp[nb * 32 - 2 * s], acc[nb]);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (chunk + 1 < 2 * TOEP_C) lstore((chunk + 1) & 1);
+    __syncthreads();
   }
   const float bb = bias[0];
 #pragma unroll
