@@ -90,6 +90,47 @@ __device__ __forceinline__ void stage_range(const float* __restrict__ src, int t
   }
 }
 
+// Row-wise staging HBM -> LDS for tensors whose rows (ROWLEN contiguous floats) keep their order in
+// LDS: one wave copies RU rows per trip; the row index is wave-uniform, so row base addresses and
+// the LayerNorm constants live in scalar registers (LN folded to one fma: y = lrelu(v*sc + sh),
+// exactly the form tf.nn.batch_normalization uses).  rowinfo(r, src_off, dst_off, sc, sh).
+template <int ROWLEN, int NWAVES, bool LN, class RowInfo>
+__device__ __forceinline__ void stage_rows(const float* __restrict__ src, float* __restrict__ dst, int nrows,
+                                           RowInfo&& rowinfo) {
+  constexpr int RU = ROWLEN >= 256 ? 2 : 4;          // rows in flight per wave
+  constexpr int PER = (ROWLEN + 63) / 64;            // loads per row and lane
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int r0 = wave * RU; r0 < nrows; r0 += NWAVES * RU) {
+    float v[RU][PER];
+    int doff[RU];
+    float sc[RU], sh[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      int r = r0 + u < nrows ? r0 + u : nrows - 1;   // clamp: duplicates are harmless
+      int soff;
+      rowinfo(r, soff, doff[u], sc[u], sh[u]);
+#pragma unroll
+      for (int p = 0; p < PER; ++p) {
+        int i = lane + 64 * p;
+        v[u][p] = (i < ROWLEN) ? src[soff + i] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u)
+#pragma unroll
+      for (int p = 0; p < PER; ++p) {
+        int i = lane + 64 * p;
+        float x = v[u][p];
+        if constexpr (LN) {
+          x = x * sc[u] + sh[u];
+          x = fmaxf(x, LEAK * x);
+        }
+        if (i < ROWLEN) dst[doff[u] + i] = x;
+      }
+  }
+}
+
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int rup(int a, int b) { return cdiv(a, b) * b; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }

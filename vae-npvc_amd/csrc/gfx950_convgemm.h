@@ -104,6 +104,22 @@ __device__ __forceinline__ void conv_stage(const ConvArgs& a, float* tile, int f
       }
       tile[f * C::FSTR + k * C::CSTR + C::HLO] = v;
     }
+  } else if constexpr (C::HIN >= 32) {
+    // rows = (frame, channel) x HIN contiguous bins; row index is wave-uniform
+    const float* src = a.in + (int64_t)f0 * PER;
+    auto rowinfo = [&](int r, int& soff, int& doff, float& sc, float& sh) {
+      int f = r / C::KC, k = r - f * C::KC;
+      soff = r * C::HIN;
+      doff = f * C::FSTR + k * C::CSTR + C::HLO;
+      sc = 1.f;
+      sh = 0.f;
+      if constexpr (C::INKIND == IN_LN) {
+        float mean = a.st[2 * (f0 + f)], rstd = a.st[2 * (f0 + f) + 1];
+        sc = rstd * a.gamma[k / C::LNDIV];
+        sh = a.beta[k / C::LNDIV] - mean * sc;
+      }
+    };
+    stage_rows<C::HIN, C::NW, C::INKIND == IN_LN>(src, tile, nfr * C::KC, rowinfo);
   } else {
     auto put = [&](int e, float v) {
       int f = e / PER;

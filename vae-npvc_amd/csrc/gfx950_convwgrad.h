@@ -50,6 +50,50 @@ struct WgArgs {
   int fchunk;  // frames per blockIdx.x (multiple of TF)
 };
 
+// Row-wise staging (see stage_rows); here the scale/shift is ALWAYS applied so that rows outside
+// the chunk / channel range are written as zeros (sc = sh = 0).
+template <int ROWLEN, bool LN, class RowInfo>
+__device__ __forceinline__ void wg_stage_rows(const float* __restrict__ src, float* __restrict__ dst, int nrows,
+                                              RowInfo&& rowinfo) {
+  constexpr int RU = ROWLEN >= 256 ? 2 : 4;
+  constexpr int PER = (ROWLEN + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int r0 = wave * RU; r0 < nrows; r0 += 4 * RU) {
+    float v[RU][PER];
+    int doff[RU];
+    float sc[RU], sh[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      int r = r0 + u < nrows ? r0 + u : nrows - 1;
+      int soff;
+      rowinfo(r, soff, doff[u], sc[u], sh[u]);
+#pragma unroll
+      for (int p = 0; p < PER; ++p) {
+        int i = lane + 64 * p;
+        v[u][p] = (i < ROWLEN) ? src[soff + i] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u)
+#pragma unroll
+      for (int p = 0; p < PER; ++p) {
+        int i = lane + 64 * p;
+        float x = v[u][p] * sc[u] + sh[u];
+        if constexpr (LN) x = fmaxf(x, LEAK * x);
+        if (i < ROWLEN) dst[doff[u] + i] = x;
+      }
+  }
+}
+template <class C, class RowInfo>
+__device__ __forceinline__ void stage_rows_x(const float* src, float* dst, int nrows, int, RowInfo&& ri) {
+  wg_stage_rows<C::XH, C::XLN>(src, dst, nrows, ri);
+}
+template <class C, class RowInfo>
+__device__ __forceinline__ void stage_rows_y(const float* src, float* dst, int nrows, int, RowInfo&& ri) {
+  wg_stage_rows<C::YH, C::YLN>(src, dst, nrows, ri);
+}
+
 template <class C>
 __global__ void __launch_bounds__(256) k_convwgrad(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -85,6 +129,26 @@ __global__ void __launch_bounds__(256) k_convwgrad(WgArgs a) {
   for (int f0 = fb; f0 < fe; f0 += C::TF) {
     __syncthreads();  // previous sub-tile consumed (first pass: zero fill done)
     const int nfr = min(C::TF, fe - f0);
+    // Both tiles are staged row-wise (row = one channel of one frame, wave-uniform index);
+    // frames past the chunk end and channels past YC are clamped on load and zeroed by scale 0.
+    if constexpr (C::XH >= 32) {
+      const float* src = a.X + (int64_t)f0 * XPER;
+      auto rowx = [&](int r, int& soff, int& doff, float& sc, float& sh) {
+        int f = r / C::XC, xc = r - f * C::XC;
+        bool ok = f < nfr;
+        int fs = ok ? f : 0;
+        soff = (fs * C::XC + xc) * C::XH;
+        doff = f * C::FSTRX + xc * C::CSTRX + C::HLO;
+        sc = ok ? 1.f : 0.f;
+        sh = 0.f;
+        if constexpr (C::XLN) {
+          float mean = a.xst[2 * (f0 + fs)], rstd = a.xst[2 * (f0 + fs) + 1];
+          sc = ok ? rstd * a.xg[xc] : 0.f;
+          sh = ok ? a.xb[xc] - mean * sc : 0.f;
+        }
+      };
+      stage_rows_x<C>(src, tX, C::TF * C::XC, nfr, rowx);
+    } else
     {  // X tile: nfr whole frames are one contiguous HBM range
       auto putx = [&](int e, float v) {
         int f = e / XPER, rem = e - f * XPER;
@@ -100,6 +164,26 @@ __global__ void __launch_bounds__(256) k_convwgrad(WgArgs a) {
           tX[f * C::FSTRX + xc * C::CSTRX + C::HLO + i] = 0.f;
         }
     }
+    if constexpr (C::YH >= 32) {
+      constexpr int YFR = C::YC * C::YH;
+      const float* src = a.Y + (int64_t)f0 * YFR + (int64_t)nc0 * C::YH;
+      const int ych = min(C::NTW * 32, C::YC - nc0);  // valid channels of this workgroup
+      auto rowy = [&](int r, int& soff, int& doff, float& sc, float& sh) {
+        int f = r / (C::NTW * 32), nl = r - f * (C::NTW * 32);
+        bool ok = f < nfr && nl < ych;
+        int fs = ok ? f : 0, ns = ok ? nl : 0;
+        soff = fs * YFR + ns * C::YH;
+        doff = f * C::FSTRY + nl * C::CSTRY;
+        sc = ok ? 1.f : 0.f;
+        sh = 0.f;
+        if constexpr (C::YLN) {
+          float mean = a.yst[2 * (f0 + fs)], rstd = a.yst[2 * (f0 + fs) + 1];
+          sc = ok ? rstd * a.yg[nc0 + ns] : 0.f;
+          sh = ok ? a.yb[nc0 + ns] - mean * sc : 0.f;
+        }
+      };
+      stage_rows_y<C>(src, tY, C::TF * C::NTW * 32, nfr, rowy);
+    } else
     {  // Y tile: per frame the valid channels of this workgroup are one contiguous run
       constexpr int YFR = C::YC * C::YH;              // floats per frame of Y
       const int ych = min(C::NTW * 32, C::YC - nc0);  // valid channels
