@@ -56,7 +56,7 @@ def cpu_baseline(arch, seconds):
     import torch
     from oracle import convvae_oracle as O
     F = 256
-    threads = int(os.environ.get('VAENPVC_CPU_THREADS', min(os.cpu_count() or 1, 32)))   # more threads oversubscribe this small model
+    threads = int(os.environ.get('VAENPVC_CPU_THREADS', min(os.cpu_count() or 1, 16)))   # measured on the MI355X box: 16 threads is the fastest (8: 865, 16: 1678, 32: 1237, 64: 857 frames/s)
     torch.set_num_threads(threads)
     P = O.torch_params(O.init_params(arch, 0), torch.float32, requires_grad=True)
     x, y, eps = O.make_inputs(arch, F, 0)
@@ -172,8 +172,18 @@ def main():
     if kern:
         avg_ms, n = kern
         ach = DEC3_FLOP_PER_FRAME * F / (avg_ms * 1e-3) / 1e12
+        # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (separate
+        # --pmc runs of this same command, FETCH_SIZE/WRITE_SIZE in KiB; see profiles/README.md)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fp:
+                t = json.load(fp).get(args.timer_tag)
+                if t and t.get('frames') == F:
+                    traffic = t['hbm_bytes_per_launch']
+        except (OSError, ValueError):
+            pass
         out['roofline'] = {'bound': 'mfma', 'kernel': args.timer_tag, 'achieved': ach, 'peak': FP32_PEAK / 1e12,
-                           'unit': 'TFLOP/s', 'frac': ach / (FP32_PEAK / 1e12), 'traffic': None,
+                           'unit': 'TFLOP/s', 'frac': ach / (FP32_PEAK / 1e12), 'traffic': traffic,
                            'avg_kernel_ms': avg_ms, 'launches': n,
                            'algorithmic_flops_per_launch': DEC3_FLOP_PER_FRAME * F}
     if not args.no_literal:
