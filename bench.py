@@ -188,7 +188,21 @@ def main():
                            'algorithmic_flops_per_launch': DEC3_FLOP_PER_FRAME * F}
     if not args.no_literal:
         dt2, _ = timed(256, 50, 5)
-        out['config']['literal_batch256'] = {'frames_per_s': world * 256 * 50 / dt2, 'ms_per_step': dt2 / 50 * 1e3}
+        lit = {'frames_per_s': world * 256 * 50 / dt2, 'ms_per_step': dt2 / 50 * 1e3, 'launch': 'eager'}
+        if world == 1:
+            # same step captured in a hipGraph (one launch per step instead of ~130)
+            x, y, eps = make_batch(256, 99)
+            st.capture(x, y, eps)
+            for _ in range(5):
+                st.replay()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                st.replay()
+            barrier()
+            dtg = time.perf_counter() - t0
+            lit['hipgraph'] = {'frames_per_s': 256 * 200 / dtg, 'ms_per_step': dtg / 200 * 1e3}
+        out['config']['literal_batch256'] = lit
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(arch, args.cpu_seconds)
     if rank == 0:

@@ -130,6 +130,13 @@ int vaenpvc_adam_step(float* d_params, const float* d_grads, float* d_m, float* 
                       int64_t step, float lr, float beta1, float beta2, float eps,
                       float grad_scale, void* stream);
 
+/* Same update, but the step counter lives in device memory: the kernel sequence first
+ * increments *d_step (int64) and derives lr_t from it on the device, so the call can be
+ * captured in a hipGraph and replayed (trainer/vae.py:94-99 hot loop without host work). */
+int vaenpvc_adam_step_dev(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n,
+                          int64_t* d_step, float lr, float beta1, float beta2, float eps,
+                          float grad_scale, void* stream);
+
 /* Tanhize.forward_process / backward_process (analyzer.py:82-87), per bin:
  * fwd: clip((x-xmin)/(xmax-xmin),0,1)*2-1 ; bwd: (x*.5+.5)*(xmax-xmin)+xmin.
  * d_xmin/d_xmax: float32 [H]. In-place allowed. */

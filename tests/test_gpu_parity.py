@@ -370,3 +370,33 @@ def test_tuned_vs_generic_large_batch():
         n = int(np.prod(shape))
         check('F2048 tuned-vs-generic grad ' + name, res['auto'][1][off:off + n], res['generic'][1][off:off + n], 2e-3, fails)
     assert not fails, '\n'.join(fails)
+
+
+def test_hipgraph_replay_matches_eager():
+    """Stepper.capture/replay (one hipGraph launch per train step) follows the eager trajectory."""
+    from hipvae.dp import Stepper
+    arch = ARCHS['vcc']
+    F = 16                                    # the reference's own batch size
+    P = O.init_params(arch, 3)
+    x, y, eps = O.make_inputs(arch, F, 3)
+    res = []
+    for use_graph in (False, True):
+        eng = make_engine('vcc', 'auto')
+        xt, yt, et = upload(eng, P, x, y, eps)
+        st = Stepper(eng, 1e-4, 0.5, 0.999)
+        if use_graph:
+            st.capture(xt, yt, et)
+            for _ in range(3):
+                l3 = st.replay()
+        else:
+            for _ in range(3):
+                l3 = st.step(xt, yt, et)
+        torch.cuda.synchronize()
+        assert st.step_count == 3
+        res.append((eng.params.cpu().numpy().copy(), l3.cpu().numpy().copy()))
+    p0 = O.flatten_params(P)
+    d_eager, d_graph = res[0][0] - p0, res[1][0] - p0
+    # atomics make the fp32 summation order run-dependent; compare the updates, not bits
+    assert np.abs(d_eager - d_graph).max() <= 0.02 * np.abs(d_eager).max() or \
+        np.mean(np.abs(d_eager - d_graph) > 0.05 * np.abs(d_eager).max()) < 0.02
+    assert np.allclose(res[0][1], res[1][1], rtol=1e-4)

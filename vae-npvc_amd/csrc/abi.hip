@@ -273,6 +273,13 @@ int vaenpvc_adam_step(float* d_params, const float* d_grads, float* d_m, float* 
   return check_launch("adam_step");
 }
 
+int vaenpvc_adam_step_dev(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n, int64_t* d_step,
+                          float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  if (!d_params || !d_grads || !d_m || !d_v || !d_step || n < 1) return fail(VAENPVC_E_ARG, "bad argument");
+  launch_adam_dev(d_params, d_grads, d_m, d_v, n, d_step, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
+  return check_launch("adam_step_dev");
+}
+
 int vaenpvc_tanhize_fwd(const float* d_sp, const float* d_xmin, const float* d_xmax, float* d_x, int64_t F,
                         int32_t H, void* stream) {
   if (!d_sp || !d_xmin || !d_xmax || !d_x || F < 1 || H < 1) return fail(VAENPVC_E_ARG, "bad argument");

@@ -65,6 +65,8 @@ void bwd_enc_layer(const Model& m, const float* P, const float* x, int64_t F, co
 // ---- elementwise / optimiser kernels (misc_kernels.hip) -------------------------
 void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
                  float eps, float gscale, hipStream_t s);
+void launch_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, int64_t* d_step, float lr, float b1,
+                     float b2, float eps, float gscale, hipStream_t s);
 void launch_tanhize(const float* in, const float* xmin, const float* xmax, float* out, int64_t F, int H,
                     bool forward, hipStream_t s);
 void launch_unpack(const float* rec, int64_t F, int rec_floats, int H, const float* xmin, const float* xmax,

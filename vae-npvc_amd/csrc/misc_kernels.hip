@@ -41,6 +41,38 @@ void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float 
                      gscale);
 }
 
+// graph-replayable variant: step counter in device memory
+__global__ void k_step_inc(int64_t* d_step) { *d_step += 1; }
+
+__global__ void k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                           float* __restrict__ v, int64_t n, const int64_t* __restrict__ d_step, float lr, float b1,
+                           float b2, float eps, float gs) {
+  __shared__ float s_lrt;
+  if (threadIdx.x == 0) {
+    double t = (double)*d_step;
+    s_lrt = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+  }
+  __syncthreads();
+  const float lr_t = s_lrt;
+  int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  for (int64_t i = i4; i < n && i < i4 + 4; ++i) {
+    float gk = g[i] * gs;
+    float mk = b1 * m[i] + (1.0f - b1) * gk;
+    float vk = b2 * v[i] + (1.0f - b2) * gk * gk;
+    m[i] = mk;
+    v[i] = vk;
+    p[i] = p[i] - lr_t * mk / (sqrtf(vk) + eps);
+  }
+}
+
+void launch_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, int64_t* d_step, float lr, float b1,
+                     float b2, float eps, float gscale, hipStream_t s) {
+  hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, s, d_step);
+  int64_t nt = (n + 3) / 4;
+  hipLaunchKernelGGL(k_adam_dev, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, d_step, lr, b1, b2, eps,
+                     gscale);
+}
+
 // Tanhize (analyzer.py:77-87)
 __global__ void k_tanhize(const float* __restrict__ in, const float* __restrict__ xmin,
                           const float* __restrict__ xmax, float* __restrict__ out, int64_t N, int H, bool fwd) {

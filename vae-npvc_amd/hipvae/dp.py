@@ -54,6 +54,46 @@ class Stepper(object):
                                self.eps, 1.0 / self.world)
         return loss3
 
+    # ------------------------------------------------------------------ hipGraph replay
+    def capture(self, x, y, eps):
+        """Capture one single-GPU train step (forward+backward+Adam, ~130 kernel launches) in a
+        hipGraph on static copies of (x, y, eps); `replay()` then runs a step with one launch.
+        Launch overhead dominates below a few thousand frames per step (the reference trains
+        with batch 16).  The optimiser state is snapshotted around the capture warm-up, so the
+        trajectory is unchanged.  Returns the static input tensors to copy new batches into."""
+        if self.world != 1:
+            raise RuntimeError('graph capture is implemented for single-process training only')
+        be = self.backend
+        self._gx, self._gy, self._ge = x.clone(), y.clone(), eps.clone()
+        self._d_step = torch.full((1,), self.step_count, dtype=torch.int64, device=be.params.device)
+        snap = (be.params.clone(), self.m.clone(), self.v.clone())
+
+        def one_step():
+            l3 = be.train_fwd_bwd(self._gx, self._gy, self._ge, self.grads)
+            be.adam_step_dev(self.grads, self.m, self.v, self._d_step, self.lr, self.beta1, self.beta2, self.eps, 1.0)
+            return l3
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                      # warm-up: module loads, attribute calls, workspace
+                one_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._gl3 = one_step()
+        be.params.copy_(snap[0])
+        self.m.copy_(snap[1])
+        self.v.copy_(snap[2])
+        self._d_step.fill_(self.step_count)
+        return self._gx, self._gy, self._ge
+
+    def replay(self):
+        """One captured step on the current contents of the static inputs; returns loss3."""
+        self._graph.replay()
+        self.step_count += 1
+        return self._gl3
+
     def mean_losses(self, loss3):
         """Average {G, D_KL, logP} over ranks (logging only)."""
         out = loss3.clone()

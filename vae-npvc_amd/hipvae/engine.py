@@ -227,6 +227,13 @@ class Engine(object):
                                            self.n_params, int(step), float(lr), float(beta1), float(beta2),
                                            float(eps), float(grad_scale), self._stream()), 'adam_step')
 
+    def adam_step_dev(self, grads, m, v, d_step, lr, beta1, beta2, eps=1e-8, grad_scale=1.0):
+        """Graph-capturable Adam: the int64 step counter `d_step` lives on the device."""
+        L.check(self.lib.vaenpvc_adam_step_dev(self.params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                               self.n_params, d_step.data_ptr(), float(lr), float(beta1),
+                                               float(beta2), float(eps), float(grad_scale), self._stream()),
+                'adam_step_dev')
+
     # ------------------------------------------------------------------ data plane
     def tanhize(self, sp, xmin, xmax, forward=True):
         sp = sp.contiguous()

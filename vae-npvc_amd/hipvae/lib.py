@@ -50,6 +50,7 @@ SIGNATURES = {
     'vaenpvc_train_fwd_bwd': (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _P, C.c_size_t, _P]),
     'vaenpvc_loss_fwd': (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, C.c_size_t, _P]),
     'vaenpvc_adam_step': (C.c_int, [_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _P]),
+    'vaenpvc_adam_step_dev': (C.c_int, [_P, _P, _P, _P, _I64, _P, _F, _F, _F, _F, _F, _P]),
     'vaenpvc_tanhize_fwd': (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P]),
     'vaenpvc_tanhize_bwd': (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P]),
     'vaenpvc_set_tuned_masks': (C.c_int, [C.c_uint32, C.c_uint32]),
