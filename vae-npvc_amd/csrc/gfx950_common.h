@@ -90,6 +90,8 @@ __device__ __forceinline__ void stage_range(const float* __restrict__ src, int t
   }
 }
 
+constexpr int cmax_c(int a, int b) { return a > b ? a : b; }
+constexpr int cmin_c(int a, int b) { return a < b ? a : b; }
 // Row-wise staging HBM -> LDS for tensors whose rows (ROWLEN contiguous floats) keep their order in
 // LDS: one wave copies RU rows per trip; the row index is wave-uniform, so row base addresses and
 // the LayerNorm constants live in scalar registers (LN folded to one fma: y = lrelu(v*sc + sh),
@@ -97,8 +99,8 @@ __device__ __forceinline__ void stage_range(const float* __restrict__ src, int t
 template <int ROWLEN, int NWAVES, bool LN, class RowInfo>
 __device__ __forceinline__ void stage_rows(const float* __restrict__ src, float* __restrict__ dst, int nrows,
                                            RowInfo&& rowinfo) {
-  constexpr int RU = ROWLEN >= 256 ? 2 : 4;          // rows in flight per wave
   constexpr int PER = (ROWLEN + 63) / 64;            // loads per row and lane
+  constexpr int RU = cmax_c(2, cmin_c(16, 32 / PER)); // rows in flight per wave (~32 loads per lane)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int r0 = wave * RU; r0 < nrows; r0 += NWAVES * RU) {

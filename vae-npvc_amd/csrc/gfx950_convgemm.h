@@ -132,7 +132,7 @@ __device__ __forceinline__ void conv_stage(const ConvArgs& a, float* tile, int f
       }
       tile[f * C::FSTR + k * C::CSTR + C::HLO + i] = v;
     };
-    stage_range<(PER % 4 == 0) ? 4 : 1, (PER % 4 == 0) ? 4 : 8, C::NTHR>(a.in + (int64_t)f0 * PER, total, put);
+    stage_range<(PER % 4 == 0) ? 4 : 1, (PER % 4 == 0) ? 8 : 16, C::NTHR>(a.in + (int64_t)f0 * PER, total, put);
   }
   __syncthreads();
 }

@@ -55,8 +55,8 @@ struct WgArgs {
 template <int ROWLEN, bool LN, class RowInfo>
 __device__ __forceinline__ void wg_stage_rows(const float* __restrict__ src, float* __restrict__ dst, int nrows,
                                               RowInfo&& rowinfo) {
-  constexpr int RU = ROWLEN >= 256 ? 2 : 4;
   constexpr int PER = (ROWLEN + 63) / 64;
+  constexpr int RU = cmax_c(2, cmin_c(16, 32 / PER));  // ~32 loads in flight per lane
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int r0 = wave * RU; r0 < nrows; r0 += 4 * RU) {
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256) k_convwgrad(WgArgs a) {
         if constexpr (C::XLN) v = lnact_v(v, a.xst[2 * (f0 + f)], a.xst[2 * (f0 + f) + 1], a.xg[xc], a.xb[xc]);
         tX[f * C::FSTRX + xc * C::CSTRX + C::HLO + i] = v;
       };
-      stage_range<(XPER % 4 == 0) ? 4 : 1, 4>(a.X + (int64_t)f0 * XPER, nfr * XPER, putx);
+      stage_range<(XPER % 4 == 0) ? 4 : 1, 8>(a.X + (int64_t)f0 * XPER, nfr * XPER, putx);
       if (nfr < C::TF)  // tail of the chunk: frames beyond it must read as zero
         for (int e = nfr * XPER + tid; e < C::TF * XPER; e += 256) {
           int f = e / XPER, rem = e - f * XPER;
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) k_convwgrad(WgArgs a) {
       const int ych = min(C::NTW * 32, C::YC - nc0);  // valid channels
       const int yper = ych * C::YH;
       const int ytot = C::TF * yper;
-      constexpr int BT = 8;
+      constexpr int BT = 16;
       for (int e0 = tid; e0 < ytot; e0 += 256 * BT) {
         float v[BT];
 #pragma unroll

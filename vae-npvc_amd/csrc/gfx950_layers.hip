@@ -271,6 +271,36 @@ static TnArgs tn_args(const float* X, int ldx, const float* Y, int ldy, int M, i
   a.fchunk = 0;
   return a;
 }
+// ---- side stream for the weight-gradient kernels --------------------------------------
+// Every weight gradient depends only on activations of the forward pass and on ONE gradient
+// tensor of the serial chain dgrad_i -> LN-backward_{i-1} -> dgrad_{i-1} ...; none of them is
+// on that chain.  They are forked onto a second stream (event fork at the point where their
+// gradient tensor is complete, one join at the end) so that they fill the MFMA pipes and the
+// kernel tails the chain leaves idle.  VAENPVC_SIDE_STREAM=0 disables the fork.
+struct Side {
+  hipStream_t s2 = nullptr;
+  hipEvent_t ev[16];
+  int next = 0;
+  bool enabled = true;
+  bool init() {
+    if (s2) return enabled;
+    const char* e = getenv("VAENPVC_SIDE_STREAM");
+    enabled = !(e && e[0] == '0');
+    if (!enabled) return false;
+    if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { enabled = false; return false; }
+    for (auto& x : ev) (void)hipEventCreateWithFlags(&x, hipEventDisableTiming);
+    return true;
+  }
+};
+static Side g_side;
+// make `to` wait for everything enqueued on `from` so far
+static void stream_dep(hipStream_t from, hipStream_t to) {
+  hipEvent_t e = g_side.ev[g_side.next];
+  g_side.next = (g_side.next + 1) % 16;
+  (void)hipEventRecord(e, from);
+  (void)hipStreamWaitEvent(to, e, 0);
+}
+
 static int kchunks_for(int F, int tiles) { return cmax(1, cmin_(cdiv(F, 64), 512 / tiles)); }  // 2 workgroups (64 KB LDS) per CU
 
 void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F64,
@@ -278,21 +308,26 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   read_env();
   const int F = (int)F64;
   (void)hipMemsetAsync(G, 0, (size_t)m.n_params * 4, s);
+  const bool fork = g_side.init();
+  hipStream_t s2 = fork ? g_side.s2 : s;   // weight-gradient stream
+  auto ready = [&]() { if (fork) stream_dep(s, s2); };   // "the tensors produced so far on s are ready for s2"
+  ready();
   bool dec_bias_done[4] = {false, false, false, false};
   bool enc_bias_done[5] = {false, false, false, false, false};
-  const int WGS = 1024;   // target workgroup count of the chunked reductions
+  const int WGS = 512;    // workgroups of the chunked weight-gradient reductions: 2 per CU (LDS-bound residency);
+                          // more chunks only deepen the same-address atomic chains on the small weight tensors
   const int LWGS = 2048;  // ... of the HBM-bound LayerNorm backward
 
   // ---- d3: the 1025-tap layer
   if (bwd_on(10)) {
     const ConvL& l2 = m.dec[2];
     TnArgs a = tn_args(w.dec_y, 4104, w.d_xh, 513, 4096, 512, F, G + m.dec[3].w_off, 0);
-    VAENPVC_TIMED("dec3_wgrad", s, launch_tngemm(a, true, kchunks_for(F, 32 * 4), s));
+    VAENPVC_TIMED("dec3_wgrad", s2, launch_tngemm(a, true, kchunks_for(F, 32 * 4), s2));
     int ech = cmax(1, cmin_(cdiv(F, 64), 256));
     int efc = cdiv(F, ech);
-    hipLaunchKernelGGL(k_toep_wgrad_edges, dim3((unsigned)cdiv(8200, 256), (unsigned)cdiv(F, efc)), dim3(256), 0, s, w.dec_y, w.d_xh,
+    hipLaunchKernelGGL(k_toep_wgrad_edges, dim3((unsigned)cdiv(8200, 256), (unsigned)cdiv(F, efc)), dim3(256), 0, s2, w.dec_y, w.d_xh,
                        G + m.dec[3].w_off, F, efc);
-    hipLaunchKernelGGL(k_sum_all_atomic, dim3((unsigned)cmin_(1024, cdiv(F * 513, 1024))), dim3(256), 0, s, w.d_xh,
+    hipLaunchKernelGGL(k_sum_all_atomic, dim3((unsigned)cmin_(1024, cdiv(F * 513, 1024))), dim3(256), 0, s2, w.d_xh,
                        (int64_t)F * 513, G + m.dec[3].b_off);
     static bool once = false;
     if (!once) {
@@ -311,7 +346,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const ConvL &l = m.dec[2], &pl = m.dec[1];
     WgArgs a{w.d_dec_a[2], nullptr, nullptr, nullptr, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off,
              G + l.w_off, F, 0};
-    VAENPVC_TIMED("dec2_wgrad", s, launch_convwgrad<WD2>(a, WGS, s));
+    ready();
+    VAENPVC_TIMED("dec2_wgrad", s2, launch_convwgrad<WD2>(a, WGS, s2));
     if (!dec_bias_done[2]) generic::bias_grad(w.d_dec_a[2], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("dec2_dgrad", s, launch_convgemm<GD2>(conv_args(w.d_dec_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::gd2,
                                                                   nullptr, w.dy_tmp, F), 1, s));
@@ -325,7 +361,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const ConvL &l = m.dec[1], &pl = m.dec[0];
     WgArgs a{w.d_dec_a[1], nullptr, nullptr, nullptr, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off,
              G + l.w_off, F, 0};
-    VAENPVC_TIMED("dec1_wgrad", s, launch_convwgrad<WD1>(a, WGS, s));
+    ready();
+    VAENPVC_TIMED("dec1_wgrad", s2, launch_convwgrad<WD1>(a, WGS, s2));
     if (!dec_bias_done[1]) generic::bias_grad(w.d_dec_a[1], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("dec1_dgrad", s, launch_convgemm<GD1>(conv_args(w.d_dec_a[1], nullptr, nullptr, nullptr, P + l.w_off, nullptr,
                                                                   w.dy_tmp, F), 1, s));
@@ -338,7 +375,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   if (bwd_on(7)) {
     const ConvL& l = m.dec[0];
     WgArgs a{w.d_dec_a[0], nullptr, nullptr, nullptr, w.h, nullptr, nullptr, nullptr, G + l.w_off, F, 0};
-    VAENPVC_TIMED("dec0_wgrad", s, launch_convwgrad<WD0>(a, WGS, s));
+    ready();
+    VAENPVC_TIMED("dec0_wgrad", s2, launch_convwgrad<WD0>(a, WGS, s2));
     if (!dec_bias_done[0]) generic::bias_grad(w.d_dec_a[0], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("dec0_dgrad", s, launch_convgemm<GD0>(conv_args(w.d_dec_a[0], nullptr, nullptr, nullptr, w.scratch + Pk::gd0,
                                                                   nullptr, w.d_h, F), 1, s));
@@ -347,10 +385,11 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   // ---- merge + embedding
   if (bwd_on(6)) {
     TnArgs a = tn_args(w.z, 128, w.d_h, 1539, 128, 1539, F, G + m.wz_off, 1539);
-    VAENPVC_TIMED("merge_wgrad", s, launch_tngemm(a, false, kchunks_for(F, 13), s));
+    ready();
+    VAENPVC_TIMED("merge_wgrad", s2, launch_tngemm(a, false, kchunks_for(F, 13), s2));
     TnArgs b = tn_args(P + m.emb_off, 128, w.d_h, 1539, 128, 1539, F, G + m.wy_off, 1539);
     b.xidx = y;
-    launch_tngemm(b, false, kchunks_for(F, 13), s);
+    launch_tngemm(b, false, kchunks_for(F, 13), s2);
     int ch = cmax(1, cmin_(cdiv(F, 64), 128)), fc = cdiv(F, ch);
     hipLaunchKernelGGL(k_colsum_atomic, dim3((unsigned)cdiv(1539, 256), (unsigned)cdiv(F, fc)), dim3(256), 0, s, w.d_h, 1539, 1539,
                        F, fc, G + m.bz_off, G + m.by_off, G + m.bm_off);
@@ -372,10 +411,11 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     a.gamma = P + l4.gamma_off;
     a.beta = P + l4.beta_off;
     a.lndiv = 3;
-    VAENPVC_TIMED("heads_wgrad", s, launch_tngemm(a, false, kchunks_for(F, 6), s));
+    ready();
+    VAENPVC_TIMED("heads_wgrad", s2, launch_tngemm(a, false, kchunks_for(F, 6), s2));
     a.Y = w.d_z_lv;
     a.C = G + m.wlv_off;
-    launch_tngemm(a, false, kchunks_for(F, 6), s);
+    launch_tngemm(a, false, kchunks_for(F, 6), s2);
     int ch = cmax(1, cmin_(cdiv(F, 64), 256)), fc = cdiv(F, ch);
     hipLaunchKernelGGL(k_colsum_atomic, dim3(1, (unsigned)cdiv(F, fc)), dim3(256), 0, s, w.d_z_mu, 128, 128, F, fc,
                        G + m.bmu_off, nullptr, nullptr);
@@ -397,7 +437,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   };
   if (bwd_on(4)) {
     const ConvL &l = m.enc[4], &pl = m.enc[3];
-    VAENPVC_TIMED("enc4_wgrad", s, launch_convwgrad<WE4>(wg_enc(4), WGS, s));
+    ready();
+    VAENPVC_TIMED("enc4_wgrad", s2, launch_convwgrad<WE4>(wg_enc(4), WGS, s2));
     if (!enc_bias_done[4]) generic::bias_grad(w.d_enc_a[4], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("enc4_dgrad", s, launch_convgemm<GE4>(conv_args(w.d_enc_a[4], nullptr, nullptr, nullptr, w.scratch + Pk::ge4,
                                                                   nullptr, w.dy_tmp, F), 1, s));
@@ -407,7 +448,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 4);
   if (bwd_on(3)) {
     const ConvL &l = m.enc[3], &pl = m.enc[2];
-    VAENPVC_TIMED("enc3_wgrad", s, launch_convwgrad<WE3>(wg_enc(3), WGS, s));
+    ready();
+    VAENPVC_TIMED("enc3_wgrad", s2, launch_convwgrad<WE3>(wg_enc(3), WGS, s2));
     if (!enc_bias_done[3]) generic::bias_grad(w.d_enc_a[3], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("enc3_dgrad", s, launch_convgemm<GE3>(conv_args(w.d_enc_a[3], nullptr, nullptr, nullptr, w.scratch + Pk::ge3,
                                                                   nullptr, w.dy_tmp, F), 1, s));
@@ -417,7 +459,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 3);
   if (bwd_on(2)) {
     const ConvL &l = m.enc[2], &pl = m.enc[1];
-    VAENPVC_TIMED("enc2_wgrad", s, launch_convwgrad<WE2>(wg_enc(2), WGS, s));
+    ready();
+    VAENPVC_TIMED("enc2_wgrad", s2, launch_convwgrad<WE2>(wg_enc(2), WGS, s2));
     if (!enc_bias_done[2]) generic::bias_grad(w.d_enc_a[2], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("enc2_dgrad", s, launch_convgemm<GE2>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
                                                                   nullptr, w.dy_tmp, F), 1, s));
@@ -427,7 +470,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 2);
   if (bwd_on(1)) {
     const ConvL &l = m.enc[1], &pl = m.enc[0];
-    VAENPVC_TIMED("enc1_wgrad", s, launch_convwgrad<WE1>(wg_enc(1), WGS, s));
+    ready();
+    VAENPVC_TIMED("enc1_wgrad", s2, launch_convwgrad<WE1>(wg_enc(1), WGS, s2));
     if (!enc_bias_done[1]) generic::bias_grad(w.d_enc_a[1], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("enc1_dgrad", s, launch_convgemm<GE1>(conv_args(w.d_enc_a[1], nullptr, nullptr, nullptr, w.scratch + Pk::ge1,
                                                                   nullptr, w.dy_tmp, F), 1, s));
@@ -438,9 +482,11 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   if (bwd_on(0)) {
     const ConvL& l = m.enc[0];
     WgArgs a{x, nullptr, nullptr, nullptr, w.d_enc_a[0], nullptr, nullptr, nullptr, G + l.w_off, F, 0};
-    VAENPVC_TIMED("enc0_wgrad", s, launch_convwgrad<WE0>(a, WGS, s));
+    ready();
+    VAENPVC_TIMED("enc0_wgrad", s2, launch_convwgrad<WE0>(a, WGS, s2));
     if (!enc_bias_done[0]) generic::bias_grad(w.d_enc_a[0], G + l.b_off, F, l.cout, l.hout, s);
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 0);
+  if (fork) stream_dep(s2, s);  // join: everything after backward (Adam) sees all gradients
 }
 
 }  // namespace tuned
