@@ -141,6 +141,16 @@ static void stats(const float* a, float* st, int F, hipStream_t s) {
   hipLaunchKernelGGL(k_ln_stats_fast<N>, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, a, st, F);
 }
 
+// column-block split of a conv GEMM: 1 for large batches, up to all blocks when F/TF workgroups
+// would leave most of the 256 CUs idle (each extra split re-stages the input tile, which is cheap)
+template <class C>
+static int nsplit_for(int F) {
+  constexpr int NBLK = cdiv(C::NT, C::NB);
+  int wgs = cdiv(F, C::TF);
+  int want = cdiv(512, wgs);
+  return cmax(1, cmin_(NBLK, want));
+}
+
 static ConvArgs conv_args(const float* in, const float* st, const float* gamma, const float* beta, const float* Bp,
                           const float* bias, float* out, int F) {
   ConvArgs a;
@@ -173,19 +183,19 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
   auto lnp = [&](int i) { return conv_args(w.enc_a[i - 1], w.enc_st[i - 1], P + m.enc[i - 1].gamma_off, P + m.enc[i - 1].beta_off,
                                            P + m.enc[i].w_off, P + m.enc[i].b_off, w.enc_a[i], F); };
   if (fwd_on(1)) {
-    VAENPVC_TIMED("enc1_fwd", s, launch_convgemm<E1F>(lnp(1), 1, s));
+    VAENPVC_TIMED("enc1_fwd", s, launch_convgemm<E1F>(lnp(1), nsplit_for<E1F>(F), s));
     stats<1824>(w.enc_a[1], w.enc_st[1], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 1);
   if (fwd_on(2)) {
-    VAENPVC_TIMED("enc2_fwd", s, launch_convgemm<E2F>(lnp(2), 1, s));
+    VAENPVC_TIMED("enc2_fwd", s, launch_convgemm<E2F>(lnp(2), nsplit_for<E2F>(F), s));
     stats<1216>(w.enc_a[2], w.enc_st[2], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 2);
   if (fwd_on(3)) {
-    VAENPVC_TIMED("enc3_fwd", s, launch_convgemm<E3F>(lnp(3), 1, s));
+    VAENPVC_TIMED("enc3_fwd", s, launch_convgemm<E3F>(lnp(3), nsplit_for<E3F>(F), s));
     stats<896>(w.enc_a[3], w.enc_st[3], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 3);
   if (fwd_on(4)) {
-    VAENPVC_TIMED("enc4_fwd", s, launch_convgemm<E4F>(lnp(4), 1, s));
+    VAENPVC_TIMED("enc4_fwd", s, launch_convgemm<E4F>(lnp(4), nsplit_for<E4F>(F), s));
     stats<768>(w.enc_a[4], w.enc_st[4], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 4);
   if (fwd_on(5)) {
@@ -213,19 +223,19 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
   } else generic::merge_fwd(m, P, z, y, F, w, s);
   if (fwd_on(7)) {
     VAENPVC_TIMED("dec0_fwd", s, launch_convgemm<D0F>(conv_args(w.h, nullptr, nullptr, nullptr, w.scratch + Pk::d0f,
-                                                                P + m.dec[0].b_off, w.dec_a[0], F), 1, s));
+                                                                P + m.dec[0].b_off, w.dec_a[0], F), nsplit_for<D0F>(F), s));
     stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 0);
   if (fwd_on(8)) {
     VAENPVC_TIMED("dec1_fwd", s, launch_convgemm<D1F>(conv_args(w.dec_a[0], w.dec_st[0], P + m.dec[0].gamma_off,
                                                                 P + m.dec[0].beta_off, w.scratch + Pk::d1f,
-                                                                P + m.dec[1].b_off, w.dec_a[1], F), 1, s));
+                                                                P + m.dec[1].b_off, w.dec_a[1], F), nsplit_for<D1F>(F), s));
     stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 1);
   if (fwd_on(9)) {
     VAENPVC_TIMED("dec2_fwd", s, launch_convgemm<D2F>(conv_args(w.dec_a[1], w.dec_st[1], P + m.dec[1].gamma_off,
                                                                 P + m.dec[1].beta_off, w.scratch + Pk::d2f,
-                                                                P + m.dec[2].b_off, w.dec_a[2], F), 1, s));
+                                                                P + m.dec[2].b_off, w.dec_a[2], F), nsplit_for<D2F>(F), s));
     hipLaunchKernelGGL((k_ln_stats_act<4104, 513>), dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
                        P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, F);
   } else {
@@ -350,7 +360,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("dec2_wgrad", s2, launch_convwgrad<WD2>(a, WGS, s2));
     if (!dec_bias_done[2]) generic::bias_grad(w.d_dec_a[2], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("dec2_dgrad", s, launch_convgemm<GD2>(conv_args(w.d_dec_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::gd2,
-                                                                  nullptr, w.dy_tmp, F), 1, s));
+                                                                  nullptr, w.dy_tmp, F), nsplit_for<GD2>(F), s));
     launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[1],
                                       G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     dec_bias_done[1] = true;
@@ -365,7 +375,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("dec1_wgrad", s2, launch_convwgrad<WD1>(a, WGS, s2));
     if (!dec_bias_done[1]) generic::bias_grad(w.d_dec_a[1], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("dec1_dgrad", s, launch_convgemm<GD1>(conv_args(w.d_dec_a[1], nullptr, nullptr, nullptr, P + l.w_off, nullptr,
-                                                                  w.dy_tmp, F), 1, s));
+                                                                  w.dy_tmp, F), nsplit_for<GD1>(F), s));
     launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[0],
                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     dec_bias_done[0] = true;
@@ -379,7 +389,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("dec0_wgrad", s2, launch_convwgrad<WD0>(a, WGS, s2));
     if (!dec_bias_done[0]) generic::bias_grad(w.d_dec_a[0], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("dec0_dgrad", s, launch_convgemm<GD0>(conv_args(w.d_dec_a[0], nullptr, nullptr, nullptr, w.scratch + Pk::gd0,
-                                                                  nullptr, w.d_h, F), 1, s));
+                                                                  nullptr, w.d_h, F), nsplit_for<GD0>(F), s));
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 0);
 
   // ---- merge + embedding
@@ -441,7 +451,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc4_wgrad", s2, launch_convwgrad<WE4>(wg_enc(4), WGS, s2));
     if (!enc_bias_done[4]) generic::bias_grad(w.d_enc_a[4], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("enc4_dgrad", s, launch_convgemm<GE4>(conv_args(w.d_enc_a[4], nullptr, nullptr, nullptr, w.scratch + Pk::ge4,
-                                                                  nullptr, w.dy_tmp, F), 1, s));
+                                                                  nullptr, w.dy_tmp, F), nsplit_for<GE4>(F), s));
     launch_ln_bwd<LnbCfg<128, 7>>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[3],
                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     enc_bias_done[3] = true;
@@ -452,7 +462,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc3_wgrad", s2, launch_convwgrad<WE3>(wg_enc(3), WGS, s2));
     if (!enc_bias_done[3]) generic::bias_grad(w.d_enc_a[3], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("enc3_dgrad", s, launch_convgemm<GE3>(conv_args(w.d_enc_a[3], nullptr, nullptr, nullptr, w.scratch + Pk::ge3,
-                                                                  nullptr, w.dy_tmp, F), 1, s));
+                                                                  nullptr, w.dy_tmp, F), nsplit_for<GE3>(F), s));
     launch_ln_bwd<LnbCfg<64, 19>>(w.dy_tmp, w.enc_a[2], w.enc_st[2], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[2],
                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     enc_bias_done[2] = true;
@@ -463,7 +473,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc2_wgrad", s2, launch_convwgrad<WE2>(wg_enc(2), WGS, s2));
     if (!enc_bias_done[2]) generic::bias_grad(w.d_enc_a[2], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("enc2_dgrad", s, launch_convgemm<GE2>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
-                                                                  nullptr, w.dy_tmp, F), 1, s));
+                                                                  nullptr, w.dy_tmp, F), nsplit_for<GE2>(F), s));
     launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.enc_a[1], w.enc_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[1],
                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     enc_bias_done[1] = true;
@@ -474,7 +484,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc1_wgrad", s2, launch_convwgrad<WE1>(wg_enc(1), WGS, s2));
     if (!enc_bias_done[1]) generic::bias_grad(w.d_enc_a[1], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("enc1_dgrad", s, launch_convgemm<GE1>(conv_args(w.d_enc_a[1], nullptr, nullptr, nullptr, w.scratch + Pk::ge1,
-                                                                  nullptr, w.dy_tmp, F), 1, s));
+                                                                  nullptr, w.dy_tmp, F), nsplit_for<GE1>(F), s));
     launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.enc_a[0], w.enc_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[0],
                                       G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     enc_bias_done[0] = true;
