@@ -434,11 +434,11 @@ struct PackDense {
   }
 };
 
-// channel-major, zero padded copy of the 1025-tap kernel: Wc[c][4 + t] = W[t][c]
+// channel-major, zero padded copy of the 1025-tap kernel: Wc[c][8 + t] = W[t][c]  (row = 1040 floats)
 struct PackToep {
   const float* src;
   __device__ float operator()(int i) const {
-    int c = i / 1032, r = i - c * 1032 - 4;
+    int c = i / 1040, r = i - c * 1040 - 8;
     return (r >= 0 && r < 1025) ? src[r * 8 + c] : 0.f;
   }
 };

@@ -341,11 +341,17 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
                        (int64_t)F * 513, G + m.dec[3].b_off);
     static bool once = false;
     if (!once) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_dgrad), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_dgrad<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_dgrad<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS);
       once = true;
     }
-    VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL(k_toep_dgrad, dim3((unsigned)cdiv(F, 32), 8), dim3(256), TD_LDS, s, w.d_xh,
-                                                      w.scratch + Pk::wc, w.dy_tmp, F));
+    if (F >= 8192) {
+      VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL((k_toep_dgrad<8, 8>), dim3((unsigned)cdiv(F, 32), 1), dim3(512), TD_LDS, s, w.d_xh,
+                                                        w.scratch + Pk::wc, w.dy_tmp, F));
+    } else {
+      VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL((k_toep_dgrad<1, 4>), dim3((unsigned)cdiv(F, 32), 8), dim3(256), TD_LDS, s, w.d_xh,
+                                                        w.scratch + Pk::wc, w.dy_tmp, F));
+    }
     launch_ln_bwd<LnbCfg<8, 513>>(w.dy_tmp, w.dec_a[2], w.dec_st[2], P + l2.gamma_off, P + l2.beta_off, w.d_dec_a[2],
                                      G + l2.gamma_off, G + l2.beta_off, G + l2.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     dec_bias_done[2] = true;

@@ -2,8 +2,10 @@
 //
 // Both operands are contiguous along their M / N index in HBM and the reduction index
 // (frame) is the slow axis, which is exactly the fp32-MFMA operand shape: lanes 0..31 of
-// an A (B) fragment read 128 contiguous bytes of frame f, lanes 32..63 of frame f+1.  So
-// operands go HBM/L2 -> VGPR -> MFMA with no LDS staging at all.
+// an A (B) fragment read 32 consecutive floats of frame f, lanes 32..63 of frame f+1.  Chunks
+// of 32 frames are staged once per workgroup through LDS (register-prefetch double buffer);
+// a first version streamed HBM/L2 -> VGPR -> MFMA directly and stalled the L1 on duplicate
+// in-flight lines (TCP_PENDING_STALL 46 %).
 //
 // Used for  * dense weight gradients: dW_heads = y4^T dz, dW_merge = [z|e]^T dh
 //           * the weight gradient of the 1025-tap last decoder layer: the correlation
@@ -129,14 +131,32 @@ __global__ void __launch_bounds__(256) k_tngemm(TnArgs a) {
     {
       const float* px = lds + buf * TN_BUF + lh * 128 + wm + l31;
       const float* py = lds + buf * TN_BUF + TN_KF * 128 + lh * 128 + wn + l31;
-#pragma unroll 4
-      for (int k = 0; k < TN_KF / 2; ++k) {
-        float x0 = px[k * 256], x1 = px[k * 256 + 32];
-        float y0 = py[k * 256], y1 = py[k * 256 + 32];
+      // fragments of k-step k+1 are read before the MFMAs of k-step k (LDS latency off the MFMA chain)
+      float x0 = px[0], x1 = px[32], y0 = py[0], y1 = py[32];
+      float u0, u1, v0, v1;
+#pragma unroll
+      for (int k = 0; k < TN_KF / 2; k += 2) {
+        u0 = px[(k + 1) * 256];
+        u1 = px[(k + 1) * 256 + 32];
+        v0 = py[(k + 1) * 256];
+        v1 = py[(k + 1) * 256 + 32];
+        __builtin_amdgcn_sched_barrier(0);
         acc[0][0] = mfma32(x0, y0, acc[0][0]);
         acc[0][1] = mfma32(x0, y1, acc[0][1]);
         acc[1][0] = mfma32(x1, y0, acc[1][0]);
         acc[1][1] = mfma32(x1, y1, acc[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k2 = k + 2 < TN_KF / 2 ? k + 2 : k;
+        x0 = px[k2 * 256];
+        x1 = px[k2 * 256 + 32];
+        y0 = py[k2 * 256];
+        y1 = py[k2 * 256 + 32];
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = mfma32(u0, v0, acc[0][0]);
+        acc[0][1] = mfma32(u0, v1, acc[0][1]);
+        acc[1][0] = mfma32(u1, v0, acc[1][0]);
+        acc[1][1] = mfma32(u1, v1, acc[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -17,41 +17,49 @@ namespace vaenpvc {
 namespace tuned {
 
 constexpr int TOEP_H = 513, TOEP_C = 8, TOEP_T = 1025;
-constexpr int WROW = 1032;  // Wc row: 4 zero floats + 1025 taps + 3 zero floats
-constexpr int WPRE = 4;
+constexpr int WROW = 1040;  // Wc row: 8 zero floats + 1025 taps + 7 zero floats
+constexpr int WPRE = 8;
 
 // ---------------------------------------------------------------- forward
 // grid (ceil(F/32), NSPLIT); 256 threads; each wave owns 16/NSPLIT/4 column tiles.
-// K = (channel c, j) is walked in 16 chunks (8 channels x 2 halves of 258 j).  Double buffered:
+// K = (channel c, j) is walked in 16 chunks (8 channels x 2 halves of 260 j).  Double buffered:
 // while the MFMAs consume chunk i from LDS buffer i&1, the global loads of chunk i+1 are in
 // flight into registers; they are written to the other buffer after the MFMA block, one
-// __syncthreads per chunk.  The 1032-float weight row of the chunk's channel travels with it.
-constexpr int TF_JC = 258;           // j-chunk (2 chunks cover 516 >= 513)
+// __syncthreads per chunk.  The 1040-float weight row of the chunk's channel travels with it.
+// Staging is row-wise (wave w copies frames w, w+4, ...: no index arithmetic beyond one add),
+// and inside the MFMA block the fragments of k-step s+1 are read before the MFMAs of step s.
+constexpr int TF_JC = 260;           // j-chunk (2 chunks cover 520 >= 513), 130 k-steps (even)
 constexpr int TF_ASTR = TF_JC + 1;   // odd row stride -> conflict-free A gathers
 constexpr int TF_BUF = 32 * TF_ASTR + WROW;   // floats per buffer: A chunk + weight row
 constexpr int TF_LDS = 2 * TF_BUF * 4;
-constexpr int TF_EPT = (32 * TF_JC + 255) / 256;  // staged A elements per thread
+constexpr int TF_RPW = 8;                         // frames (rows) per wave
+constexpr int TF_LPR = (TF_JC + 63) / 64;         // loads per row and lane (5)
 constexpr int TF_WPT = (WROW + 255) / 256;
 
 template <int NBW>  // column tiles per wave (4 -> NSPLIT 1, 2 -> NSPLIT 2, 1 -> NSPLIT 4)
 __global__ void __launch_bounds__(256) k_toep_fwd(const float* __restrict__ y2, const float* __restrict__ Wc,
                                                   const float* __restrict__ bias, float* __restrict__ xh, int F) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int f0 = blockIdx.x * 32;
   const int p0 = (blockIdx.y * 4 + wave) * NBW * 32;
   f32x16 acc[NBW];
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) acc[nb] = zero16();
-  float ra[TF_EPT], rw[TF_WPT];
+  float ra[TF_RPW][TF_LPR], rw[TF_WPT];
   auto gload = [&](int chunk) {
     const int c = chunk >> 1, jc0 = (chunk & 1) * TF_JC;
 #pragma unroll
-    for (int k = 0; k < TF_EPT; ++k) {
-      int e = tid + 256 * k;
-      int fl = e / TF_JC, jj = e - fl * TF_JC;
-      int j = jc0 + jj, f = f0 + fl;
-      ra[k] = (e < 32 * TF_JC && j < TOEP_H && f < F) ? y2[(int64_t)f * (TOEP_C * TOEP_H) + c * TOEP_H + j] : 0.f;
+    for (int r = 0; r < TF_RPW; ++r) {
+      const int fl = wave + 4 * r;                       // wave-uniform
+      const int f = f0 + fl < F ? f0 + fl : F - 1;       // clamped; rows past F are never stored
+      const float* row = y2 + (int64_t)f * (TOEP_C * TOEP_H) + c * TOEP_H + jc0;
+#pragma unroll
+      for (int p = 0; p < TF_LPR; ++p) {
+        int jj = lane + 64 * p;
+        ra[r][p] = (jj < TF_JC && jc0 + jj < TOEP_H) ? row[jj] : 0.f;
+      }
     }
 #pragma unroll
     for (int k = 0; k < TF_WPT; ++k) {
@@ -63,11 +71,12 @@ __global__ void __launch_bounds__(256) k_toep_fwd(const float* __restrict__ y2, 
     float* tA = lds + buf * TF_BUF;
     float* tW = tA + 32 * TF_ASTR;
 #pragma unroll
-    for (int k = 0; k < TF_EPT; ++k) {
-      int e = tid + 256 * k;
-      int fl = e / TF_JC, jj = e - fl * TF_JC;
-      if (e < 32 * TF_JC) tA[fl * TF_ASTR + jj] = ra[k];
-    }
+    for (int r = 0; r < TF_RPW; ++r)
+#pragma unroll
+      for (int p = 0; p < TF_LPR; ++p) {
+        int jj = lane + 64 * p;
+        if (jj < TF_JC) tA[(wave + 4 * r) * TF_ASTR + jj] = ra[r][p];
+      }
 #pragma unroll
     for (int k = 0; k < TF_WPT; ++k) {
       int i = tid + 256 * k;
@@ -87,11 +96,26 @@ __global__ void __launch_bounds__(256) k_toep_fwd(const float* __restrict__ y2, 
       const float* ap = tA + l31 * TF_ASTR + lh;
       // B index: Wc[c][p - j + 512], p = p0 + nb*32 + l31, j = jc0 + 2*s + lh
       const float* wp = tW + WPRE + 512 + p0 + l31 - lh - jc0;
-#pragma unroll 3
-      for (int s = 0; s < TF_JC / 2; ++s) {
-        float av = ap[2 * s];
+      // software pipeline: fragments of step s+1 (s+2) are in flight while step s computes
+      float a0 = ap[0], a1;
+      float b0[NBW], b1[NBW];
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) acc[nb] = mfma32(av, wp[nb * 32 - 2 * s], acc[nb]);
+      for (int nb = 0; nb < NBW; ++nb) b0[nb] = wp[nb * 32];
+      for (int s = 0; s < TF_JC / 2; s += 2) {
+        a1 = ap[2 * (s + 1)];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) b1[nb] = wp[nb * 32 - 2 * (s + 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) acc[nb] = mfma32(a0, b0[nb], acc[nb]);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = ap[2 * (s + 2)];   // last trip reads one k-step past the chunk: still inside the buffer
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) b0[nb] = wp[nb * 32 - 2 * (s + 2)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) acc[nb] = mfma32(a1, b1[nb], acc[nb]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -125,63 +149,102 @@ __global__ void __launch_bounds__(256) k_toep_fwd_lastcol(const float* __restric
 }
 
 // ---------------------------------------------------------------- input gradient
-// grid (ceil(F/32), 8 channels); 256 threads; wave w owns column tiles j0 = (4w..4w+3)*32.
-constexpr int TD_ASTR = 515;  // dxh row in LDS: 513 values + 1 zero (K padded to 514) ; odd stride
-constexpr int TD_LDS = (32 * TD_ASTR + WROW) * 4;
+// grid (ceil(F/32), 8/CPW); 256 threads; wave w owns column tiles j0 = (4w..4w+3)*32.
+// The dxh tile of 32 frames (66 KB) is staged ONCE and reused for CPW channels (CPW = 8 for large
+// batches: staging drops to ~2 % of the workgroup's time; CPW = 1 keeps small batches parallel).
+constexpr int TD_K = 516;     // reduction length p padded to an even number of k-steps (258)
+constexpr int TD_ASTR = 517;  // dxh row in LDS: 513 values + zeros up to TD_K ; odd stride
+constexpr int TD_LDS = (32 * TD_ASTR + 2 * WROW) * 4;   // A tile + two weight rows (ping-pong)
+constexpr int TD_LPR = (TOEP_H + 63) / 64;  // loads per row and lane (9; the 9th covers p = 512)
 
-__global__ void __launch_bounds__(256) k_toep_dgrad(const float* __restrict__ dxh, const float* __restrict__ Wc,
+template <int CPW, int NWV>
+__global__ void __launch_bounds__(NWV * 64) k_toep_dgrad(const float* __restrict__ dxh, const float* __restrict__ Wc,
                                                     float* __restrict__ dy, int F) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* tA = lds;
   float* tW = lds + 32 * TD_ASTR;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int f0 = blockIdx.x * 32, c = blockIdx.y;
-  for (int i = tid; i < WROW; i += 256) tW[i] = Wc[c * WROW + i];
-  {
-    constexpr int BT = 8;
-    for (int e0 = tid; e0 < 32 * TD_ASTR; e0 += 256 * BT) {
-      float v[BT];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int f0 = blockIdx.x * 32, c0 = blockIdx.y * CPW;
+  constexpr int NT = NWV * 64, NBW = 16 / NWV, RPW = 32 / NWV;   // threads, column tiles and frames per wave
+  for (int i = tid; i < WROW; i += NT) tW[i] = Wc[c0 * WROW + i];
+  // row-wise staging: wave w copies frames w, w+4, ... (4 rows = 36 loads in flight per lane)
 #pragma unroll
-      for (int bb = 0; bb < BT; ++bb) {
-        int e = e0 + 256 * bb;
-        int fl = e / TD_ASTR, p = e - fl * TD_ASTR;
-        v[bb] = (e < 32 * TD_ASTR && p < TOEP_H && f0 + fl < F) ? dxh[(int64_t)(f0 + fl) * TOEP_H + p] : 0.f;
+  for (int half = 0; half < RPW / 4; ++half) {
+    float v[4][TD_LPR];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int fl = wave + NWV * (half * 4 + r);
+      const int f = f0 + fl < F ? f0 + fl : F - 1;
+      const float* row = dxh + (int64_t)f * TOEP_H;
+#pragma unroll
+      for (int p = 0; p < TD_LPR; ++p) {
+        int i = lane + 64 * p;
+        v[r][p] = (i < TOEP_H && f0 + fl < F) ? row[i] : 0.f;
       }
+    }
 #pragma unroll
-      for (int bb = 0; bb < BT; ++bb) {
-        int e = e0 + 256 * bb;
-        if (e < 32 * TD_ASTR) tA[e] = v[bb];
+    for (int r = 0; r < 4; ++r) {
+      const int fl = wave + NWV * (half * 4 + r);
+#pragma unroll
+      for (int p = 0; p < TD_LPR; ++p) {
+        int i = lane + 64 * p;
+        if (i < TD_ASTR) tA[fl * TD_ASTR + i] = v[r][p];   // i in [513, 517) gets the zero padding
       }
     }
   }
   __syncthreads();
-  f32x16 acc[4];
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb) acc[nb] = zero16();
-  const int j0 = wave * 128;
+  const int j0 = wave * (NBW * 32);
   const float* ap = tA + l31 * TD_ASTR + lh;
-  // B[k = p][n = j] = Wc[c][p - j + 512], p = 2*s + lh, j = j0 + nb*32 + l31
-  const float* wp = tW + WPRE + 512 + lh - j0 - l31;
-#pragma unroll 3
-  for (int s = 0; s < 257; ++s) {
-    float av = ap[2 * s];
+  for (int ci = 0; ci < CPW; ++ci) {
+    const int c = c0 + ci;
+    const float* tWc = tW + (ci & 1) * WROW;
+    // next channel's weight row into the other buffer (read by nobody until the barrier below)
+    if (ci + 1 < CPW)
+      for (int i = tid; i < WROW; i += NT) tW[((ci + 1) & 1) * WROW + i] = Wc[(c + 1) * WROW + i];
+    f32x16 acc[NBW];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) acc[nb] = mfma32(av, wp[2 * s - nb * 32], acc[nb]);
-  }
+    for (int nb = 0; nb < NBW; ++nb) acc[nb] = zero16();
+    // B[k = p][n = j] = Wc[c][p - j + 512], p = 2*s + lh, j = j0 + nb*32 + l31
+    const float* wp = tWc + WPRE + 512 + lh - j0 - l31;
+    // software pipeline: fragments of the next k-step are read before the MFMAs of the current one
+    float a0 = ap[0], a1;
+    float b0[NBW], b1[NBW];
 #pragma unroll
-  for (int nb = 0; nb < 4; ++nb)
+    for (int nb = 0; nb < NBW; ++nb) b0[nb] = wp[-nb * 32];
+    for (int s = 0; s < TD_K / 2; s += 2) {
+      a1 = ap[2 * (s + 1)];
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      int f = f0 + acc_row(reg, lane);
-      if (f < F) dy[(int64_t)f * (TOEP_C * TOEP_H) + c * TOEP_H + j0 + nb * 32 + l31] = acc[nb][reg];
+      for (int nb = 0; nb < NBW; ++nb) b1[nb] = wp[2 * (s + 1) - nb * 32];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) acc[nb] = mfma32(a0, b0[nb], acc[nb]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int s2 = s + 2 < TD_K / 2 ? s + 2 : s;   // last trip: re-read a valid step (unused)
+      a0 = ap[2 * s2];
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) b0[nb] = wp[2 * s2 - nb * 32];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) acc[nb] = mfma32(a1, b1[nb], acc[nb]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-  // column j = 512: dy[f][c][512] = sum_p Wc[c][p] * dxh[f][p]; wave w reduces frames 8w..8w+7
-  for (int i = 0; i < 8; ++i) {
-    int fl = wave * 8 + i;
-    float s = 0.f;
-    for (int p = lane; p < TOEP_H; p += 64) s += tA[fl * TD_ASTR + p] * tW[WPRE + p];
-    s = wave_sum(s);
-    if (lane == 0 && f0 + fl < F) dy[(int64_t)(f0 + fl) * (TOEP_C * TOEP_H) + c * TOEP_H + 512] = s;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        int f = f0 + acc_row(reg, lane);
+        if (f < F) dy[(int64_t)f * (TOEP_C * TOEP_H) + c * TOEP_H + j0 + nb * 32 + l31] = acc[nb][reg];
+      }
+    // column j = 512: dy[f][c][512] = sum_p Wc[c][p] * dxh[f][p]; wave w reduces its RPW frames
+    for (int i = 0; i < RPW; ++i) {
+      int fl = wave * RPW + i;
+      float sum = 0.f;
+      for (int p = lane; p < TOEP_H; p += 64) sum += tA[fl * TD_ASTR + p] * tWc[WPRE + p];
+      sum = wave_sum(sum);
+      if (lane == 0 && f0 + fl < F) dy[(int64_t)(f0 + fl) * (TOEP_C * TOEP_H) + c * TOEP_H + 512] = sum;
+    }
+    __syncthreads();  // next channel's weight row complete; this channel's row no longer read
   }
 }
 
