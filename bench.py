@@ -102,8 +102,12 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
     torch.cuda.set_device(local)
-    if world > 1:
+    force_dist = os.environ.get('VAENPVC_FORCE_DIST') == '1'      # exercise the RCCL path with one rank
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     with open(os.path.join(ROOT, 'vae-npvc_amd', 'architecture-vae-vcc2016.json')) as fp:
@@ -207,7 +211,7 @@ def main():
         out['cpu_baseline'] = cpu_baseline(arch, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

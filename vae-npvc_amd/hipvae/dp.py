@@ -34,6 +34,9 @@ class Stepper(object):
         self.lr, self.beta1, self.beta2, self.eps = float(lr), float(beta1), float(beta2), float(eps)
         self.group = group
         self.rank, self.world = world_info(group)
+        import os
+        # VAENPVC_FORCE_DIST=1: run the all-reduce even with one rank (smoke-tests the RCCL path)
+        self._force_collective = os.environ.get('VAENPVC_FORCE_DIST') == '1' and dist.is_available() and dist.is_initialized()
         p = backend.params
         self.grads = torch.zeros_like(p)
         self.m = torch.zeros_like(p)      # Adam slots (tf.train.AdamOptimizer "m"/"v")
@@ -47,7 +50,7 @@ class Stepper(object):
     def step(self, x, y, eps):
         """x, y, eps are this rank's LOCAL shard.  Returns the local loss3 tensor."""
         loss3 = self.backend.train_fwd_bwd(x, y, eps, self.grads)
-        if self.world > 1:
+        if self.world > 1 or self._force_collective:
             dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group)
         self.step_count += 1
         self.backend.adam_step(self.grads, self.m, self.v, self.step_count, self.lr, self.beta1, self.beta2,
