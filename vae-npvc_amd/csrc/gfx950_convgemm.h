@@ -64,7 +64,8 @@ struct ConvCfg {
   static constexpr int FSTR = next_mod32(KCP * CSTR, (rows(0) * (TYPEP ? 1 : S)) % 32);
   static constexpr int TILE = rup(TF * FSTR, 4);
   static constexpr int RS = TYPEP ? 1 : S, TS = TYPEP ? -1 : 1, OFF = TYPEP ? 0 : -PAD;
-  static constexpr int LDS_BYTES = (TILE + NW * TBUF) * 4;
+  static constexpr int STAB = (HIN >= 32 || INKIND != IN_LN) ? 0 : 2 * KC + 2 * TF;  // = ConvStage::TAB
+  static constexpr int LDS_BYTES = (TILE + STAB + NW * TBUF) * 4;
   static constexpr int mtiles(int ph) { return cdiv(TF * rows(ph), 32); }
   static constexpr int mblk(int ph) { return cdiv(mtiles(ph), MB); }
   static_assert(!TYPEP || T > S - 1, "every phase needs a tap");
@@ -83,59 +84,107 @@ struct ConvArgs {
   int F;
 };
 
+// ---- staging of one frame tile, split into a global-load half (into registers) and an LDS-store
+// half so that the loads of tile t+1 are in flight while tile t is being computed.
+//   ROWS path (HIN >= 32): a row = HIN contiguous bins of one (frame, channel); wave w owns rows
+//     w, w+NW, ...; the row index is wave-uniform, so addresses and the LayerNorm constants are
+//     scalar and LN+lrelu is one fma + max per element (the tf.nn.batch_normalization form).
+//   ELEM path (short rows): element e = tid + NTHR*k of the contiguous tile; (frame, channel, bin)
+//     are decoded per element; LayerNorm constants come from small LDS tables.
 template <class C>
-__device__ __forceinline__ void conv_stage(const ConvArgs& a, float* tile, int f0) {
-  const int tid = threadIdx.x;
-  for (int i = tid; i < C::TILE / 4; i += C::NTHR) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-  constexpr int PER = C::KC * C::HIN;
-  const int nfr = min(C::TF, a.F - f0);
-  const int total = nfr * PER;
-  if constexpr (C::INKIND == IN_CONCAT2) {
-    constexpr int HALF = C::KC / 2;
-    for (int e = tid; e < total; e += C::NTHR) {
-      int f = e / PER, k = e - f * PER;
-      float v;
-      if (k < HALF) {
-        v = a.in[(int64_t)(f0 + f) * HALF + k];
-      } else {
-        int64_t g = a.idx ? a.idx[f0 + f] : (int64_t)(f0 + f);
-        v = a.in2[g * HALF + (k - HALF)];
-      }
-      tile[f * C::FSTR + k * C::CSTR + C::HLO] = v;
-    }
-  } else if constexpr (C::HIN >= 32) {
-    // rows = (frame, channel) x HIN contiguous bins; row index is wave-uniform
+struct ConvStage {
+  static constexpr int PER = C::KC * C::HIN;
+  static constexpr bool ROWS = C::HIN >= 32;
+  static constexpr bool LN = C::INKIND == IN_LN;
+  static constexpr int NROWS = C::TF * C::KC;
+  static constexpr int RPW = cdiv(NROWS, C::NW), LPR = cdiv(C::HIN, 64);
+  static constexpr int EPT = cdiv(C::TF * PER, C::NTHR);
+  static constexpr int NREG = ROWS ? RPW * LPR : EPT;
+  static constexpr int TAB = ROWS ? 0 : (LN ? 2 * C::KC + 2 * C::TF : 0);  // LDS floats: gamma, beta, (mean, rstd)
+
+  float v[NREG];
+  float rst;  // ELEM+LN: one statistics value per thread (tid < 2*TF)
+
+  __device__ __forceinline__ void gload(const ConvArgs& a, int f0) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nfr = min(C::TF, a.F - f0);
     const float* src = a.in + (int64_t)f0 * PER;
-    auto rowinfo = [&](int r, int& soff, int& doff, float& sc, float& sh) {
-      int f = r / C::KC, k = r - f * C::KC;
-      soff = r * C::HIN;
-      doff = f * C::FSTR + k * C::CSTR + C::HLO;
-      sc = 1.f;
-      sh = 0.f;
-      if constexpr (C::INKIND == IN_LN) {
-        float mean = a.st[2 * (f0 + f)], rstd = a.st[2 * (f0 + f) + 1];
-        sc = rstd * a.gamma[k / C::LNDIV];
-        sh = a.beta[k / C::LNDIV] - mean * sc;
+    if constexpr (ROWS) {
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        int r = wave + C::NW * rr;
+        int rs = r < nfr * C::KC ? r : 0;  // clamped: rows past the batch end are zeroed in lstore
+#pragma unroll
+        for (int p = 0; p < LPR; ++p) {
+          int i = lane + 64 * p;
+          v[rr * LPR + p] = i < C::HIN ? src[rs * C::HIN + i] : 0.f;
+        }
       }
-    };
-    stage_rows<C::HIN, C::NW, C::INKIND == IN_LN>(src, tile, nfr * C::KC, rowinfo);
-  } else {
-    auto put = [&](int e, float v) {
-      int f = e / PER;
-      int rem = e - f * PER;
-      int k = rem / C::HIN;
-      int i = rem - k * C::HIN;
-      if constexpr (C::INKIND == IN_LN) {
-        int ch = k / C::LNDIV;
-        v = lnact_v(v, a.st[2 * (f0 + f)], a.st[2 * (f0 + f) + 1], a.gamma[ch], a.beta[ch]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        int e = tid + C::NTHR * k;
+        v[k] = e < nfr * PER ? src[e] : 0.f;
       }
-      tile[f * C::FSTR + k * C::CSTR + C::HLO + i] = v;
-    };
-    stage_range<(PER % 4 == 0) ? 4 : 1, (PER % 4 == 0) ? 8 : 16, C::NTHR>(a.in + (int64_t)f0 * PER, total, put);
+      if constexpr (LN) rst = tid < 2 * nfr ? a.st[2 * f0 + tid] : 0.f;
+    }
   }
-  __syncthreads();
-}
+
+  __device__ __forceinline__ void lstore(const ConvArgs& a, float* tile, float* tab, int f0) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nfr = min(C::TF, a.F - f0);
+    if constexpr (ROWS) {
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        int r = wave + C::NW * rr;
+        if (r < NROWS) {  // wave-uniform
+          int f = r / C::KC, k = r - f * C::KC;
+          bool ok = r < nfr * C::KC;
+          float sc = ok ? 1.f : 0.f, sh = 0.f;
+          if constexpr (LN) {
+            int fs = ok ? f0 + f : f0;
+            float mean = a.st[2 * fs], rstd = a.st[2 * fs + 1];
+            sc = ok ? rstd * a.gamma[k / C::LNDIV] : 0.f;
+            sh = ok ? a.beta[k / C::LNDIV] - mean * sc : 0.f;
+          }
+          float* dst = tile + f * C::FSTR + k * C::CSTR + C::HLO;
+#pragma unroll
+          for (int p = 0; p < LPR; ++p) {
+            int i = lane + 64 * p;
+            float x = v[rr * LPR + p] * sc + sh;
+            if constexpr (LN) x = fmaxf(x, LEAK * x);
+            if (i < C::HIN) dst[i] = x;
+          }
+        }
+      }
+    } else {
+      if constexpr (LN) {
+        if (tid < 2 * C::TF) tab[2 * C::KC + tid] = rst;
+        __syncthreads();
+      }
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        int e = tid + C::NTHR * k;
+        if (e < C::TF * PER) {
+          int f = e / PER;
+          int rem = e - f * PER;
+          int ch = rem / C::HIN;
+          int i = rem - ch * C::HIN;
+          float x = v[k];
+          if constexpr (LN) {
+            float sc = tab[2 * C::KC + 2 * f + 1] * tab[ch];
+            x = (x - tab[2 * C::KC + 2 * f]) * sc + tab[C::KC + ch];
+            x = fmaxf(x, LEAK * x);
+            if (e >= nfr * PER) x = 0.f;
+          }
+          tile[f * C::FSTR + ch * C::CSTR + C::HLO + i] = x;
+        }
+      }
+    }
+  }
+};
 
 // One work item = (phase, block of MB row tiles, block of NB column tiles); the items of ALL
 // phases form one list that is dealt round-robin to the 8 waves.
@@ -267,17 +316,42 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
   }
 }
 
+// Persistent kernel: workgroup b walks the frame tiles b, b+gridDim.x, ...  The global loads of
+// the next tile are issued before the MFMA work of the current one and land in registers; they
+// are written to the (single) LDS tile after the compute phase, two barriers per tile.
 template <class C>
 __global__ void __launch_bounds__(C::NTHR) k_convgemm(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  using St = ConvStage<C>;
   float* tile = lds;
-  float* tbuf = lds + C::TILE + (threadIdx.x >> 6) * C::TBUF;
-  const int f0 = blockIdx.x * C::TF;
-  conv_stage<C>(a, tile, f0);
+  float* tab = lds + C::TILE;
+  float* tbuf = lds + C::TILE + St::TAB + (threadIdx.x >> 6) * C::TBUF;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < C::TILE / 4; i += C::NTHR) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (St::TAB > 0)
+    for (int k = tid; k < C::KC; k += C::NTHR) {
+      tab[k] = a.gamma[k / C::LNDIV];
+      tab[C::KC + k] = a.beta[k / C::LNDIV];
+    }
   constexpr int NBLK = cdiv(C::NT, C::NB);
   const int nblk0 = (int)((int64_t)NBLK * blockIdx.y / gridDim.y);
   const int nblk1 = (int)((int64_t)NBLK * (blockIdx.y + 1) / gridDim.y);
-  conv_items<C>(a, tile, tbuf, f0, nblk0, nblk1);
+  const int tiles = cdiv(a.F, C::TF);
+  St st;
+  int t = blockIdx.x;
+  st.gload(a, t * C::TF);
+  __syncthreads();  // zero fill (halos, padded channel rows) and tables complete
+  st.lstore(a, tile, tab, t * C::TF);
+  __syncthreads();
+  for (; t < tiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    if (tn < tiles) st.gload(a, tn * C::TF);
+    __builtin_amdgcn_sched_barrier(0);
+    conv_items<C>(a, tile, tbuf, t * C::TF, nblk0, nblk1);
+    __syncthreads();
+    if (tn < tiles) st.lstore(a, tile, tab, tn * C::TF);
+    __syncthreads();
+  }
   static_assert(C::NPH <= 3, "stride > 3 not instantiated");
 }
 
@@ -289,7 +363,10 @@ inline void launch_convgemm(const ConvArgs& a, int nsplit, hipStream_t s) {
                               C::LDS_BYTES);
     once = true;
   }
-  dim3 grid((unsigned)cdiv(a.F, C::TF), (unsigned)nsplit);
+  // persistent grid: as many workgroups as fit on the chip at once (LDS-bound residency)
+  const int per_cu = cmax(1, cmin_(4, (160 * 1024) / C::LDS_BYTES));
+  const int resident = cmax(1, 256 * per_cu / nsplit);
+  dim3 grid((unsigned)cmin_(cdiv(a.F, C::TF), resident), (unsigned)nsplit);
   hipLaunchKernelGGL(k_convgemm<C>, grid, dim3(C::NTHR), C::LDS_BYTES, s, a);
 }
 
