@@ -212,10 +212,10 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
 }
 
 void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* y, int64_t F64, const Ws& w,
-                 float* xh_out, hipStream_t s) {
+                 float* xh_out, hipStream_t s, bool weights_packed) {
   read_env();
   const int F = (int)F64;
-  prep(m, P, w, s);
+  if (!weights_packed) prep(m, P, w, s);
   if (fwd_on(6)) {
     DenseArgs a{z, P + m.emb_off, y, nullptr, nullptr, nullptr, w.scratch + Pk::merge_f, w.scratch + Pk::merge_bias,
                 w.h, nullptr, 0, m.merge, F};
@@ -258,8 +258,7 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
       VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL(k_toep_fwd<1>, dim3((unsigned)cdiv(F, 32), 4), dim3(256), TF_LDS, s, w.dec_y,
                                                       w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, F));
     }
-    hipLaunchKernelGGL(k_toep_fwd_lastcol, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_y, w.scratch + Pk::wc,
-                       P + m.dec[3].b_off, xh_out, F);
+    // (column p = 512 is produced inside k_toep_fwd by the workgroups with blockIdx.y == 0)
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 3);
 }
 

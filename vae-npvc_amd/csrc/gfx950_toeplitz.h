@@ -48,6 +48,12 @@ __global__ void __launch_bounds__(256) k_toep_fwd(const float* __restrict__ y2, 
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) acc[nb] = zero16();
   float ra[TF_RPW][TF_LPR], rw[TF_WPT];
+  // column p = 512 (513 = 16*32 + 1): xh[f][512] = b + sum_{c,j} Wc[c][1024-j] y2[f][c][j] is a plain
+  // dot product per frame; the workgroups with blockIdx.y == 0 accumulate it from the staged
+  // chunks (wave w: frames w, w+4, ...; lanes stride over j), 1.2 % extra LDS reads, no extra HBM pass.
+  float last[TF_RPW];
+#pragma unroll
+  for (int r = 0; r < TF_RPW; ++r) last[r] = 0.f;
   auto gload = [&](int chunk) {
     const int c = chunk >> 1, jc0 = (chunk & 1) * TF_JC;
 #pragma unroll
@@ -118,11 +124,33 @@ __global__ void __launch_bounds__(256) k_toep_fwd(const float* __restrict__ y2, 
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (blockIdx.y == 0) {
+      const float* tA = lds + (chunk & 1) * TF_BUF;
+      const float* tW = tA + 32 * TF_ASTR;
+      const int jc0 = (chunk & 1) * TF_JC;
+#pragma unroll
+      for (int p = 0; p < TF_LPR; ++p) {
+        int jj = lane + 64 * p;
+        // zero-padded on both sides: j >= 513 has y2 = 0, the weight index stays inside the row
+        float wv = jj < TF_JC ? tW[WPRE + 1024 - jc0 - jj] : 0.f;
+#pragma unroll
+        for (int r = 0; r < TF_RPW; ++r)
+          if (jj < TF_JC) last[r] += tA[(wave + 4 * r) * TF_ASTR + jj] * wv;
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (chunk + 1 < 2 * TOEP_C) lstore((chunk + 1) & 1);
     __syncthreads();
   }
   const float bb = bias[0];
+  if (blockIdx.y == 0) {
+#pragma unroll
+    for (int r = 0; r < TF_RPW; ++r) {
+      float sum = wave_sum(last[r]);
+      int f = f0 + wave + 4 * r;
+      if (lane == 0 && f < F) xh[(int64_t)f * TOEP_H + 512] = sum + bb;
+    }
+  }
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll

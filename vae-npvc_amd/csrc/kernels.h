@@ -80,8 +80,10 @@ namespace tuned {
 void set_masks(unsigned fwd, unsigned bwd);
 bool available();
 void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F, const Ws& w, hipStream_t s);
+// `weights_packed`: the packed weight copies in w.scratch are already current (the encoder of the
+// same step built them); a stand-alone decode call packs them itself.
 void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* y, int64_t F, const Ws& w,
-                 float* xh_out, hipStream_t s);
+                 float* xh_out, hipStream_t s, bool weights_packed = false);
 void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F,
               const Ws& w, float* G, hipStream_t s);
 }  // namespace tuned
