@@ -332,10 +332,9 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const ConvL& l2 = m.dec[2];
     TnArgs a = tn_args(w.dec_y, 4104, w.d_xh, 513, 4096, 512, F, G + m.dec[3].w_off, 0);
     VAENPVC_TIMED("dec3_wgrad", s2, launch_tngemm(a, true, kchunks_for(F, 32 * 4), s2));
-    int ech = cmax(1, cmin_(cdiv(F, 64), 256));
+    int ech = cmax(1, cmin_(cdiv(F, 32), 512));
     int efc = cdiv(F, ech);
-    hipLaunchKernelGGL(k_toep_wgrad_edges, dim3((unsigned)cdiv(8200, 256), (unsigned)cdiv(F, efc)), dim3(256), 0, s2, w.dec_y, w.d_xh,
-                       G + m.dec[3].w_off, F, efc);
+    hipLaunchKernelGGL(k_toep_wgrad_row512, dim3((unsigned)cdiv(F, efc)), dim3(256), 0, s2, w.dec_y, w.d_xh, G + m.dec[3].w_off, F, efc);
     hipLaunchKernelGGL(k_sum_all_atomic, dim3((unsigned)cmin_(1024, cdiv(F * 513, 1024))), dim3(256), 0, s2, w.d_xh,
                        (int64_t)F * 513, G + m.dec[3].b_off);
     static bool once = false;

@@ -68,6 +68,11 @@ __global__ void __launch_bounds__(256) k_tngemm(TnArgs a) {
     b = a.beta[mm / a.lndiv];
   }
   float rx[TN_EPT], ry[TN_EPT];
+  // TOEP edge term (column q = 512 of dxh, which the 512-wide MFMA part does not cover):
+  //   dW[1024-j][c] += sum_f y2[f,c,j] * dxh[f,512]   for j < 512
+  // is accumulated from the X values staged anyway by the workgroups with blockIdx.y == 0.
+  float edge = 0.f;
+  const bool do_edge = TOEP && blockIdx.y == 0;
   const float* __restrict__ X = a.X;
   const float* __restrict__ Y = a.Y;
   const int ldx = a.ldx, ldy = a.ldy;
@@ -89,6 +94,19 @@ __global__ void __launch_bounds__(256) k_tngemm(TnArgs a) {
         ox += 2 * ldx;
         oy += 2 * ldy;
       }
+      if constexpr (TOEP) {
+        if (do_edge) {  // workgroup-uniform; one batched block of loads, then the fmas
+          float d[TN_EPT];
+          int oe = (f0 + row0) * ldy + 512;
+#pragma unroll
+          for (int k = 0; k < TN_EPT; ++k) {
+            d[k] = Y[oe];
+            oe += 2 * ldy;
+          }
+#pragma unroll
+          for (int k = 0; k < TN_EPT; ++k) edge += rx[k] * d[k];
+        }
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < TN_EPT; ++k) {
@@ -102,6 +120,9 @@ __global__ void __launch_bounds__(256) k_tngemm(TnArgs a) {
         rx[k] = (fok && mok) ? v : 0.f;
         float w = Y[ff * ldy + nn];
         ry[k] = (fok && nok) ? w : 0.f;
+        if constexpr (TOEP) {
+          if (do_edge && fok && mok) edge += v * Y[ff * ldy + 512];
+        }
       }
     }
   };
@@ -199,6 +220,7 @@ __global__ void __launch_bounds__(256) k_tngemm(TnArgs a) {
       int t = n0 - j0 + (d - 63) + 512;  // always in [1, 1023]
       atomicAdd(a.C + t * 8 + c, dg[d]);
     }
+    if (do_edge && mok) atomicAdd(a.C + (1024 - (mm & 511)) * 8 + (mm >> 9), edge);
   }
 }
 
@@ -217,32 +239,42 @@ inline void launch_tngemm(const TnArgs& a, bool toep, int kchunks, hipStream_t s
     hipLaunchKernelGGL((k_tngemm<false, false, false>), grid, dim3(256), 0, s, b);
 }
 
-// Edge terms of the Toeplitz weight gradient not covered by the 512x512 MFMA part:
-//   t <= 512 : dW[t][c] += sum_f y2[f,c,512] * dxh[f,t]        (row j = 512, all q)
-//   t >  512 : dW[t][c] += sum_f y2[f,c,1024-t] * dxh[f,512]   (column q = 512, j < 512)
-// One thread per (t, c); grid (ceil(8200/256), frame chunks).
-__global__ void __launch_bounds__(256) k_toep_wgrad_edges(const float* __restrict__ y2, const float* __restrict__ dxh,
-                                                          float* __restrict__ dW, int F, int fchunk) {
-  int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= 1025 * 8) return;
-  int t = idx >> 3, c = idx & 7;
-  int j = t <= 512 ? 512 : 1024 - t;
-  int q = t <= 512 ? t : 512;
-  int fb = blockIdx.y * fchunk, fe = min(F, fb + fchunk);
-  float s = 0.f;
-  for (int f = fb; f < fe; f += 4) {
-    float x[4], d[4];
+// Remaining edge term of the Toeplitz weight gradient (row j = 512 of y2, all q):
+//   dW[t][c] += sum_f y2[f,c,512] * dxh[f,t]        for t <= 512
+// One workgroup per chunk of frames; thread <-> up to 3 values of t, 8 channel accumulators each.
+// Reads dxh once (67 MB at F = 32768) plus 8 floats per frame of y2.
+__global__ void __launch_bounds__(256) k_toep_wgrad_row512(const float* __restrict__ y2, const float* __restrict__ dxh,
+                                                           float* __restrict__ dW, int F, int fchunk) {
+  __shared__ float ys[8];
+  const int tid = threadIdx.x;
+  const int fb = blockIdx.x * fchunk, fe = min(F, fb + fchunk);
+  float acc[3][8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int ff = f + u < fe ? f + u : fb;
-      x[u] = y2[(int64_t)ff * 4104 + c * 513 + j];
-      d[u] = dxh[(int64_t)ff * 513 + q];
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
+  for (int f = fb; f < fe; ++f) {
+    __syncthreads();
+    if (tid < 8) ys[tid] = y2[(int64_t)f * 4104 + tid * 513 + 512];
+    float d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int t = tid + 256 * k;
+      d[k] = t <= 512 ? dxh[(int64_t)f * 513 + t] : 0.f;
     }
+    __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (f + u < fe) s += x[u] * d[u];
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[k][c] += d[k] * ys[c];
   }
-  atomicAdd(dW + idx, s);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int t = tid + 256 * k;
+    if (t <= 512)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) atomicAdd(dW + t * 8 + c, acc[k][c]);
+  }
 }
 
 }  // namespace tuned
