@@ -18,8 +18,9 @@
 //     the MFMA operand register: lanes 0..31 read 128 contiguous bytes; software
 //     prefetch one U-step chunk ahead;
 //   * v_mfma_f32_32x32x2_f32, MB x NB register blocking per wave;
-//   * epilogue: accumulators are transposed through a per-wave LDS buffer so that global
-//     stores run along the position axis.
+//   * the weights are the MFMA "A" operand and the gathered positions the "B" operand, so that
+//     accumulator rows are channels and lanes are positions: results are stored straight from
+//     the accumulators along the (contiguous) position axis.
 #pragma once
 #include "gfx950_common.h"
 
@@ -36,7 +37,7 @@ struct ConvCfg {
   static constexpr int INKIND = INKIND_, LNDIV = LNDIV_, MB = MB_, NB = NB_;
   static constexpr int NW = 8;  // waves per workgroup (2 per SIMD)
   static constexpr int NTHR = NW * 64;
-  static constexpr int TBUF = 32 * 17;  // per-wave transpose buffer (16 rows x 32 columns, padded)
+  static constexpr int TBUF = 0;        // (no transpose buffer: direct epilogue)
   // K per tap is padded so that KH = KCP/2 k-steps split into uniform chunks of U steps
   static constexpr int KCP = KC % 16 == 0 ? KC : rup(KC, 8), KH = KCP / 2;
   static constexpr int U = KH % 8 == 0 ? 8 : 4;  // k-steps (of 2) per B prefetch chunk
@@ -262,7 +263,7 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma32(av[u][mb], b[u][nb], acc[mb][nb]);
+          for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma32(b[u][nb], av[u][mb], acc[mb][nb]);  // rows = channels, lanes = positions
     };
     float b0[U][NB], b1[U][NB];
     loadB(b0, 0);
@@ -276,40 +277,21 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
       if (chunk + 1 < nchunks) compute(b1, chunk + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- epilogue: 16-row halves of each 32x32 tile are transposed through LDS so that
-    //      16 consecutive positions of one channel are stored by 16 consecutive lanes
-    const int l15 = lane & 15, lq = lane >> 4;
+    // ---- epilogue: the weights were fed as the MFMA "A" operand, so accumulator ROWS are output
+    //      channels and the 32 LANES of a half-wave are 32 consecutive (frame, position) rows:
+    //      every register is stored directly, 128 contiguous bytes per half-wave for S-type layers.
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       if ((mblk * MB + mb) >= MTILES) continue;  // wave-uniform
+      const int opos = C::TYPEP ? (C::S * rowq[mb] + ph - C::PAD) : rowq[mb];
+      float* op = a.out + (int64_t)(f0 + rowf[mb]) * C::N * C::HOUT + opos;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        // reader lane <-> row (half*16 + l15) of the tile
-        int rf = (mblk * MB + mb) * 32 + half * 16 + l15;
-        bool ok = rf < C::TF * R;
-        int rr = ok ? rf : 0;
-        int fr = rr / R;
-        int qr = Q0 + (rr - fr * R);
-        ok = ok && (f0 + fr) < a.F;
-        const int opos = C::TYPEP ? (C::S * qr + ph - C::PAD) : qr;
-        const int64_t obase = (int64_t)(f0 + fr) * C::N * C::HOUT + opos;
+      for (int nb = 0; nb < NB; ++nb) {
+        if (nbase + nb * 32 >= NP) continue;  // wave-uniform
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          if (nbase + nb * 32 >= NP) continue;  // wave-uniform
-#pragma unroll
-          for (int r8 = 0; r8 < 8; ++r8) {
-            int reg = half * 8 + r8;
-            tbuf[l31 * 17 + (acc_row(reg, lane) - half * 16)] = acc[mb][nb][reg];
-          }
-          wave_lds_sync();
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            int nl = 4 * i + lq;
-            int n = nbase + nb * 32 + nl;
-            float v = tbuf[nl * 17 + l15];
-            if (ok && n < C::N) a.out[obase + (int64_t)n * C::HOUT] = v + (a.bias ? a.bias[n] : 0.f);
-          }
-          wave_lds_sync();
+        for (int reg = 0; reg < 16; ++reg) {
+          int n = nbase + nb * 32 + acc_row(reg, lane);
+          if (rowok[mb] && n < C::N) op[n * C::HOUT] = acc[mb][nb][reg] + (a.bias ? a.bias[n] : 0.f);
         }
       }
     }
