@@ -29,11 +29,20 @@ namespace tuned {
 
 enum { IN_PLAIN = 0, IN_LN = 1, IN_CONCAT2 = 2 };
 
-template <int KC_, int HIN_, int N_, int HOUT_, int T_, int S_, int PAD_, bool TYPEP_, int TF_, int INKIND_,
+enum { CONV_S = 0, CONV_P = 1, CONV_PM = 2 };
+//   CONV_PM ("phase in M", for transposed layers with few output channels): ONE pass with all
+//   ceil(T/S) taps; the S phases become extra output columns (column = 4*channel + phase, weights
+//   of taps beyond T are zero), rows are q = (p + PAD) div S.  For N = 8 this needs 2.3x fewer
+//   MFMAs than three separate phases padded to 32 columns, and every lane ends up holding S
+//   consecutive output positions of a channel (contiguous stores instead of stride-S).
+template <int KC_, int HIN_, int N_, int HOUT_, int T_, int S_, int PAD_, int KIND_, int TF_, int INKIND_,
           int LNDIV_, int MB_, int NB_>
 struct ConvCfg {
   static constexpr int KC = KC_, HIN = HIN_, N = N_, HOUT = HOUT_, T = T_, S = S_, PAD = PAD_, TF = TF_;
-  static constexpr bool TYPEP = TYPEP_;
+  static constexpr int KIND = KIND_;
+  static constexpr bool TYPEP = KIND_ != CONV_S;   // transposed addressing (pos_in = q - tau)
+  static constexpr bool PM = KIND_ == CONV_PM;
+  static_assert(!PM || S_ <= 4, "phase slot is 2 bits");
   static constexpr int INKIND = INKIND_, LNDIV = LNDIV_, MB = MB_, NB = NB_;
   static constexpr int NW = 8;  // waves per workgroup (2 per SIMD)
   static constexpr int NTHR = NW * 64;
@@ -42,13 +51,14 @@ struct ConvCfg {
   static constexpr int KCP = KC % 16 == 0 ? KC : rup(KC, 8), KH = KCP / 2;
   static constexpr int U = KH % 8 == 0 ? 8 : 4;  // k-steps (of 2) per B prefetch chunk
   static constexpr int CPT = KH / U;             // chunks per tap
-  static constexpr int NP = rup(N, 32), NT = NP / 32;
-  static constexpr int NPH = TYPEP ? S : 1;
-  static constexpr int ntaps(int ph) { return TYPEP ? (T - ph + S - 1) / S : T; }
+  static constexpr int NE = PM ? 4 * N : N;  // GEMM columns (PM: 4 phase slots per channel)
+  static constexpr int NP = rup(NE, 32), NT = NP / 32;
+  static constexpr int NPH = (TYPEP && !PM) ? S : 1;
+  static constexpr int ntaps(int ph) { return PM ? cdiv(T, S) : (TYPEP ? (T - ph + S - 1) / S : T); }
   static constexpr int kt(int ph) { return ntaps(ph) * KH; }
   static constexpr int ktp(int ph) { return kt(ph); }  // already a multiple of U
-  static constexpr int q0(int ph) { return TYPEP ? (PAD - ph > 0 ? cdiv(PAD - ph, S) : 0) : 0; }
-  static constexpr int q1(int ph) { return TYPEP ? (HOUT - 1 + PAD - ph) / S : HOUT - 1; }
+  static constexpr int q0(int ph) { return PM ? PAD / S : (TYPEP ? (PAD - ph > 0 ? cdiv(PAD - ph, S) : 0) : 0); }
+  static constexpr int q1(int ph) { return PM ? (HOUT - 1 + PAD) / S : (TYPEP ? (HOUT - 1 + PAD - ph) / S : HOUT - 1); }
   static constexpr int rows(int ph) { return q1(ph) - q0(ph) + 1; }
   static constexpr int boff(int ph) {
     int o = 0;
@@ -283,15 +293,21 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       if ((mblk * MB + mb) >= MTILES) continue;  // wave-uniform
-      const int opos = C::TYPEP ? (C::S * rowq[mb] + ph - C::PAD) : rowq[mb];
+      const int opos = C::PM ? (C::S * rowq[mb] - C::PAD) : (C::TYPEP ? (C::S * rowq[mb] + ph - C::PAD) : rowq[mb]);
       float* op = a.out + (int64_t)(f0 + rowf[mb]) * C::N * C::HOUT + opos;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         if (nbase + nb * 32 >= NP) continue;  // wave-uniform
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-          int n = nbase + nb * 32 + acc_row(reg, lane);
-          if (rowok[mb] && n < C::N) op[n * C::HOUT] = acc[mb][nb][reg] + (a.bias ? a.bias[n] : 0.f);
+          int cn = nbase + nb * 32 + acc_row(reg, lane);
+          if constexpr (C::PM) {
+            int n = cn >> 2, phs = cn & 3, pos = opos + phs;  // registers reg&3 = 0..2: consecutive positions
+            if (rowok[mb] && n < C::N && phs < C::S && pos >= 0 && pos < C::HOUT)
+              op[n * C::HOUT + phs] = acc[mb][nb][reg] + (a.bias ? a.bias[n] : 0.f);
+          } else {
+            if (rowok[mb] && cn < C::N) op[cn * C::HOUT] = acc[mb][nb][reg] + (a.bias ? a.bias[cn] : 0.f);
+          }
         }
       }
     }

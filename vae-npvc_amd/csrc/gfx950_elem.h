@@ -406,6 +406,11 @@ struct PackConv {
     int r = i - (ph == 0 ? 0 : (ph == 1 ? C::boff(1) : C::boff(2)));
     int row = r / C::NP, n = r - row * C::NP;
     int tau = row / C::KCP, k = row - tau * C::KCP;
+    if constexpr (C::PM) {  // column = 4*channel + phase
+      ph = n & 3;
+      n >>= 2;
+      if (ph >= C::S) return 0.f;
+    }
     int t = C::TYPEP ? ph + C::S * tau : tau;
     if (t >= C::T || k >= C::KC || n >= C::N) return 0.f;
     return transposed ? src[((int64_t)t * C::N + n) * C::KC + k] : src[((int64_t)t * C::KC + k) * C::N + n];

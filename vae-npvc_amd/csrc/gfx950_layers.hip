@@ -25,21 +25,21 @@ namespace tuned {
 
 // ---------------------------------------------------------------- configurations
 //                      KC  HIN   N  HOUT T  S PAD typeP  TF  in-kind  lndiv MB NB
-using E1F = ConvCfg<16, 171, 32, 57, 7, 3, 2, false, 4, IN_LN, 1, 1, 1>;
-using E2F = ConvCfg<32, 57, 64, 19, 7, 3, 2, false, 12, IN_LN, 1, 2, 1>;
-using E3F = ConvCfg<64, 19, 128, 7, 7, 3, 3, false, 9, IN_LN, 1, 1, 1>;
-using E4F = ConvCfg<128, 7, 256, 3, 7, 3, 3, false, 21, IN_LN, 1, 2, 1>;
-using D0F = ConvCfg<81, 19, 32, 57, 9, 3, 3, true, 8, IN_PLAIN, 1, 1, 1>;
-using D1F = ConvCfg<32, 57, 16, 171, 7, 3, 2, true, 4, IN_LN, 1, 1, 1>;
-using D2F = ConvCfg<16, 171, 8, 513, 7, 3, 2, true, 4, IN_LN, 1, 1, 1>;
+using E1F = ConvCfg<16, 171, 32, 57, 7, 3, 2, CONV_S, 4, IN_LN, 1, 1, 1>;
+using E2F = ConvCfg<32, 57, 64, 19, 7, 3, 2, CONV_S, 12, IN_LN, 1, 2, 1>;
+using E3F = ConvCfg<64, 19, 128, 7, 7, 3, 3, CONV_S, 9, IN_LN, 1, 1, 1>;
+using E4F = ConvCfg<128, 7, 256, 3, 7, 3, 3, CONV_S, 21, IN_LN, 1, 2, 1>;
+using D0F = ConvCfg<81, 19, 32, 57, 9, 3, 3, CONV_P, 8, IN_PLAIN, 1, 1, 1>;
+using D1F = ConvCfg<32, 57, 16, 171, 7, 3, 2, CONV_PM, 4, IN_LN, 1, 1, 2>;
+using D2F = ConvCfg<16, 171, 8, 513, 7, 3, 2, CONV_PM, 4, IN_LN, 1, 3, 1>;
 // input gradients: conv_transpose layers (S-type) and conv layers (P-type)
-using GD2 = ConvCfg<8, 513, 16, 171, 7, 3, 2, false, 4, IN_PLAIN, 1, 1, 1>;
-using GD1 = ConvCfg<16, 171, 32, 57, 7, 3, 2, false, 4, IN_PLAIN, 1, 1, 1>;
-using GD0 = ConvCfg<32, 57, 81, 19, 9, 3, 3, false, 8, IN_PLAIN, 1, 1, 1>;
-using GE4 = ConvCfg<256, 3, 128, 7, 7, 3, 3, true, 16, IN_PLAIN, 1, 1, 2>;
-using GE3 = ConvCfg<128, 7, 64, 19, 7, 3, 3, true, 18, IN_PLAIN, 1, 1, 1>;
-using GE2 = ConvCfg<64, 19, 32, 57, 7, 3, 2, true, 8, IN_PLAIN, 1, 1, 1>;
-using GE1 = ConvCfg<32, 57, 16, 171, 7, 3, 2, true, 4, IN_PLAIN, 1, 1, 1>;
+using GD2 = ConvCfg<8, 513, 16, 171, 7, 3, 2, CONV_S, 4, IN_PLAIN, 1, 1, 1>;
+using GD1 = ConvCfg<16, 171, 32, 57, 7, 3, 2, CONV_S, 4, IN_PLAIN, 1, 1, 1>;
+using GD0 = ConvCfg<32, 57, 81, 19, 9, 3, 3, CONV_S, 8, IN_PLAIN, 1, 1, 1>;
+using GE4 = ConvCfg<256, 3, 128, 7, 7, 3, 3, CONV_P, 16, IN_PLAIN, 1, 1, 2>;
+using GE3 = ConvCfg<128, 7, 64, 19, 7, 3, 3, CONV_P, 18, IN_PLAIN, 1, 1, 1>;
+using GE2 = ConvCfg<64, 19, 32, 57, 7, 3, 2, CONV_P, 8, IN_PLAIN, 1, 1, 1>;
+using GE1 = ConvCfg<32, 57, 16, 171, 7, 3, 2, CONV_PM, 4, IN_PLAIN, 1, 1, 2>;
 //                         K    N   KCH NBW in-kind    lndiv
 using HeadsF = DenseCfg<768, 256, 256, 2, IN_LN, 3>;
 using HeadsB = DenseCfg<256, 768, 256, 3, IN_CONCAT2, 1>;
