@@ -24,8 +24,42 @@
 #pragma once
 #include "gfx950_common.h"
 
+// Compile-time ablation switch for kernel experiments (scripts/build_variant.sh); 0 in the product.
+//   1 = staging + barriers only, 2 = MFMA work only (tile staged once), 3 = no output stores
+#ifndef VAENPVC_ABL
+#define VAENPVC_ABL 0
+#endif
+
+#ifndef VAENPVC_UMAX
+#define VAENPVC_UMAX 8
+#endif
+#ifndef VAENPVC_APF
+#define VAENPVC_APF 0
+#endif
+
+#ifndef VAENPVC_PROF
+#define VAENPVC_PROF 0
+#endif
+
 namespace vaenpvc {
 namespace tuned {
+
+#if VAENPVC_PROF
+// developer instrumentation (variant builds only): per-kernel-instance cycle sums of the phases
+// of every wave: [slot][0..9] = waves, gload, setup, kloop, epilogue, barrier1, lstore, barrier2, total
+__device__ unsigned long long g_conv_prof[32][10];
+inline int g_conv_prof_next = 0;
+#define PROF_T(var) const long long var = (long long)__builtin_amdgcn_s_memtime()
+#else
+#define PROF_T(var)
+#endif
+
+constexpr int max_div_le(int n, int lim) {
+  int best = 1;
+  for (int d = 1; d <= lim; ++d)
+    if (n % d == 0) best = d;
+  return best;
+}
 
 enum { IN_PLAIN = 0, IN_LN = 1, IN_CONCAT2 = 2 };
 
@@ -36,7 +70,7 @@ enum { CONV_S = 0, CONV_P = 1, CONV_PM = 2 };
 //   MFMAs than three separate phases padded to 32 columns, and every lane ends up holding S
 //   consecutive output positions of a channel (contiguous stores instead of stride-S).
 template <int KC_, int HIN_, int N_, int HOUT_, int T_, int S_, int PAD_, int KIND_, int TF_, int INKIND_,
-          int LNDIV_, int MB_, int NB_>
+          int LNDIV_, int MB_, int NB_, int NW_ = 8>
 struct ConvCfg {
   static constexpr int KC = KC_, HIN = HIN_, N = N_, HOUT = HOUT_, T = T_, S = S_, PAD = PAD_, TF = TF_;
   static constexpr int KIND = KIND_;
@@ -44,12 +78,12 @@ struct ConvCfg {
   static constexpr bool PM = KIND_ == CONV_PM;
   static_assert(!PM || S_ <= 4, "phase slot is 2 bits");
   static constexpr int INKIND = INKIND_, LNDIV = LNDIV_, MB = MB_, NB = NB_;
-  static constexpr int NW = 8;  // waves per workgroup (2 per SIMD)
+  static constexpr int NW = NW_;  // waves per workgroup (8 = 2 per SIMD; 4 for small tiles, more workgroups per CU)
   static constexpr int NTHR = NW * 64;
   static constexpr int TBUF = 0;        // (no transpose buffer: direct epilogue)
   // K per tap is padded so that KH = KCP/2 k-steps split into uniform chunks of U steps
   static constexpr int KCP = KC % 16 == 0 ? KC : rup(KC, 8), KH = KCP / 2;
-  static constexpr int U = KH % 8 == 0 ? 8 : 4;  // k-steps (of 2) per B prefetch chunk
+  static constexpr int U = max_div_le(KH, VAENPVC_UMAX);  // k-steps (of 2) per prefetch chunk
   static constexpr int CPT = KH / U;             // chunks per tap
   static constexpr int NE = PM ? 4 * N : N;  // GEMM columns (PM: 4 phase slots per channel)
   static constexpr int NP = rup(NE, 32), NT = NP / 32;
@@ -76,10 +110,22 @@ struct ConvCfg {
   static constexpr int TILE = rup(TF * FSTR, 4);
   static constexpr int RS = TYPEP ? 1 : S, TS = TYPEP ? -1 : 1, OFF = TYPEP ? 0 : -PAD;
   static constexpr int STAB = (HIN >= 32 || INKIND != IN_LN) ? 0 : 2 * KC + 2 * TF;  // = ConvStage::TAB
-  static constexpr int LDS_BYTES = (TILE + STAB + NW * TBUF) * 4;
+  // small weight sets stay resident in LDS for the lifetime of the (persistent) workgroup: the
+  // k-loop then issues no vector-memory loads at all, so the next tile's prefetch (VMEM, returns
+  // in order) is never waited on before the staging point.  + 2 chunks of slack for the
+  // over-running prefetch of the fragment ping-pong.  The bias table (NP floats) is always in LDS.
+  static constexpr bool BLDS = BTOTAL * 4 <= 28 * 1024;
+  static constexpr int BSM = BLDS ? BTOTAL + 2 * U * 2 * NP : 0;
+  static constexpr int LDS_BYTES = (TILE + STAB + NP + BSM) * 4;
+  // LDS allows two resident workgroups -> ask the compiler for <= 128 VGPRs (4 waves per SIMD)
+  static constexpr int WPE = cmin_c(4, cmax_c(1, cmin_c(8, (160 * 1024) / LDS_BYTES) * NW / 4));
   static constexpr int mtiles(int ph) { return cdiv(TF * rows(ph), 32); }
   static constexpr int mblk(int ph) { return cdiv(mtiles(ph), MB); }
   static_assert(!TYPEP || T > S - 1, "every phase needs a tap");
+};
+
+struct __attribute__((packed, aligned(4))) packed3 {
+  float x, y, z;
 };
 
 struct ConvArgs {
@@ -93,6 +139,9 @@ struct ConvArgs {
   const float* bias;  // [N] or nullptr
   float* out;         // [F][N][HOUT]
   int F;
+#if VAENPVC_PROF
+  int slot;
+#endif
 };
 
 // ---- staging of one frame tile, split into a global-load half (into registers) and an LDS-store
@@ -147,26 +196,43 @@ struct ConvStage {
     const int nfr = min(C::TF, a.F - f0);
     if constexpr (ROWS) {
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      // batches of RB rows: first ALL scalar loads of the batch (statistics, gamma, beta; clamped
+      // indices, no branches, so they are issued back to back), then the LDS stores
+      constexpr int RB = RPW < 8 ? RPW : 8;
 #pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        int r = wave + C::NW * rr;
-        if (r < NROWS) {  // wave-uniform
-          int f = r / C::KC, k = r - f * C::KC;
+      for (int rr0 = 0; rr0 < RPW; rr0 += RB) {
+        float sc[RB], sh[RB];
+        int doff[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          int r = wave + C::NW * (rr0 + j);
+          int rc = r < NROWS ? r : NROWS - 1;
+          int f = rc / C::KC, k = rc - f * C::KC;
           bool ok = r < nfr * C::KC;
-          float sc = ok ? 1.f : 0.f, sh = 0.f;
+          sc[j] = ok ? 1.f : 0.f;
+          sh[j] = 0.f;
           if constexpr (LN) {
             int fs = ok ? f0 + f : f0;
             float mean = a.st[2 * fs], rstd = a.st[2 * fs + 1];
-            sc = ok ? rstd * a.gamma[k / C::LNDIV] : 0.f;
-            sh = ok ? a.beta[k / C::LNDIV] - mean * sc : 0.f;
+            float g = a.gamma[k / C::LNDIV], b = a.beta[k / C::LNDIV];
+            sc[j] = ok ? rstd * g : 0.f;
+            sh[j] = ok ? b - mean * sc[j] : 0.f;
           }
-          float* dst = tile + f * C::FSTR + k * C::CSTR + C::HLO;
+          doff[j] = f * C::FSTR + k * C::CSTR + C::HLO;
+        }
 #pragma unroll
-          for (int p = 0; p < LPR; ++p) {
-            int i = lane + 64 * p;
-            float x = v[rr * LPR + p] * sc + sh;
-            if constexpr (LN) x = fmaxf(x, LEAK * x);
-            if (i < C::HIN) dst[i] = x;
+        for (int j = 0; j < RB; ++j) {
+          if (rr0 + j >= RPW) continue;
+          int r = wave + C::NW * (rr0 + j);
+          if (r < NROWS) {  // wave-uniform
+            float* dst = tile + doff[j];
+#pragma unroll
+            for (int p = 0; p < LPR; ++p) {
+              int i = lane + 64 * p;
+              float x = v[(rr0 + j) * LPR + p] * sc[j] + sh[j];
+              if constexpr (LN) x = fmaxf(x, LEAK * x);
+              if (i < C::HIN) dst[i] = x;
+            }
           }
         }
       }
@@ -175,22 +241,40 @@ struct ConvStage {
         if (tid < 2 * C::TF) tab[2 * C::KC + tid] = rst;
         __syncthreads();
       }
+      constexpr int EB = EPT < 8 ? EPT : 8;
 #pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        int e = tid + C::NTHR * k;
-        if (e < C::TF * PER) {
-          int f = e / PER;
-          int rem = e - f * PER;
+      for (int k0 = 0; k0 < EPT; k0 += EB) {
+        float m[EB], rs[EB], g[EB], b[EB];
+        int doff[EB];
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {
+          int e = tid + C::NTHR * (k0 + j);
+          int ec = e < C::TF * PER ? e : C::TF * PER - 1;
+          int f = ec / PER;
+          int rem = ec - f * PER;
           int ch = rem / C::HIN;
           int i = rem - ch * C::HIN;
-          float x = v[k];
+          doff[j] = f * C::FSTR + ch * C::CSTR + C::HLO + i;
           if constexpr (LN) {
-            float sc = tab[2 * C::KC + 2 * f + 1] * tab[ch];
-            x = (x - tab[2 * C::KC + 2 * f]) * sc + tab[C::KC + ch];
-            x = fmaxf(x, LEAK * x);
-            if (e >= nfr * PER) x = 0.f;
+            m[j] = tab[2 * C::KC + 2 * f];
+            rs[j] = tab[2 * C::KC + 2 * f + 1];
+            g[j] = tab[ch];
+            b[j] = tab[C::KC + ch];
           }
-          tile[f * C::FSTR + ch * C::CSTR + C::HLO + i] = x;
+        }
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {
+          if (k0 + j >= EPT) continue;
+          int e = tid + C::NTHR * (k0 + j);
+          if (e < C::TF * PER) {
+            float x = v[k0 + j];
+            if constexpr (LN) {
+              x = (x - m[j]) * (rs[j] * g[j]) + b[j];
+              x = fmaxf(x, LEAK * x);
+              if (e >= nfr * PER) x = 0.f;
+            }
+            tile[doff[j]] = x;
+          }
         }
       }
     }
@@ -200,8 +284,12 @@ struct ConvStage {
 // One work item = (phase, block of MB row tiles, block of NB column tiles); the items of ALL
 // phases form one list that is dealt round-robin to the 8 waves.
 template <class C>
-__device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile, float* tbuf, int f0, int nblk0,
-                                           int nblk1) {
+__device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile, const float* lbias, const float* lB,
+                                           int f0, int nblk0, int nblk1
+#if VAENPVC_PROF
+                                           , long long (&pc)[8]
+#endif
+                                           ) {
   constexpr int U = C::U, MB = C::MB, NB = C::NB, NP = C::NP;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -210,6 +298,7 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
   const int it2 = it1 + (C::NPH > 1 ? C::mblk(1) * nblks : 0);
   const int items = it2 + (C::NPH > 2 ? C::mblk(2) * nblks : 0);
   for (int it = wave; it < items; it += C::NW) {
+    PROF_T(p0);
     // ---- phase parameters (wave-uniform)
     int ph = 0, local = it;
     if (C::NPH > 1 && it >= it1) { ph = 1; local = it - it1; }
@@ -221,7 +310,6 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
     const int MTILES = ph == 0 ? C::mtiles(0) : (ph == 1 ? C::mtiles(C::NPH > 1 ? 1 : 0) : C::mtiles(C::NPH > 2 ? 2 : 0));
     const int mblk = local / nblks;
     const int nblk = nblk0 + (local - mblk * nblks);
-    const int nbase = nblk * NB * 32;
     int baseA[MB], rowf[MB], rowq[MB];
     bool rowok[MB];
 #pragma unroll
@@ -236,11 +324,19 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
       rowok[mb] = ok && (f0 + f) < a.F;
       baseA[mb] = f * C::FSTR + lh * C::CSTR + C::HLO + q * C::RS + C::OFF;
     }
+    // accumulators start from the bias of their row (= output column; LDS table, zero where there
+    // is no bias): the epilogue is pure stores (a load there would serialise on vmcnt with them)
+    const int nbase = nblk * NB * 32;
     f32x16 acc[MB][NB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+    for (int nb = 0; nb < NB; ++nb) {
+      f32x16 bv;
+      const int cb = (nbase + nb * 32 < NP ? nbase + nb * 32 : NP - 32) + 4 * lh;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = zero16();
+      for (int reg = 0; reg < 16; ++reg) bv[reg] = lbias[cb + (reg & 3) + 8 * (reg >> 2)];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) acc[mb][nb] = bv;
+    }
 
     // K loop over chunks of U k-steps.  B (weights) streams from L2 into two ping-pong register
     // sets, always one chunk ahead of the MFMAs that consume it (no register copies, so the
@@ -251,7 +347,7 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
     int ncol[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) ncol[nb] = (nbase + nb * 32 < NP ? nbase + nb * 32 : NP - 32) + l31;
-    const float* bp0 = a.Bp + BOFF + lh * NP;
+    const float* bp0 = (C::BLDS ? lB : a.Bp) + BOFF + lh * NP;
     const int nchunks = (KT / C::KH) * C::CPT;
     auto loadB = [&](float (&b)[U][NB], int chunk) {
       const float* p = bp0 + chunk * (U * 2 * NP);
@@ -260,6 +356,39 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) b[u][nb] = p[u * 2 * NP + ncol[nb]];
     };
+#if VAENPVC_APF
+    auto loadA = [&](float (&av)[U][MB], int chunk) {
+      const int tau = chunk / C::CPT, c = chunk - tau * C::CPT;
+      const int aoff = tau * C::TS + c * (U * 2 * C::CSTR);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[u][mb] = tile[baseA[mb] + aoff + u * 2 * C::CSTR];
+    };
+    auto mm = [&](const float (&b)[U][NB], const float (&av)[U][MB]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma32(b[u][nb], av[u][mb], acc[mb][nb]);
+    };
+    float b0[U][NB], b1[U][NB], a0[U][MB], a1[U][MB];
+    loadB(b0, 0);
+    loadA(a0, 0);
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+      loadB(b1, chunk + 1);
+      loadA(a1, chunk + 1 < nchunks ? chunk + 1 : chunk);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(b0, a0);
+      __builtin_amdgcn_sched_barrier(0);
+      loadB(b0, chunk + 2);
+      loadA(a0, chunk + 2 < nchunks ? chunk + 2 : chunk);
+      __builtin_amdgcn_sched_barrier(0);
+      if (chunk + 1 < nchunks) mm(b1, a1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
     auto compute = [&](const float (&b)[U][NB], int chunk) {
       const int tau = chunk / C::CPT, c = chunk - tau * C::CPT;
       const int aoff = tau * C::TS + c * (U * 2 * C::CSTR);
@@ -276,6 +405,7 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
           for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mfma32(b[u][nb], av[u][mb], acc[mb][nb]);  // rows = channels, lanes = positions
     };
     float b0[U][NB], b1[U][NB];
+    PROF_T(p1);
     loadB(b0, 0);
     for (int chunk = 0; chunk < nchunks; chunk += 2) {
       loadB(b1, chunk + 1);
@@ -287,30 +417,62 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
       if (chunk + 1 < nchunks) compute(b1, chunk + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+#endif
+#if VAENPVC_PROF
+    asm volatile("s_nop 0" ::: "memory");
+#endif
+    PROF_T(p2);
     // ---- epilogue: the weights were fed as the MFMA "A" operand, so accumulator ROWS are output
     //      channels and the 32 LANES of a half-wave are 32 consecutive (frame, position) rows:
     //      every register is stored directly, 128 contiguous bytes per half-wave for S-type layers.
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
+#if VAENPVC_ABL == 3
+      if (a.F > 0) continue;
+#endif
       if ((mblk * MB + mb) >= MTILES) continue;  // wave-uniform
       const int opos = C::PM ? (C::S * rowq[mb] - C::PAD) : (C::TYPEP ? (C::S * rowq[mb] + ph - C::PAD) : rowq[mb]);
       float* op = a.out + (int64_t)(f0 + rowf[mb]) * C::N * C::HOUT + opos;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         if (nbase + nb * 32 >= NP) continue;  // wave-uniform
+        if constexpr (C::PM) {
+          // registers 4g..4g+2 of a lane = phases 0..2 = three consecutive output positions of
+          // channel n: one 12-byte store when the triple is inside the row
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          int cn = nbase + nb * 32 + acc_row(reg, lane);
-          if constexpr (C::PM) {
-            int n = cn >> 2, phs = cn & 3, pos = opos + phs;  // registers reg&3 = 0..2: consecutive positions
-            if (rowok[mb] && n < C::N && phs < C::S && pos >= 0 && pos < C::HOUT)
-              op[n * C::HOUT + phs] = acc[mb][nb][reg] + (a.bias ? a.bias[n] : 0.f);
-          } else {
-            if (rowok[mb] && cn < C::N) op[cn * C::HOUT] = acc[mb][nb][reg] + (a.bias ? a.bias[cn] : 0.f);
+          for (int g = 0; g < 4; ++g) {
+            const int n = ((nbase + nb * 32) >> 2) + 2 * g + lh;
+            float* o3 = op + n * C::HOUT;
+            const bool okn = rowok[mb] && n < C::N;
+            if (okn && opos >= 0 && opos + C::S <= C::HOUT) {
+              if constexpr (C::S == 3) {
+                *reinterpret_cast<packed3*>(o3) = packed3{acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2]};
+              } else {
+#pragma unroll
+                for (int phs = 0; phs < C::S; ++phs) o3[phs] = acc[mb][nb][4 * g + phs];
+              }
+            } else if (okn) {
+#pragma unroll
+              for (int phs = 0; phs < C::S; ++phs)
+                if (opos + phs >= 0 && opos + phs < C::HOUT) o3[phs] = acc[mb][nb][4 * g + phs];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            int cn = nbase + nb * 32 + acc_row(reg, lane);
+            if (rowok[mb] && (C::N % 32 == 0 || cn < C::N)) op[cn * C::HOUT] = acc[mb][nb][reg];
           }
         }
       }
     }
+#if VAENPVC_PROF
+    asm volatile("s_nop 0" ::: "memory");
+    PROF_T(p3);
+    pc[1] += p1 - p0;
+    pc[2] += p2 - p1;
+    pc[3] += p3 - p2;
+#endif
   }
 }
 
@@ -318,14 +480,21 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
 // the next tile are issued before the MFMA work of the current one and land in registers; they
 // are written to the (single) LDS tile after the compute phase, two barriers per tile.
 template <class C>
-__global__ void __launch_bounds__(C::NTHR) k_convgemm(ConvArgs a) {
+__global__ void __launch_bounds__(C::NTHR, C::WPE) k_convgemm(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using St = ConvStage<C>;
   float* tile = lds;
   float* tab = lds + C::TILE;
-  float* tbuf = lds + C::TILE + St::TAB + (threadIdx.x >> 6) * C::TBUF;
+  float* lbias = lds + C::TILE + St::TAB;
+  float* lB = lbias + C::NP;
   const int tid = threadIdx.x;
   for (int i = tid; i < C::TILE / 4; i += C::NTHR) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = tid; c < C::NP; c += C::NTHR) {
+    int n = C::PM ? (c >> 2) : c;
+    lbias[c] = (a.bias && n < C::N) ? a.bias[n] : 0.f;
+  }
+  if constexpr (C::BLDS)
+    for (int i = tid; i < C::BSM; i += C::NTHR) lB[i] = i < C::BTOTAL ? a.Bp[i] : 0.f;
   if constexpr (St::TAB > 0)
     for (int k = tid; k < C::KC; k += C::NTHR) {
       tab[k] = a.gamma[k / C::LNDIV];
@@ -337,34 +506,89 @@ __global__ void __launch_bounds__(C::NTHR) k_convgemm(ConvArgs a) {
   const int tiles = cdiv(a.F, C::TF);
   St st;
   int t = blockIdx.x;
+#if VAENPVC_PROF
+  long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  PROF_T(k0);
+#endif
   st.gload(a, t * C::TF);
   __syncthreads();  // zero fill (halos, padded channel rows) and tables complete
   st.lstore(a, tile, tab, t * C::TF);
   __syncthreads();
   for (; t < tiles; t += gridDim.x) {
     const int tn = t + gridDim.x;
+#if VAENPVC_PROF
+    PROF_T(q0);
     if (tn < tiles) st.gload(a, tn * C::TF);
     __builtin_amdgcn_sched_barrier(0);
-    conv_items<C>(a, tile, tbuf, t * C::TF, nblk0, nblk1);
+    PROF_T(q1);
+    conv_items<C>(a, tile, lbias, lB, t * C::TF, nblk0, nblk1, pc);
+    PROF_T(q2);
     __syncthreads();
+    PROF_T(q3);
     if (tn < tiles) st.lstore(a, tile, tab, tn * C::TF);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    PROF_T(q4);
     __syncthreads();
+    PROF_T(q5);
+    pc[0] += q1 - q0;
+    pc[4] += q3 - q2;
+    pc[5] += q4 - q3;
+    pc[6] += q5 - q4;
+#else
+#if VAENPVC_ABL != 2
+    if (tn < tiles) st.gload(a, tn * C::TF);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#if VAENPVC_ABL != 1
+    conv_items<C>(a, tile, lbias, lB, t * C::TF, nblk0, nblk1);
+#endif
+    __syncthreads();
+#if VAENPVC_ABL != 2
+    if (tn < tiles) st.lstore(a, tile, tab, tn * C::TF);
+#endif
+    __syncthreads();
+#endif
   }
+#if VAENPVC_PROF
+  {
+    PROF_T(k1);
+    if ((threadIdx.x & 63) == 0) {
+      unsigned long long* g = g_conv_prof[a.slot];
+      atomicAdd(g + 0, 1ull);
+      for (int i = 0; i < 7; ++i) atomicAdd(g + 1 + i, (unsigned long long)pc[i]);
+      atomicAdd(g + 8, (unsigned long long)(k1 - k0));
+    }
+  }
+#endif
   static_assert(C::NPH <= 3, "stride > 3 not instantiated");
 }
 
 template <class C>
 inline void launch_convgemm(const ConvArgs& a, int nsplit, hipStream_t s) {
-  static bool once = false;
-  if (!once) {
+  static int per_cu = 0;
+  if (!per_cu) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convgemm<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               C::LDS_BYTES);
-    once = true;
+    // persistent grid: exactly as many workgroups as are resident at once (LDS- or VGPR-bound)
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&k_convgemm<C>), C::NTHR,
+                                                     C::LDS_BYTES) != hipSuccess || n < 1)
+      n = 1;
+    per_cu = n;
   }
-  // persistent grid: as many workgroups as fit on the chip at once (LDS-bound residency)
-  const int per_cu = cmax(1, cmin_(4, (160 * 1024) / C::LDS_BYTES));
   const int resident = cmax(1, 256 * per_cu / nsplit);
   dim3 grid((unsigned)cmin_(cdiv(a.F, C::TF), resident), (unsigned)nsplit);
+#if VAENPVC_PROF
+  static int slot = -1;
+  if (slot < 0) {
+    slot = g_conv_prof_next++;
+    fprintf(stderr, "PROF slot %d per_cu %d grid %u : %s\n", slot, per_cu, grid.x, __PRETTY_FUNCTION__);
+  }
+  ConvArgs ap = a;
+  ap.slot = slot;
+  hipLaunchKernelGGL(k_convgemm<C>, grid, dim3(C::NTHR), C::LDS_BYTES, s, ap);
+  return;
+#endif
   hipLaunchKernelGGL(k_convgemm<C>, grid, dim3(C::NTHR), C::LDS_BYTES, s, a);
 }
 

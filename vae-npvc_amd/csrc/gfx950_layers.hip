@@ -25,21 +25,39 @@ namespace tuned {
 
 // ---------------------------------------------------------------- configurations
 //                      KC  HIN   N  HOUT T  S PAD typeP  TF  in-kind  lndiv MB NB
+#ifdef VAENPVC_EXP_NW4
+using E1F = ConvCfg<16, 171, 32, 57, 7, 3, 2, CONV_S, 2, IN_LN, 1, 1, 1, 4>;
+#else
 using E1F = ConvCfg<16, 171, 32, 57, 7, 3, 2, CONV_S, 4, IN_LN, 1, 1, 1>;
+#endif
 using E2F = ConvCfg<32, 57, 64, 19, 7, 3, 2, CONV_S, 12, IN_LN, 1, 2, 1>;
 using E3F = ConvCfg<64, 19, 128, 7, 7, 3, 3, CONV_S, 9, IN_LN, 1, 1, 1>;
 using E4F = ConvCfg<128, 7, 256, 3, 7, 3, 3, CONV_S, 21, IN_LN, 1, 2, 1>;
 using D0F = ConvCfg<81, 19, 32, 57, 9, 3, 3, CONV_P, 8, IN_PLAIN, 1, 1, 1>;
+#ifdef VAENPVC_EXP_NW4
+using D1F = ConvCfg<32, 57, 16, 171, 7, 3, 2, CONV_PM, 2, IN_LN, 1, 1, 2, 4>;
+using D2F = ConvCfg<16, 171, 8, 513, 7, 3, 2, CONV_PM, 2, IN_LN, 1, 3, 1, 4>;
+#else
 using D1F = ConvCfg<32, 57, 16, 171, 7, 3, 2, CONV_PM, 4, IN_LN, 1, 1, 2>;
 using D2F = ConvCfg<16, 171, 8, 513, 7, 3, 2, CONV_PM, 4, IN_LN, 1, 3, 1>;
+#endif
 // input gradients: conv_transpose layers (S-type) and conv layers (P-type)
+#ifdef VAENPVC_EXP_NW4
+using GD2 = ConvCfg<8, 513, 16, 171, 7, 3, 2, CONV_S, 2, IN_PLAIN, 1, 1, 1, 4>;
+using GD1 = ConvCfg<16, 171, 32, 57, 7, 3, 2, CONV_S, 2, IN_PLAIN, 1, 1, 1, 4>;
+#else
 using GD2 = ConvCfg<8, 513, 16, 171, 7, 3, 2, CONV_S, 4, IN_PLAIN, 1, 1, 1>;
 using GD1 = ConvCfg<16, 171, 32, 57, 7, 3, 2, CONV_S, 4, IN_PLAIN, 1, 1, 1>;
+#endif
 using GD0 = ConvCfg<32, 57, 81, 19, 9, 3, 3, CONV_S, 8, IN_PLAIN, 1, 1, 1>;
 using GE4 = ConvCfg<256, 3, 128, 7, 7, 3, 3, CONV_P, 16, IN_PLAIN, 1, 1, 2>;
 using GE3 = ConvCfg<128, 7, 64, 19, 7, 3, 3, CONV_P, 18, IN_PLAIN, 1, 1, 1>;
 using GE2 = ConvCfg<64, 19, 32, 57, 7, 3, 2, CONV_P, 8, IN_PLAIN, 1, 1, 1>;
+#ifdef VAENPVC_EXP_NW4
+using GE1 = ConvCfg<32, 57, 16, 171, 7, 3, 2, CONV_PM, 2, IN_PLAIN, 1, 1, 2, 4>;
+#else
 using GE1 = ConvCfg<32, 57, 16, 171, 7, 3, 2, CONV_PM, 4, IN_PLAIN, 1, 1, 2>;
+#endif
 //                         K    N   KCH NBW in-kind    lndiv
 using HeadsF = DenseCfg<768, 256, 256, 2, IN_LN, 3>;
 using HeadsB = DenseCfg<256, 768, 256, 3, IN_CONCAT2, 1>;
@@ -505,3 +523,16 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
 
 }  // namespace tuned
 }  // namespace vaenpvc
+
+#if VAENPVC_PROF
+// developer-only entry point of instrumented variant builds (not part of include/vaenpvc.h)
+extern "C" int vaenpvc_debug_conv_prof(unsigned long long* out, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -3;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(vaenpvc::tuned::g_conv_prof), sizeof(unsigned long long) * 320) != hipSuccess) return -3;
+  if (reset) {
+    static unsigned long long z[320];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vaenpvc::tuned::g_conv_prof), z, sizeof(z)) != hipSuccess) return -3;
+  }
+  return 0;
+}
+#endif

@@ -5,7 +5,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, '..', 'csrc'))
-LIB_PATH = os.path.join(CSRC, 'libvaenpvc_hip.so')
+# VAENPVC_LIB: developer override used by scripts/build_variant.sh (kernel experiments)
+LIB_PATH = os.environ.get('VAENPVC_LIB') or os.path.join(CSRC, 'libvaenpvc_hip.so')
 MAX_LAYERS = 8
 ABI_VERSION = 1
 
