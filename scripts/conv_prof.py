@@ -23,7 +23,7 @@ grads = torch.zeros(eng.n_params, dtype=torch.float32, device='cuda')
 lib = L.load_library()
 fn = lib.vaenpvc_debug_conv_prof
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
-buf = (ctypes.c_ulonglong * 320)()
+buf = (ctypes.c_ulonglong * 448)()
 for i in range(2):
     eng.train_fwd_bwd(x, y, eps, grads)
 fn(None, 1)
@@ -31,7 +31,8 @@ N = 3
 for i in range(N):
     eng.train_fwd_bwd(x, y, eps, grads)
 fn(buf, 0)
-a = np.array(buf[:], dtype=np.float64).reshape(32, 10)
+a = np.array(buf[:320], dtype=np.float64).reshape(32, 10)
+wg = np.array(buf[320:], dtype=np.float64).reshape(16, 8)
 names = ['gload', 'setup', 'kloop', 'epi', 'bar1', 'lstore', 'bar2']
 print('slot waves   total_cyc/wave | ' + ' '.join('%7s' % n for n in names) + ' | other')
 for s in range(32):
@@ -41,3 +42,13 @@ for s in range(32):
     tot = a[s, 8] / w
     parts = a[s, 1:8] / w
     print('%4d %6d %12.0f | ' % (s, w / N, tot) + ' '.join('%6.1f%%' % (100 * p / tot) for p in parts) + ' | %5.1f%%' % (100 * (tot - parts.sum()) / tot))
+
+names = ['gload', 'bar1', 'compute', 'bar2', 'epilogue', 'lstore']
+print('convwgrad slot waves total_cyc/wave | ' + ' '.join('%8s' % n for n in names) + ' | other')
+for s in range(16):
+    if wg[s, 0] == 0:
+        continue
+    w = wg[s, 0]
+    tot = wg[s, 6] / w
+    parts = wg[s, [1, 2, 3, 4, 5, 7]] / w
+    print('%4d %6d %12.0f | ' % (s, w / N, tot) + ' '.join('%7.1f%%' % (100 * p / tot) for p in parts) + ' | %5.1f%%' % (100 * (tot - parts.sum()) / tot))

@@ -100,15 +100,15 @@ void timer_begin(hipStream_t s) {
   if (g_used >= kPoolMax) return;
   if (g_used >= g_pool.size()) {
     hipEvent_t a, b;
-    hipEventCreate(&a);
-    hipEventCreate(&b);
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
     g_pool.emplace_back(a, b);
   }
-  hipEventRecord(g_pool[g_used].first, s);
+  (void)hipEventRecord(g_pool[g_used].first, s);
 }
 void timer_end(hipStream_t s) {
   if (g_used >= kPoolMax || g_used >= g_pool.size()) return;
-  hipEventRecord(g_pool[g_used].second, s);
+  (void)hipEventRecord(g_pool[g_used].second, s);
   ++g_used;
 }
 }  // namespace vaenpvc

@@ -13,18 +13,36 @@
 #pragma once
 #include "gfx950_common.h"
 
+#ifndef VAENPVC_PROF
+#define VAENPVC_PROF 0
+#endif
+
 namespace vaenpvc {
 namespace tuned {
 
+#if VAENPVC_PROF
+// developer instrumentation: [slot][0..7] = waves, stage, barrier1, compute, barrier2, epilogue, total
+__device__ unsigned long long g_wg_prof[16][8];
+inline int g_wg_prof_next = 0;
+#define WPROF_T(var) const long long var = (long long)__builtin_amdgcn_s_memtime()
+#else
+#define WPROF_T(var)
+#endif
+
 constexpr int odd_up(int v) { return v | 1; }
 
-template <int XC_, int XH_, int YC_, int YH_, int T_, int S_, int PAD_, bool XLN_, bool YLN_, int TF_, int NTW_>
+template <int XC_, int XH_, int YC_, int YH_, int T_, int S_, int PAD_, bool XLN_, bool YLN_, int TF_, int NTW_,
+          int NWV_ = 4, int WM_ = 0>
 struct WgCfg {
   static constexpr int XC = XC_, XH = XH_, YC = YC_, YH = YH_, T = T_, S = S_, PAD = PAD_, TF = TF_, NTW = NTW_;
   static constexpr bool XLN = XLN_, YLN = YLN_;
+  static constexpr int NWV = NWV_, NTHR = NWV_ * 64;
   static constexpr int M = T * XC, MTL = cdiv(M, 32);
   static constexpr int NTL = cdiv(YC, 32), NSPLIT = cdiv(NTL, NTW);
-  static constexpr int WM = MTL >= 4 ? 4 : (MTL >= 2 ? 2 : 1), WK = 4 / WM, MTW = cdiv(MTL, WM);
+  // waves = WM (split of the M tiles) x WK (split of the k-steps)
+  static constexpr int WM = WM_ > 0 ? WM_ : (MTL >= 4 ? 4 : (MTL >= 2 ? 2 : 1));
+  static constexpr int WK = NWV / WM, MTW = cdiv(MTL, WM);
+  static_assert(WM * WK == NWV, "waves = WM x WK");
   static constexpr int HLO = PAD, HHI = cmax(0, S * (YH - 1) - PAD + T - 1 - (XH - 1));
   // A gathers: lane <-> m = (t, xc) reads xc*CSTRX + t.  XC >= 32: one tap per fragment, odd
   // stride.  XC < 32: a fragment spans 32/XC taps, stride == 32/XC (mod 32) keeps all 32 banks distinct.
@@ -32,8 +50,10 @@ struct WgCfg {
   static constexpr int CSTRY = odd_up(YH);
   static constexpr int FSTRX = XC * CSTRX, FSTRY = NTW * 32 * CSTRY;
   static constexpr int XT = rup(TF * FSTRX, 4), YT = rup(TF * FSTRY, 4);
-  static constexpr int LDS_BYTES = (XT + YT) * 4;
   static_assert(TF % 2 == 0, "k-steps pair two frames");
+  static constexpr int HP = TF / 2;
+  // positions r handled per trip of the k loop (>= ~8 MFMAs between two batches of LDS reads)
+  static constexpr int RU = cmax(1, cmin_(4, 8 / (HP * MTW * NTW)));
 };
 
 struct WgArgs {
@@ -48,62 +68,179 @@ struct WgArgs {
   float* dW;  // [M][YC] atomicAdd
   int F;
   int fchunk;  // frames per blockIdx.x (multiple of TF)
+#if VAENPVC_PROF
+  int slot;
+#endif
 };
 
-// Row-wise staging (see stage_rows); here the scale/shift is ALWAYS applied so that rows outside
-// the chunk / channel range are written as zeros (sc = sh = 0).
-template <int ROWLEN, bool LN, class RowInfo>
-__device__ __forceinline__ void wg_stage_rows(const float* __restrict__ src, float* __restrict__ dst, int nrows,
-                                              RowInfo&& rowinfo) {
-  constexpr int PER = (ROWLEN + 63) / 64;
-  constexpr int RU = cmax_c(2, cmin_c(16, 32 / PER));  // ~32 loads in flight per lane
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int r0 = wave * RU; r0 < nrows; r0 += 4 * RU) {
-    float v[RU][PER];
-    int doff[RU];
-    float sc[RU], sh[RU];
+// One operand tile (CH channels x H bins of TF frames) of the weight-gradient GEMM, staged in two
+// halves: gload() issues the global loads of a sub-tile into registers (they stay in flight while
+// the MFMAs of the previous sub-tile run), lstore() applies LN+lrelu and writes the LDS tile.
+// Both halves are fully unrolled with compile-time (frame, channel) indices wherever possible, so
+// that an element costs one load / one fma+max+ds_write and almost no address arithmetic
+// (staging instructions compete with the MFMAs for issue slots).
+//   ROWS (H >= 32): wave w owns rows rr*NWV + w (row = one channel of one frame, wave-uniform:
+//     addresses and LayerNorm constants are scalar, loaded in batches before they are used).
+//   ELEM (short rows): per frame, element e = tid + NTHR*kk of the contiguous run of the tile's
+//     channels; the (channel, bin) split, the LDS offset and gamma/beta of an element do not depend
+//     on the frame and are computed once per thread (init()); mean/rstd of a frame are scalar.
+// Frames past the chunk end and channels past the tensor are clamped on load and written as zeros.
+template <int CH, int CHTOT, int H, int CSTR, int FSTR, int LPAD, bool LN, int TF, int NWV>
+struct WgOperand {
+  static constexpr bool ROWS = H >= 32;
+  static constexpr int NTHR = NWV * 64;
+  static constexpr int NROWS = TF * CH, RPW = cdiv(NROWS, NWV), LPR = cdiv(H, 64);
+  static constexpr bool RDIV = CH % NWV == 0;  // (frame, channel) of row rr*NWV + w: compile-time + w
+  static constexpr int PERF = CH * H, KPF = cdiv(PERF, NTHR);
+  static constexpr int NREG = ROWS ? RPW * LPR : TF * KPF;
+  static constexpr int NE = ROWS ? 1 : KPF;
+  float v[NREG];
+  int loff[NE];
+  float eg[NE], eb[NE];
+
+  __device__ __forceinline__ void init(const float* __restrict__ gamma, const float* __restrict__ beta, int c0, int nch) {
+    if constexpr (!ROWS) {
 #pragma unroll
-    for (int u = 0; u < RU; ++u) {
-      int r = r0 + u < nrows ? r0 + u : nrows - 1;
-      int soff;
-      rowinfo(r, soff, doff[u], sc[u], sh[u]);
-#pragma unroll
-      for (int p = 0; p < PER; ++p) {
-        int i = lane + 64 * p;
-        v[u][p] = (i < ROWLEN) ? src[soff + i] : 0.f;
+      for (int kk = 0; kk < KPF; ++kk) {
+        int e = threadIdx.x + NTHR * kk;
+        int ec = e < PERF ? e : PERF - 1;
+        int ch = ec / H, i = ec - ch * H;
+        loff[kk] = ch * CSTR + LPAD + i;
+        eg[kk] = 1.f;
+        eb[kk] = 0.f;
+        if constexpr (LN) {
+          bool ok = ch < nch;
+          eg[kk] = ok ? gamma[c0 + ch] : 0.f;
+          eb[kk] = ok ? beta[c0 + ch] : 0.f;
+        }
       }
     }
-#pragma unroll
-    for (int u = 0; u < RU; ++u)
-#pragma unroll
-      for (int p = 0; p < PER; ++p) {
-        int i = lane + 64 * p;
-        float x = v[u][p] * sc[u] + sh[u];
-        if constexpr (LN) x = fmaxf(x, LEAK * x);
-        if (i < ROWLEN) dst[doff[u] + i] = x;
-      }
   }
-}
-template <class C, class RowInfo>
-__device__ __forceinline__ void stage_rows_x(const float* src, float* dst, int nrows, int, RowInfo&& ri) {
-  wg_stage_rows<C::XH, C::XLN>(src, dst, nrows, ri);
-}
-template <class C, class RowInfo>
-__device__ __forceinline__ void stage_rows_y(const float* src, float* dst, int nrows, int, RowInfo&& ri) {
-  wg_stage_rows<C::YH, C::YLN>(src, dst, nrows, ri);
-}
 
+  static __device__ __forceinline__ void row_of(int rr, int wave, int& f, int& ch) {
+    if constexpr (RDIV) {
+      f = (rr * NWV) / CH;
+      ch = (rr * NWV) % CH + wave;
+    } else {
+      int r = rr * NWV + wave;
+      f = r / CH;
+      ch = r - f * CH;
+    }
+  }
+
+  __device__ __forceinline__ void gload(const float* __restrict__ src, int f0, int nfr, int c0, int nch) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    if constexpr (ROWS) {
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        int f, ch;
+        row_of(rr, wave, f, ch);
+        bool ok = (NROWS % NWV == 0 || rr * NWV + wave < NROWS) && f < nfr && ch < nch;
+        const float* row = src + ((f0 + (ok ? f : 0)) * CHTOT + c0 + (ok ? ch : 0)) * H;
+#pragma unroll
+        for (int p = 0; p < LPR; ++p) {
+          int i = lane + 64 * p;
+          v[rr * LPR + p] = (64 * (p + 1) <= H || i < H) ? row[i] : 0.f;
+        }
+      }
+    } else {
+      const int nvalid = nch * H;
+#pragma unroll
+      for (int f = 0; f < TF; ++f) {
+        const float* base = src + ((f0 + (f < nfr ? f : 0)) * CHTOT + c0) * H;
+#pragma unroll
+        for (int kk = 0; kk < KPF; ++kk) {
+          int e = tid + NTHR * kk;
+          v[f * KPF + kk] = e < nvalid ? base[e] : 0.f;
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void lstore(float* __restrict__ tile, const float* __restrict__ st,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, int f0,
+                                         int nfr, int c0, int nch) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    if constexpr (ROWS) {
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      constexpr int RB = RPW < 8 ? RPW : 8;
+#pragma unroll
+      for (int rr0 = 0; rr0 < RPW; rr0 += RB) {
+        float sc[RB], sh[RB];
+        int doff[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          int rr = rr0 + j < RPW ? rr0 + j : RPW - 1;
+          int f, ch;
+          row_of(rr, wave, f, ch);
+          bool ok = (NROWS % NWV == 0 || rr * NWV + wave < NROWS) && f < nfr && ch < nch;
+          sc[j] = ok ? 1.f : 0.f;
+          sh[j] = 0.f;
+          if constexpr (LN) {
+            int fs = f0 + (ok ? f : 0), cs = c0 + (ok ? ch : 0);
+            float mean = st[2 * fs], rstd = st[2 * fs + 1];
+            float g = gamma[cs], b = beta[cs];
+            sc[j] = ok ? rstd * g : 0.f;
+            sh[j] = ok ? b - mean * sc[j] : 0.f;
+          }
+          doff[j] = f * FSTR + ch * CSTR + LPAD;
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          if (rr0 + j >= RPW) continue;
+          if (NROWS % NWV == 0 || (rr0 + j) * NWV + wave < NROWS) {  // wave-uniform
+#pragma unroll
+            for (int p = 0; p < LPR; ++p) {
+              int i = lane + 64 * p;
+              float x = v[(rr0 + j) * LPR + p] * sc[j] + sh[j];
+              if constexpr (LN) x = fmaxf(x, LEAK * x);
+              if (64 * (p + 1) <= H || i < H) tile[doff[j] + i] = x;
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < TF; ++f) {
+        const bool okf = f < nfr;
+        float mean = 0.f, rstd = 0.f;
+        if constexpr (LN) {
+          int fs = f0 + (okf ? f : 0);
+          mean = st[2 * fs];
+          rstd = okf ? st[2 * fs + 1] : 0.f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < KPF; ++kk) {
+          float x = v[f * KPF + kk];
+          if constexpr (LN) {
+            x = (x - mean) * (rstd * eg[kk]) + (okf ? eb[kk] : 0.f);
+            x = fmaxf(x, LEAK * x);
+          } else {
+            x = okf ? x : 0.f;
+          }
+          if (NTHR * (kk + 1) <= PERF || tid + NTHR * kk < PERF) tile[f * FSTR + loff[kk]] = x;
+        }
+      }
+    }
+  }
+};
+
+// Software pipeline per workgroup: the global loads of sub-tile t+1 are issued before the MFMAs
+// of sub-tile t (both MFMA operands come from LDS, so nothing in the k loop waits on them) and
+// are written to the single LDS tile pair after the compute phase; two barriers per sub-tile.
 template <class C>
-__global__ void __launch_bounds__(256) k_convwgrad(WgArgs a) {
+__global__ void __launch_bounds__(C::NTHR) k_convwgrad(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  using OX = WgOperand<C::XC, C::XC, C::XH, C::CSTRX, C::FSTRX, C::HLO, C::XLN, C::TF, C::NWV>;
+  using OY = WgOperand<C::NTW * 32, C::YC, C::YH, C::CSTRY, C::FSTRY, 0, C::YLN, C::TF, C::NWV>;
   float* tX = lds;
   float* tY = lds + C::XT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int wm = wave % C::WM, wk = wave / C::WM;
-  const int nc0 = blockIdx.y * C::NTW * 32;  // first Y channel of this workgroup
-  for (int i = tid; i < (C::XT + C::YT) / 4; i += 256) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-
+  const int nc0 = blockIdx.y * C::NTW * 32;              // first Y channel of this workgroup
+  const int ych = min(C::NTW * 32, C::YC - nc0);         // valid Y channels
+  for (int i = tid; i < (C::XT + C::YT) / 4; i += C::NTHR) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   int baseA[C::MTW];
   bool aok[C::MTW];
 #pragma unroll
@@ -125,119 +262,85 @@ __global__ void __launch_bounds__(256) k_convwgrad(WgArgs a) {
 
   const int fb = blockIdx.x * a.fchunk;
   const int fe = min(a.F, fb + a.fchunk);
-  constexpr int XPER = C::XC * C::XH, YPER = C::NTW * 32 * C::YH;
+  OX ox;
+  OY oy;
+  ox.init(a.xg, a.xb, 0, C::XC);
+  oy.init(a.yg, a.yb, nc0, ych);
+#if VAENPVC_PROF
+  long long pc[6] = {0, 0, 0, 0, 0, 0};
+  WPROF_T(k0);
+#endif
+  ox.gload(a.X, fb, min(C::TF, fe - fb), 0, C::XC);
+  oy.gload(a.Y, fb, min(C::TF, fe - fb), nc0, ych);
+  __syncthreads();  // zero fill done
+  ox.lstore(tX, a.xst, a.xg, a.xb, fb, min(C::TF, fe - fb), 0, C::XC);
+  oy.lstore(tY, a.yst, a.yg, a.yb, fb, min(C::TF, fe - fb), nc0, ych);
+  __syncthreads();
   for (int f0 = fb; f0 < fe; f0 += C::TF) {
-    __syncthreads();  // previous sub-tile consumed (first pass: zero fill done)
-    const int nfr = min(C::TF, fe - f0);
-    // Both tiles are staged row-wise (row = one channel of one frame, wave-uniform index);
-    // frames past the chunk end and channels past YC are clamped on load and zeroed by scale 0.
-    if constexpr (C::XH >= 32) {
-      const float* src = a.X + (int64_t)f0 * XPER;
-      auto rowx = [&](int r, int& soff, int& doff, float& sc, float& sh) {
-        int f = r / C::XC, xc = r - f * C::XC;
-        bool ok = f < nfr;
-        int fs = ok ? f : 0;
-        soff = (fs * C::XC + xc) * C::XH;
-        doff = f * C::FSTRX + xc * C::CSTRX + C::HLO;
-        sc = ok ? 1.f : 0.f;
-        sh = 0.f;
-        if constexpr (C::XLN) {
-          float mean = a.xst[2 * (f0 + fs)], rstd = a.xst[2 * (f0 + fs) + 1];
-          sc = ok ? rstd * a.xg[xc] : 0.f;
-          sh = ok ? a.xb[xc] - mean * sc : 0.f;
-        }
-      };
-      stage_rows_x<C>(src, tX, C::TF * C::XC, nfr, rowx);
-    } else
-    {  // X tile: nfr whole frames are one contiguous HBM range
-      auto putx = [&](int e, float v) {
-        int f = e / XPER, rem = e - f * XPER;
-        int xc = rem / C::XH, i = rem - xc * C::XH;
-        if constexpr (C::XLN) v = lnact_v(v, a.xst[2 * (f0 + f)], a.xst[2 * (f0 + f) + 1], a.xg[xc], a.xb[xc]);
-        tX[f * C::FSTRX + xc * C::CSTRX + C::HLO + i] = v;
-      };
-      stage_range<(XPER % 4 == 0) ? 4 : 1, 8>(a.X + (int64_t)f0 * XPER, nfr * XPER, putx);
-      if (nfr < C::TF)  // tail of the chunk: frames beyond it must read as zero
-        for (int e = nfr * XPER + tid; e < C::TF * XPER; e += 256) {
-          int f = e / XPER, rem = e - f * XPER;
-          int xc = rem / C::XH, i = rem - xc * C::XH;
-          tX[f * C::FSTRX + xc * C::CSTRX + C::HLO + i] = 0.f;
-        }
+    const int fn = f0 + C::TF;
+    WPROF_T(w0);
+    if (fn < fe) {
+      ox.gload(a.X, fn, min(C::TF, fe - fn), 0, C::XC);
+      oy.gload(a.Y, fn, min(C::TF, fe - fn), nc0, ych);
     }
-    if constexpr (C::YH >= 32) {
-      constexpr int YFR = C::YC * C::YH;
-      const float* src = a.Y + (int64_t)f0 * YFR + (int64_t)nc0 * C::YH;
-      const int ych = min(C::NTW * 32, C::YC - nc0);  // valid channels of this workgroup
-      auto rowy = [&](int r, int& soff, int& doff, float& sc, float& sh) {
-        int f = r / (C::NTW * 32), nl = r - f * (C::NTW * 32);
-        bool ok = f < nfr && nl < ych;
-        int fs = ok ? f : 0, ns = ok ? nl : 0;
-        soff = fs * YFR + ns * C::YH;
-        doff = f * C::FSTRY + nl * C::CSTRY;
-        sc = ok ? 1.f : 0.f;
-        sh = 0.f;
-        if constexpr (C::YLN) {
-          float mean = a.yst[2 * (f0 + fs)], rstd = a.yst[2 * (f0 + fs) + 1];
-          sc = ok ? rstd * a.yg[nc0 + ns] : 0.f;
-          sh = ok ? a.yb[nc0 + ns] - mean * sc : 0.f;
-        }
-      };
-      stage_rows_y<C>(src, tY, C::TF * C::NTW * 32, nfr, rowy);
-    } else
-    {  // Y tile: per frame the valid channels of this workgroup are one contiguous run
-      constexpr int YFR = C::YC * C::YH;              // floats per frame of Y
-      const int ych = min(C::NTW * 32, C::YC - nc0);  // valid channels
-      const int yper = ych * C::YH;
-      const int ytot = C::TF * yper;
-      constexpr int BT = 16;
-      for (int e0 = tid; e0 < ytot; e0 += 256 * BT) {
-        float v[BT];
+    __builtin_amdgcn_sched_barrier(0);
+    WPROF_T(w1);
+    // k-steps: RU positions r per trip x frame pairs fp; the WK waves that share an M range take
+    // interleaved groups of positions.  All fragment reads of a trip are issued before its MFMAs.
+    for (int r0 = wk * C::RU; r0 < C::YH; r0 += C::WK * C::RU) {
+      float av[C::RU][C::HP][C::MTW], bv[C::RU][C::HP][C::NTW];
 #pragma unroll
-        for (int b = 0; b < BT; ++b) {
-          int e = e0 + 256 * b;
-          int f = e / yper, rem = e - f * yper;
-          v[b] = (e < ytot && f < nfr) ? a.Y[(int64_t)(f0 + f) * YFR + (int64_t)nc0 * C::YH + rem] : 0.f;
-        }
+      for (int u = 0; u < C::RU; ++u) {
+        const bool rok = r0 + u < C::YH;  // wave-uniform
+        const int r = rok ? r0 + u : C::YH - 1;
 #pragma unroll
-        for (int b = 0; b < BT; ++b) {
-          int e = e0 + 256 * b;
-          if (e < ytot) {
-            int f = e / yper, rem = e - f * yper;
-            int nl = rem / C::YH, r = rem - nl * C::YH;
-            float x = v[b];
-            if constexpr (C::YLN) {
-              if (f < nfr) x = lnact_v(x, a.yst[2 * (f0 + f)], a.yst[2 * (f0 + f) + 1], a.yg[nc0 + nl], a.yb[nc0 + nl]);
-            }
-            tY[f * C::FSTRY + nl * C::CSTRY + r] = x;
+        for (int fp = 0; fp < C::HP; ++fp) {
+#pragma unroll
+          for (int i = 0; i < C::MTW; ++i) {
+            float v = tX[baseA[i] + C::S * r + fp * 2 * C::FSTRX];
+            av[u][fp][i] = aok[i] ? v : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < C::NTW; ++j) {
+            float v = tY[baseB[j] + r + fp * 2 * C::FSTRY];
+            bv[u][fp][j] = rok ? v : 0.f;
           }
         }
       }
+#pragma unroll
+      for (int u = 0; u < C::RU; ++u)
+#pragma unroll
+        for (int fp = 0; fp < C::HP; ++fp)
+#pragma unroll
+          for (int i = 0; i < C::MTW; ++i)
+#pragma unroll
+            for (int j = 0; j < C::NTW; ++j) acc[i][j] = mfma32(av[u][fp][i], bv[u][fp][j], acc[i][j]);
     }
+#if VAENPVC_PROF
+    asm volatile("s_nop 0" ::: "memory");
+#endif
+    WPROF_T(w2);
+    __syncthreads();  // sub-tile consumed
+    WPROF_T(w3);
+    if (fn < fe) {
+      ox.lstore(tX, a.xst, a.xg, a.xb, fn, min(C::TF, fe - fn), 0, C::XC);
+      oy.lstore(tY, a.yst, a.yg, a.yb, fn, min(C::TF, fe - fn), nc0, ych);
+    }
+#if VAENPVC_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    WPROF_T(w4);
     __syncthreads();
-    // k-steps: position r (outer) x frame pair fp (inner, unrolled); the WK waves that share
-    // an M range take interleaved positions r.  Fragment reads of one r are all issued before
-    // its MFMAs (addresses differ only by compile-time offsets).
-    constexpr int HP = C::TF / 2;
-    for (int r = wk; r < C::YH; r += C::WK) {
-      float av[HP][C::MTW], bv[HP][C::NTW];
-#pragma unroll
-      for (int fp = 0; fp < HP; ++fp) {
-#pragma unroll
-        for (int i = 0; i < C::MTW; ++i) {
-          float v = tX[baseA[i] + C::S * r + fp * 2 * C::FSTRX];
-          av[fp][i] = aok[i] ? v : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < C::NTW; ++j) bv[fp][j] = tY[baseB[j] + r + fp * 2 * C::FSTRY];
-      }
-#pragma unroll
-      for (int fp = 0; fp < HP; ++fp)
-#pragma unroll
-        for (int i = 0; i < C::MTW; ++i)
-#pragma unroll
-          for (int j = 0; j < C::NTW; ++j) acc[i][j] = mfma32(av[fp][i], bv[fp][j], acc[i][j]);
-    }
+#if VAENPVC_PROF
+    WPROF_T(w5);
+    pc[0] += (w1 - w0);  // gload issue
+    pc[4] += (w4 - w3);  // lstore (incl. landing of the loads)
+    pc[1] += w3 - w2;                // barrier after compute
+    pc[2] += w2 - w1;                // compute
+    pc[3] += w5 - w4;                // barrier after staging
+#endif
   }
+  WPROF_T(k1);
 #pragma unroll
   for (int i = 0; i < C::MTW; ++i)
 #pragma unroll
@@ -248,21 +351,44 @@ __global__ void __launch_bounds__(256) k_convwgrad(WgArgs a) {
         int n = nc0 + j * 32 + l31;
         if (m < C::M && n < C::YC) atomicAdd(a.dW + (int64_t)m * C::YC + n, acc[i][j][reg]);
       }
+#if VAENPVC_PROF
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WPROF_T(k2);
+    if ((threadIdx.x & 63) == 0) {
+      unsigned long long* g = g_wg_prof[a.slot];
+      atomicAdd(g + 0, 1ull);
+      for (int i = 0; i < 4; ++i) atomicAdd(g + 1 + i, (unsigned long long)pc[i]);
+      atomicAdd(g + 5, (unsigned long long)(k2 - k1));
+      atomicAdd(g + 6, (unsigned long long)(k2 - k0));
+      atomicAdd(g + 7, (unsigned long long)pc[4]);
+    }
+  }
+#endif
 }
 
 template <class C>
 inline void launch_convwgrad(const WgArgs& a0, int target_wgs, hipStream_t s) {
+  constexpr int LDS_BYTES = (C::XT + C::YT) * 4;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convwgrad<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              C::LDS_BYTES);
+                              LDS_BYTES);
     once = true;
   }
   WgArgs a = a0;
   int chunks = cmax(1, target_wgs / C::NSPLIT);
   a.fchunk = rup(cmax(1, cdiv(a.F, chunks)), C::TF);
   dim3 grid((unsigned)cdiv(a.F, a.fchunk), (unsigned)C::NSPLIT);
-  hipLaunchKernelGGL(k_convwgrad<C>, grid, dim3(256), C::LDS_BYTES, s, a);
+#if VAENPVC_PROF
+  static int slot = -1;
+  if (slot < 0) {
+    slot = g_wg_prof_next++;
+    fprintf(stderr, "WPROF slot %d grid %u x %u fchunk %d lds %d : %s\n", slot, grid.x, grid.y, a.fchunk, LDS_BYTES, __PRETTY_FUNCTION__);
+  }
+  a.slot = slot;
+#endif
+  hipLaunchKernelGGL(k_convwgrad<C>, grid, dim3(C::NTHR), LDS_BYTES, s, a);
 }
 
 }  // namespace tuned
