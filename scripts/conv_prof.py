@@ -43,7 +43,7 @@ for s in range(32):
     parts = a[s, 1:8] / w
     print('%4d %6d %12.0f | ' % (s, w / N, tot) + ' '.join('%6.1f%%' % (100 * p / tot) for p in parts) + ' | %5.1f%%' % (100 * (tot - parts.sum()) / tot))
 
-names = ['gload', 'bar1', 'compute', 'bar2', 'epilogue', 'lstore']
+names = ['gload', 'bar1', 'compute', 'landing', 'epilogue', 'lstore+l']
 print('convwgrad slot waves total_cyc/wave | ' + ' '.join('%8s' % n for n in names) + ' | other')
 for s in range(16):
     if wg[s, 0] == 0:

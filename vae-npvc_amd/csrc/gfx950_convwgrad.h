@@ -85,7 +85,7 @@ struct WgArgs {
 //     channels; the (channel, bin) split, the LDS offset and gamma/beta of an element do not depend
 //     on the frame and are computed once per thread (init()); mean/rstd of a frame are scalar.
 // Frames past the chunk end and channels past the tensor are clamped on load and written as zeros.
-template <int CH, int CHTOT, int H, int CSTR, int FSTR, int LPAD, bool LN, int TF, int NWV>
+template <int CH, int CHTOT, int H, int CSTR, int FSTR, int LPAD, bool LN, int TF, int NWV, int DUMMY>
 struct WgOperand {
   static constexpr bool ROWS = H >= 32;
   static constexpr int NTHR = NWV * 64;
@@ -106,10 +106,11 @@ struct WgOperand {
         int ec = e < PERF ? e : PERF - 1;
         int ch = ec / H, i = ec - ch * H;
         loff[kk] = ch * CSTR + LPAD + i;
-        eg[kk] = 1.f;
+        bool ok = ch < nch;
+        if (e >= PERF) loff[kk] = DUMMY;  // lanes past the tile row space write to a scratch word
+        eg[kk] = ok ? 1.f : 0.f;
         eb[kk] = 0.f;
         if constexpr (LN) {
-          bool ok = ch < nch;
           eg[kk] = ok ? gamma[c0 + ch] : 0.f;
           eb[kk] = ok ? beta[c0 + ch] : 0.f;
         }
@@ -141,7 +142,8 @@ struct WgOperand {
 #pragma unroll
         for (int p = 0; p < LPR; ++p) {
           int i = lane + 64 * p;
-          v[rr * LPR + p] = (64 * (p + 1) <= H || i < H) ? row[i] : 0.f;
+          if (64 * (p + 1) > H) i = i < H ? i : H - 1;  // branch-free: duplicates are never stored
+          v[rr * LPR + p] = row[i];
         }
       }
     } else {
@@ -152,7 +154,7 @@ struct WgOperand {
 #pragma unroll
         for (int kk = 0; kk < KPF; ++kk) {
           int e = tid + NTHR * kk;
-          v[f * KPF + kk] = e < nvalid ? base[e] : 0.f;
+          v[f * KPF + kk] = base[e < nvalid ? e : nvalid - 1];  // clamped, zeroed in lstore (eg/eb/okf)
         }
       }
     }
@@ -195,7 +197,7 @@ struct WgOperand {
               int i = lane + 64 * p;
               float x = v[(rr0 + j) * LPR + p] * sc[j] + sh[j];
               if constexpr (LN) x = fmaxf(x, LEAK * x);
-              if (64 * (p + 1) <= H || i < H) tile[doff[j] + i] = x;
+              tile[(64 * (p + 1) <= H || i < H) ? doff[j] + i : DUMMY] = x;
             }
           }
         }
@@ -217,9 +219,9 @@ struct WgOperand {
             x = (x - mean) * (rstd * eg[kk]) + (okf ? eb[kk] : 0.f);
             x = fmaxf(x, LEAK * x);
           } else {
-            x = okf ? x : 0.f;
+            x = okf ? x * eg[kk] : 0.f;
           }
-          if (NTHR * (kk + 1) <= PERF || tid + NTHR * kk < PERF) tile[f * FSTR + loff[kk]] = x;
+          tile[(NTHR * (kk + 1) <= PERF || tid + NTHR * kk < PERF) ? f * FSTR + loff[kk] : DUMMY] = x;
         }
       }
     }
@@ -232,8 +234,9 @@ struct WgOperand {
 template <class C>
 __global__ void __launch_bounds__(C::NTHR) k_convwgrad(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  using OX = WgOperand<C::XC, C::XC, C::XH, C::CSTRX, C::FSTRX, C::HLO, C::XLN, C::TF, C::NWV>;
-  using OY = WgOperand<C::NTW * 32, C::YC, C::YH, C::CSTRY, C::FSTRY, 0, C::YLN, C::TF, C::NWV>;
+  // DUMMY: offset (relative to the operand's tile) of a scratch word behind both tiles
+  using OX = WgOperand<C::XC, C::XC, C::XH, C::CSTRX, C::FSTRX, C::HLO, C::XLN, C::TF, C::NWV, C::XT + C::YT>;
+  using OY = WgOperand<C::NTW * 32, C::YC, C::YH, C::CSTRY, C::FSTRY, 0, C::YLN, C::TF, C::NWV, C::YT>;
   float* tX = lds;
   float* tY = lds + C::XT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -322,6 +325,11 @@ __global__ void __launch_bounds__(C::NTHR) k_convwgrad(WgArgs a) {
     WPROF_T(w2);
     __syncthreads();  // sub-tile consumed
     WPROF_T(w3);
+#if VAENPVC_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WPROF_T(w3b);
+    pc[5] += w3b - w3;  // landing of the prefetch
+#endif
     if (fn < fe) {
       ox.lstore(tX, a.xst, a.xg, a.xb, fn, min(C::TF, fe - fn), 0, C::XC);
       oy.lstore(tY, a.yst, a.yg, a.yb, fn, min(C::TF, fe - fn), nc0, ych);
@@ -337,7 +345,6 @@ __global__ void __launch_bounds__(C::NTHR) k_convwgrad(WgArgs a) {
     pc[4] += (w4 - w3);  // lstore (incl. landing of the loads)
     pc[1] += w3 - w2;                // barrier after compute
     pc[2] += w2 - w1;                // compute
-    pc[3] += w5 - w4;                // barrier after staging
 #endif
   }
   WPROF_T(k1);
@@ -362,6 +369,7 @@ __global__ void __launch_bounds__(C::NTHR) k_convwgrad(WgArgs a) {
       atomicAdd(g + 5, (unsigned long long)(k2 - k1));
       atomicAdd(g + 6, (unsigned long long)(k2 - k0));
       atomicAdd(g + 7, (unsigned long long)pc[4]);
+      atomicAdd(g + 4, (unsigned long long)pc[5]);  // (reuses the barrier-2 column)
     }
   }
 #endif
@@ -369,7 +377,7 @@ __global__ void __launch_bounds__(C::NTHR) k_convwgrad(WgArgs a) {
 
 template <class C>
 inline void launch_convwgrad(const WgArgs& a0, int target_wgs, hipStream_t s) {
-  constexpr int LDS_BYTES = (C::XT + C::YT) * 4;
+  constexpr int LDS_BYTES = (C::XT + C::YT + 4) * 4;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convwgrad<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -377,6 +385,8 @@ inline void launch_convwgrad(const WgArgs& a0, int target_wgs, hipStream_t s) {
     once = true;
   }
   WgArgs a = a0;
+  static const int env_wgs = getenv("VAENPVC_WGS") ? atoi(getenv("VAENPVC_WGS")) : 0;  // developer knob
+  if (env_wgs > 0) target_wgs = env_wgs;
   int chunks = cmax(1, target_wgs / C::NSPLIT);
   a.fchunk = rup(cmax(1, cdiv(a.F, chunks)), C::TF);
   dim3 grid((unsigned)cdiv(a.F, a.fchunk), (unsigned)C::NSPLIT);
