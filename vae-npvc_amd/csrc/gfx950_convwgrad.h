@@ -12,9 +12,13 @@
 // chunks are combined with fp32 global atomics.
 #pragma once
 #include "gfx950_common.h"
+#include "gfx950_stage.h"
 
 #ifndef VAENPVC_PROF
 #define VAENPVC_PROF 0
+#endif
+#ifndef VAENPVC_WABL
+#define VAENPVC_WABL 0  // developer ablations: 1 no MFMA loop, 2 no LDS store of the prefetch, 3 no prefetch loads
 #endif
 
 namespace vaenpvc {
@@ -73,170 +77,14 @@ struct WgArgs {
 #endif
 };
 
-// One operand tile (CH channels x H bins of TF frames) of the weight-gradient GEMM, staged in two
-// halves: gload() issues the global loads of a sub-tile into registers (they stay in flight while
-// the MFMAs of the previous sub-tile run), lstore() applies LN+lrelu and writes the LDS tile.
-// Both halves are fully unrolled with compile-time (frame, channel) indices wherever possible, so
-// that an element costs one load / one fma+max+ds_write and almost no address arithmetic
-// (staging instructions compete with the MFMAs for issue slots).
-//   ROWS (H >= 32): wave w owns rows rr*NWV + w (row = one channel of one frame, wave-uniform:
-//     addresses and LayerNorm constants are scalar, loaded in batches before they are used).
-//   ELEM (short rows): per frame, element e = tid + NTHR*kk of the contiguous run of the tile's
-//     channels; the (channel, bin) split, the LDS offset and gamma/beta of an element do not depend
-//     on the frame and are computed once per thread (init()); mean/rstd of a frame are scalar.
-// Frames past the chunk end and channels past the tensor are clamped on load and written as zeros.
-template <int CH, int CHTOT, int H, int CSTR, int FSTR, int LPAD, bool LN, int TF, int NWV, int DUMMY>
-struct WgOperand {
-  static constexpr bool ROWS = H >= 32;
-  static constexpr int NTHR = NWV * 64;
-  static constexpr int NROWS = TF * CH, RPW = cdiv(NROWS, NWV), LPR = cdiv(H, 64);
-  static constexpr bool RDIV = CH % NWV == 0;  // (frame, channel) of row rr*NWV + w: compile-time + w
-  static constexpr int PERF = CH * H, KPF = cdiv(PERF, NTHR);
-  static constexpr int NREG = ROWS ? RPW * LPR : TF * KPF;
-  static constexpr int NE = ROWS ? 1 : KPF;
-  float v[NREG];
-  int loff[NE];
-  float eg[NE], eb[NE];
-
-  __device__ __forceinline__ void init(const float* __restrict__ gamma, const float* __restrict__ beta, int c0, int nch) {
-    if constexpr (!ROWS) {
-#pragma unroll
-      for (int kk = 0; kk < KPF; ++kk) {
-        int e = threadIdx.x + NTHR * kk;
-        int ec = e < PERF ? e : PERF - 1;
-        int ch = ec / H, i = ec - ch * H;
-        loff[kk] = ch * CSTR + LPAD + i;
-        bool ok = ch < nch;
-        if (e >= PERF) loff[kk] = DUMMY;  // lanes past the tile row space write to a scratch word
-        eg[kk] = ok ? 1.f : 0.f;
-        eb[kk] = 0.f;
-        if constexpr (LN) {
-          eg[kk] = ok ? gamma[c0 + ch] : 0.f;
-          eb[kk] = ok ? beta[c0 + ch] : 0.f;
-        }
-      }
-    }
-  }
-
-  static __device__ __forceinline__ void row_of(int rr, int wave, int& f, int& ch) {
-    if constexpr (RDIV) {
-      f = (rr * NWV) / CH;
-      ch = (rr * NWV) % CH + wave;
-    } else {
-      int r = rr * NWV + wave;
-      f = r / CH;
-      ch = r - f * CH;
-    }
-  }
-
-  __device__ __forceinline__ void gload(const float* __restrict__ src, int f0, int nfr, int c0, int nch) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    if constexpr (ROWS) {
-      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        int f, ch;
-        row_of(rr, wave, f, ch);
-        bool ok = (NROWS % NWV == 0 || rr * NWV + wave < NROWS) && f < nfr && ch < nch;
-        const float* row = src + ((f0 + (ok ? f : 0)) * CHTOT + c0 + (ok ? ch : 0)) * H;
-#pragma unroll
-        for (int p = 0; p < LPR; ++p) {
-          int i = lane + 64 * p;
-          if (64 * (p + 1) > H) i = i < H ? i : H - 1;  // branch-free: duplicates are never stored
-          v[rr * LPR + p] = row[i];
-        }
-      }
-    } else {
-      const int nvalid = nch * H;
-#pragma unroll
-      for (int f = 0; f < TF; ++f) {
-        const float* base = src + ((f0 + (f < nfr ? f : 0)) * CHTOT + c0) * H;
-#pragma unroll
-        for (int kk = 0; kk < KPF; ++kk) {
-          int e = tid + NTHR * kk;
-          v[f * KPF + kk] = base[e < nvalid ? e : nvalid - 1];  // clamped, zeroed in lstore (eg/eb/okf)
-        }
-      }
-    }
-  }
-
-  __device__ __forceinline__ void lstore(float* __restrict__ tile, const float* __restrict__ st,
-                                         const float* __restrict__ gamma, const float* __restrict__ beta, int f0,
-                                         int nfr, int c0, int nch) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    if constexpr (ROWS) {
-      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-      constexpr int RB = RPW < 8 ? RPW : 8;
-#pragma unroll
-      for (int rr0 = 0; rr0 < RPW; rr0 += RB) {
-        float sc[RB], sh[RB];
-        int doff[RB];
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-          int rr = rr0 + j < RPW ? rr0 + j : RPW - 1;
-          int f, ch;
-          row_of(rr, wave, f, ch);
-          bool ok = (NROWS % NWV == 0 || rr * NWV + wave < NROWS) && f < nfr && ch < nch;
-          sc[j] = ok ? 1.f : 0.f;
-          sh[j] = 0.f;
-          if constexpr (LN) {
-            int fs = f0 + (ok ? f : 0), cs = c0 + (ok ? ch : 0);
-            float mean = st[2 * fs], rstd = st[2 * fs + 1];
-            float g = gamma[cs], b = beta[cs];
-            sc[j] = ok ? rstd * g : 0.f;
-            sh[j] = ok ? b - mean * sc[j] : 0.f;
-          }
-          doff[j] = f * FSTR + ch * CSTR + LPAD;
-        }
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-          if (rr0 + j >= RPW) continue;
-          if (NROWS % NWV == 0 || (rr0 + j) * NWV + wave < NROWS) {  // wave-uniform
-#pragma unroll
-            for (int p = 0; p < LPR; ++p) {
-              int i = lane + 64 * p;
-              float x = v[(rr0 + j) * LPR + p] * sc[j] + sh[j];
-              if constexpr (LN) x = fmaxf(x, LEAK * x);
-              tile[(64 * (p + 1) <= H || i < H) ? doff[j] + i : DUMMY] = x;
-            }
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int f = 0; f < TF; ++f) {
-        const bool okf = f < nfr;
-        float mean = 0.f, rstd = 0.f;
-        if constexpr (LN) {
-          int fs = f0 + (okf ? f : 0);
-          mean = st[2 * fs];
-          rstd = okf ? st[2 * fs + 1] : 0.f;
-        }
-#pragma unroll
-        for (int kk = 0; kk < KPF; ++kk) {
-          float x = v[f * KPF + kk];
-          if constexpr (LN) {
-            x = (x - mean) * (rstd * eg[kk]) + (okf ? eb[kk] : 0.f);
-            x = fmaxf(x, LEAK * x);
-          } else {
-            x = okf ? x * eg[kk] : 0.f;
-          }
-          tile[(NTHR * (kk + 1) <= PERF || tid + NTHR * kk < PERF) ? f * FSTR + loff[kk] : DUMMY] = x;
-        }
-      }
-    }
-  }
-};
-
 // Software pipeline per workgroup: the global loads of sub-tile t+1 are issued before the MFMAs
 // of sub-tile t (both MFMA operands come from LDS, so nothing in the k loop waits on them) and
 // are written to the single LDS tile pair after the compute phase; two barriers per sub-tile.
 template <class C>
 __global__ void __launch_bounds__(C::NTHR) k_convwgrad(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  // DUMMY: offset (relative to the operand's tile) of a scratch word behind both tiles
-  using OX = WgOperand<C::XC, C::XC, C::XH, C::CSTRX, C::FSTRX, C::HLO, C::XLN, C::TF, C::NWV, C::XT + C::YT>;
-  using OY = WgOperand<C::NTW * 32, C::YC, C::YH, C::CSTRY, C::FSTRY, 0, C::YLN, C::TF, C::NWV, C::YT>;
+  using OX = TileStager<C::XC, C::XC, C::XH, C::CSTRX, C::FSTRX, C::HLO, C::XLN, C::TF, C::NWV>;
+  using OY = TileStager<C::NTW * 32, C::YC, C::YH, C::CSTRY, C::FSTRY, 0, C::YLN, C::TF, C::NWV>;
   float* tX = lds;
   float* tY = lds + C::XT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -267,29 +115,34 @@ __global__ void __launch_bounds__(C::NTHR) k_convwgrad(WgArgs a) {
   const int fe = min(a.F, fb + a.fchunk);
   OX ox;
   OY oy;
-  ox.init(a.xg, a.xb, 0, C::XC);
-  oy.init(a.yg, a.yb, nc0, ych);
+  ox.init(tX, a.xg, a.xb, 0, C::XC);
+  oy.init(tY, a.yg, a.yb, nc0, ych);
 #if VAENPVC_PROF
   long long pc[6] = {0, 0, 0, 0, 0, 0};
   WPROF_T(k0);
 #endif
-  ox.gload(a.X, fb, min(C::TF, fe - fb), 0, C::XC);
-  oy.gload(a.Y, fb, min(C::TF, fe - fb), nc0, ych);
+  ox.gload(a.X, a.xst, fb, min(C::TF, fe - fb), 0, C::XC);
+  oy.gload(a.Y, a.yst, fb, min(C::TF, fe - fb), nc0, ych);
   __syncthreads();  // zero fill done
-  ox.lstore(tX, a.xst, a.xg, a.xb, fb, min(C::TF, fe - fb), 0, C::XC);
-  oy.lstore(tY, a.yst, a.yg, a.yb, fb, min(C::TF, fe - fb), nc0, ych);
+  ox.lstore(tX, min(C::TF, fe - fb), C::XC);
+  oy.lstore(tY, min(C::TF, fe - fb), ych);
   __syncthreads();
   for (int f0 = fb; f0 < fe; f0 += C::TF) {
     const int fn = f0 + C::TF;
     WPROF_T(w0);
+#if VAENPVC_WABL != 3
     if (fn < fe) {
-      ox.gload(a.X, fn, min(C::TF, fe - fn), 0, C::XC);
-      oy.gload(a.Y, fn, min(C::TF, fe - fn), nc0, ych);
+      ox.gload(a.X, a.xst, fn, min(C::TF, fe - fn), 0, C::XC);
+      oy.gload(a.Y, a.yst, fn, min(C::TF, fe - fn), nc0, ych);
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     WPROF_T(w1);
     // k-steps: RU positions r per trip x frame pairs fp; the WK waves that share an M range take
     // interleaved groups of positions.  All fragment reads of a trip are issued before its MFMAs.
+#if VAENPVC_WABL == 1
+    if (a.F < 0)
+#endif
     for (int r0 = wk * C::RU; r0 < C::YH; r0 += C::WK * C::RU) {
       float av[C::RU][C::HP][C::MTW], bv[C::RU][C::HP][C::NTW];
 #pragma unroll
@@ -330,10 +183,12 @@ __global__ void __launch_bounds__(C::NTHR) k_convwgrad(WgArgs a) {
     WPROF_T(w3b);
     pc[5] += w3b - w3;  // landing of the prefetch
 #endif
+#if VAENPVC_WABL != 2
     if (fn < fe) {
-      ox.lstore(tX, a.xst, a.xg, a.xb, fn, min(C::TF, fe - fn), 0, C::XC);
-      oy.lstore(tY, a.yst, a.yg, a.yb, fn, min(C::TF, fe - fn), nc0, ych);
+      ox.lstore(tX, min(C::TF, fe - fn), C::XC);
+      oy.lstore(tY, min(C::TF, fe - fn), ych);
     }
+#endif
 #if VAENPVC_PROF
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
@@ -377,7 +232,7 @@ __global__ void __launch_bounds__(C::NTHR) k_convwgrad(WgArgs a) {
 
 template <class C>
 inline void launch_convwgrad(const WgArgs& a0, int target_wgs, hipStream_t s) {
-  constexpr int LDS_BYTES = (C::XT + C::YT + 4) * 4;
+  constexpr int LDS_BYTES = (C::XT + C::YT) * 4;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convwgrad<C>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -1,0 +1,207 @@
+// gfx950_stage.h -- HBM -> registers -> LDS staging of one activation tile, shared by the conv
+// engine (gfx950_convgemm.h) and the weight-gradient kernel (gfx950_convwgrad.h).
+//
+// A tile = CH channels x H bins of TF consecutive frames of a [F][CHTOT][H] tensor (channels
+// c0 .. c0+CH-1), laid out in LDS as  f*FSTR + ch*CSTR + LPAD + i  (zero halos around each row are
+// written once by the kernel and never touched here).  Staging is split in two halves so that the
+// global loads of tile t+1 are in flight while tile t is being multiplied:
+//   gload()  : issue every global load of the tile into registers (clamped addresses, no branches);
+//   lstore() : apply LN + leaky-relu (optional) and write the LDS tile.
+//
+// Every instruction here competes with another wave's MFMA stream for the SIMD's issue slots, so the
+// code is organised to need as few VALU instructions per element as possible:
+//   ROWS (H >= 32): wave w owns rows rr*NWV + w (row = one channel of one frame).  The row index is
+//     wave-uniform: addresses, validity and the LayerNorm constants live on the scalar unit, LDS
+//     addresses are one per-lane base + immediate offsets; per element: fma, mul, max, ds_write.
+//   ELEM (short rows): per frame, element e = tid + NTHR*kk of the contiguous run of the tile's
+//     channels; its (channel, bin) split, LDS address and gamma/beta do not depend on the frame and
+//     are computed once per thread (init()); mean/rstd of a frame are scalar; per element: fma, fma,
+//     mul, max, ds_write.
+// Frames past the end (nfr < TF) and channels past the tensor (nch < CH) are clamped on load and
+// written as zeros (uniform branches, only taken in the last tile of a chunk).
+#pragma once
+#include "gfx950_common.h"
+
+namespace vaenpvc {
+namespace tuned {
+
+template <int CH, int CHTOT, int H, int CSTR, int FSTR, int LPAD, bool LN, int TF, int NWV>
+struct TileStager {
+  static constexpr bool ROWS = H >= 32;
+  static constexpr int NTHR = NWV * 64;
+  static constexpr int NROWS = TF * CH, RPW = cdiv(NROWS, NWV), LPR = cdiv(H, 64);
+  static constexpr bool RDIV = CH % NWV == 0;  // (frame, channel) of row rr*NWV + w = compile-time + w
+  static constexpr bool RFULL = NROWS % NWV == 0;
+  static constexpr int PERF = CH * H, KPF = cdiv(PERF, NTHR);
+  static constexpr int NREG = ROWS ? RPW * LPR : TF * KPF;
+  static constexpr int NE = ROWS ? 1 : KPF;
+  static constexpr bool PARTIAL = CHTOT % CH != 0;  // the last channel tile of the tensor is not full
+  float v[NREG];
+  float* pk[NE];  // ELEM: LDS address of element kk in frame 0
+  float eg[NE], eb[NE];
+  // LayerNorm constants travel in registers, never through memory at lstore() time (a scalar or
+  // vector load there is a full memory latency in the middle of the LDS stores): lane l of `stv`
+  // holds word l of the tile's (mean, rstd) pairs (loaded with the tile in gload()), lane c of
+  // `gv`/`bv` holds gamma/beta of channel c (ROWS; loaded once); lstore() broadcasts them with
+  // v_readlane.
+  float stv, gv, bv;
+  static_assert(!LN || 2 * TF <= 64, "statistics of a tile must fit one register");
+  static_assert(!(LN && ROWS) || CH <= 64, "gamma/beta of a ROWS tile must fit one register");
+
+  static __device__ __forceinline__ float bcast(float x, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+  }
+
+  __device__ __forceinline__ void init(float* __restrict__ tile, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, int c0, int nch) {
+    if constexpr (ROWS && LN) {
+      int c = threadIdx.x & 63;
+      c = c0 + (c < nch ? c : nch - 1);
+      gv = gamma[c];
+      bv = beta[c];
+    }
+    if constexpr (!ROWS) {
+#pragma unroll
+      for (int kk = 0; kk < KPF; ++kk) {
+        int e = threadIdx.x + NTHR * kk;
+        int ec = e < PERF ? e : PERF - 1;
+        int ch = ec / H, i = ec - ch * H;
+        pk[kk] = tile + ch * CSTR + LPAD + i;
+        bool ok = ch < nch;
+        eg[kk] = ok ? 1.f : 0.f;
+        eb[kk] = 0.f;
+        if constexpr (LN) {
+          eg[kk] = ok ? gamma[c0 + ch] : 0.f;
+          eb[kk] = ok ? beta[c0 + ch] : 0.f;
+        }
+      }
+    }
+  }
+
+  static __device__ __forceinline__ void row_of(int rr, int wave, int& f, int& ch) {
+    if constexpr (RDIV) {
+      f = (rr * NWV) / CH;
+      ch = (rr * NWV) % CH + wave;
+    } else {
+      int r = rr * NWV + wave;
+      f = r / CH;
+      ch = r - f * CH;
+    }
+  }
+
+  __device__ __forceinline__ void gload(const float* __restrict__ src, const float* __restrict__ st, int f0, int nfr,
+                                        int c0, int nch) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    if constexpr (LN) stv = st[2 * f0 + (lane < 2 * nfr ? lane : 2 * nfr - 1)];
+    if constexpr (ROWS) {
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        int f, ch;
+        row_of(rr, wave, f, ch);
+        bool ok = (RFULL || rr * NWV + wave < NROWS) && f < nfr && ch < nch;
+        const float* row = src + ((int64_t)(f0 + (ok ? f : 0)) * CHTOT + c0 + (ok ? ch : 0)) * H;
+#pragma unroll
+        for (int p = 0; p < LPR; ++p) {
+          int i = lane + 64 * p;
+          if (64 * (p + 1) > H) i = i < H ? i : H - 1;  // duplicates of the last bin are never stored
+          v[rr * LPR + p] = row[i];
+        }
+      }
+    } else {
+      const int nvalid = nch * H;
+#pragma unroll
+      for (int f = 0; f < TF; ++f) {
+        const float* base = src + ((int64_t)(f0 + (f < nfr ? f : 0)) * CHTOT + c0) * H;
+#pragma unroll
+        for (int kk = 0; kk < KPF; ++kk) {
+          int e = tid + NTHR * kk;
+          v[f * KPF + kk] = base[e < nvalid ? e : nvalid - 1];  // clamped; zeroed through eg/eb
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void lstore(float* __restrict__ tile, int nfr, int nch) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    if constexpr (ROWS) {
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      float* tb = tile + lane;
+      constexpr int RB = RPW < 8 ? RPW : 8;
+#pragma unroll
+      for (int rr0 = 0; rr0 < RPW; rr0 += RB) {
+        float sc[RB], sh[RB];
+        bool okr[RB];
+        int doff[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          int rr = rr0 + j < RPW ? rr0 + j : RPW - 1;
+          int f, ch;
+          row_of(rr, wave, f, ch);
+          okr[j] = (RFULL || rr * NWV + wave < NROWS) && f < nfr && ch < nch;
+          doff[j] = f * FSTR + ch * CSTR + LPAD;
+          sc[j] = 1.f;
+          sh[j] = 0.f;
+          if constexpr (LN) {
+            int fs = okr[j] ? f : 0, cs = okr[j] ? ch : 0;
+            float mean = bcast(stv, 2 * fs), rstd = bcast(stv, 2 * fs + 1);
+            sc[j] = rstd * bcast(gv, cs);
+            sh[j] = bcast(bv, cs) - mean * sc[j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          if (rr0 + j >= RPW) continue;
+          if (!RFULL && (rr0 + j) * NWV + wave >= NROWS) continue;  // wave-uniform
+          float* dst = tb + doff[j];
+          if (okr[j]) {  // wave-uniform
+#pragma unroll
+            for (int p = 0; p < LPR; ++p) {
+              float x = v[(rr0 + j) * LPR + p];
+              if constexpr (LN) {
+                x = x * sc[j] + sh[j];
+                x = fmaxf(x, LEAK * x);
+              }
+              if (64 * (p + 1) <= H || lane + 64 * p < H) dst[64 * p] = x;
+            }
+          } else {
+#pragma unroll
+            for (int p = 0; p < LPR; ++p)
+              if (64 * (p + 1) <= H || lane + 64 * p < H) dst[64 * p] = 0.f;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < TF; ++f) {
+        if (f < nfr) {  // uniform
+          float rstd = 1.f, nmr = 0.f;
+          if constexpr (LN) {
+            float mean = bcast(stv, 2 * f);
+            rstd = bcast(stv, 2 * f + 1);
+            nmr = -mean * rstd;
+          }
+#pragma unroll
+          for (int kk = 0; kk < KPF; ++kk) {
+            float x = v[f * KPF + kk];
+            if constexpr (LN) {
+              x = x * rstd + nmr;
+              x = x * eg[kk] + eb[kk];
+              x = fmaxf(x, LEAK * x);
+            } else if constexpr (PARTIAL) {
+              x = x * eg[kk];
+            }
+            if (NTHR * (kk + 1) <= PERF || tid + NTHR * kk < PERF) pk[kk][f * FSTR] = x;
+          }
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < KPF; ++kk)
+            if (NTHR * (kk + 1) <= PERF || tid + NTHR * kk < PERF) pk[kk][f * FSTR] = 0.f;
+        }
+      }
+    }
+  }
+};
+
+}  // namespace tuned
+}  // namespace vaenpvc
