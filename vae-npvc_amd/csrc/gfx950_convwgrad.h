@@ -36,8 +36,9 @@ inline int g_wg_prof_next = 0;
 constexpr int odd_up(int v) { return v | 1; }
 
 template <int XC_, int XH_, int YC_, int YH_, int T_, int S_, int PAD_, bool XLN_, bool YLN_, int TF_, int NTW_,
-          int NWV_ = 4, int WM_ = 0>
+          int NWV_ = 4, int WM_ = 0, int WPE_ = 2>
 struct WgCfg {
+  static constexpr int WPE = WPE_;  // waves per SIMD the register allocation must allow
   static constexpr int XC = XC_, XH = XH_, YC = YC_, YH = YH_, T = T_, S = S_, PAD = PAD_, TF = TF_, NTW = NTW_;
   static constexpr bool XLN = XLN_, YLN = YLN_;
   static constexpr int NWV = NWV_, NTHR = NWV_ * 64;
@@ -81,7 +82,7 @@ struct WgArgs {
 // of sub-tile t (both MFMA operands come from LDS, so nothing in the k loop waits on them) and
 // are written to the single LDS tile pair after the compute phase; two barriers per sub-tile.
 template <class C>
-__global__ void __launch_bounds__(C::NTHR) k_convwgrad(WgArgs a) {
+__global__ void __launch_bounds__(C::NTHR, C::WPE) k_convwgrad(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using OX = TileStager<C::XC, C::XC, C::XH, C::CSTRX, C::FSTRX, C::HLO, C::XLN, C::TF, C::NWV>;
   using OY = TileStager<C::NTW * 32, C::YC, C::YH, C::CSTRY, C::FSTRY, 0, C::YLN, C::TF, C::NWV>;

@@ -66,7 +66,7 @@ using MergeB = DenseCfg<1539, 256, 256, 2, IN_PLAIN, 1>;
 //                     XC  XH   YC  YH  T  S PAD  XLN    YLN   TF NTW
 using WD2 = WgCfg<8, 513, 16, 171, 7, 3, 2, false, true, 2, 1>;
 using WD1 = WgCfg<16, 171, 32, 57, 7, 3, 2, false, true, 4, 1>;
-using WD0 = WgCfg<32, 57, 81, 19, 9, 3, 3, false, false, 6, 3>;
+using WD0 = WgCfg<32, 57, 81, 19, 9, 3, 3, false, false, 6, 3, 4, 0, 1>;
 using WE4 = WgCfg<128, 7, 256, 3, 7, 3, 3, true, false, 8, 1>;
 using WE3 = WgCfg<64, 19, 128, 7, 7, 3, 3, true, false, 8, 2>;
 using WE2 = WgCfg<32, 57, 64, 19, 7, 3, 2, true, false, 4, 2>;

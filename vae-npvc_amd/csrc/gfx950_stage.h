@@ -45,6 +45,12 @@ struct TileStager {
   // `gv`/`bv` holds gamma/beta of channel c (ROWS; loaded once); lstore() broadcasts them with
   // v_readlane.
   float stv, gv, bv;
+  // fast path (full tile): per-lane row constants, lane j <-> row j*NWV + w of this wave
+  int rst_off;      // ROWS: word offset of row j's (mean, rstd) pair inside the tile's statistics
+  float rg, rb;     // ROWS: gamma/beta of row j's channel
+  float rmean, rrstd;
+  int lane_t;       // lane index of the last 64-bin segment, clamped to H-1 (duplicates are benign)
+  int eoff[NE];     // ELEM: clamped element offset inside a frame
   static_assert(!LN || 2 * TF <= 64, "statistics of a tile must fit one register");
   static_assert(!(LN && ROWS) || CH <= 64, "gamma/beta of a ROWS tile must fit one register");
 
@@ -54,11 +60,21 @@ struct TileStager {
 
   __device__ __forceinline__ void init(float* __restrict__ tile, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, int c0, int nch) {
-    if constexpr (ROWS && LN) {
-      int c = threadIdx.x & 63;
-      c = c0 + (c < nch ? c : nch - 1);
-      gv = gamma[c];
-      bv = beta[c];
+    if constexpr (ROWS) {
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      lane_t = lane + 64 * (LPR - 1);
+      lane_t = lane_t < H ? lane_t : H - 1;
+      if constexpr (LN) {
+        int c = c0 + (lane < nch ? lane : nch - 1);
+        gv = gamma[c];
+        bv = beta[c];
+        int r = (lane < RPW ? lane : RPW - 1) * NWV + wave;
+        r = r < NROWS ? r : NROWS - 1;
+        int f = r / CH, ch = r - f * CH;
+        rst_off = 2 * f;
+        rg = gamma[c0 + (ch < nch ? ch : nch - 1)];
+        rb = beta[c0 + (ch < nch ? ch : nch - 1)];
+      }
     }
     if constexpr (!ROWS) {
 #pragma unroll
@@ -67,6 +83,7 @@ struct TileStager {
         int ec = e < PERF ? e : PERF - 1;
         int ch = ec / H, i = ec - ch * H;
         pk[kk] = tile + ch * CSTR + LPAD + i;
+        eoff[kk] = ec;
         bool ok = ch < nch;
         eg[kk] = ok ? 1.f : 0.f;
         eb[kk] = 0.f;
@@ -93,6 +110,34 @@ struct TileStager {
                                         int c0, int nch) {
     const int tid = threadIdx.x, lane = tid & 63;
     if constexpr (LN) stv = st[2 * f0 + (lane < 2 * nfr ? lane : 2 * nfr - 1)];
+    if (nfr == TF && nch == CH) {  // uniform: full tile, straight-line code with compile-time offsets
+      if constexpr (ROWS) {
+        static_assert(!LN || RPW <= 64, "row constants of a wave must fit one register");
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        if constexpr (LN) {
+          rmean = st[2 * f0 + rst_off];
+          rrstd = st[2 * f0 + rst_off + 1];
+        }
+        const float* wb = src + ((int64_t)f0 * CHTOT + c0) * H;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+          if (!RFULL && rr * NWV + wave >= NROWS) break;  // wave-uniform, last row only
+          int f, ch;
+          row_of(rr, wave, f, ch);
+          const float* row = wb + (f * CHTOT + ch) * H;
+#pragma unroll
+          for (int p = 0; p < LPR; ++p) v[rr * LPR + p] = (p == LPR - 1) ? row[lane_t] : row[lane + 64 * p];
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < TF; ++f) {
+          const float* base = src + ((int64_t)(f0 + f) * CHTOT + c0) * H;
+#pragma unroll
+          for (int kk = 0; kk < KPF; ++kk) v[f * KPF + kk] = (NTHR * (kk + 1) <= PERF) ? base[tid + NTHR * kk] : base[eoff[kk]];
+        }
+      }
+      return;
+    }
     if constexpr (ROWS) {
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
@@ -124,6 +169,61 @@ struct TileStager {
 
   __device__ __forceinline__ void lstore(float* __restrict__ tile, int nfr, int nch) {
     const int tid = threadIdx.x, lane = tid & 63;
+    if (nfr == TF && nch == CH) {  // uniform: full tile
+      if constexpr (ROWS) {
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        float scv = 1.f, shv = 0.f;
+        if constexpr (LN) {  // constants of all rows of this wave at once (lane j <-> row j)
+          scv = rrstd * rg;
+          shv = rb - rmean * scv;
+        }
+        float* tb = tile + wave * CSTR + LPAD + lane;
+        float* tt = tile + wave * CSTR + LPAD + lane_t - 64 * (LPR - 1);
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+          if (!RFULL && rr * NWV + wave >= NROWS) break;  // wave-uniform
+          int f, ch;
+          row_of(rr, wave, f, ch);
+          const int doff = f * FSTR + (ch - wave) * CSTR;  // compile-time when RDIV
+          float sc = 1.f, sh = 0.f;
+          if constexpr (LN) {
+            sc = bcast(scv, rr);
+            sh = bcast(shv, rr);
+          }
+#pragma unroll
+          for (int p = 0; p < LPR; ++p) {
+            float x = v[rr * LPR + p];
+            if constexpr (LN) {
+              x = x * sc + sh;
+              x = fmaxf(x, LEAK * x);
+            }
+            if (p == LPR - 1) tt[doff + 64 * p] = x;
+            else tb[doff + 64 * p] = x;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < TF; ++f) {
+          float rstd = 1.f, nmr = 0.f;
+          if constexpr (LN) {
+            float mean = bcast(stv, 2 * f);
+            rstd = bcast(stv, 2 * f + 1);
+            nmr = -mean * rstd;
+          }
+#pragma unroll
+          for (int kk = 0; kk < KPF; ++kk) {
+            float x = v[f * KPF + kk];
+            if constexpr (LN) {
+              x = x * rstd + nmr;
+              x = x * eg[kk] + eb[kk];
+              x = fmaxf(x, LEAK * x);
+            }
+            pk[kk][f * FSTR] = x;  // lanes past the row space hold a duplicate of the last element
+          }
+        }
+      }
+      return;
+    }
     if constexpr (ROWS) {
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
       float* tb = tile + lane;
