@@ -23,6 +23,7 @@
 //     the accumulators along the (contiguous) position axis.
 #pragma once
 #include "gfx950_common.h"
+#include "gfx950_stage.h"
 
 // Compile-time ablation switch for kernel experiments (scripts/build_variant.sh); 0 in the product.
 //   1 = staging + barriers only, 2 = MFMA work only (tile staged once), 3 = no output stores
@@ -109,14 +110,14 @@ struct ConvCfg {
   static constexpr int FSTR = next_mod32(KCP * CSTR, (rows(0) * (TYPEP ? 1 : S)) % 32);
   static constexpr int TILE = rup(TF * FSTR, 4);
   static constexpr int RS = TYPEP ? 1 : S, TS = TYPEP ? -1 : 1, OFF = TYPEP ? 0 : -PAD;
-  static constexpr int STAB = (HIN >= 32 || INKIND != IN_LN) ? 0 : 2 * KC + 2 * TF;  // = ConvStage::TAB
   // small weight sets stay resident in LDS for the lifetime of the (persistent) workgroup: the
   // k-loop then issues no vector-memory loads at all, so the next tile's prefetch (VMEM, returns
   // in order) is never waited on before the staging point.  + 2 chunks of slack for the
   // over-running prefetch of the fragment ping-pong.  The bias table (NP floats) is always in LDS.
   static constexpr bool BLDS = BTOTAL * 4 <= 28 * 1024;
   static constexpr int BSM = BLDS ? BTOTAL + 2 * U * 2 * NP : 0;
-  static constexpr int LDS_BYTES = (TILE + STAB + NP + BSM) * 4;
+  static constexpr int LDS_BYTES = (TILE + NP + BSM) * 4;
+  static_assert(INKIND != IN_LN || LNDIV == 1, "conv layers normalise per channel");
   // LDS allows two resident workgroups -> ask the compiler for <= 128 VGPRs (4 waves per SIMD)
   static constexpr int WPE = cmin_c(4, cmax_c(1, cmin_c(8, (160 * 1024) / LDS_BYTES) * NW / 4));
   static constexpr int mtiles(int ph) { return cdiv(TF * rows(ph), 32); }
@@ -142,143 +143,6 @@ struct ConvArgs {
 #if VAENPVC_PROF
   int slot;
 #endif
-};
-
-// ---- staging of one frame tile, split into a global-load half (into registers) and an LDS-store
-// half so that the loads of tile t+1 are in flight while tile t is being computed.
-//   ROWS path (HIN >= 32): a row = HIN contiguous bins of one (frame, channel); wave w owns rows
-//     w, w+NW, ...; the row index is wave-uniform, so addresses and the LayerNorm constants are
-//     scalar and LN+lrelu is one fma + max per element (the tf.nn.batch_normalization form).
-//   ELEM path (short rows): element e = tid + NTHR*k of the contiguous tile; (frame, channel, bin)
-//     are decoded per element; LayerNorm constants come from small LDS tables.
-template <class C>
-struct ConvStage {
-  static constexpr int PER = C::KC * C::HIN;
-  static constexpr bool ROWS = C::HIN >= 32;
-  static constexpr bool LN = C::INKIND == IN_LN;
-  static constexpr int NROWS = C::TF * C::KC;
-  static constexpr int RPW = cdiv(NROWS, C::NW), LPR = cdiv(C::HIN, 64);
-  static constexpr int EPT = cdiv(C::TF * PER, C::NTHR);
-  static constexpr int NREG = ROWS ? RPW * LPR : EPT;
-  static constexpr int TAB = ROWS ? 0 : (LN ? 2 * C::KC + 2 * C::TF : 0);  // LDS floats: gamma, beta, (mean, rstd)
-
-  float v[NREG];
-  float rst;  // ELEM+LN: one statistics value per thread (tid < 2*TF)
-
-  __device__ __forceinline__ void gload(const ConvArgs& a, int f0) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int nfr = min(C::TF, a.F - f0);
-    const float* src = a.in + (int64_t)f0 * PER;
-    if constexpr (ROWS) {
-      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        int r = wave + C::NW * rr;
-        int rs = r < nfr * C::KC ? r : 0;  // clamped: rows past the batch end are zeroed in lstore
-#pragma unroll
-        for (int p = 0; p < LPR; ++p) {
-          int i = lane + 64 * p;
-          v[rr * LPR + p] = i < C::HIN ? src[rs * C::HIN + i] : 0.f;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        int e = tid + C::NTHR * k;
-        v[k] = e < nfr * PER ? src[e] : 0.f;
-      }
-      if constexpr (LN) rst = tid < 2 * nfr ? a.st[2 * f0 + tid] : 0.f;
-    }
-  }
-
-  __device__ __forceinline__ void lstore(const ConvArgs& a, float* tile, float* tab, int f0) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int nfr = min(C::TF, a.F - f0);
-    if constexpr (ROWS) {
-      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-      // batches of RB rows: first ALL scalar loads of the batch (statistics, gamma, beta; clamped
-      // indices, no branches, so they are issued back to back), then the LDS stores
-      constexpr int RB = RPW < 8 ? RPW : 8;
-#pragma unroll
-      for (int rr0 = 0; rr0 < RPW; rr0 += RB) {
-        float sc[RB], sh[RB];
-        int doff[RB];
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-          int r = wave + C::NW * (rr0 + j);
-          int rc = r < NROWS ? r : NROWS - 1;
-          int f = rc / C::KC, k = rc - f * C::KC;
-          bool ok = r < nfr * C::KC;
-          sc[j] = ok ? 1.f : 0.f;
-          sh[j] = 0.f;
-          if constexpr (LN) {
-            int fs = ok ? f0 + f : f0;
-            float mean = a.st[2 * fs], rstd = a.st[2 * fs + 1];
-            float g = a.gamma[k / C::LNDIV], b = a.beta[k / C::LNDIV];
-            sc[j] = ok ? rstd * g : 0.f;
-            sh[j] = ok ? b - mean * sc[j] : 0.f;
-          }
-          doff[j] = f * C::FSTR + k * C::CSTR + C::HLO;
-        }
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-          if (rr0 + j >= RPW) continue;
-          int r = wave + C::NW * (rr0 + j);
-          if (r < NROWS) {  // wave-uniform
-            float* dst = tile + doff[j];
-#pragma unroll
-            for (int p = 0; p < LPR; ++p) {
-              int i = lane + 64 * p;
-              float x = v[(rr0 + j) * LPR + p] * sc[j] + sh[j];
-              if constexpr (LN) x = fmaxf(x, LEAK * x);
-              if (i < C::HIN) dst[i] = x;
-            }
-          }
-        }
-      }
-    } else {
-      if constexpr (LN) {
-        if (tid < 2 * C::TF) tab[2 * C::KC + tid] = rst;
-        __syncthreads();
-      }
-      constexpr int EB = EPT < 8 ? EPT : 8;
-#pragma unroll
-      for (int k0 = 0; k0 < EPT; k0 += EB) {
-        float m[EB], rs[EB], g[EB], b[EB];
-        int doff[EB];
-#pragma unroll
-        for (int j = 0; j < EB; ++j) {
-          int e = tid + C::NTHR * (k0 + j);
-          int ec = e < C::TF * PER ? e : C::TF * PER - 1;
-          int f = ec / PER;
-          int rem = ec - f * PER;
-          int ch = rem / C::HIN;
-          int i = rem - ch * C::HIN;
-          doff[j] = f * C::FSTR + ch * C::CSTR + C::HLO + i;
-          if constexpr (LN) {
-            m[j] = tab[2 * C::KC + 2 * f];
-            rs[j] = tab[2 * C::KC + 2 * f + 1];
-            g[j] = tab[ch];
-            b[j] = tab[C::KC + ch];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < EB; ++j) {
-          if (k0 + j >= EPT) continue;
-          int e = tid + C::NTHR * (k0 + j);
-          if (e < C::TF * PER) {
-            float x = v[k0 + j];
-            if constexpr (LN) {
-              x = (x - m[j]) * (rs[j] * g[j]) + b[j];
-              x = fmaxf(x, LEAK * x);
-              if (e >= nfr * PER) x = 0.f;
-            }
-            tile[doff[j]] = x;
-          }
-        }
-      }
-    }
-  }
 };
 
 // One work item = (phase, block of MB row tiles, block of NB column tiles); the items of ALL
@@ -482,10 +346,9 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
 template <class C>
 __global__ void __launch_bounds__(C::NTHR, C::WPE) k_convgemm(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  using St = ConvStage<C>;
+  using St = TileStager<C::KC, C::KC, C::HIN, C::CSTR, C::FSTR, C::HLO, C::INKIND == IN_LN, C::TF, C::NW>;
   float* tile = lds;
-  float* tab = lds + C::TILE;
-  float* lbias = lds + C::TILE + St::TAB;
+  float* lbias = lds + C::TILE;
   float* lB = lbias + C::NP;
   const int tid = threadIdx.x;
   for (int i = tid; i < C::TILE / 4; i += C::NTHR) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -495,37 +358,33 @@ __global__ void __launch_bounds__(C::NTHR, C::WPE) k_convgemm(ConvArgs a) {
   }
   if constexpr (C::BLDS)
     for (int i = tid; i < C::BSM; i += C::NTHR) lB[i] = i < C::BTOTAL ? a.Bp[i] : 0.f;
-  if constexpr (St::TAB > 0)
-    for (int k = tid; k < C::KC; k += C::NTHR) {
-      tab[k] = a.gamma[k / C::LNDIV];
-      tab[C::KC + k] = a.beta[k / C::LNDIV];
-    }
   constexpr int NBLK = cdiv(C::NT, C::NB);
   const int nblk0 = (int)((int64_t)NBLK * blockIdx.y / gridDim.y);
   const int nblk1 = (int)((int64_t)NBLK * (blockIdx.y + 1) / gridDim.y);
   const int tiles = cdiv(a.F, C::TF);
   St st;
+  st.init(tile, a.gamma, a.beta, 0, C::KC);
   int t = blockIdx.x;
 #if VAENPVC_PROF
   long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   PROF_T(k0);
 #endif
-  st.gload(a, t * C::TF);
-  __syncthreads();  // zero fill (halos, padded channel rows) and tables complete
-  st.lstore(a, tile, tab, t * C::TF);
+  st.gload(a.in, a.st, t * C::TF, min(C::TF, a.F - t * C::TF), 0, C::KC);
+  __syncthreads();  // zero fill (halos, padded channel rows), bias table and resident weights complete
+  st.lstore(tile, min(C::TF, a.F - t * C::TF), C::KC);
   __syncthreads();
   for (; t < tiles; t += gridDim.x) {
     const int tn = t + gridDim.x;
 #if VAENPVC_PROF
     PROF_T(q0);
-    if (tn < tiles) st.gload(a, tn * C::TF);
+    if (tn < tiles) st.gload(a.in, a.st, tn * C::TF, min(C::TF, a.F - tn * C::TF), 0, C::KC);
     __builtin_amdgcn_sched_barrier(0);
     PROF_T(q1);
     conv_items<C>(a, tile, lbias, lB, t * C::TF, nblk0, nblk1, pc);
     PROF_T(q2);
     __syncthreads();
     PROF_T(q3);
-    if (tn < tiles) st.lstore(a, tile, tab, tn * C::TF);
+    if (tn < tiles) st.lstore(tile, min(C::TF, a.F - tn * C::TF), C::KC);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     PROF_T(q4);
     __syncthreads();
@@ -536,7 +395,7 @@ __global__ void __launch_bounds__(C::NTHR, C::WPE) k_convgemm(ConvArgs a) {
     pc[6] += q5 - q4;
 #else
 #if VAENPVC_ABL != 2
-    if (tn < tiles) st.gload(a, tn * C::TF);
+    if (tn < tiles) st.gload(a.in, a.st, tn * C::TF, min(C::TF, a.F - tn * C::TF), 0, C::KC);
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #if VAENPVC_ABL != 1
@@ -544,7 +403,7 @@ __global__ void __launch_bounds__(C::NTHR, C::WPE) k_convgemm(ConvArgs a) {
 #endif
     __syncthreads();
 #if VAENPVC_ABL != 2
-    if (tn < tiles) st.lstore(a, tile, tab, tn * C::TF);
+    if (tn < tiles) st.lstore(tile, min(C::TF, a.F - tn * C::TF), C::KC);
 #endif
     __syncthreads();
 #endif

@@ -15,8 +15,8 @@
 //     addresses are one per-lane base + immediate offsets; per element: fma, mul, max, ds_write.
 //   ELEM (short rows): per frame, element e = tid + NTHR*kk of the contiguous run of the tile's
 //     channels; its (channel, bin) split, LDS address and gamma/beta do not depend on the frame and
-//     are computed once per thread (init()); mean/rstd of a frame are scalar; per element: fma, fma,
-//     mul, max, ds_write.
+//     are computed once per thread (init()); mean/rstd of a frame are scalar; per element: sub, mul,
+//     fma, mul, max, ds_write.
 // Frames past the end (nfr < TF) and channels past the tensor (nch < CH) are clamped on load and
 // written as zeros (uniform branches, only taken in the last tile of a chunk).
 #pragma once
@@ -204,18 +204,16 @@ struct TileStager {
       } else {
 #pragma unroll
         for (int f = 0; f < TF; ++f) {
-          float rstd = 1.f, nmr = 0.f;
+          float rstd = 1.f, mean = 0.f;
           if constexpr (LN) {
-            float mean = bcast(stv, 2 * f);
+            mean = bcast(stv, 2 * f);
             rstd = bcast(stv, 2 * f + 1);
-            nmr = -mean * rstd;
           }
 #pragma unroll
           for (int kk = 0; kk < KPF; ++kk) {
             float x = v[f * KPF + kk];
-            if constexpr (LN) {
-              x = x * rstd + nmr;
-              x = x * eg[kk] + eb[kk];
+            if constexpr (LN) {  // (x - mean) first: no cancellation between two large products
+              x = (x - mean) * (rstd * eg[kk]) + eb[kk];
               x = fmaxf(x, LEAK * x);
             }
             pk[kk][f * FSTR] = x;  // lanes past the row space hold a duplicate of the last element
@@ -275,18 +273,16 @@ struct TileStager {
 #pragma unroll
       for (int f = 0; f < TF; ++f) {
         if (f < nfr) {  // uniform
-          float rstd = 1.f, nmr = 0.f;
+          float rstd = 1.f, mean = 0.f;
           if constexpr (LN) {
-            float mean = bcast(stv, 2 * f);
+            mean = bcast(stv, 2 * f);
             rstd = bcast(stv, 2 * f + 1);
-            nmr = -mean * rstd;
           }
 #pragma unroll
           for (int kk = 0; kk < KPF; ++kk) {
             float x = v[f * KPF + kk];
             if constexpr (LN) {
-              x = x * rstd + nmr;
-              x = x * eg[kk] + eb[kk];
+              x = (x - mean) * (rstd * eg[kk]) + eb[kk];
               x = fmaxf(x, LEAK * x);
             } else if constexpr (PARTIAL) {
               x = x * eg[kk];
