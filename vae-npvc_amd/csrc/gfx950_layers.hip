@@ -11,6 +11,7 @@
 //   d3      conv2d_transpose k=1025          model/vae.py:96-99
 //   backward steps = autodiff of the same    trainer/vae.py:24
 #include <cstdlib>
+#include <cstring>
 
 #include "gfx950_convgemm.h"
 #include "gfx950_convwgrad.h"
@@ -18,6 +19,7 @@
 #include "gfx950_elem.h"
 #include "gfx950_tngemm.h"
 #include "gfx950_toeplitz.h"
+#include "gfx950_toep_bf16.h"
 #include "kernels.h"
 
 namespace vaenpvc {
@@ -91,7 +93,8 @@ struct Pk {
   static constexpr int ge1 = ge2 + GE2::BTOTAL;
   static constexpr int wc = ge1 + GE1::BTOTAL;
   static constexpr int lnpart = wc + TOEP_C * WROW;  // [LWGS][3][C] partial sums of the LN backward
-  static constexpr int total = lnpart + 2048 * 3 * 256;
+  static constexpr int wdg = lnpart + 2048 * 3 * 256;  // bf16 tap copies, input-gradient direction
+  static constexpr int total = wdg + TB_WFLOATS;
 };
 static_assert(Pk::total <= 4 * 939162 + 65536, "packed weights must fit the scratch region");
 // layers whose TF kernel tensor IS the packed operand (no copy)
@@ -99,6 +102,12 @@ static_assert(E1F::BTOTAL == 7 * 16 * 32 && E2F::BTOTAL == 7 * 32 * 64 && E3F::B
                   E4F::BTOTAL == 7 * 128 * 256 && GD1::BTOTAL == 7 * 16 * 32,
               "direct-use layers must not be padded");
 
+// VAENPVC_TOEP=f32 selects the exact-fp32 MFMA kernels of the last decoder layer instead of the
+// bf16x3 ones (same results to fp32 accuracy; kept for A/B measurements)
+static bool toep_bf16() {
+  static const bool v = !(getenv("VAENPVC_TOEP") && !strcmp(getenv("VAENPVC_TOEP"), "f32"));
+  return v;
+}
 static unsigned g_fwd_mask = 0xffffffffu, g_bwd_mask = 0xffffffffu;
 static bool g_env_read = false;
 static void read_env() {
@@ -152,6 +161,9 @@ static void prep(const Model& m, const float* P, const Ws& w, hipStream_t s) {
   launch_pack(PackConv<GE2>{P + m.enc[2].w_off, true}, S + Pk::ge2, GE2::BTOTAL, s);
   launch_pack(PackConv<GE1>{P + m.enc[1].w_off, true}, S + Pk::ge1, GE1::BTOTAL, s);
   launch_pack(PackToep{P + m.dec[3].w_off}, S + Pk::wc, TOEP_C * WROW, s);
+  if (toep_bf16())
+    hipLaunchKernelGGL(k_pack_toep_bf16<false>, dim3((unsigned)cdiv(TB_C * TB_CPY * 8 * TB_CHUNKS, 256)), dim3(256), 0, s,
+                       P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wdg));
 }
 
 template <int N>
@@ -361,6 +373,20 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_dgrad<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS);
       once = true;
     }
+    if (toep_bf16()) {
+      static bool once2 = false;
+      if (!once2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_dgrad_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS);
+        once2 = true;
+      }
+      unsigned short* gp = reinterpret_cast<unsigned short*>(w.toep_gp);
+      VAENPVC_TIMED("dec3_dgrad", s, {
+        hipLaunchKernelGGL(k_split3_rows, dim3((unsigned)((F * TB_KP + 255) / 256)), dim3(256), 0, s, w.d_xh, gp, (int64_t)F);
+        hipLaunchKernelGGL(k_toep_dgrad_bf16, dim3((unsigned)cdiv(F, DG_M)), dim3(256), DG_LDS, s, gp,
+                           reinterpret_cast<const unsigned short*>(w.scratch + Pk::wdg), w.dy_tmp, (int)F);
+        hipLaunchKernelGGL(k_toep_dgrad_edge, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.d_xh, P + m.dec[3].w_off, w.dy_tmp, (int)F);
+      });
+    } else
     if (F >= 8192) {
       VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL((k_toep_dgrad<8, 8>), dim3((unsigned)cdiv(F, 32), 1), dim3(512), TD_LDS, s, w.d_xh,
                                                         w.scratch + Pk::wc, w.dy_tmp, F));

@@ -1,0 +1,248 @@
+// gfx950_toep_bf16.h -- the 1025-tap last decoder layer on the bf16 matrix cores at fp32 accuracy.
+//
+// v_mfma_f32_32x32x16_bf16 runs 16x the MAC rate of the exact-fp32 v_mfma_f32_32x32x2_f32.  Every
+// fp32 operand x is split into three bf16 terms x = hi + mid + lo (8 + 8 + 8 mantissa bits, the
+// split is exact) and a product keeps the six term pairs of weight <= 2:
+//     a*b ~= a_lo*b_hi + a_mid*b_mid + a_hi*b_lo + a_mid*b_hi + a_hi*b_mid + a_hi*b_hi
+// (dropped terms are <= 2^-24 relative), accumulated in fp32 inside the MFMA.  Measured against an
+// fp64 reference (scripts/microbench/bf16x3.hip, K = 4112): max error 1.3e-6 of max|C| -- better
+// than a sequential fp32 fma chain (2.3e-6).  Six bf16 MFMAs replace eight fp32 MFMAs of the same
+// tile => 2.67x the fp32-MFMA peak.
+//
+// Toeplitz operand.  The weight matrix of this layer is T[k][n] = w[c][k - n + 512] (input-gradient
+// direction: k = output bin p, n = input bin i).  A B fragment of the MFMA (lane: column n0+l31,
+// eight consecutive k) is therefore eight consecutive taps starting at u0 = k0 + 8*lh - n0 - l31 + 512:
+// contiguous, but its start moves by ONE bf16 per lane.  LDS reads need 16-byte alignment, so the
+// kernel keeps eight copies of the channel's tap row, copy s shifted by s elements: lane reads the
+// 16-byte chunk u0>>3 of copy u0&7 -- one ds_read_b128 per fragment and plane; the copy index
+// depends on the lane only (all other address terms are multiples of 8).
+#pragma once
+#include "gfx950_common.h"
+
+namespace vaenpvc {
+namespace tuned {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // 16 bytes = 8 bf16 (native vector: stays in registers)
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned bf16_rn(float x) {  // round to nearest even, as 16 bits
+  unsigned u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+  h = bf16_rn(x);
+  float r = x - __uint_as_float(h << 16);
+  m = bf16_rn(r);
+  r = r - __uint_as_float(m << 16);
+  l = bf16_rn(r);
+}
+
+constexpr int TB_H = 513;             // bins
+constexpr int TB_KP = 528;            // bins padded to a multiple of 16 (k-steps of the bf16 MFMA)
+constexpr int TB_C = 8;               // channels of the layer's input
+constexpr int TB_T = 1025;            // taps
+constexpr int TB_CPY = 8;             // shifted copies of a tap row
+constexpr int TB_CHUNKS = 133;        // 16-byte chunks per copy (1064 taps; odd => the 8 copies a
+                                      // quarter-wave reads from sit in different bank groups)
+constexpr int TB_CPYB = TB_CHUNKS * 16;                       // bytes per copy
+constexpr int TB_WCH = 3 * TB_CPY * TB_CPYB;                  // bytes of one channel's copies (3 planes)
+constexpr int TB_WFLOATS = TB_C * TB_WCH / 4;                 // floats of the packed block (all channels)
+
+// ---- rows of fp32 -> three bf16 planes, zero padded to TB_KP:  dst[f][plane][TB_KP]
+__global__ void __launch_bounds__(256) k_split3_rows(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                     int64_t rows) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * TB_KP) return;
+  int64_t f = i / TB_KP;
+  int k = (int)(i - f * TB_KP);
+  unsigned h = 0, m = 0, l = 0;
+  if (k < TB_H) split3(src[f * TB_H + k], h, m, l);
+  unsigned short* d = dst + f * 3 * TB_KP + k;
+  d[0] = (unsigned short)h;
+  d[TB_KP] = (unsigned short)m;
+  d[2 * TB_KP] = (unsigned short)l;
+}
+
+// ---- shifted bf16 copies of the tap rows: dst[c][plane][s][m] = plane(w[c][m + s]), m < 8*TB_CHUNKS.
+//      REV = false: w[c][u] = W[u][c] (input gradient);  REV = true: w[c][u] = W[1024 - u][c] (forward).
+template <bool REV>
+__global__ void __launch_bounds__(256) k_pack_toep_bf16(const float* __restrict__ W, unsigned short* __restrict__ dst) {
+  constexpr int PER = 8 * TB_CHUNKS;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= TB_C * TB_CPY * PER) return;
+  int c = i / (TB_CPY * PER), r = i - c * (TB_CPY * PER);
+  int s = r / PER, m = r - s * PER;
+  int u = m + s;
+  unsigned h = 0, md = 0, l = 0;
+  if (u < TB_T) split3(W[(REV ? TB_T - 1 - u : u) * TB_C + c], h, md, l);
+  unsigned short* d = dst + (size_t)c * (TB_WCH / 2) + s * PER + m;
+  d[0] = (unsigned short)h;
+  d[TB_CPY * PER] = (unsigned short)md;
+  d[2 * TB_CPY * PER] = (unsigned short)l;
+}
+
+// ---- input gradient:  dY[f][c][i] = sum_p G[f][p] * W[p - i + 512][c]   (i < 512; column 512: k_toep_dgrad_edge)
+//
+// Workgroup = 64 frames x all 512 bins of every channel (channels in sequence); 4 waves, wave w owns
+// bins [128w, 128w+128) = 4 column tiles, both row tiles => 8 accumulators.  The reduction index p
+// runs in 3 chunks of 176 bins (11 k-steps): the chunk of the G planes is staged through registers into
+// LDS (prefetched one chunk ahead); the channel's tap copies are loaded at every channel switch.
+constexpr int DG_M = 64;                               // frames per workgroup
+constexpr int DG_KC = 176, DG_NKC = TB_KP / DG_KC;     // bins per chunk, chunks
+constexpr int DG_ROWB = DG_KC * 2 + 16;                // bytes per LDS row (368 = 16 * 23, odd)
+constexpr int DG_APL = DG_M * DG_ROWB;                 // bytes per plane of the A tile
+constexpr int DG_LDS = 3 * DG_APL + TB_WCH;            // 70 656 + 51 072 bytes
+
+__global__ void __launch_bounds__(256, 1) k_toep_dgrad_bf16(const unsigned short* __restrict__ gp,   // [F][3][528]
+                                                             const unsigned short* __restrict__ wcp,  // packed copies
+                                                             float* __restrict__ dY,                  // [F][8][513]
+                                                             int F) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;
+  unsigned char* sW = smem + 3 * DG_APL;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int f0 = blockIdx.x * DG_M;
+
+  // staging map: thread -> (row = tid >> 2, part = tid & 3) copies the 16-byte pieces part + 4*q
+  // (q < 6; a row of a chunk has 22 pieces) of all three planes: every address is a per-thread
+  // base plus a compile-time offset
+  constexpr int PPR = DG_KC * 2 / 16;  // 22
+  const int srow = tid >> 2, spart = tid & 3;
+  const int sfr = f0 + srow < F ? f0 + srow : F - 1;  // clamp: rows past the batch end are never stored
+  const unsigned char* gsrc = reinterpret_cast<const unsigned char*>(gp) + (size_t)sfr * (3 * TB_KP * 2) + spart * 16;
+  unsigned char* sdst = sA + srow * DG_ROWB + spart * 16;
+  u32x4 st[18];
+  auto gload = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        int c16 = spart + 4 * q;
+        c16 = c16 < PPR ? c16 : PPR - 1;  // (q = 5, parts 2 and 3: duplicate load, not stored)
+        st[pl * 6 + q] = *reinterpret_cast<const u32x4*>(gsrc + pl * (TB_KP * 2) + kc * (DG_KC * 2) + (c16 - spart) * 16);
+      }
+  };
+  auto lstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+        if (spart + 4 * q < PPR) *reinterpret_cast<u32x4*>(sdst + pl * DG_APL + q * 64) = st[pl * 6 + q];
+  };
+
+  // fragment addresses
+  //   A: plane*DG_APL + (32*mb + l31)*DG_ROWB + (16*ks + 8*lh)*2
+  //   B: plane*(8*TB_CPYB) + s*TB_CPYB + 16*q,  u0 = 176*kc + 16*ks + 8*lh - (128*wave + 32*nb + l31) + 512
+  const int aoff = l31 * DG_ROWB + lh * 16;
+  const int u_lane = 8 * lh - 128 * wave - l31 + 512;  // + 176*kc + 16*ks - 32*nb
+  const int s_cpy = u_lane & 7;
+  const int boff = s_cpy * TB_CPYB + ((u_lane - s_cpy) >> 3) * 16;  // + (22*kc + 2*ks - 4*nb)*16
+
+  // fragments: A of a whole k-step (2 row tiles x 3 planes), B of ONE column tile (3 planes); both
+  // ping-pong: while the 12 MFMAs of column tile nb run, the B fragments of tile nb+1 (or, for the
+  // last tile, A and B(0) of the next k-step) are already being read from LDS
+  u32x4 fa[2][2][3], fb[2][3];
+  auto loadA = [&](int set, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        fa[set][mb][pl] = *reinterpret_cast<const u32x4*>(sA + pl * DG_APL + mb * 32 * DG_ROWB + aoff + ks * 32);
+  };
+  auto loadB = [&](int set, int kc, int ks, int nb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      fb[set][pl] = *reinterpret_cast<const u32x4*>(sW + pl * (TB_CPY * TB_CPYB) + boff + (22 * kc + 2 * ks - 4 * nb) * 16);
+  };
+  f32x16 acc[2][4];
+  auto mm = [&](int sa, int sb, int nb) __attribute__((always_inline)) {
+    // six term pairs, smallest first
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = mfma_bf16(fa[sa][mb][PA[t]], fb[sb][PB[t]], acc[mb][nb]);
+  };
+
+  gload(0);
+  for (int c = 0; c < TB_C; ++c) {
+    __syncthreads();  // previous channel fully consumed (tap copies and A tile)
+    {  // tap copies of channel c
+      const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wcp) + (size_t)c * TB_WCH);
+      for (int i = tid; i < TB_WCH / 16; i += 256) reinterpret_cast<u32x4*>(sW)[i] = src[i];
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = zero16();
+    for (int kc = 0; kc < DG_NKC; ++kc) {
+      lstore();  // chunk kc (prefetched)
+      __syncthreads();
+      {  // prefetch the next chunk (same rows, next bins; wraps to chunk 0 for the next channel)
+        int kn = kc + 1 < DG_NKC ? kc + 1 : 0;
+        gload(kn);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      loadA(0, 0);
+      loadB(0, kc, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 11; ++ks) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const int sa = ks & 1, sb = (4 * ks + nb) & 1;
+          if (nb < 3) {
+            loadB(sb ^ 1, kc, ks, nb + 1);
+          } else if (ks + 1 < 11) {
+            loadA(sa ^ 1, ks + 1);
+            loadB(sb ^ 1, kc, ks + 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mm(sa, sb, nb);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();  // chunk consumed
+    }
+    // epilogue: rows = frames, lanes = 32 consecutive bins -> 128-byte stores
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          int f = f0 + mb * 32 + acc_row(reg, lane);
+          int i = 128 * wave + 32 * nb + l31;
+          if (f < F) dY[((int64_t)f * TB_C + c) * TB_H + i] = acc[mb][nb][reg];
+        }
+  }
+}
+
+// column i = 512 of the input gradient: dY[f][c][512] = sum_p G[f][p] * W[p][c]; one wave per frame.
+__global__ void __launch_bounds__(256) k_toep_dgrad_edge(const float* __restrict__ G, const float* __restrict__ W,
+                                                         float* __restrict__ dY, int F) {
+  const int lane = threadIdx.x & 63;
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= F) return;
+  float s[TB_C];
+#pragma unroll
+  for (int c = 0; c < TB_C; ++c) s[c] = 0.f;
+  for (int p = lane; p < TB_H; p += 64) {
+    float g = G[(int64_t)f * TB_H + p];
+#pragma unroll
+    for (int c = 0; c < TB_C; ++c) s[c] += g * W[p * TB_C + c];
+  }
+#pragma unroll
+  for (int c = 0; c < TB_C; ++c) {
+    float v = wave_sum(s[c]);
+    if (lane == 0) dY[((int64_t)f * TB_C + c) * TB_H + 512] = v;
+  }
+}
+
+}  // namespace tuned
+}  // namespace vaenpvc

@@ -21,6 +21,7 @@ struct Ws {  // resolved workspace pointers (see workspace_layout)
   float *d_h, *d_z, *d_e, *d_z_mu, *d_z_lv;
   float* d_enc_a[VAENPVC_MAX_LAYERS];
   float* dy_tmp;
+  float* toep_gp;  // bf16 planes of d_xh
   float* scratch;
   int64_t scratch_floats;
 };

@@ -158,6 +158,9 @@ std::vector<Region> workspace_layout(const Model& m, int64_t F, int mode, int64_
     add("d_z_lv", F * m.z);
     for (int i = m.n_enc - 1; i >= 0; --i) add("d_enc_a" + std::to_string(i), F * m.enc[i].cout * m.enc[i].hout);
     add("dy_tmp", F * maxact);
+    // three bf16 planes (hi, mid, lo) of d_xh, rows zero padded to a multiple of 16 bins (bf16 MFMA path
+    // of the last decoder layer)
+    add("toep_gp", F * 3 * ((m.H + 15) / 16 * 16) / 2);
   }
   *total_floats = off;
   return r;
