@@ -23,7 +23,7 @@ grads = torch.zeros(eng.n_params, dtype=torch.float32, device='cuda')
 lib = L.load_library()
 fn = lib.vaenpvc_debug_conv_prof
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
-buf = (ctypes.c_ulonglong * 448)()
+buf = (ctypes.c_ulonglong * 456)()
 for i in range(2):
     eng.train_fwd_bwd(x, y, eps, grads)
 fn(None, 1)
@@ -32,7 +32,8 @@ for i in range(N):
     eng.train_fwd_bwd(x, y, eps, grads)
 fn(buf, 0)
 a = np.array(buf[:320], dtype=np.float64).reshape(32, 10)
-wg = np.array(buf[320:], dtype=np.float64).reshape(16, 8)
+wg = np.array(buf[320:448], dtype=np.float64).reshape(16, 8)
+tb = np.array(buf[448:456], dtype=np.float64)
 names = ['gload', 'setup', 'kloop', 'epi', 'bar1', 'lstore', 'bar2']
 print('slot waves   total_cyc/wave | ' + ' '.join('%7s' % n for n in names) + ' | other')
 for s in range(32):
@@ -52,3 +53,10 @@ for s in range(16):
     tot = wg[s, 6] / w
     parts = wg[s, [1, 2, 3, 4, 5, 7]] / w
     print('%4d %6d %12.0f | ' % (s, w / N, tot) + ' '.join('%7.1f%%' % (100 * p / tot) for p in parts) + ' | %5.1f%%' % (100 * (tot - parts.sum()) / tot))
+
+if tb[0] > 0:
+    w = tb[0]
+    tot = tb[5] / w
+    print('toep_dgrad_bf16: waves %d total_cyc/wave %.0f | tapcopy %.1f%% stage+bar %.1f%% kloop %.1f%% epilogue %.1f%% other %.1f%%' % (
+        w / N, tot, 100 * tb[1] / w / tot, 100 * tb[2] / w / tot, 100 * tb[3] / w / tot, 100 * tb[4] / w / tot,
+        100 * (tot - tb[1:5].sum() / w) / tot))

@@ -556,10 +556,12 @@ extern "C" int vaenpvc_debug_conv_prof(unsigned long long* out, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return -3;
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(vaenpvc::tuned::g_conv_prof), sizeof(unsigned long long) * 320) != hipSuccess) return -3;
   if (out && hipMemcpyFromSymbol(out + 320, HIP_SYMBOL(vaenpvc::tuned::g_wg_prof), sizeof(unsigned long long) * 128) != hipSuccess) return -3;
+  if (out && hipMemcpyFromSymbol(out + 448, HIP_SYMBOL(vaenpvc::tuned::g_tb_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -3;
   if (reset) {
     static unsigned long long z[320];
     if (hipMemcpyToSymbol(HIP_SYMBOL(vaenpvc::tuned::g_conv_prof), z, sizeof(z)) != hipSuccess) return -3;
     if (hipMemcpyToSymbol(HIP_SYMBOL(vaenpvc::tuned::g_wg_prof), z, sizeof(unsigned long long) * 128) != hipSuccess) return -3;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vaenpvc::tuned::g_tb_prof), z, sizeof(unsigned long long) * 8) != hipSuccess) return -3;
   }
   return 0;
 }

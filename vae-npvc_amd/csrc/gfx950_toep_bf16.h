@@ -19,11 +19,27 @@
 #pragma once
 #include "gfx950_common.h"
 
+#ifndef VAENPVC_PROF
+#define VAENPVC_PROF 0
+#endif
+
 namespace vaenpvc {
 namespace tuned {
 
+#if VAENPVC_PROF
+// developer instrumentation: cycle sums per wave: [0] waves, [1] tap-copy load, [2] A store + barriers,
+// [3] k loop, [4] epilogue, [5] total
+__device__ unsigned long long g_tb_prof[8];
+#define TBPROF_T(var) const long long var = (long long)__builtin_amdgcn_s_memtime()
+#else
+#define TBPROF_T(var)
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // 16 bytes = 8 bf16 (native vector: stays in registers)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) packed4 {
+  float x, y, z, w;
+};  // 16 bytes = 8 bf16 (native vector: stays in registers)
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -137,12 +153,17 @@ __global__ void __launch_bounds__(256, 1) k_toep_dgrad_bf16(const unsigned short
 
   // fragment addresses
   //   A: plane*DG_APL + (32*mb + l31)*DG_ROWB + (16*ks + 8*lh)*2
-  //   B: plane*(8*TB_CPYB) + s*TB_CPYB + 16*q,  u0 = 176*kc + 16*ks + 8*lh - (128*wave + 32*nb + l31) + 512
+  //   B: plane*(8*TB_CPYB) + s*TB_CPYB + 16*q,  u0 = 176*kc + 16*ks + 8*lh - bin + 512
   const int aoff = l31 * DG_ROWB + lh * 16;
-  const int u_lane = 8 * lh - 128 * wave - l31 + 512;  // + 176*kc + 16*ks - 32*nb
-  const int s_cpy = u_lane & 7;
-  const int boff = s_cpy * TB_CPYB + ((u_lane - s_cpy) >> 3) * 16;  // + (22*kc + 2*ks - 4*nb)*16
-
+  //      column tile nb of wave w = bins 128*w + 4*l31 + nb (lane-interleaved, so that a lane ends up
+  //      with 4 CONSECUTIVE bins of a row: one 16-byte store instead of four 4-byte ones)
+  int boff[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int u_lane = 8 * lh - 128 * wave - 4 * l31 - nb + 512;  // + 176*kc + 16*ks
+    const int s_cpy = u_lane & 7;
+    boff[nb] = s_cpy * TB_CPYB + ((u_lane - s_cpy) >> 3) * 16;  // + (22*kc + 2*ks)*16
+  }
   // fragments: A of a whole k-step (2 row tiles x 3 planes), B of ONE column tile (3 planes); both
   // ping-pong: while the 12 MFMAs of column tile nb run, the B fragments of tile nb+1 (or, for the
   // last tile, A and B(0) of the next k-step) are already being read from LDS
@@ -157,7 +178,7 @@ __global__ void __launch_bounds__(256, 1) k_toep_dgrad_bf16(const unsigned short
   auto loadB = [&](int set, int kc, int ks, int nb) __attribute__((always_inline)) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
-      fb[set][pl] = *reinterpret_cast<const u32x4*>(sW + pl * (TB_CPY * TB_CPYB) + boff + (22 * kc + 2 * ks - 4 * nb) * 16);
+      fb[set][pl] = *reinterpret_cast<const u32x4*>(sW + pl * (TB_CPY * TB_CPYB) + boff[nb] + (22 * kc + 2 * ks) * 16);
   };
   f32x16 acc[2][4];
   auto mm = [&](int sa, int sb, int nb) __attribute__((always_inline)) {
@@ -170,20 +191,42 @@ __global__ void __launch_bounds__(256, 1) k_toep_dgrad_bf16(const unsigned short
       for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = mfma_bf16(fa[sa][mb][PA[t]], fb[sb][PB[t]], acc[mb][nb]);
   };
 
+#if VAENPVC_PROF
+  long long pc[4] = {0, 0, 0, 0};
+  TBPROF_T(k0);
+#endif
   gload(0);
   for (int c = 0; c < TB_C; ++c) {
+    TBPROF_T(t0);
     __syncthreads();  // previous channel fully consumed (tap copies and A tile)
-    {  // tap copies of channel c
+    {  // tap copies of channel c: all loads first (one L2 latency), then the LDS stores
+      constexpr int NW16 = TB_WCH / 16, WPT = (NW16 + 255) / 256;  // 3192 pieces, 13 per thread
       const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wcp) + (size_t)c * TB_WCH);
-      for (int i = tid; i < TB_WCH / 16; i += 256) reinterpret_cast<u32x4*>(sW)[i] = src[i];
+      u32x4 wv[WPT];
+#pragma unroll
+      for (int k = 0; k < WPT; ++k) {
+        int i = tid + 256 * k;
+        wv[k] = src[i < NW16 ? i : NW16 - 1];
+      }
+#pragma unroll
+      for (int k = 0; k < WPT; ++k) {
+        int i = tid + 256 * k;
+        if (i < NW16) reinterpret_cast<u32x4*>(sW)[i] = wv[k];
+      }
     }
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = zero16();
+    TBPROF_T(t1);
+#if VAENPVC_PROF
+    pc[0] += t1 - t0;
+#endif
     for (int kc = 0; kc < DG_NKC; ++kc) {
+      TBPROF_T(t2);
       lstore();  // chunk kc (prefetched)
       __syncthreads();
+      TBPROF_T(t3);
       {  // prefetch the next chunk (same rows, next bins; wraps to chunk 0 for the next channel)
         int kn = kc + 1 < DG_NKC ? kc + 1 : 0;
         gload(kn);
@@ -207,20 +250,50 @@ __global__ void __launch_bounds__(256, 1) k_toep_dgrad_bf16(const unsigned short
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+#if VAENPVC_PROF
+      asm volatile("s_nop 0" ::: "memory");
+#endif
+      TBPROF_T(t4);
       __syncthreads();  // chunk consumed
+#if VAENPVC_PROF
+      TBPROF_T(t5);
+      pc[1] += (t3 - t2) + (t5 - t4);
+      pc[2] += t4 - t3;
+#endif
     }
-    // epilogue: rows = frames, lanes = 32 consecutive bins -> 128-byte stores
+    TBPROF_T(t6);
+    // epilogue: rows = frames, lanes = 32 consecutive bins -> 128-byte stores; one uniform base
+    // per workgroup and channel, 32-bit lane offsets, column tiles through the immediate offset
+    {
+      float* ob = dY + ((int64_t)f0 * TB_C + c) * TB_H;
+      const int lo = (4 * lh) * (TB_C * TB_H) + 128 * wave + 4 * l31;
+      const bool full = f0 + DG_M <= F;  // uniform
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
+      for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-          int f = f0 + mb * 32 + acc_row(reg, lane);
-          int i = 128 * wave + 32 * nb + l31;
-          if (f < F) dY[((int64_t)f * TB_C + c) * TB_H + i] = acc[mb][nb][reg];
+          const int r = mb * 32 + (reg & 3) + 8 * (reg >> 2);  // + 4*lh
+          float* o = ob + lo + r * (TB_C * TB_H);
+          if (full || f0 + r + 4 * lh < F)  // rows are only 4-byte aligned (513 bins): packed 16-byte store
+            *reinterpret_cast<packed4*>(o) = packed4{acc[mb][0][reg], acc[mb][1][reg], acc[mb][2][reg], acc[mb][3][reg]};
         }
+    }
+#if VAENPVC_PROF
+    asm volatile("s_nop 0" ::: "memory");
+    TBPROF_T(t7);
+    pc[3] += t7 - t6;
+#endif
   }
+#if VAENPVC_PROF
+  {
+    TBPROF_T(k1);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(g_tb_prof + 0, 1ull);
+      for (int i = 0; i < 4; ++i) atomicAdd(g_tb_prof + 1 + i, (unsigned long long)pc[i]);
+      atomicAdd(g_tb_prof + 5, (unsigned long long)(k1 - k0));
+    }
+  }
+#endif
 }
 
 // column i = 512 of the input gradient: dY[f][c][512] = sum_p G[f][p] * W[p][c]; one wave per frame.
