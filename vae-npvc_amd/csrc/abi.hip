@@ -75,6 +75,7 @@ static int resolve(vaenpvc_ctx* c, int64_t F, int mode, void* d_ws, size_t ws_by
     else if (n == "d_z_lv") w->d_z_lv = p;
     else if (n == "dy_tmp") w->dy_tmp = p;
     else if (n == "toep_gp") w->toep_gp = p;
+    else if (n == "toep_yp") w->toep_yp = p;
     else if (n == "scratch") { w->scratch = p; w->scratch_floats = r.count; }
   }
   return 0;

@@ -94,7 +94,8 @@ struct Pk {
   static constexpr int wc = ge1 + GE1::BTOTAL;
   static constexpr int lnpart = wc + TOEP_C * WROW;  // [LWGS][3][C] partial sums of the LN backward
   static constexpr int wdg = lnpart + 2048 * 3 * 256;  // bf16 tap copies, input-gradient direction
-  static constexpr int total = wdg + TB_WFLOATS;
+  static constexpr int wfw = wdg + TB_WFLOATS;  // bf16 tap copies, forward direction (reversed)
+  static constexpr int total = wfw + TB_WFLOATS;
 };
 static_assert(Pk::total <= 4 * 939162 + 65536, "packed weights must fit the scratch region");
 // layers whose TF kernel tensor IS the packed operand (no copy)
@@ -164,6 +165,9 @@ static void prep(const Model& m, const float* P, const Ws& w, hipStream_t s) {
   if (toep_bf16())
     hipLaunchKernelGGL(k_pack_toep_bf16<false>, dim3((unsigned)cdiv(TB_C * TB_CPY * 8 * TB_CHUNKS, 256)), dim3(256), 0, s,
                        P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wdg));
+  if (toep_bf16())
+    hipLaunchKernelGGL(k_pack_toep_bf16<true>, dim3((unsigned)cdiv(TB_C * TB_CPY * 8 * TB_CHUNKS, 256)), dim3(256), 0, s,
+                       P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wfw));
 }
 
 template <int N>
@@ -266,8 +270,13 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     VAENPVC_TIMED("dec2_fwd", s, launch_convgemm<D2F>(conv_args(w.dec_a[1], w.dec_st[1], P + m.dec[1].gamma_off,
                                                                 P + m.dec[1].beta_off, w.scratch + Pk::d2f,
                                                                 P + m.dec[2].b_off, w.dec_a[2], F), nsplit_for<D2F>(F), s));
-    hipLaunchKernelGGL((k_ln_stats_act<4104, 513>), dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
-                       P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, F);
+    if (toep_bf16() && fwd_on(10))
+      hipLaunchKernelGGL(k_ln_stats_act_planes, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
+                         P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, reinterpret_cast<unsigned short*>(w.toep_yp),
+                         w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, (int)F);
+    else
+      hipLaunchKernelGGL((k_ln_stats_act<4104, 513>), dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
+                         P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, F);
   } else {
     generic::dec_layer_fwd(m, P, F, w, xh_out, s, 2);
     int64_t tot = (int64_t)F * 4104;
@@ -281,6 +290,17 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS);
       once = true;
     }
+    if (toep_bf16() && fwd_on(9)) {  // (the planes come from the tuned layer-9 epilogue kernel)
+      static bool once2 = false;
+      if (!once2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_gemm_bf16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS);
+        once2 = true;
+      }
+      VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL(k_toep_gemm_bf16<true>, dim3((unsigned)cdiv(F, DG_M)), dim3(256), DG_LDS, s,
+                                                      reinterpret_cast<const unsigned short*>(w.toep_yp),
+                                                      reinterpret_cast<const unsigned short*>(w.scratch + Pk::wfw),
+                                                      P + m.dec[3].b_off, xh_out, (int)F));
+    } else
     if (F >= 2048) {
       VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL(k_toep_fwd<4>, dim3((unsigned)cdiv(F, 32), 1), dim3(256), TF_LDS, s, w.dec_y,
                                                       w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, F));
@@ -376,14 +396,14 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     if (toep_bf16()) {
       static bool once2 = false;
       if (!once2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_dgrad_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_gemm_bf16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS);
         once2 = true;
       }
       unsigned short* gp = reinterpret_cast<unsigned short*>(w.toep_gp);
       VAENPVC_TIMED("dec3_dgrad", s, {
         hipLaunchKernelGGL(k_split3_rows, dim3((unsigned)((F * TB_KP + 255) / 256)), dim3(256), 0, s, w.d_xh, gp, (int64_t)F);
-        hipLaunchKernelGGL(k_toep_dgrad_bf16, dim3((unsigned)cdiv(F, DG_M)), dim3(256), DG_LDS, s, gp,
-                           reinterpret_cast<const unsigned short*>(w.scratch + Pk::wdg), w.dy_tmp, (int)F);
+        hipLaunchKernelGGL(k_toep_gemm_bf16<false>, dim3((unsigned)cdiv(F, DG_M)), dim3(256), DG_LDS, s, gp,
+                           reinterpret_cast<const unsigned short*>(w.scratch + Pk::wdg), (const float*)nullptr, w.dy_tmp, (int)F);
         hipLaunchKernelGGL(k_toep_dgrad_edge, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.d_xh, P + m.dec[3].w_off, w.dy_tmp, (int)F);
       });
     } else

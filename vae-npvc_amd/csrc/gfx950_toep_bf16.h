@@ -114,10 +114,19 @@ constexpr int DG_ROWB = DG_KC * 2 + 16;                // bytes per LDS row (368
 constexpr int DG_APL = DG_M * DG_ROWB;                 // bytes per plane of the A tile
 constexpr int DG_LDS = 3 * DG_APL + TB_WCH;            // 70 656 + 51 072 bytes
 
-__global__ void __launch_bounds__(256, 1) k_toep_dgrad_bf16(const unsigned short* __restrict__ gp,   // [F][3][528]
-                                                             const unsigned short* __restrict__ wcp,  // packed copies
-                                                             float* __restrict__ dY,                  // [F][8][513]
-                                                             int F) {
+//
+// FWD = true is the forward direction of the same layer with the same machinery:
+//     xh[f][p] = bias + sum_c sum_i y[f][c][i] * W[p - i + 512][c]        (p < 512; column 512: the plane producer)
+// k = input bin i, column = output bin p, taps read from the REVERSED copies (u = 512 - p + i); the A
+// planes are per channel ([F][3][8][528]) and the accumulators run over all 8 channels.
+template <bool FWD>
+__global__ void __launch_bounds__(256, 1) k_toep_gemm_bf16(const unsigned short* __restrict__ gp,   // A planes
+                                                            const unsigned short* __restrict__ wcp,  // packed tap copies
+                                                            const float* __restrict__ bias,          // FWD: [1]
+                                                            float* __restrict__ dY,  // dgrad: [F][8][513]; fwd: [F][513]
+                                                            int F) {
+  constexpr int A_PL = (FWD ? TB_C : 1) * TB_KP * 2;  // bytes between planes of a frame
+  constexpr int A_FR = 3 * A_PL;                      // bytes per frame
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
   unsigned char* sW = smem + 3 * DG_APL;
@@ -130,17 +139,17 @@ __global__ void __launch_bounds__(256, 1) k_toep_dgrad_bf16(const unsigned short
   constexpr int PPR = DG_KC * 2 / 16;  // 22
   const int srow = tid >> 2, spart = tid & 3;
   const int sfr = f0 + srow < F ? f0 + srow : F - 1;  // clamp: rows past the batch end are never stored
-  const unsigned char* gsrc = reinterpret_cast<const unsigned char*>(gp) + (size_t)sfr * (3 * TB_KP * 2) + spart * 16;
+  const unsigned char* gsrc = reinterpret_cast<const unsigned char*>(gp) + (size_t)sfr * A_FR + spart * 16;
   unsigned char* sdst = sA + srow * DG_ROWB + spart * 16;
   u32x4 st[18];
-  auto gload = [&](int kc) __attribute__((always_inline)) {
+  auto gload = [&](int c, int kc) __attribute__((always_inline)) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         int c16 = spart + 4 * q;
         c16 = c16 < PPR ? c16 : PPR - 1;  // (q = 5, parts 2 and 3: duplicate load, not stored)
-        st[pl * 6 + q] = *reinterpret_cast<const u32x4*>(gsrc + pl * (TB_KP * 2) + kc * (DG_KC * 2) + (c16 - spart) * 16);
+        st[pl * 6 + q] = *reinterpret_cast<const u32x4*>(gsrc + pl * A_PL + (FWD ? c * (TB_KP * 2) : 0) + kc * (DG_KC * 2) + (c16 - spart) * 16);
       }
   };
   auto lstore = [&]() __attribute__((always_inline)) {
@@ -195,7 +204,8 @@ __global__ void __launch_bounds__(256, 1) k_toep_dgrad_bf16(const unsigned short
   long long pc[4] = {0, 0, 0, 0};
   TBPROF_T(k0);
 #endif
-  gload(0);
+  gload(0, 0);
+#pragma unroll 1
   for (int c = 0; c < TB_C; ++c) {
     TBPROF_T(t0);
     __syncthreads();  // previous channel fully consumed (tap copies and A tile)
@@ -214,10 +224,12 @@ __global__ void __launch_bounds__(256, 1) k_toep_dgrad_bf16(const unsigned short
         if (i < NW16) reinterpret_cast<u32x4*>(sW)[i] = wv[k];
       }
     }
+    if (!FWD || c == 0) {
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+      for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = zero16();
+        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = zero16();
+    }
     TBPROF_T(t1);
 #if VAENPVC_PROF
     pc[0] += t1 - t0;
@@ -229,7 +241,8 @@ __global__ void __launch_bounds__(256, 1) k_toep_dgrad_bf16(const unsigned short
       TBPROF_T(t3);
       {  // prefetch the next chunk (same rows, next bins; wraps to chunk 0 for the next channel)
         int kn = kc + 1 < DG_NKC ? kc + 1 : 0;
-        gload(kn);
+        int cn = kc + 1 < DG_NKC ? c : (c + 1 < TB_C ? c + 1 : c);
+        gload(cn, kn);
       }
       __builtin_amdgcn_sched_barrier(0);
       loadA(0, 0);
@@ -262,20 +275,23 @@ __global__ void __launch_bounds__(256, 1) k_toep_dgrad_bf16(const unsigned short
 #endif
     }
     TBPROF_T(t6);
+    if (FWD && c + 1 < TB_C) continue;
     // epilogue: rows = frames, lanes = 32 consecutive bins -> 128-byte stores; one uniform base
     // per workgroup and channel, 32-bit lane offsets, column tiles through the immediate offset
     {
-      float* ob = dY + ((int64_t)f0 * TB_C + c) * TB_H;
-      const int lo = (4 * lh) * (TB_C * TB_H) + 128 * wave + 4 * l31;
+      constexpr int ORS = (FWD ? 1 : TB_C) * TB_H;  // floats between consecutive frames of the output
+      float* ob = dY + ((int64_t)f0 * (FWD ? 1 : TB_C) + (FWD ? 0 : c)) * TB_H;
+      const int lo = (4 * lh) * ORS + 128 * wave + 4 * l31;
       const bool full = f0 + DG_M <= F;  // uniform
+      const float bb = FWD ? bias[0] : 0.f;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int r = mb * 32 + (reg & 3) + 8 * (reg >> 2);  // + 4*lh
-          float* o = ob + lo + r * (TB_C * TB_H);
+          float* o = ob + lo + r * ORS;
           if (full || f0 + r + 4 * lh < F)  // rows are only 4-byte aligned (513 bins): packed 16-byte store
-            *reinterpret_cast<packed4*>(o) = packed4{acc[mb][0][reg], acc[mb][1][reg], acc[mb][2][reg], acc[mb][3][reg]};
+            *reinterpret_cast<packed4*>(o) = packed4{acc[mb][0][reg] + bb, acc[mb][1][reg] + bb, acc[mb][2][reg] + bb, acc[mb][3][reg] + bb};
         }
     }
 #if VAENPVC_PROF
@@ -294,6 +310,105 @@ __global__ void __launch_bounds__(256, 1) k_toep_dgrad_bf16(const unsigned short
     }
   }
 #endif
+}
+
+// ---- producer of the forward operand: LayerNorm statistics of the layer in front (8 x 513 per frame),
+//      its activated output as fp32 (still read by the weight-gradient GEMM) AND as three bf16 planes
+//      yp[f][plane][c][528], plus column p = 512 of the forward result, which is a plain dot product
+//      of the activated frame with the taps W[1024 - i][c] (the GEMM kernel covers p < 512).
+//      One wave per frame; lane l owns bins 8l .. 8l+7 of every channel, lanes 0..7 also bin 512 of
+//      channel l.
+__global__ void __launch_bounds__(256) k_ln_stats_act_planes(const float* __restrict__ a, float* __restrict__ st,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ y, unsigned short* __restrict__ yp,
+                                                             const float* __restrict__ Wc,  // [8][WROW]: Wc[c][8 + t]
+                                                             const float* __restrict__ bias, float* __restrict__ xh, int F) {
+  constexpr int WROWC = 1040;
+  const int lane = threadIdx.x & 63;
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= F) return;
+  const float* af = a + (int64_t)f * (TB_C * TB_H);
+  float v[TB_C][8], vt = 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < TB_C; ++c) {
+    packed4 p0 = *reinterpret_cast<const packed4*>(af + c * TB_H + 8 * lane);
+    packed4 p1 = *reinterpret_cast<const packed4*>(af + c * TB_H + 8 * lane + 4);
+    v[c][0] = p0.x; v[c][1] = p0.y; v[c][2] = p0.z; v[c][3] = p0.w;
+    v[c][4] = p1.x; v[c][5] = p1.y; v[c][6] = p1.z; v[c][7] = p1.w;
+    s += ((v[c][0] + v[c][1]) + (v[c][2] + v[c][3])) + ((v[c][4] + v[c][5]) + (v[c][6] + v[c][7]));
+  }
+  if (lane < TB_C) {
+    vt = af[lane * TB_H + 512];
+    s += vt;
+  }
+  const float mean = wave_sum(s) / (TB_C * TB_H);
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < TB_C; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float d = v[c][j] - mean;
+      q += d * d;
+    }
+  if (lane < TB_C) q += (vt - mean) * (vt - mean);
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (TB_C * TB_H) + LN_EPS);
+  if (lane == 0) {
+    st[2 * f] = mean;
+    st[2 * f + 1] = rstd;
+  }
+  float* yf = y + (int64_t)f * (TB_C * TB_H);
+  unsigned short* ypf = yp + (int64_t)f * (3 * TB_C * TB_KP);
+  float dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < TB_C; ++c) {
+    const float g = gamma[c], b = beta[c];
+    // taps W[1024 - i][c] for i = 8*lane + j  =  Wc[c][8 + 1024 - 8*lane - j]: one ascending block, reversed
+    const float* wp = Wc + c * WROWC + 8 + 1017 - 8 * lane;
+    packed4 w0 = *reinterpret_cast<const packed4*>(wp), w1 = *reinterpret_cast<const packed4*>(wp + 4);
+    const float wr[8] = {w1.w, w1.z, w1.y, w1.x, w0.w, w0.z, w0.y, w0.x};
+    float o[8];
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o[j] = lnact_v(v[c][j], mean, rstd, g, b);
+      dot += o[j] * wr[j];
+      split3(o[j], h[j], m[j], l[j]);
+    }
+    *reinterpret_cast<packed4*>(yf + c * TB_H + 8 * lane) = packed4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<packed4*>(yf + c * TB_H + 8 * lane + 4) = packed4{o[4], o[5], o[6], o[7]};
+    u32x4 ph, pm, pl;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ph[k] = h[2 * k] | (h[2 * k + 1] << 16);
+      pm[k] = m[2 * k] | (m[2 * k + 1] << 16);
+      pl[k] = l[2 * k] | (l[2 * k + 1] << 16);
+    }
+    *reinterpret_cast<u32x4*>(ypf + (0 * TB_C + c) * TB_KP + 8 * lane) = ph;
+    *reinterpret_cast<u32x4*>(ypf + (1 * TB_C + c) * TB_KP + 8 * lane) = pm;
+    *reinterpret_cast<u32x4*>(ypf + (2 * TB_C + c) * TB_KP + 8 * lane) = pl;
+  }
+  if (lane < TB_C) {  // bin 512 of channel `lane`, and the zero padding 513..527 of its plane rows
+    const int c = lane;
+    float o = lnact_v(vt, mean, rstd, gamma[c], beta[c]);
+    yf[c * TB_H + 512] = o;
+    dot += o * Wc[c * WROWC + 8 + 512];
+    unsigned h, m, l;
+    split3(o, h, m, l);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    u32x4 t;
+    t = z; t[0] = h;
+    *reinterpret_cast<u32x4*>(ypf + (0 * TB_C + c) * TB_KP + 512) = t;
+    *reinterpret_cast<u32x4*>(ypf + (0 * TB_C + c) * TB_KP + 520) = z;
+    t = z; t[0] = m;
+    *reinterpret_cast<u32x4*>(ypf + (1 * TB_C + c) * TB_KP + 512) = t;
+    *reinterpret_cast<u32x4*>(ypf + (1 * TB_C + c) * TB_KP + 520) = z;
+    t = z; t[0] = l;
+    *reinterpret_cast<u32x4*>(ypf + (2 * TB_C + c) * TB_KP + 512) = t;
+    *reinterpret_cast<u32x4*>(ypf + (2 * TB_C + c) * TB_KP + 520) = z;
+  }
+  dot = wave_sum(dot);
+  if (lane == 0) xh[(int64_t)f * TB_H + 512] = dot + bias[0];
 }
 
 // column i = 512 of the input gradient: dY[f][c][512] = sum_p G[f][p] * W[p][c]; one wave per frame.

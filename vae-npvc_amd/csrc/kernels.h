@@ -22,6 +22,7 @@ struct Ws {  // resolved workspace pointers (see workspace_layout)
   float* d_enc_a[VAENPVC_MAX_LAYERS];
   float* dy_tmp;
   float* toep_gp;  // bf16 planes of d_xh
+  float* toep_yp;  // bf16 planes of dec_y
   float* scratch;
   int64_t scratch_floats;
 };

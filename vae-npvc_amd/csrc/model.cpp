@@ -143,6 +143,8 @@ std::vector<Region> workspace_layout(const Model& m, int64_t F, int mode, int64_
   }
   // activated output of the last LN layer of the decoder (operand of the final layer's GEMMs)
   if (m.n_dec >= 2) add("dec_y", F * m.dec[m.n_dec - 2].cout * m.dec[m.n_dec - 2].hout);
+  // the same tensor as three bf16 planes, bins padded to a multiple of 16 (bf16 MFMA path of the last layer)
+  if (m.n_dec >= 2) add("toep_yp", F * 3 * m.dec[m.n_dec - 2].cout * ((m.dec[m.n_dec - 2].hout + 15) / 16 * 16) / 2);
   add("xh", F * m.H);
   add("kl_f", F);
   add("nll_f", F);
