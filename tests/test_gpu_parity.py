@@ -348,12 +348,29 @@ def test_all_tuned_steps(F, seed):
     assert not fails, '\n'.join(fails)
 
 
-def test_tuned_vs_generic_large_batch():
-    """F = 2048: tuned kernels against the generic kernels on the GPU (the float64 oracle
-    would take minutes on the host): activations, losses and gradients."""
+BF16_TOEP = (0xbfffffff, 0xffffffff)   # forward-mask bit 30 cleared: bf16x3 Toeplitz kernels at any batch size
+
+
+@pytest.mark.parametrize('F,seed', [(37, 5), (64, 6), (1, 7), (130, 9)])
+def test_bf16_split_toeplitz_kernels_against_oracle(F, seed):
+    """The last decoder layer on the bf16 matrix cores (3-term operand split, six products):
+    forward and input gradient against the float64 oracle, same tolerances as the fp32 kernels.
+    (By default these kernels only run at F >= 8192; the mask forces them here.)"""
+    eng = make_engine('vcc', 'auto', BF16_TOEP)
+    try:
+        fails = compare_everything(eng, F, seed, 'bf16x3 toeplitz F%d ' % F)
+    finally:
+        eng.lib.vaenpvc_set_tuned_masks(0xffffffff, 0xffffffff)
+    assert not fails, '\n'.join(fails)
+
+
+@pytest.mark.parametrize('F', [2048, 8192])
+def test_tuned_vs_generic_large_batch(F):
+    """Tuned kernels against the generic kernels on the GPU (the float64 oracle would take
+    minutes on the host): activations, losses and gradients.  F = 8192 is the smallest batch
+    at which the bf16x3 kernels of the last decoder layer are selected by default."""
     from hipvae import lib as L
     arch = ARCHS['vcc']
-    F = 2048
     P = O.init_params(arch, 21)
     x, y, eps = O.make_inputs(arch, F, 21)
     res = {}
@@ -364,11 +381,11 @@ def test_tuned_vs_generic_large_batch():
         del eng
         torch.cuda.empty_cache()
     fails = []
-    check('F2048 tuned-vs-generic loss3', res['auto'][0], res['generic'][0], TOL_ACT, fails)
-    check('F2048 tuned-vs-generic xh', res['auto'][2], res['generic'][2], TOL_ACT, fails)
+    check('F%d tuned-vs-generic loss3' % F, res['auto'][0], res['generic'][0], TOL_ACT, fails)
+    check('F%d tuned-vs-generic xh' % F, res['auto'][2], res['generic'][2], TOL_ACT, fails)
     for name, (off, shape) in res['auto'][3].items():
         n = int(np.prod(shape))
-        check('F2048 tuned-vs-generic grad ' + name, res['auto'][1][off:off + n], res['generic'][1][off:off + n], 2e-3, fails)
+        check('F%d tuned-vs-generic grad ' % F + name, res['auto'][1][off:off + n], res['generic'][1][off:off + n], 2e-3, fails)
     assert not fails, '\n'.join(fails)
 
 

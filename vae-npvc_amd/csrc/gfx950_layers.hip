@@ -110,6 +110,11 @@ static bool toep_bf16() {
   return v;
 }
 static unsigned g_fwd_mask = 0xffffffffu, g_bwd_mask = 0xffffffffu;
+// The bf16 kernels own 64 frames per workgroup: below ~8k frames they cannot fill the chip and the
+// fp32 kernels (32 frames per workgroup, bins split over more workgroups) are faster.  Clearing bit 30
+// of the forward mask forces them at any batch size (parity tests).
+constexpr int64_t TOEP_BF16_MIN_FRAMES = 8192;
+static bool toep_bf16_for(int64_t F) { return toep_bf16() && (F >= TOEP_BF16_MIN_FRAMES || !((g_fwd_mask >> 30) & 1u)); }
 static bool g_env_read = false;
 static void read_env() {
   if (g_env_read) return;
@@ -270,7 +275,7 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     VAENPVC_TIMED("dec2_fwd", s, launch_convgemm<D2F>(conv_args(w.dec_a[1], w.dec_st[1], P + m.dec[1].gamma_off,
                                                                 P + m.dec[1].beta_off, w.scratch + Pk::d2f,
                                                                 P + m.dec[2].b_off, w.dec_a[2], F), nsplit_for<D2F>(F), s));
-    if (toep_bf16() && fwd_on(10))
+    if (toep_bf16_for(F) && fwd_on(10))
       hipLaunchKernelGGL(k_ln_stats_act_planes, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
                          P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, reinterpret_cast<unsigned short*>(w.toep_yp),
                          w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, (int)F);
@@ -290,7 +295,7 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS);
       once = true;
     }
-    if (toep_bf16() && fwd_on(9)) {  // (the planes come from the tuned layer-9 epilogue kernel)
+    if (toep_bf16_for(F) && fwd_on(9)) {  // (the planes come from the tuned layer-9 epilogue kernel)
       static bool once2 = false;
       if (!once2) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_gemm_bf16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS);
@@ -393,7 +398,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_dgrad<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS);
       once = true;
     }
-    if (toep_bf16()) {
+    if (toep_bf16_for(F)) {
       static bool once2 = false;
       if (!once2) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_gemm_bf16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS);
