@@ -372,7 +372,9 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   read_env();
   const int F = (int)F64;
   (void)hipMemsetAsync(G, 0, (size_t)m.n_params * 4, s);
-  const bool fork = g_side.init();
+  // (bit 30 of the backward mask cleared = no fork for this call: serialised kernels, used by bench.py to
+  //  time single kernels without concurrent neighbours)
+  const bool fork = g_side.init() && ((g_bwd_mask >> 30) & 1u);
   hipStream_t s2 = fork ? g_side.s2 : s;   // weight-gradient stream
   auto ready = [&]() { if (fork) stream_dep(s, s2); };   // "the tensors produced so far on s are ready for s2"
   ready();
