@@ -377,6 +377,11 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   const bool fork = g_side.init() && ((g_bwd_mask >> 30) & 1u);
   hipStream_t s2 = fork ? g_side.s2 : s;   // weight-gradient stream
   auto ready = [&]() { if (fork) stream_dep(s, s2); };   // "the tensors produced so far on s are ready for s2"
+  // three bf16 planes of d(xh): operand of the bf16 input-gradient AND weight-gradient kernels of the last layer
+  const bool toep_planes = bwd_on(10) && toep_bf16_for(F);
+  if (toep_planes)
+    hipLaunchKernelGGL(k_split3_rows, dim3((unsigned)((F * TB_KP + 255) / 256)), dim3(256), 0, s, w.d_xh,
+                       reinterpret_cast<unsigned short*>(w.toep_gp), (int64_t)F);
   ready();
   bool dec_bias_done[4] = {false, false, false, false};
   bool enc_bias_done[5] = {false, false, false, false, false};
@@ -387,8 +392,22 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   // ---- d3: the 1025-tap layer
   if (bwd_on(10)) {
     const ConvL& l2 = m.dec[2];
-    TnArgs a = tn_args(w.dec_y, 4104, w.d_xh, 513, 4096, 512, F, G + m.dec[3].w_off, 0);
-    VAENPVC_TIMED("dec3_wgrad", s2, launch_tngemm(a, true, kchunks_for(F, 32 * 4), s2));
+    if (toep_bf16_for(F) && fwd_on(9) && fwd_on(10) && !getenv("VAENPVC_TOEP_WGRAD_F32")) {
+      // bf16 planes of both operands exist (forward producer, k_split3_rows above)
+      static bool once3 = false;
+      if (!once3) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_wgrad_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS);
+        once3 = true;
+      }
+      unsigned short* gp = reinterpret_cast<unsigned short*>(w.toep_gp);
+      const int zc = (int)cmax(1, cmin_(8, cdiv(F, 1024)));  // 8 x 8 x zc workgroups (512 at F >= 8192)
+      const int fch = rup(cdiv((int)F, zc), WG_KF);
+      VAENPVC_TIMED("dec3_wgrad", s2, hipLaunchKernelGGL(k_toep_wgrad_bf16, dim3(8, TB_C, (unsigned)cdiv((int)F, fch)), dim3(512), WG_LDS, s2,
+                                                        reinterpret_cast<const unsigned short*>(w.toep_yp), gp, G + m.dec[3].w_off, (int)F, fch));
+    } else {
+      TnArgs a = tn_args(w.dec_y, 4104, w.d_xh, 513, 4096, 512, F, G + m.dec[3].w_off, 0);
+      VAENPVC_TIMED("dec3_wgrad", s2, launch_tngemm(a, true, kchunks_for(F, 32 * 4), s2));
+    }
     int ech = cmax(1, cmin_(cdiv(F, 32), 512));
     int efc = cdiv(F, ech);
     hipLaunchKernelGGL(k_toep_wgrad_row512, dim3((unsigned)cdiv(F, efc)), dim3(256), 0, s2, w.dec_y, w.d_xh, G + m.dec[3].w_off, F, efc);
@@ -408,7 +427,6 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       }
       unsigned short* gp = reinterpret_cast<unsigned short*>(w.toep_gp);
       VAENPVC_TIMED("dec3_dgrad", s, {
-        hipLaunchKernelGGL(k_split3_rows, dim3((unsigned)((F * TB_KP + 255) / 256)), dim3(256), 0, s, w.d_xh, gp, (int64_t)F);
         hipLaunchKernelGGL(k_toep_gemm_bf16<false>, dim3((unsigned)cdiv(F, DG_M)), dim3(256), DG_LDS, s, gp,
                            reinterpret_cast<const unsigned short*>(w.scratch + Pk::wdg), (const float*)nullptr, w.dy_tmp, (int)F);
         hipLaunchKernelGGL(k_toep_dgrad_edge, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.d_xh, P + m.dec[3].w_off, w.dy_tmp, (int)F);

@@ -432,5 +432,180 @@ __global__ void __launch_bounds__(256) k_toep_dgrad_edge(const float* __restrict
   }
 }
 
+// ---- weight gradient:  dW[t][c] = sum_f sum_i y[f][c][i] * G[f][i + t - 512]
+//
+// Computed as the cross product P_c[i][q] = sum_f y[f][c][i] * G[f][q] (same MAC count, plain GEMM with
+// the FRAME as reduction index) followed by a sum along the diagonals t = q - i + 512.  Both operands
+// exist as row-major bf16 planes (toep_yp, toep_gp: rows = frames); a row-major [32 frames][columns] tile in
+// LDS feeds the MFMA through ds_read_b64_tr_b16 (hardware 4x16 transpose: lane l receives 4 consecutive
+// FRAMES of column l&15; semantics pinned by scripts/microbench/trread.hip).
+//
+// Workgroup = channel c, 128 bins i x 256 bins q, frames [z*fchunk, (z+1)*fchunk); 8 waves as 2 (i) x 4 (q),
+// wave tile 64 x 64 (2 x 2 MFMA tiles).  The workgroups of the upper q half also own the column q = 512: a
+// strip of four 32 x 32 tiles (only their first column is non-zero) dealt to the waves wc < 2 on even
+// k-steps and wc >= 2 on odd ones (one extra accumulator per wave).  Row i = 512 of y: k_toep_wgrad_row512.
+constexpr int WG_KF = 32;                       // frames per staged chunk (two k-steps of 16)
+constexpr int WG_RSA = 128 * 2 + 64;            // bytes per LDS row, A tile (320 = 64 mod 256: the 4 rows of a
+constexpr int WG_RSB = 256 * 2 + 64;            //   transpose read sit in different bank quarters); B: 576
+constexpr int WG_APL = WG_KF * WG_RSA, WG_BPL = WG_KF * WG_RSB;
+constexpr int WG_LDS = 3 * (WG_APL + WG_BPL);   // 30 720 + 55 296 bytes
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 tr_read8(const unsigned char* p, int row4_bytes) {
+  // two transpose reads: frames +0..3 and +4..7 of this lane's column
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + row4_bytes));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);  // register pairs side by side, no ALU work
+  return __builtin_bit_cast(u32x4, ab);
+}
+
+__global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16(const unsigned short* __restrict__ yp,  // [F][3][8][528]
+                                                             const unsigned short* __restrict__ gp,  // [F][3][528]
+                                                             float* __restrict__ dW,                 // [1025][8] atomicAdd
+                                                             int F, int fchunk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 3 * WG_APL;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int i0 = (blockIdx.x >> 1) * 128, q0 = (blockIdx.x & 1) * 256, c = blockIdx.y;
+  const bool strip = (blockIdx.x & 1) != 0;  // uniform: this workgroup also owns q = 512
+  const int fb = blockIdx.z * fchunk, fe = min(F, fb + fchunk);
+
+  // ---- staging (16-byte pieces): A 3 planes x 32 rows x 16: thread -> (row tid>>4, piece tid&15), plane k;
+  //      B 3 x 32 x 32: thread -> (row tid>>5 + 16*(k&1), piece tid&31), plane k>>1;
+  //      strip: bins 512..527 = pieces 64, 65 of the G row -> tile pieces 32, 33: threads < 192
+  const int arow = tid >> 4, apc = tid & 15;
+  const int brow = tid >> 5, bpc = tid & 31;
+  const int epl = tid >> 6, erow = (tid >> 1) & 31, epc = tid & 1;
+  u32x4 sta[3], stb[6], ste;
+  auto gload = [&](int f0) __attribute__((always_inline)) {
+    {
+      int f = f0 + arow;
+      f = f < F ? f : F - 1;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(yp) + ((size_t)f * 3 * TB_C + c) * (TB_KP * 2) + (i0 * 2 + apc * 16);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) sta[pl] = *reinterpret_cast<const u32x4*>(src + (size_t)pl * TB_C * TB_KP * 2);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      int f = f0 + brow + 16 * (k & 1);
+      f = f < F ? f : F - 1;
+      stb[k] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(gp) + ((size_t)f * 3 + (k >> 1)) * (TB_KP * 2) + q0 * 2 + bpc * 16);
+    }
+    if (strip && tid < 192) {
+      int f = f0 + erow;
+      f = f < F ? f : F - 1;
+      ste = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(gp) + ((size_t)f * 3 + epl) * (TB_KP * 2) + (64 + epc) * 16);
+    }
+  };
+  auto lstore = [&](int f0) __attribute__((always_inline)) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    const bool tail = f0 + WG_KF > fe;  // uniform: frames past the chunk contribute zero (A rows zeroed)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      *reinterpret_cast<u32x4*>(sA + pl * WG_APL + arow * WG_RSA + apc * 16) = (tail && f0 + arow >= fe) ? z : sta[pl];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      *reinterpret_cast<u32x4*>(sB + (k >> 1) * WG_BPL + (brow + 16 * (k & 1)) * WG_RSB + bpc * 16) = stb[k];
+    if (strip && tid < 192) *reinterpret_cast<u32x4*>(sB + epl * WG_BPL + erow * WG_RSB + (32 + epc) * 16) = ste;
+  };
+
+  // ---- fragment addresses (transpose reads): lane -> (frame row (l&15)>>2 (+8*lh), column quad 4*(l&3) + 16*((l>>4)&1))
+  const int trow = ((lane & 15) >> 2) + 8 * lh, tcol = 4 * (lane & 3) + 16 * ((lane >> 4) & 1);
+  const int aoff = trow * WG_RSA + (64 * wr + tcol) * 2;   // + plane*WG_APL + 64*ri + ks*16*WG_RSA
+  const int boff = trow * WG_RSB + (64 * wc + tcol) * 2;   // + plane*WG_BPL + 64*cj + ks*16*WG_RSB
+  const int eoff = trow * WG_RSB + (256 + tcol) * 2;       // the q = 512 strip (tile columns 256..287)
+  const int eri = wc & 1;                                  // this wave's strip row tile = 2*wr + eri, on k-step wc>>1
+
+  f32x16 acc[2][2], acce;
+#pragma unroll
+  for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+    for (int cj = 0; cj < 2; ++cj) acc[ri][cj] = zero16();
+  acce = zero16();
+
+  u32x4 fa[2][2][3], fbq[2][2][3], fe3[3];
+  auto loadF = [&](int set, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) fa[set][ri][pl] = tr_read8(sA + pl * WG_APL + aoff + ri * 64 + ks * 16 * WG_RSA, 4 * WG_RSA);
+#pragma unroll
+    for (int cj = 0; cj < 2; ++cj)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) fbq[set][cj][pl] = tr_read8(sB + pl * WG_BPL + boff + cj * 64 + ks * 16 * WG_RSB, 4 * WG_RSB);
+    if (strip && (wc >> 1) == ks) {  // wave-uniform: this wave's turn on the q = 512 strip
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) fe3[pl] = tr_read8(sB + pl * WG_BPL + eoff + ks * 16 * WG_RSB, 4 * WG_RSB);
+    }
+  };
+  auto mm = [&](int set, int ks) __attribute__((always_inline)) {
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int cj = 0; cj < 2; ++cj) acc[ri][cj] = mfma_bf16(fa[set][ri][PA[t]], fbq[set][cj][PB[t]], acc[ri][cj]);
+    if (strip && (wc >> 1) == ks) {  // wave-uniform
+      u32x4 af[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) af[pl] = eri == 0 ? fa[set][0][pl] : fa[set][1][pl];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) acce = mfma_bf16(af[PA[t]], fe3[PB[t]], acce);
+    }
+  };
+
+  if (fb < fe) gload(fb);
+  for (int f0 = fb; f0 < fe; f0 += WG_KF) {
+    __syncthreads();  // previous chunk consumed
+    lstore(f0);
+    __syncthreads();
+    if (f0 + WG_KF < fe) gload(f0 + WG_KF);
+    __builtin_amdgcn_sched_barrier(0);
+    loadF(0, 0);
+    loadF(1, 1);  // (reads of the second k-step land while the MFMAs of the first run)
+    __builtin_amdgcn_sched_barrier(0);
+    mm(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- epilogue: diagonals.  Wave tile = rows i0+64wr .. +63, columns q0+64wc .. +63: d = col - row in [-63, 63]
+  __syncthreads();
+  float* dg = reinterpret_cast<float*>(smem) + wave * 128;
+  dg[lane] = 0.f;
+  dg[lane + 64] = 0.f;
+  wave_lds_sync();
+#pragma unroll
+  for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+    for (int cj = 0; cj < 2; ++cj)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        int row = ri * 32 + acc_row(reg, lane);
+        int cl = cj * 32 + l31;
+        atomicAdd(&dg[cl - row + 63], acc[ri][cj][reg]);
+      }
+  wave_lds_sync();
+  for (int d = lane; d < 127; d += 64) {
+    int t = (q0 + 64 * wc) - (i0 + 64 * wr) + (d - 63) + 512;  // in [1, 1023]
+    atomicAdd(dW + t * TB_C + c, dg[d]);
+  }
+  // the q = 512 strip: column 512 is lane l31 == 0 of the strip tile; t = 512 - i + 512
+  if (strip && l31 == 0) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      int i = i0 + 64 * wr + 32 * eri + acc_row(reg, lane);
+      atomicAdd(dW + (1024 - i) * TB_C + c, acce[reg]);
+    }
+  }
+}
+
 }  // namespace tuned
 }  // namespace vaenpvc
