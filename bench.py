@@ -32,7 +32,7 @@ FP32_PEAK = 157.3e12
 # dominant kernel family: the last decoder layer (1025-tap conv_transpose = dense Toeplitz GEMM
 # [F,4104] x [4104,513]); algorithmic flops per frame for one pass (fwd, or dgrad, or wgrad)
 DEC3_FLOP_PER_FRAME = 2.0 * 8 * 513 * 513
-# its forward / input-gradient kernels run on the bf16 matrix cores with a 3-term operand split
+# at >= 8192 frames its three GEMMs run on the bf16 matrix cores with a 3-term operand split
 # (six bf16 MFMAs per fp32 product): peak in fp32-equivalent flops = dense bf16 peak / 6
 BF16_PEAK = 2500e12
 BF16X3_PEAK = BF16_PEAK / 6.0
@@ -201,7 +201,7 @@ def main():
                     traffic = t['hbm_bytes_per_launch']
         except (OSError, ValueError):
             pass
-        bf16 = args.timer_tag in ('dec3_fwd', 'dec3_dgrad') and F >= 8192
+        bf16 = args.timer_tag in ('dec3_fwd', 'dec3_dgrad', 'dec3_wgrad') and F >= 8192 and args.impl == 'auto'
         peak = (BF16X3_PEAK if bf16 else FP32_PEAK) / 1e12
         out['roofline'] = {'bound': 'mfma', 'kernel': args.timer_tag, 'achieved': ach, 'peak': peak,
                            'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,

@@ -23,7 +23,7 @@ grads = torch.zeros(eng.n_params, dtype=torch.float32, device='cuda')
 lib = L.load_library()
 fn = lib.vaenpvc_debug_conv_prof
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
-buf = (ctypes.c_ulonglong * 456)()
+buf = (ctypes.c_ulonglong * 464)()
 for i in range(2):
     eng.train_fwd_bwd(x, y, eps, grads)
 fn(None, 1)
@@ -60,3 +60,10 @@ if tb[0] > 0:
     print('toep_dgrad_bf16: waves %d total_cyc/wave %.0f | tapcopy %.1f%% stage+bar %.1f%% kloop %.1f%% epilogue %.1f%% other %.1f%%' % (
         w / N, tot, 100 * tb[1] / w / tot, 100 * tb[2] / w / tot, 100 * tb[3] / w / tot, 100 * tb[4] / w / tot,
         100 * (tot - tb[1:5].sum() / w) / tot))
+
+tw = np.array(buf[456:464], dtype=np.float64)
+if tw[0] > 0:
+    w = tw[0]
+    tot = tw[7] / w
+    print('toep_wgrad_bf16: waves %d total_cyc/wave %.0f | gload %.1f%% loadF %.1f%% mfma %.1f%% lstore %.1f%% barrier %.1f%% epilogue %.1f%%' % (
+        w / N, tot, *[100 * tw[i] / w / tot for i in range(1, 7)]))

@@ -115,6 +115,12 @@ static unsigned g_fwd_mask = 0xffffffffu, g_bwd_mask = 0xffffffffu;
 // of the forward mask forces them at any batch size (parity tests).
 constexpr int64_t TOEP_BF16_MIN_FRAMES = 8192;
 static bool toep_bf16_for(int64_t F) { return toep_bf16() && (F >= TOEP_BF16_MIN_FRAMES || !((g_fwd_mask >> 30) & 1u)); }
+static inline bool fwd_on(int bit);
+// the weight gradient of that layer reads both operands as bf16 planes (then the fp32 copy of y is not stored)
+static bool toep_wgrad_bf16_for(int64_t F) {
+  static const bool f32 = getenv("VAENPVC_TOEP_WGRAD_F32") != nullptr;
+  return toep_bf16_for(F) && fwd_on(9) && fwd_on(10) && !f32;
+}
 static bool g_env_read = false;
 static void read_env() {
   if (g_env_read) return;
@@ -278,7 +284,7 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     if (toep_bf16_for(F) && fwd_on(10))
       hipLaunchKernelGGL(k_ln_stats_act_planes, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
                          P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, reinterpret_cast<unsigned short*>(w.toep_yp),
-                         w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, (int)F);
+                         w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, (int)F, toep_wgrad_bf16_for(F) ? 0 : 1);
     else
       hipLaunchKernelGGL((k_ln_stats_act<4104, 513>), dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
                          P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, F);
@@ -392,7 +398,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   // ---- d3: the 1025-tap layer
   if (bwd_on(10)) {
     const ConvL& l2 = m.dec[2];
-    if (toep_bf16_for(F) && fwd_on(9) && fwd_on(10) && !getenv("VAENPVC_TOEP_WGRAD_F32")) {
+    if (toep_wgrad_bf16_for(F)) {
       // bf16 planes of both operands exist (forward producer, k_split3_rows above)
       static bool once3 = false;
       if (!once3) {
@@ -602,11 +608,13 @@ extern "C" int vaenpvc_debug_conv_prof(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(vaenpvc::tuned::g_conv_prof), sizeof(unsigned long long) * 320) != hipSuccess) return -3;
   if (out && hipMemcpyFromSymbol(out + 320, HIP_SYMBOL(vaenpvc::tuned::g_wg_prof), sizeof(unsigned long long) * 128) != hipSuccess) return -3;
   if (out && hipMemcpyFromSymbol(out + 448, HIP_SYMBOL(vaenpvc::tuned::g_tb_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -3;
+  if (out && hipMemcpyFromSymbol(out + 456, HIP_SYMBOL(vaenpvc::tuned::g_tw_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -3;
   if (reset) {
     static unsigned long long z[320];
     if (hipMemcpyToSymbol(HIP_SYMBOL(vaenpvc::tuned::g_conv_prof), z, sizeof(z)) != hipSuccess) return -3;
     if (hipMemcpyToSymbol(HIP_SYMBOL(vaenpvc::tuned::g_wg_prof), z, sizeof(unsigned long long) * 128) != hipSuccess) return -3;
     if (hipMemcpyToSymbol(HIP_SYMBOL(vaenpvc::tuned::g_tb_prof), z, sizeof(unsigned long long) * 8) != hipSuccess) return -3;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vaenpvc::tuned::g_tw_prof), z, sizeof(unsigned long long) * 8) != hipSuccess) return -3;
   }
   return 0;
 }

@@ -30,6 +30,7 @@ namespace tuned {
 // developer instrumentation: cycle sums per wave: [0] waves, [1] tap-copy load, [2] A store + barriers,
 // [3] k loop, [4] epilogue, [5] total
 __device__ unsigned long long g_tb_prof[8];
+__device__ unsigned long long g_tw_prof[8];  // wgrad: waves, gload, loadF, mm, lstore, barrier, epilogue, total
 #define TBPROF_T(var) const long long var = (long long)__builtin_amdgcn_s_memtime()
 #else
 #define TBPROF_T(var)
@@ -322,7 +323,8 @@ __global__ void __launch_bounds__(256) k_ln_stats_act_planes(const float* __rest
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ y, unsigned short* __restrict__ yp,
                                                              const float* __restrict__ Wc,  // [8][WROW]: Wc[c][8 + t]
-                                                             const float* __restrict__ bias, float* __restrict__ xh, int F) {
+                                                             const float* __restrict__ bias, float* __restrict__ xh, int F,
+                                                             int write_y) {  // 0: only bin 512 of y (fp32) is stored
   constexpr int WROWC = 1040;
   const int lane = threadIdx.x & 63;
   const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -375,8 +377,10 @@ __global__ void __launch_bounds__(256) k_ln_stats_act_planes(const float* __rest
       dot += o[j] * wr[j];
       split3(o[j], h[j], m[j], l[j]);
     }
-    *reinterpret_cast<packed4*>(yf + c * TB_H + 8 * lane) = packed4{o[0], o[1], o[2], o[3]};
-    *reinterpret_cast<packed4*>(yf + c * TB_H + 8 * lane + 4) = packed4{o[4], o[5], o[6], o[7]};
+    if (write_y) {  // uniform; the fp32 copy is only read by the exact-fp32 weight-gradient kernel
+      *reinterpret_cast<packed4*>(yf + c * TB_H + 8 * lane) = packed4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<packed4*>(yf + c * TB_H + 8 * lane + 4) = packed4{o[4], o[5], o[6], o[7]};
+    }
     u32x4 ph, pm, pl;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -444,11 +448,12 @@ __global__ void __launch_bounds__(256) k_toep_dgrad_edge(const float* __restrict
 // wave tile 64 x 64 (2 x 2 MFMA tiles).  The workgroups of the upper q half also own the column q = 512: a
 // strip of four 32 x 32 tiles (only their first column is non-zero) dealt to the waves wc < 2 on even
 // k-steps and wc >= 2 on odd ones (one extra accumulator per wave).  Row i = 512 of y: k_toep_wgrad_row512.
-constexpr int WG_KF = 32;                       // frames per staged chunk (two k-steps of 16)
+constexpr int WG_KF = 16;                       // frames per staged chunk = one k-step; two LDS buffers
 constexpr int WG_RSA = 128 * 2 + 64;            // bytes per LDS row, A tile (320 = 64 mod 256: the 4 rows of a
 constexpr int WG_RSB = 256 * 2 + 64;            //   transpose read sit in different bank quarters); B: 576
 constexpr int WG_APL = WG_KF * WG_RSA, WG_BPL = WG_KF * WG_RSB;
-constexpr int WG_LDS = 3 * (WG_APL + WG_BPL);   // 30 720 + 55 296 bytes
+constexpr int WG_BUF = 3 * (WG_APL + WG_BPL);   // 15 360 + 27 648 bytes per buffer
+constexpr int WG_LDS = 2 * WG_BUF;
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4 tr_read8(const unsigned char* p, int row4_bytes) {
@@ -466,59 +471,80 @@ __global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16(const unsigned short
                                                              float* __restrict__ dW,                 // [1025][8] atomicAdd
                                                              int F, int fchunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;
-  unsigned char* sB = smem + 3 * WG_APL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int wr = wave >> 2, wc = wave & 3;
   const int i0 = (blockIdx.x >> 1) * 128, q0 = (blockIdx.x & 1) * 256, c = blockIdx.y;
   const bool strip = (blockIdx.x & 1) != 0;  // uniform: this workgroup also owns q = 512
   const int fb = blockIdx.z * fchunk, fe = min(F, fb + fchunk);
 
-  // ---- staging (16-byte pieces): A 3 planes x 32 rows x 16: thread -> (row tid>>4, piece tid&15), plane k;
-  //      B 3 x 32 x 32: thread -> (row tid>>5 + 16*(k&1), piece tid&31), plane k>>1;
-  //      strip: bins 512..527 = pieces 64, 65 of the G row -> tile pieces 32, 33: threads < 192
-  const int arow = tid >> 4, apc = tid & 15;
+  // ---- staging (16-byte pieces) of one 16-frame chunk into buffer `buf`:
+  //      A 3 planes x 16 rows x 16: threads < 256 -> (row tid>>4, piece tid&15), plane k;
+  //      B 3 x 16 x 32: thread -> (row tid>>5, piece tid&31), plane k;
+  //      strip: bins 512..527 = pieces 64, 65 of the G row -> tile pieces 32, 33: threads < 96
+  const int arow = (tid >> 4) & 15, apc = tid & 15;
   const int brow = tid >> 5, bpc = tid & 31;
-  const int epl = tid >> 6, erow = (tid >> 1) & 31, epc = tid & 1;
-  u32x4 sta[3], stb[6], ste;
+  const int epl = tid >> 5, erow = (tid >> 1) & 15, epc = tid & 1;
+  u32x4 sta[3], stb[3], ste;
+  // per-thread source pointers of chunk fb, advanced by 16 frames per chunk (address arithmetic in the
+  // staging phases competes with the partner wave's MFMAs: keep it to three 64-bit adds per chunk)
+  const unsigned char* pa = reinterpret_cast<const unsigned char*>(yp) + ((size_t)(fb + arow) * 3 * TB_C + c) * (TB_KP * 2) + (i0 * 2 + apc * 16);
+  const unsigned char* pb = reinterpret_cast<const unsigned char*>(gp) + (size_t)(fb + brow) * 3 * (TB_KP * 2) + q0 * 2 + bpc * 16;
+  const unsigned char* pe = reinterpret_cast<const unsigned char*>(gp) + ((size_t)(fb + erow) * 3 + epl) * (TB_KP * 2) + (64 + epc) * 16;
   auto gload = [&](int f0) __attribute__((always_inline)) {
-    {
-      int f = f0 + arow;
-      f = f < F ? f : F - 1;
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(yp) + ((size_t)f * 3 * TB_C + c) * (TB_KP * 2) + (i0 * 2 + apc * 16);
+    if (f0 + WG_KF <= F) {  // uniform: all 16 frames exist
+      if (tid < 256) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) sta[pl] = *reinterpret_cast<const u32x4*>(src + (size_t)pl * TB_C * TB_KP * 2);
-    }
+        for (int pl = 0; pl < 3; ++pl) sta[pl] = *reinterpret_cast<const u32x4*>(pa + (size_t)pl * TB_C * TB_KP * 2);
+      }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      int f = f0 + brow + 16 * (k & 1);
-      f = f < F ? f : F - 1;
-      stb[k] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(gp) + ((size_t)f * 3 + (k >> 1)) * (TB_KP * 2) + q0 * 2 + bpc * 16);
+      for (int pl = 0; pl < 3; ++pl) stb[pl] = *reinterpret_cast<const u32x4*>(pb + pl * (TB_KP * 2));
+      if (strip && tid < 96) ste = *reinterpret_cast<const u32x4*>(pe);
+    } else {  // last chunk of the batch: clamp the frame index (rows past the end are zeroed in lstore)
+      if (tid < 256) {
+        int f = f0 + arow;
+        f = f < F ? f : F - 1;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(yp) + ((size_t)f * 3 * TB_C + c) * (TB_KP * 2) + (i0 * 2 + apc * 16);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) sta[pl] = *reinterpret_cast<const u32x4*>(src + (size_t)pl * TB_C * TB_KP * 2);
+      }
+      {
+        int f = f0 + brow;
+        f = f < F ? f : F - 1;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(gp) + (size_t)f * 3 * (TB_KP * 2) + q0 * 2 + bpc * 16;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) stb[pl] = *reinterpret_cast<const u32x4*>(src + pl * (TB_KP * 2));
+      }
+      if (strip && tid < 96) {
+        int f = f0 + erow;
+        f = f < F ? f : F - 1;
+        ste = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(gp) + ((size_t)f * 3 + epl) * (TB_KP * 2) + (64 + epc) * 16);
+      }
     }
-    if (strip && tid < 192) {
-      int f = f0 + erow;
-      f = f < F ? f : F - 1;
-      ste = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(gp) + ((size_t)f * 3 + epl) * (TB_KP * 2) + (64 + epc) * 16);
-    }
+    pa += (size_t)WG_KF * 3 * TB_C * TB_KP * 2;
+    pb += (size_t)WG_KF * 3 * TB_KP * 2;
+    pe += (size_t)WG_KF * 3 * TB_KP * 2;
   };
-  auto lstore = [&](int f0) __attribute__((always_inline)) {
+  auto lstore = [&](int f0, int buf) __attribute__((always_inline)) {
+    unsigned char* sA = smem + buf * WG_BUF;
+    unsigned char* sB = sA + 3 * WG_APL;
     const u32x4 z = {0u, 0u, 0u, 0u};
     const bool tail = f0 + WG_KF > fe;  // uniform: frames past the chunk contribute zero (A rows zeroed)
+    if (tid < 256) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      *reinterpret_cast<u32x4*>(sA + pl * WG_APL + arow * WG_RSA + apc * 16) = (tail && f0 + arow >= fe) ? z : sta[pl];
+      for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<u32x4*>(sA + pl * WG_APL + arow * WG_RSA + apc * 16) = (tail && f0 + arow >= fe) ? z : sta[pl];
+    }
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
-      *reinterpret_cast<u32x4*>(sB + (k >> 1) * WG_BPL + (brow + 16 * (k & 1)) * WG_RSB + bpc * 16) = stb[k];
-    if (strip && tid < 192) *reinterpret_cast<u32x4*>(sB + epl * WG_BPL + erow * WG_RSB + (32 + epc) * 16) = ste;
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(sB + pl * WG_BPL + brow * WG_RSB + bpc * 16) = stb[pl];
+    if (strip && tid < 96) *reinterpret_cast<u32x4*>(sB + epl * WG_BPL + erow * WG_RSB + (32 + epc) * 16) = ste;
   };
 
   // ---- fragment addresses (transpose reads): lane -> (frame row (l&15)>>2 (+8*lh), column quad 4*(l&3) + 16*((l>>4)&1))
   const int trow = ((lane & 15) >> 2) + 8 * lh, tcol = 4 * (lane & 3) + 16 * ((lane >> 4) & 1);
-  const int aoff = trow * WG_RSA + (64 * wr + tcol) * 2;   // + plane*WG_APL + 64*ri + ks*16*WG_RSA
-  const int boff = trow * WG_RSB + (64 * wc + tcol) * 2;   // + plane*WG_BPL + 64*cj + ks*16*WG_RSB
-  const int eoff = trow * WG_RSB + (256 + tcol) * 2;       // the q = 512 strip (tile columns 256..287)
-  const int eri = wc & 1;                                  // this wave's strip row tile = 2*wr + eri, on k-step wc>>1
+  const int aoff = trow * WG_RSA + (64 * wr + tcol) * 2;                 // + buf + plane*WG_APL + 64*ri
+  const int boff = 3 * WG_APL + trow * WG_RSB + (64 * wc + tcol) * 2;    // + buf + plane*WG_BPL + 64*cj
+  const int eoff = 3 * WG_APL + trow * WG_RSB + (256 + tcol) * 2;        // the q = 512 strip (tile columns 256..287)
+  const int eri = wc & 1;                                                // this wave's strip row tile = 2*wr + eri, on chunks of parity wc>>1
 
   f32x16 acc[2][2], acce;
 #pragma unroll
@@ -527,22 +553,23 @@ __global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16(const unsigned short
     for (int cj = 0; cj < 2; ++cj) acc[ri][cj] = zero16();
   acce = zero16();
 
-  u32x4 fa[2][2][3], fbq[2][2][3], fe3[3];
-  auto loadF = [&](int set, int ks) __attribute__((always_inline)) {
+  u32x4 fa[2][3], fbq[2][3], fe3[3];
+  auto loadF = [&](int buf, bool mine) __attribute__((always_inline)) {
+    const unsigned char* sb = smem + buf * WG_BUF;
 #pragma unroll
     for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fa[set][ri][pl] = tr_read8(sA + pl * WG_APL + aoff + ri * 64 + ks * 16 * WG_RSA, 4 * WG_RSA);
+      for (int pl = 0; pl < 3; ++pl) fa[ri][pl] = tr_read8(sb + pl * WG_APL + aoff + ri * 64, 4 * WG_RSA);
 #pragma unroll
     for (int cj = 0; cj < 2; ++cj)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fbq[set][cj][pl] = tr_read8(sB + pl * WG_BPL + boff + cj * 64 + ks * 16 * WG_RSB, 4 * WG_RSB);
-    if (strip && (wc >> 1) == ks) {  // wave-uniform: this wave's turn on the q = 512 strip
+      for (int pl = 0; pl < 3; ++pl) fbq[cj][pl] = tr_read8(sb + pl * WG_BPL + boff + cj * 64, 4 * WG_RSB);
+    if (mine) {  // wave-uniform: this wave's turn on the q = 512 strip
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fe3[pl] = tr_read8(sB + pl * WG_BPL + eoff + ks * 16 * WG_RSB, 4 * WG_RSB);
+      for (int pl = 0; pl < 3; ++pl) fe3[pl] = tr_read8(sb + pl * WG_BPL + eoff, 4 * WG_RSB);
     }
   };
-  auto mm = [&](int set, int ks) __attribute__((always_inline)) {
+  auto mm = [&](bool mine) __attribute__((always_inline)) {
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
     constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
@@ -550,38 +577,68 @@ __global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16(const unsigned short
 #pragma unroll
       for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
-        for (int cj = 0; cj < 2; ++cj) acc[ri][cj] = mfma_bf16(fa[set][ri][PA[t]], fbq[set][cj][PB[t]], acc[ri][cj]);
-    if (strip && (wc >> 1) == ks) {  // wave-uniform
+        for (int cj = 0; cj < 2; ++cj) acc[ri][cj] = mfma_bf16(fa[ri][PA[t]], fbq[cj][PB[t]], acc[ri][cj]);
+    if (mine) {  // wave-uniform
       u32x4 af[3];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) af[pl] = eri == 0 ? fa[set][0][pl] : fa[set][1][pl];
+      for (int pl = 0; pl < 3; ++pl) af[pl] = eri == 0 ? fa[0][pl] : fa[1][pl];
 #pragma unroll
       for (int t = 0; t < 6; ++t) acce = mfma_bf16(af[PA[t]], fe3[PB[t]], acce);
     }
   };
 
-  if (fb < fe) gload(fb);
-  for (int f0 = fb; f0 < fe; f0 += WG_KF) {
-    __syncthreads();  // previous chunk consumed
-    lstore(f0);
-    __syncthreads();
-    if (f0 + WG_KF < fe) gload(f0 + WG_KF);
-    __builtin_amdgcn_sched_barrier(0);
-    loadF(0, 0);
-    loadF(1, 1);  // (reads of the second k-step land while the MFMAs of the first run)
-    __builtin_amdgcn_sched_barrier(0);
-    mm(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(1, 1);
-    __builtin_amdgcn_sched_barrier(0);
+  // one barrier per chunk, two LDS buffers: a wave that finished the MFMAs of chunk n stores chunk n+1
+  // into the other buffer while slower waves still read buffer n (the waves of a SIMD drift apart and
+  // overlap each other's load and MFMA phases)
+#if VAENPVC_PROF
+  long long pc[6] = {0, 0, 0, 0, 0, 0};
+  TBPROF_T(k0);
+#endif
+  if (fb < fe) {
+    gload(fb);
+    lstore(fb, 0);
   }
+  __syncthreads();
+  int n = 0;
+  for (int f0 = fb; f0 < fe; f0 += WG_KF, ++n) {
+    const bool more = f0 + WG_KF < fe;
+    const bool mine = strip && (wc >> 1) == (n & 1);
+    TBPROF_T(t0);
+    if (more) gload(f0 + WG_KF);
+    __builtin_amdgcn_sched_barrier(0);
+    TBPROF_T(t1);
+    loadF(n & 1, mine);
+#if VAENPVC_PROF
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    TBPROF_T(t2);
+    mm(mine);
+#if VAENPVC_PROF
+    asm volatile("s_nop 0" ::: "memory");
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    TBPROF_T(t3);
+    if (more) lstore(f0 + WG_KF, (n + 1) & 1);
+#if VAENPVC_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    TBPROF_T(t4);
+    __syncthreads();
+#if VAENPVC_PROF
+    TBPROF_T(t5);
+    pc[0] += t1 - t0; pc[1] += t2 - t1; pc[2] += t3 - t2; pc[3] += t4 - t3; pc[4] += t5 - t4;
+#endif
+  }
+  TBPROF_T(k1);
 
   // ---- epilogue: diagonals.  Wave tile = rows i0+64wr .. +63, columns q0+64wc .. +63: d = col - row in [-63, 63]
+  // all 8 wave tiles of the workgroup (128 x 256) share 383 diagonals: reduce them in LDS first,
+  // then ONE global atomic per diagonal and workgroup
+  float* dg = reinterpret_cast<float*>(smem);
+  if (tid < 384) dg[tid] = 0.f;
   __syncthreads();
-  float* dg = reinterpret_cast<float*>(smem) + wave * 128;
-  dg[lane] = 0.f;
-  dg[lane + 64] = 0.f;
-  wave_lds_sync();
+  const int dbase = 64 * wc - 64 * wr + 127;  // + (cl - row) in [-63, 63]  ->  [0, 382]
 #pragma unroll
   for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
@@ -590,12 +647,12 @@ __global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16(const unsigned short
       for (int reg = 0; reg < 16; ++reg) {
         int row = ri * 32 + acc_row(reg, lane);
         int cl = cj * 32 + l31;
-        atomicAdd(&dg[cl - row + 63], acc[ri][cj][reg]);
+        atomicAdd(&dg[dbase + cl - row], acc[ri][cj][reg]);
       }
-  wave_lds_sync();
-  for (int d = lane; d < 127; d += 64) {
-    int t = (q0 + 64 * wc) - (i0 + 64 * wr) + (d - 63) + 512;  // in [1, 1023]
-    atomicAdd(dW + t * TB_C + c, dg[d]);
+  __syncthreads();
+  if (tid < 383) {
+    int t = q0 - i0 + (tid - 127) + 512;  // in [1, 1023]
+    atomicAdd(dW + t * TB_C + c, dg[tid]);
   }
   // the q = 512 strip: column 512 is lane l31 == 0 of the strip tile; t = 512 - i + 512
   if (strip && l31 == 0) {
@@ -605,6 +662,18 @@ __global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16(const unsigned short
       atomicAdd(dW + (1024 - i) * TB_C + c, acce[reg]);
     }
   }
+#if VAENPVC_PROF
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TBPROF_T(k2);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(g_tw_prof + 0, 1ull);
+      for (int i = 0; i < 5; ++i) atomicAdd(g_tw_prof + 1 + i, (unsigned long long)pc[i]);
+      atomicAdd(g_tw_prof + 6, (unsigned long long)(k2 - k1));
+      atomicAdd(g_tw_prof + 7, (unsigned long long)(k2 - k0));
+    }
+  }
+#endif
 }
 
 }  // namespace tuned
