@@ -8,8 +8,11 @@
 //   forward : xh[f][p]     = b + sum_c sum_j Wc[c][p-j+512] * y2[f][c][j]   (p < 512 here;
 //             y2 = lrelu(LN(a2)) is materialised once by the LN-statistics kernel of layer 2)
 //   dgrad   : dy2[f][c][j] =     sum_p     Wc[c][p-j+512] * dxh[f][p]       (all j)
-// 513 = 16*32 + 1: the MFMA part covers 512 columns; forward column p = 512 is a side
-// kernel (k_toep_fwd_lastcol), dgrad column j = 512 is a wave reduction inside the kernel.
+// 513 = 16*32 + 1: the MFMA part covers 512 columns; forward column p = 512 is accumulated
+// inside k_toep_fwd by the workgroups with blockIdx.y == 0, dgrad column j = 512 is a wave reduction
+// inside the kernel.
+// These exact-fp32 kernels serve batches below 8192 frames (and VAENPVC_TOEP=f32); larger batches
+// use the bf16 matrix cores with a 3-term operand split, gfx950_toep_bf16.h.
 #pragma once
 #include "gfx950_common.h"
 
@@ -158,22 +161,6 @@ __global__ void __launch_bounds__(256) k_toep_fwd(const float* __restrict__ y2, 
       int f = f0 + acc_row(reg, lane);
       if (f < F) xh[(int64_t)f * TOEP_H + p0 + nb * 32 + l31] = acc[nb][reg] + bb;
     }
-}
-
-// forward column p = 512: xh[f][512] = b + sum_{c,j} Wc[c][1024-j] * y2[f][c][j]; one wave per frame
-__global__ void __launch_bounds__(256) k_toep_fwd_lastcol(const float* __restrict__ y2, const float* __restrict__ Wc,
-                                                          const float* __restrict__ bias, float* __restrict__ xh, int F) {
-  const int lane = threadIdx.x & 63;
-  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (f >= F) return;
-  float s = 0.f;
-  for (int c = 0; c < TOEP_C; ++c) {
-    const float* row = y2 + (int64_t)f * (TOEP_C * TOEP_H) + c * TOEP_H;
-    const float* w = Wc + c * WROW + WPRE + 1024;
-    for (int j = lane; j < TOEP_H; j += 64) s += row[j] * w[-j];
-  }
-  s = wave_sum(s);
-  if (lane == 0) xh[(int64_t)f * TOEP_H + 512] = s + bias[0];
 }
 
 // ---------------------------------------------------------------- input gradient
