@@ -393,6 +393,36 @@ inline void launch_pack(Fn fn, float* dst, int count, hipStream_t s) {
   hipLaunchKernelGGL(k_pack<Fn>, dim3((unsigned)cdiv(count, 256)), dim3(256), 0, s, fn, dst, count);
 }
 
+// All weight-packing jobs of a step in ONE launch (they are ~17 tiny kernels otherwise, each a few
+// microseconds of launch gap): job k owns the block range [sum_{j<k} blocks(j), +blocks(k)).
+template <class Fn>
+struct PackJob {
+  Fn fn;
+  float* dst;
+  int count;
+  __device__ void run(int i) const { dst[i] = fn(i); }
+};
+template <class Fn>
+inline PackJob<Fn> pack_job(Fn fn, float* dst, int count) { return PackJob<Fn>{fn, dst, count}; }
+template <class J0, class... Js>
+__device__ __forceinline__ void run_pack_jobs(int blk, const J0& j0, const Js&... js) {
+  const int nb = (j0.count + 255) / 256;
+  if (blk < nb) {
+    int i = blk * 256 + threadIdx.x;
+    if (i < j0.count) j0.run(i);
+  } else if constexpr (sizeof...(Js) > 0) {
+    run_pack_jobs(blk - nb, js...);
+  }
+}
+template <class... Js>
+__global__ void __launch_bounds__(256) k_pack_multi(Js... js) { run_pack_jobs((int)blockIdx.x, js...); }
+template <class... Js>
+inline void launch_pack_multi(hipStream_t s, Js... js) {
+  int blocks = 0;
+  ((blocks += (js.count + 255) / 256), ...);
+  hipLaunchKernelGGL(k_pack_multi<Js...>, dim3((unsigned)blocks), dim3(256), 0, s, js...);
+}
+
 // packed B of a ConvCfg from a TF kernel tensor.
 //   transposed == false: src[(t*KC + k)*N + n]     transposed == true: src[(t*N + n)*KC + k]
 template <class C>

@@ -151,34 +151,31 @@ struct PackSum3 {
 // ---------------------------------------------------------------- weight packing
 static void prep(const Model& m, const float* P, const Ws& w, hipStream_t s) {
   float* S = w.scratch;
-  launch_pack(PackDense{P + m.wmu_off, P + m.wlv_off, 0, 768, 256, HeadsF::NP, 128, 128}, S + Pk::heads_f,
-              HeadsF::KP * HeadsF::NP, s);
-  launch_pack(PackDense{P + m.wmu_off, P + m.wlv_off, 2, 256, 768, HeadsB::NP, 128, 128}, S + Pk::heads_b,
-              HeadsB::KP * HeadsB::NP, s);
-  launch_pack(PackDense{P + m.wz_off, P + m.wy_off, 1, 256, 1539, MergeF::NP, 128, 0}, S + Pk::merge_f,
-              MergeF::KP * MergeF::NP, s);
-  launch_pack(PackDense{P + m.wz_off, P + m.wy_off, 3, 1539, 256, MergeB::NP, 128, 0}, S + Pk::merge_b,
-              MergeB::KP * MergeB::NP, s);
-  launch_pack(PackSum3{P + m.bz_off, P + m.by_off, P + m.bm_off, 1539}, S + Pk::merge_bias, 1600, s);
-  // conv_transpose forward: B[t][k=cin][n=cout] from TF [t][cout][cin]  -> transposed
-  launch_pack(PackConv<D0F>{P + m.dec[0].w_off, true}, S + Pk::d0f, D0F::BTOTAL, s);
-  launch_pack(PackConv<D1F>{P + m.dec[1].w_off, true}, S + Pk::d1f, D1F::BTOTAL, s);
-  launch_pack(PackConv<D2F>{P + m.dec[2].w_off, true}, S + Pk::d2f, D2F::BTOTAL, s);
-  // conv_transpose input-gradient: B[t][k=cout][n=cin] = TF layout (padded copies only)
-  launch_pack(PackConv<GD2>{P + m.dec[2].w_off, false}, S + Pk::gd2, GD2::BTOTAL, s);
-  launch_pack(PackConv<GD0>{P + m.dec[0].w_off, false}, S + Pk::gd0, GD0::BTOTAL, s);
-  // conv input-gradient: B[t][k=cout][n=cin] from TF [t][cin][cout] -> transposed
-  launch_pack(PackConv<GE4>{P + m.enc[4].w_off, true}, S + Pk::ge4, GE4::BTOTAL, s);
-  launch_pack(PackConv<GE3>{P + m.enc[3].w_off, true}, S + Pk::ge3, GE3::BTOTAL, s);
-  launch_pack(PackConv<GE2>{P + m.enc[2].w_off, true}, S + Pk::ge2, GE2::BTOTAL, s);
-  launch_pack(PackConv<GE1>{P + m.enc[1].w_off, true}, S + Pk::ge1, GE1::BTOTAL, s);
-  launch_pack(PackToep{P + m.dec[3].w_off}, S + Pk::wc, TOEP_C * WROW, s);
-  if (toep_bf16())
-    hipLaunchKernelGGL(k_pack_toep_bf16<false>, dim3((unsigned)cdiv(TB_C * TB_CPY * 8 * TB_CHUNKS, 256)), dim3(256), 0, s,
-                       P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wdg));
-  if (toep_bf16())
-    hipLaunchKernelGGL(k_pack_toep_bf16<true>, dim3((unsigned)cdiv(TB_C * TB_CPY * 8 * TB_CHUNKS, 256)), dim3(256), 0, s,
-                       P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wfw));
+  constexpr int NTB = TB_C * TB_CPY * 8 * TB_CHUNKS;
+  // one launch for all packed copies (see k_pack_multi)
+  launch_pack_multi(
+      s,
+      pack_job(PackDense{P + m.wmu_off, P + m.wlv_off, 0, 768, 256, HeadsF::NP, 128, 128}, S + Pk::heads_f, HeadsF::KP * HeadsF::NP),
+      pack_job(PackDense{P + m.wmu_off, P + m.wlv_off, 2, 256, 768, HeadsB::NP, 128, 128}, S + Pk::heads_b, HeadsB::KP * HeadsB::NP),
+      pack_job(PackDense{P + m.wz_off, P + m.wy_off, 1, 256, 1539, MergeF::NP, 128, 0}, S + Pk::merge_f, MergeF::KP * MergeF::NP),
+      pack_job(PackDense{P + m.wz_off, P + m.wy_off, 3, 1539, 256, MergeB::NP, 128, 0}, S + Pk::merge_b, MergeB::KP * MergeB::NP),
+      pack_job(PackSum3{P + m.bz_off, P + m.by_off, P + m.bm_off, 1539}, S + Pk::merge_bias, 1600),
+      // conv_transpose forward: B[t][k=cin][n=cout] from TF [t][cout][cin]  -> transposed
+      pack_job(PackConv<D0F>{P + m.dec[0].w_off, true}, S + Pk::d0f, D0F::BTOTAL),
+      pack_job(PackConv<D1F>{P + m.dec[1].w_off, true}, S + Pk::d1f, D1F::BTOTAL),
+      pack_job(PackConv<D2F>{P + m.dec[2].w_off, true}, S + Pk::d2f, D2F::BTOTAL),
+      // conv_transpose input-gradient: B[t][k=cout][n=cin] = TF layout (padded copies only)
+      pack_job(PackConv<GD2>{P + m.dec[2].w_off, false}, S + Pk::gd2, GD2::BTOTAL),
+      pack_job(PackConv<GD0>{P + m.dec[0].w_off, false}, S + Pk::gd0, GD0::BTOTAL),
+      // conv input-gradient: B[t][k=cout][n=cin] from TF [t][cin][cout] -> transposed
+      pack_job(PackConv<GE4>{P + m.enc[4].w_off, true}, S + Pk::ge4, GE4::BTOTAL),
+      pack_job(PackConv<GE3>{P + m.enc[3].w_off, true}, S + Pk::ge3, GE3::BTOTAL),
+      pack_job(PackConv<GE2>{P + m.enc[2].w_off, true}, S + Pk::ge2, GE2::BTOTAL),
+      pack_job(PackConv<GE1>{P + m.enc[1].w_off, true}, S + Pk::ge1, GE1::BTOTAL),
+      pack_job(PackToep{P + m.dec[3].w_off}, S + Pk::wc, TOEP_C * WROW),
+      // shifted bf16 tap copies of the last layer (count 0 = skipped when the fp32 kernels are selected)
+      PackToepBf16Job<false>{P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wdg), toep_bf16() ? NTB : 0},
+      PackToepBf16Job<true>{P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wfw), toep_bf16() ? NTB : 0});
 }
 
 template <int N>

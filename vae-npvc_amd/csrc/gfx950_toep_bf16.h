@@ -88,6 +88,24 @@ __global__ void __launch_bounds__(256) k_split3_rows(const float* __restrict__ s
 // ---- shifted bf16 copies of the tap rows: dst[c][plane][s][m] = plane(w[c][m + s]), m < 8*TB_CHUNKS.
 //      REV = false: w[c][u] = W[u][c] (input gradient);  REV = true: w[c][u] = W[1024 - u][c] (forward).
 template <bool REV>
+struct PackToepBf16Job {  // job of k_pack_multi (gfx950_elem.h)
+  const float* W;
+  unsigned short* dst;
+  int count;  // TB_C * TB_CPY * 8 * TB_CHUNKS
+  __device__ void run(int i) const {
+    constexpr int PER = 8 * TB_CHUNKS;
+    int c = i / (TB_CPY * PER), r = i - c * (TB_CPY * PER);
+    int s = r / PER, m = r - s * PER;
+    int u = m + s;
+    unsigned h = 0, md = 0, l = 0;
+    if (u < TB_T) split3(W[(REV ? TB_T - 1 - u : u) * TB_C + c], h, md, l);
+    unsigned short* d = dst + (size_t)c * (TB_WCH / 2) + s * PER + m;
+    d[0] = (unsigned short)h;
+    d[TB_CPY * PER] = (unsigned short)md;
+    d[2 * TB_CPY * PER] = (unsigned short)l;
+  }
+};
+template <bool REV>
 __global__ void __launch_bounds__(256) k_pack_toep_bf16(const float* __restrict__ W, unsigned short* __restrict__ dst) {
   constexpr int PER = 8 * TB_CHUNKS;
   int i = blockIdx.x * 256 + threadIdx.x;
