@@ -331,7 +331,14 @@ __global__ void __launch_bounds__(256) k_colsum_atomic(const float* __restrict__
   if (n >= N) return;
   int fb = blockIdx.y * fchunk, fe = min(F, fb + fchunk);
   float s = 0.f;
-  for (int f = fb; f < fe; ++f) s += d[(int64_t)f * ld + n];
+  int f = fb;
+  for (; f + 8 <= fe; f += 8) {  // eight independent loads in flight
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = d[(int64_t)(f + u) * ld + n];
+    s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  for (; f < fe; ++f) s += d[(int64_t)f * ld + n];
   atomicAdd(o1 + n, s);
   if (o2) atomicAdd(o2 + n, s);
   if (o3) atomicAdd(o3 + n, s);

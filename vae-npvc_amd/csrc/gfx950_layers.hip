@@ -411,9 +411,9 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       TnArgs a = tn_args(w.dec_y, 4104, w.d_xh, 513, 4096, 512, F, G + m.dec[3].w_off, 0);
       VAENPVC_TIMED("dec3_wgrad", s2, launch_tngemm(a, true, kchunks_for(F, 32 * 4), s2));
     }
-    int ech = cmax(1, cmin_(cdiv(F, 32), 512));
-    int efc = cdiv(F, ech);
-    hipLaunchKernelGGL(k_toep_wgrad_row512, dim3((unsigned)cdiv(F, efc)), dim3(256), 0, s2, w.dec_y, w.d_xh, G + m.dec[3].w_off, F, efc);
+    int ech = cmax(1, cmin_(cdiv(F, 64), 128));
+    int efc = rup(cdiv(F, ech), 64);
+    hipLaunchKernelGGL(k_toep_wgrad_row512, dim3((unsigned)cdiv(F, efc), 3), dim3(256), 0, s2, w.dec_y, w.d_xh, G + m.dec[3].w_off, F, efc);
     hipLaunchKernelGGL(k_sum_all_atomic, dim3((unsigned)cmin_(1024, cdiv(F * 513, 1024))), dim3(256), 0, s2, w.d_xh,
                        (int64_t)F * 513, G + m.dec[3].b_off);
     static bool once = false;
@@ -496,7 +496,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     TnArgs b = tn_args(P + m.emb_off, 128, w.d_h, 1539, 128, 1539, F, G + m.wy_off, 1539);
     b.xidx = y;
     launch_tngemm(b, false, kchunks_for(F, 13), s2);
-    int ch = cmax(1, cmin_(cdiv(F, 64), 128)), fc = cdiv(F, ch);
+    int ch = cmax(1, cmin_(cdiv(F, 32), 256)), fc = cdiv(F, ch);
     hipLaunchKernelGGL(k_colsum_atomic, dim3((unsigned)cdiv(1539, 256), (unsigned)cdiv(F, fc)), dim3(256), 0, s, w.d_h, 1539, 1539,
                        F, fc, G + m.bz_off, G + m.by_off, G + m.bm_off);
     DenseArgs d{w.d_h, nullptr, nullptr, nullptr, nullptr, nullptr, w.scratch + Pk::merge_b, nullptr,
@@ -522,7 +522,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     a.Y = w.d_z_lv;
     a.C = G + m.wlv_off;
     launch_tngemm(a, false, kchunks_for(F, 6), s2);
-    int ch = cmax(1, cmin_(cdiv(F, 64), 256)), fc = cdiv(F, ch);
+    int ch = cmax(1, cmin_(cdiv(F, 32), 1024)), fc = cdiv(F, ch);
     hipLaunchKernelGGL(k_colsum_atomic, dim3(1, (unsigned)cdiv(F, fc)), dim3(256), 0, s, w.d_z_mu, 128, 128, F, fc,
                        G + m.bmu_off, nullptr, nullptr);
     hipLaunchKernelGGL(k_colsum_atomic, dim3(1, (unsigned)cdiv(F, fc)), dim3(256), 0, s, w.d_z_lv, 128, 128, F, fc,

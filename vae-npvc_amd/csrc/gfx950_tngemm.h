@@ -241,40 +241,38 @@ inline void launch_tngemm(const TnArgs& a, bool toep, int kchunks, hipStream_t s
 
 // Remaining edge term of the Toeplitz weight gradient (row j = 512 of y2, all q):
 //   dW[t][c] += sum_f y2[f,c,512] * dxh[f,t]        for t <= 512
-// One workgroup per chunk of frames; thread <-> up to 3 values of t, 8 channel accumulators each.
-// Reads dxh once (67 MB at F = 32768) plus 8 floats per frame of y2.
+// grid (frame chunks, 3): thread <-> ONE tap t = 256*blockIdx.y + tid with 8 channel accumulators.  The
+// 8 y2 values of 64 frames sit in 8 registers (lane <-> frame) and are broadcast with v_readlane, so a
+// frame costs one coalesced load and 8 FMAs.  Few, long chunks: the result is 513 x 8 atomics per
+// workgroup onto the same 4104 addresses (with 512 chunks those atomics WERE the kernel's run time).
 __global__ void __launch_bounds__(256) k_toep_wgrad_row512(const float* __restrict__ y2, const float* __restrict__ dxh,
                                                            float* __restrict__ dW, int F, int fchunk) {
-  __shared__ float ys[8];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int t = 256 * blockIdx.y + tid;
+  const bool tok = t <= 512;
   const int fb = blockIdx.x * fchunk, fe = min(F, fb + fchunk);
-  float acc[3][8];
+  float acc[8];
 #pragma unroll
-  for (int k = 0; k < 3; ++k)
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+  for (int f0 = fb; f0 < fe; f0 += 64) {
+    const int nf = min(64, fe - f0);
+    float yv[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
-  for (int f = fb; f < fe; ++f) {
-    __syncthreads();
-    if (tid < 8) ys[tid] = y2[(int64_t)f * 4104 + tid * 513 + 512];
-    float d[3];
+    for (int c = 0; c < 8; ++c) yv[c] = lane < nf ? y2[(int64_t)(f0 + lane) * 4104 + c * 513 + 512] : 0.f;
+    for (int j = 0; j < nf; j += 4) {
+      float d[4];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      int t = tid + 256 * k;
-      d[k] = t <= 512 ? dxh[(int64_t)f * 513 + t] : 0.f;
+      for (int u = 0; u < 4; ++u) d[u] = (tok && j + u < nf) ? dxh[(int64_t)(f0 + j + u) * 513 + t] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          acc[c] += d[u] * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yv[c]), (j + u) & 63));
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) acc[k][c] += d[k] * ys[c];
   }
+  if (tok)
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    int t = tid + 256 * k;
-    if (t <= 512)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) atomicAdd(dW + t * 8 + c, acc[k][c]);
-  }
+    for (int c = 0; c < 8; ++c) atomicAdd(dW + t * 8 + c, acc[c]);
 }
 
 }  // namespace tuned
