@@ -234,6 +234,7 @@ __global__ void __launch_bounds__(C::NTHR, C::WPE) k_convwgrad(WgArgs a) {
 template <class C>
 inline void launch_convwgrad(const WgArgs& a0, int target_wgs, hipStream_t s) {
   constexpr int LDS_BYTES = (C::XT + C::YT) * 4;
+  static_assert(LDS_BYTES <= 160 * 1024, "operand tiles exceed the LDS of a CU");
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convwgrad<C>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -66,14 +66,41 @@ using HeadsB = DenseCfg<256, 768, 256, 3, IN_CONCAT2, 1>;
 using MergeF = DenseCfg<256, 1539, 256, 2, IN_CONCAT2, 1>;
 using MergeB = DenseCfg<1539, 256, 256, 2, IN_PLAIN, 1>;
 //                     XC  XH   YC  YH  T  S PAD  XLN    YLN   TF NTW
-using WD2 = WgCfg<8, 513, 16, 171, 7, 3, 2, false, true, 2, 1>;
-using WD1 = WgCfg<16, 171, 32, 57, 7, 3, 2, false, true, 4, 1>;
-using WD0 = WgCfg<32, 57, 81, 19, 9, 3, 3, false, false, 6, 3, 4, 0, 1>;
-using WE4 = WgCfg<128, 7, 256, 3, 7, 3, 3, true, false, 8, 1>;
-using WE3 = WgCfg<64, 19, 128, 7, 7, 3, 3, true, false, 8, 2>;
-using WE2 = WgCfg<32, 57, 64, 19, 7, 3, 2, true, false, 4, 2>;
-using WE1 = WgCfg<16, 171, 32, 57, 7, 3, 2, true, false, 4, 1>;
-using WE0 = WgCfg<1, 513, 16, 171, 7, 3, 2, false, false, 2, 1>;
+// weight-gradient tilings: trailing parameters = TF (frames per sub-tile), NTW (column tiles per workgroup),
+// NWV (waves), WM (waves along M, 0 = auto), WPE (waves per SIMD the register budget must allow);
+// overridable per layer for tuning sweeps (scripts/build_variant.sh NAME "-DWD2_T=4,1,4,0,2")
+#ifndef WD2_T
+#define WD2_T 2, 1, 4, 0, 2
+#endif
+#ifndef WD1_T
+#define WD1_T 4, 1, 8, 0, 2
+#endif
+#ifndef WD0_T
+#define WD0_T 4, 3, 4, 0, 1
+#endif
+#ifndef WE4_T
+#define WE4_T 8, 1, 4, 0, 2
+#endif
+#ifndef WE3_T
+#define WE3_T 8, 2, 4, 0, 2
+#endif
+#ifndef WE2_T
+#define WE2_T 4, 2, 4, 0, 2
+#endif
+#ifndef WE1_T
+#define WE1_T 4, 1, 8, 0, 2
+#endif
+#ifndef WE0_T
+#define WE0_T 2, 1, 4, 0, 2
+#endif
+using WD2 = WgCfg<8, 513, 16, 171, 7, 3, 2, false, true, WD2_T>;
+using WD1 = WgCfg<16, 171, 32, 57, 7, 3, 2, false, true, WD1_T>;
+using WD0 = WgCfg<32, 57, 81, 19, 9, 3, 3, false, false, WD0_T>;
+using WE4 = WgCfg<128, 7, 256, 3, 7, 3, 3, true, false, WE4_T>;
+using WE3 = WgCfg<64, 19, 128, 7, 7, 3, 3, true, false, WE3_T>;
+using WE2 = WgCfg<32, 57, 64, 19, 7, 3, 2, true, false, WE2_T>;
+using WE1 = WgCfg<16, 171, 32, 57, 7, 3, 2, true, false, WE1_T>;
+using WE0 = WgCfg<1, 513, 16, 171, 7, 3, 2, false, false, WE0_T>;
 
 // packed-weight scratch layout (float offsets)
 struct Pk {
