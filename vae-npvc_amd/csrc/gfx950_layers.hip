@@ -26,41 +26,69 @@ namespace vaenpvc {
 namespace tuned {
 
 // ---------------------------------------------------------------- configurations
-//                      KC  HIN   N  HOUT T  S PAD typeP  TF  in-kind  lndiv MB NB
-#ifdef VAENPVC_EXP_NW4
-using E1F = ConvCfg<16, 171, 32, 57, 7, 3, 2, CONV_S, 2, IN_LN, 1, 1, 1, 4>;
-#else
-using E1F = ConvCfg<16, 171, 32, 57, 7, 3, 2, CONV_S, 4, IN_LN, 1, 1, 1>;
+// ConvCfg<KC, HIN, N, HOUT, T, S, PAD, kind, TF, in-kind, lndiv, MB, NB, NW>; the tiling (TF = frames per tile,
+// MB x NB = MFMA tiles per work item, NW = waves) is overridable per layer for tuning sweeps
+// (scripts/build_variant.sh NAME "-DE2F_T=6,1,1,8"):  X_T = TF, MB, NB, NW
+#ifndef E1F_T
+#define E1F_T 4, 1, 1, 8
 #endif
-using E2F = ConvCfg<32, 57, 64, 19, 7, 3, 2, CONV_S, 12, IN_LN, 1, 2, 1>;
-using E3F = ConvCfg<64, 19, 128, 7, 7, 3, 3, CONV_S, 9, IN_LN, 1, 1, 1>;
-using E4F = ConvCfg<128, 7, 256, 3, 7, 3, 3, CONV_S, 21, IN_LN, 1, 2, 1>;
-using D0F = ConvCfg<81, 19, 32, 57, 9, 3, 3, CONV_P, 8, IN_PLAIN, 1, 1, 1>;
-#ifdef VAENPVC_EXP_NW4
-using D1F = ConvCfg<32, 57, 16, 171, 7, 3, 2, CONV_PM, 2, IN_LN, 1, 1, 2, 4>;
-using D2F = ConvCfg<16, 171, 8, 513, 7, 3, 2, CONV_PM, 2, IN_LN, 1, 3, 1, 4>;
-#else
-using D1F = ConvCfg<32, 57, 16, 171, 7, 3, 2, CONV_PM, 4, IN_LN, 1, 1, 2>;
-using D2F = ConvCfg<16, 171, 8, 513, 7, 3, 2, CONV_PM, 4, IN_LN, 1, 3, 1>;
+#ifndef E2F_T
+#define E2F_T 12, 2, 1, 8
 #endif
-// input gradients: conv_transpose layers (S-type) and conv layers (P-type)
-#ifdef VAENPVC_EXP_NW4
-using GD2 = ConvCfg<8, 513, 16, 171, 7, 3, 2, CONV_S, 2, IN_PLAIN, 1, 1, 1, 4>;
-using GD1 = ConvCfg<16, 171, 32, 57, 7, 3, 2, CONV_S, 2, IN_PLAIN, 1, 1, 1, 4>;
-#else
-using GD2 = ConvCfg<8, 513, 16, 171, 7, 3, 2, CONV_S, 4, IN_PLAIN, 1, 1, 1>;
-using GD1 = ConvCfg<16, 171, 32, 57, 7, 3, 2, CONV_S, 4, IN_PLAIN, 1, 1, 1>;
+#ifndef E3F_T
+#define E3F_T 18, 2, 1, 8
 #endif
-using GD0 = ConvCfg<32, 57, 81, 19, 9, 3, 3, CONV_S, 8, IN_PLAIN, 1, 1, 1>;
-using GE4 = ConvCfg<256, 3, 128, 7, 7, 3, 3, CONV_P, 16, IN_PLAIN, 1, 1, 2>;
-using GE3 = ConvCfg<128, 7, 64, 19, 7, 3, 3, CONV_P, 18, IN_PLAIN, 1, 1, 1>;
-using GE2 = ConvCfg<64, 19, 32, 57, 7, 3, 2, CONV_P, 8, IN_PLAIN, 1, 1, 1>;
-#ifdef VAENPVC_EXP_NW4
-using GE1 = ConvCfg<32, 57, 16, 171, 7, 3, 2, CONV_PM, 2, IN_PLAIN, 1, 1, 2, 4>;
-#else
-using GE1 = ConvCfg<32, 57, 16, 171, 7, 3, 2, CONV_PM, 4, IN_PLAIN, 1, 1, 2>;
+#ifndef E4F_T
+#define E4F_T 21, 2, 1, 8
 #endif
-//                         K    N   KCH NBW in-kind    lndiv
+#ifndef D0F_T
+#define D0F_T 13, 1, 1, 8
+#endif
+#ifndef D1F_T
+#define D1F_T 4, 1, 2, 8
+#endif
+#ifndef D2F_T
+#define D2F_T 4, 3, 1, 8
+#endif
+#ifndef GD2_T
+#define GD2_T 4, 3, 1, 8
+#endif
+#ifndef GD1_T
+#define GD1_T 4, 1, 1, 8
+#endif
+#ifndef GD0_T
+#define GD0_T 13, 1, 1, 8
+#endif
+#ifndef GE4_T
+#define GE4_T 16, 1, 2, 8
+#endif
+#ifndef GE3_T
+#define GE3_T 18, 1, 1, 8
+#endif
+#ifndef GE2_T
+#define GE2_T 8, 1, 1, 8
+#endif
+#ifndef GE1_T
+#define GE1_T 4, 1, 2, 8
+#endif
+template <int KC, int HIN, int N, int HOUT, int T, int S, int PAD, int KIND, int INKIND, int TF, int MB, int NB, int NW>
+using ConvT = ConvCfg<KC, HIN, N, HOUT, T, S, PAD, KIND, TF, INKIND, 1, MB, NB, NW>;
+using E1F = ConvT<16, 171, 32, 57, 7, 3, 2, CONV_S, IN_LN, E1F_T>;
+using E2F = ConvT<32, 57, 64, 19, 7, 3, 2, CONV_S, IN_LN, E2F_T>;
+using E3F = ConvT<64, 19, 128, 7, 7, 3, 3, CONV_S, IN_LN, E3F_T>;
+using E4F = ConvT<128, 7, 256, 3, 7, 3, 3, CONV_S, IN_LN, E4F_T>;
+using D0F = ConvT<81, 19, 32, 57, 9, 3, 3, CONV_P, IN_PLAIN, D0F_T>;
+using D1F = ConvT<32, 57, 16, 171, 7, 3, 2, CONV_PM, IN_LN, D1F_T>;
+using D2F = ConvT<16, 171, 8, 513, 7, 3, 2, CONV_PM, IN_LN, D2F_T>;
+// input gradients: conv_transpose layers (S-type) and conv layers (transposed kinds)
+using GD2 = ConvT<8, 513, 16, 171, 7, 3, 2, CONV_S, IN_PLAIN, GD2_T>;
+using GD1 = ConvT<16, 171, 32, 57, 7, 3, 2, CONV_S, IN_PLAIN, GD1_T>;
+using GD0 = ConvT<32, 57, 81, 19, 9, 3, 3, CONV_S, IN_PLAIN, GD0_T>;
+using GE4 = ConvT<256, 3, 128, 7, 7, 3, 3, CONV_P, IN_PLAIN, GE4_T>;
+using GE3 = ConvT<128, 7, 64, 19, 7, 3, 3, CONV_P, IN_PLAIN, GE3_T>;
+using GE2 = ConvT<64, 19, 32, 57, 7, 3, 2, CONV_P, IN_PLAIN, GE2_T>;
+using GE1 = ConvT<32, 57, 16, 171, 7, 3, 2, CONV_PM, IN_PLAIN, GE1_T>;
+
 using HeadsF = DenseCfg<768, 256, 256, 2, IN_LN, 3>;
 using HeadsB = DenseCfg<256, 768, 256, 3, IN_CONCAT2, 1>;
 using MergeF = DenseCfg<256, 1539, 256, 2, IN_CONCAT2, 1>;
