@@ -1,7 +1,7 @@
 // gfx950_dense.h -- dense layers (encoder heads, speaker/latent merge) forward and
 // input-gradient:  out[f][n] = bias[n] + sum_k A'[f][k] * B[k][n]
 //
-// One workgroup = 32 frames (one MFMA row tile) x up to 4*NBW column tiles.  A' is staged
+// One workgroup = 32*MB frames (MB MFMA row tiles) x up to 4*NBW column tiles.  A' is staged
 // through LDS in K-chunks of KCH (coalesced HBM reads; LN+lrelu on load, or the
 // [z | E[y]] / [dz_mu | dz_lv] concatenation), B (packed [KP][NP] by gfx950_prep) streams
 // from L2 into the MFMA operand register (128 contiguous bytes per half-wave).  The
@@ -29,15 +29,19 @@ struct DenseArgs {
   int F;
 };
 
-template <int K_, int N_, int KCH_, int NBW_, int INKIND_, int LNDIV_>
+template <int K_, int N_, int KCH_, int NBW_, int INKIND_, int LNDIV_, int MB_ = 2>
 struct DenseCfg {
   static constexpr int K = K_, N = N_, KCH = KCH_, NBW = NBW_, INKIND = INKIND_, LNDIV = LNDIV_;
+  // row tiles (of 32 frames) per workgroup: every weight fragment streamed from L2 feeds MB MFMAs (a CU
+  // sustains only ~10 B/clk of L1 misses; at one 256-byte fragment per MFMA that caps the chip near half
+  // of the fp32-MFMA rate)
+  static constexpr int MB = MB_, ROWS = 32 * MB_;
   static constexpr int NP = rup(N, 32), NT = NP / 32;
   static constexpr int NCHUNK = cdiv(K, KCH);
   static constexpr int KP = NCHUNK * KCH;  // packed B rows (zero padded)
   static constexpr int ASTR = KCH + 1;     // odd -> conflict-free gathers (lane <-> frame)
   static constexpr int NSPLIT = cdiv(NT, 4 * NBW);
-  static constexpr int LDS_BYTES = 32 * ASTR * 4;
+  static constexpr int LDS_BYTES = ROWS * ASTR * 4;
   static_assert(KCH % 64 == 0, "chunk = multiple of the prefetch depth and of the staging batch");
 };
 
@@ -45,18 +49,20 @@ template <class C>
 __global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
   extern __shared__ __attribute__((aligned(16))) float tA[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int f0 = blockIdx.x * 32;
+  const int f0 = blockIdx.x * C::ROWS;
   const int nt0 = (blockIdx.y * 4 + wave) * C::NBW;  // first column tile of this wave
-  f32x16 acc[C::NBW];
+  f32x16 acc[C::MB][C::NBW];
 #pragma unroll
-  for (int nb = 0; nb < C::NBW; ++nb) acc[nb] = zero16();
+  for (int mb = 0; mb < C::MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < C::NBW; ++nb) acc[mb][nb] = zero16();
   const float* ap = tA + l31 * C::ASTR + lh;
   constexpr int U = 8;
   for (int ch = 0; ch < C::NCHUNK; ++ch) {
     const int kc0 = ch * C::KCH;
     __syncthreads();
     constexpr int BT = 8;
-    for (int e0 = tid; e0 < 32 * C::KCH; e0 += 256 * BT) {
+    for (int e0 = tid; e0 < C::ROWS * C::KCH; e0 += 256 * BT) {
       float v[BT];
 #pragma unroll
       for (int b = 0; b < BT; ++b) {
@@ -110,13 +116,17 @@ __global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
           for (int nb = 0; nb < C::NBW; ++nb) b[u][nb] = bp[(c8 * U + u) * 2 * C::NP + ncol[nb]];
       };
       auto compute = [&](const float (&b)[U][C::NBW], int c8) {
-        float av[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) av[u] = ap[(c8 * U + u) * 2];
+        float av[U][C::MB];
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-          for (int nb = 0; nb < C::NBW; ++nb) acc[nb] = mfma32(av[u], b[u][nb], acc[nb]);
+          for (int mb = 0; mb < C::MB; ++mb) av[u][mb] = ap[mb * 32 * C::ASTR + (c8 * U + u) * 2];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int mb = 0; mb < C::MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < C::NBW; ++nb) acc[mb][nb] = mfma32(av[u][mb], b[u][nb], acc[mb][nb]);
       };
       float b0[U][C::NBW], b1[U][C::NBW];
       loadB(b0, 0);
@@ -141,15 +151,17 @@ __global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
     if (nt0 + nb < C::NT && n < C::N) {
       float bb = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        int f = f0 + acc_row(reg, lane);
-        if (f < a.F) {
-          if (a.out2 && n >= a.split)
-            a.out2[(int64_t)f * a.ldo + (n - a.split)] = acc[nb][reg] + bb;
-          else
-            a.out[(int64_t)f * a.ldo + n] = acc[nb][reg] + bb;
+      for (int mb = 0; mb < C::MB; ++mb)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          int f = f0 + mb * 32 + acc_row(reg, lane);
+          if (f < a.F) {
+            if (a.out2 && n >= a.split)
+              a.out2[(int64_t)f * a.ldo + (n - a.split)] = acc[mb][nb][reg] + bb;
+            else
+              a.out[(int64_t)f * a.ldo + n] = acc[mb][nb][reg] + bb;
+          }
         }
-      }
     }
   }
 }
@@ -162,7 +174,7 @@ inline void launch_densegemm(const DenseArgs& a, hipStream_t s) {
                               C::LDS_BYTES);
     once = true;
   }
-  dim3 grid((unsigned)cdiv(a.F, 32), (unsigned)C::NSPLIT);
+  dim3 grid((unsigned)cdiv(a.F, C::ROWS), (unsigned)C::NSPLIT);
   hipLaunchKernelGGL(k_densegemm<C>, grid, dim3(256), C::LDS_BYTES, s, a);
 }
 

@@ -42,7 +42,7 @@ namespace tuned {
 #define E4F_T 21, 2, 1, 8
 #endif
 #ifndef D0F_T
-#define D0F_T 13, 1, 1, 8
+#define D0F_T 13, 2, 1, 8
 #endif
 #ifndef D1F_T
 #define D1F_T 4, 1, 2, 8
@@ -63,10 +63,10 @@ namespace tuned {
 #define GE4_T 16, 1, 2, 8
 #endif
 #ifndef GE3_T
-#define GE3_T 18, 1, 1, 8
+#define GE3_T 18, 2, 1, 8
 #endif
 #ifndef GE2_T
-#define GE2_T 8, 1, 1, 8
+#define GE2_T 13, 2, 1, 8
 #endif
 #ifndef GE1_T
 #define GE1_T 4, 1, 2, 8
@@ -91,7 +91,7 @@ using GE1 = ConvT<32, 57, 16, 171, 7, 3, 2, CONV_PM, IN_PLAIN, GE1_T>;
 
 using HeadsF = DenseCfg<768, 256, 256, 2, IN_LN, 3>;
 using HeadsB = DenseCfg<256, 768, 256, 3, IN_CONCAT2, 1>;
-using MergeF = DenseCfg<256, 1539, 256, 2, IN_CONCAT2, 1>;
+using MergeF = DenseCfg<256, 1539, 256, 2, IN_CONCAT2, 1, 1>;  // K = 256 is one chunk: 32-frame tiles (more workgroups) win
 using MergeB = DenseCfg<1539, 256, 256, 2, IN_PLAIN, 1>;
 //                     XC  XH   YC  YH  T  S PAD  XLN    YLN   TF NTW
 // weight-gradient tilings: trailing parameters = TF (frames per sub-tile), NTW (column tiles per workgroup),
