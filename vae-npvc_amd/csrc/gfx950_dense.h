@@ -61,6 +61,44 @@ __global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
   for (int ch = 0; ch < C::NCHUNK; ++ch) {
     const int kc0 = ch * C::KCH;
     __syncthreads();
+    if constexpr (C::INKIND != IN_LN && C::KCH == 256) {
+      // row-wise staging: one wave per frame row, lane l <-> floats 4l .. 4l+3 of the 256-float chunk (one
+      // 16-byte load per row and lane; rows are only 4-byte aligned).  The row index and the gathered
+      // embedding row are wave-uniform; all loads of a wave's rows are issued before the LDS stores.
+      constexpr int RPW = C::ROWS / 4;  // rows per wave
+      struct __attribute__((packed, aligned(4))) p4 { float x, y, z, w; };
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      p4 v[RPW];
+      const int k = kc0 + 4 * lane;
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const int f = f0 + wv + 4 * r;
+        const int fc = f < a.F ? f : a.F - 1;
+        const float* src;
+        if constexpr (C::INKIND == IN_CONCAT2) {
+          constexpr int HALF = C::K / 2;  // (K == KCH == 256: lanes 0..31 first half, 32..63 second half)
+          const int64_t g = a.idx ? a.idx[fc] : (int64_t)fc;
+          src = lane < 32 ? a.in + (int64_t)fc * HALF + 4 * lane : a.in2 + g * HALF + 4 * (lane - 32);
+        } else {
+          src = a.in + (int64_t)fc * C::K + (k + 3 < C::K ? k : 0);
+        }
+        v[r] = *reinterpret_cast<const p4*>(src);
+      }
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const int fl = wv + 4 * r;
+        const bool okf = f0 + fl < a.F;
+        float x[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+        if constexpr (C::INKIND != IN_CONCAT2) {
+          if (k + 3 >= C::K) {  // last chunk: tail of the row (re-read element-wise, clamped)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = (k + j < C::K && okf) ? a.in[(int64_t)(f0 + fl) * C::K + k + j] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tA[fl * C::ASTR + 4 * lane + j] = okf ? x[j] : 0.f;
+      }
+    } else {
     constexpr int BT = 8;
     for (int e0 = tid; e0 < C::ROWS * C::KCH; e0 += 256 * BT) {
       float v[BT];
@@ -98,6 +136,7 @@ __global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
         }
         tA[fl * C::ASTR + kk] = x;
       }
+    }
     }
     __syncthreads();
     if (nt0 < C::NT) {  // wave-uniform

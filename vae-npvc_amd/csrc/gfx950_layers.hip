@@ -91,7 +91,7 @@ using GE1 = ConvT<32, 57, 16, 171, 7, 3, 2, CONV_PM, IN_PLAIN, GE1_T>;
 
 using HeadsF = DenseCfg<768, 256, 256, 2, IN_LN, 3>;
 using HeadsB = DenseCfg<256, 768, 256, 3, IN_CONCAT2, 1>;
-using MergeF = DenseCfg<256, 1539, 256, 2, IN_CONCAT2, 1, 1>;  // K = 256 is one chunk: 32-frame tiles (more workgroups) win
+using MergeF = DenseCfg<256, 1539, 256, 2, IN_CONCAT2, 1>;
 using MergeB = DenseCfg<1539, 256, 256, 2, IN_PLAIN, 1>;
 //                     XC  XH   YC  YH  T  S PAD  XLN    YLN   TF NTW
 // weight-gradient tilings: trailing parameters = TF (frames per sub-tile), NTW (column tiles per workgroup),
