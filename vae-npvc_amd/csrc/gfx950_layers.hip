@@ -89,10 +89,26 @@ using GE3 = ConvT<128, 7, 64, 19, 7, 3, 3, CONV_P, IN_PLAIN, GE3_T>;
 using GE2 = ConvT<64, 19, 32, 57, 7, 3, 2, CONV_P, IN_PLAIN, GE2_T>;
 using GE1 = ConvT<32, 57, 16, 171, 7, 3, 2, CONV_PM, IN_PLAIN, GE1_T>;
 
+// small-batch tilings (F < SMALL_BATCH_FRAMES): fewer frames per tile = more workgroups; the packed weights
+// do not depend on the tiling, so both variants of a layer read the same copy
+constexpr int64_t SMALL_BATCH_FRAMES = 2048;
+using E3Fs = ConvT<64, 19, 128, 7, 7, 3, 3, CONV_S, IN_LN, 9, 1, 1, 8>;
+using D0Fs = ConvT<81, 19, 32, 57, 9, 3, 3, CONV_P, IN_PLAIN, 8, 1, 1, 8>;
+using GD0s = ConvT<32, 57, 81, 19, 9, 3, 3, CONV_S, IN_PLAIN, 8, 1, 1, 8>;
+using GE3s = ConvT<128, 7, 64, 19, 7, 3, 3, CONV_P, IN_PLAIN, 18, 1, 1, 8>;
+using GE2s = ConvT<64, 19, 32, 57, 7, 3, 2, CONV_P, IN_PLAIN, 8, 1, 1, 8>;
+static_assert(E3Fs::BTOTAL == E3F::BTOTAL && D0Fs::BTOTAL == D0F::BTOTAL && GD0s::BTOTAL == GD0::BTOTAL &&
+                  GE3s::BTOTAL == GE3::BTOTAL && GE2s::BTOTAL == GE2::BTOTAL,
+              "both tilings of a layer share one packed weight copy");
+
 using HeadsF = DenseCfg<768, 256, 256, 2, IN_LN, 3>;
 using HeadsB = DenseCfg<256, 768, 256, 3, IN_CONCAT2, 1>;
 using MergeF = DenseCfg<256, 1539, 256, 2, IN_CONCAT2, 1>;
 using MergeB = DenseCfg<1539, 256, 256, 2, IN_PLAIN, 1>;
+using HeadsFs = DenseCfg<768, 256, 256, 2, IN_LN, 3, 1>;
+using HeadsBs = DenseCfg<256, 768, 256, 3, IN_CONCAT2, 1, 1>;
+using MergeFs = DenseCfg<256, 1539, 256, 2, IN_CONCAT2, 1, 1>;
+using MergeBs = DenseCfg<1539, 256, 256, 2, IN_PLAIN, 1, 1>;
 //                     XC  XH   YC  YH  T  S PAD  XLN    YLN   TF NTW
 // weight-gradient tilings: trailing parameters = TF (frames per sub-tile), NTW (column tiles per workgroup),
 // NWV (waves), WM (waves along M, 0 = auto), WPE (waves per SIMD the register budget must allow);
@@ -288,7 +304,7 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
     stats<1216>(w.enc_a[2], w.enc_st[2], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 2);
   if (fwd_on(3)) {
-    VAENPVC_TIMED("enc3_fwd", s, launch_convgemm<E3F>(lnp(3), nsplit_for<E3F>(F), s));
+    VAENPVC_TIMED("enc3_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<E3Fs>(lnp(3), nsplit_for<E3Fs>(F), s) : launch_convgemm<E3F>(lnp(3), nsplit_for<E3F>(F), s)));
     stats<896>(w.enc_a[3], w.enc_st[3], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 3);
   if (fwd_on(4)) {
@@ -300,7 +316,7 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
                 w.scratch + Pk::heads_f, nullptr, w.z_mu, w.z_lv, 128, 128, F};
     // the two biases live in separate tensors: add them through the split as well
     a.bias = nullptr;
-    VAENPVC_TIMED("heads_fwd", s, launch_densegemm<HeadsF>(a, s));
+    VAENPVC_TIMED("heads_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<HeadsFs>(a, s) : launch_densegemm<HeadsF>(a, s)));
     // bias add (tiny): z_mu += b_mu ; z_lv += b_lv
     int64_t n = (int64_t)F * m.z;
     hipLaunchKernelGGL(k_add_bias, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.z_mu, P + m.bmu_off, n, m.z);
@@ -316,11 +332,12 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
   if (fwd_on(6)) {
     DenseArgs a{z, P + m.emb_off, y, nullptr, nullptr, nullptr, w.scratch + Pk::merge_f, w.scratch + Pk::merge_bias,
                 w.h, nullptr, 0, m.merge, F};
-    VAENPVC_TIMED("merge_fwd", s, launch_densegemm<MergeF>(a, s));
+    VAENPVC_TIMED("merge_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<MergeFs>(a, s) : launch_densegemm<MergeF>(a, s)));
   } else generic::merge_fwd(m, P, z, y, F, w, s);
   if (fwd_on(7)) {
-    VAENPVC_TIMED("dec0_fwd", s, launch_convgemm<D0F>(conv_args(w.h, nullptr, nullptr, nullptr, w.scratch + Pk::d0f,
-                                                                P + m.dec[0].b_off, w.dec_a[0], F), nsplit_for<D0F>(F), s));
+    VAENPVC_TIMED("dec0_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<D0Fs>(conv_args(w.h, nullptr, nullptr, nullptr, w.scratch + Pk::d0f,
+                                                                P + m.dec[0].b_off, w.dec_a[0], F), nsplit_for<D0Fs>(F), s) : launch_convgemm<D0F>(conv_args(w.h, nullptr, nullptr, nullptr, w.scratch + Pk::d0f,
+                                                                P + m.dec[0].b_off, w.dec_a[0], F), nsplit_for<D0F>(F), s)));
     stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 0);
   if (fwd_on(8)) {
@@ -539,8 +556,9 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     ready();
     VAENPVC_TIMED("dec0_wgrad", s2, launch_convwgrad<WD0>(a, WGS, s2));
     if (!dec_bias_done[0]) generic::bias_grad(w.d_dec_a[0], G + l.b_off, F, l.cout, l.hout, s);
-    VAENPVC_TIMED("dec0_dgrad", s, launch_convgemm<GD0>(conv_args(w.d_dec_a[0], nullptr, nullptr, nullptr, w.scratch + Pk::gd0,
-                                                                  nullptr, w.d_h, F), nsplit_for<GD0>(F), s));
+    VAENPVC_TIMED("dec0_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<GD0s>(conv_args(w.d_dec_a[0], nullptr, nullptr, nullptr, w.scratch + Pk::gd0,
+                                                                  nullptr, w.d_h, F), nsplit_for<GD0s>(F), s) : launch_convgemm<GD0>(conv_args(w.d_dec_a[0], nullptr, nullptr, nullptr, w.scratch + Pk::gd0,
+                                                                  nullptr, w.d_h, F), nsplit_for<GD0>(F), s)));
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 0);
 
   // ---- merge + embedding
@@ -556,7 +574,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
                        F, fc, G + m.bz_off, G + m.by_off, G + m.bm_off);
     DenseArgs d{w.d_h, nullptr, nullptr, nullptr, nullptr, nullptr, w.scratch + Pk::merge_b, nullptr,
                 w.d_z, w.d_e, 128, 128, F};
-    VAENPVC_TIMED("merge_dgrad", s, launch_densegemm<MergeB>(d, s));
+    VAENPVC_TIMED("merge_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<MergeBs>(d, s) : launch_densegemm<MergeB>(d, s)));
     int ech = cmax(1, cmin_(cdiv(F, 32), 256)), efc = cdiv(F, ech);
     hipLaunchKernelGGL(k_emb_grad_fast, dim3((unsigned)cdiv(F, efc)), dim3(256), (size_t)m.ny * m.z * 4, s, w.d_e, 128, 0, y,
                        G + m.emb_off, F, efc, m.z, m.ny);
@@ -584,7 +602,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
                        G + m.blv_off, nullptr, nullptr);
     DenseArgs d{w.d_z_mu, w.d_z_lv, nullptr, nullptr, nullptr, nullptr, w.scratch + Pk::heads_b, nullptr,
                 w.dy_tmp, nullptr, 0, 768, F};
-    VAENPVC_TIMED("heads_dgrad", s, launch_densegemm<HeadsB>(d, s));
+    VAENPVC_TIMED("heads_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<HeadsBs>(d, s) : launch_densegemm<HeadsB>(d, s)));
     launch_ln_bwd<LnbCfg<256, 3>>(w.dy_tmp, w.enc_a[4], w.enc_st[4], P + l4.gamma_off, P + l4.beta_off, w.d_enc_a[4],
                                      G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     enc_bias_done[4] = true;
@@ -612,8 +630,9 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     ready();
     VAENPVC_TIMED("enc3_wgrad", s2, launch_convwgrad<WE3>(wg_enc(3), WGS, s2));
     if (!enc_bias_done[3]) generic::bias_grad(w.d_enc_a[3], G + l.b_off, F, l.cout, l.hout, s);
-    VAENPVC_TIMED("enc3_dgrad", s, launch_convgemm<GE3>(conv_args(w.d_enc_a[3], nullptr, nullptr, nullptr, w.scratch + Pk::ge3,
-                                                                  nullptr, w.dy_tmp, F), nsplit_for<GE3>(F), s));
+    VAENPVC_TIMED("enc3_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<GE3s>(conv_args(w.d_enc_a[3], nullptr, nullptr, nullptr, w.scratch + Pk::ge3,
+                                                                  nullptr, w.dy_tmp, F), nsplit_for<GE3s>(F), s) : launch_convgemm<GE3>(conv_args(w.d_enc_a[3], nullptr, nullptr, nullptr, w.scratch + Pk::ge3,
+                                                                  nullptr, w.dy_tmp, F), nsplit_for<GE3>(F), s)));
     launch_ln_bwd<LnbCfg<64, 19>>(w.dy_tmp, w.enc_a[2], w.enc_st[2], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[2],
                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     enc_bias_done[2] = true;
@@ -623,8 +642,9 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     ready();
     VAENPVC_TIMED("enc2_wgrad", s2, launch_convwgrad<WE2>(wg_enc(2), WGS, s2));
     if (!enc_bias_done[2]) generic::bias_grad(w.d_enc_a[2], G + l.b_off, F, l.cout, l.hout, s);
-    VAENPVC_TIMED("enc2_dgrad", s, launch_convgemm<GE2>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
-                                                                  nullptr, w.dy_tmp, F), nsplit_for<GE2>(F), s));
+    VAENPVC_TIMED("enc2_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<GE2s>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
+                                                                  nullptr, w.dy_tmp, F), nsplit_for<GE2s>(F), s) : launch_convgemm<GE2>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
+                                                                  nullptr, w.dy_tmp, F), nsplit_for<GE2>(F), s)));
     launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.enc_a[1], w.enc_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[1],
                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     enc_bias_done[1] = true;
