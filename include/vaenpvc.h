@@ -155,7 +155,11 @@ int vaenpvc_unpack_records(const float* d_records, int64_t F, int32_t rec_floats
  * gfx950 kernel (bit set) and the geometry-generic kernel (bit clear) when the context
  * runs in VAENPVC_IMPL_AUTO on the VCC2016 geometry.  Bits 0..4 = encoder conv i,
  * 5 = heads, 6 = merge, 7..10 = decoder layer i; one mask for forward steps, one for
- * backward steps.  Default: all ones.  Process-global. */
+ * backward steps.  Default: all ones.  Process-global.
+ * Bit 30 of the forward mask (default set): cleared = use the bf16-split kernels of the last decoder layer at
+ * any batch size (they are selected at >= 8192 frames otherwise; parity tests).  Bit 30 of the backward mask
+ * (default set): cleared = launch the weight-gradient kernels on the caller's stream instead of the internal
+ * side stream (serialised kernels; used by bench.py to time single kernels). */
 int vaenpvc_set_tuned_masks(uint32_t fwd_mask, uint32_t bwd_mask);
 
 /* Measurement hook (no reference counterpart): brackets every launch of ONE tagged
