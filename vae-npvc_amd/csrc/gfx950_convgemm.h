@@ -161,7 +161,12 @@ __device__ __forceinline__ void conv_items(const ConvArgs& a, const float* tile,
   const int it1 = C::mblk(0) * nblks;
   const int it2 = it1 + (C::NPH > 1 ? C::mblk(1) * nblks : 0);
   const int items = it2 + (C::NPH > 2 ? C::mblk(2) * nblks : 0);
-  for (int it = wave; it < items; it += C::NW) {
+  // items are dealt to the waves in boustrophedon order (round 0: waves 0..7, round 1: waves 7..0, ...): the
+  // phases of a transposed conv have different tap counts (3/2/2), and a plain round-robin gives the waves
+  // that drew the heavy first-phase items a second item while others hold one light one
+  for (int it0 = 0, rnd = 0; it0 < items; it0 += C::NW, ++rnd) {
+    const int it = it0 + ((rnd & 1) ? C::NW - 1 - wave : wave);
+    if (it >= items) continue;
     PROF_T(p0);
     // ---- phase parameters (wave-uniform)
     int ph = 0, local = it;

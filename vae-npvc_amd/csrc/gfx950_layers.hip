@@ -60,7 +60,7 @@ namespace tuned {
 #define GD0_T 13, 1, 1, 8
 #endif
 #ifndef GE4_T
-#define GE4_T 16, 1, 2, 8
+#define GE4_T 16, 1, 1, 8
 #endif
 #ifndef GE3_T
 #define GE3_T 18, 2, 1, 8
