@@ -11,6 +11,7 @@ namespace vaenpvc {
 namespace tuned {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define LN_EPS 1e-5f
 #define LEAK 0.02f

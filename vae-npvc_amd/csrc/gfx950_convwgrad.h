@@ -36,13 +36,17 @@ inline int g_wg_prof_next = 0;
 constexpr int odd_up(int v) { return v | 1; }
 
 template <int XC_, int XH_, int YC_, int YH_, int T_, int S_, int PAD_, bool XLN_, bool YLN_, int TF_, int NTW_,
-          int NWV_ = 4, int WM_ = 0, int WPE_ = 2>
+          int NWV_ = 4, int WM_ = 0, int WPE_ = 2, bool T16_ = false>
 struct WgCfg {
   static constexpr int WPE = WPE_;  // waves per SIMD the register allocation must allow
+  // T16: 16x16x4 MFMA tiles (v_mfma_f32_16x16x4_f32, same MAC rate) for layers with <= 16 output channels
+  // or very few (tap, channel) rows: a 32-wide tile would be half / three quarters padding.  k = 4 =
+  // two frames x two consecutive positions.
+  static constexpr bool T16 = T16_;
   static constexpr int XC = XC_, XH = XH_, YC = YC_, YH = YH_, T = T_, S = S_, PAD = PAD_, TF = TF_, NTW = NTW_;
   static constexpr bool XLN = XLN_, YLN = YLN_;
   static constexpr int NWV = NWV_, NTHR = NWV_ * 64;
-  static constexpr int M = T * XC, MTL = cdiv(M, 32);
+  static constexpr int M = T * XC, MTL = cdiv(M, T16_ ? 16 : 32);
   static constexpr int NTL = cdiv(YC, 32), NSPLIT = cdiv(NTL, NTW);
   // waves = WM (split of the M tiles) x WK (split of the k-steps)
   static constexpr int WM = WM_ > 0 ? WM_ : (MTL >= 4 ? 4 : (MTL >= 2 ? 2 : 1));
@@ -93,24 +97,35 @@ __global__ void __launch_bounds__(C::NTHR, C::WPE) k_convwgrad(WgArgs a) {
   const int nc0 = blockIdx.y * C::NTW * 32;              // first Y channel of this workgroup
   const int ych = min(C::NTW * 32, C::YC - nc0);         // valid Y channels
   for (int i = tid; i < (C::XT + C::YT) / 4; i += C::NTHR) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int TS = C::T16 ? 16 : 32;                       // tile edge
+  constexpr int NTS = C::T16 ? cdiv(cmin_(C::YC, C::NTW * 32), 16) : C::NTW;  // column tiles per workgroup
+  const int lt = C::T16 ? (lane & 15) : l31;                 // lane's row / column inside a tile
+  const int g = lane >> 4;                                   // T16: k-group = (frame g&1, position +(g>>1))
   int baseA[C::MTW];
   bool aok[C::MTW];
 #pragma unroll
   for (int i = 0; i < C::MTW; ++i) {
-    int m = (wm + i * C::WM) * 32 + l31;
+    int m = (wm + i * C::WM) * TS + lt;
     aok[i] = m < C::M;
     int mm = aok[i] ? m : 0;
     int t = mm / C::XC, xc = mm - t * C::XC;
-    baseA[i] = lh * C::FSTRX + xc * C::CSTRX + C::HLO - C::PAD + t;
+    baseA[i] = C::T16 ? (g & 1) * C::FSTRX + xc * C::CSTRX + C::HLO - C::PAD + t + C::S * (g >> 1)
+                      : lh * C::FSTRX + xc * C::CSTRX + C::HLO - C::PAD + t;
   }
-  int baseB[C::NTW];
+  int baseB[NTS];
 #pragma unroll
-  for (int j = 0; j < C::NTW; ++j) baseB[j] = lh * C::FSTRY + (j * 32 + l31) * C::CSTRY;
-  f32x16 acc[C::MTW][C::NTW];
+  for (int j = 0; j < NTS; ++j)
+    baseB[j] = C::T16 ? (g & 1) * C::FSTRY + (j * 16 + lt) * C::CSTRY + (g >> 1) : lh * C::FSTRY + (j * 32 + l31) * C::CSTRY;
+  f32x16 acc[C::T16 ? 1 : C::MTW][C::T16 ? 1 : C::NTW];
+  f32x4 acc4[C::T16 ? C::MTW : 1][C::T16 ? NTS : 1];
 #pragma unroll
-  for (int i = 0; i < C::MTW; ++i)
+  for (int i = 0; i < (C::T16 ? 1 : C::MTW); ++i)
 #pragma unroll
-    for (int j = 0; j < C::NTW; ++j) acc[i][j] = zero16();
+    for (int j = 0; j < (C::T16 ? 1 : C::NTW); ++j) acc[i][j] = zero16();
+#pragma unroll
+  for (int i = 0; i < (C::T16 ? C::MTW : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < (C::T16 ? NTS : 1); ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fb = blockIdx.x * a.fchunk;
   const int fe = min(a.F, fb + a.fchunk);
@@ -144,6 +159,40 @@ __global__ void __launch_bounds__(C::NTHR, C::WPE) k_convwgrad(WgArgs a) {
 #if VAENPVC_WABL == 1
     if (a.F < 0)
 #endif
+    if constexpr (C::T16) {
+      // position PAIRS (2*rp, 2*rp+1) x frame pairs; RU16 pairs per trip
+      constexpr int NRP = cdiv(C::YH, 2), RU16 = 4;
+      for (int rp0 = wk * RU16; rp0 < NRP; rp0 += C::WK * RU16) {
+        float av[RU16][C::HP][C::MTW], bv[RU16][C::HP][NTS];
+#pragma unroll
+        for (int u = 0; u < RU16; ++u) {
+          const int rp = rp0 + u < NRP ? rp0 + u : NRP - 1;
+          const bool rok = rp0 + u < NRP && 2 * rp + (g >> 1) < C::YH;  // (odd YH: the last pair has one position)
+#pragma unroll
+          for (int fp = 0; fp < C::HP; ++fp) {
+#pragma unroll
+            for (int i = 0; i < C::MTW; ++i) {
+              float v = tX[baseA[i] + C::S * 2 * rp + fp * 2 * C::FSTRX];
+              av[u][fp][i] = aok[i] ? v : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < NTS; ++j) {
+              float v = tY[baseB[j] + 2 * rp + fp * 2 * C::FSTRY];
+              bv[u][fp][j] = rok ? v : 0.f;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < RU16; ++u)
+#pragma unroll
+          for (int fp = 0; fp < C::HP; ++fp)
+#pragma unroll
+            for (int i = 0; i < C::MTW; ++i)
+#pragma unroll
+              for (int j = 0; j < NTS; ++j)
+                acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][fp][i], bv[u][fp][j], acc4[i][j], 0, 0, 0);
+      }
+    } else
     for (int r0 = wk * C::RU; r0 < C::YH; r0 += C::WK * C::RU) {
       float av[C::RU][C::HP][C::MTW], bv[C::RU][C::HP][C::NTW];
 #pragma unroll
@@ -204,6 +253,19 @@ __global__ void __launch_bounds__(C::NTHR, C::WPE) k_convwgrad(WgArgs a) {
 #endif
   }
   WPROF_T(k1);
+  if constexpr (C::T16) {
+    // 16x16 accumulator: column = lane & 15, row = 4*(lane >> 4) + reg
+#pragma unroll
+    for (int i = 0; i < C::MTW; ++i)
+#pragma unroll
+      for (int j = 0; j < NTS; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          int m = (wm + i * C::WM) * 16 + 4 * g + reg;
+          int n = nc0 + j * 16 + lt;
+          if (m < C::M && n < C::YC) atomicAdd(a.dW + (int64_t)m * C::YC + n, acc4[i][j][reg]);
+        }
+  } else {
 #pragma unroll
   for (int i = 0; i < C::MTW; ++i)
 #pragma unroll
@@ -214,6 +276,7 @@ __global__ void __launch_bounds__(C::NTHR, C::WPE) k_convwgrad(WgArgs a) {
         int n = nc0 + j * 32 + l31;
         if (m < C::M && n < C::YC) atomicAdd(a.dW + (int64_t)m * C::YC + n, acc[i][j][reg]);
       }
+  }
 #if VAENPVC_PROF
   {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

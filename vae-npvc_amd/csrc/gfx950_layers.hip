@@ -114,7 +114,7 @@ using MergeBs = DenseCfg<1539, 256, 256, 2, IN_PLAIN, 1, 1>;
 // NWV (waves), WM (waves along M, 0 = auto), WPE (waves per SIMD the register budget must allow);
 // overridable per layer for tuning sweeps (scripts/build_variant.sh NAME "-DWD2_T=4,1,4,0,2")
 #ifndef WD2_T
-#define WD2_T 2, 1, 4, 0, 2
+#define WD2_T 2, 1, 4, 2, 2, true
 #endif
 #ifndef WD1_T
 #define WD1_T 4, 1, 8, 0, 2
@@ -135,7 +135,7 @@ using MergeBs = DenseCfg<1539, 256, 256, 2, IN_PLAIN, 1, 1>;
 #define WE1_T 4, 1, 8, 0, 2
 #endif
 #ifndef WE0_T
-#define WE0_T 2, 1, 4, 0, 2
+#define WE0_T 2, 1, 4, 1, 2, true
 #endif
 using WD2 = WgCfg<8, 513, 16, 171, 7, 3, 2, false, true, WD2_T>;
 using WD1 = WgCfg<16, 171, 32, 57, 7, 3, 2, false, true, WD1_T>;
