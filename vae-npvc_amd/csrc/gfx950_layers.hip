@@ -452,11 +452,12 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   const bool fork = g_side.init() && ((g_bwd_mask >> 30) & 1u);
   hipStream_t s2 = fork ? g_side.s2 : s;   // weight-gradient stream
   auto ready = [&]() { if (fork) stream_dep(s, s2); };   // "the tensors produced so far on s are ready for s2"
-  // three bf16 planes of d(xh): operand of the bf16 input-gradient AND weight-gradient kernels of the last layer
+  // one pass over d(xh) for the bf16 kernels of the last layer: its three planes (operand of the input-gradient
+  // and weight-gradient GEMMs), column 512 of the input gradient, the bias gradient
   const bool toep_planes = bwd_on(10) && toep_bf16_for(F);
   if (toep_planes)
-    hipLaunchKernelGGL(k_split3_rows, dim3((unsigned)((F * TB_KP + 255) / 256)), dim3(256), 0, s, w.d_xh,
-                       reinterpret_cast<unsigned short*>(w.toep_gp), (int64_t)F);
+    hipLaunchKernelGGL(k_dxh_post, dim3((unsigned)cmin_(2048, cdiv((int)F, 4))), dim3(256), 0, s, w.d_xh, P + m.dec[3].w_off,
+                       reinterpret_cast<unsigned short*>(w.toep_gp), w.dy_tmp, G + m.dec[3].b_off, (int)F);
   ready();
   bool dec_bias_done[4] = {false, false, false, false};
   bool enc_bias_done[5] = {false, false, false, false, false};
@@ -468,7 +469,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   if (bwd_on(10)) {
     const ConvL& l2 = m.dec[2];
     if (toep_wgrad_bf16_for(F)) {
-      // bf16 planes of both operands exist (forward producer, k_split3_rows above)
+      // bf16 planes of both operands exist (forward producer, k_dxh_post above)
       static bool once3 = false;
       if (!once3) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_wgrad_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS);
@@ -486,8 +487,9 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     int ech = cmax(1, cmin_(cdiv(F, 64), 128));
     int efc = rup(cdiv(F, ech), 64);
     hipLaunchKernelGGL(k_toep_wgrad_row512, dim3((unsigned)cdiv(F, efc), 3), dim3(256), 0, s2, w.dec_y, w.d_xh, G + m.dec[3].w_off, F, efc);
-    hipLaunchKernelGGL(k_sum_all_atomic, dim3((unsigned)cmin_(1024, cdiv(F * 513, 1024))), dim3(256), 0, s2, w.d_xh,
-                       (int64_t)F * 513, G + m.dec[3].b_off);
+    if (!toep_planes)  // (k_dxh_post computed it)
+      hipLaunchKernelGGL(k_sum_all_atomic, dim3((unsigned)cmin_(1024, cdiv(F * 513, 1024))), dim3(256), 0, s2, w.d_xh,
+                         (int64_t)F * 513, G + m.dec[3].b_off);
     static bool once = false;
     if (!once) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_dgrad<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS);
@@ -501,11 +503,9 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
         once2 = true;
       }
       unsigned short* gp = reinterpret_cast<unsigned short*>(w.toep_gp);
-      VAENPVC_TIMED("dec3_dgrad", s, {
-        hipLaunchKernelGGL(k_toep_gemm_bf16<false>, dim3((unsigned)cdiv(F, DG_M)), dim3(256), DG_LDS, s, gp,
-                           reinterpret_cast<const unsigned short*>(w.scratch + Pk::wdg), (const float*)nullptr, w.dy_tmp, (int)F);
-        hipLaunchKernelGGL(k_toep_dgrad_edge, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.d_xh, P + m.dec[3].w_off, w.dy_tmp, (int)F);
-      });
+      VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL(k_toep_gemm_bf16<false>, dim3((unsigned)cdiv(F, DG_M)), dim3(256), DG_LDS, s, gp,
+                                                        reinterpret_cast<const unsigned short*>(w.scratch + Pk::wdg), (const float*)nullptr,
+                                                        w.dy_tmp, (int)F));  // (column 512: k_dxh_post)
     } else
     if (F >= 8192) {
       VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL((k_toep_dgrad<8, 8>), dim3((unsigned)cdiv(F, 32), 1), dim3(512), TD_LDS, s, w.d_xh,

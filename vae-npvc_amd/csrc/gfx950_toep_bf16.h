@@ -70,19 +70,84 @@ constexpr int TB_CPYB = TB_CHUNKS * 16;                       // bytes per copy
 constexpr int TB_WCH = 3 * TB_CPY * TB_CPYB;                  // bytes of one channel's copies (3 planes)
 constexpr int TB_WFLOATS = TB_C * TB_WCH / 4;                 // floats of the packed block (all channels)
 
-// ---- rows of fp32 -> three bf16 planes, zero padded to TB_KP:  dst[f][plane][TB_KP]
-__global__ void __launch_bounds__(256) k_split3_rows(const float* __restrict__ src, unsigned short* __restrict__ dst,
-                                                     int64_t rows) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= rows * TB_KP) return;
-  int64_t f = i / TB_KP;
-  int k = (int)(i - f * TB_KP);
-  unsigned h = 0, m = 0, l = 0;
-  if (k < TB_H) split3(src[f * TB_H + k], h, m, l);
-  unsigned short* d = dst + f * 3 * TB_KP + k;
-  d[0] = (unsigned short)h;
-  d[TB_KP] = (unsigned short)m;
-  d[2 * TB_KP] = (unsigned short)l;
+// ---- ONE pass over d(xh) [F][513] for everything the last layer's backward needs from it besides the GEMMs:
+//      (1) the three bf16 planes dst[f][plane][528], (2) column i = 512 of the input gradient
+//      dY[f][c][512] = sum_p G[f][p] * W[p][c], (3) the bias gradient sum_f sum_p G[f][p] (one atomic per
+//      workgroup).  One wave per frame, lane l owns bins 8l .. 8l+7 (lane 0 also bin 512); waves walk the frames
+//      with a grid stride.
+__global__ void __launch_bounds__(256) k_dxh_post(const float* __restrict__ G, const float* __restrict__ W,
+                                                  unsigned short* __restrict__ dst, float* __restrict__ dY,
+                                                  float* __restrict__ dbias, int F) {
+  __shared__ float sm[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // taps of this lane's 8 bins, all 8 channels: W[(8l + j)*8 + c], 64 contiguous floats
+  float wt[8][TB_C];
+  {
+    const float* wp = W + (size_t)lane * 64;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int c = 0; c < TB_C; ++c) wt[j][c] = wp[j * TB_C + c];
+  }
+  float wl[TB_C];  // bin 512 (lane 0)
+#pragma unroll
+  for (int c = 0; c < TB_C; ++c) wl[c] = W[512 * TB_C + c];
+  float bsum = 0.f;
+  for (int f = blockIdx.x * 4 + wv; f < F; f += gridDim.x * 4) {
+    const float* gf = G + (int64_t)f * TB_H;
+    packed4 p0 = *reinterpret_cast<const packed4*>(gf + 8 * lane);
+    packed4 p1 = *reinterpret_cast<const packed4*>(gf + 8 * lane + 4);
+    const float g[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    const float gt = lane == 0 ? gf[512] : 0.f;
+    unsigned h[8], m[8], l[8];
+    float dot[TB_C];
+#pragma unroll
+    for (int c = 0; c < TB_C; ++c) dot[c] = gt * wl[c];
+    float sfr = gt;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      split3(g[j], h[j], m[j], l[j]);
+      sfr += g[j];
+#pragma unroll
+      for (int c = 0; c < TB_C; ++c) dot[c] += g[j] * wt[j][c];
+    }
+    bsum += sfr;
+    u32x4 ph, pm, pl;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ph[k] = h[2 * k] | (h[2 * k + 1] << 16);
+      pm[k] = m[2 * k] | (m[2 * k + 1] << 16);
+      pl[k] = l[2 * k] | (l[2 * k + 1] << 16);
+    }
+    unsigned short* d = dst + (int64_t)f * (3 * TB_KP);
+    *reinterpret_cast<u32x4*>(d + 8 * lane) = ph;
+    *reinterpret_cast<u32x4*>(d + TB_KP + 8 * lane) = pm;
+    *reinterpret_cast<u32x4*>(d + 2 * TB_KP + 8 * lane) = pl;
+    if (lane == 0) {  // bin 512 and the zero padding 513..527
+      unsigned th, tm, tl;
+      split3(gt, th, tm, tl);
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      u32x4 t = z;
+      t[0] = th;
+      *reinterpret_cast<u32x4*>(d + 512) = t;
+      *reinterpret_cast<u32x4*>(d + 520) = z;
+      t[0] = tm;
+      *reinterpret_cast<u32x4*>(d + TB_KP + 512) = t;
+      *reinterpret_cast<u32x4*>(d + TB_KP + 520) = z;
+      t[0] = tl;
+      *reinterpret_cast<u32x4*>(d + 2 * TB_KP + 512) = t;
+      *reinterpret_cast<u32x4*>(d + 2 * TB_KP + 520) = z;
+    }
+#pragma unroll
+    for (int c = 0; c < TB_C; ++c) {
+      float v = wave_sum(dot[c]);
+      if (lane == 0) dY[((int64_t)f * TB_C + c) * TB_H + 512] = v;
+    }
+  }
+  bsum = wave_sum(bsum);
+  if (lane == 0) sm[wv] = bsum;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dbias, (sm[0] + sm[1]) + (sm[2] + sm[3]));
 }
 
 // ---- shifted bf16 copies of the tap rows: dst[c][plane][s][m] = plane(w[c][m + s]), m < 8*TB_CHUNKS.
@@ -121,7 +186,7 @@ __global__ void __launch_bounds__(256) k_pack_toep_bf16(const float* __restrict_
   d[2 * TB_CPY * PER] = (unsigned short)l;
 }
 
-// ---- input gradient:  dY[f][c][i] = sum_p G[f][p] * W[p - i + 512][c]   (i < 512; column 512: k_toep_dgrad_edge)
+// ---- input gradient:  dY[f][c][i] = sum_p G[f][p] * W[p - i + 512][c]   (i < 512; column 512: k_dxh_post)
 //
 // Workgroup = 64 frames x all 512 bins of every channel (channels in sequence); 4 waves, wave w owns
 // bins [128w, 128w+128) = 4 column tiles, both row tiles => 8 accumulators.  The reduction index p
@@ -431,27 +496,6 @@ __global__ void __launch_bounds__(256) k_ln_stats_act_planes(const float* __rest
   }
   dot = wave_sum(dot);
   if (lane == 0) xh[(int64_t)f * TB_H + 512] = dot + bias[0];
-}
-
-// column i = 512 of the input gradient: dY[f][c][512] = sum_p G[f][p] * W[p][c]; one wave per frame.
-__global__ void __launch_bounds__(256) k_toep_dgrad_edge(const float* __restrict__ G, const float* __restrict__ W,
-                                                         float* __restrict__ dY, int F) {
-  const int lane = threadIdx.x & 63;
-  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (f >= F) return;
-  float s[TB_C];
-#pragma unroll
-  for (int c = 0; c < TB_C; ++c) s[c] = 0.f;
-  for (int p = lane; p < TB_H; p += 64) {
-    float g = G[(int64_t)f * TB_H + p];
-#pragma unroll
-    for (int c = 0; c < TB_C; ++c) s[c] += g * W[p * TB_C + c];
-  }
-#pragma unroll
-  for (int c = 0; c < TB_C; ++c) {
-    float v = wave_sum(s[c]);
-    if (lane == 0) dY[((int64_t)f * TB_C + c) * TB_H + 512] = v;
-  }
 }
 
 // ---- weight gradient:  dW[t][c] = sum_f sum_i y[f][c][i] * G[f][i + t - 512]
