@@ -389,6 +389,47 @@ __global__ void __launch_bounds__(256) k_reparam_bwd_ld(const float* __restrict_
   dzlv[i] = g * (0.5f * eps[i] * sqrtf(v)) + 0.5f * (v / (1.0f + EPSILON) - 1.0f) * invF;
 }
 
+// Same arithmetic, fused with the bias gradients of the two heads (column sums of dz_mu / dz_lv): one
+// workgroup owns RF frames; thread -> (column k = tid & 127, frame phase tid >> 7); the two phases are
+// combined in LDS and every workgroup issues 2 x 128 atomics.  Replaces one element-wise kernel and two
+// column-sum kernels.
+__global__ void __launch_bounds__(256) k_reparam_bwd_colsum(const float* __restrict__ dz, const float* __restrict__ zmu,
+                                                            const float* __restrict__ zlv, const float* __restrict__ eps,
+                                                            float* __restrict__ dzmu, float* __restrict__ dzlv,
+                                                            float* __restrict__ gbmu, float* __restrict__ gblv, int F,
+                                                            int fchunk, float invF) {
+  __shared__ float sm[2][128];
+  const int k = threadIdx.x & 127, ph = threadIdx.x >> 7;
+  const int fb = blockIdx.x * fchunk, fe = min(F, fb + fchunk);
+  float smu = 0.f, slv = 0.f;
+  for (int f = fb + ph; f < fe; f += 2) {
+    const int64_t i = (int64_t)f * 128 + k;
+    float mu = zmu[i], lv = zlv[i], v = expf(lv), g = dz[i];
+    float a = g + mu / (1.0f + EPSILON) * invF;
+    float b = g * (0.5f * eps[i] * sqrtf(v)) + 0.5f * (v / (1.0f + EPSILON) - 1.0f) * invF;
+    dzmu[i] = a;
+    dzlv[i] = b;
+    smu += a;
+    slv += b;
+  }
+  if (ph == 1) {
+    sm[0][k] = smu;
+    sm[1][k] = slv;
+  }
+  __syncthreads();
+  if (ph == 0) {
+    atomicAdd(gbmu + k, smu + sm[0][k]);
+    atomicAdd(gblv + k, slv + sm[1][k]);
+  }
+}
+
+// [a | b] concatenation (two bias vectors of the encoder heads -> one bias row of the fused dense layer)
+struct PackCat2 {
+  const float *a, *b;
+  int n;
+  __device__ float operator()(int i) const { return i < n ? a[i] : b[i - n]; }
+};
+
 // ---------------------------------------------------------------- weight packing
 template <class Fn>
 __global__ void __launch_bounds__(256) k_pack(Fn fn, float* __restrict__ dst, int count) {

@@ -166,7 +166,8 @@ struct Pk {
   static constexpr int lnpart = wc + TOEP_C * WROW;  // [LWGS][3][C] partial sums of the LN backward
   static constexpr int wdg = lnpart + 2048 * 3 * 256;  // bf16 tap copies, input-gradient direction
   static constexpr int wfw = wdg + TB_WFLOATS;  // bf16 tap copies, forward direction (reversed)
-  static constexpr int total = wfw + TB_WFLOATS;
+  static constexpr int heads_bias = wfw + TB_WFLOATS;  // [b_mu | b_lv]
+  static constexpr int total = heads_bias + 256;
 };
 static_assert(Pk::total <= 4 * 939162 + 65536, "packed weights must fit the scratch region");
 // layers whose TF kernel tensor IS the packed operand (no copy)
@@ -208,10 +209,6 @@ bool available() { return true; }
 static inline bool fwd_on(int bit) { return (g_fwd_mask >> bit) & 1u; }
 static inline bool bwd_on(int bit) { return (g_bwd_mask >> bit) & 1u; }
 
-__global__ void __launch_bounds__(256) k_add_bias(float* z, const float* b, int64_t n, int zd) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) z[i] += b[i % zd];
-}
 
 struct PackSum3 {
   const float *a, *b, *c;
@@ -231,6 +228,7 @@ static void prep(const Model& m, const float* P, const Ws& w, hipStream_t s) {
       pack_job(PackDense{P + m.wz_off, P + m.wy_off, 1, 256, 1539, MergeF::NP, 128, 0}, S + Pk::merge_f, MergeF::KP * MergeF::NP),
       pack_job(PackDense{P + m.wz_off, P + m.wy_off, 3, 1539, 256, MergeB::NP, 128, 0}, S + Pk::merge_b, MergeB::KP * MergeB::NP),
       pack_job(PackSum3{P + m.bz_off, P + m.by_off, P + m.bm_off, 1539}, S + Pk::merge_bias, 1600),
+      pack_job(PackCat2{P + m.bmu_off, P + m.blv_off, 128}, S + Pk::heads_bias, 256),
       // conv_transpose forward: B[t][k=cin][n=cout] from TF [t][cout][cin]  -> transposed
       pack_job(PackConv<D0F>{P + m.dec[0].w_off, true}, S + Pk::d0f, D0F::BTOTAL),
       pack_job(PackConv<D1F>{P + m.dec[1].w_off, true}, S + Pk::d1f, D1F::BTOTAL),
@@ -314,13 +312,8 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
   if (fwd_on(5)) {
     DenseArgs a{w.enc_a[4], nullptr, nullptr, w.enc_st[4], P + m.enc[4].gamma_off, P + m.enc[4].beta_off,
                 w.scratch + Pk::heads_f, nullptr, w.z_mu, w.z_lv, 128, 128, F};
-    // the two biases live in separate tensors: add them through the split as well
-    a.bias = nullptr;
+    a.bias = w.scratch + Pk::heads_bias;  // [b_mu | b_lv], packed by prep()
     VAENPVC_TIMED("heads_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<HeadsFs>(a, s) : launch_densegemm<HeadsF>(a, s)));
-    // bias add (tiny): z_mu += b_mu ; z_lv += b_lv
-    int64_t n = (int64_t)F * m.z;
-    hipLaunchKernelGGL(k_add_bias, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.z_mu, P + m.bmu_off, n, m.z);
-    hipLaunchKernelGGL(k_add_bias, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.z_lv, P + m.blv_off, n, m.z);
   } else generic::heads_fwd(m, P, F, w, s);
 }
 
@@ -580,7 +573,12 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
                        G + m.emb_off, F, efc, m.z, m.ny);
   } else generic::bwd_merge(m, P, y, F, w, G, s);
 
-  generic::bwd_reparam(m, eps, F, w, s);
+  const bool heads_tuned = bwd_on(5);
+  if (heads_tuned) {  // sampler + KL backward fused with the two head-bias gradients
+    const int rch = cmax(1, cmin_(cdiv(F, 32), 1024)), rfc = cdiv(F, rch);
+    hipLaunchKernelGGL(k_reparam_bwd_colsum, dim3((unsigned)cdiv(F, rfc)), dim3(256), 0, s, w.d_z, w.z_mu, w.z_lv, eps, w.d_z_mu,
+                       w.d_z_lv, G + m.bmu_off, G + m.blv_off, (int)F, rfc, 1.0f / (float)F);
+  } else generic::bwd_reparam(m, eps, F, w, s);
 
   // ---- heads
   if (bwd_on(5)) {
@@ -595,11 +593,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     a.Y = w.d_z_lv;
     a.C = G + m.wlv_off;
     launch_tngemm(a, false, kchunks_for(F, 6), s2);
-    int ch = cmax(1, cmin_(cdiv(F, 32), 1024)), fc = cdiv(F, ch);
-    hipLaunchKernelGGL(k_colsum_atomic, dim3(1, (unsigned)cdiv(F, fc)), dim3(256), 0, s, w.d_z_mu, 128, 128, F, fc,
-                       G + m.bmu_off, nullptr, nullptr);
-    hipLaunchKernelGGL(k_colsum_atomic, dim3(1, (unsigned)cdiv(F, fc)), dim3(256), 0, s, w.d_z_lv, 128, 128, F, fc,
-                       G + m.blv_off, nullptr, nullptr);
+    // (the two head-bias gradients were accumulated by k_reparam_bwd_colsum)
     DenseArgs d{w.d_z_mu, w.d_z_lv, nullptr, nullptr, nullptr, nullptr, w.scratch + Pk::heads_b, nullptr,
                 w.dy_tmp, nullptr, 0, 768, F};
     VAENPVC_TIMED("heads_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<HeadsBs>(d, s) : launch_densegemm<HeadsB>(d, s)));
