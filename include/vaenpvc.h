@@ -9,9 +9,20 @@
  *
  * Conventions
  *   - every pointer named d_* is a DEVICE pointer owned by the caller, contiguous,
- *     16-byte aligned; nothing is allocated or freed behind the ABI;
- *   - all work is enqueued on the caller's `hipStream_t` (passed as void*), nothing
- *     synchronises the host;
+ *     16-byte aligned; no device memory is allocated or freed behind the ABI;
+ *   - all work is enqueued on the caller's `hipStream_t` (passed as void*) and is ordered
+ *     with it; nothing synchronises the host (exceptions, stated at the function:
+ *     vaenpvc_timer_read, vaenpvc_validate_ids).  ONE internal helper stream per context:
+ *     the backward pass forks the weight-gradient kernels onto it (event fork after the
+ *     gradient tensor they read is complete, event join before the call returns its work
+ *     to the caller's stream), so the caller observes plain stream order.  The stream and
+ *     its events are created lazily on the device that is current at the context's first
+ *     launch and destroyed by vaenpvc_ctx_destroy; VAENPVC_SIDE_STREAM=0 (read at context
+ *     creation) or backward-mask bit 30 cleared keeps everything on the caller's stream;
+ *   - no mutable state outside the context: masks, precision, timer and the helper stream
+ *     belong to the `vaenpvc_ctx`; entry points that take a context lock it for the
+ *     duration of the call, so different contexts may be driven from different host
+ *     threads (and devices) concurrently, and one context from several threads serially;
  *   - return value: 0 = ok, <0 = error (see VAENPVC_E_*); `vaenpvc_last_error()`
  *     returns a thread-local message; no C++ exception crosses the ABI;
  *   - frames are rows: x is [F, H] float32 (the reference's [F,1,H,1] NCHW tensor,
@@ -42,6 +53,12 @@ extern "C" {
 /* workspace modes */
 #define VAENPVC_MODE_INFER 0
 #define VAENPVC_MODE_TRAIN 1
+
+/* operand precision of the GEMM-shaped kernels on the bf16 matrix cores (vaenpvc_set_precision):
+ * every fp32 operand is split into this many bf16 terms; accumulation is always fp32 */
+#define VAENPVC_PREC_BF16X3 3 /* 3 terms, 6 products: fp32-exact (1e-6 of max|C|) */
+#define VAENPVC_PREC_BF16X2 2 /* 2 terms, 3 products: 16 mantissa bits per operand (~1e-5); default */
+#define VAENPVC_PREC_BF16 1   /* plain bf16 operands (BASELINE.json config 2 "bf16"; ~1e-2) */
 
 /* Architecture description = the keys model/vae.py actually reads from
  * architecture-*.json (model/vae.py:22-23,39,74,80-81,86,95).  Kernels are [k,1],
@@ -74,6 +91,11 @@ const char* vaenpvc_last_error(void);
 int vaenpvc_ctx_create(const vaenpvc_arch* arch, vaenpvc_ctx** out);
 void vaenpvc_ctx_destroy(vaenpvc_ctx* ctx);
 int vaenpvc_set_impl(vaenpvc_ctx* ctx, int impl);
+/* Operand precision of this context (VAENPVC_PREC_*).  The reference computes in fp32
+ * (tf.float32 everywhere); BF16X2 / BF16X3 meet its 1e-4 parity bar, BF16 is the reduced
+ * precision training mode. */
+int vaenpvc_set_precision(vaenpvc_ctx* ctx, int planes);
+int vaenpvc_get_precision(const vaenpvc_ctx* ctx);
 
 /* Trainable-tensor table = tf.trainable_variables() of the reference in creation
  * order (model/vae.py:20-24,72-103; util/layers.py:33-64): 44 tensors for the
@@ -88,7 +110,7 @@ int vaenpvc_param_info(const vaenpvc_ctx* ctx, int index, char* name, int name_c
 /* Workspace (activations kept for backward, per-frame statistics, gradient
  * scratch).  `vaenpvc_ws_find` exposes named regions (float offsets into d_ws) so
  * that tests can inspect every intermediate the reference graph would hold:
- *   enc_a<i>, enc_st<i>, z_mu, z_lv, z, h, dec_a<i>, dec_st<i>, xh,
+ *   enc_a<i>, enc_st<i>, z_mu, z_lv, z, eps, h, dec_a<i>, dec_st<i>, xh,
  *   kl_f, nll_f, d_enc_a<i>, d_z_mu, d_z_lv, d_z, d_h, d_dec_a<i>, d_xh        */
 int64_t vaenpvc_workspace_bytes(const vaenpvc_ctx* ctx, int64_t F, int mode);
 int vaenpvc_ws_find(const vaenpvc_ctx* ctx, int64_t F, int mode, const char* name,
@@ -117,10 +139,41 @@ int vaenpvc_train_fwd_bwd(vaenpvc_ctx* ctx, const float* d_params, const float* 
                           const int64_t* d_y, const float* d_eps, int64_t F, float* d_grads,
                           float* d_loss3, void* d_ws, size_t ws_bytes, void* stream);
 
+/* Same step with the sampler's N(0,1) draw generated on the device inside the sampler kernel
+ * (util/layers.py:154 tf.random_normal): Philox4x32-10 keyed by `seed`, counter words 2-3 =
+ * `offset` (pass the global step so every step draws fresh noise; with data parallelism give
+ * every rank its own seed).  Element e of the [F, z_dim] draw is the (e & 3)-th Box-Muller
+ * normal of Philox counter (e >> 2, offset); vaenpvc_philox_normal produces the identical
+ * tensor stand-alone.  The draw is kept in workspace region "eps" for the backward pass.
+ * d_offset (may be NULL): device int64 added to `offset` when the kernel RUNS, so that a
+ * captured hipGraph draws fresh noise on every replay (pass the device step counter that
+ * vaenpvc_adam_step_dev increments). */
+int vaenpvc_train_fwd_bwd_seeded(vaenpvc_ctx* ctx, const float* d_params, const float* d_x,
+                                 const int64_t* d_y, uint64_t seed, uint64_t offset,
+                                 const int64_t* d_offset, int64_t F, float* d_grads,
+                                 float* d_loss3, void* d_ws, size_t ws_bytes, void* stream);
+int vaenpvc_philox_normal(uint64_t seed, uint64_t offset, float* d_out, int64_t n, void* stream);
+
+/* Gradient buckets for data-parallel overlap (no reference counterpart: the reference is single
+ * GPU).  The backward pass finishes the flat gradient buffer back to front -- decoder convs,
+ * merge, heads, then embedding + encoder -- and each of those is ONE contiguous range of
+ * d_grads.  When a callback is registered it is invoked ON THE CALLING HOST THREAD, during
+ * vaenpvc_train_fwd_bwd*, once per range as soon as every kernel that writes it has been
+ * enqueued; `ready_stream` is a stream on which those kernels are ordered before anything the
+ * callback enqueues on it (record an event there / make the communication stream wait on it and
+ * start the all-reduce of d_grads[offset, offset + count) while the rest of the backward pass
+ * still runs).  bucket ids count up from 0 in call order; cb = NULL unregisters. */
+typedef void (*vaenpvc_bucket_cb)(void* user, int32_t bucket, int64_t offset_floats,
+                                  int64_t count_floats, void* ready_stream);
+int vaenpvc_set_bucket_callback(vaenpvc_ctx* ctx, vaenpvc_bucket_cb cb, void* user);
+
 /* Forward + losses only (VAETrainer._refresh_status fetch, trainer/vae.py:31-36). */
 int vaenpvc_loss_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_x,
                      const int64_t* d_y, const float* d_eps, int64_t F, float* d_loss3,
                      void* d_ws, size_t ws_bytes, void* stream);
+int vaenpvc_loss_fwd_seeded(vaenpvc_ctx* ctx, const float* d_params, const float* d_x,
+                            const int64_t* d_y, uint64_t seed, uint64_t offset, int64_t F,
+                            float* d_loss3, void* d_ws, size_t ws_bytes, void* stream);
 
 /* tf.train.AdamOptimizer apply for all trainables as ONE fused pass over the flat
  * buffers (trainer/vae.py:16-24; TF-flavour: p -= lr_t * m / (sqrt(v) + eps),
@@ -150,26 +203,48 @@ int vaenpvc_tanhize_bwd(const float* d_x, const float* d_xmin, const float* d_xm
 int vaenpvc_unpack_records(const float* d_records, int64_t F, int32_t rec_floats, int32_t H,
                            const float* d_xmin, const float* d_xmax, float* d_x, int64_t* d_y,
                            void* stream);
+/* The shuffle_batch dequeue of analyzer.py:128-135 fused with the slicing: output row f is
+ * built from record d_index[f] (int64, 0 <= d_index[f] < n_records; checked on the host side
+ * of the binding, not here) of the HBM-resident record store. */
+int vaenpvc_gather_unpack_records(const float* d_records, int64_t n_records, const int64_t* d_index,
+                                  int64_t F, int32_t rec_floats, int32_t H, const float* d_xmin,
+                                  const float* d_xmax, float* d_x, int64_t* d_y, void* stream);
+
+/* Speaker ids index the embedding table (model/vae.py:89): TensorFlow raises on an id outside
+ * [0, y_dim) on the CPU.  Here the kernels clamp ids (no out-of-bounds access) and this check
+ * reports them: synchronises `stream`, returns VAENPVC_E_ARG if any d_y[f] is out of range.
+ * d_flag: int32[1] device scratch. */
+int vaenpvc_validate_ids(const vaenpvc_ctx* ctx, const int64_t* d_y, int64_t F, int32_t* d_flag,
+                         void* stream);
+
+/* tf.summary.histogram payload (model/vae.py:132-136: histograms of x and xh): d_stats =
+ * double[4] {min, max, sum, sum of squares}, d_counts = uint64[n_edges + 1] with bucket b
+ * counting d_edges[b-1] <= v < d_edges[b] (d_edges ascending float32, n_edges <= 2048).
+ * Both outputs are ACCUMULATED into: the caller initialises them ({+inf, -inf, 0, 0}, zeros). */
+int vaenpvc_summary(const float* d_data, int64_t n, const float* d_edges, int32_t n_edges,
+                    double* d_stats, uint64_t* d_counts, void* stream);
 
 /* Debug/validation hook (no reference counterpart): per-step selection between the tuned
  * gfx950 kernel (bit set) and the geometry-generic kernel (bit clear) when the context
  * runs in VAENPVC_IMPL_AUTO on the VCC2016 geometry.  Bits 0..4 = encoder conv i,
  * 5 = heads, 6 = merge, 7..10 = decoder layer i; one mask for forward steps, one for
- * backward steps.  Default: all ones.  Process-global.
+ * backward steps.  Default: all ones.  State of THIS context.
  * Bit 30 of the forward mask (default set): cleared = use the bf16-split kernels of the last decoder layer at
  * any batch size (they are selected at >= 8192 frames otherwise; parity tests).  Bit 30 of the backward mask
- * (default set): cleared = launch the weight-gradient kernels on the caller's stream instead of the internal
- * side stream (serialised kernels; used by bench.py to time single kernels). */
-int vaenpvc_set_tuned_masks(uint32_t fwd_mask, uint32_t bwd_mask);
+ * (default set): cleared = launch the weight-gradient kernels on the caller's stream instead of the context's
+ * helper stream (serialised kernels; used by bench.py to time single kernels).
+ * Bit 29 of either mask (default set): cleared = keep the dense layers (heads, merge, encoder layer 4) on the
+ * exact-fp32 MFMA kernels instead of the bf16-split GEMM kernels. */
+int vaenpvc_set_tuned_masks(vaenpvc_ctx* ctx, uint32_t fwd_mask, uint32_t bwd_mask);
 
 /* Measurement hook (no reference counterpart): brackets every launch of ONE tagged
  * kernel with a hipEvent pair on the launch stream, so bench.py can report that
  * kernel's average duration over the timed region.  Tags are the kernel-site names
- * listed in DESIGN.md (e.g. "dec3_fwd").  NULL or "" disables.  Process-global. */
-int vaenpvc_timer_select(const char* tag);
-/* Synchronises the recorded events, returns the summed milliseconds and the number of
- * launches since the last read, and resets the accumulator. */
-int vaenpvc_timer_read(double* total_ms, int64_t* launches);
+ * listed in DESIGN.md (e.g. "dec3_fwd").  NULL or "" disables.  State of THIS context. */
+int vaenpvc_timer_select(vaenpvc_ctx* ctx, const char* tag);
+/* Synchronises the recorded events (blocks the host), returns the summed milliseconds and the
+ * number of launches since the last read, and resets the accumulator. */
+int vaenpvc_timer_read(vaenpvc_ctx* ctx, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -424,3 +424,11 @@ def convert_f0(f0, mu_s, std_s, mu_t, std_t):   # convert.py:51-57 (thresholds o
     lf0 = np.where(lf0 > 1.0, (lf0 - np.float32(mu_s)) / np.float32(std_s) * np.float32(std_t) + np.float32(mu_t), lf0)
     lf0 = np.where(lf0 > 1.0, np.exp(lf0), lf0)
     return lf0.astype(np.float32)
+
+
+def pw2wav_inputs(sp, ap, f0, en):       # analyzer.py:160-171 (dict branch, as convert.py:105-112 calls it)
+    """Arrays handed to pyworld.synthesize: arithmetic in the input dtype, then float64 C-order copies."""
+    en = np.reshape(en, [-1, 1])
+    spl = en * np.power(10., sp)
+    return (np.asarray(f0).astype(np.float64).copy(order='C'), spl.astype(np.float64).copy(order='C'),
+            np.asarray(ap).astype(np.float64).copy(order='C'))

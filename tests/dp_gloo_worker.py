@@ -1,4 +1,4 @@
-"""One rank of the world_size-N gloo data-parallel test (launched by test_dp_gloo.py)."""
+"""One rank of the world_size-N gloo data-parallel tests (launched by test_dp_gloo.py)."""
 import os
 import sys
 
@@ -12,22 +12,52 @@ for p in (HERE, ROOT, os.path.join(ROOT, 'vae-npvc_amd')):
     sys.path.insert(0, p)
 from helpers import SMALL_ARCH  # noqa: E402
 from oracle import convvae_oracle as O  # noqa: E402
+from oracle import philox_ref  # noqa: E402
 
 
 class OracleBackend(object):
-    """CPU stand-in for hipvae.Engine built from the oracle (test infrastructure)."""
+    """CPU stand-in for hipvae.Engine built from the oracle (test infrastructure).  It mirrors the engine's
+    contract towards hipvae.dp: losses are written into `out`, the sampler draw comes from (seed, offset)
+    when eps is None, and the flat gradient buffer is reported back to front in the library's four
+    contiguous ranges (decoder convs, merge, heads, embedding + encoder) through the bucket callback."""
 
     def __init__(self, arch, seed):
         self.arch = arch
-        self.names = list(O.param_layout(arch).keys())
+        lay = O.param_layout(arch)
+        self.names = list(lay.keys())
         self.params = torch.tensor(O.flatten_params(O.init_params(arch, seed)), dtype=torch.float64)
         self.n_params = self.params.numel()
+        off, offs = 0, {}
+        for n, shp in lay.items():
+            offs[n] = off
+            off += int(np.prod(shp))
+        cut = [offs['Generator/conv2d_transpose/kernel'], offs['Generator/fully_connected/weights'],
+               offs['Encoder/dense/kernel'], 0]
+        ends = [self.n_params] + cut[:-1]
+        self.ranges = list(zip(cut, ends))
+        self.cb = None
+        self.draws = []
 
-    def train_fwd_bwd(self, x, y, eps, grads):
+    def set_bucket_callback(self, fn):
+        self.cb = fn
+
+    def train_fwd_bwd(self, x, y, eps, grads, out=None, seed=None, offset=0, d_offset=None):
+        if eps is None:
+            z = self.arch['z_dim']
+            eps = torch.tensor(philox_ref.normal(x.shape[0] * z, seed, offset).reshape(x.shape[0], z))
+            self.draws.append(eps.numpy().copy())
         P = O.unflatten_params(self.arch, self.params.numpy())
         L, G = O.torch_loss_and_grads(self.arch, P, x.numpy(), y.numpy(), eps.numpy(), torch.float64)
-        grads.copy_(torch.tensor(np.concatenate([G[n].ravel() for n in self.names])))
-        return torch.tensor([float(L['G']), float(L['D_KL']), float(L['logP'])], dtype=torch.float64)
+        l3 = torch.tensor([float(L['G']), float(L['D_KL']), float(L['logP'])], dtype=torch.float64)
+        if out is not None:
+            out.copy_(l3)
+        flat = torch.tensor(np.concatenate([G[n].ravel() for n in self.names]))
+        grads.fill_(float('nan'))           # a range must be complete before its callback fires
+        for b, (lo, hi) in enumerate(self.ranges):
+            grads[lo:hi] = flat[lo:hi]
+            if self.cb is not None:
+                self.cb(b, lo, hi - lo, None)
+        return out if out is not None else l3
 
     def adam_step(self, grads, m, v, step, lr, b1, b2, eps, grad_scale):
         p, mm, vv = O.tf_adam_step(self.params.numpy(), grads.numpy() * grad_scale, m.numpy(), v.numpy(), step,
@@ -37,30 +67,99 @@ class OracleBackend(object):
         v.copy_(torch.tensor(vv))
 
 
-def run(rank, world, F, steps, out):
-    from hipvae.dp import Stepper, shard_range
+def run(rank, world, F, steps, out, mode):
+    from hipvae.dp import Stepper, shard_range, rank_seed
     be = OracleBackend(SMALL_ARCH, seed=10 + rank)     # different init per rank: broadcast must fix it
-    st = Stepper(be, 1e-3, 0.5, 0.999)
+    st = Stepper(be, 1e-3, 0.5, 0.999, overlap=(mode != 'flat'), seed=3)
     assert st.world == world and st.rank == rank
     st.broadcast_params()
+    if mode == 'seeded':
+        # every rank draws its OWN sampler noise: keys differ, and step t uses counter t
+        assert st.seed == rank_seed(3, rank, world)
     l3 = None
     for t in range(steps):
         x, y, eps = O.make_inputs(SMALL_ARCH, F, 50 + t)
+        x[F // 2:] *= 0.25                # shards with visibly different content (and losses)
         lo, hi = shard_range(F, rank, world)
-        l3 = st.step(torch.tensor(x[lo:hi]), torch.tensor(y[lo:hi]), torch.tensor(eps[lo:hi]))
+        if mode == 'seeded':
+            l3 = st.step(torch.tensor(x[lo:hi]), torch.tensor(y[lo:hi]))
+        else:
+            l3 = st.step(torch.tensor(x[lo:hi]), torch.tensor(y[lo:hi]), torch.tensor(eps[lo:hi]))
     gl = st.mean_losses(l3)
+    assert torch.allclose(gl, l3)
+    if mode == 'seeded':
+        np.save(out + '.draw%d.npy' % rank, np.stack(be.draws))
     if rank == 0:
         np.save(out, np.concatenate([be.params.numpy(), gl.numpy()]))
+
+
+def run_trainer(rank, world, F, steps, out):
+    """VAETrainer.train under N ranks with a status interval of ZERO seconds on odd ranks and 'never' on even
+    ones: any collective inside the status path would pair with a gradient all-reduce of another rank
+    (hang or corrupted gradients).  Also exercises checkpoint save + restore-and-continue."""
+    import types
+    from trainer.vae import VAETrainer
+    from model.vae import LossDict
+    be = OracleBackend(SMALL_ARCH, seed=10)
+    be.layout = {}
+
+    class Source(object):
+        t = 0
+
+        def next_batch(self):
+            x, y, _ = O.make_inputs(SMALL_ARCH, F, 50 + self.t)
+            self.t += 1
+            lo, hi = (rank * F // world, (rank + 1) * F // world)
+            return torch.tensor(x[lo:hi]), torch.tensor(y[lo:hi])
+    loss = LossDict()
+    loss.machine = types.SimpleNamespace(engine=be)
+    loss.source = Source()
+    arch = dict(SMALL_ARCH)
+    arch['training'] = dict(SMALL_ARCH['training'], max_iter=steps)
+    logdir = out + '.logdir'
+    args = types.SimpleNamespace(seed=0, restore_from=None, ckpt=None)
+    tr = VAETrainer(loss, arch, args, {'logdir': logdir, 'logdir_root': logdir, 'restore_from': logdir})
+    ck = tr.train(steps, status_secs=0 if rank % 2 else 1e9, save_secs=1e9)
+    if rank == 0:
+        assert os.path.basename(ck) == 'model.ckpt-%d' % steps
+        msgs = open(os.path.join(logdir, 'training.log')).read().strip().splitlines()
+        assert msgs and msgs[-1].startswith('Iter %05d: log P(x|z, y) = ' % steps)
+    if world > 1:
+        dist.barrier()
+    # restore and continue: two more steps from the checkpoint == uninterrupted run
+    be2 = OracleBackend(SMALL_ARCH, seed=99)
+    be2.layout = {}
+    loss2 = LossDict()
+    loss2.machine = types.SimpleNamespace(engine=be2)
+    loss2.source = Source()
+    loss2.source.t = steps
+    arch2 = dict(arch)
+    arch2['training'] = dict(arch['training'], max_iter=steps + 2)
+    args2 = types.SimpleNamespace(seed=0, restore_from=logdir, ckpt=None)
+    tr2 = VAETrainer(loss2, arch2, args2, {'logdir': logdir + '2', 'logdir_root': logdir, 'restore_from': logdir})
+    tr2.train(steps + 2, status_secs=1e9, save_secs=1e9)
+    assert tr2.opt['g'].step_count == steps + 2
+    loss.source.t = steps
+    arch['training']['max_iter'] = steps + 2
+    tr.train(steps + 2, status_secs=1e9, save_secs=1e9)
+    assert np.abs(be.params.numpy() - be2.params.numpy()).max() < 1e-12
+    if rank == 0:
+        np.save(out, be.params.numpy())
 
 
 if __name__ == '__main__':
     torch.set_num_threads(1)
     rank, world, port, F, steps, out = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]),
                                         int(sys.argv[5]), sys.argv[6])
+    mode = sys.argv[7] if len(sys.argv) > 7 else 'bucket'
     if world > 1:
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ['MASTER_PORT'] = port
+        os.environ['RANK'], os.environ['WORLD_SIZE'] = str(rank), str(world)
         dist.init_process_group('gloo', rank=rank, world_size=world)
-    run(rank, world, F, steps, out)
+    if mode == 'trainer':
+        run_trainer(rank, world, F, steps, out)
+    else:
+        run(rank, world, F, steps, out, mode)
     if world > 1:
         dist.destroy_process_group()

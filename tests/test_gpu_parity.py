@@ -38,10 +38,10 @@ def check(tag, got, want, tol, fails):
 ARCHS = {'vcc': load_arch(), 'small': SMALL_ARCH}
 
 
-def make_engine(which, impl, masks=(0xffffffff, 0xffffffff)):
+def make_engine(which, impl, masks=(0xffffffff, 0xffffffff), precision=None):
     from hipvae import Engine
-    eng = Engine(ARCHS[which], impl=impl)
-    eng.lib.vaenpvc_set_tuned_masks(masks[0], masks[1])
+    eng = Engine(ARCHS[which], impl=impl, precision=precision)
+    eng.set_tuned_masks(masks[0], masks[1])      # state of THIS engine's context (nothing process-global)
     return eng
 
 
@@ -334,10 +334,7 @@ def test_tuned_step_isolated(step, direction):
     bit = 1 << STEPS.index(step)
     masks = (bit, 0) if direction == 'fwd' else (0, bit)
     eng = make_engine('vcc', 'auto', masks)
-    try:
-        fails = compare_everything(eng, 37, 5, 'isolated %s/%s ' % (direction, step))
-    finally:
-        eng.lib.vaenpvc_set_tuned_masks(0xffffffff, 0xffffffff)
+    fails = compare_everything(eng, 37, 5, 'isolated %s/%s ' % (direction, step))
     assert not fails, '\n'.join(fails)
 
 
@@ -348,45 +345,104 @@ def test_all_tuned_steps(F, seed):
     assert not fails, '\n'.join(fails)
 
 
-BF16_TOEP = (0xbfffffff, 0xffffffff)   # forward-mask bit 30 cleared: bf16x3 Toeplitz kernels at any batch size
+BF16_TOEP = (0xbfffffff, 0xffffffff)   # forward-mask bit 30 cleared: bf16-split Toeplitz kernels at any batch size
 
 
+@pytest.mark.parametrize('precision', ['bf16x2', 'bf16x3'])
 @pytest.mark.parametrize('F,seed', [(37, 5), (64, 6), (1, 7), (130, 9)])
-def test_bf16_split_toeplitz_kernels_against_oracle(F, seed):
-    """The last decoder layer on the bf16 matrix cores (3-term operand split, six products):
-    forward and input gradient against the float64 oracle, same tolerances as the fp32 kernels.
-    (By default these kernels only run at F >= 8192; the mask forces them here.)"""
-    eng = make_engine('vcc', 'auto', BF16_TOEP)
-    try:
-        fails = compare_everything(eng, F, seed, 'bf16x3 toeplitz F%d ' % F)
-    finally:
-        eng.lib.vaenpvc_set_tuned_masks(0xffffffff, 0xffffffff)
+def test_bf16_split_toeplitz_kernels_against_oracle(F, seed, precision):
+    """The last decoder layer on the bf16 matrix cores (operands split into 2 or 3 bf16 terms, fp32
+    accumulation): forward, input gradient and weight gradient against the float64 oracle, same
+    tolerances as the fp32 kernels.  (By default these kernels only run at F >= 8192; the mask forces them.)"""
+    eng = make_engine('vcc', 'auto', BF16_TOEP, precision=precision)
+    fails = compare_everything(eng, F, seed, '%s toeplitz F%d ' % (precision, F))
     assert not fails, '\n'.join(fails)
 
 
-@pytest.mark.parametrize('F', [2048, 8192])
-def test_tuned_vs_generic_large_batch(F):
-    """Tuned kernels against the generic kernels on the GPU (the float64 oracle would take
-    minutes on the host): activations, losses and gradients.  F = 8192 is the smallest batch
-    at which the bf16x3 kernels of the last decoder layer are selected by default."""
+def _golden_large(F, seed, precision, tag, tol_act=TOL_ACT, tol_grad=TOL_GRAD):
+    """Default (auto) path at a benchmarked batch size against the committed chunked-float64 oracle fixture
+    (tests/golden/make_golden_large.py): losses, z_mu / z_lv / xh rows of 16 sampled frames, and per tensor the
+    gradient L2 norm and 64 sampled entries -- ONE gradient bar for every batch size."""
     from hipvae import lib as L
     arch = ARCHS['vcc']
-    P = O.init_params(arch, 21)
-    x, y, eps = O.make_inputs(arch, F, 21)
-    res = {}
-    for impl in ('generic', 'auto'):
-        eng = make_engine('vcc', impl)
-        l3, g = run_train(eng, P, x, y, eps)
-        res[impl] = (l3, g, eng.ws_region(F, L.MODE_TRAIN, 'xh').cpu().numpy().copy(), eng.layout)
-        del eng
-        torch.cuda.empty_cache()
+    gold = np.load(os.path.join(GOLDEN, 'vcc2016_F%d_seed%d.npz' % (F, seed)))
+    eng = make_engine('vcc', 'auto', precision=precision)
+    P = O.init_params(arch, seed)
+    x, y, eps = O.make_inputs(arch, F, seed)
+    l3, g = run_train(eng, P, x, y, eps)
     fails = []
-    check('F%d tuned-vs-generic loss3' % F, res['auto'][0], res['generic'][0], TOL_ACT, fails)
-    check('F%d tuned-vs-generic xh' % F, res['auto'][2], res['generic'][2], TOL_ACT, fails)
-    for name, (off, shape) in res['auto'][3].items():
+    check(tag + 'loss3', l3, gold['loss3'], tol_act, fails)
+    fidx = gold['frame_idx']
+    for k, width in (('z_mu', 128), ('z_lv', 128), ('xh', 513)):
+        got = eng.ws_region(F, L.MODE_TRAIN, k).view(F, width)[torch.as_tensor(fidx, device=eng.device)].cpu().numpy()
+        check(tag + k + ' rows', got, gold[k + '_rows'], tol_act, fails)
+    report(tag + 'recon-L1 mean|xh-xh_ref| (16 frames)',
+           float(np.abs(eng.ws_region(F, L.MODE_TRAIN, 'xh').view(F, 513)[torch.as_tensor(fidx, device=eng.device)].cpu().numpy()
+                        - gold['xh_rows']).mean()), 1.0)
+    assert np.isfinite(g).all()
+    for i, (name, (off, shape)) in enumerate(eng.layout.items()):
         n = int(np.prod(shape))
-        check('F%d tuned-vs-generic grad ' % F + name, res['auto'][1][off:off + n], res['generic'][1][off:off + n], 2e-3, fails)
+        gi = g[off:off + n].astype(np.float64)
+        e = abs(np.sqrt((gi ** 2).sum()) - gold['grad_l2'][i]) / max(gold['grad_l2'][i], 1e-12)
+        report(tag + 'grad_l2 ' + name, e, tol_grad)
+        if e > tol_grad:
+            fails.append('grad_l2 %s %.3e' % (name, e))
+        k = min(64, n)
+        e = np.abs(gi[sample_idx(n, 64)] - gold['grad_samples'][i][:k]).max() / max(gold['grad_absmax'][i], 1e-12)
+        report(tag + 'grad_samples ' + name, e, tol_grad)
+        if e > tol_grad:
+            fails.append('grad_samples %s %.3e' % (name, e))
+    return fails
+
+
+@pytest.mark.parametrize('F,seed', [(8192, 21), (32768, 22)])
+@pytest.mark.parametrize('precision', ['bf16x2', 'bf16x3'])
+def test_benchmarked_batch_sizes_against_oracle_fixture(F, seed, precision):
+    """F = 32768 is the bench's batch (256 x [1,513,128]); F = 8192 the smallest one that selects the bf16-split
+    Toeplitz kernels by default.  Both fp32-class precisions are held to the SAME bars as the small batches:
+    1e-4 on activations / losses, 2e-4 on gradients (weight gradient of the 1025-tap layer with its frame-chunk
+    split and atomics included)."""
+    fails = _golden_large(F, seed, precision, 'golden F%d %s ' % (F, precision))
     assert not fails, '\n'.join(fails)
+
+
+BF16_TOL_ACT, BF16_TOL_GRAD = 3e-2, 6e-2   # bf16 MODE (one bf16 term per operand, ~3 significant digits)
+
+
+def test_bf16_mode_against_oracle_fixture():
+    """BASELINE.json config 2 names bf16: the reduced-precision mode (plain bf16 operands on the GEMM-shaped
+    kernels of the bf16 path, fp32 accumulation, fp32 LayerNorm statistics / losses / Adam) is reported beside the
+    fp32-class default, never instead of it, and its tolerance is stated separately."""
+    fails = _golden_large(8192, 21, 'bf16', 'golden F8192 bf16-mode ', BF16_TOL_ACT, BF16_TOL_GRAD)
+    assert not fails, '\n'.join(fails)
+
+
+def test_properties_at_benchmarked_batch():
+    """Size-independent properties at F = 32768 (the bench batch): the data-parallel identity (gradient of the
+    batch == mean of the gradients of its two halves, i.e. what a 2-GPU run computes) and frame-permutation
+    equivariance of the conversion path."""
+    arch = ARCHS['vcc']
+    F = 32768
+    eng = make_engine('vcc', 'auto')
+    P = O.init_params(arch, 31)
+    x, y, eps = O.make_inputs(arch, F, 31)
+    l3, g = run_train(eng, P, x, y, eps)
+    h = F // 2
+    la, ga = run_train(eng, P, x[:h], y[:h], eps[:h])
+    lb, gb = run_train(eng, P, x[h:], y[h:], eps[h:])
+    assert np.allclose(0.5 * (la + lb), l3, rtol=2e-5)
+    for name, (off, shape) in eng.layout.items():
+        n = int(np.prod(shape))
+        e = rel_err(0.5 * (ga[off:off + n] + gb[off:off + n]), g[off:off + n])
+        report('F32768 halves-vs-whole grad ' + name, e, TOL_GRAD)
+        assert e < TOL_GRAD, name
+    perm = np.random.default_rng(0).permutation(F)
+    xt = torch.tensor(x, device=eng.device)
+    yt = torch.tensor(y, device=eng.device)
+    pt = torch.as_tensor(perm, device=eng.device)
+    out = eng.decode(eng.encode(xt), yt)
+    outp = eng.decode(eng.encode(xt[pt]), yt[pt])
+    assert rel_err(outp.cpu().numpy(), out[pt].cpu().numpy()) < 1e-5
 
 
 def test_hipgraph_replay_matches_eager():
@@ -410,10 +466,17 @@ def test_hipgraph_replay_matches_eager():
                 l3 = st.step(xt, yt, et)
         torch.cuda.synchronize()
         assert st.step_count == 3
-        res.append((eng.params.cpu().numpy().copy(), l3.cpu().numpy().copy()))
+        res.append((eng.params.cpu().numpy().copy(), l3.cpu().numpy().copy(), st.grads.cpu().numpy().copy()))
     p0 = O.flatten_params(P)
     d_eager, d_graph = res[0][0] - p0, res[1][0] - p0
-    # atomics make the fp32 summation order run-dependent; compare the updates, not bits
-    assert np.abs(d_eager - d_graph).max() <= 0.02 * np.abs(d_eager).max() or \
-        np.mean(np.abs(d_eager - d_graph) > 0.05 * np.abs(d_eager).max()) < 0.02
-    assert np.allclose(res[0][1], res[1][1], rtol=1e-4)
+    # same kernels, same order; only the summation order of fp32 atomics may differ between the two runs.
+    # (1) the last step's gradients agree to a few ulps of their scale; (2) ONE max-norm bound on the three-step
+    # update wherever the gradient is above the rounding floor (there an update is ~lr * sign(g), so floor-level
+    # entries may legitimately flip and are bounded in the mean instead).
+    g_e, g_g = res[0][2], res[1][2]
+    assert np.abs(g_e - g_g).max() <= 1e-5 * np.abs(g_e).max()
+    strong = np.abs(g_e) > 1e-3 * np.abs(g_e).max()
+    assert strong.sum() > 10000
+    assert np.abs(d_eager - d_graph)[strong].max() <= 1e-3 * np.abs(d_eager).max()
+    assert np.abs(d_eager - d_graph).mean() <= 1e-3 * np.abs(d_eager).max()
+    assert np.allclose(res[0][1], res[1][1], rtol=1e-5)

@@ -46,10 +46,6 @@ def test_train_three_steps_through_plugins(tmp_path):
     image, label = analyzer.read(arch['training']['datadir'], 16, normalizer=normalizer, seed=3)
     machine = ConvVAE(arch, seed=5)
     p0 = machine.engine.params.cpu().numpy().copy()
-    # inject the sampler noise so the oracle can follow the same trajectory
-    eps_list = [torch.randn(16, 128, generator=torch.Generator().manual_seed(100 + i)) for i in range(3)]
-    it = iter(eps_list)
-    machine._draw_eps = lambda F: next(it).to(machine.engine.device)
     batches = []
     orig = image.source.next_batch
     def spy():
@@ -60,10 +56,25 @@ def test_train_three_steps_through_plugins(tmp_path):
     loss = machine.loss(image, label)
     assert set(loss.keys()) == {'G', 'D_KL', 'logP'}
     dirs = {'logdir': os.path.join(str(tmp_path), 'logdir', 'train', 'stamp')}
-    trainer = VAETrainer(loss, arch, None, dirs)
-    ckpt = trainer.train(nIter=123456, machine=machine)          # nIter ignored (trap T7)
+    import types
+    trainer = VAETrainer(loss, arch, types.SimpleNamespace(seed=17, restore_from=None, ckpt=None), dirs)
+    # the sampler draws on the device (Philox keyed by the trainer's seed, counter = global step): the oracle
+    # follows the same trajectory on the NumPy restatement of that draw
+    from oracle import philox_ref
+    eps_list = [torch.tensor(philox_ref.normal(16 * 128, trainer.opt['g'].seed, t).reshape(16, 128)) for t in range(3)]
+    ckpt = trainer.train(nIter=123456, machine=machine, summary_secs=0)     # nIter ignored (trap T7)
     assert os.path.basename(ckpt) == 'model.ckpt-3' and os.path.exists(ckpt)
     assert os.path.exists(os.path.join(dirs['logdir'], 'training.log'))
+    # summaries of model/vae.py:132-136 in a TensorBoard event file (written on every step here: summary_secs=0)
+    from util.summary import read_events
+    evf = [f for f in os.listdir(dirs['logdir']) if f.startswith('events.out.tfevents')]
+    assert len(evf) == 1
+    ev = read_events(os.path.join(dirs['logdir'], evf[0]))
+    assert [e['step'] for e in ev[1:]] == [1, 2, 3]
+    assert set(ev[1]['scalars']) == {'KL-div', 'logPx'} and set(ev[1]['histograms']) == {'x', 'xh'}
+    hx = ev[1]['histograms']['x']
+    assert hx['num'] == 16 * 513 and abs(hx['min'] - batches[0][0].min()) < 1e-6 and abs(hx['max'] - batches[0][0].max()) < 1e-6
+    assert abs(hx['sum'] - batches[0][0].astype(np.float64).sum()) < 1e-3
     # speaker ids are bit-exact and only {0, 9}
     for xb, yb in batches:
         assert yb.dtype == np.int64 and set(yb.tolist()) <= {0, 9}
@@ -91,6 +102,16 @@ def test_train_three_steps_through_plugins(tmp_path):
     m2 = ConvVAE(arch, seed=99)
     step = load(m2.engine, dirs['logdir'], ckpt='model.ckpt-3')
     assert step == 3 and torch.equal(m2.engine.params, machine.engine.params)
+    # --restore_from: parameters, Adam slots and global_step come back and training continues from step 3
+    arch2 = json.loads(json.dumps(arch))
+    arch2['training']['max_iter'] = 5
+    m3 = ConvVAE(arch2, seed=123)
+    image3, label3 = analyzer.read(arch['training']['datadir'], 16, normalizer=normalizer, seed=3)
+    dirs3 = {'logdir': os.path.join(str(tmp_path), 'logdir', 'train', 'stamp2'), 'restore_from': dirs['logdir']}
+    tr3 = VAETrainer(m3.loss(image3, label3), arch2, types.SimpleNamespace(seed=17, restore_from=dirs['logdir'], ckpt=None), dirs3)
+    ck3 = tr3.train(nIter=0, machine=m3)
+    assert os.path.basename(ck3) == 'model.ckpt-5' and tr3.opt['g'].step_count == 5
+    assert torch.equal(tr3.opt['g'].m != 0, trainer.opt['g'].m != 0)
 
 
 def test_convert_utterance_matches_oracle(tmp_path):
@@ -114,3 +135,62 @@ def test_convert_utterance_matches_oracle(tmp_path):
     nhwc = machine.decode(machine.encode(torch.tensor(x, dtype=torch.float32, device='cuda').view(-1, 1, 513, 1)),
                           torch.full((len(x),), trg, dtype=torch.int64, device='cuda'))
     assert tuple(nhwc.shape) == (len(x), 513, 1, 1)
+
+
+def test_convert_cli_end_to_end(tmp_path, monkeypatch):
+    """convert.main() on a synthetic tree (convert.py:66-116): checkpoint + architecture lookup, per-utterance device
+    path, log-F0 transform, and the arrays handed to the vocoder (analyzer.pw2wav, analyzer.py:160-171) -- WORLD and
+    soundfile themselves are external, so stand-ins record what they are given."""
+    import sys
+    import types
+    import analyzer
+    import convert as conv_cli
+    from model.vae import ConvVAE
+    arch = load_arch()
+    root = str(tmp_path)
+    allr, xmin, xmax = make_dataset(root, n_utt=2, seed=6)
+    os.makedirs(os.path.join(root, 'etc'))
+    xmin.tofile(os.path.join(root, 'etc', 'xmin.npf'))
+    xmax.astype(np.float64).tofile(os.path.join(root, 'etc', 'xmax.npf'))      # both on-disk dtypes (trap T4)
+    np.array([5.0, 0.25], np.float32).tofile(os.path.join(root, 'etc', 'SF1.npf'))
+    np.array([4.7, 0.30], np.float32).tofile(os.path.join(root, 'etc', 'TM3.npf'))
+    logdir = os.path.join(root, 'logdir', 'train', 'stamp')
+    os.makedirs(logdir)
+    with open(os.path.join(logdir, 'architecture-vae-vcc2016.json'), 'w') as fp:
+        json.dump(arch, fp)
+    machine = ConvVAE(arch, seed=8)
+    torch.save({'params': machine.engine.params.cpu(), 'step': 7}, os.path.join(logdir, 'model.ckpt-7'))
+    calls, written = [], []
+    fake_pw = types.ModuleType('pyworld')
+    fake_pw.synthesize = lambda f0, sp, ap, fs: (calls.append((f0, sp, ap, fs)) or np.zeros(8))
+    fake_sf = types.ModuleType('soundfile')
+    fake_sf.write = lambda name, y, fs: written.append((name, fs))
+    monkeypatch.setitem(sys.modules, 'pyworld', fake_pw)
+    monkeypatch.setitem(sys.modules, 'soundfile', fake_sf)
+    monkeypatch.chdir(root)
+    pattern = os.path.join(root, 'bin', 'Training Set', '{}', '*.bin')
+    out_dir = conv_cli.main(['--src', 'SF1', '--trg', 'TM3', '--model', 'ConvVAE', '--checkpoint',
+                             os.path.join(logdir, 'model.ckpt-7'), '--output_dir', os.path.join(root, 'logdir'),
+                             '--file_pattern', pattern])
+    assert len(calls) == 2 and len(written) == 2
+    assert sorted(os.path.basename(n) for n, _ in written) == ['SF1-TM3-100000.wav', 'SF1-TM3-100001.wav']
+    assert all(os.path.dirname(n) == out_dir and fs == 16000 for n, fs in written)
+    assert os.path.normpath(out_dir).startswith(os.path.normpath(os.path.join(root, 'logdir', 'output')))
+    P = O.unflatten_params(arch, machine.engine.params.cpu().numpy())
+    trg = analyzer.SPEAKERS.index('TM3')
+    files = sorted(os.listdir(os.path.join(root, 'bin', 'Training Set', 'SF1')))
+    for (f0, sp, ap, fs), f in zip(calls, files):
+        raw = O.parse_records(open(os.path.join(root, 'bin', 'Training Set', 'SF1', f), 'rb').read())
+        x = O.tanhize_forward(raw['sp'].astype(np.float64), xmin.astype(np.float64), xmax.astype(np.float64))
+        R = O.np_forward(arch, P, x, np.full(len(x), trg), None)
+        sp_conv = O.tanhize_backward(R['xh'], xmin.astype(np.float64), xmax.astype(np.float64))
+        want_f0, want_sp, want_ap = O.pw2wav_inputs(sp_conv.astype(np.float32), raw['ap'],
+                                                    O.convert_f0(raw['f0'], 5.0, 0.25, 4.7, 0.30), raw['en'])
+        for a in (f0, sp, ap):
+            assert a.dtype == np.float64 and a.flags['C_CONTIGUOUS']
+        assert fs == 16000 and np.allclose(f0, want_f0, rtol=1e-6) and np.array_equal(ap, want_ap)
+        # 10^sp amplifies the 1e-4 parity bar of the log-spectrum by ln(10) * |range|: compare in the log domain
+        # (the synthetic `en` column is signed; signs must agree exactly, magnitudes in the log domain)
+        assert np.array_equal(np.sign(sp), np.sign(want_sp))
+        la, lb = np.log10(np.abs(sp)), np.log10(np.abs(want_sp))
+        assert np.abs(la - lb).max() < 1e-4 * np.abs(lb).max()

@@ -164,3 +164,19 @@ def test_data_plane_restatement():
     out = O.convert_f0(f0, 5.0, 0.2, 4.8, 0.3)
     assert out[0] == 0.0 and out[3] == 0.5
     assert np.allclose(out[1], np.exp((np.log(100.0) - 5.0) / 0.2 * 0.3 + 4.8), rtol=1e-5)
+
+
+def test_philox_block_function_known_answers():
+    """Philox4x32-10 against the Random123 known-answer vectors (kat_vectors: counter, key -> output); the device
+    sampler (csrc/philox.h) is compared with this restatement in tests/test_gpu_runtime.py."""
+    from oracle import philox_ref as P
+    kats = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+            ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+            ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+             [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for c, k, want in kats:
+        got = P.philox4x32_10(np.array([c], np.uint32), np.array([k], np.uint32))[0]
+        assert [int(v) for v in got] == want
+    x = P.normal(1 << 18, seed=11, offset=3)
+    assert x.dtype == np.float32 and abs(x.mean()) < 1e-2 and abs(x.std() - 1) < 1e-2 and abs((x ** 4).mean() - 3) < 0.1
+    assert not np.array_equal(x[:64], P.normal(64, seed=11, offset=4)) and np.array_equal(x[:64], P.normal(64, 11, 3))

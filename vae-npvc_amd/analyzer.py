@@ -2,8 +2,10 @@
 
 The TF queue machinery is replaced by an HBM-resident frame store: every matching
 `.bin` file (records of 1029 float32 = [sp(513) | ap(513) | f0 | en | speaker]) is
-uploaded once; a batch is a device-side gather of shuffled record rows followed by the
-`unpack_records` HIP kernel (slice sp, Tanhize, int64 speaker cast).  WORLD feature
+uploaded once; a batch is ONE HIP kernel that gathers the shuffled record rows' sp columns,
+applies Tanhize and casts the speaker column to int64 (`vaenpvc_gather_unpack_records`); the shuffle
+order comes from a host-side BoundedShuffler with the reference queue's capacity /
+min_after_dequeue semantics.  WORLD feature
 extraction / synthesis (pyworld) is out of scope.
 """
 import glob
@@ -52,8 +54,9 @@ class Tanhize(object):
         x2 = x.reshape(-1, self.xmin.numel()).contiguous()
         out = torch.empty_like(x2)
         fn = lib.vaenpvc_tanhize_fwd if fwd else lib.vaenpvc_tanhize_bwd
-        L.check(fn(x2.data_ptr(), self.xmin.data_ptr(), self.xmax.data_ptr(), out.data_ptr(), x2.shape[0],
-                   x2.shape[1], torch.cuda.current_stream().cuda_stream), 'tanhize')
+        with torch.cuda.device(x2.device):
+            L.check(fn(x2.data_ptr(), self.xmin.data_ptr(), self.xmax.data_ptr(), out.data_ptr(), x2.shape[0],
+                       x2.shape[1], torch.cuda.current_stream(x2.device).cuda_stream), 'tanhize')
         return out.reshape(shape)
 
     def forward_process(self, x):
@@ -69,55 +72,157 @@ class _Handle(object):
         self.source, self.which = source, which
 
 
-class FrameStore(object):
-    """All records resident in HBM; `next_batch()` = shuffle_batch dequeue
-    (analyzer.py:128-135) without replacement within an epoch.  With data parallelism
-    every rank draws the same permutation (shared seed) and takes its own slice."""
+class BoundedShuffler(object):
+    """Host-side index stream with the semantics of the reference's input queues
+    (analyzer.py:103-135): `tf.train.string_input_producer(files)` reshuffles the FILE order every
+    epoch and a FixedLengthRecordReader walks each file's records in order; `tf.train.shuffle_batch`
+    keeps a RandomShuffleQueue of at most `capacity` records and dequeues uniformly at random while at
+    least `min_after_dequeue` remain.  A record can therefore only move a bounded distance away from its
+    file-order position: mixing is LOCAL (capacity 2048 / min_after_dequeue 1024 in main.py:65-66).
 
-    def __init__(self, records, batch_size, normalizer, seed=0, rank=0, world=1, device='cuda'):
+    This class produces the same kind of sequence on record NUMBERS (the records themselves stay in
+    HBM): a pool is refilled to `capacity` from the epoch stream before every draw and
+    min(n, len(pool) - min_after_dequeue) distinct entries leave it uniformly at random per draw.
+    Deterministic given `seed`; every data-parallel rank builds the same sequence and slices it."""
+
+    def __init__(self, file_sizes, capacity, min_after_dequeue, seed=0):
+        if capacity <= min_after_dequeue:
+            raise ValueError('capacity must be larger than min_after_dequeue')   # tf.train.shuffle_batch's own check
+        self.sizes = [int(n) for n in file_sizes]
+        self.starts = np.concatenate([[0], np.cumsum(self.sizes)[:-1]]).astype(np.int64)
+        self.capacity, self.min_after = int(capacity), int(min_after_dequeue)
+        ss = np.random.SeedSequence(seed).spawn(2)        # independent streams: file order / picks from the pool
+        self.rng_files = np.random.Generator(np.random.PCG64(ss[0]))
+        self.rng = np.random.Generator(np.random.PCG64(ss[1]))
+        self.pool = np.empty(0, np.int64)
+        self._pending = np.empty(0, np.int64)
+
+    def _more(self, n):
+        """next n record numbers of the (endless) epoch stream"""
+        while self._pending.size < n:
+            order = self.rng_files.permutation(len(self.sizes))       # string_input_producer(shuffle=True)
+            epoch = np.concatenate([self.starts[i] + np.arange(self.sizes[i], dtype=np.int64) for i in order])
+            self._pending = np.concatenate([self._pending, epoch])
+        out, self._pending = self._pending[:n], self._pending[n:]
+        return out
+
+    def next(self, n):
+        out = []
+        while n > 0:
+            if self.pool.size < self.capacity:
+                self.pool = np.concatenate([self.pool, self._more(self.capacity - self.pool.size)])
+            k = min(n, self.pool.size - self.min_after)
+            pick = self.rng.choice(self.pool.size, size=k, replace=False)
+            out.append(self.pool[pick])
+            keep = np.ones(self.pool.size, bool)
+            keep[pick] = False
+            self.pool = self.pool[keep]
+            n -= k
+        return np.concatenate(out)
+
+
+class FrameStore(object):
+    """All records resident in HBM; `next_batch()` = the shuffle_batch dequeue (analyzer.py:128-135): the
+    BoundedShuffler picks record numbers on the host, ONE HIP kernel gathers those records' sp columns,
+    normalises them and casts the speaker column (vaenpvc_gather_unpack_records).  With data parallelism
+    every rank draws the same global index sequence (shared seed) and takes its own slice."""
+
+    def __init__(self, records, batch_size, normalizer, seed=0, rank=0, world=1, device='cuda',
+                 capacity=None, min_after_dequeue=None, file_sizes=None, y_dim=None):
         self.rec = torch.as_tensor(records, dtype=torch.float32).to(device).contiguous()
         if self.rec.dim() != 2 or self.rec.shape[1] != FEAT_DIM:
             raise ValueError('records must be [N, %d] float32' % FEAT_DIM)
+        n = self.rec.shape[0]
         self.batch_size, self.normalizer = int(batch_size), normalizer
         self.rank, self.world = rank, world
-        self.gen = torch.Generator(device='cpu')
-        self.gen.manual_seed(seed)
-        self.perm, self.pos = None, 0
+        sizes = [n] if file_sizes is None else list(file_sizes)
+        assert sum(sizes) == n
+        capacity = min(int(capacity), n) if capacity else n
+        min_after = min(int(min_after_dequeue), capacity - 1) if min_after_dequeue is not None else 0
+        self.shuffler = BoundedShuffler(sizes, capacity, max(0, min_after), seed=seed)
         self.lib = L.load_library()
-
-    def _indices(self):
-        n, b = self.rec.shape[0], self.batch_size * self.world
-        if self.perm is None or self.pos + b > n:
-            self.perm = torch.randperm(n, generator=self.gen)
-            self.pos = 0
-            if b > n:
-                raise ValueError('global batch larger than the data set')
-        idx = self.perm[self.pos:self.pos + b]
-        self.pos += b
-        return idx[self.rank * self.batch_size:(self.rank + 1) * self.batch_size]
+        # speaker ids index the embedding table: an id outside [0, y_dim) is an error in TensorFlow; check the
+        # (integral float) speaker column once, here, instead of on every batch
+        spk = self.rec[:, -1]
+        ny = len(SPEAKERS) if y_dim is None else int(y_dim)
+        bad = int(((spk < 0) | (spk >= ny) | (spk != spk.floor())).sum().item())
+        if bad:
+            raise ValueError('%d record(s) carry a speaker id outside [0, %d)' % (bad, ny))
 
     def next_batch(self):
-        idx = self._indices().to(self.rec.device)
-        rows = self.rec.index_select(0, idx)
-        F = rows.shape[0]
-        x = torch.empty(F, SP_DIM, dtype=torch.float32, device=rows.device)
-        y = torch.empty(F, dtype=torch.int64, device=rows.device)
+        idx = self.shuffler.next(self.batch_size * self.world)
+        idx = idx[self.rank * self.batch_size:(self.rank + 1) * self.batch_size]
+        dev = self.rec.device
+        idx = torch.from_numpy(np.ascontiguousarray(idx)).to(dev)
+        F = idx.numel()
+        x = torch.empty(F, SP_DIM, dtype=torch.float32, device=dev)
+        y = torch.empty(F, dtype=torch.int64, device=dev)
         nz = self.normalizer
-        L.check(self.lib.vaenpvc_unpack_records(rows.data_ptr(), F, FEAT_DIM, SP_DIM, nz.xmin.data_ptr(),
-                                                nz.xmax.data_ptr(), x.data_ptr(), y.data_ptr(),
-                                                torch.cuda.current_stream().cuda_stream), 'unpack_records')
+        with torch.cuda.device(dev):
+            L.check(self.lib.vaenpvc_gather_unpack_records(self.rec.data_ptr(), self.rec.shape[0], idx.data_ptr(), F,
+                                                           FEAT_DIM, SP_DIM, nz.xmin.data_ptr(), nz.xmax.data_ptr(),
+                                                           x.data_ptr(), y.data_ptr(),
+                                                           torch.cuda.current_stream(dev).cuda_stream),
+                    'gather_unpack_records')
         return x.view(F, 1, SP_DIM, 1), y        # NCHW [F,1,513,1] (analyzer.py:121-122)
 
 
 def read(file_pattern, batch_size, record_bytes=RECORD_BYTES, capacity=256, min_after_dequeue=128,
          num_threads=8, format='NCHW', normalizer=None, seed=0, rank=0, world=1):
-    """analyzer.py:90-135 signature; returns lazy (feature, speaker) handles."""
+    """analyzer.py:90-135 signature; returns lazy (feature, speaker) handles.  `capacity` and
+    `min_after_dequeue` bound the shuffle exactly like the reference's RandomShuffleQueue (BoundedShuffler);
+    `num_threads` is meaningless here (no reader threads: the records live in HBM)."""
+    if record_bytes != RECORD_BYTES:
+        raise ValueError('records are %d bytes' % RECORD_BYTES)
     files = sorted(glob.glob(file_pattern))
     if not files:
         raise FileNotFoundError('no files match %r' % file_pattern)
     recs = [np.fromfile(f, '<f4').reshape(-1, FEAT_DIM) for f in files]
-    store = FrameStore(np.concatenate(recs, 0), batch_size, normalizer, seed=seed, rank=rank, world=world)
+    store = FrameStore(np.concatenate(recs, 0), batch_size, normalizer, seed=seed, rank=rank, world=world,
+                       capacity=capacity, min_after_dequeue=min_after_dequeue, file_sizes=[len(r) for r in recs])
     return _Handle(store, 'feature'), _Handle(store, 'speaker')
+
+
+def write_bin(path, sp, ap, f0, en, speaker):
+    """One utterance in the reference's on-disk format (analyzer.py:39-47,62-72): rows of 1029
+    little-endian float32 = [sp(513) log10 energy-normalised | ap(513) | f0 | en | speaker id]."""
+    sp, ap = np.asarray(sp, np.float32), np.asarray(ap, np.float32)
+    n = sp.shape[0]
+    if sp.shape != (n, SP_DIM) or ap.shape != (n, SP_DIM):
+        raise ValueError('sp and ap must be [N, %d]' % SP_DIM)
+    spk = SPEAKERS.index(speaker) if isinstance(speaker, str) else int(speaker)
+    rows = np.concatenate([sp, ap, np.asarray(f0, np.float32).reshape(n, 1), np.asarray(en, np.float32).reshape(n, 1),
+                           np.full((n, 1), spk, np.float32)], axis=1).astype('<f4')
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, 'wb') as fp:
+        fp.write(rows.tobytes())
+    return rows
+
+
+def pw2wav_inputs(features, feat_dim=SP_DIM):
+    """The arrays analyzer.pw2wav (analyzer.py:160-185) hands to pyworld.synthesize(f0, sp, ap, fs): float64,
+    C-contiguous, sp de-normalised to the linear spectrum 10^sp * en.  Like the reference, the dict form
+    (what convert.py:105-112 passes) does the 10^sp * en arithmetic in the arrays' OWN dtype (float32 there)
+    and casts afterwards; the matrix form casts to float64 first.  Returns (f0, sp, ap)."""
+    if isinstance(features, dict):
+        en = np.reshape(features['en'], [-1, 1])
+        sp = en * np.power(10., features['sp'])
+        f0, ap = np.asarray(features['f0']), np.asarray(features['ap'])
+    else:
+        features = np.asarray(features).astype(np.float64)
+        ap = features[:, feat_dim:feat_dim * 2]
+        f0 = features[:, feat_dim * 2]
+        en = np.reshape(features[:, feat_dim * 2 + 1], [-1, 1])
+        sp = en * np.power(10., features[:, :feat_dim])
+    return (f0.astype(np.float64).copy(order='C'), sp.astype(np.float64).copy(order='C'),
+            ap.astype(np.float64).copy(order='C'))
+
+
+def pw2wav(features, feat_dim=SP_DIM, fs=16000):
+    """analyzer.py:160-185.  WORLD synthesis itself is the external pyworld C library (not in this image)."""
+    import pyworld as pw
+    f0, sp, ap = pw2wav_inputs(features, feat_dim)
+    return pw.synthesize(f0, sp, ap, fs)
 
 
 def read_whole_features(file_pattern, num_epochs=1):

@@ -92,24 +92,29 @@ def main(argv=None):
     os.makedirs(output_dir, exist_ok=True)
     trg_id = SPEAKERS.index(args.trg)
     try:
-        import pyworld as pw
+        import pyworld  # noqa: F401  (absent in this image: the features are saved instead of a wav)
         import soundfile as sf
+        have_world = True
     except ImportError:
-        pw = sf = None
+        sf, have_world = None, False
+    from analyzer import pw2wav
     for feat in read_whole_features(args.file_pattern.format(args.src)):
+        machine.engine.validate_ids(_ids(machine, feat['sp'].shape[0], trg_id))
         sp = convert_utterance(machine, normalizer, feat['sp'], trg_id).cpu().numpy()
         f0 = convert_f0(feat['f0'], args.src, args.trg)
         feat.update({'sp': sp, 'f0': f0})
-        if pw is not None:
-            # analyzer.pw2wav (analyzer.py:162-173): sp_lin = 10^sp * en, float64 C-contiguous
-            en = feat['en'].reshape(-1, 1).astype(np.float64)
-            sp_lin = np.ascontiguousarray(np.power(10., sp.astype(np.float64)) * en)
-            y = pw.synthesize(np.ascontiguousarray(f0.astype(np.float64)), sp_lin,
-                              np.ascontiguousarray(feat['ap'].astype(np.float64)), FS)
+        if have_world:
+            y = pw2wav(feat)                                               # convert.py:110-112
             sf.write(make_output_name(output_dir, feat['filename'], args.src, args.trg, 'wav'), y, FS)
         else:
             np.savez(make_output_name(output_dir, feat['filename'], args.src, args.trg, 'npz'),
                      sp=sp, f0=f0, ap=feat['ap'], en=feat['en'])
+    return output_dir
+
+
+def _ids(machine, n, trg_id):
+    import torch
+    return torch.full((max(1, n),), int(trg_id), dtype=torch.int64, device=machine.engine.device)
 
 
 if __name__ == '__main__':

@@ -4,17 +4,28 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 
 #include "kernels.h"
 
 using namespace vaenpvc;
 
+typedef std::pair<std::vector<Region>, int64_t> Layout;
 struct vaenpvc_ctx {
   Model m;
   int impl = VAENPVC_IMPL_AUTO;
-  std::mutex mu;
-  std::map<std::pair<int64_t, int>, std::pair<std::vector<Region>, int64_t>> ws_cache;
+  Runtime rt;                // every piece of mutable state besides the layout cache (runtime.h)
+  std::recursive_mutex mu;   // taken by every entry point that receives the context
+  std::map<std::pair<int64_t, int>, std::shared_ptr<const Layout>> ws_cache;
+};
+// lock + bind the context's Runtime to this thread for the duration of an entry point
+struct Call {
+  std::lock_guard<std::recursive_mutex> lk;
+  RtScope sc;
+  explicit Call(vaenpvc_ctx* c, bool launches = true) : lk(c->mu), sc(&c->rt) {
+    if (launches) c->rt.bind_device();
+  }
 };
 
 static thread_local char g_err[512] = "";
@@ -26,15 +37,16 @@ static int fail(int code, const char* f, ...) {
   return code;
 }
 
-static const std::pair<std::vector<Region>, int64_t>& layout_of(vaenpvc_ctx* c, int64_t F, int mode) {
-  std::lock_guard<std::mutex> lk(c->mu);
+// shared ownership: a layout handed out stays valid even if the cache is trimmed meanwhile
+static std::shared_ptr<const Layout> layout_of(vaenpvc_ctx* c, int64_t F, int mode) {
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
   auto key = std::make_pair(F, mode);
   auto it = c->ws_cache.find(key);
   if (it == c->ws_cache.end()) {
     if (c->ws_cache.size() > 64) c->ws_cache.clear();
     int64_t total = 0;
     auto regs = workspace_layout(c->m, F, mode, &total);
-    it = c->ws_cache.emplace(key, std::make_pair(std::move(regs), total)).first;
+    it = c->ws_cache.emplace(key, std::make_shared<const Layout>(std::move(regs), total)).first;
   }
   return it->second;
 }
@@ -42,7 +54,8 @@ static const std::pair<std::vector<Region>, int64_t>& layout_of(vaenpvc_ctx* c, 
 static int resolve(vaenpvc_ctx* c, int64_t F, int mode, void* d_ws, size_t ws_bytes, Ws* w) {
   if (F < 1) return fail(VAENPVC_E_ARG, "F must be >= 1 (got %lld)", (long long)F);
   if (F > (1LL << 18)) return fail(VAENPVC_E_ARG, "F too large (%lld > 262144 frames per call)", (long long)F);
-  const auto& lay = layout_of(c, F, mode);
+  const auto layp = layout_of(c, F, mode);
+  const Layout& lay = *layp;
   if (d_ws == nullptr || ws_bytes < (size_t)lay.second * 4)
     return fail(VAENPVC_E_WORKSPACE, "workspace too small: need %lld bytes, got %lld", (long long)lay.second * 4,
                 (long long)ws_bytes);
@@ -62,6 +75,7 @@ static int resolve(vaenpvc_ctx* c, int64_t F, int mode, void* d_ws, size_t ws_by
     else if (n == "z_mu") w->z_mu = p;
     else if (n == "z_lv") w->z_lv = p;
     else if (n == "z") w->z = p;
+    else if (n == "eps") w->eps = p;
     else if (n == "h") w->h = p;
     else if (n == "xh") w->xh = p;
     else if (n == "dec_y") w->dec_y = p;
@@ -91,58 +105,58 @@ static bool use_tuned(const vaenpvc_ctx* c) {
   return c->impl == VAENPVC_IMPL_AUTO && c->m.is_vcc2016 && tuned::available();
 }
 
-// ---- single-kernel event timer ---------------------------------------------------
-namespace vaenpvc {
-static std::string g_tag;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
-static size_t g_used = 0;
-static const size_t kPoolMax = 16384;
-bool timer_match(const char* tag) { return !g_tag.empty() && g_tag == tag; }
-void timer_begin(hipStream_t s) {
-  if (g_used >= kPoolMax) return;
-  if (g_used >= g_pool.size()) {
-    hipEvent_t a, b;
-    (void)hipEventCreate(&a);
-    (void)hipEventCreate(&b);
-    g_pool.emplace_back(a, b);
-  }
-  (void)hipEventRecord(g_pool[g_used].first, s);
-}
-void timer_end(hipStream_t s) {
-  if (g_used >= kPoolMax || g_used >= g_pool.size()) return;
-  (void)hipEventRecord(g_pool[g_used].second, s);
-  ++g_used;
-}
-}  // namespace vaenpvc
-
 extern "C" {
 
-int vaenpvc_set_tuned_masks(uint32_t fwd_mask, uint32_t bwd_mask) {
-  tuned::set_masks(fwd_mask, bwd_mask);
+int vaenpvc_set_tuned_masks(vaenpvc_ctx* ctx, uint32_t fwd_mask, uint32_t bwd_mask) {
+  if (!ctx) return fail(VAENPVC_E_ARG, "null context");
+  Call call(ctx, false);
+  ctx->rt.fwd_mask = fwd_mask;
+  ctx->rt.bwd_mask = bwd_mask;
   return 0;
 }
 
-int vaenpvc_timer_select(const char* tag) {
-  g_tag = tag ? tag : "";
-  g_used = 0;
+int vaenpvc_set_precision(vaenpvc_ctx* ctx, int planes) {
+  if (!ctx || planes < 1 || planes > 3) return fail(VAENPVC_E_ARG, "precision must be 1, 2 or 3 bf16 terms");
+  Call call(ctx, false);
+  ctx->rt.planes = planes;
+  return 0;
+}
+int vaenpvc_get_precision(const vaenpvc_ctx* ctx) { return ctx ? ctx->rt.planes : VAENPVC_E_ARG; }
+
+int vaenpvc_set_bucket_callback(vaenpvc_ctx* ctx, vaenpvc_bucket_cb cb, void* user) {
+  if (!ctx) return fail(VAENPVC_E_ARG, "null context");
+  Call call(ctx, false);
+  ctx->rt.bucket_cb = cb;
+  ctx->rt.bucket_user = user;
   return 0;
 }
 
-int vaenpvc_timer_read(double* total_ms, int64_t* launches) {
+int vaenpvc_timer_select(vaenpvc_ctx* ctx, const char* tag) {
+  if (!ctx) return fail(VAENPVC_E_ARG, "null context");
+  Call call(ctx, false);
+  ctx->rt.tag = tag ? tag : "";
+  ctx->rt.used = 0;
+  return 0;
+}
+
+int vaenpvc_timer_read(vaenpvc_ctx* ctx, double* total_ms, int64_t* launches) {
+  if (!ctx) return fail(VAENPVC_E_ARG, "null context");
+  Call call(ctx, false);
+  Runtime& r = ctx->rt;
   double tot = 0.0;
-  for (size_t i = 0; i < g_used; ++i) {
+  for (size_t i = 0; i < r.used; ++i) {
     float ms = 0.f;
-    if (hipEventSynchronize(g_pool[i].second) != hipSuccess) return fail(VAENPVC_E_HIP, "timer sync");
-    if (hipEventElapsedTime(&ms, g_pool[i].first, g_pool[i].second) != hipSuccess) return fail(VAENPVC_E_HIP, "timer elapsed");
+    if (hipEventSynchronize(r.pool[i].second) != hipSuccess) return fail(VAENPVC_E_HIP, "timer sync");
+    if (hipEventElapsedTime(&ms, r.pool[i].first, r.pool[i].second) != hipSuccess) return fail(VAENPVC_E_HIP, "timer elapsed");
     tot += ms;
   }
   if (total_ms) *total_ms = tot;
-  if (launches) *launches = (int64_t)g_used;
-  g_used = 0;
+  if (launches) *launches = (int64_t)r.used;
+  r.used = 0;
   return 0;
 }
 
-int vaenpvc_abi_version(void) { return 1; }
+int vaenpvc_abi_version(void) { return 2; }
 const char* vaenpvc_last_error(void) { return g_err; }
 
 int vaenpvc_ctx_create(const vaenpvc_arch* arch, vaenpvc_ctx** out) {
@@ -156,14 +170,28 @@ int vaenpvc_ctx_create(const vaenpvc_arch* arch, vaenpvc_ctx** out) {
   }
   const char* env = getenv("VAENPVC_IMPL");
   if (env && strcmp(env, "generic") == 0) c->impl = VAENPVC_IMPL_GENERIC;
+  c->rt.read_env();
   *out = c;
   return 0;
 }
 
-void vaenpvc_ctx_destroy(vaenpvc_ctx* ctx) { delete ctx; }
+void vaenpvc_ctx_destroy(vaenpvc_ctx* ctx) {
+  if (!ctx) return;
+  {
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    int cur = -1;
+    if (ctx->rt.device >= 0 && hipGetDevice(&cur) == hipSuccess) {
+      if (cur != ctx->rt.device) (void)hipSetDevice(ctx->rt.device);
+      ctx->rt.release();
+      if (cur != ctx->rt.device) (void)hipSetDevice(cur);
+    }
+  }
+  delete ctx;
+}
 
 int vaenpvc_set_impl(vaenpvc_ctx* ctx, int impl) {
   if (!ctx || (impl != VAENPVC_IMPL_AUTO && impl != VAENPVC_IMPL_GENERIC)) return fail(VAENPVC_E_ARG, "bad impl");
+  Call call(ctx, false);
   ctx->impl = impl;
   return 0;
 }
@@ -188,14 +216,14 @@ int vaenpvc_param_info(const vaenpvc_ctx* ctx, int index, char* name, int name_c
 
 int64_t vaenpvc_workspace_bytes(const vaenpvc_ctx* ctx, int64_t F, int mode) {
   if (!ctx || F < 1 || (mode != VAENPVC_MODE_INFER && mode != VAENPVC_MODE_TRAIN)) return fail(VAENPVC_E_ARG, "bad argument");
-  return layout_of(const_cast<vaenpvc_ctx*>(ctx), F, mode).second * 4;
+  return layout_of(const_cast<vaenpvc_ctx*>(ctx), F, mode)->second * 4;
 }
 
 int vaenpvc_ws_find(const vaenpvc_ctx* ctx, int64_t F, int mode, const char* name, int64_t* offset_floats,
                     int64_t* count_floats) {
   if (!ctx || !name || F < 1) return fail(VAENPVC_E_ARG, "bad argument");
-  const auto& lay = layout_of(const_cast<vaenpvc_ctx*>(ctx), F, mode);
-  for (const Region& r : lay.first)
+  const auto lay = layout_of(const_cast<vaenpvc_ctx*>(ctx), F, mode);
+  for (const Region& r : lay->first)
     if (r.name == name) {
       if (offset_floats) *offset_floats = r.offset;
       if (count_floats) *count_floats = r.count;
@@ -207,6 +235,7 @@ int vaenpvc_ws_find(const vaenpvc_ctx* ctx, int64_t F, int mode, const char* nam
 int vaenpvc_encode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, int64_t F, float* d_z_mu,
                        float* d_z_lv, void* d_ws, size_t ws_bytes, void* stream) {
   if (!ctx || !d_params || !d_x || !d_z_mu) return fail(VAENPVC_E_ARG, "null argument");
+  Call call(ctx);
   Ws w;
   int rc = resolve(ctx, F, VAENPVC_MODE_INFER, d_ws, ws_bytes, &w);
   if (rc) return rc;
@@ -222,6 +251,7 @@ int vaenpvc_encode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_x
 int vaenpvc_decode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_z, const int64_t* d_y, int64_t F,
                        float* d_xh, void* d_ws, size_t ws_bytes, void* stream) {
   if (!ctx || !d_params || !d_z || !d_y || !d_xh) return fail(VAENPVC_E_ARG, "null argument");
+  Call call(ctx);
   Ws w;
   int rc = resolve(ctx, F, VAENPVC_MODE_INFER, d_ws, ws_bytes, &w);
   if (rc) return rc;
@@ -231,39 +261,81 @@ int vaenpvc_decode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_z
   return check_launch("decode_fwd");
 }
 
-static int fwd_all(vaenpvc_ctx* ctx, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F,
-                   const Ws& w, bool want_grad, float* loss3, hipStream_t s) {
+static int fwd_all(vaenpvc_ctx* ctx, const float* P, const float* x, const int64_t* y, const float* eps,
+                   const PhiloxKey* key, int64_t F, const Ws& w, bool want_grad, float* loss3, hipStream_t s) {
   if (use_tuned(ctx)) tuned::encoder_fwd(ctx->m, P, x, F, w, s);
   else generic::encoder_fwd(ctx->m, P, x, F, w, s);
-  generic::reparam_fwd(ctx->m, eps, F, w, s);
+  generic::reparam_fwd(ctx->m, eps, key, F, w, s);
   if (use_tuned(ctx)) tuned::decoder_fwd(ctx->m, P, w.z, y, F, w, w.xh, s, /*weights_packed=*/true);
   else generic::decoder_fwd(ctx->m, P, w.z, y, F, w, w.xh, s);
   generic::loss_fwd(ctx->m, x, F, w, want_grad, loss3, s);
   return 0;
 }
 
-int vaenpvc_loss_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, const int64_t* d_y,
-                     const float* d_eps, int64_t F, float* d_loss3, void* d_ws, size_t ws_bytes, void* stream) {
-  if (!ctx || !d_params || !d_x || !d_y || !d_eps || !d_loss3) return fail(VAENPVC_E_ARG, "null argument");
+static PhiloxKey make_key(uint64_t seed, uint64_t offset, const int64_t* d_offset = nullptr) {
+  return PhiloxKey{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), d_offset};
+}
+
+static int loss_impl(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, const int64_t* d_y, const float* d_eps,
+                     const PhiloxKey* key, int64_t F, float* d_loss3, void* d_ws, size_t ws_bytes, void* stream) {
+  if (!ctx || !d_params || !d_x || !d_y || (!d_eps && !key) || !d_loss3) return fail(VAENPVC_E_ARG, "null argument");
+  Call call(ctx);
   Ws w;
   int rc = resolve(ctx, F, VAENPVC_MODE_INFER, d_ws, ws_bytes, &w);
   if (rc) return rc;
-  fwd_all(ctx, d_params, d_x, d_y, d_eps, F, w, false, d_loss3, (hipStream_t)stream);
+  fwd_all(ctx, d_params, d_x, d_y, d_eps, key, F, w, false, d_loss3, (hipStream_t)stream);
   return check_launch("loss_fwd");
+}
+
+int vaenpvc_loss_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, const int64_t* d_y,
+                     const float* d_eps, int64_t F, float* d_loss3, void* d_ws, size_t ws_bytes, void* stream) {
+  return loss_impl(ctx, d_params, d_x, d_y, d_eps, nullptr, F, d_loss3, d_ws, ws_bytes, stream);
+}
+int vaenpvc_loss_fwd_seeded(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, const int64_t* d_y,
+                            uint64_t seed, uint64_t offset, int64_t F, float* d_loss3, void* d_ws, size_t ws_bytes,
+                            void* stream) {
+  PhiloxKey k = make_key(seed, offset);
+  return loss_impl(ctx, d_params, d_x, d_y, nullptr, &k, F, d_loss3, d_ws, ws_bytes, stream);
+}
+
+static int train_impl(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, const int64_t* d_y,
+                      const float* d_eps, const PhiloxKey* key, int64_t F, float* d_grads, float* d_loss3, void* d_ws,
+                      size_t ws_bytes, void* stream) {
+  if (!ctx || !d_params || !d_x || !d_y || (!d_eps && !key) || !d_grads || !d_loss3) return fail(VAENPVC_E_ARG, "null argument");
+  Call call(ctx);
+  Ws w;
+  int rc = resolve(ctx, F, VAENPVC_MODE_TRAIN, d_ws, ws_bytes, &w);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  fwd_all(ctx, d_params, d_x, d_y, d_eps, key, F, w, true, d_loss3, s);
+  const float* eps_bwd = key ? w.eps : d_eps;   // (the seeded sampler stored its draw in the workspace)
+  ctx->rt.bucket_next = 0;
+  if (use_tuned(ctx)) {
+    tuned::backward(ctx->m, d_params, d_x, d_y, eps_bwd, F, w, d_grads, s);
+  } else {
+    generic::backward(ctx->m, d_params, d_x, d_y, eps_bwd, F, w, d_grads, s);
+    if (ctx->rt.bucket_cb)  // the generic path finishes everything at once: one bucket
+      ctx->rt.bucket_cb(ctx->rt.bucket_user, 0, 0, ctx->m.n_params, (void*)s);
+  }
+  return check_launch("train_fwd_bwd");
 }
 
 int vaenpvc_train_fwd_bwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, const int64_t* d_y,
                           const float* d_eps, int64_t F, float* d_grads, float* d_loss3, void* d_ws,
                           size_t ws_bytes, void* stream) {
-  if (!ctx || !d_params || !d_x || !d_y || !d_eps || !d_grads || !d_loss3) return fail(VAENPVC_E_ARG, "null argument");
-  Ws w;
-  int rc = resolve(ctx, F, VAENPVC_MODE_TRAIN, d_ws, ws_bytes, &w);
-  if (rc) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  fwd_all(ctx, d_params, d_x, d_y, d_eps, F, w, true, d_loss3, s);
-  if (use_tuned(ctx)) tuned::backward(ctx->m, d_params, d_x, d_y, d_eps, F, w, d_grads, s);
-  else generic::backward(ctx->m, d_params, d_x, d_y, d_eps, F, w, d_grads, s);
-  return check_launch("train_fwd_bwd");
+  return train_impl(ctx, d_params, d_x, d_y, d_eps, nullptr, F, d_grads, d_loss3, d_ws, ws_bytes, stream);
+}
+int vaenpvc_train_fwd_bwd_seeded(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, const int64_t* d_y,
+                                 uint64_t seed, uint64_t offset, const int64_t* d_offset, int64_t F, float* d_grads,
+                                 float* d_loss3, void* d_ws, size_t ws_bytes, void* stream) {
+  PhiloxKey k = make_key(seed, offset, d_offset);
+  return train_impl(ctx, d_params, d_x, d_y, nullptr, &k, F, d_grads, d_loss3, d_ws, ws_bytes, stream);
+}
+
+int vaenpvc_philox_normal(uint64_t seed, uint64_t offset, float* d_out, int64_t n, void* stream) {
+  if (!d_out || n < 1) return fail(VAENPVC_E_ARG, "bad argument");
+  launch_philox_normal(d_out, n, make_key(seed, offset), (hipStream_t)stream);
+  return check_launch("philox_normal");
 }
 
 int vaenpvc_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n, int64_t step,
@@ -300,8 +372,36 @@ int vaenpvc_unpack_records(const float* d_records, int64_t F, int32_t rec_floats
                            const float* d_xmax, float* d_x, int64_t* d_y, void* stream) {
   if (!d_records || !d_xmin || !d_xmax || !d_x || !d_y || F < 1 || H < 1 || rec_floats < H + 1)
     return fail(VAENPVC_E_ARG, "bad argument");
-  launch_unpack(d_records, F, rec_floats, H, d_xmin, d_xmax, d_x, d_y, (hipStream_t)stream);
+  launch_unpack(d_records, nullptr, F, rec_floats, H, d_xmin, d_xmax, d_x, d_y, (hipStream_t)stream);
   return check_launch("unpack_records");
+}
+
+int vaenpvc_gather_unpack_records(const float* d_records, int64_t n_records, const int64_t* d_index, int64_t F,
+                                  int32_t rec_floats, int32_t H, const float* d_xmin, const float* d_xmax, float* d_x,
+                                  int64_t* d_y, void* stream) {
+  if (!d_records || !d_index || !d_xmin || !d_xmax || !d_x || !d_y || F < 1 || n_records < 1 || H < 1 || rec_floats < H + 1)
+    return fail(VAENPVC_E_ARG, "bad argument");
+  launch_unpack(d_records, d_index, F, rec_floats, H, d_xmin, d_xmax, d_x, d_y, (hipStream_t)stream);
+  return check_launch("gather_unpack_records");
+}
+
+int vaenpvc_validate_ids(const vaenpvc_ctx* ctx, const int64_t* d_y, int64_t F, int32_t* d_flag, void* stream) {
+  if (!ctx || !d_y || !d_flag || F < 1) return fail(VAENPVC_E_ARG, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  int32_t bad = 0;
+  launch_check_ids(d_y, F, ctx->m.ny, d_flag, s);
+  if (hipMemcpyAsync(&bad, d_flag, sizeof bad, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    return fail(VAENPVC_E_HIP, "validate_ids: copy");
+  if (bad) return fail(VAENPVC_E_ARG, "%d speaker id(s) outside [0, %d)", (int)bad, ctx->m.ny);
+  return check_launch("validate_ids");
+}
+
+int vaenpvc_summary(const float* d_data, int64_t n, const float* d_edges, int32_t n_edges, double* d_stats,
+                    uint64_t* d_counts, void* stream) {
+  if (!d_data || !d_edges || !d_stats || !d_counts || n < 1 || n_edges < 1 || n_edges > 2048)
+    return fail(VAENPVC_E_ARG, "bad argument");
+  launch_summary(d_data, n, d_edges, n_edges, d_stats, reinterpret_cast<unsigned long long*>(d_counts), (hipStream_t)stream);
+  return check_launch("summary");
 }
 
 }  // extern "C"

@@ -117,15 +117,25 @@ __global__ void k_heads_fwd(const float* __restrict__ a, Act ai, int hlast, cons
 }
 
 // util/layers.py:152-156 sampler and 170-183 KL (mu2 = lv2 = 0), one block per frame
+// eps: injected draw, or (key != nullptr) drawn here with Philox and stored to eps_out for the backward pass
 __global__ void k_reparam(const float* __restrict__ zmu, const float* __restrict__ zlv,
-                          const float* __restrict__ eps, float* __restrict__ z, float* __restrict__ kl_f, int zd) {
+                          const float* __restrict__ eps, float* __restrict__ z, float* __restrict__ kl_f, int zd,
+                          PhiloxKey key, int draw, float* __restrict__ eps_out) {
   __shared__ float sm[16];
   int64_t f = blockIdx.x;
   float kl = 0.f;
+  if (draw) key = philox_resolve(key);
   for (int d = threadIdx.x; d < zd; d += blockDim.x) {
     float mu = zmu[f * zd + d], lv = zlv[f * zd + d];
     float v = expf(lv);
-    z[f * zd + d] = eps ? mu + eps[f * zd + d] * sqrtf(v) : mu;
+    float e = 0.f;
+    if (draw) {
+      e = philox_normal(key, (uint64_t)(f * zd + d));
+      eps_out[f * zd + d] = e;
+    } else if (eps) {
+      e = eps[f * zd + d];
+    }
+    z[f * zd + d] = (draw || eps) ? mu + e * sqrtf(v) : mu;
     kl += 0.5f * ((0.f - lv) + (v + mu * mu) / (1.0f + EPSILON) - 1.0f);
   }
   kl = block_sum(kl, sm);
@@ -491,8 +501,10 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F, cons
   heads_fwd(m, P, F, w, s);
 }
 
-void reparam_fwd(const Model& m, const float* eps, int64_t F, const Ws& w, hipStream_t s) {
-  hipLaunchKernelGGL(k_reparam, dim3((unsigned)F), dim3(128), 0, s, w.z_mu, w.z_lv, eps, w.z, w.kl_f, m.z);
+void reparam_fwd(const Model& m, const float* eps, const PhiloxKey* key, int64_t F, const Ws& w, hipStream_t s) {
+  PhiloxKey k = key ? *key : PhiloxKey{0, 0, 0, 0, nullptr};
+  hipLaunchKernelGGL(k_reparam, dim3((unsigned)F), dim3(128), 0, s, w.z_mu, w.z_lv, eps, w.z, w.kl_f, m.z, k,
+                     key ? 1 : 0, w.eps);
 }
 
 void merge_fwd(const Model& m, const float* P, const float* z, const int64_t* y, int64_t F, const Ws& w, hipStream_t s) {

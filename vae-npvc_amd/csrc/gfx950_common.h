@@ -7,6 +7,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "runtime.h"
+
 namespace vaenpvc {
 namespace tuned {
 

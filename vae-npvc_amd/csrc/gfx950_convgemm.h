@@ -429,17 +429,16 @@ __global__ void __launch_bounds__(C::NTHR, C::WPE) k_convgemm(ConvArgs a) {
 
 template <class C>
 inline void launch_convgemm(const ConvArgs& a, int nsplit, hipStream_t s) {
-  static int per_cu = 0;
-  if (!per_cu) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convgemm<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              C::LDS_BYTES);
-    // persistent grid: exactly as many workgroups as are resident at once (LDS- or VGPR-bound)
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_convgemm<C>), C::LDS_BYTES);
+  // persistent grid: exactly as many workgroups as are resident at once (LDS- or VGPR-bound); a property of
+  // the kernel binary, queried once (thread-safe static initialisation)
+  static const int per_cu = [] {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&k_convgemm<C>), C::NTHR,
                                                      C::LDS_BYTES) != hipSuccess || n < 1)
       n = 1;
-    per_cu = n;
-  }
+    return n;
+  }();
   const int resident = cmax(1, 256 * per_cu / nsplit);
   dim3 grid((unsigned)cmin_(cdiv(a.F, C::TF), resident), (unsigned)nsplit);
 #if VAENPVC_PROF

@@ -298,15 +298,8 @@ template <class C>
 inline void launch_convwgrad(const WgArgs& a0, int target_wgs, hipStream_t s) {
   constexpr int LDS_BYTES = (C::XT + C::YT) * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "operand tiles exceed the LDS of a CU");
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convwgrad<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              LDS_BYTES);
-    once = true;
-  }
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_convwgrad<C>), LDS_BYTES);
   WgArgs a = a0;
-  static const int env_wgs = getenv("VAENPVC_WGS") ? atoi(getenv("VAENPVC_WGS")) : 0;  // developer knob
-  if (env_wgs > 0) target_wgs = env_wgs;
   int chunks = cmax(1, target_wgs / C::NSPLIT);
   a.fchunk = rup(cmax(1, cdiv(a.F, chunks)), C::TF);
   dim3 grid((unsigned)cdiv(a.F, a.fchunk), (unsigned)C::NSPLIT);

@@ -207,12 +207,7 @@ __global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
 
 template <class C>
 inline void launch_densegemm(const DenseArgs& a, hipStream_t s) {
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_densegemm<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              C::LDS_BYTES);
-    once = true;
-  }
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_densegemm<C>), C::LDS_BYTES);
   dim3 grid((unsigned)cdiv(a.F, C::ROWS), (unsigned)C::NSPLIT);
   hipLaunchKernelGGL(k_densegemm<C>, grid, dim3(256), C::LDS_BYTES, s, a);
 }

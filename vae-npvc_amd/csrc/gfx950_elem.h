@@ -310,12 +310,7 @@ template <class L>
 inline void launch_ln_bwd(const float* dy, const float* a, const float* st, const float* gamma, const float* beta,
                           float* da, float* dgamma, float* dbeta, float* dbias, float* part, int F, int target_wgs,
                           hipStream_t s) {
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_bwd_fused<L>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES);
-    once = true;
-  }
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_ln_bwd_fused<L>), L::LDS_BYTES);
   int fchunk = cmax(1, cdiv(F, target_wgs));
   int nwg = cdiv(F, fchunk);
   hipLaunchKernelGGL(k_ln_bwd_fused<L>, dim3((unsigned)nwg), dim3(256), L::LDS_BYTES, s, dy, a, st, gamma, beta, da, part, F,

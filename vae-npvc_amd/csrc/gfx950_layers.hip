@@ -12,6 +12,7 @@
 //   backward steps = autodiff of the same    trainer/vae.py:24
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "gfx950_convgemm.h"
 #include "gfx950_convwgrad.h"
@@ -175,40 +176,31 @@ static_assert(E1F::BTOTAL == 7 * 16 * 32 && E2F::BTOTAL == 7 * 32 * 64 && E3F::B
                   E4F::BTOTAL == 7 * 128 * 256 && GD1::BTOTAL == 7 * 16 * 32,
               "direct-use layers must not be padded");
 
-// VAENPVC_TOEP=f32 selects the exact-fp32 MFMA kernels of the last decoder layer instead of the
-// bf16x3 ones (same results to fp32 accuracy; kept for A/B measurements)
-static bool toep_bf16() {
-  static const bool v = !(getenv("VAENPVC_TOEP") && !strcmp(getenv("VAENPVC_TOEP"), "f32"));
-  return v;
-}
-static unsigned g_fwd_mask = 0xffffffffu, g_bwd_mask = 0xffffffffu;
+// Kernel selection lives in the calling context's Runtime (runtime.h): no process-global state.
+//   rt().toep_f32 (VAENPVC_TOEP=f32 at context creation) selects the exact-fp32 MFMA kernels of the last decoder
+//   layer instead of the bf16-split ones (kept for A/B measurements).
 // The bf16 kernels own 64 frames per workgroup: below ~8k frames they cannot fill the chip and the
 // fp32 kernels (32 frames per workgroup, bins split over more workgroups) are faster.  Clearing bit 30
 // of the forward mask forces them at any batch size (parity tests).
 constexpr int64_t TOEP_BF16_MIN_FRAMES = 8192;
-static bool toep_bf16_for(int64_t F) { return toep_bf16() && (F >= TOEP_BF16_MIN_FRAMES || !((g_fwd_mask >> 30) & 1u)); }
-static inline bool fwd_on(int bit);
-// the weight gradient of that layer reads both operands as bf16 planes (then the fp32 copy of y is not stored)
-static bool toep_wgrad_bf16_for(int64_t F) {
-  static const bool f32 = getenv("VAENPVC_TOEP_WGRAD_F32") != nullptr;
-  return toep_bf16_for(F) && fwd_on(9) && fwd_on(10) && !f32;
-}
-static bool g_env_read = false;
-static void read_env() {
-  if (g_env_read) return;
-  g_env_read = true;
-  if (const char* e = getenv("VAENPVC_FWD_MASK")) g_fwd_mask = (unsigned)strtoul(e, nullptr, 0);
-  if (const char* e = getenv("VAENPVC_BWD_MASK")) g_bwd_mask = (unsigned)strtoul(e, nullptr, 0);
-}
-void set_masks(unsigned fwd, unsigned bwd) {
-  g_env_read = true;
-  g_fwd_mask = fwd;
-  g_bwd_mask = bwd;
-}
 bool available() { return true; }
-static inline bool fwd_on(int bit) { return (g_fwd_mask >> bit) & 1u; }
-static inline bool bwd_on(int bit) { return (g_bwd_mask >> bit) & 1u; }
+static inline bool fwd_on(int bit) { return (rt().fwd_mask >> bit) & 1u; }
+static inline bool bwd_on(int bit) { return (rt().bwd_mask >> bit) & 1u; }
+static bool toep_bf16_for(int64_t F) { return !rt().toep_f32 && (F >= TOEP_BF16_MIN_FRAMES || !fwd_on(30)); }
+// the weight gradient of that layer reads both operands as bf16 planes (then the fp32 copy of y is not stored)
+static bool toep_wgrad_bf16_for(int64_t F) { return toep_bf16_for(F) && fwd_on(9) && fwd_on(10) && !rt().toep_wgrad_f32; }
+static inline void read_env() {}
 
+
+// dispatch on the context's operand precision: fn(std::integral_constant<int, NPL>)
+template <class Fn>
+static void for_planes(Fn&& fn) {
+  switch (rt().planes) {
+    case 1: fn(std::integral_constant<int, 1>{}); break;
+    case 3: fn(std::integral_constant<int, 3>{}); break;
+    default: fn(std::integral_constant<int, 2>{}); break;
+  }
+}
 
 struct PackSum3 {
   const float *a, *b, *c;
@@ -221,6 +213,8 @@ static void prep(const Model& m, const float* P, const Ws& w, hipStream_t s) {
   float* S = w.scratch;
   constexpr int NTB = TB_C * TB_CPY * 8 * TB_CHUNKS;
   // one launch for all packed copies (see k_pack_multi)
+  for_planes([&](auto npl) {
+  constexpr int NPL = decltype(npl)::value;
   launch_pack_multi(
       s,
       pack_job(PackDense{P + m.wmu_off, P + m.wlv_off, 0, 768, 256, HeadsF::NP, 128, 128}, S + Pk::heads_f, HeadsF::KP * HeadsF::NP),
@@ -243,8 +237,9 @@ static void prep(const Model& m, const float* P, const Ws& w, hipStream_t s) {
       pack_job(PackConv<GE1>{P + m.enc[1].w_off, true}, S + Pk::ge1, GE1::BTOTAL),
       pack_job(PackToep{P + m.dec[3].w_off}, S + Pk::wc, TOEP_C * WROW),
       // shifted bf16 tap copies of the last layer (count 0 = skipped when the fp32 kernels are selected)
-      PackToepBf16Job<false>{P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wdg), toep_bf16() ? NTB : 0},
-      PackToepBf16Job<true>{P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wfw), toep_bf16() ? NTB : 0});
+      PackToepBf16Job<false, NPL>{P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wdg), !rt().toep_f32 ? NTB : 0},
+      PackToepBf16Job<true, NPL>{P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wfw), !rt().toep_f32 ? NTB : 0});
+  });
 }
 
 template <int N>
@@ -344,9 +339,11 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
                                                                 P + m.dec[1].beta_off, w.scratch + Pk::d2f,
                                                                 P + m.dec[2].b_off, w.dec_a[2], F), nsplit_for<D2F>(F), s));
     if (toep_bf16_for(F) && fwd_on(10))
-      hipLaunchKernelGGL(k_ln_stats_act_planes, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
-                         P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, reinterpret_cast<unsigned short*>(w.toep_yp),
-                         w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, (int)F, toep_wgrad_bf16_for(F) ? 0 : 1);
+      for_planes([&](auto npl) {
+        hipLaunchKernelGGL(k_ln_stats_act_planes<decltype(npl)::value>, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
+                           P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, reinterpret_cast<unsigned short*>(w.toep_yp),
+                           w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, (int)F, toep_wgrad_bf16_for(F) ? 0 : 1);
+      });
     else
       hipLaunchKernelGGL((k_ln_stats_act<4104, 513>), dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
                          P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, F);
@@ -357,22 +354,17 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
                        P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, tot, 4104, 513);
   }
   if (fwd_on(10)) {
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_fwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS);
-      once = true;
-    }
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_fwd<4>), TF_LDS);
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_fwd<1>), TF_LDS);
     if (toep_bf16_for(F) && fwd_on(9)) {  // (the planes come from the tuned layer-9 epilogue kernel)
-      static bool once2 = false;
-      if (!once2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_gemm_bf16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS);
-        once2 = true;
-      }
-      VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL(k_toep_gemm_bf16<true>, dim3((unsigned)cdiv(F, DG_M)), dim3(256), DG_LDS, s,
-                                                      reinterpret_cast<const unsigned short*>(w.toep_yp),
-                                                      reinterpret_cast<const unsigned short*>(w.scratch + Pk::wfw),
-                                                      P + m.dec[3].b_off, xh_out, (int)F));
+      for_planes([&](auto npl) {
+        constexpr int NPL = decltype(npl)::value;
+        rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_gemm_bf16<true, NPL>), dg_lds(NPL));
+        VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL((k_toep_gemm_bf16<true, NPL>), dim3((unsigned)cdiv(F, DG_M)), dim3(256), dg_lds(NPL), s,
+                                                        reinterpret_cast<const unsigned short*>(w.toep_yp),
+                                                        reinterpret_cast<const unsigned short*>(w.scratch + Pk::wfw),
+                                                        P + m.dec[3].b_off, xh_out, (int)F));
+      });
     } else
     if (F >= 2048) {
       VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL(k_toep_fwd<4>, dim3((unsigned)cdiv(F, 32), 1), dim3(256), TF_LDS, s, w.dec_y,
@@ -409,30 +401,8 @@ static TnArgs tn_args(const float* X, int ldx, const float* Y, int ldy, int M, i
 // on that chain.  They are forked onto a second stream (event fork at the point where their
 // gradient tensor is complete, one join at the end) so that they fill the MFMA pipes and the
 // kernel tails the chain leaves idle.  VAENPVC_SIDE_STREAM=0 disables the fork.
-struct Side {
-  hipStream_t s2 = nullptr;
-  hipEvent_t ev[16];
-  int next = 0;
-  bool enabled = true;
-  bool init() {
-    if (s2) return enabled;
-    const char* e = getenv("VAENPVC_SIDE_STREAM");
-    enabled = !(e && e[0] == '0');
-    if (!enabled) return false;
-    if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { enabled = false; return false; }
-    for (auto& x : ev) (void)hipEventCreateWithFlags(&x, hipEventDisableTiming);
-    return true;
-  }
-};
-static Side g_side;
-// make `to` wait for everything enqueued on `from` so far
-static void stream_dep(hipStream_t from, hipStream_t to) {
-  hipEvent_t e = g_side.ev[g_side.next];
-  g_side.next = (g_side.next + 1) % 16;
-  (void)hipEventRecord(e, from);
-  (void)hipStreamWaitEvent(to, e, 0);
-}
-
+// The stream and its event ring belong to the context (Runtime::side_stream, created lazily on the context's
+// device, destroyed with it).
 static int kchunks_for(int F, int tiles) { return cmax(1, cmin_(cdiv(F, 64), 512 / tiles)); }  // 2 workgroups (64 KB LDS) per CU
 
 void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F64,
@@ -442,15 +412,26 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   (void)hipMemsetAsync(G, 0, (size_t)m.n_params * 4, s);
   // (bit 30 of the backward mask cleared = no fork for this call: serialised kernels, used by bench.py to
   //  time single kernels without concurrent neighbours)
-  const bool fork = g_side.init() && ((g_bwd_mask >> 30) & 1u);
-  hipStream_t s2 = fork ? g_side.s2 : s;   // weight-gradient stream
-  auto ready = [&]() { if (fork) stream_dep(s, s2); };   // "the tensors produced so far on s are ready for s2"
+  hipStream_t side = bwd_on(30) ? rt().side_stream() : nullptr;
+  const bool fork = side != nullptr;
+  hipStream_t s2 = fork ? side : s;   // weight-gradient stream
+  auto ready = [&]() { if (fork) rt().stream_dep(s, s2); };   // "the tensors produced so far on s are ready for s2"
+  // gradient range [off, end) of the flat buffer is complete once everything enqueued so far has run: hand it to
+  // the data-parallel host (vaenpvc_set_bucket_callback) on the weight-gradient stream, which then holds all of it
+  auto bucket = [&](int64_t off, int64_t end) {
+    Runtime& r = rt();
+    if (!r.bucket_cb) return;
+    ready();
+    r.bucket_cb(r.bucket_user, r.bucket_next++, off, end - off, (void*)s2);
+  };
   // one pass over d(xh) for the bf16 kernels of the last layer: its three planes (operand of the input-gradient
   // and weight-gradient GEMMs), column 512 of the input gradient, the bias gradient
   const bool toep_planes = bwd_on(10) && toep_bf16_for(F);
   if (toep_planes)
-    hipLaunchKernelGGL(k_dxh_post, dim3((unsigned)cmin_(2048, cdiv((int)F, 4))), dim3(256), 0, s, w.d_xh, P + m.dec[3].w_off,
-                       reinterpret_cast<unsigned short*>(w.toep_gp), w.dy_tmp, G + m.dec[3].b_off, (int)F);
+    for_planes([&](auto npl) {
+      hipLaunchKernelGGL(k_dxh_post<decltype(npl)::value>, dim3((unsigned)cmin_(2048, cdiv((int)F, 4))), dim3(256), 0, s, w.d_xh, P + m.dec[3].w_off,
+                         reinterpret_cast<unsigned short*>(w.toep_gp), w.dy_tmp, G + m.dec[3].b_off, (int)F);
+    });
   ready();
   bool dec_bias_done[4] = {false, false, false, false};
   bool enc_bias_done[5] = {false, false, false, false, false};
@@ -463,16 +444,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const ConvL& l2 = m.dec[2];
     if (toep_wgrad_bf16_for(F)) {
       // bf16 planes of both operands exist (forward producer, k_dxh_post above)
-      static bool once3 = false;
-      if (!once3) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_wgrad_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS);
-        once3 = true;
-      }
       unsigned short* gp = reinterpret_cast<unsigned short*>(w.toep_gp);
       const int zc = (int)cmax(1, cmin_(8, cdiv(F, 1024)));  // 8 x 8 x zc workgroups (512 at F >= 8192)
       const int fch = rup(cdiv((int)F, zc), WG_KF);
-      VAENPVC_TIMED("dec3_wgrad", s2, hipLaunchKernelGGL(k_toep_wgrad_bf16, dim3(8, TB_C, (unsigned)cdiv((int)F, fch)), dim3(512), WG_LDS, s2,
-                                                        reinterpret_cast<const unsigned short*>(w.toep_yp), gp, G + m.dec[3].w_off, (int)F, fch));
+      for_planes([&](auto npl) {
+        constexpr int NPL = decltype(npl)::value;
+        rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_wgrad_bf16<NPL>), wg_lds(NPL));
+        VAENPVC_TIMED("dec3_wgrad", s2, hipLaunchKernelGGL(k_toep_wgrad_bf16<NPL>, dim3(8, TB_C, (unsigned)cdiv((int)F, fch)), dim3(512), wg_lds(NPL), s2,
+                                                          reinterpret_cast<const unsigned short*>(w.toep_yp), gp, G + m.dec[3].w_off, (int)F, fch));
+      });
     } else {
       TnArgs a = tn_args(w.dec_y, 4104, w.d_xh, 513, 4096, 512, F, G + m.dec[3].w_off, 0);
       VAENPVC_TIMED("dec3_wgrad", s2, launch_tngemm(a, true, kchunks_for(F, 32 * 4), s2));
@@ -483,22 +463,17 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     if (!toep_planes)  // (k_dxh_post computed it)
       hipLaunchKernelGGL(k_sum_all_atomic, dim3((unsigned)cmin_(1024, cdiv(F * 513, 1024))), dim3(256), 0, s2, w.d_xh,
                          (int64_t)F * 513, G + m.dec[3].b_off);
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_dgrad<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_dgrad<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_LDS);
-      once = true;
-    }
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_dgrad<8, 8>), TD_LDS);
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_dgrad<1, 4>), TD_LDS);
     if (toep_bf16_for(F)) {
-      static bool once2 = false;
-      if (!once2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_toep_gemm_bf16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS);
-        once2 = true;
-      }
       unsigned short* gp = reinterpret_cast<unsigned short*>(w.toep_gp);
-      VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL(k_toep_gemm_bf16<false>, dim3((unsigned)cdiv(F, DG_M)), dim3(256), DG_LDS, s, gp,
-                                                        reinterpret_cast<const unsigned short*>(w.scratch + Pk::wdg), (const float*)nullptr,
-                                                        w.dy_tmp, (int)F));  // (column 512: k_dxh_post)
+      for_planes([&](auto npl) {
+        constexpr int NPL = decltype(npl)::value;
+        rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_gemm_bf16<false, NPL>), dg_lds(NPL));
+        VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL((k_toep_gemm_bf16<false, NPL>), dim3((unsigned)cdiv(F, DG_M)), dim3(256), dg_lds(NPL), s, gp,
+                                                          reinterpret_cast<const unsigned short*>(w.scratch + Pk::wdg), (const float*)nullptr,
+                                                          w.dy_tmp, (int)F));  // (column 512: k_dxh_post)
+      });
     } else
     if (F >= 8192) {
       VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL((k_toep_dgrad<8, 8>), dim3((unsigned)cdiv(F, 32), 1), dim3(512), TD_LDS, s, w.d_xh,
@@ -553,6 +528,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
                                                                   nullptr, w.d_h, F), nsplit_for<GD0s>(F), s) : launch_convgemm<GD0>(conv_args(w.d_dec_a[0], nullptr, nullptr, nullptr, w.scratch + Pk::gd0,
                                                                   nullptr, w.d_h, F), nsplit_for<GD0>(F), s)));
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 0);
+  bucket(m.dec[0].w_off, m.n_params);  // all decoder conv layers (kernels, biases, LayerNorm parameters)
 
   // ---- merge + embedding
   if (bwd_on(6)) {
@@ -572,6 +548,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     hipLaunchKernelGGL(k_emb_grad_fast, dim3((unsigned)cdiv(F, efc)), dim3(256), (size_t)m.ny * m.z * 4, s, w.d_e, 128, 0, y,
                        G + m.emb_off, F, efc, m.z, m.ny);
   } else generic::bwd_merge(m, P, y, F, w, G, s);
+  bucket(m.wz_off, m.dec[0].w_off);  // the two merge FCs and the three merge biases (the embedding goes last)
 
   const bool heads_tuned = bwd_on(5);
   if (heads_tuned) {  // sampler + KL backward fused with the two head-bias gradients
@@ -601,6 +578,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
                                      G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
     enc_bias_done[4] = true;
   } else generic::bwd_heads(m, P, F, w, G, s);
+  bucket(m.wmu_off, m.wz_off);  // the two dense heads
 
   // ---- encoder convs
   auto wg_enc = [&](int i) {
@@ -661,7 +639,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc0_wgrad", s2, launch_convwgrad<WE0>(a, WGS, s2));
     if (!enc_bias_done[0]) generic::bias_grad(w.d_enc_a[0], G + l.b_off, F, l.cout, l.hout, s);
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 0);
-  if (fork) stream_dep(s2, s);  // join: everything after backward (Adam) sees all gradients
+  bucket(0, m.wmu_off);  // speaker embedding + encoder convs
+  if (fork) rt().stream_dep(s2, s);  // join: everything after backward (Adam) sees all gradients
 }
 
 }  // namespace tuned

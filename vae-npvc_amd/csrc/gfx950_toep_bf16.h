@@ -1,13 +1,15 @@
 // gfx950_toep_bf16.h -- the 1025-tap last decoder layer on the bf16 matrix cores at fp32 accuracy.
 //
 // v_mfma_f32_32x32x16_bf16 runs 16x the MAC rate of the exact-fp32 v_mfma_f32_32x32x2_f32.  Every
-// fp32 operand x is split into three bf16 terms x = hi + mid + lo (8 + 8 + 8 mantissa bits, the
-// split is exact) and a product keeps the six term pairs of weight <= 2:
-//     a*b ~= a_lo*b_hi + a_mid*b_mid + a_hi*b_lo + a_mid*b_hi + a_hi*b_mid + a_hi*b_hi
-// (dropped terms are <= 2^-24 relative), accumulated in fp32 inside the MFMA.  Measured against an
-// fp64 reference (scripts/microbench/bf16x3.hip, K = 4112): max error 1.3e-6 of max|C| -- better
-// than a sequential fp32 fma chain (2.3e-6).  Six bf16 MFMAs replace eight fp32 MFMAs of the same
-// tile => 2.67x the fp32-MFMA peak.
+// fp32 operand x is split into NPL bf16 terms (planes), x = t0 + t1 (+ t2), 8 mantissa bits each, and a
+// product keeps the term pairs (i, j) with i + j < NPL, accumulated in fp32 inside the MFMA:
+//   NPL = 3: six products (dropped terms <= 2^-24 relative): fp32-exact, measured 1.3e-6 of max|C| at K = 4112
+//            against fp64 (scripts/microbench/bf16x3.hip) -- better than a sequential fp32 fma chain (2.3e-6);
+//            6 bf16 MFMAs replace 8 fp32 MFMAs of the same tile => 2.67x the fp32-MFMA peak;
+//   NPL = 2: three products, operands carry 16 mantissa bits (relative error <= 2^-17 per operand):
+//            ~1e-5 of max|C|, inside the 1e-4 parity bar; 5.3x the fp32-MFMA peak.  The default;
+//   NPL = 1: plain bf16 operands with fp32 accumulation (the bf16 training mode, BASELINE config 2).
+// Selected per context (vaenpvc_set_precision).
 //
 // Toeplitz operand.  The weight matrix of this layer is T[k][n] = w[c][k - n + 512] (input-gradient
 // direction: k = output bin p, n = input bin i).  A B fragment of the MFMA (lane: column n0+l31,
@@ -51,13 +53,37 @@ __device__ __forceinline__ unsigned bf16_rn(float x) {  // round to nearest even
   u += 0x7fffu + ((u >> 16) & 1u);
   return u >> 16;
 }
-__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-  h = bf16_rn(x);
-  float r = x - __uint_as_float(h << 16);
-  m = bf16_rn(r);
-  r = r - __uint_as_float(m << 16);
-  l = bf16_rn(r);
+// x = t[0] + t[1] + ... (each term the bf16 rounding of what the previous terms left over)
+template <int NPL>
+__device__ __forceinline__ void split_n(float x, unsigned (&t)[NPL]) {
+  float r = x;
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) {
+    t[p] = bf16_rn(r);
+    if (p + 1 < NPL) r = r - __uint_as_float(t[p] << 16);
+  }
 }
+// term pairs (plane of A, plane of B) kept by a product, smallest first
+template <int NPL>
+struct Prod;
+template <>
+struct Prod<3> {
+  static constexpr int N = 6;
+  static constexpr int A[6] = {2, 1, 0, 1, 0, 0};
+  static constexpr int B[6] = {0, 1, 2, 0, 1, 0};
+};
+template <>
+struct Prod<2> {
+  static constexpr int N = 3;
+  static constexpr int A[3] = {1, 0, 0};
+  static constexpr int B[3] = {0, 1, 0};
+};
+template <>
+struct Prod<1> {
+  static constexpr int N = 1;
+  static constexpr int A[1] = {0};
+  static constexpr int B[1] = {0};
+};
 
 constexpr int TB_H = 513;             // bins
 constexpr int TB_KP = 528;            // bins padded to a multiple of 16 (k-steps of the bf16 MFMA)
@@ -67,14 +93,15 @@ constexpr int TB_CPY = 8;             // shifted copies of a tap row
 constexpr int TB_CHUNKS = 133;        // 16-byte chunks per copy (1064 taps; odd => the 8 copies a
                                       // quarter-wave reads from sit in different bank groups)
 constexpr int TB_CPYB = TB_CHUNKS * 16;                       // bytes per copy
-constexpr int TB_WCH = 3 * TB_CPY * TB_CPYB;                  // bytes of one channel's copies (3 planes)
-constexpr int TB_WFLOATS = TB_C * TB_WCH / 4;                 // floats of the packed block (all channels)
+constexpr int tb_wch(int npl) { return npl * TB_CPY * TB_CPYB; }  // bytes of one channel's copies (npl planes)
+constexpr int TB_WFLOATS = TB_C * tb_wch(3) / 4;              // floats reserved for the packed block (all channels)
 
 // ---- ONE pass over d(xh) [F][513] for everything the last layer's backward needs from it besides the GEMMs:
-//      (1) the three bf16 planes dst[f][plane][528], (2) column i = 512 of the input gradient
+//      (1) its NPL bf16 planes dst[f][plane][528], (2) column i = 512 of the input gradient
 //      dY[f][c][512] = sum_p G[f][p] * W[p][c], (3) the bias gradient sum_f sum_p G[f][p] (one atomic per
 //      workgroup).  One wave per frame, lane l owns bins 8l .. 8l+7 (lane 0 also bin 512); waves walk the frames
 //      with a grid stride.
+template <int NPL>
 __global__ void __launch_bounds__(256) k_dxh_post(const float* __restrict__ G, const float* __restrict__ W,
                                                   unsigned short* __restrict__ dst, float* __restrict__ dY,
                                                   float* __restrict__ dbias, int F) {
@@ -99,44 +126,38 @@ __global__ void __launch_bounds__(256) k_dxh_post(const float* __restrict__ G, c
     packed4 p1 = *reinterpret_cast<const packed4*>(gf + 8 * lane + 4);
     const float g[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
     const float gt = lane == 0 ? gf[512] : 0.f;
-    unsigned h[8], m[8], l[8];
+    unsigned tm[8][NPL];
     float dot[TB_C];
 #pragma unroll
     for (int c = 0; c < TB_C; ++c) dot[c] = gt * wl[c];
     float sfr = gt;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      split3(g[j], h[j], m[j], l[j]);
+      split_n<NPL>(g[j], tm[j]);
       sfr += g[j];
 #pragma unroll
       for (int c = 0; c < TB_C; ++c) dot[c] += g[j] * wt[j][c];
     }
     bsum += sfr;
-    u32x4 ph, pm, pl;
+    unsigned short* d = dst + (int64_t)f * (NPL * TB_KP);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      ph[k] = h[2 * k] | (h[2 * k + 1] << 16);
-      pm[k] = m[2 * k] | (m[2 * k + 1] << 16);
-      pl[k] = l[2 * k] | (l[2 * k + 1] << 16);
+    for (int p = 0; p < NPL; ++p) {
+      u32x4 pk;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pk[k] = tm[2 * k][p] | (tm[2 * k + 1][p] << 16);
+      *reinterpret_cast<u32x4*>(d + p * TB_KP + 8 * lane) = pk;
     }
-    unsigned short* d = dst + (int64_t)f * (3 * TB_KP);
-    *reinterpret_cast<u32x4*>(d + 8 * lane) = ph;
-    *reinterpret_cast<u32x4*>(d + TB_KP + 8 * lane) = pm;
-    *reinterpret_cast<u32x4*>(d + 2 * TB_KP + 8 * lane) = pl;
     if (lane == 0) {  // bin 512 and the zero padding 513..527
-      unsigned th, tm, tl;
-      split3(gt, th, tm, tl);
+      unsigned tt[NPL];
+      split_n<NPL>(gt, tt);
       const u32x4 z = {0u, 0u, 0u, 0u};
-      u32x4 t = z;
-      t[0] = th;
-      *reinterpret_cast<u32x4*>(d + 512) = t;
-      *reinterpret_cast<u32x4*>(d + 520) = z;
-      t[0] = tm;
-      *reinterpret_cast<u32x4*>(d + TB_KP + 512) = t;
-      *reinterpret_cast<u32x4*>(d + TB_KP + 520) = z;
-      t[0] = tl;
-      *reinterpret_cast<u32x4*>(d + 2 * TB_KP + 512) = t;
-      *reinterpret_cast<u32x4*>(d + 2 * TB_KP + 520) = z;
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        u32x4 t = z;
+        t[0] = tt[p];
+        *reinterpret_cast<u32x4*>(d + p * TB_KP + 512) = t;
+        *reinterpret_cast<u32x4*>(d + p * TB_KP + 520) = z;
+      }
     }
 #pragma unroll
     for (int c = 0; c < TB_C; ++c) {
@@ -152,7 +173,7 @@ __global__ void __launch_bounds__(256) k_dxh_post(const float* __restrict__ G, c
 
 // ---- shifted bf16 copies of the tap rows: dst[c][plane][s][m] = plane(w[c][m + s]), m < 8*TB_CHUNKS.
 //      REV = false: w[c][u] = W[u][c] (input gradient);  REV = true: w[c][u] = W[1024 - u][c] (forward).
-template <bool REV>
+template <bool REV, int NPL>
 struct PackToepBf16Job {  // job of k_pack_multi (gfx950_elem.h)
   const float* W;
   unsigned short* dst;
@@ -160,31 +181,17 @@ struct PackToepBf16Job {  // job of k_pack_multi (gfx950_elem.h)
   __device__ void run(int i) const {
     constexpr int PER = 8 * TB_CHUNKS;
     int c = i / (TB_CPY * PER), r = i - c * (TB_CPY * PER);
-    int s = r / PER, m = r - s * PER;
-    int u = m + s;
-    unsigned h = 0, md = 0, l = 0;
-    if (u < TB_T) split3(W[(REV ? TB_T - 1 - u : u) * TB_C + c], h, md, l);
-    unsigned short* d = dst + (size_t)c * (TB_WCH / 2) + s * PER + m;
-    d[0] = (unsigned short)h;
-    d[TB_CPY * PER] = (unsigned short)md;
-    d[2 * TB_CPY * PER] = (unsigned short)l;
+    int sh = r / PER, m = r - sh * PER;
+    int u = m + sh;
+    unsigned t[NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) t[p] = 0;
+    if (u < TB_T) split_n<NPL>(W[(REV ? TB_T - 1 - u : u) * TB_C + c], t);
+    unsigned short* d = dst + (size_t)c * (tb_wch(NPL) / 2) + sh * PER + m;
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) d[p * TB_CPY * PER] = (unsigned short)t[p];
   }
 };
-template <bool REV>
-__global__ void __launch_bounds__(256) k_pack_toep_bf16(const float* __restrict__ W, unsigned short* __restrict__ dst) {
-  constexpr int PER = 8 * TB_CHUNKS;
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= TB_C * TB_CPY * PER) return;
-  int c = i / (TB_CPY * PER), r = i - c * (TB_CPY * PER);
-  int s = r / PER, m = r - s * PER;
-  int u = m + s;
-  unsigned h = 0, md = 0, l = 0;
-  if (u < TB_T) split3(W[(REV ? TB_T - 1 - u : u) * TB_C + c], h, md, l);
-  unsigned short* d = dst + (size_t)c * (TB_WCH / 2) + s * PER + m;
-  d[0] = (unsigned short)h;
-  d[TB_CPY * PER] = (unsigned short)md;
-  d[2 * TB_CPY * PER] = (unsigned short)l;
-}
 
 // ---- input gradient:  dY[f][c][i] = sum_p G[f][p] * W[p - i + 512][c]   (i < 512; column 512: k_dxh_post)
 //
@@ -196,24 +203,25 @@ constexpr int DG_M = 64;                               // frames per workgroup
 constexpr int DG_KC = 176, DG_NKC = TB_KP / DG_KC;     // bins per chunk, chunks
 constexpr int DG_ROWB = DG_KC * 2 + 16;                // bytes per LDS row (368 = 16 * 23, odd)
 constexpr int DG_APL = DG_M * DG_ROWB;                 // bytes per plane of the A tile
-constexpr int DG_LDS = 3 * DG_APL + TB_WCH;            // 70 656 + 51 072 bytes
+constexpr int dg_lds(int npl) { return npl * DG_APL + tb_wch(npl); }  // NPL = 3: 70 656 + 51 072 bytes
 
 //
 // FWD = true is the forward direction of the same layer with the same machinery:
 //     xh[f][p] = bias + sum_c sum_i y[f][c][i] * W[p - i + 512][c]        (p < 512; column 512: the plane producer)
 // k = input bin i, column = output bin p, taps read from the REVERSED copies (u = 512 - p + i); the A
 // planes are per channel ([F][3][8][528]) and the accumulators run over all 8 channels.
-template <bool FWD>
+template <bool FWD, int NPL>
 __global__ void __launch_bounds__(256, 1) k_toep_gemm_bf16(const unsigned short* __restrict__ gp,   // A planes
                                                             const unsigned short* __restrict__ wcp,  // packed tap copies
                                                             const float* __restrict__ bias,          // FWD: [1]
                                                             float* __restrict__ dY,  // dgrad: [F][8][513]; fwd: [F][513]
                                                             int F) {
   constexpr int A_PL = (FWD ? TB_C : 1) * TB_KP * 2;  // bytes between planes of a frame
-  constexpr int A_FR = 3 * A_PL;                      // bytes per frame
+  constexpr int A_FR = NPL * A_PL;                    // bytes per frame
+  constexpr int TB_WCH = tb_wch(NPL);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
-  unsigned char* sW = smem + 3 * DG_APL;
+  unsigned char* sW = smem + NPL * DG_APL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int f0 = blockIdx.x * DG_M;
 
@@ -225,10 +233,10 @@ __global__ void __launch_bounds__(256, 1) k_toep_gemm_bf16(const unsigned short*
   const int sfr = f0 + srow < F ? f0 + srow : F - 1;  // clamp: rows past the batch end are never stored
   const unsigned char* gsrc = reinterpret_cast<const unsigned char*>(gp) + (size_t)sfr * A_FR + spart * 16;
   unsigned char* sdst = sA + srow * DG_ROWB + spart * 16;
-  u32x4 st[18];
+  u32x4 st[6 * NPL];
   auto gload = [&](int c, int kc) __attribute__((always_inline)) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         int c16 = spart + 4 * q;
@@ -238,7 +246,7 @@ __global__ void __launch_bounds__(256, 1) k_toep_gemm_bf16(const unsigned short*
   };
   auto lstore = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
       for (int q = 0; q < 6; ++q)
         if (spart + 4 * q < PPR) *reinterpret_cast<u32x4*>(sdst + pl * DG_APL + q * 64) = st[pl * 6 + q];
@@ -260,28 +268,27 @@ __global__ void __launch_bounds__(256, 1) k_toep_gemm_bf16(const unsigned short*
   // fragments: A of a whole k-step (2 row tiles x 3 planes), B of ONE column tile (3 planes); both
   // ping-pong: while the 12 MFMAs of column tile nb run, the B fragments of tile nb+1 (or, for the
   // last tile, A and B(0) of the next k-step) are already being read from LDS
-  u32x4 fa[2][2][3], fb[2][3];
+  u32x4 fa[2][2][NPL], fb[2][NPL];
   auto loadA = [&](int set, int ks) __attribute__((always_inline)) {
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < NPL; ++pl)
         fa[set][mb][pl] = *reinterpret_cast<const u32x4*>(sA + pl * DG_APL + mb * 32 * DG_ROWB + aoff + ks * 32);
   };
   auto loadB = [&](int set, int kc, int ks, int nb) __attribute__((always_inline)) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
       fb[set][pl] = *reinterpret_cast<const u32x4*>(sW + pl * (TB_CPY * TB_CPYB) + boff[nb] + (22 * kc + 2 * ks) * 16);
   };
   f32x16 acc[2][4];
   auto mm = [&](int sa, int sb, int nb) __attribute__((always_inline)) {
-    // six term pairs, smallest first
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    // term pairs, smallest first
+    using PR = Prod<NPL>;
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < PR::N; ++t)
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = mfma_bf16(fa[sa][mb][PA[t]], fb[sb][PB[t]], acc[mb][nb]);
+      for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = mfma_bf16(fa[sa][mb][PR::A[t]], fb[sb][PR::B[t]], acc[mb][nb]);
   };
 
 #if VAENPVC_PROF
@@ -294,7 +301,7 @@ __global__ void __launch_bounds__(256, 1) k_toep_gemm_bf16(const unsigned short*
     TBPROF_T(t0);
     __syncthreads();  // previous channel fully consumed (tap copies and A tile)
     {  // tap copies of channel c: all loads first (one L2 latency), then the LDS stores
-      constexpr int NW16 = TB_WCH / 16, WPT = (NW16 + 255) / 256;  // 3192 pieces, 13 per thread
+      constexpr int NW16 = TB_WCH / 16, WPT = (NW16 + 255) / 256;  // NPL = 3: 3192 pieces, 13 per thread
       const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wcp) + (size_t)c * TB_WCH);
       u32x4 wv[WPT];
 #pragma unroll
@@ -402,6 +409,7 @@ __global__ void __launch_bounds__(256, 1) k_toep_gemm_bf16(const unsigned short*
 //      of the activated frame with the taps W[1024 - i][c] (the GEMM kernel covers p < 512).
 //      One wave per frame; lane l owns bins 8l .. 8l+7 of every channel, lanes 0..7 also bin 512 of
 //      channel l.
+template <int NPL>
 __global__ void __launch_bounds__(256) k_ln_stats_act_planes(const float* __restrict__ a, float* __restrict__ st,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ y, unsigned short* __restrict__ yp,
@@ -443,7 +451,7 @@ __global__ void __launch_bounds__(256) k_ln_stats_act_planes(const float* __rest
     st[2 * f + 1] = rstd;
   }
   float* yf = y + (int64_t)f * (TB_C * TB_H);
-  unsigned short* ypf = yp + (int64_t)f * (3 * TB_C * TB_KP);
+  unsigned short* ypf = yp + (int64_t)f * (NPL * TB_C * TB_KP);
   float dot = 0.f;
 #pragma unroll
   for (int c = 0; c < TB_C; ++c) {
@@ -453,46 +461,40 @@ __global__ void __launch_bounds__(256) k_ln_stats_act_planes(const float* __rest
     packed4 w0 = *reinterpret_cast<const packed4*>(wp), w1 = *reinterpret_cast<const packed4*>(wp + 4);
     const float wr[8] = {w1.w, w1.z, w1.y, w1.x, w0.w, w0.z, w0.y, w0.x};
     float o[8];
-    unsigned h[8], m[8], l[8];
+    unsigned tm[8][NPL];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       o[j] = lnact_v(v[c][j], mean, rstd, g, b);
       dot += o[j] * wr[j];
-      split3(o[j], h[j], m[j], l[j]);
+      split_n<NPL>(o[j], tm[j]);
     }
     if (write_y) {  // uniform; the fp32 copy is only read by the exact-fp32 weight-gradient kernel
       *reinterpret_cast<packed4*>(yf + c * TB_H + 8 * lane) = packed4{o[0], o[1], o[2], o[3]};
       *reinterpret_cast<packed4*>(yf + c * TB_H + 8 * lane + 4) = packed4{o[4], o[5], o[6], o[7]};
     }
-    u32x4 ph, pm, pl;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      ph[k] = h[2 * k] | (h[2 * k + 1] << 16);
-      pm[k] = m[2 * k] | (m[2 * k + 1] << 16);
-      pl[k] = l[2 * k] | (l[2 * k + 1] << 16);
+    for (int p = 0; p < NPL; ++p) {
+      u32x4 pk;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pk[k] = tm[2 * k][p] | (tm[2 * k + 1][p] << 16);
+      *reinterpret_cast<u32x4*>(ypf + (p * TB_C + c) * TB_KP + 8 * lane) = pk;
     }
-    *reinterpret_cast<u32x4*>(ypf + (0 * TB_C + c) * TB_KP + 8 * lane) = ph;
-    *reinterpret_cast<u32x4*>(ypf + (1 * TB_C + c) * TB_KP + 8 * lane) = pm;
-    *reinterpret_cast<u32x4*>(ypf + (2 * TB_C + c) * TB_KP + 8 * lane) = pl;
   }
   if (lane < TB_C) {  // bin 512 of channel `lane`, and the zero padding 513..527 of its plane rows
     const int c = lane;
     float o = lnact_v(vt, mean, rstd, gamma[c], beta[c]);
     yf[c * TB_H + 512] = o;
     dot += o * Wc[c * WROWC + 8 + 512];
-    unsigned h, m, l;
-    split3(o, h, m, l);
+    unsigned tt[NPL];
+    split_n<NPL>(o, tt);
     const u32x4 z = {0u, 0u, 0u, 0u};
-    u32x4 t;
-    t = z; t[0] = h;
-    *reinterpret_cast<u32x4*>(ypf + (0 * TB_C + c) * TB_KP + 512) = t;
-    *reinterpret_cast<u32x4*>(ypf + (0 * TB_C + c) * TB_KP + 520) = z;
-    t = z; t[0] = m;
-    *reinterpret_cast<u32x4*>(ypf + (1 * TB_C + c) * TB_KP + 512) = t;
-    *reinterpret_cast<u32x4*>(ypf + (1 * TB_C + c) * TB_KP + 520) = z;
-    t = z; t[0] = l;
-    *reinterpret_cast<u32x4*>(ypf + (2 * TB_C + c) * TB_KP + 512) = t;
-    *reinterpret_cast<u32x4*>(ypf + (2 * TB_C + c) * TB_KP + 520) = z;
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+      u32x4 t = z;
+      t[0] = tt[p];
+      *reinterpret_cast<u32x4*>(ypf + (p * TB_C + c) * TB_KP + 512) = t;
+      *reinterpret_cast<u32x4*>(ypf + (p * TB_C + c) * TB_KP + 520) = z;
+    }
   }
   dot = wave_sum(dot);
   if (lane == 0) xh[(int64_t)f * TB_H + 512] = dot + bias[0];
@@ -514,8 +516,8 @@ constexpr int WG_KF = 16;                       // frames per staged chunk = one
 constexpr int WG_RSA = 128 * 2 + 64;            // bytes per LDS row, A tile (320 = 64 mod 256: the 4 rows of a
 constexpr int WG_RSB = 256 * 2 + 64;            //   transpose read sit in different bank quarters); B: 576
 constexpr int WG_APL = WG_KF * WG_RSA, WG_BPL = WG_KF * WG_RSB;
-constexpr int WG_BUF = 3 * (WG_APL + WG_BPL);   // 15 360 + 27 648 bytes per buffer
-constexpr int WG_LDS = 2 * WG_BUF;
+constexpr int wg_buf(int npl) { return npl * (WG_APL + WG_BPL); }  // NPL = 3: 15 360 + 27 648 bytes per buffer
+constexpr int wg_lds(int npl) { return 2 * wg_buf(npl); }
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4 tr_read8(const unsigned char* p, int row4_bytes) {
@@ -528,11 +530,13 @@ __device__ __forceinline__ u32x4 tr_read8(const unsigned char* p, int row4_bytes
   return __builtin_bit_cast(u32x4, ab);
 }
 
-__global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16(const unsigned short* __restrict__ yp,  // [F][3][8][528]
-                                                             const unsigned short* __restrict__ gp,  // [F][3][528]
+template <int NPL>
+__global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16(const unsigned short* __restrict__ yp,  // [F][NPL][8][528]
+                                                             const unsigned short* __restrict__ gp,  // [F][NPL][528]
                                                              float* __restrict__ dW,                 // [1025][8] atomicAdd
                                                              int F, int fchunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int WG_BUF = wg_buf(NPL);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int wr = wave >> 2, wc = wave & 3;
   const int i0 = (blockIdx.x >> 1) * 128, q0 = (blockIdx.x & 1) * 256, c = blockIdx.y;
@@ -542,70 +546,70 @@ __global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16(const unsigned short
   // ---- staging (16-byte pieces) of one 16-frame chunk into buffer `buf`:
   //      A 3 planes x 16 rows x 16: threads < 256 -> (row tid>>4, piece tid&15), plane k;
   //      B 3 x 16 x 32: thread -> (row tid>>5, piece tid&31), plane k;
-  //      strip: bins 512..527 = pieces 64, 65 of the G row -> tile pieces 32, 33: threads < 96
+  //      strip: bins 512..527 = pieces 64, 65 of the G row -> tile pieces 32, 33: threads < 32 * NPL
   const int arow = (tid >> 4) & 15, apc = tid & 15;
   const int brow = tid >> 5, bpc = tid & 31;
   const int epl = tid >> 5, erow = (tid >> 1) & 15, epc = tid & 1;
-  u32x4 sta[3], stb[3], ste;
+  u32x4 sta[NPL], stb[NPL], ste;
   // per-thread source pointers of chunk fb, advanced by 16 frames per chunk (address arithmetic in the
   // staging phases competes with the partner wave's MFMAs: keep it to three 64-bit adds per chunk)
-  const unsigned char* pa = reinterpret_cast<const unsigned char*>(yp) + ((size_t)(fb + arow) * 3 * TB_C + c) * (TB_KP * 2) + (i0 * 2 + apc * 16);
-  const unsigned char* pb = reinterpret_cast<const unsigned char*>(gp) + (size_t)(fb + brow) * 3 * (TB_KP * 2) + q0 * 2 + bpc * 16;
-  const unsigned char* pe = reinterpret_cast<const unsigned char*>(gp) + ((size_t)(fb + erow) * 3 + epl) * (TB_KP * 2) + (64 + epc) * 16;
+  const unsigned char* pa = reinterpret_cast<const unsigned char*>(yp) + ((size_t)(fb + arow) * NPL * TB_C + c) * (TB_KP * 2) + (i0 * 2 + apc * 16);
+  const unsigned char* pb = reinterpret_cast<const unsigned char*>(gp) + (size_t)(fb + brow) * NPL * (TB_KP * 2) + q0 * 2 + bpc * 16;
+  const unsigned char* pe = reinterpret_cast<const unsigned char*>(gp) + ((size_t)(fb + erow) * NPL + epl) * (TB_KP * 2) + (64 + epc) * 16;
   auto gload = [&](int f0) __attribute__((always_inline)) {
     if (f0 + WG_KF <= F) {  // uniform: all 16 frames exist
       if (tid < 256) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) sta[pl] = *reinterpret_cast<const u32x4*>(pa + (size_t)pl * TB_C * TB_KP * 2);
+        for (int pl = 0; pl < NPL; ++pl) sta[pl] = *reinterpret_cast<const u32x4*>(pa + (size_t)pl * TB_C * TB_KP * 2);
       }
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) stb[pl] = *reinterpret_cast<const u32x4*>(pb + pl * (TB_KP * 2));
-      if (strip && tid < 96) ste = *reinterpret_cast<const u32x4*>(pe);
+      for (int pl = 0; pl < NPL; ++pl) stb[pl] = *reinterpret_cast<const u32x4*>(pb + pl * (TB_KP * 2));
+      if (strip && tid < 32 * NPL) ste = *reinterpret_cast<const u32x4*>(pe);
     } else {  // last chunk of the batch: clamp the frame index (rows past the end are zeroed in lstore)
       if (tid < 256) {
         int f = f0 + arow;
         f = f < F ? f : F - 1;
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(yp) + ((size_t)f * 3 * TB_C + c) * (TB_KP * 2) + (i0 * 2 + apc * 16);
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(yp) + ((size_t)f * NPL * TB_C + c) * (TB_KP * 2) + (i0 * 2 + apc * 16);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) sta[pl] = *reinterpret_cast<const u32x4*>(src + (size_t)pl * TB_C * TB_KP * 2);
+        for (int pl = 0; pl < NPL; ++pl) sta[pl] = *reinterpret_cast<const u32x4*>(src + (size_t)pl * TB_C * TB_KP * 2);
       }
       {
         int f = f0 + brow;
         f = f < F ? f : F - 1;
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(gp) + (size_t)f * 3 * (TB_KP * 2) + q0 * 2 + bpc * 16;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(gp) + (size_t)f * NPL * (TB_KP * 2) + q0 * 2 + bpc * 16;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) stb[pl] = *reinterpret_cast<const u32x4*>(src + pl * (TB_KP * 2));
+        for (int pl = 0; pl < NPL; ++pl) stb[pl] = *reinterpret_cast<const u32x4*>(src + pl * (TB_KP * 2));
       }
-      if (strip && tid < 96) {
+      if (strip && tid < 32 * NPL) {
         int f = f0 + erow;
         f = f < F ? f : F - 1;
-        ste = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(gp) + ((size_t)f * 3 + epl) * (TB_KP * 2) + (64 + epc) * 16);
+        ste = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(gp) + ((size_t)f * NPL + epl) * (TB_KP * 2) + (64 + epc) * 16);
       }
     }
-    pa += (size_t)WG_KF * 3 * TB_C * TB_KP * 2;
-    pb += (size_t)WG_KF * 3 * TB_KP * 2;
-    pe += (size_t)WG_KF * 3 * TB_KP * 2;
+    pa += (size_t)WG_KF * NPL * TB_C * TB_KP * 2;
+    pb += (size_t)WG_KF * NPL * TB_KP * 2;
+    pe += (size_t)WG_KF * NPL * TB_KP * 2;
   };
   auto lstore = [&](int f0, int buf) __attribute__((always_inline)) {
     unsigned char* sA = smem + buf * WG_BUF;
-    unsigned char* sB = sA + 3 * WG_APL;
+    unsigned char* sB = sA + NPL * WG_APL;
     const u32x4 z = {0u, 0u, 0u, 0u};
     const bool tail = f0 + WG_KF > fe;  // uniform: frames past the chunk contribute zero (A rows zeroed)
     if (tid < 256) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < NPL; ++pl)
         *reinterpret_cast<u32x4*>(sA + pl * WG_APL + arow * WG_RSA + apc * 16) = (tail && f0 + arow >= fe) ? z : sta[pl];
     }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(sB + pl * WG_BPL + brow * WG_RSB + bpc * 16) = stb[pl];
-    if (strip && tid < 96) *reinterpret_cast<u32x4*>(sB + epl * WG_BPL + erow * WG_RSB + (32 + epc) * 16) = ste;
+    for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x4*>(sB + pl * WG_BPL + brow * WG_RSB + bpc * 16) = stb[pl];
+    if (strip && tid < 32 * NPL) *reinterpret_cast<u32x4*>(sB + epl * WG_BPL + erow * WG_RSB + (32 + epc) * 16) = ste;
   };
 
   // ---- fragment addresses (transpose reads): lane -> (frame row (l&15)>>2 (+8*lh), column quad 4*(l&3) + 16*((l>>4)&1))
   const int trow = ((lane & 15) >> 2) + 8 * lh, tcol = 4 * (lane & 3) + 16 * ((lane >> 4) & 1);
   const int aoff = trow * WG_RSA + (64 * wr + tcol) * 2;                 // + buf + plane*WG_APL + 64*ri
-  const int boff = 3 * WG_APL + trow * WG_RSB + (64 * wc + tcol) * 2;    // + buf + plane*WG_BPL + 64*cj
-  const int eoff = 3 * WG_APL + trow * WG_RSB + (256 + tcol) * 2;        // the q = 512 strip (tile columns 256..287)
+  const int boff = NPL * WG_APL + trow * WG_RSB + (64 * wc + tcol) * 2;    // + buf + plane*WG_BPL + 64*cj
+  const int eoff = NPL * WG_APL + trow * WG_RSB + (256 + tcol) * 2;        // the q = 512 strip (tile columns 256..287)
   const int eri = wc & 1;                                                // this wave's strip row tile = 2*wr + eri, on chunks of parity wc>>1
 
   f32x16 acc[2][2], acce;
@@ -615,37 +619,36 @@ __global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16(const unsigned short
     for (int cj = 0; cj < 2; ++cj) acc[ri][cj] = zero16();
   acce = zero16();
 
-  u32x4 fa[2][3], fbq[2][3], fe3[3];
+  u32x4 fa[2][NPL], fbq[2][NPL], fe3[NPL];
   auto loadF = [&](int buf, bool mine) __attribute__((always_inline)) {
     const unsigned char* sb = smem + buf * WG_BUF;
 #pragma unroll
     for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fa[ri][pl] = tr_read8(sb + pl * WG_APL + aoff + ri * 64, 4 * WG_RSA);
+      for (int pl = 0; pl < NPL; ++pl) fa[ri][pl] = tr_read8(sb + pl * WG_APL + aoff + ri * 64, 4 * WG_RSA);
 #pragma unroll
     for (int cj = 0; cj < 2; ++cj)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fbq[cj][pl] = tr_read8(sb + pl * WG_BPL + boff + cj * 64, 4 * WG_RSB);
+      for (int pl = 0; pl < NPL; ++pl) fbq[cj][pl] = tr_read8(sb + pl * WG_BPL + boff + cj * 64, 4 * WG_RSB);
     if (mine) {  // wave-uniform: this wave's turn on the q = 512 strip
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fe3[pl] = tr_read8(sb + pl * WG_BPL + eoff, 4 * WG_RSB);
+      for (int pl = 0; pl < NPL; ++pl) fe3[pl] = tr_read8(sb + pl * WG_BPL + eoff, 4 * WG_RSB);
     }
   };
   auto mm = [&](bool mine) __attribute__((always_inline)) {
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    using PR = Prod<NPL>;
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < PR::N; ++t)
 #pragma unroll
       for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
-        for (int cj = 0; cj < 2; ++cj) acc[ri][cj] = mfma_bf16(fa[ri][PA[t]], fbq[cj][PB[t]], acc[ri][cj]);
+        for (int cj = 0; cj < 2; ++cj) acc[ri][cj] = mfma_bf16(fa[ri][PR::A[t]], fbq[cj][PR::B[t]], acc[ri][cj]);
     if (mine) {  // wave-uniform
-      u32x4 af[3];
+      u32x4 af[NPL];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) af[pl] = eri == 0 ? fa[0][pl] : fa[1][pl];
+      for (int pl = 0; pl < NPL; ++pl) af[pl] = eri == 0 ? fa[0][pl] : fa[1][pl];
 #pragma unroll
-      for (int t = 0; t < 6; ++t) acce = mfma_bf16(af[PA[t]], fe3[PB[t]], acce);
+      for (int t = 0; t < PR::N; ++t) acce = mfma_bf16(af[PR::A[t]], fe3[PR::B[t]], acce);
     }
   };
 

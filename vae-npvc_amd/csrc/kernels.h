@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include "model.h"
+#include "philox.h"
+#include "runtime.h"
 
 namespace vaenpvc {
 
@@ -11,6 +13,7 @@ struct Ws {  // resolved workspace pointers (see workspace_layout)
   float* enc_a[VAENPVC_MAX_LAYERS];
   float* enc_st[VAENPVC_MAX_LAYERS];
   float *z_mu, *z_lv, *z, *h;
+  float* eps;  // N(0,1) draw of the sampler when it is generated on the device (seeded entry points)
   float* dec_a[VAENPVC_MAX_LAYERS];
   float* dec_st[VAENPVC_MAX_LAYERS];
   float *xh, *kl_f, *nll_f;
@@ -27,23 +30,22 @@ struct Ws {  // resolved workspace pointers (see workspace_layout)
   int64_t scratch_floats;
 };
 
-// ---- single-kernel event timer (abi.hip) ----------------------------------------
-bool timer_match(const char* tag);
-void timer_begin(hipStream_t s);
-void timer_end(hipStream_t s);
-#define VAENPVC_TIMED(tag, stream, stmt)        \
-  do {                                          \
-    bool _tm = ::vaenpvc::timer_match(tag);     \
-    if (_tm) ::vaenpvc::timer_begin(stream);    \
-    stmt;                                       \
-    if (_tm) ::vaenpvc::timer_end(stream);      \
+// ---- single-kernel event timer (state in the context's Runtime, runtime.h) --------
+#define VAENPVC_TIMED(tag, stream, stmt)              \
+  do {                                                \
+    ::vaenpvc::Runtime& _rt = ::vaenpvc::rt();        \
+    bool _tm = _rt.timer_match(tag);                  \
+    if (_tm) _rt.timer_begin(stream);                 \
+    stmt;                                             \
+    if (_tm) _rt.timer_end(stream);                   \
   } while (0)
 
 // ---- geometry-generic HIP kernels (generic_kernels.hip) -------------------------
 namespace generic {
 void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F, const Ws& w, hipStream_t s);
 // z = z_mu + eps*sqrt(exp(z_lv)) (eps may be null -> z = z_mu); also per-frame KL
-void reparam_fwd(const Model& m, const float* eps, int64_t F, const Ws& w, hipStream_t s);
+// (key != nullptr: eps is drawn on the device with Philox and stored in w.eps for the backward pass)
+void reparam_fwd(const Model& m, const float* eps, const PhiloxKey* key, int64_t F, const Ws& w, hipStream_t s);
 // decoder from z (w.z or external) and y -> xh_out
 void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* y, int64_t F, const Ws& w,
                  float* xh_out, hipStream_t s);
@@ -71,15 +73,21 @@ void launch_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, in
                      float b2, float eps, float gscale, hipStream_t s);
 void launch_tanhize(const float* in, const float* xmin, const float* xmax, float* out, int64_t F, int H,
                     bool forward, hipStream_t s);
-void launch_unpack(const float* rec, int64_t F, int rec_floats, int H, const float* xmin, const float* xmax,
-                   float* x, int64_t* y, hipStream_t s);
+// rows gathered through `idx` (int64 record numbers) when it is not null
+void launch_unpack(const float* rec, const int64_t* idx, int64_t F, int rec_floats, int H, const float* xmin,
+                   const float* xmax, float* x, int64_t* y, hipStream_t s);
+void launch_check_ids(const int64_t* y, int64_t F, int ny, int* flag, hipStream_t s);
+void launch_philox_normal(float* out, int64_t n, PhiloxKey key, hipStream_t s);
+// min, max, sum, sum of squares (double[4]) and counts per bucket (uint64[n_edges + 1]; bucket b holds
+// edges[b-1] <= v < edges[b]) of `n` floats; the outputs must be zeroed by the caller (stats[0..1] = +-inf)
+void launch_summary(const float* d, int64_t n, const float* edges, int n_edges, double* stats, unsigned long long* counts,
+                    hipStream_t s);
 
 // ---- tuned gfx950 kernels for the VCC2016 geometry (gfx950_*.hip) ----------------
 namespace tuned {
 // step masks: bit set = use the tuned kernel for that step, clear = generic kernel.
 //   forward  bits: 0..4 encoder conv i | 5 heads | 6 merge | 7..10 decoder layer i
 //   backward bits: 0..4 encoder conv i | 5 heads | 6 merge | 7..10 decoder layer i
-void set_masks(unsigned fwd, unsigned bwd);
 bool available();
 void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F, const Ws& w, hipStream_t s);
 // `weights_packed`: the packed weight copies in w.scratch are already current (the encoder of the

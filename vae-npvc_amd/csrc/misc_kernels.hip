@@ -95,27 +95,123 @@ void launch_tanhize(const float* in, const float* xmin, const float* xmax, float
   hipLaunchKernelGGL(k_tanhize, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, in, xmin, xmax, out, N, H, forward);
 }
 
-// analyzer.py:113-127: x = Tanhize(record[:H]) ; y = int64(record[-1])
-__global__ void k_unpack(const float* __restrict__ rec, int64_t F, int R, int H, const float* __restrict__ xmin,
-                         const float* __restrict__ xmax, float* __restrict__ x, int64_t* __restrict__ y) {
+// analyzer.py:113-127: x = Tanhize(record[:H]) ; y = int64(record[-1]).  `idx` (optional) selects the record
+// of every output row: the shuffled-batch gather of analyzer.py:128-135 happens inside this pass, so a batch
+// costs one read of the H + 1 floats it uses instead of a full-record gather followed by a second pass.
+__global__ void k_unpack(const float* __restrict__ rec, const int64_t* __restrict__ idx, int64_t F, int R, int H,
+                         const float* __restrict__ xmin, const float* __restrict__ xmax, float* __restrict__ x,
+                         int64_t* __restrict__ y) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= F * (H + 1)) return;
   int b = (int)(i % (H + 1));
   int64_t f = i / (H + 1);
+  const int64_t r = idx ? idx[f] : f;
   if (b == H) {
-    y[f] = (int64_t)rec[f * R + R - 1];  // tf.cast(float32 -> int64): truncation toward zero
+    y[f] = (int64_t)rec[r * R + R - 1];  // tf.cast(float32 -> int64): truncation toward zero
   } else {
     float lo = xmin[b], sc = xmax[b] - lo;
-    float u = (rec[f * R + b] - lo) / sc;
+    float u = (rec[r * R + b] - lo) / sc;
     u = fminf(fmaxf(u, 0.f), 1.f);
     x[f * H + b] = u * 2.f - 1.f;
   }
 }
 
-void launch_unpack(const float* rec, int64_t F, int rec_floats, int H, const float* xmin, const float* xmax,
-                   float* x, int64_t* y, hipStream_t s) {
+void launch_unpack(const float* rec, const int64_t* idx, int64_t F, int rec_floats, int H, const float* xmin,
+                   const float* xmax, float* x, int64_t* y, hipStream_t s) {
   int64_t N = F * (H + 1);
-  hipLaunchKernelGGL(k_unpack, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rec, F, rec_floats, H, xmin, xmax, x, y);
+  hipLaunchKernelGGL(k_unpack, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rec, idx, F, rec_floats, H, xmin, xmax, x, y);
+}
+
+// count of speaker ids outside [0, ny)
+__global__ void k_check_ids(const int64_t* __restrict__ y, int64_t F, int ny, int* __restrict__ flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < F && (y[i] < 0 || y[i] >= ny)) atomicAdd(flag, 1);
+}
+void launch_check_ids(const int64_t* y, int64_t F, int ny, int* flag, hipStream_t s) {
+  (void)hipMemsetAsync(flag, 0, sizeof(int), s);
+  hipLaunchKernelGGL(k_check_ids, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, s, y, F, ny, flag);
+}
+
+// stand-alone N(0,1) draw, identical to what the seeded train step draws inside its sampler kernel
+__global__ void k_philox_normal(float* __restrict__ out, int64_t n, PhiloxKey key) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = philox_normal(philox_resolve(key), (uint64_t)i);
+}
+void launch_philox_normal(float* out, int64_t n, PhiloxKey key, hipStream_t s) {
+  hipLaunchKernelGGL(k_philox_normal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, key);
+}
+
+// tf.summary.histogram payload of model/vae.py:134-135 (x, xh): min / max / sum / sum of squares and bucket
+// counts over caller-supplied ascending bucket limits.  Edges sit in LDS; a workgroup keeps a private
+// histogram and flushes it with one atomic per non-empty bucket.
+constexpr int kMaxEdges = 2048;
+__device__ __forceinline__ void atomic_min_d(double* a, double v) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(a);
+  unsigned long long old = *p;
+  while (v < __longlong_as_double((long long)old)) {
+    unsigned long long prev = atomicCAS(p, old, (unsigned long long)__double_as_longlong(v));
+    if (prev == old) break;
+    old = prev;
+  }
+}
+__device__ __forceinline__ void atomic_max_d(double* a, double v) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(a);
+  unsigned long long old = *p;
+  while (v > __longlong_as_double((long long)old)) {
+    unsigned long long prev = atomicCAS(p, old, (unsigned long long)__double_as_longlong(v));
+    if (prev == old) break;
+    old = prev;
+  }
+}
+__global__ void __launch_bounds__(256) k_summary(const float* __restrict__ d, int64_t n, const float* __restrict__ edges,
+                                                 int n_edges, double* __restrict__ stats,
+                                                 unsigned long long* __restrict__ counts) {
+  __shared__ float se[kMaxEdges];
+  __shared__ unsigned sh[kMaxEdges + 1];
+  __shared__ double red[4][4];
+  for (int i = threadIdx.x; i < n_edges; i += 256) se[i] = edges[i];
+  for (int i = threadIdx.x; i <= n_edges; i += 256) sh[i] = 0u;
+  __syncthreads();
+  double mn = 1e300, mx = -1e300, sm = 0.0, sq = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = d[i];
+    int lo = 0, hi = n_edges;  // first edge > v  (bucket index)
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (se[mid] > v) hi = mid; else lo = mid + 1;
+    }
+    atomicAdd(&sh[lo], 1u);
+    mn = fmin(mn, (double)v);
+    mx = fmax(mx, (double)v);
+    sm += v;
+    sq += (double)v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fmin(mn, __shfl_xor(mn, o));
+    mx = fmax(mx, __shfl_xor(mx, o));
+    sm += __shfl_xor(sm, o);
+    sq += __shfl_xor(sq, o);
+  }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[0][wv] = mn; red[1][wv] = mx; red[2][wv] = sm; red[3][wv] = sq;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomic_min_d(stats + 0, fmin(fmin(red[0][0], red[0][1]), fmin(red[0][2], red[0][3])));
+    atomic_max_d(stats + 1, fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3])));
+    atomicAdd(stats + 2, (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]));
+    atomicAdd(stats + 3, (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]));
+  }
+  for (int i = threadIdx.x; i <= n_edges; i += 256)
+    if (sh[i]) atomicAdd(counts + i, (unsigned long long)sh[i]);
+}
+void launch_summary(const float* d, int64_t n, const float* edges, int n_edges, double* stats, unsigned long long* counts,
+                    hipStream_t s) {
+  int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_summary, dim3((unsigned)blocks), dim3(256), 0, s, d, n, edges, n_edges, stats, counts);
 }
 
 }  // namespace vaenpvc

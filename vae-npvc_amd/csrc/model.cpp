@@ -134,6 +134,7 @@ std::vector<Region> workspace_layout(const Model& m, int64_t F, int mode, int64_
   add("z_mu", F * m.z);
   add("z_lv", F * m.z);
   add("z", F * m.z);
+  add("eps", F * m.z);  // sampler draw when it is generated on the device (seeded entry points)
   add("h", F * m.merge);
   maxact = std::max<int64_t>(maxact, m.merge);
   for (int i = 0; i < m.n_dec - 1; ++i) {

@@ -1,0 +1,67 @@
+// runtime.h -- mutable per-context state of the library.
+//
+// include/vaenpvc.h promises "no global mutable state besides the ctx": everything that changes
+// after load time lives in a Runtime owned by one vaenpvc_ctx -- the kernel-selection masks,
+// the operand precision, the internal weight-gradient stream with its event ring, the
+// per-device function-attribute cache and the single-kernel event timer.  An ABI entry point
+// locks its context, binds the Runtime to the calling host thread for the duration of the call
+// (RtScope) and the launch code reaches it through rt(); two contexts driven by two host
+// threads therefore never share anything mutable.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <unordered_set>
+#include <utility>
+#include <vector>
+
+namespace vaenpvc {
+
+struct Runtime {
+  // ---- kernel selection (vaenpvc_set_tuned_masks / vaenpvc_set_precision)
+  unsigned fwd_mask = 0xffffffffu, bwd_mask = 0xffffffffu;
+  int planes = 2;               // bf16 terms per fp32 operand on the bf16 matrix cores: 3, 2 or 1
+  bool toep_f32 = false;        // VAENPVC_TOEP=f32: exact-fp32 MFMA kernels for the 1025-tap layer
+  bool toep_wgrad_f32 = false;  // VAENPVC_TOEP_WGRAD_F32
+  bool side_enabled = true;     // VAENPVC_SIDE_STREAM=0 disables the internal weight-gradient stream
+  // ---- device binding: created lazily on the device that is current at the first launch
+  int device = -1;
+  hipStream_t s2 = nullptr;
+  hipEvent_t ev[16] = {};
+  int ev_next = 0;
+  std::unordered_set<const void*> attr_done;  // kernels whose dynamic-LDS limit was raised on `device`
+  // ---- gradient-bucket callback (vaenpvc_set_bucket_callback)
+  void (*bucket_cb)(void* user, int32_t bucket, int64_t off, int64_t cnt, void* ready_stream) = nullptr;
+  void* bucket_user = nullptr;
+  int bucket_next = 0;
+  // ---- single-kernel event timer (vaenpvc_timer_select / _read)
+  std::string tag;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  size_t used = 0;
+
+  void read_env();
+  // (re)binds to the current device; drops stream, events and the attribute cache when it changed
+  void bind_device();
+  void release();
+  // raises hipFuncAttributeMaxDynamicSharedMemorySize once per kernel and device
+  void ensure_lds(const void* fn, int bytes);
+  // internal stream for the weight-gradient kernels; nullptr when disabled or creation failed
+  hipStream_t side_stream();
+  // make `to` wait for everything enqueued on `from` so far
+  void stream_dep(hipStream_t from, hipStream_t to);
+
+  bool timer_match(const char* t) const { return !tag.empty() && tag == t; }
+  void timer_begin(hipStream_t s);
+  void timer_end(hipStream_t s);
+};
+
+// Runtime bound to the calling thread by the ABI entry point that is executing
+Runtime& rt();
+struct RtScope {
+  Runtime* prev;
+  explicit RtScope(Runtime* r);
+  ~RtScope();
+};
+
+}  // namespace vaenpvc

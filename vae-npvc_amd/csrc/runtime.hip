@@ -1,0 +1,108 @@
+// runtime.hip -- per-context mutable state (see runtime.h).
+#include "runtime.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace vaenpvc {
+
+static thread_local Runtime* tl_rt = nullptr;
+static Runtime g_detached;  // used only if a launcher runs outside an ABI call (never in the product)
+
+Runtime& rt() { return tl_rt ? *tl_rt : g_detached; }
+RtScope::RtScope(Runtime* r) : prev(tl_rt) { tl_rt = r; }
+RtScope::~RtScope() { tl_rt = prev; }
+
+// Developer knobs, read ONCE when the context is created (not process-global state):
+//   VAENPVC_FWD_MASK / VAENPVC_BWD_MASK   initial kernel-selection masks
+//   VAENPVC_SIDE_STREAM=0                 weight gradients on the caller's stream
+//   VAENPVC_TOEP=f32                      exact-fp32 MFMA kernels for the 1025-tap layer
+//   VAENPVC_TOEP_WGRAD_F32                exact-fp32 weight gradient of that layer only
+//   VAENPVC_PLANES=1|2|3                  bf16 terms per fp32 operand (vaenpvc_set_precision)
+void Runtime::read_env() {
+  if (const char* e = getenv("VAENPVC_FWD_MASK")) fwd_mask = (unsigned)strtoul(e, nullptr, 0);
+  if (const char* e = getenv("VAENPVC_BWD_MASK")) bwd_mask = (unsigned)strtoul(e, nullptr, 0);
+  if (const char* e = getenv("VAENPVC_SIDE_STREAM")) side_enabled = e[0] != '0';
+  if (const char* e = getenv("VAENPVC_TOEP")) toep_f32 = !strcmp(e, "f32");
+  toep_wgrad_f32 = getenv("VAENPVC_TOEP_WGRAD_F32") != nullptr;
+  if (const char* e = getenv("VAENPVC_PLANES")) {
+    int p = atoi(e);
+    if (p >= 1 && p <= 3) planes = p;
+  }
+}
+
+void Runtime::release() {
+  if (s2) {
+    (void)hipStreamSynchronize(s2);
+    (void)hipStreamDestroy(s2);
+    for (auto& e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
+  s2 = nullptr;
+  for (auto& e : ev) e = nullptr;
+  ev_next = 0;
+  for (auto& p : pool) {
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+  pool.clear();
+  used = 0;
+  attr_done.clear();
+}
+
+void Runtime::bind_device() {
+  int d = -1;
+  if (hipGetDevice(&d) != hipSuccess) return;
+  if (d == device) return;
+  if (device >= 0) {  // the context moved to another device: its stream, events and attributes do not follow
+    int cur = d;
+    (void)hipSetDevice(device);
+    release();
+    (void)hipSetDevice(cur);
+  }
+  device = d;
+}
+
+void Runtime::ensure_lds(const void* fn, int bytes) {
+  if (attr_done.count(fn)) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  attr_done.insert(fn);
+}
+
+hipStream_t Runtime::side_stream() {
+  if (!side_enabled) return nullptr;
+  if (s2) return s2;
+  if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) {
+    s2 = nullptr;
+    side_enabled = false;
+    return nullptr;
+  }
+  for (auto& e : ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  return s2;
+}
+
+void Runtime::stream_dep(hipStream_t from, hipStream_t to) {
+  hipEvent_t e = ev[ev_next];
+  ev_next = (ev_next + 1) % 16;
+  (void)hipEventRecord(e, from);
+  (void)hipStreamWaitEvent(to, e, 0);
+}
+
+static const size_t kPoolMax = 16384;
+void Runtime::timer_begin(hipStream_t s) {
+  if (used >= kPoolMax) return;
+  if (used >= pool.size()) {
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    pool.emplace_back(a, b);
+  }
+  (void)hipEventRecord(pool[used].first, s);
+}
+void Runtime::timer_end(hipStream_t s) {
+  if (used >= kPoolMax || used >= pool.size()) return;
+  (void)hipEventRecord(pool[used].second, s);
+  ++used;
+}
+
+}  // namespace vaenpvc

@@ -1,15 +1,26 @@
-"""Data-parallel train step: one process per GPU, gradients all-reduced (SUM) as ONE
-flat float32 buffer over torch.distributed ("nccl" == RCCL over xGMI on ROCm), the
-1/world_size mean folded into the fused Adam kernel (grad_scale).
+"""Data-parallel train step: one process per GPU, gradients all-reduced (SUM) over
+torch.distributed ("nccl" == RCCL over xGMI on ROCm), the 1/world_size mean folded into the fused
+Adam kernel (grad_scale).
 
-The reference has no multi-GPU code at all; frames are independent
-(per-sample LayerNorm, batch-mean loss), so sharding frames over ranks is exactly one
-big batch up to summation order.
+The reference has no multi-GPU code at all; frames are independent (per-sample
+LayerNorm, batch-mean loss), so sharding frames over ranks is exactly one big batch up to
+summation order.
 
-`backend` is anything with `.params`, `.n_params`, `.train_fwd_bwd(x,y,eps,grads)` and
-`.adam_step(grads,m,v,step,lr,b1,b2,eps,grad_scale)`; the only shipped backend is
-hipvae.Engine (HIP).  Tests inject a CPU stand-in to exercise this host logic under gloo.
+Overlap.  The backward pass finishes the flat gradient buffer back to front in four
+contiguous ranges -- decoder convs, merge, heads, embedding + encoder -- and the library reports each
+one through a callback the moment its kernels are enqueued (vaenpvc_set_bucket_callback).  The
+callback starts that range's all-reduce on the communicator's stream, ordered after the library's
+weight-gradient stream, so 3.3 of the 3.76 MB fly while the encoder backward still runs; Adam waits
+for all of them.  The three losses ride in the tail of the same buffer (they are final before the
+first range), so every rank holds the global mean losses after every step WITHOUT a collective of
+its own: logging can never issue a collective that other ranks do not issue.
+
+`backend` is anything with `.params`, `.n_params`, `.train_fwd_bwd(x, y, eps, grads, out=, seed=, offset=)`
+and `.adam_step(...)`; the only shipped backend is hipvae.Engine (HIP).  Tests inject a CPU
+stand-in to exercise this host logic under gloo.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -28,52 +39,122 @@ def shard_range(F, rank, world):
     return rank * per, (rank + 1) * per
 
 
+def rank_seed(seed, rank, world):
+    """Sampler seed of a rank: every rank must draw DIFFERENT noise for its shard (the reference
+    draws independent N(0,1) per frame, util/layers.py:154)."""
+    return (int(seed) * int(world) + int(rank)) & (2 ** 64 - 1)
+
+
 class Stepper(object):
-    def __init__(self, backend, lr, beta1, beta2, eps=1e-8, group=None):
+    TAIL = 4    # floats appended to the gradient buffer: {G, D_KL, logP} of the step + padding
+
+    def __init__(self, backend, lr, beta1, beta2, eps=1e-8, group=None, overlap=True, seed=0):
         self.backend = backend
         self.lr, self.beta1, self.beta2, self.eps = float(lr), float(beta1), float(beta2), float(eps)
         self.group = group
         self.rank, self.world = world_info(group)
-        import os
-        # VAENPVC_FORCE_DIST=1: run the all-reduce even with one rank (smoke-tests the RCCL path)
-        self._force_collective = os.environ.get('VAENPVC_FORCE_DIST') == '1' and dist.is_available() and dist.is_initialized()
+        # VAENPVC_FORCE_DIST=1: run the collectives even with one rank (smoke-tests the RCCL path)
+        self._force_collective = (os.environ.get('VAENPVC_FORCE_DIST') == '1' and dist.is_available()
+                                  and dist.is_initialized())
+        self.collective = self.world > 1 or self._force_collective
         p = backend.params
-        self.grads = torch.zeros_like(p)
+        n = p.numel()
+        self._gbuf = torch.zeros(n + self.TAIL, dtype=p.dtype, device=p.device)
+        self.grads = self._gbuf[:n]             # flat gradient buffer, same layout as the parameters
+        self._loss_tail = self._gbuf[n:n + 3]   # this step's losses; SUM over ranks after the all-reduce
         self.m = torch.zeros_like(p)      # Adam slots (tf.train.AdamOptimizer "m"/"v")
         self.v = torch.zeros_like(p)
         self.step_count = 0               # global_step (trainer/vae.py:15)
+        self.seed = rank_seed(seed, self.rank, self.world)
+        self.overlap = bool(overlap) and hasattr(backend, 'set_bucket_callback')
+        self._works = []
+        self._cb_on = False
 
     def broadcast_params(self, src=0):
         if self.world > 1:
             dist.broadcast(self.backend.params, src=src, group=self.group)
 
-    def step(self, x, y, eps):
-        """x, y, eps are this rank's LOCAL shard.  Returns the local loss3 tensor."""
-        loss3 = self.backend.train_fwd_bwd(x, y, eps, self.grads)
-        if self.world > 1 or self._force_collective:
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group)
+    # ------------------------------------------------------------------ bucketed all-reduce
+    def _bucket_ready(self, bucket, off, cnt, ready_stream):
+        n = self.grads.numel()
+        if off + cnt == n:
+            cnt += self.TAIL                   # the losses travel with the range that ends the buffer
+        seg = self._gbuf[off:off + cnt]
+        if seg.is_cuda and ready_stream:
+            # order the collective after the library stream that holds this range (ProcessGroupNCCL
+            # makes its own stream wait for the stream that is current when the collective is issued)
+            ext = torch.cuda.ExternalStream(int(ready_stream), device=seg.device)
+            with torch.cuda.stream(ext):
+                w = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            w = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append(w)
+
+    def _set_cb(self, on):
+        if on != self._cb_on:
+            self.backend.set_bucket_callback(self._bucket_ready if on else None)
+            self._cb_on = on
+
+    def step(self, x, y, eps=None):
+        """x, y (and optionally an injected eps) are this rank's LOCAL shard.  Without eps the sampler
+        draws on the device, keyed by (rank seed, global step).  Returns {G, D_KL, logP}: this rank's
+        values on one rank, the mean over ranks otherwise."""
+        be = self.backend
+        use_cb = self.collective and self.overlap
+        self._set_cb(use_cb)
+        self._works = []
+        if eps is None:
+            loss3 = be.train_fwd_bwd(x, y, None, self.grads, out=self._loss_tail, seed=self.seed,
+                                     offset=self.step_count)
+        else:
+            loss3 = be.train_fwd_bwd(x, y, eps, self.grads, out=self._loss_tail)
+        if self.collective:
+            if use_cb:
+                for w in self._works:          # current stream waits for every range
+                    w.wait()
+                self._works = []
+            else:
+                dist.all_reduce(self._gbuf, op=dist.ReduceOp.SUM, group=self.group)
         self.step_count += 1
-        self.backend.adam_step(self.grads, self.m, self.v, self.step_count, self.lr, self.beta1, self.beta2,
-                               self.eps, 1.0 / self.world)
-        return loss3
+        be.adam_step(self.grads, self.m, self.v, self.step_count, self.lr, self.beta1, self.beta2,
+                     self.eps, 1.0 / self.world)
+        # (with a collective the tail now holds the SUM over ranks: hand out the mean, as a new tensor)
+        return self._loss_tail / float(self.world) if self.collective else loss3
+
+    def mean_losses(self, loss3=None):
+        """{G, D_KL, logP} of the LAST step averaged over ranks.  No collective: the sums arrived with the
+        gradient all-reduce, so ranks may call this at different times (or not at all)."""
+        if self.collective:
+            return self._loss_tail / float(self.world)
+        return self._loss_tail.clone() if loss3 is None else loss3.clone()
 
     # ------------------------------------------------------------------ hipGraph replay
-    def capture(self, x, y, eps):
-        """Capture one single-GPU train step (forward+backward+Adam, ~130 kernel launches) in a
-        hipGraph on static copies of (x, y, eps); `replay()` then runs a step with one launch.
-        Launch overhead dominates below a few thousand frames per step (the reference trains
-        with batch 16).  The optimiser state is snapshotted around the capture warm-up, so the
-        trajectory is unchanged.  Returns the static input tensors to copy new batches into."""
-        if self.world != 1:
-            raise RuntimeError('graph capture is implemented for single-process training only')
+    def capture(self, x, y, eps=None):
+        """Capture one train step (forward + backward [+ all-reduce] + Adam, ~130 kernel launches) in a
+        hipGraph on static copies of (x, y[, eps]); `replay()` then runs a step with one launch.
+        Launch overhead dominates below a few thousand frames per step (the reference trains with
+        batch 16).  Without eps the sampler draws inside the graph, keyed by the DEVICE step counter, so
+        every replay sees fresh noise.  With more than one rank the (single, unbucketed) gradient
+        all-reduce is captured with the step.  The optimiser state is snapshotted around the capture
+        warm-up, so the trajectory is unchanged.  Returns the static input tensors to copy new
+        batches into."""
         be = self.backend
-        self._gx, self._gy, self._ge = x.clone(), y.clone(), eps.clone()
+        self._set_cb(False)
+        self._gx, self._gy = x.clone(), y.clone()
+        self._ge = eps.clone() if eps is not None else None
         self._d_step = torch.full((1,), self.step_count, dtype=torch.int64, device=be.params.device)
         snap = (be.params.clone(), self.m.clone(), self.v.clone())
 
         def one_step():
-            l3 = be.train_fwd_bwd(self._gx, self._gy, self._ge, self.grads)
-            be.adam_step_dev(self.grads, self.m, self.v, self._d_step, self.lr, self.beta1, self.beta2, self.eps, 1.0)
+            if self._ge is None:
+                l3 = be.train_fwd_bwd(self._gx, self._gy, None, self.grads, out=self._loss_tail, seed=self.seed,
+                                      offset=0, d_offset=self._d_step)
+            else:
+                l3 = be.train_fwd_bwd(self._gx, self._gy, self._ge, self.grads, out=self._loss_tail)
+            if self.collective:
+                dist.all_reduce(self._gbuf, op=dist.ReduceOp.SUM, group=self.group)
+            be.adam_step_dev(self.grads, self.m, self.v, self._d_step, self.lr, self.beta1, self.beta2, self.eps,
+                             1.0 / self.world)
             return l3
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -89,21 +170,14 @@ class Stepper(object):
         self.m.copy_(snap[1])
         self.v.copy_(snap[2])
         self._d_step.fill_(self.step_count)
-        return self._gx, self._gy, self._ge
+        return (self._gx, self._gy, self._ge) if self._ge is not None else (self._gx, self._gy)
 
     def replay(self):
-        """One captured step on the current contents of the static inputs; returns loss3."""
+        """One captured step on the current contents of the static inputs; returns loss3 (with more than one
+        rank: the SUM over ranks -- use mean_losses())."""
         self._graph.replay()
         self.step_count += 1
         return self._gl3
-
-    def mean_losses(self, loss3):
-        """Average {G, D_KL, logP} over ranks (logging only)."""
-        out = loss3.clone()
-        if self.world > 1:
-            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
-            out /= self.world
-        return out
 
     def state_dict(self):
         return {'params': self.backend.params.detach().cpu(), 'm': self.m.cpu(), 'v': self.v.cpu(),

@@ -71,7 +71,7 @@ def glorot_init(layout, seed=None, device='cpu'):
 
 
 class Engine(object):
-    def __init__(self, arch, device=None, impl=None):
+    def __init__(self, arch, device=None, impl=None, precision=None):
         self.lib = L.load_library()
         if not torch.cuda.is_available():
             raise L.HipVaeError('no GPU visible: the ConvVAE hot path has no CPU implementation')
@@ -83,12 +83,16 @@ class Engine(object):
         self.ctx = ctx
         if impl is not None:
             self.set_impl(impl)
+        if precision is not None:
+            self.set_precision(precision)
         self.layout = self._query_layout()
         self.n_params = int(self.lib.vaenpvc_param_floats(self.ctx))
         self.z_dim, self.H = self._astruct.z_dim, self._astruct.H
         self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
         self._ws = None
         self._loss3 = torch.zeros(3, dtype=torch.float32, device=self.device)
+        self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._bucket_cb = None      # keeps the ctypes thunk alive while it is registered
 
     def __del__(self):
         try:
@@ -102,6 +106,38 @@ class Engine(object):
     def set_impl(self, impl):
         code = {'auto': L.IMPL_AUTO, 'generic': L.IMPL_GENERIC}.get(impl, impl)
         L.check(self.lib.vaenpvc_set_impl(self.ctx, int(code)), 'set_impl')
+
+    def set_precision(self, precision):
+        """'bf16x3' (fp32-exact), 'bf16x2' (default, 16 mantissa bits per operand) or 'bf16'."""
+        code = L.PRECISIONS.get(precision, precision)
+        L.check(self.lib.vaenpvc_set_precision(self.ctx, int(code)), 'set_precision')
+
+    @property
+    def precision(self):
+        return int(self.lib.vaenpvc_get_precision(self.ctx))
+
+    def set_tuned_masks(self, fwd=0xffffffff, bwd=0xffffffff):
+        """Per-step tuned/generic kernel selection of THIS engine's context (include/vaenpvc.h)."""
+        L.check(self.lib.vaenpvc_set_tuned_masks(self.ctx, fwd & 0xffffffff, bwd & 0xffffffff), 'set_tuned_masks')
+
+    def timer_select(self, tag):
+        L.check(self.lib.vaenpvc_timer_select(self.ctx, tag.encode() if tag else None), 'timer_select')
+
+    def timer_read(self):
+        ms, n = C.c_double(), C.c_int64()
+        L.check(self.lib.vaenpvc_timer_read(self.ctx, C.byref(ms), C.byref(n)), 'timer_read')
+        return ms.value, n.value
+
+    def set_bucket_callback(self, fn):
+        """fn(bucket, offset_floats, count_floats, ready_stream_ptr) is called during train_fwd_bwd as soon as
+        a contiguous range of the flat gradient buffer is complete (hipvae.dp overlaps its all-reduce)."""
+        if fn is None:
+            L.check(self.lib.vaenpvc_set_bucket_callback(self.ctx, L.BUCKET_CB(), None), 'set_bucket_callback')
+            self._bucket_cb = None
+            return
+        thunk = L.BUCKET_CB(lambda user, b, off, cnt, stream: fn(int(b), int(off), int(cnt), stream))
+        L.check(self.lib.vaenpvc_set_bucket_callback(self.ctx, thunk, None), 'set_bucket_callback')
+        self._bucket_cb = thunk
 
     def _query_layout(self):
         out = OrderedDict()
@@ -150,9 +186,13 @@ class Engine(object):
         ws, _ = self._workspace(F, mode)
         return ws.view(torch.float32)[off.value:off.value + cnt.value]
 
-    @staticmethod
-    def _stream():
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def _stream(self):
+        # the current stream OF THIS ENGINE'S DEVICE (not of whatever device happens to be current)
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _on_device(self):
+        """Launches must happen with the engine's device current (HIP launches go to the current device)."""
+        return torch.cuda.device(self.device)
 
     def _chk_x(self, x):
         if x.dtype != torch.float32 or not x.is_cuda:
@@ -176,9 +216,10 @@ class Engine(object):
         ws, nb = self._workspace(F, L.MODE_INFER)
         z_mu = torch.empty(F, self.z_dim, dtype=torch.float32, device=self.device)
         z_lv = torch.empty_like(z_mu) if want_lv else None
-        L.check(self.lib.vaenpvc_encode_fwd(self.ctx, self.params.data_ptr(), x.data_ptr(), F, z_mu.data_ptr(),
-                                            z_lv.data_ptr() if want_lv else None, ws.data_ptr(), nb,
-                                            self._stream()), 'encode_fwd')
+        with self._on_device():
+            L.check(self.lib.vaenpvc_encode_fwd(self.ctx, self.params.data_ptr(), x.data_ptr(), F, z_mu.data_ptr(),
+                                                z_lv.data_ptr() if want_lv else None, ws.data_ptr(), nb,
+                                                self._stream()), 'encode_fwd')
         return (z_mu, z_lv) if want_lv else z_mu
 
     def decode(self, z, y):
@@ -189,8 +230,9 @@ class Engine(object):
         y = self._chk_y(y, F)
         ws, nb = self._workspace(F, L.MODE_INFER)
         xh = torch.empty(F, self.H, dtype=torch.float32, device=self.device)
-        L.check(self.lib.vaenpvc_decode_fwd(self.ctx, self.params.data_ptr(), z.data_ptr(), y.data_ptr(), F,
-                                            xh.data_ptr(), ws.data_ptr(), nb, self._stream()), 'decode_fwd')
+        with self._on_device():
+            L.check(self.lib.vaenpvc_decode_fwd(self.ctx, self.params.data_ptr(), z.data_ptr(), y.data_ptr(), F,
+                                                xh.data_ptr(), ws.data_ptr(), nb, self._stream()), 'decode_fwd')
         return xh
 
     def _chk_eps(self, eps, F):
@@ -198,56 +240,120 @@ class Engine(object):
             raise TypeError('eps must be float32 CUDA [F, %d]' % self.z_dim)
         return eps.contiguous()
 
-    def loss_fwd(self, x, y, eps, out=None):
+    def loss_fwd(self, x, y, eps=None, out=None, seed=None, offset=0):
+        """{G, D_KL, logP}.  eps: injected N(0,1) draw [F, z]; or seed/offset: drawn on the device (Philox)."""
         x = self._chk_x(x)
         F = x.shape[0]
-        y, eps = self._chk_y(y, F), self._chk_eps(eps, F)
+        y = self._chk_y(y, F)
         out = self._loss3 if out is None else out
         ws, nb = self._workspace(F, L.MODE_TRAIN)   # same buffer as training; INFER layout is a prefix
-        L.check(self.lib.vaenpvc_loss_fwd(self.ctx, self.params.data_ptr(), x.data_ptr(), y.data_ptr(),
-                                          eps.data_ptr(), F, out.data_ptr(), ws.data_ptr(), nb, self._stream()),
-                'loss_fwd')
+        with self._on_device():
+            if eps is None:
+                if seed is None:
+                    raise TypeError('either eps or seed is required')
+                L.check(self.lib.vaenpvc_loss_fwd_seeded(self.ctx, self.params.data_ptr(), x.data_ptr(), y.data_ptr(),
+                                                         int(seed) & (2 ** 64 - 1), int(offset), F, out.data_ptr(),
+                                                         ws.data_ptr(), nb, self._stream()), 'loss_fwd_seeded')
+            else:
+                eps = self._chk_eps(eps, F)
+                L.check(self.lib.vaenpvc_loss_fwd(self.ctx, self.params.data_ptr(), x.data_ptr(), y.data_ptr(),
+                                                  eps.data_ptr(), F, out.data_ptr(), ws.data_ptr(), nb,
+                                                  self._stream()), 'loss_fwd')
         return out
 
-    def train_fwd_bwd(self, x, y, eps, grads, out=None):
+    def train_fwd_bwd(self, x, y, eps, grads, out=None, seed=None, offset=0, d_offset=None):
+        """Forward + backward.  eps: injected draw; eps=None with seed/offset: the sampler draws on the device
+        (vaenpvc_train_fwd_bwd_seeded; the draw is readable afterwards as ws_region(F, MODE_TRAIN, 'eps'))."""
         x = self._chk_x(x)
         F = x.shape[0]
-        y, eps = self._chk_y(y, F), self._chk_eps(eps, F)
+        y = self._chk_y(y, F)
         if grads.dtype != torch.float32 or grads.numel() != self.n_params or not grads.is_cuda:
             raise TypeError('grads must be a flat float32 CUDA buffer of %d elements' % self.n_params)
         out = self._loss3 if out is None else out
         ws, nb = self._workspace(F, L.MODE_TRAIN)
-        L.check(self.lib.vaenpvc_train_fwd_bwd(self.ctx, self.params.data_ptr(), x.data_ptr(), y.data_ptr(),
-                                               eps.data_ptr(), F, grads.data_ptr(), out.data_ptr(), ws.data_ptr(),
-                                               nb, self._stream()), 'train_fwd_bwd')
+        with self._on_device():
+            if eps is None:
+                if seed is None:
+                    raise TypeError('either eps or seed is required')
+                L.check(self.lib.vaenpvc_train_fwd_bwd_seeded(self.ctx, self.params.data_ptr(), x.data_ptr(),
+                                                              y.data_ptr(), int(seed) & (2 ** 64 - 1), int(offset),
+                                                              d_offset.data_ptr() if d_offset is not None else None, F,
+                                                              grads.data_ptr(), out.data_ptr(), ws.data_ptr(), nb,
+                                                              self._stream()), 'train_fwd_bwd_seeded')
+            else:
+                eps = self._chk_eps(eps, F)
+                L.check(self.lib.vaenpvc_train_fwd_bwd(self.ctx, self.params.data_ptr(), x.data_ptr(), y.data_ptr(),
+                                                       eps.data_ptr(), F, grads.data_ptr(), out.data_ptr(),
+                                                       ws.data_ptr(), nb, self._stream()), 'train_fwd_bwd')
         return out
 
+    def philox_normal(self, rows, seed, offset=0):
+        """The N(0,1) tensor [rows, z_dim] the seeded entry points draw for (seed, offset)."""
+        out = torch.empty(rows, self.z_dim, dtype=torch.float32, device=self.device)
+        with self._on_device():
+            L.check(self.lib.vaenpvc_philox_normal(int(seed) & (2 ** 64 - 1), int(offset), out.data_ptr(), out.numel(),
+                                                   self._stream()), 'philox_normal')
+        return out
+
+    def validate_ids(self, y):
+        """Raises HipVaeError if any speaker id is outside [0, y_dim) (TF raises on the CPU; the kernels clamp)."""
+        y = self._chk_y(y, y.numel())
+        with self._on_device():
+            L.check(self.lib.vaenpvc_validate_ids(self.ctx, y.data_ptr(), y.numel(), self._flag.data_ptr(),
+                                                  self._stream()), 'validate_ids')
+
     def adam_step(self, grads, m, v, step, lr, beta1, beta2, eps=1e-8, grad_scale=1.0):
-        L.check(self.lib.vaenpvc_adam_step(self.params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(),
-                                           self.n_params, int(step), float(lr), float(beta1), float(beta2),
-                                           float(eps), float(grad_scale), self._stream()), 'adam_step')
+        with self._on_device():
+            L.check(self.lib.vaenpvc_adam_step(self.params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                               self.n_params, int(step), float(lr), float(beta1), float(beta2),
+                                               float(eps), float(grad_scale), self._stream()), 'adam_step')
 
     def adam_step_dev(self, grads, m, v, d_step, lr, beta1, beta2, eps=1e-8, grad_scale=1.0):
         """Graph-capturable Adam: the int64 step counter `d_step` lives on the device."""
-        L.check(self.lib.vaenpvc_adam_step_dev(self.params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(),
-                                               self.n_params, d_step.data_ptr(), float(lr), float(beta1),
-                                               float(beta2), float(eps), float(grad_scale), self._stream()),
-                'adam_step_dev')
+        with self._on_device():
+            L.check(self.lib.vaenpvc_adam_step_dev(self.params.data_ptr(), grads.data_ptr(), m.data_ptr(),
+                                                   v.data_ptr(), self.n_params, d_step.data_ptr(), float(lr),
+                                                   float(beta1), float(beta2), float(eps), float(grad_scale),
+                                                   self._stream()), 'adam_step_dev')
 
     # ------------------------------------------------------------------ data plane
     def tanhize(self, sp, xmin, xmax, forward=True):
         sp = sp.contiguous()
         out = torch.empty_like(sp)
         fn = self.lib.vaenpvc_tanhize_fwd if forward else self.lib.vaenpvc_tanhize_bwd
-        L.check(fn(sp.data_ptr(), xmin.data_ptr(), xmax.data_ptr(), out.data_ptr(), sp.shape[0], sp.shape[1],
-                   self._stream()), 'tanhize')
+        with self._on_device():
+            L.check(fn(sp.data_ptr(), xmin.data_ptr(), xmax.data_ptr(), out.data_ptr(), sp.shape[0], sp.shape[1],
+                       self._stream()), 'tanhize')
         return out
 
-    def unpack_records(self, rec, xmin, xmax):
+    def unpack_records(self, rec, xmin, xmax, index=None):
+        """x = Tanhize(rec[i, :H]), y = int64(rec[i, -1]) for i in `index` (int64 CUDA tensor; default: all rows).
+        The gather runs inside the kernel (analyzer.py:113-135 dequeue + slicing in one pass)."""
         rec = rec.contiguous()
-        F, R = rec.shape
+        N, R = rec.shape
+        F = N if index is None else int(index.numel())
         x = torch.empty(F, self.H, dtype=torch.float32, device=self.device)
         y = torch.empty(F, dtype=torch.int64, device=self.device)
-        L.check(self.lib.vaenpvc_unpack_records(rec.data_ptr(), F, R, self.H, xmin.data_ptr(), xmax.data_ptr(),
-                                                x.data_ptr(), y.data_ptr(), self._stream()), 'unpack_records')
+        with self._on_device():
+            if index is None:
+                L.check(self.lib.vaenpvc_unpack_records(rec.data_ptr(), F, R, self.H, xmin.data_ptr(), xmax.data_ptr(),
+                                                        x.data_ptr(), y.data_ptr(), self._stream()), 'unpack_records')
+            else:
+                if index.dtype != torch.int64 or not index.is_cuda:
+                    raise TypeError('index must be an int64 CUDA tensor')
+                index = index.contiguous()
+                L.check(self.lib.vaenpvc_gather_unpack_records(rec.data_ptr(), N, index.data_ptr(), F, R, self.H,
+                                                               xmin.data_ptr(), xmax.data_ptr(), x.data_ptr(),
+                                                               y.data_ptr(), self._stream()), 'gather_unpack_records')
         return x, y
+
+    def summary(self, data, edges):
+        """tf.summary.histogram payload of a float32 CUDA tensor over ascending bucket limits `edges` (float32
+        CUDA, <= 2048): returns (stats float64[4] = min, max, sum, sum of squares; counts int64[len(edges)+1])."""
+        data = data.contiguous().view(-1)
+        stats = torch.tensor([float('inf'), float('-inf'), 0.0, 0.0], dtype=torch.float64, device=self.device)
+        counts = torch.zeros(edges.numel() + 1, dtype=torch.int64, device=self.device)
+        with self._on_device():
+            L.check(self.lib.vaenpvc_summary(data.data_ptr(), data.numel(), edges.data_ptr(), edges.numel(),
+                                             stats.data_ptr(), counts.data_ptr(), self._stream()), 'summary')
+        return stats, counts

@@ -8,10 +8,12 @@ CSRC = os.path.normpath(os.path.join(_HERE, '..', 'csrc'))
 # VAENPVC_LIB: developer override used by scripts/build_variant.sh (kernel experiments)
 LIB_PATH = os.environ.get('VAENPVC_LIB') or os.path.join(CSRC, 'libvaenpvc_hip.so')
 MAX_LAYERS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 MODE_INFER, MODE_TRAIN = 0, 1
 IMPL_AUTO, IMPL_GENERIC = 0, 1
+PREC_BF16X3, PREC_BF16X2, PREC_BF16 = 3, 2, 1
+PRECISIONS = {'bf16x3': 3, 'bf16x2': 2, 'bf16': 1, 'f32': 3}
 
 
 class HipVaeError(RuntimeError):
@@ -33,7 +35,9 @@ class Arch(C.Structure):
 
 # name -> (restype, argtypes); kept in one table so tests can check every symbol of
 # include/vaenpvc.h is exported.
-_P, _I64, _I32, _F = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+_P, _I64, _I32, _F, _U64 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint64
+# vaenpvc_bucket_cb(user, bucket, offset_floats, count_floats, ready_stream)
+BUCKET_CB = C.CFUNCTYPE(None, _P, _I32, _I64, _I64, _P)
 SIGNATURES = {
     'vaenpvc_abi_version': (C.c_int, []),
     'vaenpvc_last_error': (C.c_char_p, []),
@@ -54,10 +58,19 @@ SIGNATURES = {
     'vaenpvc_adam_step_dev': (C.c_int, [_P, _P, _P, _P, _I64, _P, _F, _F, _F, _F, _F, _P]),
     'vaenpvc_tanhize_fwd': (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P]),
     'vaenpvc_tanhize_bwd': (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P]),
-    'vaenpvc_set_tuned_masks': (C.c_int, [C.c_uint32, C.c_uint32]),
-    'vaenpvc_timer_select': (C.c_int, [C.c_char_p]),
-    'vaenpvc_timer_read': (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64)]),
+    'vaenpvc_set_tuned_masks': (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    'vaenpvc_timer_select': (C.c_int, [_P, C.c_char_p]),
+    'vaenpvc_timer_read': (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
     'vaenpvc_unpack_records': (C.c_int, [_P, _I64, _I32, _I32, _P, _P, _P, _P, _P]),
+    'vaenpvc_gather_unpack_records': (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P]),
+    'vaenpvc_set_precision': (C.c_int, [_P, C.c_int]),
+    'vaenpvc_get_precision': (C.c_int, [_P]),
+    'vaenpvc_train_fwd_bwd_seeded': (C.c_int, [_P, _P, _P, _P, _U64, _U64, _P, _I64, _P, _P, _P, C.c_size_t, _P]),
+    'vaenpvc_loss_fwd_seeded': (C.c_int, [_P, _P, _P, _P, _U64, _U64, _I64, _P, _P, C.c_size_t, _P]),
+    'vaenpvc_philox_normal': (C.c_int, [_U64, _U64, _P, _I64, _P]),
+    'vaenpvc_set_bucket_callback': (C.c_int, [_P, BUCKET_CB, _P]),
+    'vaenpvc_validate_ids': (C.c_int, [_P, _P, _I64, _P, _P]),
+    'vaenpvc_summary': (C.c_int, [_P, _I64, _P, _I32, _P, _P, _P]),
 }
 
 _lib = None

@@ -28,7 +28,8 @@ def parse_args(argv=None):
     p.add_argument('--model', default=None, help='Model: ConvVAE')
     p.add_argument('--trainer_module', default='trainer.vae', help='Trainer module')
     p.add_argument('--trainer', default=None, help='Trainer: VAETrainer')
-    p.add_argument('--seed', type=int, default=0, help='(new) weight-init / shuffle seed')
+    p.add_argument('--seed', type=int, default=0, help='(new) weight-init / shuffle / sampler seed')
+    p.add_argument('--precision', default=None, help='(new) bf16x2 (default) | bf16x3 (fp32-exact) | bf16')
     args = p.parse_args(argv)
     if args.model is None or args.trainer is None:          # main.py:33-37
         raise ValueError('\n  Both `model` and `trainer` should be assigned.'
@@ -53,7 +54,11 @@ def main(argv=None):
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
         dist.init_process_group('nccl')
 
-    dirs = validate_log_dirs(args)
+    # the default logdir carries a wall-clock stamp: rank 0 chooses it, everybody else receives it
+    box = [validate_log_dirs(args) if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    dirs = box[0]
     os.makedirs(dirs['logdir'], exist_ok=True)
     with open(args.architecture) as f:
         arch = json.load(f)
@@ -65,7 +70,7 @@ def main(argv=None):
     image, label = read(file_pattern=arch['training']['datadir'], batch_size=arch['training']['batch_size'],
                         capacity=2048, min_after_dequeue=1024, normalizer=normalizer, seed=args.seed,
                         rank=rank, world=world)
-    machine = MODEL(arch, seed=args.seed)
+    machine = MODEL(arch, seed=args.seed, **({'precision': args.precision} if args.precision else {}))
     loss = machine.loss(image, label)
     trainer = TRAINER(loss, arch, args, dirs)
     trainer.train(nIter=arch['training']['max_iter'], machine=machine)

@@ -7,8 +7,6 @@ device tensors (evaluated now, eps ~ N(0,1) drawn on the device like
 GaussianSampleLayer, util/layers.py:152-156) or the lazy (image, label) handles returned
 by `analyzer.read` (evaluated by the trainer each step, like `sess.run`).
 """
-import torch
-
 from hipvae.engine import Engine
 
 
@@ -20,12 +18,18 @@ class LossDict(dict):
 
 
 class ConvVAE(object):
-    def __init__(self, arch, is_training=False, device=None, seed=None, impl=None):
+    def __init__(self, arch, is_training=False, device=None, seed=None, impl=None, precision=None):
         self.arch = arch
         self._sanity_check()
         self.is_training = is_training           # unused, kept like the reference (vae.py:14)
-        self.engine = Engine(arch, device=device, impl=impl)
+        self.engine = Engine(arch, device=device, impl=impl, precision=precision)
         self.engine.init_params(seed)
+        # sampler stream of eager loss() calls: Philox keyed by (seed, rank), one counter tick per call
+        import os
+        from hipvae.dp import rank_seed
+        self._eps_seed = rank_seed(0 if seed is None else seed, int(os.environ.get('RANK', '0')),
+                                   int(os.environ.get('WORLD_SIZE', '1'))) ^ 0x5A17
+        self._eps_calls = 0
         self.generate = self.decode              # vae.py:34 (VAE-GAN extension alias)
 
     def _sanity_check(self):                     # vae.py:37-39
@@ -37,7 +41,10 @@ class ConvVAE(object):
         return self.engine.param_views()['y_embedding/y_emb']
 
     def _draw_eps(self, F):
-        return torch.randn(F, self.engine.z_dim, dtype=torch.float32, device=self.engine.device)
+        """The N(0,1) draw [F, z_dim] of GaussianSampleLayer (util/layers.py:154) from the library's own
+        counter-based generator (one fresh counter value per call; ranks use different keys)."""
+        self._eps_calls += 1
+        return self.engine.philox_normal(F, self._eps_seed, self._eps_calls)
 
     def loss(self, x, y, eps=None):
         """vae.py:106-137 -> {'G': -logPx + D_KL, 'D_KL', 'logP'} (0-d device tensors),
@@ -48,9 +55,11 @@ class ConvVAE(object):
             out.source = x.source
             out.update({'G': None, 'D_KL': None, 'logP': None})
             return out
-        F = x.shape[0]
-        eps = self._draw_eps(F) if eps is None else eps
-        l3 = self.engine.loss_fwd(x, y, eps).clone()
+        if eps is None:       # drawn inside the sampler kernel
+            self._eps_calls += 1
+            l3 = self.engine.loss_fwd(x, y, seed=self._eps_seed, offset=self._eps_calls).clone()
+        else:
+            l3 = self.engine.loss_fwd(x, y, eps).clone()
         out.update({'G': l3[0], 'D_KL': l3[1], 'logP': l3[2]})
         return out
 

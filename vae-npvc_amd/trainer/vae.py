@@ -26,14 +26,16 @@ class VAETrainer(object):
         self.log = logging.getLogger('vaenpvc.train.%x' % id(self))
         self.log.setLevel(logging.INFO)
         self.log.propagate = False
-        self.log.addHandler(logging.FileHandler(os.path.join(dirs['logdir'], 'training.log')))
+        if self.opt['g'].rank == 0:
+            self.log.addHandler(logging.FileHandler(os.path.join(dirs['logdir'], 'training.log')))
+        self.summary = None
 
     def _optimize(self):                                  # trainer/vae.py:10-28
         t = self.arch['training']
         machine = getattr(self.loss, 'machine', None)
         if machine is None:
             raise ValueError('loss must come from ConvVAE.loss (it carries the machine)')
-        stepper = Stepper(machine.engine, t['lr'], t['beta1'], t['beta2'])
+        stepper = Stepper(machine.engine, t['lr'], t['beta1'], t['beta2'], seed=getattr(self.args, 'seed', 0) or 0)
         return {'g': stepper, 'global_step': lambda: stepper.step_count}
 
     def _status_message(self, step, logP, D_KL):          # trainer/vae.py:47-50
@@ -42,7 +44,10 @@ class VAETrainer(object):
         msg += 'D_KL(z) = {:.3e} '.format(D_KL)
         return msg
 
-    def _refresh_status(self, l3):                        # trainer/vae.py:31-52
+    def _refresh_status(self, l3=None):                   # trainer/vae.py:31-52
+        """Formats and logs the status line from the LAST step's losses.  Issues NO collective (the loss
+        sums arrive with the gradient all-reduce, hipvae/dp.py), so ranks may refresh at different
+        wall-clock moments without ever desynchronising the communicator."""
         st = self.opt['g']
         l3 = st.mean_losses(l3).cpu()
         msg = self._status_message(st.step_count, float(l3[2]), float(l3[1]))
@@ -61,24 +66,48 @@ class VAETrainer(object):
         torch.save(sd, path)
         return path
 
-    def train(self, nIter, machine=None, summary_op=None, status_secs=60, save_secs=300):
+    def restore(self, restore_from, ckpt=None):
+        """tf.train.Supervisor restore (trainer/vae.py:77-84 + util/wrapper.py:32-62): parameters, the Adam
+        slots and global_step of `<restore_from>/<ckpt or newest model.ckpt-N>`.  Returns the restored
+        step, or None when the directory holds no checkpoint (fresh run, like the Supervisor)."""
+        from util.wrapper import find_ckpt, read_ckpt
+        path = find_ckpt(restore_from, ckpt)
+        if path is None:
+            return None
+        self.opt['g'].load_state_dict(read_ckpt(path))
+        return self.opt['g'].step_count
+
+    def train(self, nIter, machine=None, summary_op=None, status_secs=60, save_secs=300, summary_secs=120):
         """trainer/vae.py:73-99.  Like the reference, the iteration count comes from
-        arch['training']['max_iter'] (nIter is ignored, trap T7)."""
+        arch['training']['max_iter'] (nIter is ignored, trap T7) and counts GLOBAL steps: a restored
+        run continues at its checkpoint's step."""
         st = self.opt['g']
         machine = machine or self.loss.machine
         source = self.loss.source
         if source is None:
             raise ValueError('loss was not built from analyzer.read() handles')
+        restore_from = self.dirs.get('restore_from')
+        if restore_from and os.path.isdir(restore_from) and (getattr(self.args, 'restore_from', None)
+                                                              or getattr(self.args, 'ckpt', None)):
+            step = self.restore(restore_from, getattr(self.args, 'ckpt', None))
+            if st.rank == 0 and step is not None:
+                self.log.info('restored step {} from {}'.format(step, restore_from))
         st.broadcast_params()
         max_iter = self.arch['training']['max_iter']
+        if st.rank == 0 and self.summary is None and hasattr(st.backend, 'summary'):
+            from util.summary import SummaryWriter          # Supervisor summary thread (save_summaries_secs = 120)
+            self.summary = SummaryWriter(self.dirs['logdir'], st.backend, secs=summary_secs)
         t_status = t_save = time.time()
         l3 = None
-        for step in range(max_iter):
+        while st.step_count < max_iter:
             x, y = source.next_batch()                    # analyzer.read dequeue
-            eps = machine._draw_eps(x.shape[0])           # GaussianSampleLayer draw
-            l3 = st.step(x, y, eps)                       # sess.run(self.opt['g'])
+            l3 = st.step(x, y)                            # sess.run(self.opt['g']); the sampler draws on the device
             now = time.time()
-            if now - t_status >= status_secs:
+            if self.summary is not None and self.summary.due(now):      # model/vae.py:132-136, rank 0 only
+                from hipvae import lib as L
+                xh = st.backend.ws_region(x.shape[0], L.MODE_TRAIN, 'xh')
+                self.summary.write(st.step_count, st.mean_losses(l3).cpu(), x, xh)
+            if now - t_status >= status_secs:             # per-rank wall clock is fine: no collective inside
                 self._refresh_status(l3)
                 t_status = now
             if now - t_save >= save_secs:                 # Supervisor save_model_secs=300

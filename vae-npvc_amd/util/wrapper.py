@@ -28,16 +28,32 @@ def validate_log_dirs(args):
     return {'logdir': logdir, 'logdir_root': logdir_root, 'restore_from': restore_from}
 
 
+def find_ckpt(logdir, ckpt=None):
+    """`<logdir>/<ckpt>` or the newest model.ckpt-N under logdir (wrapper.py:32-62); None if there is none."""
+    if ckpt is None:
+        if not os.path.isdir(logdir):
+            return None
+        cands = [f for f in os.listdir(logdir) if re.match(r'model\.ckpt-\d+$', f)]
+        if not cands:
+            return None
+        ckpt = max(cands, key=lambda f: int(f.rsplit('-', 1)[1]))
+    path = os.path.join(logdir, ckpt)
+    return path if os.path.exists(path) else None
+
+
+def read_ckpt(path):
+    """A checkpoint written by VAETrainer.save: {'params', 'm', 'v', 'step', 'layout'} (flat float32 buffers in
+    the tensor order of include/vaenpvc.h)."""
+    return torch.load(path, map_location='cpu')
+
+
 def load(engine, logdir, ckpt=None):
     """Restore parameters from `<logdir>/<ckpt>` or the newest model.ckpt-N
     (wrapper.py:32-62); returns the global step parsed from the -N suffix."""
-    if ckpt is None:
-        cands = [f for f in os.listdir(logdir) if re.match(r'model\.ckpt-\d+$', f)]
-        if not cands:
-            raise FileNotFoundError('no model.ckpt-N under %s' % logdir)
-        ckpt = max(cands, key=lambda f: int(f.rsplit('-', 1)[1]))
-    path = os.path.join(logdir, ckpt)
-    sd = torch.load(path, map_location='cpu')
+    path = find_ckpt(logdir, ckpt)
+    if path is None:
+        raise FileNotFoundError('no model.ckpt-N under %s' % logdir)
+    sd = read_ckpt(path)
     engine.load_flat(sd['params'])
-    m = re.search(r'-(\d+)$', ckpt)
+    m = re.search(r'-(\d+)$', path)
     return int(m.group(1)) if m else int(sd.get('step', 0))
