@@ -143,17 +143,20 @@ __global__ void k_reparam(const float* __restrict__ zmu, const float* __restrict
 }
 
 // model/vae.py:51-61,89 : h = z*Wz + bz + E[y]*Wy + by + b
+// speaker ids outside [0, ny) are clamped (vaenpvc_validate_ids reports them): no out-of-bounds access
+__device__ __forceinline__ int64_t clamp_id(int64_t v, int ny) { return v < 0 ? 0 : (v >= ny ? ny - 1 : v); }
+
 __global__ void k_merge_fwd(const float* __restrict__ z, const int64_t* __restrict__ y,
                             const float* __restrict__ emb, const float* __restrict__ Wz,
                             const float* __restrict__ bz, const float* __restrict__ Wy,
                             const float* __restrict__ by, const float* __restrict__ bm, float* __restrict__ h,
-                            int64_t F, int zd, int M) {
+                            int64_t F, int zd, int M, int ny) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= F * M) return;
   int n = (int)(idx % M);
   int64_t f = idx / M;
   const float* zr = z + f * zd;
-  const float* er = emb + y[f] * zd;
+  const float* er = emb + clamp_id(y[f], ny) * zd;
   float a1 = bz[n], a2 = by[n];
   for (int k = 0; k < zd; ++k) {
     a1 += zr[k] * Wz[(int64_t)k * M + n];
@@ -446,7 +449,7 @@ __global__ void k_merge_bwd_data(const float* __restrict__ dh, const float* __re
 // dWz[k,n] = sum_f z[f,k] dh[f,n] ; dWy[k,n] = sum_f E[y_f,k] dh[f,n]
 __global__ void k_merge_bwd_w(const float* __restrict__ z, const int64_t* __restrict__ y,
                               const float* __restrict__ emb, const float* __restrict__ dh,
-                              float* __restrict__ dWz, float* __restrict__ dWy, int64_t F, int zd, int M) {
+                              float* __restrict__ dWz, float* __restrict__ dWy, int64_t F, int zd, int M, int ny) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)zd * M) return;
   int n = (int)(idx % M);
@@ -455,7 +458,7 @@ __global__ void k_merge_bwd_w(const float* __restrict__ z, const int64_t* __rest
   for (int64_t f = 0; f < F; ++f) {
     float g = dh[f * M + n];
     a1 += z[f * zd + k] * g;
-    a2 += emb[y[f] * zd + k] * g;
+    a2 += emb[clamp_id(y[f], ny) * zd + k] * g;
   }
   dWz[idx] = a1;
   dWy[idx] = a2;
@@ -470,7 +473,7 @@ __global__ void k_emb_grad(const float* __restrict__ de, const int64_t* __restri
   int spk = idx / zd;
   float s = 0.f;
   for (int64_t f = 0; f < F; ++f)
-    if (y[f] == spk) s += de[f * zd + k];
+    if (clamp_id(y[f], ny) == spk) s += de[f * zd + k];
   dE[idx] = s;
 }
 
@@ -509,7 +512,7 @@ void reparam_fwd(const Model& m, const float* eps, const PhiloxKey* key, int64_t
 
 void merge_fwd(const Model& m, const float* P, const float* z, const int64_t* y, int64_t F, const Ws& w, hipStream_t s) {
   hipLaunchKernelGGL(k_merge_fwd, grid1(F * m.merge), dim3(256), 0, s, z, y, P + m.emb_off, P + m.wz_off,
-                     P + m.bz_off, P + m.wy_off, P + m.by_off, P + m.bm_off, w.h, F, m.z, m.merge);
+                     P + m.bz_off, P + m.wy_off, P + m.by_off, P + m.bm_off, w.h, F, m.z, m.merge, m.ny);
 }
 
 void dec_layer_fwd(const Model& m, const float* P, int64_t F, const Ws& w, float* xh_out, hipStream_t s, int i) {
@@ -565,7 +568,7 @@ void bwd_dec_layer(const Model& m, const float* P, int64_t F, const Ws& w, float
 
 void bwd_merge(const Model& m, const float* P, const int64_t* y, int64_t F, const Ws& w, float* G, hipStream_t s) {
   hipLaunchKernelGGL(k_merge_bwd_w, grid1((int64_t)m.z * m.merge), dim3(256), 0, s, w.z, y, P + m.emb_off, w.d_h,
-                     G + m.wz_off, G + m.wy_off, F, m.z, m.merge);
+                     G + m.wz_off, G + m.wy_off, F, m.z, m.merge, m.ny);
   hipLaunchKernelGGL(k_colsum, grid1(m.merge), dim3(256), 0, s, w.d_h, F, m.merge, G + m.bz_off, G + m.by_off,
                      G + m.bm_off);
   hipLaunchKernelGGL(k_merge_bwd_data, grid1(F * m.z), dim3(256), 0, s, w.d_h, P + m.wz_off, P + m.wy_off, w.d_z,

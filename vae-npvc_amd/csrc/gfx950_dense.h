@@ -21,6 +21,8 @@ struct DenseArgs {
   const float* gamma;
   const float* beta;
   const float* Bp;  // packed [KP][NP], zero padded
+  const float* rowbias;  // optional [nrb][ldo] table: row idx[f] is added to output row f (merge: T = E Wy + biases)
+  int nrb;               // rows of the table (idx is clamped to it)
   const float* bias;
   float* out;   // [F][ldo]            (columns n <  split)
   float* out2;  // [F][ldo] or nullptr  (columns n >= split, stored at n - split)
@@ -184,13 +186,29 @@ __global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
       }
     }
   }
+  // row offsets into the per-row bias table (merge: the speaker's row of T), fetched once for all column tiles
+  int rbo[C::MB][16];
+  if (a.rowbias) {  // uniform
+#pragma unroll
+    for (int mb = 0; mb < C::MB; ++mb)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        int f = f0 + mb * 32 + acc_row(reg, lane);
+        int64_t r = a.idx[f < a.F ? f : a.F - 1];
+        r = r < 0 ? 0 : (r >= a.nrb ? a.nrb - 1 : r);
+        rbo[mb][reg] = (int)r * a.ldo;
+      }
+  }
 #pragma unroll
   for (int nb = 0; nb < C::NBW; ++nb) {
     int n = (nt0 + nb) * 32 + l31;
     if (nt0 + nb < C::NT && n < C::N) {
       float bb = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
-      for (int mb = 0; mb < C::MB; ++mb)
+      for (int mb = 0; mb < C::MB; ++mb) {
+        float rb[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) rb[reg] = a.rowbias ? a.rowbias[rbo[mb][reg] + n] : 0.f;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           int f = f0 + mb * 32 + acc_row(reg, lane);
@@ -198,9 +216,10 @@ __global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
             if (a.out2 && n >= a.split)
               a.out2[(int64_t)f * a.ldo + (n - a.split)] = acc[mb][nb][reg] + bb;
             else
-              a.out[(int64_t)f * a.ldo + n] = acc[mb][nb][reg] + bb;
+              a.out[(int64_t)f * a.ldo + n] = acc[mb][nb][reg] + bb + rb[reg];
           }
         }
+      }
     }
   }
 }

@@ -418,6 +418,98 @@ __global__ void __launch_bounds__(256) k_reparam_bwd_colsum(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------- merge layer algebra (model/vae.py:51-61,89)
+// h = z Wz + bz + E[y] Wy + by + b.  E[y] takes only `ny` (10) distinct values, so
+//   forward : h = z Wz + T[y],  T[k] = E[k] Wy + (bz + by + b)                 (a [ny][1539] table, built per step)
+//   backward: S[k] = sum_{f: y_f = k} dh[f]   (segmented column sum, [ny][1539])
+//             d bz = d by = d b = sum_k S[k] ;  dWy = E^T S ;  dE = S Wy^T ;  dz = dh Wz^T (the only GEMM left)
+// instead of a K = 256 forward GEMM, a gathered weight-gradient GEMM and a per-frame d(e) GEMM.
+struct PackMergeTable {  // job of k_pack_multi: T[k][n], count = ny * M
+  const float *E, *Wy, *bz, *by, *bm;
+  int zd, M;
+  __device__ float operator()(int i) const {
+    const int k = i / M, n = i - k * M;
+    float acc = (bz[n] + by[n]) + bm[n];
+    const float* e = E + k * zd;
+    for (int j = 0; j < zd; ++j) acc += e[j] * Wy[(int64_t)j * M + n];
+    return acc;
+  }
+};
+
+// S[y_f][n] += d[f][n]: grid (ceil(N/256), frame chunks); the speaker of a frame is block-uniform, the ny
+// partial sums of a thread's column live in registers (uniform switch), ny atomics per thread at the end
+template <int NY>
+__global__ void __launch_bounds__(256) k_segsum_atomic(const float* __restrict__ d, const int64_t* __restrict__ y, int N, int F,
+                                                       int fchunk, float* __restrict__ S) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int fb = blockIdx.y * fchunk, fe = min(F, fb + fchunk);
+  float acc[NY];
+#pragma unroll
+  for (int k = 0; k < NY; ++k) acc[k] = 0.f;
+  const int nn = n < N ? n : N - 1;
+  for (int f0 = fb; f0 < fe; f0 += 8) {
+    float v[8];
+    int yk[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int f = f0 + u < fe ? f0 + u : fe - 1;
+      v[u] = f0 + u < fe ? d[(int64_t)f * N + nn] : 0.f;
+      int64_t yy = y[f];
+      yk[u] = (int)(yy < 0 ? 0 : (yy >= NY ? NY - 1 : yy));   // ids are clamped (vaenpvc_validate_ids reports them)
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int ku = __builtin_amdgcn_readfirstlane(yk[u]);    // block-uniform
+#pragma unroll
+      for (int k = 0; k < NY; ++k)
+        if (ku == k) acc[k] += v[u];
+    }
+  }
+  if (n < N) {
+#pragma unroll
+    for (int k = 0; k < NY; ++k)
+      if (acc[k] != 0.f) atomicAdd(S + (int64_t)k * N + n, acc[k]);
+  }
+}
+
+// everything the merge backward derives from S (plain stores: nothing else writes these gradients):
+//   blocks [0, nb_w)        : dWy[m][n] = sum_k E[k][m] S[k][n]        (one thread per element)
+//   blocks [nb_w, +nb_e)    : dE[k][m]  = sum_n S[k][n] Wy[m][n]       (one wave per element)
+//   blocks [.., +nb_b)      : the three bias gradients sum_k S[k][n]
+template <int NY>
+__global__ void __launch_bounds__(256) k_merge_small(const float* __restrict__ S, const float* __restrict__ E,
+                                                     const float* __restrict__ Wy, int zd, int M, float* __restrict__ dWy,
+                                                     float* __restrict__ dE, float* __restrict__ db1, float* __restrict__ db2,
+                                                     float* __restrict__ db3, int nb_w, int nb_e) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b < nb_w) {
+    const int i = b * 256 + tid;
+    if (i >= zd * M) return;
+    const int m = i / M, n = i - m * M;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < NY; ++k) acc += E[k * zd + m] * S[(int64_t)k * M + n];
+    dWy[i] = acc;
+  } else if (b < nb_w + nb_e) {
+    const int o = (b - nb_w) * 4 + (tid >> 6), lane = tid & 63;
+    if (o >= NY * zd) return;
+    const int k = o / zd, m = o - k * zd;
+    float acc = 0.f;
+    for (int n = lane; n < M; n += 64) acc += S[(int64_t)k * M + n] * Wy[(int64_t)m * M + n];
+    acc = wave_sum(acc);
+    if (lane == 0) dE[o] = acc;
+  } else {
+    const int n = (b - nb_w - nb_e) * 256 + tid;
+    if (n >= M) return;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < NY; ++k) acc += S[(int64_t)k * M + n];
+    db1[n] = acc;
+    db2[n] = acc;
+    db3[n] = acc;
+  }
+}
+
 // [a | b] concatenation (two bias vectors of the encoder heads -> one bias row of the fused dense layer)
 struct PackCat2 {
   const float *a, *b;

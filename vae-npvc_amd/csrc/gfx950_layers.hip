@@ -104,12 +104,14 @@ static_assert(E3Fs::BTOTAL == E3F::BTOTAL && D0Fs::BTOTAL == D0F::BTOTAL && GD0s
 
 using HeadsF = DenseCfg<768, 256, 256, 2, IN_LN, 3>;
 using HeadsB = DenseCfg<256, 768, 256, 3, IN_CONCAT2, 1>;
-using MergeF = DenseCfg<256, 1539, 256, 2, IN_CONCAT2, 1>;
-using MergeB = DenseCfg<1539, 256, 256, 2, IN_PLAIN, 1>;
+// merge: h = z Wz + T[y] (K = 128, the speaker's table row added in the epilogue); dz = dh Wz^T (N = 128)
+using MergeF = DenseCfg<128, 1539, 128, 2, IN_PLAIN, 1>;
+using MergeB = DenseCfg<1539, 128, 256, 1, IN_PLAIN, 1>;
 using HeadsFs = DenseCfg<768, 256, 256, 2, IN_LN, 3, 1>;
 using HeadsBs = DenseCfg<256, 768, 256, 3, IN_CONCAT2, 1, 1>;
-using MergeFs = DenseCfg<256, 1539, 256, 2, IN_CONCAT2, 1, 1>;
-using MergeBs = DenseCfg<1539, 256, 256, 2, IN_PLAIN, 1, 1>;
+using MergeFs = DenseCfg<128, 1539, 128, 2, IN_PLAIN, 1, 1>;
+using MergeBs = DenseCfg<1539, 128, 256, 1, IN_PLAIN, 1, 1>;
+constexpr int MERGE_NY = 10;   // speakers of the VCC2016 geometry (the tuned path is selected for it only)
 //                     XC  XH   YC  YH  T  S PAD  XLN    YLN   TF NTW
 // weight-gradient tilings: trailing parameters = TF (frames per sub-tile), NTW (column tiles per workgroup),
 // NWV (waves), WM (waves along M, 0 = auto), WPE (waves per SIMD the register budget must allow);
@@ -153,8 +155,9 @@ struct Pk {
   static constexpr int heads_b = heads_f + HeadsF::KP * HeadsF::NP;
   static constexpr int merge_f = heads_b + HeadsB::KP * HeadsB::NP;
   static constexpr int merge_b = merge_f + MergeF::KP * MergeF::NP;
-  static constexpr int merge_bias = merge_b + MergeB::KP * MergeB::NP;
-  static constexpr int d0f = merge_bias + 1600;
+  static constexpr int merge_tb = merge_b + MergeB::KP * MergeB::NP;   // T[ny][1539]: E Wy + the three biases
+  static constexpr int merge_s = merge_tb + MERGE_NY * 1539 + 2;        // S[ny][1539]: per-speaker sums of d(h)
+  static constexpr int d0f = merge_s + MERGE_NY * 1539 + 2;
   static constexpr int d1f = d0f + D0F::BTOTAL;
   static constexpr int d2f = d1f + D1F::BTOTAL;
   static constexpr int gd2 = d2f + D2F::BTOTAL;
@@ -202,12 +205,6 @@ static void for_planes(Fn&& fn) {
   }
 }
 
-struct PackSum3 {
-  const float *a, *b, *c;
-  int n;
-  __device__ float operator()(int i) const { return i < n ? (a[i] + b[i]) + c[i] : 0.f; }
-};
-
 // ---------------------------------------------------------------- weight packing
 static void prep(const Model& m, const float* P, const Ws& w, hipStream_t s) {
   float* S = w.scratch;
@@ -219,9 +216,10 @@ static void prep(const Model& m, const float* P, const Ws& w, hipStream_t s) {
       s,
       pack_job(PackDense{P + m.wmu_off, P + m.wlv_off, 0, 768, 256, HeadsF::NP, 128, 128}, S + Pk::heads_f, HeadsF::KP * HeadsF::NP),
       pack_job(PackDense{P + m.wmu_off, P + m.wlv_off, 2, 256, 768, HeadsB::NP, 128, 128}, S + Pk::heads_b, HeadsB::KP * HeadsB::NP),
-      pack_job(PackDense{P + m.wz_off, P + m.wy_off, 1, 256, 1539, MergeF::NP, 128, 0}, S + Pk::merge_f, MergeF::KP * MergeF::NP),
-      pack_job(PackDense{P + m.wz_off, P + m.wy_off, 3, 1539, 256, MergeB::NP, 128, 0}, S + Pk::merge_b, MergeB::KP * MergeB::NP),
-      pack_job(PackSum3{P + m.bz_off, P + m.by_off, P + m.bm_off, 1539}, S + Pk::merge_bias, 1600),
+      pack_job(PackDense{P + m.wz_off, P + m.wz_off, 1, 128, 1539, MergeF::NP, 128, 0}, S + Pk::merge_f, MergeF::KP * MergeF::NP),
+      pack_job(PackDense{P + m.wz_off, P + m.wz_off, 3, 1539, 128, MergeB::NP, 128, 0}, S + Pk::merge_b, MergeB::KP * MergeB::NP),
+      pack_job(PackMergeTable{P + m.emb_off, P + m.wy_off, P + m.bz_off, P + m.by_off, P + m.bm_off, m.z, m.merge},
+               S + Pk::merge_tb, MERGE_NY * 1539),
       pack_job(PackCat2{P + m.bmu_off, P + m.blv_off, 128}, S + Pk::heads_bias, 256),
       // conv_transpose forward: B[t][k=cin][n=cout] from TF [t][cout][cin]  -> transposed
       pack_job(PackConv<D0F>{P + m.dec[0].w_off, true}, S + Pk::d0f, D0F::BTOTAL),
@@ -255,6 +253,17 @@ static int nsplit_for(int F) {
   int wgs = cdiv(F, C::TF);
   int want = cdiv(512, wgs);
   return cmax(1, cmin_(NBLK, want));
+}
+
+static DenseArgs dense_args(const float* in, const float* Bp, float* out, int ldo, int F) {
+  DenseArgs a;
+  memset(&a, 0, sizeof a);
+  a.in = in;
+  a.Bp = Bp;
+  a.out = out;
+  a.ldo = ldo;
+  a.F = F;
+  return a;
 }
 
 static ConvArgs conv_args(const float* in, const float* st, const float* gamma, const float* beta, const float* Bp,
@@ -305,8 +314,12 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
     stats<768>(w.enc_a[4], w.enc_st[4], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 4);
   if (fwd_on(5)) {
-    DenseArgs a{w.enc_a[4], nullptr, nullptr, w.enc_st[4], P + m.enc[4].gamma_off, P + m.enc[4].beta_off,
-                w.scratch + Pk::heads_f, nullptr, w.z_mu, w.z_lv, 128, 128, F};
+    DenseArgs a = dense_args(w.enc_a[4], w.scratch + Pk::heads_f, w.z_mu, 128, F);
+    a.st = w.enc_st[4];
+    a.gamma = P + m.enc[4].gamma_off;
+    a.beta = P + m.enc[4].beta_off;
+    a.out2 = w.z_lv;
+    a.split = 128;
     a.bias = w.scratch + Pk::heads_bias;  // [b_mu | b_lv], packed by prep()
     VAENPVC_TIMED("heads_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<HeadsFs>(a, s) : launch_densegemm<HeadsF>(a, s)));
   } else generic::heads_fwd(m, P, F, w, s);
@@ -318,8 +331,10 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
   const int F = (int)F64;
   if (!weights_packed) prep(m, P, w, s);
   if (fwd_on(6)) {
-    DenseArgs a{z, P + m.emb_off, y, nullptr, nullptr, nullptr, w.scratch + Pk::merge_f, w.scratch + Pk::merge_bias,
-                w.h, nullptr, 0, m.merge, F};
+    DenseArgs a = dense_args(z, w.scratch + Pk::merge_f, w.h, m.merge, F);
+    a.idx = y;                                // + T[y_f]: the speaker's row of E Wy + (bz + by + b)
+    a.rowbias = w.scratch + Pk::merge_tb;
+    a.nrb = MERGE_NY;
     VAENPVC_TIMED("merge_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<MergeFs>(a, s) : launch_densegemm<MergeF>(a, s)));
   } else generic::merge_fwd(m, P, z, y, F, w, s);
   if (fwd_on(7)) {
@@ -535,18 +550,17 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     TnArgs a = tn_args(w.z, 128, w.d_h, 1539, 128, 1539, F, G + m.wz_off, 1539);
     ready();
     VAENPVC_TIMED("merge_wgrad", s2, launch_tngemm(a, false, kchunks_for(F, 13), s2));
-    TnArgs b = tn_args(P + m.emb_off, 128, w.d_h, 1539, 128, 1539, F, G + m.wy_off, 1539);
-    b.xidx = y;
-    launch_tngemm(b, false, kchunks_for(F, 13), s2);
-    int ch = cmax(1, cmin_(cdiv(F, 32), 256)), fc = cdiv(F, ch);
-    hipLaunchKernelGGL(k_colsum_atomic, dim3((unsigned)cdiv(1539, 256), (unsigned)cdiv(F, fc)), dim3(256), 0, s, w.d_h, 1539, 1539,
-                       F, fc, G + m.bz_off, G + m.by_off, G + m.bm_off);
-    DenseArgs d{w.d_h, nullptr, nullptr, nullptr, nullptr, nullptr, w.scratch + Pk::merge_b, nullptr,
-                w.d_z, w.d_e, 128, 128, F};
+    // S[k] = per-speaker column sums of d(h); the bias gradients, dWy = E^T S and dE = S Wy^T follow from it
+    float* Sg = w.scratch + Pk::merge_s;
+    (void)hipMemsetAsync(Sg, 0, (size_t)MERGE_NY * 1539 * 4, s);
+    int ch = cmax(1, cmin_(cdiv(F, 64), 128)), fc = cdiv(F, ch);
+    VAENPVC_TIMED("merge_segsum", s, hipLaunchKernelGGL(k_segsum_atomic<MERGE_NY>, dim3((unsigned)cdiv(1539, 256), (unsigned)cdiv(F, fc)), dim3(256), 0, s,
+                                                        w.d_h, y, 1539, F, fc, Sg));
+    const int nb_w = cdiv(128 * 1539, 256), nb_e = cdiv(MERGE_NY * 128, 4), nb_b = cdiv(1539, 256);
+    hipLaunchKernelGGL(k_merge_small<MERGE_NY>, dim3((unsigned)(nb_w + nb_e + nb_b)), dim3(256), 0, s, Sg, P + m.emb_off, P + m.wy_off, 128,
+                       1539, G + m.wy_off, G + m.emb_off, G + m.bz_off, G + m.by_off, G + m.bm_off, nb_w, nb_e);
+    DenseArgs d = dense_args(w.d_h, w.scratch + Pk::merge_b, w.d_z, 128, F);
     VAENPVC_TIMED("merge_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<MergeBs>(d, s) : launch_densegemm<MergeB>(d, s)));
-    int ech = cmax(1, cmin_(cdiv(F, 32), 256)), efc = cdiv(F, ech);
-    hipLaunchKernelGGL(k_emb_grad_fast, dim3((unsigned)cdiv(F, efc)), dim3(256), (size_t)m.ny * m.z * 4, s, w.d_e, 128, 0, y,
-                       G + m.emb_off, F, efc, m.z, m.ny);
   } else generic::bwd_merge(m, P, y, F, w, G, s);
   bucket(m.wz_off, m.dec[0].w_off);  // the two merge FCs and the three merge biases (the embedding goes last)
 
@@ -571,8 +585,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     a.C = G + m.wlv_off;
     launch_tngemm(a, false, kchunks_for(F, 6), s2);
     // (the two head-bias gradients were accumulated by k_reparam_bwd_colsum)
-    DenseArgs d{w.d_z_mu, w.d_z_lv, nullptr, nullptr, nullptr, nullptr, w.scratch + Pk::heads_b, nullptr,
-                w.dy_tmp, nullptr, 0, 768, F};
+    DenseArgs d = dense_args(w.d_z_mu, w.scratch + Pk::heads_b, w.dy_tmp, 768, F);
+    d.in2 = w.d_z_lv;
     VAENPVC_TIMED("heads_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<HeadsBs>(d, s) : launch_densegemm<HeadsB>(d, s)));
     launch_ln_bwd<LnbCfg<256, 3>>(w.dy_tmp, w.enc_a[4], w.enc_st[4], P + l4.gamma_off, P + l4.beta_off, w.d_enc_a[4],
                                      G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
