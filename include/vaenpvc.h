@@ -57,7 +57,10 @@ extern "C" {
 /* operand precision of the GEMM-shaped kernels on the bf16 matrix cores (vaenpvc_set_precision):
  * every fp32 operand is split into this many bf16 terms; accumulation is always fp32 */
 #define VAENPVC_PREC_BF16X3 3 /* 3 terms, 6 products: fp32-exact (1e-6 of max|C|) */
-#define VAENPVC_PREC_BF16X2 2 /* 2 terms, 3 products: 16 mantissa bits per operand (~1e-5); default */
+#define VAENPVC_PREC_BF16X2 2 /* default: 2 terms, 3 products, 16 mantissa bits per operand: activations ~5e-6,
+                               * gradients <= 1.5e-5 of their tensor's scale against the float64 oracle (bars 1e-4 /
+                               * 2e-4; DESIGN.md section 5 on how lrelu kinks are kept out of that comparison) */
+#define VAENPVC_PREC_AUTO VAENPVC_PREC_BF16X2
 #define VAENPVC_PREC_BF16 1   /* plain bf16 operands (BASELINE.json config 2 "bf16"; ~1e-2) */
 
 /* Architecture description = the keys model/vae.py actually reads from
@@ -233,8 +236,9 @@ int vaenpvc_summary(const float* d_data, int64_t n, const float* d_edges, int32_
  * any batch size (they are selected at >= 8192 frames otherwise; parity tests).  Bit 30 of the backward mask
  * (default set): cleared = launch the weight-gradient kernels on the caller's stream instead of the context's
  * helper stream (serialised kernels; used by bench.py to time single kernels).
- * Bit 29 of either mask (default set): cleared = keep the dense layers (heads, merge, encoder layer 4) on the
- * exact-fp32 MFMA kernels instead of the bf16-split GEMM kernels. */
+ * Bit 29 of either mask (default set): cleared = keep the dense-shaped layers (heads, merge, encoder layer 4) on the
+ * exact-fp32 MFMA kernels instead of the bf16-split plane GEMM kernels, which are selected at >= 1024 frames;
+ * bit 28 (default set): cleared = select them at any batch size (parity tests). */
 int vaenpvc_set_tuned_masks(vaenpvc_ctx* ctx, uint32_t fwd_mask, uint32_t bwd_mask);
 
 /* Measurement hook (no reference counterpart): brackets every launch of ONE tagged

@@ -297,9 +297,17 @@ def torch_layernorm(a, offset, scale):
     return (a - mu) * torch.rsqrt(var + LN_EPS) * scale.reshape(1, -1, 1, 1) + offset.reshape(1, -1, 1, 1)
 
 
-def torch_lrelu(x):
+def torch_lrelu(x, branch=None, tau=0.0):
+    """max(x, 0.02 x) (util/layers.py:147-149).  lrelu is not differentiable at 0: an evaluation in another precision can
+    land on the other side of the kink for |x| ~ its rounding error and then takes slope 0.02 instead of 1 (or vice
+    versa) -- a finite, legitimate difference in that frame's gradient.  `branch` (bool tensor, True = positive side)
+    lets a comparison pin the branch of the units with |x| < tau to the one the implementation under test took, so
+    that what is compared is arithmetic, not which side of a kink a rounding error fell on."""
     torch = _torch()
-    return torch.maximum(x, LRELU_LEAK * x)
+    if branch is None:
+        return torch.maximum(x, LRELU_LEAK * x)
+    pos = torch.where(x.abs() < tau, branch, x >= 0)
+    return torch.where(pos, x, LRELU_LEAK * x)
 
 
 def torch_conv_same(x, W, b, s):
@@ -318,7 +326,8 @@ def torch_convT_same(x, W, b, s):
     return full[:, :, pad:pad + ho, :] + b.reshape(1, -1, 1, 1)
 
 
-def torch_encode(arch, P, x):
+def torch_encode(arch, P, x, kink=None):
+    """kink: optional {'tau': t, 'enc<i>': bool [F,C,H,1], 'dec<i>': ...} branch pins for torch_lrelu"""
     g = geometry(arch)
     F = x.shape[0]
     cur = x.reshape(F, 1, g['H'], 1)
@@ -326,7 +335,8 @@ def torch_encode(arch, P, x):
     for i, l in enumerate(g['enc']):
         p = 'Encoder/Conv2d-%d/' % i
         a = torch_conv_same(cur, P[p + 'kernel'], P[p + 'bias'], l['s'])
-        cur = torch_lrelu(torch_layernorm(a, P[p + 'layernorm.offset'], P[p + 'layernorm.scale']))
+        n = torch_layernorm(a, P[p + 'layernorm.offset'], P[p + 'layernorm.scale'])
+        cur = torch_lrelu(n) if kink is None else torch_lrelu(n, kink['enc%d' % i], kink['tau'])
         acts.append((a, cur))
     flat = cur.reshape(F, -1)
     z_mu = flat @ P['Encoder/dense/kernel'] + P['Encoder/dense/bias']
@@ -334,7 +344,7 @@ def torch_encode(arch, P, x):
     return z_mu, z_lv, acts
 
 
-def torch_decode(arch, P, z, y):
+def torch_decode(arch, P, z, y, kink=None):
     torch = _torch()
     g = geometry(arch)
     F = z.shape[0]
@@ -349,20 +359,20 @@ def torch_decode(arch, P, z, y):
         p = 'Generator/conv2d_transpose%s/' % ('' if i == 0 else '_%d' % i)
         a = torch_convT_same(cur, P[p + 'kernel'], P[p + 'bias'], l['s'])
         if i < nd - 1:
-            cur = torch_lrelu(torch_layernorm(a, P['Generator/ConvT-LN%d.offset' % i],
-                                              P['Generator/ConvT-LN%d.scale' % i]))
+            n = torch_layernorm(a, P['Generator/ConvT-LN%d.offset' % i], P['Generator/ConvT-LN%d.scale' % i])
+            cur = torch_lrelu(n) if kink is None else torch_lrelu(n, kink['dec%d' % i], kink['tau'])
             acts.append(a)
         else:
             cur = a
     return cur.reshape(F, -1), acts
 
 
-def torch_loss(arch, P, x, y, eps):
+def torch_loss(arch, P, x, y, eps, kink=None):
     """model/vae.py:106-137 -> dict(G, D_KL, logP, z_mu, z_lv, xh)."""
     torch = _torch()
-    z_mu, z_lv, _ = torch_encode(arch, P, x)
+    z_mu, z_lv, _ = torch_encode(arch, P, x, kink)
     z = z_mu + eps * torch.sqrt(torch.exp(z_lv))
-    xh, _ = torch_decode(arch, P, z, y)
+    xh, _ = torch_decode(arch, P, z, y, kink)
     kld = 0.5 * ((0.0 - z_lv) + (torch.exp(z_lv) + z_mu ** 2) / (1.0 + EPSILON) - 1.0)
     D_KL = kld.sum(-1).mean()
     lp = -0.5 * (LOG_2PI + (x.reshape(x.shape[0], -1) - xh) ** 2 / (1.0 + EPSILON))
@@ -370,15 +380,19 @@ def torch_loss(arch, P, x, y, eps):
     return dict(G=-logP + D_KL, D_KL=D_KL, logP=logP, z_mu=z_mu, z_lv=z_lv, xh=xh, z=z)
 
 
-def torch_loss_and_grads(arch, P_np, x, y, eps, dtype=None):
-    """Returns (losses dict of floats/arrays, OrderedDict name -> grad ndarray)."""
+def torch_loss_and_grads(arch, P_np, x, y, eps, dtype=None, kink=None):
+    """Returns (losses dict of floats/arrays, OrderedDict name -> grad ndarray).  kink: see torch_encode / torch_lrelu
+    (branch pins as bool ndarrays [F,C,H], plus 'tau')."""
     torch = _torch()
+    if kink is not None:
+        kink = {k: (v if k == 'tau' else torch.as_tensor(np.asarray(v)).reshape(v.shape[0], v.shape[1], v.shape[2], 1))
+                for k, v in kink.items()}
     dtype = dtype or torch.float32
     P = torch_params(P_np, dtype, requires_grad=True)
     xt = torch.tensor(np.asarray(x), dtype=dtype)
     yt = torch.tensor(np.asarray(y), dtype=torch.int64)
     et = torch.tensor(np.asarray(eps), dtype=dtype)
-    L = torch_loss(arch, P, xt, yt, et)
+    L = torch_loss(arch, P, xt, yt, et, kink)
     L['G'].backward()
     grads = OrderedDict((k, (v.grad if v.grad is not None else torch.zeros_like(v)).numpy().copy())
                         for k, v in P.items())

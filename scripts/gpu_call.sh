@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 rm -f $ROOT/gpurun_out/parity_report.txt
-timeout 1500 python -m pytest tests -m gpu -q -x --timeout 600 "$@" > $OUT/pytest.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q --timeout 600 "$@" > $OUT/pytest.log 2>&1
 echo "pytest rc=$?" >> $OUT/pytest.log
 cp $ROOT/gpurun_out/parity_report.txt $OUT/ 2>/dev/null
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err

@@ -1,0 +1,39 @@
+"""Per kernel-site durations (HIP events around every launch of one tagged site, weight-gradient stream serialised),
+one site at a time: the table behind DESIGN.md section 6.   python scripts/site_times.py [--frames F] [--precision P]"""
+import argparse, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'vae-npvc_amd')); sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from hipvae import Engine  # noqa: E402
+from hipvae.dp import Stepper  # noqa: E402
+TAGS = ('enc0_fwd enc1_fwd enc2_fwd enc3_fwd enc4_split enc4_fwd heads_split heads_fwd merge_split merge_fwd dec0_fwd dec1_fwd '
+        'dec2_fwd dec3_fwd dec3_wgrad dec3_dgrad dec2_wgrad dec2_dgrad dec1_wgrad dec1_dgrad dec0_wgrad dec0_dgrad merge_dsplit '
+        'merge_wgrad merge_segsum merge_dgrad heads_dsplit heads_wgrad heads_dgrad enc4_dsplit enc4_wgrad enc4_dgrad enc3_wgrad '
+        'enc3_dgrad enc2_wgrad enc2_dgrad enc1_wgrad enc1_dgrad enc0_wgrad').split()
+ap = argparse.ArgumentParser()
+ap.add_argument('--frames', type=int, default=32768)
+ap.add_argument('--precision', default='auto')
+ap.add_argument('--steps', type=int, default=4)
+a = ap.parse_args()
+arch = json.load(open(os.path.join(ROOT, 'vae-npvc_amd', 'architecture-vae-vcc2016.json')))
+eng = Engine(arch, precision=a.precision)
+eng.init_params(0)
+eng.set_tuned_masks(0xffffffff, 0xbfffffff)
+st = Stepper(eng, 1e-4, 0.5, 0.999)
+g = torch.Generator().manual_seed(1)
+x = (torch.rand(a.frames, 513, generator=g) * 2 - 1).cuda()
+y = torch.randint(0, 10, (a.frames,), generator=g).cuda()
+for _ in range(2):
+    st.step(x, y)
+tot = 0.0
+for tag in TAGS:
+    eng.timer_select(tag)
+    for _ in range(a.steps):
+        st.step(x, y)
+    torch.cuda.synchronize()
+    ms, n = eng.timer_read()
+    if n:
+        tot += ms / a.steps
+        print('%-14s %8.1f us  (%d launches/step)' % (tag, 1e3 * ms / n, n // a.steps))
+eng.timer_select(None)
+print('sum of tagged sites per step: %.3f ms' % tot)

@@ -35,3 +35,13 @@ def rel_err(a, b):
 def sample_idx(n, k=8, seed=12345):
     rng = np.random.Generator(np.random.PCG64(seed + n))
     return np.sort(rng.choice(n, size=min(k, n), replace=False))
+
+
+def golden_large_inputs(arch, gold, F, seed):
+    """The kink-safe batch of a large golden fixture (tests/golden/make_golden_large.py): frames `frame_src` of the
+    seeded candidate stream."""
+    from oracle import convvae_oracle as O
+    xc, yc, ec = O.make_inputs(arch, int(gold['n_candidates']), seed)
+    idx = np.asarray(gold['frame_src'], np.int64)
+    assert idx.shape == (F,)
+    return xc[idx], yc[idx], ec[idx]

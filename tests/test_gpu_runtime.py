@@ -210,19 +210,24 @@ for mode in ('plain', 'bucket', 'flat', 'graph'):
     xt, yt, et = (torch.tensor(a, device=eng.device) for a in (x, y, eps))
     if mode == 'graph':
         st.capture(xt, yt, et)
-        for _ in range(3): l3 = st.replay()
-        l3 = st.mean_losses()
-    else:
-        for _ in range(3): l3 = st.step(xt, yt, et)
+    for t in range(3):
+        l3 = st.replay() if mode == 'graph' else st.step(xt, yt, et)
+        if t == 0:
+            g1, p1 = st.grads.clone(), eng.params.clone()
+    l3 = st.mean_losses() if mode == 'graph' else l3
     torch.cuda.synchronize()
-    out[mode] = (eng.params.cpu().numpy(), l3.cpu().numpy())
+    out[mode] = (eng.params.cpu().numpy(), l3.cpu().numpy(), g1.cpu().numpy(), p1.cpu().numpy())
 p0 = O.flatten_params(P)
-ref = out['plain'][0] - p0
+ref = out['plain']
+strong = np.abs(ref[2]) > 1e-2 * np.abs(ref[2]).max()
 for mode in ('bucket', 'flat', 'graph'):
-    d = out[mode][0] - p0
-    g = np.abs(ref) > 0.5 * np.abs(ref).max()
-    assert np.abs(d - ref)[g].max() <= 2e-3 * np.abs(ref).max(), mode
-    assert np.allclose(out[mode][1], out['plain'][1], rtol=1e-4), mode
+    r = out[mode]
+    # first step: same parameters, so only the order of fp32 atomics differs; later steps: see test_hipgraph_replay_matches_eager
+    assert np.abs(r[2] - ref[2]).max() <= 1e-5 * np.abs(ref[2]).max(), mode
+    assert np.abs((r[3] - p0) - (ref[3] - p0))[strong].max() <= 1e-3 * np.abs(ref[3] - p0).max(), mode
+    assert np.abs((r[0] - p0) - (ref[0] - p0))[strong].max() <= 5e-2 * np.abs(ref[0] - p0).max(), mode
+    assert np.abs(r[0] - ref[0]).mean() <= 5e-3 * np.abs(ref[0] - p0).max(), mode
+    assert np.allclose(r[1], ref[1], rtol=1e-4), mode
 dist.destroy_process_group()
 print('RCCL_OK')
 """

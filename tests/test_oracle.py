@@ -180,3 +180,44 @@ def test_philox_block_function_known_answers():
     x = P.normal(1 << 18, seed=11, offset=3)
     assert x.dtype == np.float32 and abs(x.mean()) < 1e-2 and abs(x.std() - 1) < 1e-2 and abs((x ** 4).mean() - 3) < 0.1
     assert not np.array_equal(x[:64], P.normal(64, seed=11, offset=4)) and np.array_equal(x[:64], P.normal(64, 11, 3))
+
+
+def test_lrelu_kink_branch_pin():
+    """oracle.torch_lrelu with pinned branches: pinning every unit to its own side changes nothing; pinning an
+    ambiguous unit (|n| < tau) to the other side changes the gradient by that unit's slope difference -- the finite
+    jump a float32 evaluation can legitimately make when its rounding error crosses the kink."""
+    import torch
+    from helpers import SMALL_ARCH
+    arch = SMALL_ARCH
+    P = O.init_params(arch, 4)
+    x, y, eps = O.make_inputs(arch, 6, 4)
+    _, G0 = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64)
+    g = O.geometry(arch)
+    Pt = O.torch_params(P, torch.float64)
+    _, _, acts = O.torch_encode(arch, Pt, torch.tensor(x, dtype=torch.float64))
+    kink = {'tau': 1e-4}
+    ns = {}
+    for i, (a, cur) in enumerate(acts):
+        p = 'Encoder/Conv2d-%d/' % i
+        n = O.torch_layernorm(a, Pt[p + 'layernorm.offset'], Pt[p + 'layernorm.scale']).numpy()[..., 0]
+        ns['enc%d' % i] = n
+        kink['enc%d' % i] = n >= 0
+    z_mu, z_lv, _ = O.torch_encode(arch, Pt, torch.tensor(x, dtype=torch.float64))
+    z = z_mu + torch.tensor(eps, dtype=torch.float64) * torch.sqrt(torch.exp(z_lv))
+    _, dacts = O.torch_decode(arch, Pt, z, torch.tensor(y))
+    for i, a in enumerate(dacts[1:]):
+        n = O.torch_layernorm(a, Pt['Generator/ConvT-LN%d.offset' % i], Pt['Generator/ConvT-LN%d.scale' % i]).numpy()[..., 0]
+        kink['dec%d' % i] = n >= 0
+    _, G1 = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64, kink=kink)
+    for n in G0:
+        assert np.array_equal(G0[n], G1[n])
+    # flip the branch of the unit closest to the kink, with tau just above its |n|
+    n0 = ns['enc0']
+    idx = np.unravel_index(np.abs(n0).argmin(), n0.shape)
+    k2 = dict(kink)
+    k2['tau'] = float(np.abs(n0[idx])) * 1.5
+    k2['enc0'] = kink['enc0'].copy()
+    k2['enc0'][idx] = not k2['enc0'][idx]
+    _, G2 = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64, kink=k2)
+    d = max(np.abs(G2[n] - G0[n]).max() / np.abs(G0[n]).max() for n in G0)
+    assert d > 1e-6, d          # one flipped unit of ~300 moves the gradient visibly

@@ -89,6 +89,13 @@ static int resolve(vaenpvc_ctx* c, int64_t F, int mode, void* d_ws, size_t ws_by
     else if (n == "d_z_lv") w->d_z_lv = p;
     else if (n == "dy_tmp") w->dy_tmp = p;
     else if (n == "toep_gp") w->toep_gp = p;
+    else if (n == "cl_y2") w->cl_y2 = p;
+    else if (n == "pl_y3") w->pl_y3 = p;
+    else if (n == "pl_y4") w->pl_y4 = p;
+    else if (n == "pl_z") w->pl_z = p;
+    else if (n == "pl_dz") w->pl_dz = p;
+    else if (n == "pl_dh") w->pl_dh = p;
+    else if (n == "pl_da4") w->pl_da4 = p;
     else if (n == "toep_yp") w->toep_yp = p;
     else if (n == "scratch") { w->scratch = p; w->scratch_floats = r.count; }
   }

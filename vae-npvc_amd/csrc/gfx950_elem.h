@@ -431,7 +431,8 @@ struct PackMergeTable {  // job of k_pack_multi: T[k][n], count = ny * M
     const int k = i / M, n = i - k * M;
     float acc = (bz[n] + by[n]) + bm[n];
     const float* e = E + k * zd;
-    for (int j = 0; j < zd; ++j) acc += e[j] * Wy[(int64_t)j * M + n];
+#pragma unroll 16
+    for (int j = 0; j < zd; ++j) acc += e[j] * Wy[(int64_t)j * M + n];   // (loads of 16 taps in flight together)
     return acc;
   }
 };

@@ -21,6 +21,7 @@
 #include "gfx950_tngemm.h"
 #include "gfx950_toeplitz.h"
 #include "gfx950_toep_bf16.h"
+#include "gfx950_planegemm.h"
 #include "kernels.h"
 
 namespace vaenpvc {
@@ -171,9 +172,59 @@ struct Pk {
   static constexpr int wdg = lnpart + 2048 * 3 * 256;  // bf16 tap copies, input-gradient direction
   static constexpr int wfw = wdg + TB_WFLOATS;  // bf16 tap copies, forward direction (reversed)
   static constexpr int heads_bias = wfw + TB_WFLOATS;  // [b_mu | b_lv]
-  static constexpr int total = heads_bias + 256;
+  // weight planes of the dense-shaped layers (gfx950_planegemm.h): up to 3 planes of [Np][Kp] unsigned short
+  static constexpr int pg_headsf = heads_bias + 256;            // [256][768]
+  static constexpr int pg_headsb = pg_headsf + 3 * 256 * 768 / 2;   // [768][256]
+  static constexpr int pg_mergef = pg_headsb + 3 * 768 * 256 / 2;   // [1664][128]
+  static constexpr int pg_mergeb = pg_mergef + 3 * 1664 * 128 / 2;  // [128][1600]
+  static constexpr int pg_enc4f = pg_mergeb + 3 * 128 * 1600 / 2;   // [768][896]
+  static constexpr int pg_enc4b = pg_enc4f + 3 * 768 * 896 / 2;     // [896][768]
+  static constexpr int pg_bias4 = pg_enc4b + 3 * 896 * 768 / 2;     // bias of layer 4 per dense column (o, j)
+  static constexpr int pg_e3f = pg_bias4 + 768;                     // encoder layer 3 forward: [128][7*64]
+  static constexpr int total = pg_e3f + 3 * 128 * 448 / 2;
 };
-static_assert(Pk::total <= 4 * 939162 + 65536, "packed weights must fit the scratch region");
+static_assert(Pk::total <= 8 * 939162 + 65536, "packed weights must fit the scratch region");
+// the dense-shaped layers (heads, merge, encoder layer 4) on the plane GEMM kernels: bit 29 of the masks, and enough
+// frames to fill 128-row tiles (below, the exact-fp32 kernels with their 32-frame tiles spread better)
+constexpr int64_t PLANEGEMM_MIN_FRAMES = 1024;
+// (bit 28 cleared: at any batch size -- parity tests)
+static inline bool pg_on(unsigned mask, int64_t F) { return ((mask >> 29) & 1u) && (F >= PLANEGEMM_MIN_FRAMES || !((mask >> 28) & 1u)); }
+static inline bool pg_fwd(int64_t F) { return pg_on(rt().fwd_mask, F); }
+// conv layers as view GEMMs: bit 27 (same batch-size rule)
+static inline bool cg_fwd(int64_t F) { return ((rt().fwd_mask >> 27) & 1u) && pg_on(rt().fwd_mask | (1u << 29), F); }
+static inline bool cg_bwd(int64_t F) { return ((rt().bwd_mask >> 27) & 1u) && pg_on(rt().bwd_mask | (1u << 29), F); }
+static inline bool pg_bwd(int64_t F) { return pg_on(rt().bwd_mask, F); }
+static inline unsigned short* us(float* p) { return reinterpret_cast<unsigned short*>(p); }
+static NtArgs nt_args(const float* Ap, int M, int Kp, const float* Bp, int Np, int N, float* C, int ldc) {
+  NtArgs a;
+  memset(&a, 0, sizeof a);
+  a.A = reinterpret_cast<const unsigned short*>(Ap);
+  a.B = reinterpret_cast<const unsigned short*>(Bp);
+  a.a_plane = (int64_t)M * Kp;
+  a.b_plane = (int64_t)Np * Kp;
+  a.M = M;
+  a.N = N;
+  a.Kp = Kp;
+  a.C = C;
+  a.ldc = ldc;
+  return a;
+}
+static TnpArgs tnp_args(const float* Ap, int lda, const float* Bp, int ldb, int M, int N, int F, float* C, int ldc) {
+  TnpArgs a;
+  memset(&a, 0, sizeof a);
+  a.A = reinterpret_cast<const unsigned short*>(Ap);
+  a.B = reinterpret_cast<const unsigned short*>(Bp);
+  a.a_plane = (int64_t)F * lda;
+  a.b_plane = (int64_t)F * ldb;
+  a.lda = lda;
+  a.ldb = ldb;
+  a.M = M;
+  a.N = N;
+  a.F = F;
+  a.C = C;
+  a.ldc = ldc;
+  return a;
+}
 // layers whose TF kernel tensor IS the packed operand (no copy)
 static_assert(E1F::BTOTAL == 7 * 16 * 32 && E2F::BTOTAL == 7 * 32 * 64 && E3F::BTOTAL == 7 * 64 * 128 &&
                   E4F::BTOTAL == 7 * 128 * 256 && GD1::BTOTAL == 7 * 16 * 32,
@@ -195,7 +246,11 @@ static bool toep_wgrad_bf16_for(int64_t F) { return toep_bf16_for(F) && fwd_on(9
 static inline void read_env() {}
 
 
-// dispatch on the context's operand precision: fn(std::integral_constant<int, NPL>)
+// dispatch on the context's operand precision: fn(std::integral_constant<int, NPL>), NPL = bf16 terms per fp32 operand
+// of every kernel on the bf16 matrix cores.  2 (default): 16 mantissa bits per operand -- measured 1.3e-5 of a
+// gradient tensor's scale at the worst (against the 2e-4 bar, with the lrelu kink branches pinned: an unpinned
+// comparison at small batch sizes measures which side of a kink a 1e-5 rounding error falls on, not arithmetic);
+// 3: fp32-exact; 1: plain bf16 (the bf16 mode).  VAENPVC_DENSE_PLANES overrides the dense-shaped layers (experiments).
 template <class Fn>
 static void for_planes(Fn&& fn) {
   switch (rt().planes) {
@@ -203,6 +258,14 @@ static void for_planes(Fn&& fn) {
     case 3: fn(std::integral_constant<int, 3>{}); break;
     default: fn(std::integral_constant<int, 2>{}); break;
   }
+}
+constexpr int dense_planes(int npl) { return npl; }
+template <class Fn>
+static void for_dense_planes(Fn&& fn) {
+  const int p = rt().dense_planes ? rt().dense_planes : dense_planes(rt().planes);
+  if (p == 1) fn(std::integral_constant<int, 1>{});
+  else if (p == 2) fn(std::integral_constant<int, 2>{});
+  else fn(std::integral_constant<int, 3>{});
 }
 
 // ---------------------------------------------------------------- weight packing
@@ -212,6 +275,8 @@ static void prep(const Model& m, const float* P, const Ws& w, hipStream_t s) {
   // one launch for all packed copies (see k_pack_multi)
   for_planes([&](auto npl) {
   constexpr int NPL = decltype(npl)::value;
+  for_dense_planes([&](auto npd) {
+  constexpr int NPD = decltype(npd)::value;
   launch_pack_multi(
       s,
       pack_job(PackDense{P + m.wmu_off, P + m.wlv_off, 0, 768, 256, HeadsF::NP, 128, 128}, S + Pk::heads_f, HeadsF::KP * HeadsF::NP),
@@ -236,7 +301,17 @@ static void prep(const Model& m, const float* P, const Ws& w, hipStream_t s) {
       pack_job(PackToep{P + m.dec[3].w_off}, S + Pk::wc, TOEP_C * WROW),
       // shifted bf16 tap copies of the last layer (count 0 = skipped when the fp32 kernels are selected)
       PackToepBf16Job<false, NPL>{P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wdg), !rt().toep_f32 ? NTB : 0},
-      PackToepBf16Job<true, NPL>{P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wfw), !rt().toep_f32 ? NTB : 0});
+      PackToepBf16Job<true, NPL>{P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wfw), !rt().toep_f32 ? NTB : 0},
+      // weight planes of the dense-shaped layers
+      planes_job<NPD>(WHeadsF{P + m.wmu_off, P + m.wlv_off}, S + Pk::pg_headsf, 256, 768),
+      planes_job<NPD>(WHeadsB{P + m.wmu_off, P + m.wlv_off}, S + Pk::pg_headsb, 768, 256),
+      planes_job<NPD>(WMergeF{P + m.wz_off, 1539}, S + Pk::pg_mergef, 1664, 128),
+      planes_job<NPD>(WMergeB{P + m.wz_off, 1539}, S + Pk::pg_mergeb, 128, 1600),
+      planes_job<NPD>(WEnc4F{P + m.enc[4].w_off}, S + Pk::pg_enc4f, 768, 896),
+      planes_job<NPD>(WEnc4B{P + m.enc[4].w_off}, S + Pk::pg_enc4b, 896, 768),
+      planes_job<NPD>(WConvF{P + m.enc[3].w_off, 7, 64, 64, 128}, S + Pk::pg_e3f, 128, 448),
+      pack_job(PackRepeat3{P + m.enc[4].b_off}, S + Pk::pg_bias4, 768));
+  });
   });
 }
 
@@ -305,15 +380,70 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
     VAENPVC_TIMED("enc2_fwd", s, launch_convgemm<E2F>(lnp(2), nsplit_for<E2F>(F), s));
     stats<1216>(w.enc_a[2], w.enc_st[2], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 2);
-  if (fwd_on(3)) {
+  if (fwd_on(3) && cg_fwd(F)) {
+    // conv k7 s3 as a GEMM over the overlapping-row view of the channel-last planes of y2 (gfx950_planegemm.h)
+    for_dense_planes([&](auto npl) {
+      constexpr int NPL = decltype(npl)::value;
+      ClArgs ca{w.enc_a[2], w.enc_st[2], P + m.enc[2].gamma_off, P + m.enc[2].beta_off, 64, 19, 64, 3, 25, F, us(w.cl_y2)};
+      VAENPVC_TIMED("enc3_split", s, launch_split_cl<NPL>(ca, s));
+      CgArgs a;
+      memset(&a, 0, sizeof a);
+      a.W = reinterpret_cast<const unsigned short*>(w.scratch + Pk::pg_e3f);
+      a.X = reinterpret_cast<const unsigned short*>(w.cl_y2);
+      a.w_plane = 128 * 448;
+      a.x_plane = (int64_t)F * 25 * 64;
+      a.xv = RowView{7, 25 * 64, 0, 3 * 64};
+      a.Kp = 448;
+      a.M = 128;
+      a.N = F * 7;
+      a.out = w.enc_a[3];
+      a.ofs = 128 * 7;
+      a.om = 7;
+      a.oq = 1;
+      a.OH = 7;
+      a.bias = P + m.enc[3].b_off;
+      VAENPVC_TIMED("enc3_fwd", s, launch_cgemm<NPL>(a, 1, s));
+    });
+    stats<896>(w.enc_a[3], w.enc_st[3], F, s);
+  } else if (fwd_on(3)) {
     VAENPVC_TIMED("enc3_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<E3Fs>(lnp(3), nsplit_for<E3Fs>(F), s) : launch_convgemm<E3F>(lnp(3), nsplit_for<E3F>(F), s)));
     stats<896>(w.enc_a[3], w.enc_st[3], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 3);
-  if (fwd_on(4)) {
+  if (fwd_on(4) && pg_fwd(F)) {
+    // layer 4 as the dense layer [F, 896] x [896, 768] on the bf16 matrix cores (gfx950_planegemm.h)
+    for_dense_planes([&](auto npl) {
+      constexpr int NPL = decltype(npl)::value;
+      SplitArgs sa = split_args(w.enc_a[3], 896, 896, F, us(w.pl_y3));
+      sa.st = w.enc_st[3];
+      sa.gamma = P + m.enc[3].gamma_off;
+      sa.beta = P + m.enc[3].beta_off;
+      sa.lndiv = 7;
+      VAENPVC_TIMED("enc4_split", s, launch_split<NPL>(sa, s));
+      NtArgs a = nt_args(w.pl_y3, F, 896, w.scratch + Pk::pg_enc4f, 768, 768, w.enc_a[4], 768);
+      a.bias = w.scratch + Pk::pg_bias4;
+      VAENPVC_TIMED("enc4_fwd", s, launch_gemm_nt<NPL>(a, s));
+    });
+    stats<768>(w.enc_a[4], w.enc_st[4], F, s);
+  } else if (fwd_on(4)) {
     VAENPVC_TIMED("enc4_fwd", s, launch_convgemm<E4F>(lnp(4), nsplit_for<E4F>(F), s));
     stats<768>(w.enc_a[4], w.enc_st[4], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 4);
-  if (fwd_on(5)) {
+  if (fwd_on(5) && pg_fwd(F)) {
+    for_dense_planes([&](auto npl) {
+      constexpr int NPL = decltype(npl)::value;
+      SplitArgs sa = split_args(w.enc_a[4], 768, 768, F, us(w.pl_y4));
+      sa.st = w.enc_st[4];
+      sa.gamma = P + m.enc[4].gamma_off;
+      sa.beta = P + m.enc[4].beta_off;
+      sa.lndiv = 3;
+      VAENPVC_TIMED("heads_split", s, launch_split<NPL>(sa, s));
+      NtArgs a = nt_args(w.pl_y4, F, 768, w.scratch + Pk::pg_headsf, 256, 256, w.z_mu, 128);
+      a.C2 = w.z_lv;
+      a.split = 128;
+      a.bias = w.scratch + Pk::heads_bias;
+      VAENPVC_TIMED("heads_fwd", s, launch_gemm_nt<NPL>(a, s));
+    });
+  } else if (fwd_on(5)) {
     DenseArgs a = dense_args(w.enc_a[4], w.scratch + Pk::heads_f, w.z_mu, 128, F);
     a.st = w.enc_st[4];
     a.gamma = P + m.enc[4].gamma_off;
@@ -330,7 +460,18 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
   read_env();
   const int F = (int)F64;
   if (!weights_packed) prep(m, P, w, s);
-  if (fwd_on(6)) {
+  if (fwd_on(6) && pg_fwd(F)) {
+    for_dense_planes([&](auto npl) {
+      constexpr int NPL = decltype(npl)::value;
+      VAENPVC_TIMED("merge_split", s, launch_split<NPL>(split_args(z, 128, 128, F, us(w.pl_z)), s));
+      NtArgs a = nt_args(w.pl_z, F, 128, w.scratch + Pk::pg_mergef, 1664, 1539, w.h, 1539);
+      a.rowbias = w.scratch + Pk::merge_tb;   // + T[y_f]: the speaker's row of E Wy + (bz + by + b)
+      a.idx = y;
+      a.nrb = MERGE_NY;
+      a.ldrb = 1539;
+      VAENPVC_TIMED("merge_fwd", s, launch_gemm_nt<NPL>(a, s));
+    });
+  } else if (fwd_on(6)) {
     DenseArgs a = dense_args(z, w.scratch + Pk::merge_f, w.h, m.merge, F);
     a.idx = y;                                // + T[y_f]: the speaker's row of E Wy + (bz + by + b)
     a.rowbias = w.scratch + Pk::merge_tb;
@@ -547,9 +688,22 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
 
   // ---- merge + embedding
   if (bwd_on(6)) {
+    // (the plane kernels read the z planes the forward pass left behind: both directions must be on them)
+    const bool pgm = pg_bwd(F) && pg_fwd(F) && fwd_on(6);
+    if (pgm) {
+      for_dense_planes([&](auto npl) {
+        constexpr int NPL = decltype(npl)::value;
+        SplitArgs sa = split_args(w.d_h, 1539, 1600, F, us(w.pl_dh));
+        VAENPVC_TIMED("merge_dsplit", s, launch_split<NPL>(sa, s));
+        ready();
+        TnpArgs t = tnp_args(w.pl_z, 128, w.pl_dh, 1600, 128, 1539, F, G + m.wz_off, 1539);
+        VAENPVC_TIMED("merge_wgrad", s2, (launch_gemm_tn<NPL, TN_EPI_PLAIN>(t, 512, s2)));
+      });
+    } else {
     TnArgs a = tn_args(w.z, 128, w.d_h, 1539, 128, 1539, F, G + m.wz_off, 1539);
     ready();
     VAENPVC_TIMED("merge_wgrad", s2, launch_tngemm(a, false, kchunks_for(F, 13), s2));
+    }
     // S[k] = per-speaker column sums of d(h); the bias gradients, dWy = E^T S and dE = S Wy^T follow from it
     float* Sg = w.scratch + Pk::merge_s;
     (void)hipMemsetAsync(Sg, 0, (size_t)MERGE_NY * 1539 * 4, s);
@@ -559,8 +713,16 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const int nb_w = cdiv(128 * 1539, 256), nb_e = cdiv(MERGE_NY * 128, 4), nb_b = cdiv(1539, 256);
     hipLaunchKernelGGL(k_merge_small<MERGE_NY>, dim3((unsigned)(nb_w + nb_e + nb_b)), dim3(256), 0, s, Sg, P + m.emb_off, P + m.wy_off, 128,
                        1539, G + m.wy_off, G + m.emb_off, G + m.bz_off, G + m.by_off, G + m.bm_off, nb_w, nb_e);
-    DenseArgs d = dense_args(w.d_h, w.scratch + Pk::merge_b, w.d_z, 128, F);
-    VAENPVC_TIMED("merge_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<MergeBs>(d, s) : launch_densegemm<MergeB>(d, s)));
+    if (pgm) {
+      for_dense_planes([&](auto npl) {
+        constexpr int NPL = decltype(npl)::value;
+        NtArgs a = nt_args(w.pl_dh, F, 1600, w.scratch + Pk::pg_mergeb, 128, 128, w.d_z, 128);
+        VAENPVC_TIMED("merge_dgrad", s, launch_gemm_nt<NPL>(a, s));
+      });
+    } else {
+      DenseArgs d = dense_args(w.d_h, w.scratch + Pk::merge_b, w.d_z, 128, F);
+      VAENPVC_TIMED("merge_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<MergeBs>(d, s) : launch_densegemm<MergeB>(d, s)));
+    }
   } else generic::bwd_merge(m, P, y, F, w, G, s);
   bucket(m.wz_off, m.dec[0].w_off);  // the two merge FCs and the three merge biases (the embedding goes last)
 
@@ -572,7 +734,28 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   } else generic::bwd_reparam(m, eps, F, w, s);
 
   // ---- heads
-  if (bwd_on(5)) {
+  if (bwd_on(5) && pg_bwd(F) && pg_fwd(F) && fwd_on(5)) {
+    const ConvL& l4 = m.enc[4];
+    for_dense_planes([&](auto npl) {
+      constexpr int NPL = decltype(npl)::value;
+      SplitArgs sa = split_args(w.d_z_mu, 256, 256, F, us(w.pl_dz));   // [dz_mu | dz_lv]
+      sa.k1 = 128;
+      sa.ld1 = 128;
+      sa.src2 = w.d_z_lv;
+      sa.ld2 = 128;
+      VAENPVC_TIMED("heads_dsplit", s, launch_split<NPL>(sa, s));
+      ready();
+      TnpArgs t = tnp_args(w.pl_y4, 768, w.pl_dz, 256, 768, 256, F, G + m.wmu_off, 128);
+      t.C2 = G + m.wlv_off;
+      t.split = 128;
+      VAENPVC_TIMED("heads_wgrad", s2, (launch_gemm_tn<NPL, TN_EPI_PLAIN>(t, 512, s2)));
+      NtArgs a = nt_args(w.pl_dz, F, 256, w.scratch + Pk::pg_headsb, 768, 768, w.dy_tmp, 768);
+      VAENPVC_TIMED("heads_dgrad", s, launch_gemm_nt<NPL>(a, s));
+    });
+    launch_ln_bwd<LnbCfg<256, 3>>(w.dy_tmp, w.enc_a[4], w.enc_st[4], P + l4.gamma_off, P + l4.beta_off, w.d_enc_a[4],
+                                     G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
+    enc_bias_done[4] = true;
+  } else if (bwd_on(5)) {
     const ConvL& l4 = m.enc[4];
     TnArgs a = tn_args(w.enc_a[4], 768, w.d_z_mu, 128, 768, 128, F, G + m.wmu_off, 128);
     a.st = w.enc_st[4];
@@ -600,7 +783,23 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     return WgArgs{w.enc_a[i - 1], w.enc_st[i - 1], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[i], nullptr, nullptr, nullptr,
                   G + l.w_off, F, 0};
   };
-  if (bwd_on(4)) {
+  if (bwd_on(4) && pg_bwd(F) && pg_fwd(F) && fwd_on(4)) {
+    // layer 4 as a dense layer: dW from [F,896]^T x [F,768] folded back onto the 7 taps, d(y3) = d(a4) x Wd
+    const ConvL &l = m.enc[4], &pl = m.enc[3];
+    for_dense_planes([&](auto npl) {
+      constexpr int NPL = decltype(npl)::value;
+      VAENPVC_TIMED("enc4_dsplit", s, launch_split<NPL>(split_args(w.d_enc_a[4], 768, 768, F, us(w.pl_da4)), s));
+      ready();
+      TnpArgs t = tnp_args(w.pl_y3, 896, w.pl_da4, 768, 896, 768, F, G + l.w_off, 0);
+      VAENPVC_TIMED("enc4_wgrad", s2, (launch_gemm_tn<NPL, TN_EPI_ENC4>(t, 512, s2)));
+      NtArgs a = nt_args(w.pl_da4, F, 768, w.scratch + Pk::pg_enc4b, 896, 896, w.dy_tmp, 896);
+      VAENPVC_TIMED("enc4_dgrad", s, launch_gemm_nt<NPL>(a, s));
+    });
+    if (!enc_bias_done[4]) generic::bias_grad(w.d_enc_a[4], G + l.b_off, F, l.cout, l.hout, s);
+    launch_ln_bwd<LnbCfg<128, 7>>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[3],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
+    enc_bias_done[3] = true;
+  } else if (bwd_on(4)) {
     const ConvL &l = m.enc[4], &pl = m.enc[3];
     ready();
     VAENPVC_TIMED("enc4_wgrad", s2, launch_convwgrad<WE4>(wg_enc(4), WGS, s2));

@@ -1,0 +1,690 @@
+// gfx950_planegemm.h -- plain GEMMs on the bf16 matrix cores for the dense-shaped layers (encoder heads,
+// merge FC, encoder layer 4 written as a dense layer) in all three directions.
+//
+// Operands are "plane" tensors: an fp32 matrix X[rows][K] split into NPL bf16 terms X = t0 + t1 (+ t2),
+// stored plane-major as unsigned short [NPL][rows][Kp] (Kp = K padded with zeros to a multiple of 64, so the
+// kernels have no K tail).  Products keep the term pairs (i, j) with i + j < NPL and accumulate in fp32 inside
+// v_mfma_f32_32x32x16_bf16 (gfx950_toep_bf16.h explains the arithmetic; NPL is the context's precision).
+//
+//   k_split_planes : fp32 activation / gradient tensor -> planes (optionally LayerNorm + lrelu on the way,
+//                    util/layers.py:32-44,149, or the [a | b] concatenation of two tensors); HBM-bound
+//   PackPlanesJob  : weight matrices -> planes, inside the step's single packing launch
+//   k_gemm_nt      : C[m][n] = sum_k A[m][k] B[n][k] (+ bias[n] + T[idx[m]][n])     forward / input gradient
+//   k_gemm_tn      : C[m][n] += sum_f A[f][m] B[f][n]                                weight gradient
+//
+// Encoder layer 4 (conv k7 s3 SAME on 7 positions -> 3 positions, util/layers.py:56-64) touches every input
+// position from nearly every output position, so it is run as the dense layer [F, 128*7] x [896, 256*3] whose
+// weight matrix holds W[h - 3j + 3][c][o] (zero where the tap index leaves 0..6: 6 of 21 (h, j) pairs): 29 % more
+// MACs than the conv, at 5-16x the MAC rate, with the canonical [F][C][H] tensors as operands and results.
+#pragma once
+#include "gfx950_common.h"
+#include "gfx950_toep_bf16.h"  // split_n, Prod, mfma_bf16, u32x4, packed4, tr_read8
+
+namespace vaenpvc {
+namespace tuned {
+
+constexpr int PG_KA = 64;  // K granule of every plane tensor
+
+// ---------------------------------------------------------------- producers
+struct SplitArgs {
+  const float* src;    // [rows][ld1], columns [0, k1)
+  const float* src2;   // optional: columns [k1, K) come from src2[rows][ld2]
+  int k1, ld1, ld2;
+  const float* st;     // LN: per-row (mean, rstd)
+  const float* gamma;  // LN: per channel, channel = column / lndiv
+  const float* beta;
+  int lndiv;
+  int K, Kp;
+  int64_t rows;
+  unsigned short* dst;  // [NPL][rows][Kp]
+};
+
+// one thread = 8 consecutive columns of one row: two 16-byte loads, NPL 16-byte stores
+template <int NPL, bool LN>
+__global__ void __launch_bounds__(256) k_split_planes(SplitArgs a) {
+  const int g8 = a.Kp >> 3;
+  const int64_t total = a.rows * g8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / g8;
+    const int k0 = (int)(i - r * g8) * 8;
+    float v[8];
+    if (k0 + 8 <= a.k1) {
+      const float* p = a.src + r * a.ld1 + k0;
+      packed4 p0 = *reinterpret_cast<const packed4*>(p), p1 = *reinterpret_cast<const packed4*>(p + 4);
+      v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
+    } else if (a.src2 && k0 >= a.k1 && k0 + 8 <= a.K) {
+      const float* p = a.src2 + r * a.ld2 + (k0 - a.k1);
+      packed4 p0 = *reinterpret_cast<const packed4*>(p), p1 = *reinterpret_cast<const packed4*>(p + 4);
+      v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        v[j] = k < a.k1 ? a.src[r * a.ld1 + k] : ((a.src2 && k < a.K) ? a.src2[r * a.ld2 + (k - a.k1)] : 0.f);
+      }
+    }
+    if constexpr (LN) {
+      const float mean = a.st[2 * r], rstd = a.st[2 * r + 1];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        const int c = (k < a.K ? k : a.K - 1) / a.lndiv;
+        const float y = lnact_v(v[j], mean, rstd, a.gamma[c], a.beta[c]);
+        v[j] = k < a.K ? y : 0.f;
+      }
+    }
+    unsigned t[8][NPL];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split_n<NPL>(v[j], t[j]);
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+      u32x4 pk;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pk[q] = t[2 * q][p] | (t[2 * q + 1][p] << 16);
+      *reinterpret_cast<u32x4*>(a.dst + ((int64_t)p * a.rows + r) * a.Kp + k0) = pk;
+    }
+  }
+}
+
+template <int NPL>
+inline void launch_split(const SplitArgs& a, hipStream_t s) {
+  const int64_t total = a.rows * (a.Kp >> 3);
+  const unsigned blocks = (unsigned)cmin_((int)((total + 255) / 256), 8192);
+  if (a.st)
+    hipLaunchKernelGGL((k_split_planes<NPL, true>), dim3(blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_split_planes<NPL, false>), dim3(blocks), dim3(256), 0, s, a);
+}
+
+static inline SplitArgs split_args(const float* src, int K, int Kp, int64_t rows, unsigned short* dst) {
+  SplitArgs a;
+  a.src = src;
+  a.src2 = nullptr;
+  a.k1 = K;
+  a.ld1 = K;
+  a.ld2 = 0;
+  a.st = a.gamma = a.beta = nullptr;
+  a.lndiv = 1;
+  a.K = K;
+  a.Kp = Kp;
+  a.rows = rows;
+  a.dst = dst;
+  return a;
+}
+
+// weight matrix B[n][k] = fn(n, k) (zero outside the logical N x K) -> planes [NPL][Np][Kp]; job of k_pack_multi
+template <class Fn, int NPL>
+struct PackPlanesJob {
+  Fn fn;
+  unsigned short* dst;
+  int Np, Kp;
+  int count;  // Np * Kp
+  __device__ void run(int i) const {
+    const int n = i / Kp, k = i - n * Kp;
+    unsigned t[NPL];
+    split_n<NPL>(fn(n, k), t);
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) dst[(size_t)p * Np * Kp + i] = (unsigned short)t[p];
+  }
+};
+template <int NPL, class Fn>
+inline PackPlanesJob<Fn, NPL> planes_job(Fn fn, float* dst, int Np, int Kp) {
+  return PackPlanesJob<Fn, NPL>{fn, reinterpret_cast<unsigned short*>(dst), Np, Kp, Np * Kp};
+}
+
+// the weight matrices of the dense-shaped layers (TF layouts: dense [in][out], conv [t][cin][cout])
+struct WHeadsF {  // z = y4 [F,768] x B^T : B[n][k] = n < 128 ? Wmu[k][n] : Wlv[k][n - 128]
+  const float *Wmu, *Wlv;
+  __device__ float operator()(int n, int k) const {
+    if (n >= 256 || k >= 768) return 0.f;
+    return n < 128 ? Wmu[k * 128 + n] : Wlv[k * 128 + (n - 128)];
+  }
+};
+struct WHeadsB {  // dy4 [F,768] = [dz_mu | dz_lv] [F,256] x B^T : B[n][k] = k < 128 ? Wmu[n][k] : Wlv[n][k - 128]
+  const float *Wmu, *Wlv;
+  __device__ float operator()(int n, int k) const {
+    if (n >= 768 || k >= 256) return 0.f;
+    return k < 128 ? Wmu[n * 128 + k] : Wlv[n * 128 + (k - 128)];
+  }
+};
+struct WMergeF {  // h = z [F,128] x B^T : B[n][k] = Wz[k][n]
+  const float* Wz;
+  int M;
+  __device__ float operator()(int n, int k) const { return (n < M && k < 128) ? Wz[(int64_t)k * M + n] : 0.f; }
+};
+struct WMergeB {  // dz [F,128] = dh [F,M] x B^T : B[n][k] = Wz[n][k]
+  const float* Wz;
+  int M;
+  __device__ float operator()(int n, int k) const { return (n < 128 && k < M) ? Wz[(int64_t)n * M + k] : 0.f; }
+};
+// encoder layer 4 as a dense layer: column (o, j) = o*3 + j, row (c, h) = c*7 + h, tap t = h - 3j + 3
+struct WEnc4F {  // a4 [F,768] = y3 [F,896] x B^T : B[n = (o,j)][k = (c,h)]
+  const float* W;  // [7][128][256]
+  __device__ float operator()(int n, int k) const {
+    if (n >= 768 || k >= 896) return 0.f;
+    const int o = n / 3, j = n - 3 * o, c = k / 7, h = k - 7 * c, t = h - 3 * j + 3;
+    return (t >= 0 && t < 7) ? W[(t * 128 + c) * 256 + o] : 0.f;
+  }
+};
+struct WEnc4B {  // dy3 [F,896] = da4 [F,768] x B^T : B[n = (c,h)][k = (o,j)]
+  const float* W;
+  __device__ float operator()(int n, int k) const {
+    if (n >= 896 || k >= 768) return 0.f;
+    const int o = k / 3, j = k - 3 * o, c = n / 7, h = n - 7 * c, t = h - 3 * j + 3;
+    return (t >= 0 && t < 7) ? W[(t * 128 + c) * 256 + o] : 0.f;
+  }
+};
+struct PackRepeat3 {  // bias of layer 4 per dense column (o, j): b[o]
+  const float* b;
+  __device__ float operator()(int i) const { return i < 768 ? b[i / 3] : 0.f; }
+};
+
+// ---------------------------------------------------------------- C = A B^T
+// Workgroup = 128 x 128 tile, 4 waves as 2 x 2, wave tile 64 x 64 (2 x 2 MFMA tiles).  K runs in chunks of 64:
+// the chunk of both operands is prefetched from HBM / L2 into registers while the previous one is multiplied
+// from LDS (rows padded to 144 bytes: the 16 rows a quarter-wave reads sit in different bank quads).
+struct NtArgs {
+  const unsigned short* A;  // planes [NPL][M][Kp]
+  const unsigned short* B;  // planes [NPL][Np][Kp], Np = number of 128-column tiles * 128
+  int64_t a_plane, b_plane;  // elements between planes
+  int M, N, Kp;
+  float* C;   // [M][ldc]            (columns n <  split)
+  float* C2;  // [M][ldc] or nullptr  (columns n >= split, stored at n - split)
+  int split, ldc;
+  const float* bias;      // [N] or nullptr
+  const float* rowbias;   // [nrb][ldrb] or nullptr: row idx[m] is added to output row m
+  const int64_t* idx;
+  int nrb, ldrb;
+};
+constexpr int NT_BM = 128, NT_BN = 128;
+// K chunk: 64 with up to two planes, 32 with three (LDS and prefetch registers stay at two workgroups per CU; the
+// MFMAs between two barriers are the same 48 per wave either way)
+constexpr int nt_bk(int npl) { return npl >= 3 ? 32 : 64; }
+constexpr int nt_lds(int npl) { return npl * (NT_BM + NT_BN) * (nt_bk(npl) * 2 + 16); }  // 73 728 (2 planes) / 61 440 (3)
+
+template <int NPL>
+__global__ void __launch_bounds__(256, 2) k_gemm_nt(NtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NT_BK = nt_bk(NPL), NT_RS = NT_BK * 2 + 16, NQ = NT_BK / 16;   // NQ: 16-byte pieces per thread, plane, operand
+  constexpr int APL = NT_BM * NT_RS, BPL = NT_BN * NT_RS;
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + NPL * APL;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * NT_BM, n0 = blockIdx.y * NT_BN;
+  // staging: thread -> (row tid >> 1, half tid & 1 of the row's chunk) of both tiles: NQ pieces of 16 bytes per plane and operand
+  const int srow = tid >> 1, shalf = tid & 1;
+  const int arow = m0 + srow < a.M ? m0 + srow : a.M - 1;  // rows past the end: duplicates, never stored
+  const unsigned char* ga = reinterpret_cast<const unsigned char*>(a.A) + ((size_t)arow * a.Kp) * 2 + shalf * NT_BK;
+  const unsigned char* gb = reinterpret_cast<const unsigned char*>(a.B) + ((size_t)(n0 + srow) * a.Kp) * 2 + shalf * NT_BK;
+  unsigned char* da = sA + srow * NT_RS + shalf * NT_BK;
+  unsigned char* db = sB + srow * NT_RS + shalf * NT_BK;
+  u32x4 ra[NPL][NQ], rb[NPL][NQ];
+  auto gload = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        ra[p][q] = *reinterpret_cast<const u32x4*>(ga + (size_t)p * a.a_plane * 2 + kc * (NT_BK * 2) + q * 16);
+        rb[p][q] = *reinterpret_cast<const u32x4*>(gb + (size_t)p * a.b_plane * 2 + kc * (NT_BK * 2) + q * 16);
+      }
+  };
+  auto lstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        *reinterpret_cast<u32x4*>(da + p * APL + q * 16) = ra[p][q];
+        *reinterpret_cast<u32x4*>(db + p * BPL + q * 16) = rb[p][q];
+      }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+  const int aoff = (wm * 64 + l31) * NT_RS + lh * 16;
+  const int boff = (wn * 64 + l31) * NT_RS + lh * 16;
+  u32x4 fa[2][2][NPL], fb[2][2][NPL];
+  auto loadF = [&](int set, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        fa[set][t][p] = *reinterpret_cast<const u32x4*>(sA + p * APL + aoff + t * 32 * NT_RS + ks * 32);
+        fb[set][t][p] = *reinterpret_cast<const u32x4*>(sB + p * BPL + boff + t * 32 * NT_RS + ks * 32);
+      }
+  };
+  auto mm = [&](int set) __attribute__((always_inline)) {
+    using PR = Prod<NPL>;
+#pragma unroll
+    for (int t = 0; t < PR::N; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[set][i][PR::A[t]], fb[set][j][PR::B[t]], acc[i][j]);
+  };
+  const int nch = a.Kp / NT_BK;
+  gload(0);
+  for (int kc = 0; kc < nch; ++kc) {
+    lstore();  // chunk kc (prefetched)
+    __syncthreads();
+    if (kc + 1 < nch) gload(kc + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    loadF(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < NT_BK / 16; ++ks) {
+      if (ks + 1 < NT_BK / 16) loadF((ks + 1) & 1, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // chunk consumed
+  }
+  // epilogue: lanes = 32 consecutive columns of a row -> 128-byte stores
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + l31;
+    if (n >= a.N) continue;
+    const float bb = a.bias ? a.bias[n] : 0.f;
+    float* cb = a.C;
+    int nn = n;
+    if (a.C2 && n >= a.split) {
+      cb = a.C2;
+      nn = n - a.split;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float rbv[16];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        rbv[reg] = 0.f;
+        if (a.rowbias) {  // uniform
+          const int m = m0 + wm * 64 + i * 32 + acc_row(reg, lane);
+          int64_t r = a.idx[m < a.M ? m : a.M - 1];
+          r = r < 0 ? 0 : (r >= a.nrb ? a.nrb - 1 : r);
+          rbv[reg] = a.rowbias[r * a.ldrb + n];
+        }
+      }
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + wm * 64 + i * 32 + acc_row(reg, lane);
+        if (m < a.M) cb[(int64_t)m * a.ldc + nn] = acc[i][j][reg] + bb + rbv[reg];
+      }
+    }
+  }
+}
+
+template <int NPL>
+inline void launch_gemm_nt(const NtArgs& a, hipStream_t s) {
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_nt<NPL>), nt_lds(NPL));
+  dim3 grid((unsigned)cdiv(a.M, NT_BM), (unsigned)cdiv(a.N, NT_BN));
+  hipLaunchKernelGGL(k_gemm_nt<NPL>, grid, dim3(256), nt_lds(NPL), s, a);
+}
+
+// ---------------------------------------------------------------- C += A^T B   (reduction over frames)
+// Workgroup = 128 (m) x 256 (n) tile over the frames [z*fchunk, (z+1)*fchunk); 8 waves as 2 x 4, wave tile 64 x 64.
+// Both operands are frame-major planes; a row-major [16 frames][columns] LDS tile feeds the MFMA through
+// ds_read_b64_tr_b16 (gfx950_toep_bf16.h: k_toep_wgrad_bf16 is the same machine with a diagonal epilogue).
+// Partial sums over frame chunks are combined with fp32 global atomics.
+enum { TN_EPI_PLAIN = 0, TN_EPI_ENC4 = 1 };
+struct TnpArgs {
+  const unsigned short* A;  // planes [NPL][F][lda]
+  const unsigned short* B;  // planes [NPL][F][ldb]
+  int64_t a_plane, b_plane;
+  int lda, ldb;
+  int M, N, F, fchunk;
+  float* C;   // PLAIN: C[m*ldc + n] (n < split) ; ENC4: the TF kernel tensor [7][128][256]
+  float* C2;  // PLAIN: columns n >= split at n - split
+  int split, ldc;
+};
+constexpr int TP_KF = 16;
+constexpr int TP_RSA = 128 * 2 + 64, TP_RSB = 256 * 2 + 64;   // LDS row strides (bytes): see WG_RSA / WG_RSB
+constexpr int TP_APL = TP_KF * TP_RSA, TP_BPL = TP_KF * TP_RSB;
+constexpr int tp_buf(int npl) { return npl * (TP_APL + TP_BPL); }
+constexpr int tp_lds(int npl) { return 2 * tp_buf(npl); }
+
+template <int NPL, int EPI>
+__global__ void __launch_bounds__(512, 2) k_gemm_tn(TnpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BUF = tp_buf(NPL);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lh = lane >> 5, l31 = lane & 31;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 256;
+  const int fb = blockIdx.z * a.fchunk, fe = min(a.F, fb + a.fchunk);
+  // staging of one 16-frame chunk: A 16 rows x 16 pieces (threads < 256), B 16 rows x 32 pieces (all threads)
+  const int arow = (tid >> 4) & 15, apc = tid & 15;
+  const int brow = tid >> 5, bpc = tid & 31;
+  // pieces past the row end (last column tile of a ragged N) are clamped to the row's last piece: finite data, masked
+  // in the epilogue
+  const int acol = cmin_(m0 * 2 + apc * 16, a.lda * 2 - 16);
+  const int bcol = cmin_(n0 * 2 + bpc * 16, a.ldb * 2 - 16);
+  const unsigned char* A8 = reinterpret_cast<const unsigned char*>(a.A);
+  const unsigned char* B8 = reinterpret_cast<const unsigned char*>(a.B);
+  u32x4 sta[NPL], stb[NPL];
+  auto gload = [&](int f0) __attribute__((always_inline)) {
+    int fa_ = f0 + arow, fb_ = f0 + brow;
+    fa_ = fa_ < a.F ? fa_ : a.F - 1;
+    fb_ = fb_ < a.F ? fb_ : a.F - 1;
+    if (tid < 256) {
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) sta[p] = *reinterpret_cast<const u32x4*>(A8 + ((size_t)p * a.a_plane + (size_t)fa_ * a.lda) * 2 + acol);
+    }
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) stb[p] = *reinterpret_cast<const u32x4*>(B8 + ((size_t)p * a.b_plane + (size_t)fb_ * a.ldb) * 2 + bcol);
+  };
+  auto lstore = [&](int f0, int buf) __attribute__((always_inline)) {
+    unsigned char* sA = smem + buf * BUF;
+    unsigned char* sB = sA + NPL * TP_APL;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    const bool tail = f0 + TP_KF > fe;  // uniform: frames past the chunk contribute zero (A rows zeroed)
+    if (tid < 256) {
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+        *reinterpret_cast<u32x4*>(sA + p * TP_APL + arow * TP_RSA + apc * 16) = (tail && f0 + arow >= fe) ? z : sta[p];
+    }
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(sB + p * TP_BPL + brow * TP_RSB + bpc * 16) = stb[p];
+  };
+  // fragment addresses (transpose reads): lane -> (frame row (l&15)>>2 (+8*lh), column quad 4*(l&3) + 16*((l>>4)&1))
+  const int trow = ((lane & 15) >> 2) + 8 * lh, tcol = 4 * (lane & 3) + 16 * ((lane >> 4) & 1);
+  const int aoff = trow * TP_RSA + (64 * wr + tcol) * 2;
+  const int boff = NPL * TP_APL + trow * TP_RSB + (64 * wc + tcol) * 2;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+  u32x4 fa[2][NPL], fbq[2][NPL];
+  auto loadF = [&](int buf) __attribute__((always_inline)) {
+    const unsigned char* sb = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) fa[i][p] = tr_read8(sb + p * TP_APL + aoff + i * 64, 4 * TP_RSA);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) fbq[j][p] = tr_read8(sb + p * TP_BPL + boff + j * 64, 4 * TP_RSB);
+  };
+  auto mm = [&]() __attribute__((always_inline)) {
+    using PR = Prod<NPL>;
+#pragma unroll
+    for (int t = 0; t < PR::N; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[i][PR::A[t]], fbq[j][PR::B[t]], acc[i][j]);
+  };
+  if (fb < fe) {
+    gload(fb);
+    lstore(fb, 0);
+  }
+  __syncthreads();
+  int nq = 0;
+  for (int f0 = fb; f0 < fe; f0 += TP_KF, ++nq) {
+    const bool more = f0 + TP_KF < fe;
+    if (more) gload(f0 + TP_KF);
+    __builtin_amdgcn_sched_barrier(0);
+    loadF(nq & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm();
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) lstore(f0 + TP_KF, (nq + 1) & 1);
+    __syncthreads();
+  }
+  // epilogue: acc[i][j][reg] = C[m0 + 64 wr + 32 i + acc_row(reg)][n0 + 64 wc + 32 j + l31]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + 64 * wc + 32 * j + l31;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + 64 * wr + 32 * i + acc_row(reg, lane);
+        if (m >= a.M) continue;
+        const float v = acc[i][j][reg];
+        if constexpr (EPI == TN_EPI_ENC4) {
+          // m = (c, h) = c*7 + h, n = (o, j3) = o*3 + j3: dW[t][c][o] with t = h - 3*j3 + 3
+          const int c = m / 7, h = m - 7 * c, o = n / 3, j3 = n - 3 * o, t = h - 3 * j3 + 3;
+          if (t >= 0 && t < 7) atomicAdd(a.C + ((t * 128 + c) * 256 + o), v);
+        } else {
+          if (a.C2 && n >= a.split) atomicAdd(a.C2 + (int64_t)m * a.ldc + (n - a.split), v);
+          else atomicAdd(a.C + (int64_t)m * a.ldc + n, v);
+        }
+      }
+    }
+}
+
+template <int NPL, int EPI>
+inline void launch_gemm_tn(TnpArgs a, int target_wgs, hipStream_t s) {
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_tn<NPL, EPI>), tp_lds(NPL));
+  const int tiles = cdiv(a.M, 128) * cdiv(a.N, 256);
+  const int zc = cmax(1, cmin_(cdiv(a.F, 64), cdiv(target_wgs, tiles)));
+  a.fchunk = rup(cdiv(a.F, zc), TP_KF);
+  dim3 grid((unsigned)cdiv(a.M, 128), (unsigned)cdiv(a.N, 256), (unsigned)cdiv(a.F, a.fchunk));
+  hipLaunchKernelGGL((k_gemm_tn<NPL, EPI>), grid, dim3(512), tp_lds(NPL), s, a);
+}
+
+// =====================================================================================================
+// Conv layers on the same machine.  Activations / gradients as CHANNEL-LAST planes with zero halo rows,
+//     X[p][f][pos][c]   (unsigned short [NPL][F][HP][CP], HP = HLO + H + HHI, CP = channels padded to 8),
+// turn every 1-D conv of the network into a plain GEMM over an overlapping-row VIEW of that tensor: the K-run
+// of output row (f, q) -- taps x channels -- is ONE contiguous stretch of X starting at
+//     f*HP*CP + x0 + q*xstep          (xstep = stride*CP for a conv, CP for a phase of a transposed conv),
+// so there is no im2col, no gather and no shifted copy: rows simply overlap in memory.
+//   conv forward / conv_transpose input gradient (util/layers.py:56-64, model/vae.py:96-99 backward):
+//       out[f][o][j] = sum_{t,c} X[f][S j + t][c] W[t][c][o]                      K = T*CP, xstep = S*CP
+//   conv_transpose forward / conv input gradient: S phases r, p = S q + r - PAD, taps t = S d + r, d < ceil(T/S):
+//       out[f][o][p] = sum_{d,c} X[f][q - d][c] W[S d + r][..]                     K = ceil(T/S)*CP, xstep = CP
+//   weight gradients: C[(t,c)][o] += sum_{(f,j)} X[f][S j + t][c] G[f][j][o]  -- k_gemm_tn with the view as A.
+// The weights are the MFMA "A" operand (accumulator rows = output channels) and the view the "B" operand
+// (lanes = positions), so results land in the canonical [F][C][H] fp32 tensors along the position axis.
+struct RowView {      // row r of a channel-last plane tensor: element offset (r / R) * fs + x0 + (r % R) * step
+  int R, fs, x0, step;
+};
+__device__ __forceinline__ int64_t view_off(const RowView& v, int r) {
+  const int f = r / v.R, q = r - f * v.R;
+  return (int64_t)f * v.fs + v.x0 + q * v.step;
+}
+
+struct CgArgs {
+  const unsigned short* W;   // weight planes [phase][NPL][Mp][Kp]
+  const unsigned short* X;   // activation planes [NPL][...]
+  int64_t w_plane, w_phase, x_plane;   // elements
+  RowView xv;                // rows of the GEMM's N index n = f*R + q
+  int Kp, M, N;              // M = output channels, N = F * R
+  float* out;                // out[f*ofs + m*om + pos], pos = q*oq + o0 + phase*o0s, stored when 0 <= pos < OH
+  int ofs, om, oq, o0, o0s, OH;
+  const float* bias;         // [M] or nullptr
+};
+
+template <int NPL>
+__global__ void __launch_bounds__(256, 2) k_cgemm(CgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NT_BK = nt_bk(NPL), NT_RS = NT_BK * 2 + 16, NQ = NT_BK / 16;
+  constexpr int APL = NT_BM * NT_RS, BPL = NT_BN * NT_RS;
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + NPL * APL;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = blockIdx.x * NT_BN, m0 = blockIdx.y * NT_BM, ph = blockIdx.z;
+  const int srow = tid >> 1, shalf = tid & 1;
+  const unsigned char* ga = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)ph * a.w_phase + (size_t)(m0 + srow) * a.Kp) * 2 + shalf * NT_BK;
+  const int brow = n0 + srow < a.N ? n0 + srow : a.N - 1;   // rows past the end: duplicates, never stored
+  const unsigned char* gb = reinterpret_cast<const unsigned char*>(a.X) + (size_t)view_off(a.xv, brow) * 2 + shalf * NT_BK;
+  unsigned char* da = sA + srow * NT_RS + shalf * NT_BK;
+  unsigned char* db = sB + srow * NT_RS + shalf * NT_BK;
+  u32x4 ra[NPL][NQ], rb[NPL][NQ];
+  auto gload = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        ra[p][q] = *reinterpret_cast<const u32x4*>(ga + (size_t)p * a.w_plane * 2 + kc * (NT_BK * 2) + q * 16);
+        rb[p][q] = *reinterpret_cast<const u32x4*>(gb + (size_t)p * a.x_plane * 2 + kc * (NT_BK * 2) + q * 16);
+      }
+  };
+  auto lstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        *reinterpret_cast<u32x4*>(da + p * APL + q * 16) = ra[p][q];
+        *reinterpret_cast<u32x4*>(db + p * BPL + q * 16) = rb[p][q];
+      }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+  const int aoff = (wm * 64 + l31) * NT_RS + lh * 16;
+  const int boff = (wn * 64 + l31) * NT_RS + lh * 16;
+  u32x4 fa[2][2][NPL], fb[2][2][NPL];
+  auto loadF = [&](int set, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        fa[set][t][p] = *reinterpret_cast<const u32x4*>(sA + p * APL + aoff + t * 32 * NT_RS + ks * 32);
+        fb[set][t][p] = *reinterpret_cast<const u32x4*>(sB + p * BPL + boff + t * 32 * NT_RS + ks * 32);
+      }
+  };
+  auto mm = [&](int set) __attribute__((always_inline)) {
+    using PR = Prod<NPL>;
+#pragma unroll
+    for (int t = 0; t < PR::N; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[set][i][PR::A[t]], fb[set][j][PR::B[t]], acc[i][j]);
+  };
+  const int nch = a.Kp / NT_BK;
+  gload(0);
+  for (int kc = 0; kc < nch; ++kc) {
+    lstore();
+    __syncthreads();
+    if (kc + 1 < nch) gload(kc + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    loadF(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < NT_BK / 16; ++ks) {
+      if (ks + 1 < NT_BK / 16) loadF((ks + 1) & 1, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  // epilogue: accumulator rows = channels, lanes = 32 consecutive (frame, position) rows
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + l31;
+    if (n >= a.N) continue;
+    const int f = n / a.xv.R, q = n - f * a.xv.R;
+    const int pos = q * a.oq + a.o0 + ph * a.o0s;
+    if (pos < 0 || pos >= a.OH) continue;
+    float* ob = a.out + (int64_t)f * a.ofs + pos;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + wm * 64 + i * 32 + acc_row(reg, lane);
+        if (m < a.M) ob[(int64_t)m * a.om] = acc[i][j][reg] + (a.bias ? a.bias[m] : 0.f);
+      }
+  }
+}
+
+template <int NPL>
+inline void launch_cgemm(const CgArgs& a, int phases, hipStream_t s) {
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_cgemm<NPL>), nt_lds(NPL));
+  dim3 grid((unsigned)cdiv(a.N, NT_BN), (unsigned)cdiv(a.M, NT_BM), (unsigned)phases);
+  hipLaunchKernelGGL(k_cgemm<NPL>, grid, dim3(256), nt_lds(NPL), s, a);
+}
+
+// fp32 canonical [F][C][H] (+ LayerNorm + lrelu) -> channel-last planes [NPL][F][HP][CP] with zero halo rows and zero
+// channel padding.  One workgroup per frame chunk; a frame is transposed through LDS: coalesced reads along H,
+// 16-byte stores along C.
+struct ClArgs {
+  const float* src;    // [F][C][H]
+  const float* st;     // LN: (mean, rstd) per frame, or nullptr
+  const float* gamma;
+  const float* beta;
+  int C, H, CP, HLO, HP;
+  int F;
+  unsigned short* dst;  // [NPL][F][HP][CP]
+};
+template <int NPL, bool LN>
+__global__ void __launch_bounds__(256) k_split_cl(ClArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [C][H + 1]
+  const int tid = threadIdx.x;
+  const int HS = a.H + 1;
+  const int g8 = a.CP >> 3;
+  for (int f = blockIdx.x; f < a.F; f += gridDim.x) {
+    const float* sf = a.src + (int64_t)f * a.C * a.H;
+    float mean = 0.f, rstd = 1.f;
+    if constexpr (LN) {
+      mean = a.st[2 * f];
+      rstd = a.st[2 * f + 1];
+    }
+    __syncthreads();
+    for (int i = tid; i < a.C * a.H; i += 256) {
+      const int c = i / a.H, h = i - c * a.H;
+      float v = sf[i];
+      if constexpr (LN) v = lnact_v(v, mean, rstd, a.gamma[c], a.beta[c]);
+      tile[c * HS + h] = v;
+    }
+    __syncthreads();
+    // one item = (padded position hp, group of 8 channels)
+    for (int i = tid; i < a.HP * g8; i += 256) {
+      const int hp = i / g8, cg = i - hp * g8;
+      const int h = hp - a.HLO;
+      unsigned t[8][NPL];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+        const float v = (h >= 0 && h < a.H && c < a.C) ? tile[c * HS + h] : 0.f;
+        split_n<NPL>(v, t[j]);
+      }
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        u32x4 pk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pk[q] = t[2 * q][p] | (t[2 * q + 1][p] << 16);
+        *reinterpret_cast<u32x4*>(a.dst + (((int64_t)p * a.F + f) * a.HP + hp) * a.CP + cg * 8) = pk;
+      }
+    }
+  }
+}
+template <int NPL>
+inline void launch_split_cl(const ClArgs& a, hipStream_t s) {
+  const int lds = a.C * (a.H + 1) * 4;
+  const unsigned blocks = (unsigned)cmin_(a.F, 4096);
+  if (a.st) {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_split_cl<NPL, true>), lds);
+    hipLaunchKernelGGL((k_split_cl<NPL, true>), dim3(blocks), dim3(256), lds, s, a);
+  } else {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_split_cl<NPL, false>), lds);
+    hipLaunchKernelGGL((k_split_cl<NPL, false>), dim3(blocks), dim3(256), lds, s, a);
+  }
+}
+
+// conv weights (TF [T][1][Cin][Cout]) for the forward view GEMM: B[m = o][k = t*CP + c] = W[t][c][o]
+struct WConvF {
+  const float* W;
+  int T, C, CP, O;
+  __device__ float operator()(int m, int k) const {
+    const int t = k / CP, c = k - t * CP;
+    return (m < O && t < T && c < C) ? W[((int64_t)t * C + c) * O + m] : 0.f;
+  }
+};
+
+}  // namespace tuned
+}  // namespace vaenpvc
+
+// (A large-tile variant -- 8 waves, 256 x 256 or 128 x 512 per workgroup, 128 accumulator registers per lane, one
+//  workgroup per CU -- was measured and dropped: enc4 forward 194 us against 157 us for the 128 x 128 kernel above,
+//  merge forward 250 against 150.  With 8 MFMA tiles per wave there is no room left for a second fragment set, so a
+//  wave's LDS reads and MFMAs no longer overlap, and one workgroup per CU leaves nothing to cover the barriers.)

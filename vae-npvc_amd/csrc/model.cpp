@@ -146,11 +146,20 @@ std::vector<Region> workspace_layout(const Model& m, int64_t F, int mode, int64_
   if (m.n_dec >= 2) add("dec_y", F * m.dec[m.n_dec - 2].cout * m.dec[m.n_dec - 2].hout);
   // the same tensor as three bf16 planes, bins padded to a multiple of 16 (bf16 MFMA path of the last layer)
   if (m.n_dec >= 2) add("toep_yp", F * 3 * m.dec[m.n_dec - 2].cout * ((m.dec[m.n_dec - 2].hout + 15) / 16 * 16) / 2);
+  // bf16 operand planes of the dense-shaped layers on the bf16 matrix cores (gfx950_planegemm.h), up to 3 planes
+  // of [F][Kp] unsigned short each: activated outputs of encoder layers 3 and 4, and z
+  if (m.is_vcc2016) {
+    // channel-last planes with zero halo rows ([F][HP][CP], gfx950_planegemm.h: conv layers as view GEMMs)
+    add("cl_y2", F * 25 * 64 * 3 / 2);   // activated output of encoder layer 2: 19 + 3 + 3 positions x 64 channels
+    add("pl_y3", F * 896 * 3 / 2);
+    add("pl_y4", F * 768 * 3 / 2);
+    add("pl_z", F * 128 * 3 / 2);
+  }
   add("xh", F * m.H);
   add("kl_f", F);
   add("nll_f", F);
   // packed / transposed weight copies of the tuned kernels (F-independent)
-  add("scratch", 4 * m.n_params + 65536);
+  add("scratch", 8 * m.n_params + 65536);
   if (mode == VAENPVC_MODE_TRAIN) {
     add("d_xh", F * m.H);
     for (int i = m.n_dec - 2; i >= 0; --i) add("d_dec_a" + std::to_string(i), F * m.dec[i].cout * m.dec[i].hout);
@@ -161,6 +170,11 @@ std::vector<Region> workspace_layout(const Model& m, int64_t F, int mode, int64_
     add("d_z_lv", F * m.z);
     for (int i = m.n_enc - 1; i >= 0; --i) add("d_enc_a" + std::to_string(i), F * m.enc[i].cout * m.enc[i].hout);
     add("dy_tmp", F * maxact);
+    if (m.is_vcc2016) {  // planes of [dz_mu | dz_lv], d(h) (1539 -> 1600 columns) and d(pre-LN output of encoder layer 4)
+      add("pl_dz", F * 256 * 3 / 2);
+      add("pl_dh", F * 1600 * 3 / 2);
+      add("pl_da4", F * 768 * 3 / 2);
+    }
     // three bf16 planes (hi, mid, lo) of d_xh, rows zero padded to a multiple of 16 bins (bf16 MFMA path
     // of the last decoder layer)
     add("toep_gp", F * 3 * ((m.H + 15) / 16 * 16) / 2);

@@ -22,6 +22,7 @@ struct Runtime {
   // ---- kernel selection (vaenpvc_set_tuned_masks / vaenpvc_set_precision)
   unsigned fwd_mask = 0xffffffffu, bwd_mask = 0xffffffffu;
   int planes = 2;               // bf16 terms per fp32 operand on the bf16 matrix cores: 3, 2 or 1
+  int dense_planes = 0;         // developer override for the dense-shaped layers (VAENPVC_DENSE_PLANES); 0 = by rule
   bool toep_f32 = false;        // VAENPVC_TOEP=f32: exact-fp32 MFMA kernels for the 1025-tap layer
   bool toep_wgrad_f32 = false;  // VAENPVC_TOEP_WGRAD_F32
   bool side_enabled = true;     // VAENPVC_SIDE_STREAM=0 disables the internal weight-gradient stream

@@ -19,12 +19,17 @@ RtScope::~RtScope() { tl_rt = prev; }
 //   VAENPVC_TOEP=f32                      exact-fp32 MFMA kernels for the 1025-tap layer
 //   VAENPVC_TOEP_WGRAD_F32                exact-fp32 weight gradient of that layer only
 //   VAENPVC_PLANES=1|2|3                  bf16 terms per fp32 operand (vaenpvc_set_precision)
+//   VAENPVC_DENSE_PLANES=1|2|3            terms on the dense-shaped layers regardless of the precision rule (experiments)
 void Runtime::read_env() {
   if (const char* e = getenv("VAENPVC_FWD_MASK")) fwd_mask = (unsigned)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_BWD_MASK")) bwd_mask = (unsigned)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_SIDE_STREAM")) side_enabled = e[0] != '0';
   if (const char* e = getenv("VAENPVC_TOEP")) toep_f32 = !strcmp(e, "f32");
   toep_wgrad_f32 = getenv("VAENPVC_TOEP_WGRAD_F32") != nullptr;
+  if (const char* e = getenv("VAENPVC_DENSE_PLANES")) {
+    int p = atoi(e);
+    if (p >= 1 && p <= 3) dense_planes = p;
+  }
   if (const char* e = getenv("VAENPVC_PLANES")) {
     int p = atoi(e);
     if (p >= 1 && p <= 3) planes = p;

@@ -13,7 +13,9 @@ ABI_VERSION = 2
 MODE_INFER, MODE_TRAIN = 0, 1
 IMPL_AUTO, IMPL_GENERIC = 0, 1
 PREC_BF16X3, PREC_BF16X2, PREC_BF16 = 3, 2, 1
-PRECISIONS = {'bf16x3': 3, 'bf16x2': 2, 'bf16': 1, 'f32': 3}
+# bf16 terms per fp32 operand on the bf16 matrix cores: 'bf16x2' (default, alias 'auto'): 16 mantissa bits per operand;
+# 'bf16x3': fp32-exact; 'bf16': plain bf16 operands (the bf16 mode)
+PRECISIONS = {'auto': 2, 'bf16x2': 2, 'bf16x3': 3, 'bf16': 1}
 
 
 class HipVaeError(RuntimeError):
