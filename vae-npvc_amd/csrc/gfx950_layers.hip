@@ -315,6 +315,20 @@ static void prep(const Model& m, const float* P, const Ws& w, hipStream_t s) {
   });
 }
 
+// statistics of encoder layer 3 / 4 outputs; when the next layer runs on the plane GEMM kernels the activated planes
+// (canonical [F][C*H] order) are written in the same pass
+template <int N, int H>
+static void stats_planes(const float* a, float* st, const float* gamma, const float* beta, float* planes, bool want, int F,
+                         hipStream_t s) {
+  if (!want) {
+    hipLaunchKernelGGL(k_ln_stats_fast<N>, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, a, st, F);
+    return;
+  }
+  for_dense_planes([&](auto npl) {
+    hipLaunchKernelGGL((k_ln_stats_planes<N, H, decltype(npl)::value>), dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, a, st, gamma,
+                       beta, reinterpret_cast<unsigned short*>(planes), F);
+  });
+}
 template <int N>
 static void stats(const float* a, float* st, int F, hipStream_t s) {
   hipLaunchKernelGGL(k_ln_stats_fast<N>, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, a, st, F);
@@ -404,39 +418,47 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
       a.bias = P + m.enc[3].b_off;
       VAENPVC_TIMED("enc3_fwd", s, launch_cgemm<NPL>(a, 1, s));
     });
-    stats<896>(w.enc_a[3], w.enc_st[3], F, s);
+    stats_planes<896, 7>(w.enc_a[3], w.enc_st[3], P + m.enc[3].gamma_off, P + m.enc[3].beta_off, w.pl_y3,
+                         fwd_on(4) && pg_fwd(F), F, s);
   } else if (fwd_on(3)) {
     VAENPVC_TIMED("enc3_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<E3Fs>(lnp(3), nsplit_for<E3Fs>(F), s) : launch_convgemm<E3F>(lnp(3), nsplit_for<E3F>(F), s)));
-    stats<896>(w.enc_a[3], w.enc_st[3], F, s);
+    stats_planes<896, 7>(w.enc_a[3], w.enc_st[3], P + m.enc[3].gamma_off, P + m.enc[3].beta_off, w.pl_y3,
+                         fwd_on(4) && pg_fwd(F), F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 3);
   if (fwd_on(4) && pg_fwd(F)) {
     // layer 4 as the dense layer [F, 896] x [896, 768] on the bf16 matrix cores (gfx950_planegemm.h)
     for_dense_planes([&](auto npl) {
       constexpr int NPL = decltype(npl)::value;
-      SplitArgs sa = split_args(w.enc_a[3], 896, 896, F, us(w.pl_y3));
-      sa.st = w.enc_st[3];
-      sa.gamma = P + m.enc[3].gamma_off;
-      sa.beta = P + m.enc[3].beta_off;
-      sa.lndiv = 7;
-      VAENPVC_TIMED("enc4_split", s, launch_split<NPL>(sa, s));
+      if (!fwd_on(3)) {  // (layer 3 ran on the generic kernel: its statistics pass did not write the planes)
+        SplitArgs sa = split_args(w.enc_a[3], 896, 896, F, us(w.pl_y3));
+        sa.st = w.enc_st[3];
+        sa.gamma = P + m.enc[3].gamma_off;
+        sa.beta = P + m.enc[3].beta_off;
+        sa.lndiv = 7;
+        VAENPVC_TIMED("enc4_split", s, launch_split<NPL>(sa, s));
+      }
       NtArgs a = nt_args(w.pl_y3, F, 896, w.scratch + Pk::pg_enc4f, 768, 768, w.enc_a[4], 768);
       a.bias = w.scratch + Pk::pg_bias4;
       VAENPVC_TIMED("enc4_fwd", s, launch_gemm_nt<NPL>(a, s));
     });
-    stats<768>(w.enc_a[4], w.enc_st[4], F, s);
+    stats_planes<768, 3>(w.enc_a[4], w.enc_st[4], P + m.enc[4].gamma_off, P + m.enc[4].beta_off, w.pl_y4,
+                         fwd_on(5) && pg_fwd(F), F, s);
   } else if (fwd_on(4)) {
     VAENPVC_TIMED("enc4_fwd", s, launch_convgemm<E4F>(lnp(4), nsplit_for<E4F>(F), s));
-    stats<768>(w.enc_a[4], w.enc_st[4], F, s);
+    stats_planes<768, 3>(w.enc_a[4], w.enc_st[4], P + m.enc[4].gamma_off, P + m.enc[4].beta_off, w.pl_y4,
+                         fwd_on(5) && pg_fwd(F), F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 4);
   if (fwd_on(5) && pg_fwd(F)) {
     for_dense_planes([&](auto npl) {
       constexpr int NPL = decltype(npl)::value;
-      SplitArgs sa = split_args(w.enc_a[4], 768, 768, F, us(w.pl_y4));
-      sa.st = w.enc_st[4];
-      sa.gamma = P + m.enc[4].gamma_off;
-      sa.beta = P + m.enc[4].beta_off;
-      sa.lndiv = 3;
-      VAENPVC_TIMED("heads_split", s, launch_split<NPL>(sa, s));
+      if (!fwd_on(4)) {  // (layer 4 ran on the generic kernel)
+        SplitArgs sa = split_args(w.enc_a[4], 768, 768, F, us(w.pl_y4));
+        sa.st = w.enc_st[4];
+        sa.gamma = P + m.enc[4].gamma_off;
+        sa.beta = P + m.enc[4].beta_off;
+        sa.lndiv = 3;
+        VAENPVC_TIMED("heads_split", s, launch_split<NPL>(sa, s));
+      }
       NtArgs a = nt_args(w.pl_y4, F, 768, w.scratch + Pk::pg_headsf, 256, 256, w.z_mu, 128);
       a.C2 = w.z_lv;
       a.split = 128;
@@ -605,6 +627,16 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       const int fch = rup(cdiv((int)F, zc), WG_KF);
       for_planes([&](auto npl) {
         constexpr int NPL = decltype(npl)::value;
+        if constexpr (NPL <= 2) {
+          if (!rt().toep_wgrad_k16) {   // 32-frame chunks: two k-steps per barrier
+            const int fch32 = rup(cdiv((int)F, zc), W2_KF);
+            rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_wgrad_bf16_k32<NPL>), w2_lds(NPL));
+            VAENPVC_TIMED("dec3_wgrad", s2, hipLaunchKernelGGL(k_toep_wgrad_bf16_k32<NPL>, dim3(8, TB_C, (unsigned)cdiv((int)F, fch32)), dim3(512),
+                                                              w2_lds(NPL), s2, reinterpret_cast<const unsigned short*>(w.toep_yp), gp,
+                                                              G + m.dec[3].w_off, (int)F, fch32));
+            return;
+          }
+        }
         rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_wgrad_bf16<NPL>), wg_lds(NPL));
         VAENPVC_TIMED("dec3_wgrad", s2, hipLaunchKernelGGL(k_toep_wgrad_bf16<NPL>, dim3(8, TB_C, (unsigned)cdiv((int)F, fch)), dim3(512), wg_lds(NPL), s2,
                                                           reinterpret_cast<const unsigned short*>(w.toep_yp), gp, G + m.dec[3].w_off, (int)F, fch));

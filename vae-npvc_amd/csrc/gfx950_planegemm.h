@@ -86,6 +86,64 @@ __global__ void __launch_bounds__(256) k_split_planes(SplitArgs a) {
   }
 }
 
+// LayerNorm statistics of a layer's pre-LN output (N = C*H floats per frame, util/layers.py:32) AND the planes of its
+// activated output in the same pass (one wave per frame, the frame stays in registers): replaces k_ln_stats_fast
+// + k_split_planes<LN> for the tensors the dense-shaped layers consume (saves a read of the tensor)
+template <int N, int H, int NPL>
+__global__ void __launch_bounds__(256) k_ln_stats_planes(const float* __restrict__ a, float* __restrict__ st,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         unsigned short* __restrict__ dst, int F) {
+  static_assert(N % 64 == 0, "plane rows are padded to 64 columns");
+  constexpr int NV = N / 4, PER = cdiv(NV, 64);
+  const int lane = threadIdx.x & 63;
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= F) return;
+  const float4* p = reinterpret_cast<const float4*>(a + (int64_t)f * N);
+  float4 v[PER];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    int idx = lane + 64 * i;
+    v[i] = idx < NV ? p[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / N;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    if (lane + 64 * i < NV) {
+      float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / N + LN_EPS);
+  if (lane == 0) {
+    st[2 * f] = mean;
+    st[2 * f + 1] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int idx = lane + 64 * i;
+    if (idx < NV) {
+      const int e = 4 * idx;
+      const float y4[4] = {lnact_v(v[i].x, mean, rstd, gamma[e / H], beta[e / H]),
+                           lnact_v(v[i].y, mean, rstd, gamma[(e + 1) / H], beta[(e + 1) / H]),
+                           lnact_v(v[i].z, mean, rstd, gamma[(e + 2) / H], beta[(e + 2) / H]),
+                           lnact_v(v[i].w, mean, rstd, gamma[(e + 3) / H], beta[(e + 3) / H])};
+      unsigned t[4][NPL];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split_n<NPL>(y4[j], t[j]);
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        uint2 pk;
+        pk.x = t[0][pl] | (t[1][pl] << 16);
+        pk.y = t[2][pl] | (t[3][pl] << 16);
+        *reinterpret_cast<uint2*>(dst + ((int64_t)pl * F + f) * N + e) = pk;
+      }
+    }
+  }
+}
+
 template <int NPL>
 inline void launch_split(const SplitArgs& a, hipStream_t s) {
   const int64_t total = a.rows * (a.Kp >> 3);

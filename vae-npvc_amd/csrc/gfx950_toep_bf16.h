@@ -741,5 +741,152 @@ __global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16(const unsigned short
 #endif
 }
 
+
+// ---- the same weight gradient with 32-frame chunks (NPL <= 2: two planes leave the LDS room): two MFMA k-steps
+//      (24 MFMAs per wave at NPL = 2) between barriers instead of one.  Same tile, same fragment reads, same epilogue.
+constexpr int W2_KF = 32;
+constexpr int w2_buf(int npl) { return npl * W2_KF * (WG_RSA + WG_RSB); }
+constexpr int w2_lds(int npl) { return 2 * w2_buf(npl); }   // 114 688 bytes at NPL = 2
+
+template <int NPL>
+__global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16_k32(const unsigned short* __restrict__ yp,  // [F][NPL][8][528]
+                                                                 const unsigned short* __restrict__ gp,  // [F][NPL][528]
+                                                                 float* __restrict__ dW,                 // [1025][8] atomicAdd
+                                                                 int F, int fchunk) {
+  static_assert(NPL <= 2, "three planes do not fit two 32-frame buffers");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int APL = W2_KF * WG_RSA, BPL = W2_KF * WG_RSB, BUF = w2_buf(NPL);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int i0 = (blockIdx.x >> 1) * 128, q0 = (blockIdx.x & 1) * 256, c = blockIdx.y;
+  const bool strip = (blockIdx.x & 1) != 0;  // uniform: this workgroup also owns q = 512
+  const int fb = blockIdx.z * fchunk, fe = min(F, fb + fchunk);
+  // staging of one 32-frame chunk (16-byte pieces): A 32 rows x 16 pieces: one per thread and plane;
+  // B 32 rows x 32 pieces: two per thread and plane (rows brow, brow + 16); strip: 32 rows x 2 pieces x NPL: threads < 64*NPL
+  const int arow = tid >> 4, apc = tid & 15;
+  const int brow = tid >> 5, bpc = tid & 31;
+  const int epl = tid >> 6, erow = (tid >> 1) & 31, epc = tid & 1;
+  u32x4 sta[NPL], stb[NPL][2], ste;
+  const unsigned char* Y8 = reinterpret_cast<const unsigned char*>(yp);
+  const unsigned char* G8 = reinterpret_cast<const unsigned char*>(gp);
+  auto gload = [&](int f0) __attribute__((always_inline)) {
+    const int fa_ = min(f0 + arow, F - 1), fb0 = min(f0 + brow, F - 1), fb1 = min(f0 + brow + 16, F - 1);
+    const unsigned char* pa = Y8 + ((size_t)fa_ * NPL * TB_C + c) * (TB_KP * 2) + (i0 * 2 + apc * 16);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) sta[pl] = *reinterpret_cast<const u32x4*>(pa + (size_t)pl * TB_C * TB_KP * 2);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+      stb[pl][0] = *reinterpret_cast<const u32x4*>(G8 + ((size_t)fb0 * NPL + pl) * (TB_KP * 2) + q0 * 2 + bpc * 16);
+      stb[pl][1] = *reinterpret_cast<const u32x4*>(G8 + ((size_t)fb1 * NPL + pl) * (TB_KP * 2) + q0 * 2 + bpc * 16);
+    }
+    if (strip && tid < 64 * NPL) {
+      const int fe_ = min(f0 + erow, F - 1);
+      ste = *reinterpret_cast<const u32x4*>(G8 + ((size_t)fe_ * NPL + epl) * (TB_KP * 2) + (64 + epc) * 16);
+    }
+  };
+  auto lstore = [&](int f0, int buf) __attribute__((always_inline)) {
+    unsigned char* sA = smem + buf * BUF;
+    unsigned char* sB = sA + NPL * APL;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    const bool zero = f0 + arow >= fe;   // frames past the chunk contribute zero (A rows zeroed)
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x4*>(sA + pl * APL + arow * WG_RSA + apc * 16) = zero ? z : sta[pl];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+      *reinterpret_cast<u32x4*>(sB + pl * BPL + brow * WG_RSB + bpc * 16) = stb[pl][0];
+      *reinterpret_cast<u32x4*>(sB + pl * BPL + (brow + 16) * WG_RSB + bpc * 16) = stb[pl][1];
+    }
+    if (strip && tid < 64 * NPL) *reinterpret_cast<u32x4*>(sB + epl * BPL + erow * WG_RSB + (32 + epc) * 16) = ste;
+  };
+  // fragment addresses (transpose reads) inside a 16-frame half of the chunk
+  const int trow = ((lane & 15) >> 2) + 8 * lh, tcol = 4 * (lane & 3) + 16 * ((lane >> 4) & 1);
+  const int aoff = trow * WG_RSA + (64 * wr + tcol) * 2;
+  const int boff = NPL * APL + trow * WG_RSB + (64 * wc + tcol) * 2;
+  const int eoff = NPL * APL + trow * WG_RSB + (256 + tcol) * 2;
+  const int eri = wc & 1;   // this wave's strip row tile = 2*wr + eri, on k-steps of parity wc >> 1
+  f32x16 acc[2][2], acce;
+#pragma unroll
+  for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+    for (int cj = 0; cj < 2; ++cj) acc[ri][cj] = zero16();
+  acce = zero16();
+  u32x4 fa[2][NPL], fbq[2][NPL], fe3[NPL];
+  auto step = [&](int buf, int ks) __attribute__((always_inline)) {
+    const unsigned char* sb = smem + buf * BUF;
+    const bool mine = strip && (wc >> 1) == ks;   // wave-uniform
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) fa[ri][pl] = tr_read8(sb + pl * APL + ks * 16 * WG_RSA + aoff + ri * 64, 4 * WG_RSA);
+#pragma unroll
+    for (int cj = 0; cj < 2; ++cj)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) fbq[cj][pl] = tr_read8(sb + pl * BPL + ks * 16 * WG_RSB + boff + cj * 64, 4 * WG_RSB);
+    if (mine) {
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) fe3[pl] = tr_read8(sb + pl * BPL + ks * 16 * WG_RSB + eoff, 4 * WG_RSB);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    using PR = Prod<NPL>;
+#pragma unroll
+    for (int t = 0; t < PR::N; ++t)
+#pragma unroll
+      for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int cj = 0; cj < 2; ++cj) acc[ri][cj] = mfma_bf16(fa[ri][PR::A[t]], fbq[cj][PR::B[t]], acc[ri][cj]);
+    if (mine) {
+      u32x4 af[NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) af[pl] = eri == 0 ? fa[0][pl] : fa[1][pl];
+#pragma unroll
+      for (int t = 0; t < PR::N; ++t) acce = mfma_bf16(af[PR::A[t]], fe3[PR::B[t]], acce);
+    }
+  };
+  if (fb < fe) {
+    gload(fb);
+    lstore(fb, 0);
+  }
+  __syncthreads();
+  int n = 0;
+  for (int f0 = fb; f0 < fe; f0 += W2_KF, ++n) {
+    const bool more = f0 + W2_KF < fe;
+    if (more) gload(f0 + W2_KF);
+    __builtin_amdgcn_sched_barrier(0);
+    step(n & 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    step(n & 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) lstore(f0 + W2_KF, (n + 1) & 1);
+    __syncthreads();
+  }
+  // ---- epilogue (as k_toep_wgrad_bf16): 383 diagonals reduced in LDS, one global atomic per diagonal and workgroup
+  float* dg = reinterpret_cast<float*>(smem);
+  if (tid < 384) dg[tid] = 0.f;
+  __syncthreads();
+  const int dbase = 64 * wc - 64 * wr + 127;
+#pragma unroll
+  for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+    for (int cj = 0; cj < 2; ++cj)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        int row = ri * 32 + acc_row(reg, lane);
+        int cl = cj * 32 + l31;
+        atomicAdd(&dg[dbase + cl - row], acc[ri][cj][reg]);
+      }
+  __syncthreads();
+  if (tid < 383) {
+    int t = q0 - i0 + (tid - 127) + 512;
+    atomicAdd(dW + t * TB_C + c, dg[tid]);
+  }
+  if (strip && l31 == 0) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      int i = i0 + 64 * wr + 32 * eri + acc_row(reg, lane);
+      atomicAdd(dW + (1024 - i) * TB_C + c, acce[reg]);
+    }
+  }
+}
+
 }  // namespace tuned
 }  // namespace vaenpvc

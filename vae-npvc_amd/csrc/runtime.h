@@ -25,6 +25,7 @@ struct Runtime {
   int dense_planes = 0;         // developer override for the dense-shaped layers (VAENPVC_DENSE_PLANES); 0 = by rule
   bool toep_f32 = false;        // VAENPVC_TOEP=f32: exact-fp32 MFMA kernels for the 1025-tap layer
   bool toep_wgrad_f32 = false;  // VAENPVC_TOEP_WGRAD_F32
+  bool toep_wgrad_k16 = false;  // VAENPVC_TOEP_WGRAD_K16: 16-frame chunks in the bf16 weight gradient (A/B measurements)
   bool side_enabled = true;     // VAENPVC_SIDE_STREAM=0 disables the internal weight-gradient stream
   // ---- device binding: created lazily on the device that is current at the first launch
   int device = -1;
