@@ -22,4 +22,5 @@ trace() {  # name, bench args
 }
 trace big --steps 10 --warmup 3
 trace f256 --frames 256 --steps 100 --warmup 10
+trace f16 --frames 16 --steps 100 --warmup 10
 tail -3 $OUT/pytest.log; head -c 600 $OUT/bench.json; tail -2 $OUT/bench.err

@@ -182,7 +182,9 @@ template <class L>
 __global__ void __launch_bounds__(256) k_ln_bwd_fused(const float* __restrict__ dy, const float* __restrict__ a,
                                                       const float* __restrict__ st, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float* __restrict__ da,
-                                                      float* __restrict__ part, int F, int fchunk) {
+                                                      float* __restrict__ part, int F, int fchunk,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      float* __restrict__ dbias) {  // non-null: accumulate directly (few workgroups)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[2][4][2];
   constexpr int N = L::N, H = L::H, C = L::C, EPT = L::EPT;
@@ -266,10 +268,16 @@ __global__ void __launch_bounds__(256) k_ln_bwd_fused(const float* __restrict__ 
       w = wave_sum(w);
       d = wave_sum(d);
       if (lane == 0) {
-        float* pp = part + (int64_t)blockIdx.x * (3 * C);
-        pp[c] = u;
-        pp[C + c] = w;
-        pp[2 * C + c] = d;
+        if (dgamma) {  // uniform
+          atomicAdd(dgamma + c, u);
+          atomicAdd(dbeta + c, w);
+          atomicAdd(dbias + c, d);
+        } else {
+          float* pp = part + (int64_t)blockIdx.x * (3 * C);
+          pp[c] = u;
+          pp[C + c] = w;
+          pp[2 * C + c] = d;
+        }
       }
     }
   } else {
@@ -280,10 +288,16 @@ __global__ void __launch_bounds__(256) k_ln_bwd_fused(const float* __restrict__ 
         w += eW[c * H + h];
         d += eD[c * H + h];
       }
-      float* pp = part + (int64_t)blockIdx.x * (3 * C);
-      pp[c] = u;
-      pp[C + c] = w;
-      pp[2 * C + c] = d;
+      if (dgamma) {  // uniform
+        atomicAdd(dgamma + c, u);
+        atomicAdd(dbeta + c, w);
+        atomicAdd(dbias + c, d);
+      } else {
+        float* pp = part + (int64_t)blockIdx.x * (3 * C);
+        pp[c] = u;
+        pp[C + c] = w;
+        pp[2 * C + c] = d;
+      }
     }
   }
 }
@@ -313,8 +327,13 @@ inline void launch_ln_bwd(const float* dy, const float* a, const float* st, cons
   rt().ensure_lds(reinterpret_cast<const void*>(&k_ln_bwd_fused<L>), L::LDS_BYTES);
   int fchunk = cmax(1, cdiv(F, target_wgs));
   int nwg = cdiv(F, fchunk);
+  if (nwg <= 8) {  // tiny batches only: same-address atomics from many workgroups serialise (256 workgroups: 104 us against 7 + 5)
+    hipLaunchKernelGGL(k_ln_bwd_fused<L>, dim3((unsigned)nwg), dim3(256), L::LDS_BYTES, s, dy, a, st, gamma, beta, da, part, F,
+                       fchunk, dgamma, dbeta, dbias);
+    return;
+  }
   hipLaunchKernelGGL(k_ln_bwd_fused<L>, dim3((unsigned)nwg), dim3(256), L::LDS_BYTES, s, dy, a, st, gamma, beta, da, part, F,
-                     fchunk);
+                     fchunk, (float*)nullptr, (float*)nullptr, (float*)nullptr);
   hipLaunchKernelGGL(k_ln_bwd_reduce, dim3(3 * L::C), dim3(256), 0, s, part, nwg, L::C, dgamma, dbeta, dbias);
 }
 

@@ -236,7 +236,18 @@ static_assert(E1F::BTOTAL == 7 * 16 * 32 && E2F::BTOTAL == 7 * 32 * 64 && E3F::B
 // The bf16 kernels own 64 frames per workgroup: below ~8k frames they cannot fill the chip and the
 // fp32 kernels (32 frames per workgroup, bins split over more workgroups) are faster.  Clearing bit 30
 // of the forward mask forces them at any batch size (parity tests).
-constexpr int64_t TOEP_BF16_MIN_FRAMES = 8192;
+constexpr int64_t TOEP_BF16_MIN_FRAMES = 16;
+// channel groups of the bf16 Toeplitz GEMM kernels: each workgroup owns 64 frames, so small batches spread the 8
+// channels over up to 8 workgroups per frame tile (>= 256 workgroups where the batch allows it)
+static int toep_groups(int64_t F) {
+  const int wgs = cdiv((int)F, DG_M);
+  int g = 1;
+  while (g < TB_C && wgs * g < 256) g *= 2;
+  return g;
+}
+// the forward direction combines its channel groups with fp32 atomics (order-dependent rounding): only inside a
+// train / loss step; a stand-alone decode (conversion path) stays bitwise reproducible with one group
+static int toep_fwd_groups(int64_t F, bool in_step) { return in_step ? toep_groups(F) : 1; }
 bool available() { return true; }
 static inline bool fwd_on(int bit) { return (rt().fwd_mask >> bit) & 1u; }
 static inline bool bwd_on(int bit) { return (rt().bwd_mask >> bit) & 1u; }
@@ -520,7 +531,8 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
       for_planes([&](auto npl) {
         hipLaunchKernelGGL(k_ln_stats_act_planes<decltype(npl)::value>, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
                            P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, reinterpret_cast<unsigned short*>(w.toep_yp),
-                           w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, (int)F, toep_wgrad_bf16_for(F) ? 0 : 1);
+                           w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, (int)F, toep_wgrad_bf16_for(F) ? 0 : 1,
+                           toep_fwd_groups(F, weights_packed) > 1 ? 1 : 0);
       });
     else
       hipLaunchKernelGGL((k_ln_stats_act<4104, 513>), dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
@@ -538,7 +550,7 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
       for_planes([&](auto npl) {
         constexpr int NPL = decltype(npl)::value;
         rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_gemm_bf16<true, NPL>), dg_lds(NPL));
-        VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL((k_toep_gemm_bf16<true, NPL>), dim3((unsigned)cdiv(F, DG_M)), dim3(256), dg_lds(NPL), s,
+        VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL((k_toep_gemm_bf16<true, NPL>), dim3((unsigned)cdiv(F, DG_M), (unsigned)toep_fwd_groups(F, weights_packed)), dim3(256), dg_lds(NPL), s,
                                                         reinterpret_cast<const unsigned short*>(w.toep_yp),
                                                         reinterpret_cast<const unsigned short*>(w.scratch + Pk::wfw),
                                                         P + m.dec[3].b_off, xh_out, (int)F));
@@ -658,7 +670,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       for_planes([&](auto npl) {
         constexpr int NPL = decltype(npl)::value;
         rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_gemm_bf16<false, NPL>), dg_lds(NPL));
-        VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL((k_toep_gemm_bf16<false, NPL>), dim3((unsigned)cdiv(F, DG_M)), dim3(256), dg_lds(NPL), s, gp,
+        VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL((k_toep_gemm_bf16<false, NPL>), dim3((unsigned)cdiv(F, DG_M), (unsigned)toep_groups(F)), dim3(256), dg_lds(NPL), s, gp,
                                                           reinterpret_cast<const unsigned short*>(w.scratch + Pk::wdg), (const float*)nullptr,
                                                           w.dy_tmp, (int)F));  // (column 512: k_dxh_post)
       });

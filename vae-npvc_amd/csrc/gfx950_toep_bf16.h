@@ -295,9 +295,13 @@ __global__ void __launch_bounds__(256, 1) k_toep_gemm_bf16(const unsigned short*
   long long pc[4] = {0, 0, 0, 0};
   TBPROF_T(k0);
 #endif
-  gload(0, 0);
+  // channel range of this workgroup: gridDim.y groups share the 8 channels (small batches: more workgroups; the
+  // forward direction then accumulates its partial sums over channel groups with atomics into a zeroed output)
+  const int cpg = TB_C / (int)gridDim.y, c_lo = (int)blockIdx.y * cpg, c_hi = c_lo + cpg;
+  const bool split_out = FWD && gridDim.y > 1;
+  gload(c_lo, 0);
 #pragma unroll 1
-  for (int c = 0; c < TB_C; ++c) {
+  for (int c = c_lo; c < c_hi; ++c) {
     TBPROF_T(t0);
     __syncthreads();  // previous channel fully consumed (tap copies and A tile)
     {  // tap copies of channel c: all loads first (one L2 latency), then the LDS stores
@@ -315,7 +319,7 @@ __global__ void __launch_bounds__(256, 1) k_toep_gemm_bf16(const unsigned short*
         if (i < NW16) reinterpret_cast<u32x4*>(sW)[i] = wv[k];
       }
     }
-    if (!FWD || c == 0) {
+    if (!FWD || c == c_lo) {
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -332,7 +336,7 @@ __global__ void __launch_bounds__(256, 1) k_toep_gemm_bf16(const unsigned short*
       TBPROF_T(t3);
       {  // prefetch the next chunk (same rows, next bins; wraps to chunk 0 for the next channel)
         int kn = kc + 1 < DG_NKC ? kc + 1 : 0;
-        int cn = kc + 1 < DG_NKC ? c : (c + 1 < TB_C ? c + 1 : c);
+        int cn = kc + 1 < DG_NKC ? c : (c + 1 < c_hi ? c + 1 : c);
         gload(cn, kn);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -366,7 +370,7 @@ __global__ void __launch_bounds__(256, 1) k_toep_gemm_bf16(const unsigned short*
 #endif
     }
     TBPROF_T(t6);
-    if (FWD && c + 1 < TB_C) continue;
+    if (FWD && c + 1 < c_hi) continue;
     // epilogue: rows = frames, lanes = 32 consecutive bins -> 128-byte stores; one uniform base
     // per workgroup and channel, 32-bit lane offsets, column tiles through the immediate offset
     {
@@ -374,15 +378,21 @@ __global__ void __launch_bounds__(256, 1) k_toep_gemm_bf16(const unsigned short*
       float* ob = dY + ((int64_t)f0 * (FWD ? 1 : TB_C) + (FWD ? 0 : c)) * TB_H;
       const int lo = (4 * lh) * ORS + 128 * wave + 4 * l31;
       const bool full = f0 + DG_M <= F;  // uniform
-      const float bb = FWD ? bias[0] : 0.f;
+      const float bb = (FWD && c_lo == 0) ? bias[0] : 0.f;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int r = mb * 32 + (reg & 3) + 8 * (reg >> 2);  // + 4*lh
           float* o = ob + lo + r * ORS;
-          if (full || f0 + r + 4 * lh < F)  // rows are only 4-byte aligned (513 bins): packed 16-byte store
-            *reinterpret_cast<packed4*>(o) = packed4{acc[mb][0][reg] + bb, acc[mb][1][reg] + bb, acc[mb][2][reg] + bb, acc[mb][3][reg] + bb};
+          if (full || f0 + r + 4 * lh < F) {
+            if (split_out) {  // uniform: partial sum of this channel group (the plane producer zeroed the row)
+#pragma unroll
+              for (int nb = 0; nb < 4; ++nb) atomicAdd(o + nb, acc[mb][nb][reg] + bb);
+            } else {  // rows are only 4-byte aligned (513 bins): packed 16-byte store
+              *reinterpret_cast<packed4*>(o) = packed4{acc[mb][0][reg] + bb, acc[mb][1][reg] + bb, acc[mb][2][reg] + bb, acc[mb][3][reg] + bb};
+            }
+          }
         }
     }
 #if VAENPVC_PROF
@@ -415,7 +425,9 @@ __global__ void __launch_bounds__(256) k_ln_stats_act_planes(const float* __rest
                                                              float* __restrict__ y, unsigned short* __restrict__ yp,
                                                              const float* __restrict__ Wc,  // [8][WROW]: Wc[c][8 + t]
                                                              const float* __restrict__ bias, float* __restrict__ xh, int F,
-                                                             int write_y) {  // 0: only bin 512 of y (fp32) is stored
+                                                             int write_y,    // 0: only bin 512 of y (fp32) is stored
+                                                             int zero_xh) {  // 1: bins 0..511 of xh are zeroed (the forward
+                                                                             // GEMM accumulates channel groups into them)
   constexpr int WROWC = 1040;
   const int lane = threadIdx.x & 63;
   const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -498,6 +510,11 @@ __global__ void __launch_bounds__(256) k_ln_stats_act_planes(const float* __rest
   }
   dot = wave_sum(dot);
   if (lane == 0) xh[(int64_t)f * TB_H + 512] = dot + bias[0];
+  if (zero_xh) {  // uniform
+    float* xr = xh + (int64_t)f * TB_H + 8 * lane;
+    *reinterpret_cast<packed4*>(xr) = packed4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<packed4*>(xr + 4) = packed4{0.f, 0.f, 0.f, 0.f};
+  }
 }
 
 // ---- weight gradient:  dW[t][c] = sum_f sum_i y[f][c][i] * G[f][i + t - 512]
