@@ -216,3 +216,66 @@ def test_event_file_writer_roundtrip(tmp_path):
 def test_rank_seeds_differ():
     from hipvae.dp import rank_seed
     assert len({rank_seed(s, r, 8) for s in range(4) for r in range(8)}) == 32
+
+
+def test_tf_checkpoint_bundle_roundtrip_and_import(tmp_path):
+    """util.tf_checkpoint: TensorFlow V2 checkpoints (LevelDB-format index + raw data shard) written and read without
+    TensorFlow; the reference's variable names map onto the flat parameter buffer (parameters, Adam slots, step)."""
+    import struct
+    import torch
+    from helpers import SMALL_ARCH
+    from util import tf_checkpoint as T
+    rng = np.random.default_rng(0)
+    tensors = {'layer_%02d/kernel' % i: rng.standard_normal((3, 1, i + 1, 2)).astype(np.float32) for i in range(40)}
+    tensors['global_step'] = np.array(1234, np.int64)
+    tensors['counts'] = np.arange(7, dtype=np.int32)
+    prefix = str(tmp_path / 'model.ckpt-1234')
+    T.write_bundle(prefix, tensors)
+    raw = open(prefix + '.index', 'rb').read()
+    assert struct.unpack('<Q', raw[-8:])[0] == 0xdb4775248b80fb57 and len(raw) > 48
+    # prefix compression really happened (41 keys share 'layer_'): the index is much smaller than the sum of key lengths + entries
+    got = T.read_bundle(prefix)
+    assert set(got) == set(tensors)
+    for k in tensors:
+        assert got[k].dtype == tensors[k].dtype and got[k].shape == tensors[k].shape and np.array_equal(got[k], tensors[k])
+    # corruption is detected: a flipped byte in the data shard (tensor CRC) and in the index (block CRC)
+    d = bytearray(open(prefix + '.data-00000-of-00001', 'rb').read())
+    d[10] ^= 0xFF
+    open(prefix + '.data-00000-of-00001', 'wb').write(bytes(d))
+    with pytest.raises(ValueError, match='CRC'):
+        T.read_bundle(prefix)
+    T.write_bundle(prefix, tensors)
+    b = bytearray(raw)
+    b[20] ^= 0xFF
+    open(prefix + '.index', 'wb').write(bytes(b))
+    with pytest.raises(ValueError, match='CRC'):
+        T.read_bundle(prefix)
+    open(prefix + '.index', 'wb').write(raw[:-1] + b'\x00')
+    with pytest.raises(ValueError, match='magic'):
+        T.read_bundle(prefix)
+    # the reference's variables <-> the flat buffer (names = SURVEY App. A.5 = vaenpvc_param_info)
+    lay = O.param_layout(SMALL_ARCH)
+    layout, off = {}, 0
+    for name, shp in lay.items():
+        layout[name] = (off, tuple(shp))
+        off += int(np.prod(shp))
+    state = {'params': torch.tensor(rng.standard_normal(off).astype(np.float32)), 'm': torch.tensor(rng.standard_normal(off).astype(np.float32)),
+             'v': torch.tensor(rng.random(off).astype(np.float32)), 'step': 77}
+    p2 = str(tmp_path / 'tf' / 'model.ckpt-77')
+    T.export_checkpoint(p2, layout, state)
+    names = T.read_bundle(p2)
+    assert 'Encoder/Conv2d-0/kernel' in names and 'Encoder/Conv2d-0/kernel/Adam_1' in names and int(names['global_step']) == 77
+    assert names['Generator/fully_connected/weights'].shape == tuple(lay['Generator/fully_connected/weights'])
+    back = T.import_checkpoint(p2, layout)
+    for k in ('params', 'm', 'v'):
+        assert torch.equal(back[k], state[k])
+    assert back['step'] == 77
+    # util.wrapper finds and reads it like one of its own checkpoints
+    from util.wrapper import find_ckpt, read_ckpt
+    assert find_ckpt(str(tmp_path / 'tf')) == p2
+    assert torch.equal(read_ckpt(p2, layout)['params'], state['params'])
+    # a checkpoint of another model is refused by name
+    del names['Encoder/dense/bias']
+    T.write_bundle(p2, names)
+    with pytest.raises(KeyError, match='lacks'):
+        T.import_checkpoint(p2, layout)

@@ -74,7 +74,7 @@ class VAETrainer(object):
         path = find_ckpt(restore_from, ckpt)
         if path is None:
             return None
-        self.opt['g'].load_state_dict(read_ckpt(path))
+        self.opt['g'].load_state_dict(read_ckpt(path, getattr(self.opt['g'].backend, 'layout', None)))
         return self.opt['g'].step_count
 
     def train(self, nIter, machine=None, summary_op=None, status_secs=60, save_secs=300, summary_secs=120):

@@ -173,8 +173,8 @@ def _read_varint(buf, pos):
         shift += 7
 
 
-def _parse(buf):
-    """protobuf message bytes -> {field: [values]} (wire types 0, 1, 2, 5)."""
+def _parse(buf, fixed32_int=False):
+    """protobuf message bytes -> {field: [values]} (wire types 0, 1, 2, 5; fixed32 as float unless fixed32_int)."""
     out, pos = {}, 0
     while pos < len(buf):
         k, pos = _read_varint(buf, pos)
@@ -185,7 +185,7 @@ def _parse(buf):
             v = struct.unpack_from('<d', buf, pos)[0]
             pos += 8
         elif wire == 5:
-            v = struct.unpack_from('<f', buf, pos)[0]
+            v = struct.unpack_from('<I' if fixed32_int else '<f', buf, pos)[0]
             pos += 4
         elif wire == 2:
             n, pos = _read_varint(buf, pos)

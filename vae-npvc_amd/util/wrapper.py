@@ -33,17 +33,23 @@ def find_ckpt(logdir, ckpt=None):
     if ckpt is None:
         if not os.path.isdir(logdir):
             return None
-        cands = [f for f in os.listdir(logdir) if re.match(r'model\.ckpt-\d+$', f)]
+        cands = sorted({re.sub(r'\.index$', '', f) for f in os.listdir(logdir) if re.match(r'model\.ckpt-\d+(\.index)?$', f)})
         if not cands:
             return None
         ckpt = max(cands, key=lambda f: int(f.rsplit('-', 1)[1]))
     path = os.path.join(logdir, ckpt)
-    return path if os.path.exists(path) else None
+    return path if (os.path.exists(path) or os.path.exists(path + '.index')) else None
 
 
-def read_ckpt(path):
+def read_ckpt(path, layout=None):
     """A checkpoint written by VAETrainer.save: {'params', 'm', 'v', 'step', 'layout'} (flat float32 buffers in
-    the tensor order of include/vaenpvc.h)."""
+    the tensor order of include/vaenpvc.h) -- or, when `<path>.index` exists, a TensorFlow V2 checkpoint of the
+    reference's graph (util/tf_checkpoint.py; needs the engine's `layout` to place the variables)."""
+    if not os.path.exists(path) and os.path.exists(path + '.index'):
+        from util.tf_checkpoint import import_checkpoint
+        if layout is None:
+            raise ValueError('a TensorFlow checkpoint needs the parameter layout')
+        return import_checkpoint(path, layout)
     return torch.load(path, map_location='cpu')
 
 
@@ -53,7 +59,7 @@ def load(engine, logdir, ckpt=None):
     path = find_ckpt(logdir, ckpt)
     if path is None:
         raise FileNotFoundError('no model.ckpt-N under %s' % logdir)
-    sd = read_ckpt(path)
+    sd = read_ckpt(path, getattr(engine, 'layout', None))
     engine.load_flat(sd['params'])
     m = re.search(r'-(\d+)$', path)
     return int(m.group(1)) if m else int(sd.get('step', 0))
