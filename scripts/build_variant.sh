@@ -1,13 +1,16 @@
 #!/bin/bash
-# usage: scripts/build_variant.sh NAME "-DVAENPVC_ABL=1 ..."   -> variants/NAME/libvaenpvc_hip.so
-# (kernel experiments: the layer file is rebuilt with extra flags and linked with the regular
-#  objects; select with VAENPVC_LIB=variants/NAME/libvaenpvc_hip.so)
+# Developer tool: build a variant library with extra -D flags into variants/<name>/libvaenpvc_hip.so
+# (select it with VAENPVC_LIB=variants/<name>/libvaenpvc_hip.so).  usage: scripts/build_variant.sh NAME "-DFOO=1 ..."
 set -e
 NAME=$1; FLAGS=$2
-cd "$(dirname "$0")/../vae-npvc_amd/csrc"
-make -s
-mkdir -p ../../variants/$NAME
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result $FLAGS -c gfx950_layers.hip -o ../../variants/$NAME/gfx950_layers.o
-OBJS=$(ls *.o | grep -v gfx950_layers.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/$NAME/libvaenpvc_hip.so $OBJS ../../variants/$NAME/gfx950_layers.o
-echo built variants/$NAME
+ROOT=$(cd $(dirname $0)/.. && pwd)
+OUT=$ROOT/variants/$NAME
+mkdir -p $OUT
+cd $ROOT/vae-npvc_amd/csrc
+for f in abi.hip runtime.hip generic_kernels.hip misc_kernels.hip gfx950_layers.hip; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $FLAGS -c $f -o $OUT/${f%.hip}.o &
+done
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -x hip -c model.cpp -o $OUT/model.o &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libvaenpvc_hip.so $OUT/*.o
+echo built $OUT/libvaenpvc_hip.so

@@ -401,6 +401,21 @@ def test_plane_gemm_dense_layers_against_oracle(F, seed, precision):
     assert not fails, '\n'.join(fails)
 
 
+VIEW_CONV = (0xebffffff, 0xebffffff)    # ... and bit 26: every conv site on the view GEMMs (csrc/gfx950_viewconv.h)
+
+
+@pytest.mark.parametrize('precision', ['bf16x2', 'bf16x3'])
+@pytest.mark.parametrize('F,seed', [(37, 5), (130, 9), (1, 7), (257, 12)])
+def test_view_conv_layers_against_oracle(F, seed, precision):
+    """Encoder layers 1-3 and decoder layers 0-2 (forward, input gradient, weight gradient) as GEMMs over the
+    overlapping-row view of channel-last bf16 planes (csrc/gfx950_viewconv.h) against the float64 oracle -- the
+    kernels of the bf16 training mode, run here with 2 / 3 operand planes so the fp32-class bars apply and pin the
+    indexing of every site (strided S-type, phase-stacked P-type, transposed weight-gradient epilogue)."""
+    eng = make_engine('vcc', 'auto', VIEW_CONV, precision=precision)
+    fails = compare_everything(eng, F, seed, '%s view-conv F%d ' % (precision, F))
+    assert not fails, '\n'.join(fails)
+
+
 def _golden_large(F, seed, precision, tag, tol_act=TOL_ACT, tol_grad=TOL_GRAD):
     """Default (auto) path at a benchmarked batch size against the committed chunked-float64 oracle fixture
     (tests/golden/make_golden_large.py): losses, z_mu / z_lv / xh rows of 16 sampled frames, and per tensor the

@@ -89,7 +89,7 @@ static int resolve(vaenpvc_ctx* c, int64_t F, int mode, void* d_ws, size_t ws_by
     else if (n == "d_z_lv") w->d_z_lv = p;
     else if (n == "dy_tmp") w->dy_tmp = p;
     else if (n == "toep_gp") w->toep_gp = p;
-    else if (n == "cl_y2") w->cl_y2 = p;
+    else if (n.rfind("cl", 0) == 0) w->cl[idx(2)] = p;
     else if (n == "pl_y3") w->pl_y3 = p;
     else if (n == "pl_y4") w->pl_y4 = p;
     else if (n == "pl_z") w->pl_z = p;

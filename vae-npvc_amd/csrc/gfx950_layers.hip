@@ -22,6 +22,7 @@
 #include "gfx950_toeplitz.h"
 #include "gfx950_toep_bf16.h"
 #include "gfx950_planegemm.h"
+#include "gfx950_viewconv.h"
 #include "kernels.h"
 
 namespace vaenpvc {
@@ -180,8 +181,8 @@ struct Pk {
   static constexpr int pg_enc4f = pg_mergeb + 3 * 128 * 1600 / 2;   // [768][896]
   static constexpr int pg_enc4b = pg_enc4f + 3 * 768 * 896 / 2;     // [896][768]
   static constexpr int pg_bias4 = pg_enc4b + 3 * 896 * 768 / 2;     // bias of layer 4 per dense column (o, j)
-  static constexpr int pg_e3f = pg_bias4 + 768;                     // encoder layer 3 forward: [128][7*64]
-  static constexpr int total = pg_e3f + 3 * 128 * 448 / 2;
+  static constexpr int cvw = pg_bias4 + 768;                        // weight planes of the conv view-GEMM sites
+  static constexpr int total = cvw + CV_WTOTAL;
 };
 static_assert(Pk::total <= 8 * 939162 + 65536, "packed weights must fit the scratch region");
 // the dense-shaped layers (heads, merge, encoder layer 4) on the plane GEMM kernels: bit 29 of the masks, and enough
@@ -194,6 +195,11 @@ static inline bool pg_fwd(int64_t F) { return pg_on(rt().fwd_mask, F); }
 static inline bool cg_fwd(int64_t F) { return ((rt().fwd_mask >> 27) & 1u) && pg_on(rt().fwd_mask | (1u << 29), F); }
 static inline bool cg_bwd(int64_t F) { return ((rt().bwd_mask >> 27) & 1u) && pg_on(rt().bwd_mask | (1u << 29), F); }
 static inline bool pg_bwd(int64_t F) { return pg_on(rt().bwd_mask, F); }
+// ... per site: the context's site set (runtime.h: cv_sites), or every site when bit 26 of the mask is cleared
+static inline bool cv_sel(unsigned mask, int site) { return !((mask >> 26) & 1u) || ((rt().cv_sites() >> site) & 1u); }
+static inline bool cv_fwd(int site, int64_t F) { return cg_fwd(F) && cv_sel(rt().fwd_mask, site); }
+static inline bool cv_bwd(int site, int64_t F) { return cg_bwd(F) && cv_sel(rt().bwd_mask, site); }
+static inline bool cw_bwd(int site, int64_t F) { return cg_bwd(F) && cv_sel(rt().bwd_mask, CV_COUNT + site); }
 static inline unsigned short* us(float* p) { return reinterpret_cast<unsigned short*>(p); }
 static NtArgs nt_args(const float* Ap, int M, int Kp, const float* Bp, int Np, int N, float* C, int ldc) {
   NtArgs a;
@@ -216,6 +222,8 @@ static TnpArgs tnp_args(const float* Ap, int lda, const float* Bp, int ldb, int 
   a.B = reinterpret_cast<const unsigned short*>(Bp);
   a.a_plane = (int64_t)F * lda;
   a.b_plane = (int64_t)F * ldb;
+  a.av = plain_rows(lda);
+  a.bv = plain_rows(ldb);
   a.lda = lda;
   a.ldb = ldb;
   a.M = M;
@@ -320,8 +328,17 @@ static void prep(const Model& m, const float* P, const Ws& w, hipStream_t s) {
       planes_job<NPD>(WMergeB{P + m.wz_off, 1539}, S + Pk::pg_mergeb, 128, 1600),
       planes_job<NPD>(WEnc4F{P + m.enc[4].w_off}, S + Pk::pg_enc4f, 768, 896),
       planes_job<NPD>(WEnc4B{P + m.enc[4].w_off}, S + Pk::pg_enc4b, 896, 768),
-      planes_job<NPD>(WConvF{P + m.enc[3].w_off, 7, 64, 64, 128}, S + Pk::pg_e3f, 128, 448),
       pack_job(PackRepeat3{P + m.enc[4].b_off}, S + Pk::pg_bias4, 768));
+  // weight planes of the conv view-GEMM sites.  TF layouts: conv [T][Cin][Cout], conv_transpose [T][Cout][Cin];
+  // (s_t, s_o, s_c) = strides of (tap, GEMM output channel, contracted channel)
+  if (cg_fwd(0x7fffffff) || cg_bwd(0x7fffffff)) {
+    auto ef = [&](int site, int i) { const ConvL& l = m.enc[i]; return cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, 1, l.cout, S + Pk::cvw + cv_woff(site)); };
+    auto eg = [&](int site, int i) { const ConvL& l = m.enc[i]; return cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, l.cout, 1, S + Pk::cvw + cv_woff(site)); };
+    auto df = [&](int site, int i) { const ConvL& l = m.dec[i]; return cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, l.cin, 1, S + Pk::cvw + cv_woff(site)); };
+    auto dg = [&](int site, int i) { const ConvL& l = m.dec[i]; return cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, 1, l.cin, S + Pk::cvw + cv_woff(site)); };
+    launch_pack_multi(s, ef(CV_E1F, 1), ef(CV_E2F, 2), ef(CV_E3F, 3), df(CV_D0F, 0), df(CV_D1F, 1), df(CV_D2F, 2),
+                      eg(CV_E3G, 3), eg(CV_E2G, 2), eg(CV_E1G, 1), dg(CV_D0G, 0), dg(CV_D1G, 1), dg(CV_D2G, 2));
+  }
   });
   });
 }
@@ -397,38 +414,28 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
   }
   auto lnp = [&](int i) { return conv_args(w.enc_a[i - 1], w.enc_st[i - 1], P + m.enc[i - 1].gamma_off, P + m.enc[i - 1].beta_off,
                                            P + m.enc[i].w_off, P + m.enc[i].b_off, w.enc_a[i], F); };
+  // a conv site as a GEMM over the overlapping-row view of channel-last planes (gfx950_viewconv.h): producer of the
+  // activated input planes (LayerNorm + lrelu of layer i - 1), then the GEMM
+  auto enc_view = [&](int site, int cl, int i, const char* tsplit, const char* tgemm) {
+    for_dense_planes([&](auto npl) {
+      constexpr int NPL = decltype(npl)::value;
+      VAENPVC_TIMED(tsplit, s, cv_split<NPL>(cl, w.enc_a[i - 1], w.enc_st[i - 1], P + m.enc[i - 1].gamma_off, P + m.enc[i - 1].beta_off,
+                                             w.cl[cl], F, s));
+      VAENPVC_TIMED(tgemm, s, cv_gemm<NPL>(site, w.scratch + Pk::cvw + cv_woff(site), w.cl[cl], w.enc_a[i], P + m.enc[i].b_off, F, s));
+    });
+  };
   if (fwd_on(1)) {
-    VAENPVC_TIMED("enc1_fwd", s, launch_convgemm<E1F>(lnp(1), nsplit_for<E1F>(F), s));
+    if (cv_fwd(CV_E1F, F)) enc_view(CV_E1F, CL_Y0, 1, "enc1_split", "enc1_fwd");
+    else VAENPVC_TIMED("enc1_fwd", s, launch_convgemm<E1F>(lnp(1), nsplit_for<E1F>(F), s));
     stats<1824>(w.enc_a[1], w.enc_st[1], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 1);
   if (fwd_on(2)) {
-    VAENPVC_TIMED("enc2_fwd", s, launch_convgemm<E2F>(lnp(2), nsplit_for<E2F>(F), s));
+    if (cv_fwd(CV_E2F, F)) enc_view(CV_E2F, CL_Y1, 2, "enc2_split", "enc2_fwd");
+    else VAENPVC_TIMED("enc2_fwd", s, launch_convgemm<E2F>(lnp(2), nsplit_for<E2F>(F), s));
     stats<1216>(w.enc_a[2], w.enc_st[2], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 2);
-  if (fwd_on(3) && cg_fwd(F)) {
-    // conv k7 s3 as a GEMM over the overlapping-row view of the channel-last planes of y2 (gfx950_planegemm.h)
-    for_dense_planes([&](auto npl) {
-      constexpr int NPL = decltype(npl)::value;
-      ClArgs ca{w.enc_a[2], w.enc_st[2], P + m.enc[2].gamma_off, P + m.enc[2].beta_off, 64, 19, 64, 3, 25, F, us(w.cl_y2)};
-      VAENPVC_TIMED("enc3_split", s, launch_split_cl<NPL>(ca, s));
-      CgArgs a;
-      memset(&a, 0, sizeof a);
-      a.W = reinterpret_cast<const unsigned short*>(w.scratch + Pk::pg_e3f);
-      a.X = reinterpret_cast<const unsigned short*>(w.cl_y2);
-      a.w_plane = 128 * 448;
-      a.x_plane = (int64_t)F * 25 * 64;
-      a.xv = RowView{7, 25 * 64, 0, 3 * 64};
-      a.Kp = 448;
-      a.M = 128;
-      a.N = F * 7;
-      a.out = w.enc_a[3];
-      a.ofs = 128 * 7;
-      a.om = 7;
-      a.oq = 1;
-      a.OH = 7;
-      a.bias = P + m.enc[3].b_off;
-      VAENPVC_TIMED("enc3_fwd", s, launch_cgemm<NPL>(a, 1, s));
-    });
+  if (fwd_on(3) && cv_fwd(CV_E3F, F)) {
+    enc_view(CV_E3F, CL_Y2, 3, "enc3_split", "enc3_fwd");
     stats_planes<896, 7>(w.enc_a[3], w.enc_st[3], P + m.enc[3].gamma_off, P + m.enc[3].beta_off, w.pl_y3,
                          fwd_on(4) && pg_fwd(F), F, s);
   } else if (fwd_on(3)) {
@@ -511,19 +518,35 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     a.nrb = MERGE_NY;
     VAENPVC_TIMED("merge_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<MergeFs>(a, s) : launch_densegemm<MergeF>(a, s)));
   } else generic::merge_fwd(m, P, z, y, F, w, s);
-  if (fwd_on(7)) {
+  auto dec_view = [&](int site, int cl, int i, const float* src, const char* tsplit, const char* tgemm) {
+    for_dense_planes([&](auto npl) {
+      constexpr int NPL = decltype(npl)::value;
+      if (i == 0) VAENPVC_TIMED(tsplit, s, cv_split<NPL>(cl, src, nullptr, nullptr, nullptr, w.cl[cl], F, s));
+      else VAENPVC_TIMED(tsplit, s, cv_split<NPL>(cl, src, w.dec_st[i - 1], P + m.dec[i - 1].gamma_off, P + m.dec[i - 1].beta_off, w.cl[cl], F, s));
+      VAENPVC_TIMED(tgemm, s, cv_gemm<NPL>(site, w.scratch + Pk::cvw + cv_woff(site), w.cl[cl], w.dec_a[i], P + m.dec[i].b_off, F, s));
+    });
+  };
+  if (fwd_on(7) && cv_fwd(CV_D0F, F)) {
+    dec_view(CV_D0F, CL_H, 0, w.h, "dec0_split", "dec0_fwd");
+    stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
+  } else if (fwd_on(7)) {
     VAENPVC_TIMED("dec0_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<D0Fs>(conv_args(w.h, nullptr, nullptr, nullptr, w.scratch + Pk::d0f,
                                                                 P + m.dec[0].b_off, w.dec_a[0], F), nsplit_for<D0Fs>(F), s) : launch_convgemm<D0F>(conv_args(w.h, nullptr, nullptr, nullptr, w.scratch + Pk::d0f,
                                                                 P + m.dec[0].b_off, w.dec_a[0], F), nsplit_for<D0F>(F), s)));
     stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 0);
-  if (fwd_on(8)) {
+  if (fwd_on(8) && cv_fwd(CV_D1F, F)) {
+    dec_view(CV_D1F, CL_YD0, 1, w.dec_a[0], "dec1_split", "dec1_fwd");
+    stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
+  } else if (fwd_on(8)) {
     VAENPVC_TIMED("dec1_fwd", s, launch_convgemm<D1F>(conv_args(w.dec_a[0], w.dec_st[0], P + m.dec[0].gamma_off,
                                                                 P + m.dec[0].beta_off, w.scratch + Pk::d1f,
                                                                 P + m.dec[1].b_off, w.dec_a[1], F), nsplit_for<D1F>(F), s));
     stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 1);
   if (fwd_on(9)) {
+    if (cv_fwd(CV_D2F, F)) dec_view(CV_D2F, CL_YD1, 2, w.dec_a[1], "dec2_split", "dec2_fwd");
+    else
     VAENPVC_TIMED("dec2_fwd", s, launch_convgemm<D2F>(conv_args(w.dec_a[1], w.dec_st[1], P + m.dec[1].gamma_off,
                                                                 P + m.dec[1].beta_off, w.scratch + Pk::d2f,
                                                                 P + m.dec[2].b_off, w.dec_a[2], F), nsplit_for<D2F>(F), s));
@@ -629,6 +652,29 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
                           // more chunks only deepen the same-address atomic chains on the small weight tensors
   const int LWGS = 2048;  // ... of the HBM-bound LayerNorm backward
 
+  // ---- conv layers on the view GEMMs (gfx950_viewconv.h): producers / consumers of the channel-last planes
+  auto gsplit = [&](int cl, const float* src, const char* tag) {   // gradient tensor -> planes
+    for_dense_planes([&](auto npl) {
+      VAENPVC_TIMED(tag, s, cv_split<decltype(npl)::value>(cl, src, nullptr, nullptr, nullptr, w.cl[cl], F, s));
+    });
+  };
+  auto asplit = [&](int cl, const float* src, const float* st, const ConvL* ln, const char* tag) {   // activation the forward pass did not leave
+    for_dense_planes([&](auto npl) {
+      VAENPVC_TIMED(tag, s, cv_split<decltype(npl)::value>(cl, src, st, ln ? P + ln->gamma_off : nullptr, ln ? P + ln->beta_off : nullptr,
+                                                           w.cl[cl], F, s));
+    });
+  };
+  auto vwgrad = [&](int wsite, float* dW, const char* tag) {
+    for_dense_planes([&](auto npl) {
+      VAENPVC_TIMED(tag, s2, cv_wgrad<decltype(npl)::value>(wsite, w.cl[CWS[wsite].a], w.cl[CWS[wsite].b], dW, F, 512, s2));
+    });
+  };
+  auto vdgrad = [&](int site, float* out, const char* tag) {
+    for_dense_planes([&](auto npl) {
+      VAENPVC_TIMED(tag, s, cv_gemm<decltype(npl)::value>(site, w.scratch + Pk::cvw + cv_woff(site), w.cl[CVS[site].x], out, nullptr, F, s));
+    });
+  };
+
   // ---- d3: the 1025-tap layer
   if (bwd_on(10)) {
     const ConvL& l2 = m.dec[2];
@@ -692,9 +738,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const ConvL &l = m.dec[2], &pl = m.dec[1];
     WgArgs a{w.d_dec_a[2], nullptr, nullptr, nullptr, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off,
              G + l.w_off, F, 0};
+    const bool vg = cv_bwd(CV_D2G, F), vw = cw_bwd(CW_D2, F);
+    if (vg || vw) gsplit(CL_GD2, w.d_dec_a[2], "dec2_gsplit");
+    if (vw && !(fwd_on(9) && cv_fwd(CV_D2F, F))) asplit(CL_YD1, w.dec_a[1], w.dec_st[1], &pl, "dec2_asplit");
     ready();
-    VAENPVC_TIMED("dec2_wgrad", s2, launch_convwgrad<WD2>(a, WGS, s2));
+    if (vw) vwgrad(CW_D2, G + l.w_off, "dec2_wgrad");
+    else VAENPVC_TIMED("dec2_wgrad", s2, launch_convwgrad<WD2>(a, WGS, s2));
     if (!dec_bias_done[2]) generic::bias_grad(w.d_dec_a[2], G + l.b_off, F, l.cout, l.hout, s);
+    if (vg) vdgrad(CV_D2G, w.dy_tmp, "dec2_dgrad");
+    else
     VAENPVC_TIMED("dec2_dgrad", s, launch_convgemm<GD2>(conv_args(w.d_dec_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::gd2,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GD2>(F), s));
     launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[1],
@@ -707,9 +759,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const ConvL &l = m.dec[1], &pl = m.dec[0];
     WgArgs a{w.d_dec_a[1], nullptr, nullptr, nullptr, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off,
              G + l.w_off, F, 0};
+    const bool vg = cv_bwd(CV_D1G, F), vw = cw_bwd(CW_D1, F);
+    if (vg || vw) gsplit(CL_GD1, w.d_dec_a[1], "dec1_gsplit");
+    if (vw && !(fwd_on(8) && cv_fwd(CV_D1F, F))) asplit(CL_YD0, w.dec_a[0], w.dec_st[0], &pl, "dec1_asplit");
     ready();
-    VAENPVC_TIMED("dec1_wgrad", s2, launch_convwgrad<WD1>(a, WGS, s2));
+    if (vw) vwgrad(CW_D1, G + l.w_off, "dec1_wgrad");
+    else VAENPVC_TIMED("dec1_wgrad", s2, launch_convwgrad<WD1>(a, WGS, s2));
     if (!dec_bias_done[1]) generic::bias_grad(w.d_dec_a[1], G + l.b_off, F, l.cout, l.hout, s);
+    if (vg) vdgrad(CV_D1G, w.dy_tmp, "dec1_dgrad");
+    else
     VAENPVC_TIMED("dec1_dgrad", s, launch_convgemm<GD1>(conv_args(w.d_dec_a[1], nullptr, nullptr, nullptr, P + l.w_off, nullptr,
                                                                   w.dy_tmp, F), nsplit_for<GD1>(F), s));
     launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[0],
@@ -721,9 +779,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   if (bwd_on(7)) {
     const ConvL& l = m.dec[0];
     WgArgs a{w.d_dec_a[0], nullptr, nullptr, nullptr, w.h, nullptr, nullptr, nullptr, G + l.w_off, F, 0};
+    const bool vg = cv_bwd(CV_D0G, F), vw = cw_bwd(CW_D0, F);
+    if (vg || vw) gsplit(CL_GD0, w.d_dec_a[0], "dec0_gsplit");
+    if (vw && !(fwd_on(7) && cv_fwd(CV_D0F, F))) asplit(CL_H, w.h, nullptr, nullptr, "dec0_asplit");
     ready();
-    VAENPVC_TIMED("dec0_wgrad", s2, launch_convwgrad<WD0>(a, WGS, s2));
+    if (vw) vwgrad(CW_D0, G + l.w_off, "dec0_wgrad");
+    else VAENPVC_TIMED("dec0_wgrad", s2, launch_convwgrad<WD0>(a, WGS, s2));
     if (!dec_bias_done[0]) generic::bias_grad(w.d_dec_a[0], G + l.b_off, F, l.cout, l.hout, s);
+    if (vg) vdgrad(CV_D0G, w.d_h, "dec0_dgrad");
+    else
     VAENPVC_TIMED("dec0_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<GD0s>(conv_args(w.d_dec_a[0], nullptr, nullptr, nullptr, w.scratch + Pk::gd0,
                                                                   nullptr, w.d_h, F), nsplit_for<GD0s>(F), s) : launch_convgemm<GD0>(conv_args(w.d_dec_a[0], nullptr, nullptr, nullptr, w.scratch + Pk::gd0,
                                                                   nullptr, w.d_h, F), nsplit_for<GD0>(F), s)));
@@ -856,9 +920,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 4);
   if (bwd_on(3)) {
     const ConvL &l = m.enc[3], &pl = m.enc[2];
+    const bool vg = cv_bwd(CV_E3G, F), vw = cw_bwd(CW_E3, F);
+    if (vg || vw) gsplit(CL_GE3, w.d_enc_a[3], "enc3_gsplit");
+    if (vw && !(fwd_on(3) && cv_fwd(CV_E3F, F))) asplit(CL_Y2, w.enc_a[2], w.enc_st[2], &pl, "enc3_asplit");
     ready();
-    VAENPVC_TIMED("enc3_wgrad", s2, launch_convwgrad<WE3>(wg_enc(3), WGS, s2));
+    if (vw) vwgrad(CW_E3, G + l.w_off, "enc3_wgrad");
+    else VAENPVC_TIMED("enc3_wgrad", s2, launch_convwgrad<WE3>(wg_enc(3), WGS, s2));
     if (!enc_bias_done[3]) generic::bias_grad(w.d_enc_a[3], G + l.b_off, F, l.cout, l.hout, s);
+    if (vg) vdgrad(CV_E3G, w.dy_tmp, "enc3_dgrad");
+    else
     VAENPVC_TIMED("enc3_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<GE3s>(conv_args(w.d_enc_a[3], nullptr, nullptr, nullptr, w.scratch + Pk::ge3,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE3s>(F), s) : launch_convgemm<GE3>(conv_args(w.d_enc_a[3], nullptr, nullptr, nullptr, w.scratch + Pk::ge3,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE3>(F), s)));
@@ -868,9 +938,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 3);
   if (bwd_on(2)) {
     const ConvL &l = m.enc[2], &pl = m.enc[1];
+    const bool vg = cv_bwd(CV_E2G, F), vw = cw_bwd(CW_E2, F);
+    if (vg || vw) gsplit(CL_GE2, w.d_enc_a[2], "enc2_gsplit");
+    if (vw && !(fwd_on(2) && cv_fwd(CV_E2F, F))) asplit(CL_Y1, w.enc_a[1], w.enc_st[1], &pl, "enc2_asplit");
     ready();
-    VAENPVC_TIMED("enc2_wgrad", s2, launch_convwgrad<WE2>(wg_enc(2), WGS, s2));
+    if (vw) vwgrad(CW_E2, G + l.w_off, "enc2_wgrad");
+    else VAENPVC_TIMED("enc2_wgrad", s2, launch_convwgrad<WE2>(wg_enc(2), WGS, s2));
     if (!enc_bias_done[2]) generic::bias_grad(w.d_enc_a[2], G + l.b_off, F, l.cout, l.hout, s);
+    if (vg) vdgrad(CV_E2G, w.dy_tmp, "enc2_dgrad");
+    else
     VAENPVC_TIMED("enc2_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<GE2s>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE2s>(F), s) : launch_convgemm<GE2>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE2>(F), s)));
@@ -880,9 +956,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 2);
   if (bwd_on(1)) {
     const ConvL &l = m.enc[1], &pl = m.enc[0];
+    const bool vg = cv_bwd(CV_E1G, F), vw = cw_bwd(CW_E1, F);
+    if (vg || vw) gsplit(CL_GE1, w.d_enc_a[1], "enc1_gsplit");
+    if (vw && !(fwd_on(1) && cv_fwd(CV_E1F, F))) asplit(CL_Y0, w.enc_a[0], w.enc_st[0], &pl, "enc1_asplit");
     ready();
-    VAENPVC_TIMED("enc1_wgrad", s2, launch_convwgrad<WE1>(wg_enc(1), WGS, s2));
+    if (vw) vwgrad(CW_E1, G + l.w_off, "enc1_wgrad");
+    else VAENPVC_TIMED("enc1_wgrad", s2, launch_convwgrad<WE1>(wg_enc(1), WGS, s2));
     if (!enc_bias_done[1]) generic::bias_grad(w.d_enc_a[1], G + l.b_off, F, l.cout, l.hout, s);
+    if (vg) vdgrad(CV_E1G, w.dy_tmp, "enc1_dgrad");
+    else
     VAENPVC_TIMED("enc1_dgrad", s, launch_convgemm<GE1>(conv_args(w.d_enc_a[1], nullptr, nullptr, nullptr, w.scratch + Pk::ge1,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE1>(F), s));
     launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.enc_a[0], w.enc_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[0],

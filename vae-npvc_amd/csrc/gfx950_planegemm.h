@@ -25,6 +25,17 @@ namespace tuned {
 
 constexpr int PG_KA = 64;  // K granule of every plane tensor
 
+// row r of a plane tensor: element offset (r / R) * fs + x0 + (r % R) * step.  Plain matrices: R = INT_MAX, step = leading
+// dimension; channel-last conv tensors: R rows per frame, fs elements per frame, rows may overlap (see k_cgemm below)
+struct RowView {
+  int R, fs, x0, step;
+};
+__device__ __forceinline__ int64_t view_off(const RowView& v, int r) {
+  const int f = r / v.R, q = r - f * v.R;
+  return (int64_t)f * v.fs + v.x0 + q * v.step;
+}
+static inline RowView plain_rows(int ld) { return RowView{0x7fffffff, 0, 0, ld}; }
+
 // ---------------------------------------------------------------- producers
 struct SplitArgs {
   const float* src;    // [rows][ld1], columns [0, k1)
@@ -257,11 +268,17 @@ struct NtArgs {
 constexpr int NT_BM = 128, NT_BN = 128;
 // K chunk: 64 with up to two planes, 32 with three (LDS and prefetch registers stay at two workgroups per CU; the
 // MFMAs between two barriers are the same 48 per wave either way)
-constexpr int nt_bk(int npl) { return npl >= 3 ? 32 : 64; }
+#ifndef VAENPVC_NT_BK2
+#define VAENPVC_NT_BK2 64
+#endif
+constexpr int nt_bk(int npl) { return npl >= 3 ? 32 : VAENPVC_NT_BK2; }
 constexpr int nt_lds(int npl) { return npl * (NT_BM + NT_BN) * (nt_bk(npl) * 2 + 16); }  // 73 728 (2 planes) / 61 440 (3)
 
+#ifndef VAENPVC_NT_WPS
+#define VAENPVC_NT_WPS 2
+#endif
 template <int NPL>
-__global__ void __launch_bounds__(256, 2) k_gemm_nt(NtArgs a) {
+__global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT_BK = nt_bk(NPL), NT_RS = NT_BK * 2 + 16, NQ = NT_BK / 16;   // NQ: 16-byte pieces per thread, plane, operand
   constexpr int APL = NT_BM * NT_RS, BPL = NT_BN * NT_RS;
@@ -385,34 +402,43 @@ inline void launch_gemm_nt(const NtArgs& a, hipStream_t s) {
 // Both operands are frame-major planes; a row-major [16 frames][columns] LDS tile feeds the MFMA through
 // ds_read_b64_tr_b16 (gfx950_toep_bf16.h: k_toep_wgrad_bf16 is the same machine with a diagonal epilogue).
 // Partial sums over frame chunks are combined with fp32 global atomics.
-enum { TN_EPI_PLAIN = 0, TN_EPI_ENC4 = 1 };
+enum { TN_EPI_PLAIN = 0, TN_EPI_ENC4 = 1, TN_EPI_TRANS = 2 };
 struct TnpArgs {
-  const unsigned short* A;  // planes [NPL][F][lda]
-  const unsigned short* B;  // planes [NPL][F][ldb]
+  const unsigned short* A;  // planes; row r (the reduction index) of A at view_off(av, r), M columns from there
+  const unsigned short* B;  // planes; row r of B at view_off(bv, r), N columns
   int64_t a_plane, b_plane;
-  int lda, ldb;
-  int M, N, F, fchunk;
-  float* C;   // PLAIN: C[m*ldc + n] (n < split) ; ENC4: the TF kernel tensor [7][128][256]
+  RowView av, bv;
+  int lda, ldb;   // readable elements per row (loads are clamped to the row: ragged last column tile)
+  int M, N, F, fchunk;   // F = number of reduction rows
+  float* C;   // PLAIN: C[m*ldc + n] (n < split) ; ENC4: the TF kernel tensor [7][128][256] ; TRANS: C[n*ldc + m]
   float* C2;  // PLAIN: columns n >= split at n - split
   int split, ldc;
 };
 constexpr int TP_KF = 16;
-constexpr int TP_RSA = 128 * 2 + 64, TP_RSB = 256 * 2 + 64;   // LDS row strides (bytes): see WG_RSA / WG_RSB
-constexpr int TP_APL = TP_KF * TP_RSA, TP_BPL = TP_KF * TP_RSB;
-constexpr int tp_buf(int npl) { return npl * (TP_APL + TP_BPL); }
-constexpr int tp_lds(int npl) { return 2 * tp_buf(npl); }
+// Tile: 8 waves as 2 x 4, a wave owns TI x TJ MFMA tiles: <2,2> = 128 x 256 (the dense layers), <1,2> = 64 x 256,
+// <1,1> = 64 x 128 (thin conv layers).  LDS row strides padded by 64 bytes (see WG_RSA / WG_RSB).
+template <int NPL, int TI, int TJ>
+struct TnTile {
+  static constexpr int BM = 64 * TI, BN = 128 * TJ;
+  static constexpr int RSA = BM * 2 + 64, RSB = BN * 2 + 64;
+  static constexpr int APL = TP_KF * RSA, BPL = TP_KF * RSB;
+  static constexpr int BUF = NPL * (APL + BPL), LDS = 2 * BUF;
+  static constexpr int APC = BM / 8, BPC = BN / 8;   // 16-byte pieces per row
+};
 
-template <int NPL, int EPI>
+template <int NPL, int EPI, int TI = 2, int TJ = 2>
 __global__ void __launch_bounds__(512, 2) k_gemm_tn(TnpArgs a) {
+  using T = TnTile<NPL, TI, TJ>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int BUF = tp_buf(NPL);
+  constexpr int BUF = T::BUF;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lh = lane >> 5, l31 = lane & 31;
   const int wr = wave >> 2, wc = wave & 3;
-  const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 256;
+  const int m0 = blockIdx.x * T::BM, n0 = blockIdx.y * T::BN;
   const int fb = blockIdx.z * a.fchunk, fe = min(a.F, fb + a.fchunk);
-  // staging of one 16-frame chunk: A 16 rows x 16 pieces (threads < 256), B 16 rows x 32 pieces (all threads)
-  const int arow = (tid >> 4) & 15, apc = tid & 15;
-  const int brow = tid >> 5, bpc = tid & 31;
+  // staging of one 16-row chunk: A 16 rows x APC pieces, B 16 rows x BPC pieces (the first 16*APC / 16*BPC threads)
+  const bool a_thr = tid < TP_KF * T::APC, b_thr = tid < TP_KF * T::BPC;
+  const int arow = (tid / T::APC) & 15, apc = tid % T::APC;
+  const int brow = (tid / T::BPC) & 15, bpc = tid % T::BPC;
   // pieces past the row end (last column tile of a ragged N) are clamped to the row's last piece: finite data, masked
   // in the epilogue
   const int acol = cmin_(m0 * 2 + apc * 16, a.lda * 2 - 16);
@@ -424,55 +450,61 @@ __global__ void __launch_bounds__(512, 2) k_gemm_tn(TnpArgs a) {
     int fa_ = f0 + arow, fb_ = f0 + brow;
     fa_ = fa_ < a.F ? fa_ : a.F - 1;
     fb_ = fb_ < a.F ? fb_ : a.F - 1;
-    if (tid < 256) {
+    if (a_thr) {
+      const size_t ra = (size_t)view_off(a.av, fa_);
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) sta[p] = *reinterpret_cast<const u32x4*>(A8 + ((size_t)p * a.a_plane + (size_t)fa_ * a.lda) * 2 + acol);
+      for (int p = 0; p < NPL; ++p) sta[p] = *reinterpret_cast<const u32x4*>(A8 + ((size_t)p * a.a_plane + ra) * 2 + acol);
     }
+    if (b_thr) {
+      const size_t rb = (size_t)view_off(a.bv, fb_);
 #pragma unroll
-    for (int p = 0; p < NPL; ++p) stb[p] = *reinterpret_cast<const u32x4*>(B8 + ((size_t)p * a.b_plane + (size_t)fb_ * a.ldb) * 2 + bcol);
+      for (int p = 0; p < NPL; ++p) stb[p] = *reinterpret_cast<const u32x4*>(B8 + ((size_t)p * a.b_plane + rb) * 2 + bcol);
+    }
   };
   auto lstore = [&](int f0, int buf) __attribute__((always_inline)) {
     unsigned char* sA = smem + buf * BUF;
-    unsigned char* sB = sA + NPL * TP_APL;
+    unsigned char* sB = sA + NPL * T::APL;
     const u32x4 z = {0u, 0u, 0u, 0u};
-    const bool tail = f0 + TP_KF > fe;  // uniform: frames past the chunk contribute zero (A rows zeroed)
-    if (tid < 256) {
+    const bool tail = f0 + TP_KF > fe;  // uniform: rows past the chunk contribute zero (A rows zeroed)
+    if (a_thr) {
 #pragma unroll
       for (int p = 0; p < NPL; ++p)
-        *reinterpret_cast<u32x4*>(sA + p * TP_APL + arow * TP_RSA + apc * 16) = (tail && f0 + arow >= fe) ? z : sta[p];
+        *reinterpret_cast<u32x4*>(sA + p * T::APL + arow * T::RSA + apc * 16) = (tail && f0 + arow >= fe) ? z : sta[p];
     }
+    if (b_thr) {
 #pragma unroll
-    for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(sB + p * TP_BPL + brow * TP_RSB + bpc * 16) = stb[p];
+      for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(sB + p * T::BPL + brow * T::RSB + bpc * 16) = stb[p];
+    }
   };
-  // fragment addresses (transpose reads): lane -> (frame row (l&15)>>2 (+8*lh), column quad 4*(l&3) + 16*((l>>4)&1))
+  // fragment addresses (transpose reads): lane -> (row (l&15)>>2 (+8*lh), column quad 4*(l&3) + 16*((l>>4)&1))
   const int trow = ((lane & 15) >> 2) + 8 * lh, tcol = 4 * (lane & 3) + 16 * ((lane >> 4) & 1);
-  const int aoff = trow * TP_RSA + (64 * wr + tcol) * 2;
-  const int boff = NPL * TP_APL + trow * TP_RSB + (64 * wc + tcol) * 2;
-  f32x16 acc[2][2];
+  const int aoff = trow * T::RSA + (32 * TI * wr + tcol) * 2;
+  const int boff = NPL * T::APL + trow * T::RSB + (32 * TJ * wc + tcol) * 2;
+  f32x16 acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
-  u32x4 fa[2][NPL], fbq[2][NPL];
+    for (int j = 0; j < TJ; ++j) acc[i][j] = zero16();
+  u32x4 fa[TI][NPL], fbq[TJ][NPL];
   auto loadF = [&](int buf) __attribute__((always_inline)) {
     const unsigned char* sb = smem + buf * BUF;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) fa[i][p] = tr_read8(sb + p * TP_APL + aoff + i * 64, 4 * TP_RSA);
+      for (int p = 0; p < NPL; ++p) fa[i][p] = tr_read8(sb + p * T::APL + aoff + i * 64, 4 * T::RSA);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) fbq[j][p] = tr_read8(sb + p * TP_BPL + boff + j * 64, 4 * TP_RSB);
+      for (int p = 0; p < NPL; ++p) fbq[j][p] = tr_read8(sb + p * T::BPL + boff + j * 64, 4 * T::RSB);
   };
   auto mm = [&]() __attribute__((always_inline)) {
     using PR = Prod<NPL>;
 #pragma unroll
     for (int t = 0; t < PR::N; ++t)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[i][PR::A[t]], fbq[j][PR::B[t]], acc[i][j]);
+        for (int j = 0; j < TJ; ++j) acc[i][j] = mfma_bf16(fa[i][PR::A[t]], fbq[j][PR::B[t]], acc[i][j]);
   };
   if (fb < fe) {
     gload(fb);
@@ -491,19 +523,21 @@ __global__ void __launch_bounds__(512, 2) k_gemm_tn(TnpArgs a) {
     if (more) lstore(f0 + TP_KF, (nq + 1) & 1);
     __syncthreads();
   }
-  // epilogue: acc[i][j][reg] = C[m0 + 64 wr + 32 i + acc_row(reg)][n0 + 64 wc + 32 j + l31]
+  // epilogue: acc[i][j][reg] = C[m0 + 32 TI wr + 32 i + acc_row(reg)][n0 + 32 TJ wc + 32 j + l31]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + 64 * wc + 32 * j + l31;
+    for (int j = 0; j < TJ; ++j) {
+      const int n = n0 + 32 * TJ * wc + 32 * j + l31;
       if (n >= a.N) continue;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const int m = m0 + 64 * wr + 32 * i + acc_row(reg, lane);
+        const int m = m0 + 32 * TI * wr + 32 * i + acc_row(reg, lane);
         if (m >= a.M) continue;
         const float v = acc[i][j][reg];
-        if constexpr (EPI == TN_EPI_ENC4) {
+        if constexpr (EPI == TN_EPI_TRANS) {
+          atomicAdd(a.C + (int64_t)n * a.ldc + m, v);
+        } else if constexpr (EPI == TN_EPI_ENC4) {
           // m = (c, h) = c*7 + h, n = (o, j3) = o*3 + j3: dW[t][c][o] with t = h - 3*j3 + 3
           const int c = m / 7, h = m - 7 * c, o = n / 3, j3 = n - 3 * o, t = h - 3 * j3 + 3;
           if (t >= 0 && t < 7) atomicAdd(a.C + ((t * 128 + c) * 256 + o), v);
@@ -515,14 +549,15 @@ __global__ void __launch_bounds__(512, 2) k_gemm_tn(TnpArgs a) {
     }
 }
 
-template <int NPL, int EPI>
+template <int NPL, int EPI, int TI = 2, int TJ = 2>
 inline void launch_gemm_tn(TnpArgs a, int target_wgs, hipStream_t s) {
-  rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_tn<NPL, EPI>), tp_lds(NPL));
-  const int tiles = cdiv(a.M, 128) * cdiv(a.N, 256);
+  using T = TnTile<NPL, TI, TJ>;
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_tn<NPL, EPI, TI, TJ>), T::LDS);
+  const int tiles = cdiv(a.M, T::BM) * cdiv(a.N, T::BN);
   const int zc = cmax(1, cmin_(cdiv(a.F, 64), cdiv(target_wgs, tiles)));
   a.fchunk = rup(cdiv(a.F, zc), TP_KF);
-  dim3 grid((unsigned)cdiv(a.M, 128), (unsigned)cdiv(a.N, 256), (unsigned)cdiv(a.F, a.fchunk));
-  hipLaunchKernelGGL((k_gemm_tn<NPL, EPI>), grid, dim3(512), tp_lds(NPL), s, a);
+  dim3 grid((unsigned)cdiv(a.M, T::BM), (unsigned)cdiv(a.N, T::BN), (unsigned)cdiv(a.F, a.fchunk));
+  hipLaunchKernelGGL((k_gemm_tn<NPL, EPI, TI, TJ>), grid, dim3(512), T::LDS, s, a);
 }
 
 // =====================================================================================================
@@ -539,87 +574,103 @@ inline void launch_gemm_tn(TnpArgs a, int target_wgs, hipStream_t s) {
 //   weight gradients: C[(t,c)][o] += sum_{(f,j)} X[f][S j + t][c] G[f][j][o]  -- k_gemm_tn with the view as A.
 // The weights are the MFMA "A" operand (accumulator rows = output channels) and the view the "B" operand
 // (lanes = positions), so results land in the canonical [F][C][H] fp32 tensors along the position axis.
-struct RowView {      // row r of a channel-last plane tensor: element offset (r / R) * fs + x0 + (r % R) * step
-  int R, fs, x0, step;
-};
-__device__ __forceinline__ int64_t view_off(const RowView& v, int r) {
-  const int f = r / v.R, q = r - f * v.R;
-  return (int64_t)f * v.fs + v.x0 + q * v.step;
-}
 
 struct CgArgs {
-  const unsigned short* W;   // weight planes [phase][NPL][Mp][Kp]
+  const unsigned short* W;   // weight planes [NPL][Mp][Kp]
   const unsigned short* X;   // activation planes [NPL][...]
-  int64_t w_plane, w_phase, x_plane;   // elements
+  int64_t w_plane, x_plane;  // elements
   RowView xv;                // rows of the GEMM's N index n = f*R + q
-  int Kp, M, N;              // M = output channels, N = F * R
-  float* out;                // out[f*ofs + m*om + pos], pos = q*oq + o0 + phase*o0s, stored when 0 <= pos < OH
-  int ofs, om, oq, o0, o0s, OH;
-  const float* bias;         // [M] or nullptr
+  int Kp, M, N;              // M = GEMM rows (output channels, or phase * mdiv + channel), N = F * R
+  // out[f*ofs + ch*om + pos], ch = m % mdiv, pos = q*oq + o0 + (m / mdiv)*o0s, stored when 0 <= pos < OH and ch < C
+  // (transposed convs put their S output phases into M: one pass over the taps, S consecutive positions per row q)
+  float* out;
+  int mdiv, C, ofs, om, oq, o0, o0s, OH;
+  const float* bias;         // [C] or nullptr
 };
 
-template <int NPL>
+// Tile: 4 waves as WM x (4 / WM); a wave owns MT x 2 MFMA tiles.  <2,2>: 128 x 128 (>= 96 GEMM rows); <1,2>: 64 x 256;
+// <1,1>: 32 x 256 (thin layers).  K chunks of 64 for the square tile with <= 2 planes, 32 otherwise.
+template <int NPL, int WM, int MT>
+struct CgTile {
+  static constexpr int WN = 4 / WM, BM = WM * MT * 32, BN = WN * 64, ROWS = BM + BN;
+  static constexpr int BK = (WM == 2 && MT == 2) ? nt_bk(NPL) : 32;
+  static constexpr int RS = BK * 2 + 16;
+  static constexpr int PIECES = ROWS * (BK * 2 / 16), PPT = cdiv(PIECES, 256);
+  static constexpr int LDS = NPL * ROWS * RS;
+};
+
+template <int NPL, int WM, int MT>
 __global__ void __launch_bounds__(256, 2) k_cgemm(CgArgs a) {
+  using T = CgTile<NPL, WM, MT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NT_BK = nt_bk(NPL), NT_RS = NT_BK * 2 + 16, NQ = NT_BK / 16;
-  constexpr int APL = NT_BM * NT_RS, BPL = NT_BN * NT_RS;
-  unsigned char* sA = smem;
-  unsigned char* sB = smem + NPL * APL;
+  constexpr int PLB = T::ROWS * T::RS;   // bytes per plane of the LDS image: weight rows, then view rows
+  constexpr int PPR = T::BK * 2 / 16;    // 16-byte pieces per row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int n0 = blockIdx.x * NT_BN, m0 = blockIdx.y * NT_BM, ph = blockIdx.z;
-  const int srow = tid >> 1, shalf = tid & 1;
-  const unsigned char* ga = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)ph * a.w_phase + (size_t)(m0 + srow) * a.Kp) * 2 + shalf * NT_BK;
-  const int brow = n0 + srow < a.N ? n0 + srow : a.N - 1;   // rows past the end: duplicates, never stored
-  const unsigned char* gb = reinterpret_cast<const unsigned char*>(a.X) + (size_t)view_off(a.xv, brow) * 2 + shalf * NT_BK;
-  unsigned char* da = sA + srow * NT_RS + shalf * NT_BK;
-  unsigned char* db = sB + srow * NT_RS + shalf * NT_BK;
-  u32x4 ra[NPL][NQ], rb[NPL][NQ];
+  const int wm = wave / T::WN, wn = wave % T::WN;
+  const int n0 = blockIdx.x * T::BN, m0 = blockIdx.y * T::BM;
+  // staging: piece id = tid + 256*i -> (row id / PPR, piece id % PPR)
+  const unsigned char* gp[T::PPT];
+  int gplane2[T::PPT];   // bytes between planes / 2 (fits an int: planes are < 4 GB apart in elements)
+  int lofs[T::PPT];
+#pragma unroll
+  for (int i = 0; i < T::PPT; ++i) {
+    int id = tid + 256 * i;
+    id = id < T::PIECES ? id : T::PIECES - 1;
+    const int row = id / PPR, pc = id - row * PPR;
+    lofs[i] = row * T::RS + pc * 16;
+    if (row < T::BM) {
+      gp[i] = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)(m0 + row) * a.Kp) * 2 + pc * 16;
+      gplane2[i] = (int)a.w_plane;
+    } else {
+      int r = n0 + row - T::BM;
+      r = r < a.N ? r : a.N - 1;   // rows past the end: duplicates, never stored
+      gp[i] = reinterpret_cast<const unsigned char*>(a.X) + (size_t)view_off(a.xv, r) * 2 + pc * 16;
+      gplane2[i] = (int)a.x_plane;
+    }
+  }
+  u32x4 rg[NPL][T::PPT];
   auto gload = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < NPL; ++p)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        ra[p][q] = *reinterpret_cast<const u32x4*>(ga + (size_t)p * a.w_plane * 2 + kc * (NT_BK * 2) + q * 16);
-        rb[p][q] = *reinterpret_cast<const u32x4*>(gb + (size_t)p * a.x_plane * 2 + kc * (NT_BK * 2) + q * 16);
-      }
+      for (int i = 0; i < T::PPT; ++i)
+        rg[p][i] = *reinterpret_cast<const u32x4*>(gp[i] + (size_t)p * (size_t)gplane2[i] * 2 + kc * (T::BK * 2));
   };
   auto lstore = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < NPL; ++p)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        *reinterpret_cast<u32x4*>(da + p * APL + q * 16) = ra[p][q];
-        *reinterpret_cast<u32x4*>(db + p * BPL + q * 16) = rb[p][q];
-      }
+      for (int i = 0; i < T::PPT; ++i)
+        if (T::PIECES % 256 == 0 || tid + 256 * i < T::PIECES) *reinterpret_cast<u32x4*>(smem + p * PLB + lofs[i]) = rg[p][i];
   };
-  f32x16 acc[2][2];
+  f32x16 acc[MT][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
-  const int aoff = (wm * 64 + l31) * NT_RS + lh * 16;
-  const int boff = (wn * 64 + l31) * NT_RS + lh * 16;
-  u32x4 fa[2][2][NPL], fb[2][2][NPL];
+  const int aoff = (wm * MT * 32 + l31) * T::RS + lh * 16;
+  const int boff = (T::BM + wn * 64 + l31) * T::RS + lh * 16;
+  u32x4 fa[2][MT][NPL], fb[2][2][NPL];
   auto loadF = [&](int set, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) fa[set][t][p] = *reinterpret_cast<const u32x4*>(smem + p * PLB + aoff + t * 32 * T::RS + ks * 32);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) {
-        fa[set][t][p] = *reinterpret_cast<const u32x4*>(sA + p * APL + aoff + t * 32 * NT_RS + ks * 32);
-        fb[set][t][p] = *reinterpret_cast<const u32x4*>(sB + p * BPL + boff + t * 32 * NT_RS + ks * 32);
-      }
+      for (int p = 0; p < NPL; ++p) fb[set][t][p] = *reinterpret_cast<const u32x4*>(smem + p * PLB + boff + t * 32 * T::RS + ks * 32);
   };
   auto mm = [&](int set) __attribute__((always_inline)) {
     using PR = Prod<NPL>;
 #pragma unroll
     for (int t = 0; t < PR::N; ++t)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[set][i][PR::A[t]], fb[set][j][PR::B[t]], acc[i][j]);
   };
-  const int nch = a.Kp / NT_BK;
+  const int nch = a.Kp / T::BK;
   gload(0);
   for (int kc = 0; kc < nch; ++kc) {
     lstore();
@@ -628,38 +679,48 @@ __global__ void __launch_bounds__(256, 2) k_cgemm(CgArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     loadF(0, 0);
 #pragma unroll
-    for (int ks = 0; ks < NT_BK / 16; ++ks) {
-      if (ks + 1 < NT_BK / 16) loadF((ks + 1) & 1, ks + 1);
+    for (int ks = 0; ks < T::BK / 16; ++ks) {
+      if (ks + 1 < T::BK / 16) loadF((ks + 1) & 1, ks + 1);
       __builtin_amdgcn_sched_barrier(0);
       mm(ks & 1);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
-  // epilogue: accumulator rows = channels, lanes = 32 consecutive (frame, position) rows
+  // epilogue: accumulator rows = GEMM rows m, lanes = 32 consecutive (frame, position) rows
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn * 64 + j * 32 + l31;
     if (n >= a.N) continue;
     const int f = n / a.xv.R, q = n - f * a.xv.R;
-    const int pos = q * a.oq + a.o0 + ph * a.o0s;
-    if (pos < 0 || pos >= a.OH) continue;
-    float* ob = a.out + (int64_t)f * a.ofs + pos;
+    float* ob = a.out + (int64_t)f * a.ofs;
+    const int pbase = q * a.oq + a.o0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const int m = m0 + wm * 64 + i * 32 + acc_row(reg, lane);
-        if (m < a.M) ob[(int64_t)m * a.om] = acc[i][j][reg] + (a.bias ? a.bias[m] : 0.f);
+        const int m = m0 + wm * MT * 32 + i * 32 + acc_row(reg, lane);
+        if (m >= a.M) continue;
+        const int pim = m / a.mdiv, ch = m - pim * a.mdiv;
+        const int pos = pbase + pim * a.o0s;
+        if (ch < a.C && pos >= 0 && pos < a.OH) ob[(int64_t)ch * a.om + pos] = acc[i][j][reg] + (a.bias ? a.bias[ch] : 0.f);
       }
   }
 }
 
+template <int NPL, int WM, int MT>
+inline void launch_cgemm(const CgArgs& a, hipStream_t s) {
+  using T = CgTile<NPL, WM, MT>;
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_cgemm<NPL, WM, MT>), T::LDS);
+  dim3 grid((unsigned)cdiv(a.N, T::BN), (unsigned)cdiv(a.M, T::BM));
+  hipLaunchKernelGGL((k_cgemm<NPL, WM, MT>), grid, dim3(256), T::LDS, s, a);
+}
+// tile by the number of GEMM rows
 template <int NPL>
-inline void launch_cgemm(const CgArgs& a, int phases, hipStream_t s) {
-  rt().ensure_lds(reinterpret_cast<const void*>(&k_cgemm<NPL>), nt_lds(NPL));
-  dim3 grid((unsigned)cdiv(a.N, NT_BN), (unsigned)cdiv(a.M, NT_BM), (unsigned)phases);
-  hipLaunchKernelGGL(k_cgemm<NPL>, grid, dim3(256), nt_lds(NPL), s, a);
+inline void launch_cgemm_auto(const CgArgs& a, hipStream_t s) {
+  if (a.M <= 32) launch_cgemm<NPL, 1, 1>(a, s);
+  else if (a.M <= 64) launch_cgemm<NPL, 1, 2>(a, s);
+  else launch_cgemm<NPL, 2, 2>(a, s);
 }
 
 // fp32 canonical [F][C][H] (+ LayerNorm + lrelu) -> channel-last planes [NPL][F][HP][CP] with zero halo rows and zero
@@ -672,7 +733,8 @@ struct ClArgs {
   const float* beta;
   int C, H, CP, HLO, HP;
   int F;
-  unsigned short* dst;  // [NPL][F][HP][CP]
+  unsigned short* dst;  // [NPL][plane]: [F][HP][CP] then a zero tail
+  int64_t plane;        // elements between planes (>= F*HP*CP; the remainder is zeroed)
 };
 template <int NPL, bool LN>
 __global__ void __launch_bounds__(256) k_split_cl(ClArgs a) {
@@ -680,6 +742,12 @@ __global__ void __launch_bounds__(256) k_split_cl(ClArgs a) {
   const int tid = threadIdx.x;
   const int HS = a.H + 1;
   const int g8 = a.CP >> 3;
+  if (blockIdx.x == 0) {  // zero tails (K runs padded to the chunk size are read into them)
+    const int64_t used = (int64_t)a.F * a.HP * a.CP;
+    for (int64_t i = used + tid; i < a.plane; i += 256)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) a.dst[p * a.plane + i] = 0;
+  }
   for (int f = blockIdx.x; f < a.F; f += gridDim.x) {
     const float* sf = a.src + (int64_t)f * a.C * a.H;
     float mean = 0.f, rstd = 1.f;
@@ -711,7 +779,7 @@ __global__ void __launch_bounds__(256) k_split_cl(ClArgs a) {
         u32x4 pk;
 #pragma unroll
         for (int q = 0; q < 4; ++q) pk[q] = t[2 * q][p] | (t[2 * q + 1][p] << 16);
-        *reinterpret_cast<u32x4*>(a.dst + (((int64_t)p * a.F + f) * a.HP + hp) * a.CP + cg * 8) = pk;
+        *reinterpret_cast<u32x4*>(a.dst + p * a.plane + ((int64_t)f * a.HP + hp) * a.CP + cg * 8) = pk;
       }
     }
   }
@@ -728,16 +796,6 @@ inline void launch_split_cl(const ClArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((k_split_cl<NPL, false>), dim3(blocks), dim3(256), lds, s, a);
   }
 }
-
-// conv weights (TF [T][1][Cin][Cout]) for the forward view GEMM: B[m = o][k = t*CP + c] = W[t][c][o]
-struct WConvF {
-  const float* W;
-  int T, C, CP, O;
-  __device__ float operator()(int m, int k) const {
-    const int t = k / CP, c = k - t * CP;
-    return (m < O && t < T && c < C) ? W[((int64_t)t * C + c) * O + m] : 0.f;
-  }
-};
 
 }  // namespace tuned
 }  // namespace vaenpvc

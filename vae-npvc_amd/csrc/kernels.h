@@ -25,7 +25,7 @@ struct Ws {  // resolved workspace pointers (see workspace_layout)
   float* d_enc_a[VAENPVC_MAX_LAYERS];
   float* dy_tmp;
   float *pl_y3, *pl_y4, *pl_z, *pl_dz, *pl_dh, *pl_da4;
-  float* cl_y2;  // channel-last planes of the activated output of encoder layer 2  // bf16 operand planes of the dense-shaped layers
+  float* cl[12];  // channel-last planes of the conv view GEMMs (cl_layout.h: CL_*)
   float* toep_gp;  // bf16 planes of d_xh
   float* toep_yp;  // bf16 planes of dec_y
   float* scratch;

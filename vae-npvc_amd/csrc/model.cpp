@@ -1,5 +1,6 @@
 // model.cpp -- shape chain, parameter table, workspace layout (host only).
 #include "model.h"
+#include "cl_layout.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -149,8 +150,8 @@ std::vector<Region> workspace_layout(const Model& m, int64_t F, int mode, int64_
   // bf16 operand planes of the dense-shaped layers on the bf16 matrix cores (gfx950_planegemm.h), up to 3 planes
   // of [F][Kp] unsigned short each: activated outputs of encoder layers 3 and 4, and z
   if (m.is_vcc2016) {
-    // channel-last planes with zero halo rows ([F][HP][CP], gfx950_planegemm.h: conv layers as view GEMMs)
-    add("cl_y2", F * 25 * 64 * 3 / 2);   // activated output of encoder layer 2: 19 + 3 + 3 positions x 64 channels
+    // channel-last planes with zero halo rows ([F][HP][CP], cl_layout.h: conv layers as view GEMMs)
+    for (int i = 0; i < tuned::CL_FWD_COUNT; ++i) add("cl" + std::to_string(i), tuned::cl_floats(i, F));
     add("pl_y3", F * 896 * 3 / 2);
     add("pl_y4", F * 768 * 3 / 2);
     add("pl_z", F * 128 * 3 / 2);
@@ -174,6 +175,7 @@ std::vector<Region> workspace_layout(const Model& m, int64_t F, int mode, int64_
       add("pl_dz", F * 256 * 3 / 2);
       add("pl_dh", F * 1600 * 3 / 2);
       add("pl_da4", F * 768 * 3 / 2);
+      for (int i = tuned::CL_FWD_COUNT; i < tuned::CL_COUNT; ++i) add("cl" + std::to_string(i), tuned::cl_floats(i, F));
     }
     // three bf16 planes (hi, mid, lo) of d_xh, rows zero padded to a multiple of 16 bins (bf16 MFMA path
     // of the last decoder layer)

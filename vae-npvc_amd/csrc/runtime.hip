@@ -20,6 +20,7 @@ RtScope::~RtScope() { tl_rt = prev; }
 //   VAENPVC_TOEP_WGRAD_F32                exact-fp32 weight gradient of that layer only
 //   VAENPVC_PLANES=1|2|3                  bf16 terms per fp32 operand (vaenpvc_set_precision)
 //   VAENPVC_DENSE_PLANES=1|2|3            terms on the dense-shaped layers regardless of the precision rule (experiments)
+//   VAENPVC_CV_SITES=<mask>               conv sites on the view GEMMs (runtime.h: cv_sites)
 void Runtime::read_env() {
   if (const char* e = getenv("VAENPVC_FWD_MASK")) fwd_mask = (unsigned)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_BWD_MASK")) bwd_mask = (unsigned)strtoul(e, nullptr, 0);
@@ -27,6 +28,7 @@ void Runtime::read_env() {
   if (const char* e = getenv("VAENPVC_TOEP")) toep_f32 = !strcmp(e, "f32");
   toep_wgrad_f32 = getenv("VAENPVC_TOEP_WGRAD_F32") != nullptr;
   toep_wgrad_k16 = getenv("VAENPVC_TOEP_WGRAD_K16") != nullptr;
+  if (const char* e = getenv("VAENPVC_CV_SITES")) cv_sites_env = (long)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_DENSE_PLANES")) {
     int p = atoi(e);
     if (p >= 1 && p <= 3) dense_planes = p;
