@@ -288,7 +288,7 @@ static void for_dense_planes(Fn&& fn) {
 }
 
 // ---------------------------------------------------------------- weight packing
-static void prep(const Model& m, const float* P, const Ws& w, hipStream_t s) {
+static void prep(const Model& m, const float* P, const Ws& w, int64_t F, hipStream_t s) {
   float* S = w.scratch;
   constexpr int NTB = TB_C * TB_CPY * 8 * TB_CHUNKS;
   // one launch for all packed copies (see k_pack_multi)
@@ -331,7 +331,7 @@ static void prep(const Model& m, const float* P, const Ws& w, hipStream_t s) {
       pack_job(PackRepeat3{P + m.enc[4].b_off}, S + Pk::pg_bias4, 768));
   // weight planes of the conv view-GEMM sites.  TF layouts: conv [T][Cin][Cout], conv_transpose [T][Cout][Cin];
   // (s_t, s_o, s_c) = strides of (tap, GEMM output channel, contracted channel)
-  if (cg_fwd(0x7fffffff) || cg_bwd(0x7fffffff)) {
+  if (cg_fwd(F) || cg_bwd(F)) {
     auto ef = [&](int site, int i) { const ConvL& l = m.enc[i]; return cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, 1, l.cout, S + Pk::cvw + cv_woff(site)); };
     auto eg = [&](int site, int i) { const ConvL& l = m.enc[i]; return cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, l.cout, 1, S + Pk::cvw + cv_woff(site)); };
     auto df = [&](int site, int i) { const ConvL& l = m.dec[i]; return cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, l.cin, 1, S + Pk::cvw + cv_woff(site)); };
@@ -403,7 +403,7 @@ static ConvArgs conv_args(const float* in, const float* st, const float* gamma, 
 void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, const Ws& w, hipStream_t s) {
   read_env();
   const int F = (int)F64;
-  prep(m, P, w, s);
+  prep(m, P, w, F, s);
   // e0: Cin = 1, K = 7 -- 0.4 % of the MACs, HBM-bound: VALU conv fused with its LN statistics
   if (fwd_on(0)) {
     int fch = cmax(1, cdiv(F, 4096));
@@ -416,26 +416,39 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
                                            P + m.enc[i].w_off, P + m.enc[i].b_off, w.enc_a[i], F); };
   // a conv site as a GEMM over the overlapping-row view of channel-last planes (gfx950_viewconv.h): producer of the
   // activated input planes (LayerNorm + lrelu of layer i - 1), then the GEMM
-  auto enc_view = [&](int site, int cl, int i, const char* tsplit, const char* tgemm) {
+  auto enc_view = [&](int site, int cl, int i, bool have, const char* tsplit, const char* tgemm) {
     for_dense_planes([&](auto npl) {
       constexpr int NPL = decltype(npl)::value;
-      VAENPVC_TIMED(tsplit, s, cv_split<NPL>(cl, w.enc_a[i - 1], w.enc_st[i - 1], P + m.enc[i - 1].gamma_off, P + m.enc[i - 1].beta_off,
-                                             w.cl[cl], F, s));
+      if (!have)
+        VAENPVC_TIMED(tsplit, s, cv_split<NPL>(cl, w.enc_a[i - 1], w.enc_st[i - 1], P + m.enc[i - 1].gamma_off, P + m.enc[i - 1].beta_off,
+                                               w.cl[cl], F, s));
       VAENPVC_TIMED(tgemm, s, cv_gemm<NPL>(site, w.scratch + Pk::cvw + cv_woff(site), w.cl[cl], w.enc_a[i], P + m.enc[i].b_off, F, s));
     });
   };
+  // LayerNorm statistics of layer i's output; when the next layer is a view-GEMM site its activated input planes are
+  // written in the same pass over the tensor
+  auto enc_stats = [&](int i, int next_site, int cl, const char* tag) {
+    const bool fuse = fwd_on(i + 1) && cv_fwd(next_site, F);
+    if (fuse)
+      for_dense_planes([&](auto npl) {
+        VAENPVC_TIMED(tag, s, cv_stats_split<decltype(npl)::value>(cl, w.enc_a[i], w.enc_st[i], P + m.enc[i].gamma_off, P + m.enc[i].beta_off,
+                                                                   w.cl[cl], F, s));
+      });
+    return fuse;
+  };
+  bool have_y1 = false, have_y2 = false;
   if (fwd_on(1)) {
-    if (cv_fwd(CV_E1F, F)) enc_view(CV_E1F, CL_Y0, 1, "enc1_split", "enc1_fwd");
+    if (cv_fwd(CV_E1F, F)) enc_view(CV_E1F, CL_Y0, 1, false, "enc1_split", "enc1_fwd");
     else VAENPVC_TIMED("enc1_fwd", s, launch_convgemm<E1F>(lnp(1), nsplit_for<E1F>(F), s));
-    stats<1824>(w.enc_a[1], w.enc_st[1], F, s);
+    if (!(have_y1 = enc_stats(1, CV_E2F, CL_Y1, "enc2_split"))) stats<1824>(w.enc_a[1], w.enc_st[1], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 1);
   if (fwd_on(2)) {
-    if (cv_fwd(CV_E2F, F)) enc_view(CV_E2F, CL_Y1, 2, "enc2_split", "enc2_fwd");
+    if (cv_fwd(CV_E2F, F)) enc_view(CV_E2F, CL_Y1, 2, have_y1, "enc2_split", "enc2_fwd");
     else VAENPVC_TIMED("enc2_fwd", s, launch_convgemm<E2F>(lnp(2), nsplit_for<E2F>(F), s));
-    stats<1216>(w.enc_a[2], w.enc_st[2], F, s);
+    if (!(have_y2 = enc_stats(2, CV_E3F, CL_Y2, "enc3_split"))) stats<1216>(w.enc_a[2], w.enc_st[2], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 2);
   if (fwd_on(3) && cv_fwd(CV_E3F, F)) {
-    enc_view(CV_E3F, CL_Y2, 3, "enc3_split", "enc3_fwd");
+    enc_view(CV_E3F, CL_Y2, 3, have_y2, "enc3_split", "enc3_fwd");
     stats_planes<896, 7>(w.enc_a[3], w.enc_st[3], P + m.enc[3].gamma_off, P + m.enc[3].beta_off, w.pl_y3,
                          fwd_on(4) && pg_fwd(F), F, s);
   } else if (fwd_on(3)) {
@@ -499,7 +512,7 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
                  float* xh_out, hipStream_t s, bool weights_packed) {
   read_env();
   const int F = (int)F64;
-  if (!weights_packed) prep(m, P, w, s);
+  if (!weights_packed) prep(m, P, w, F, s);
   if (fwd_on(6) && pg_fwd(F)) {
     for_dense_planes([&](auto npl) {
       constexpr int NPL = decltype(npl)::value;
@@ -518,34 +531,45 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     a.nrb = MERGE_NY;
     VAENPVC_TIMED("merge_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<MergeFs>(a, s) : launch_densegemm<MergeF>(a, s)));
   } else generic::merge_fwd(m, P, z, y, F, w, s);
-  auto dec_view = [&](int site, int cl, int i, const float* src, const char* tsplit, const char* tgemm) {
+  auto dec_view = [&](int site, int cl, int i, bool have, const float* src, const char* tsplit, const char* tgemm) {
     for_dense_planes([&](auto npl) {
       constexpr int NPL = decltype(npl)::value;
-      if (i == 0) VAENPVC_TIMED(tsplit, s, cv_split<NPL>(cl, src, nullptr, nullptr, nullptr, w.cl[cl], F, s));
+      if (have) {}
+      else if (i == 0) VAENPVC_TIMED(tsplit, s, cv_split<NPL>(cl, src, nullptr, nullptr, nullptr, w.cl[cl], F, s));
       else VAENPVC_TIMED(tsplit, s, cv_split<NPL>(cl, src, w.dec_st[i - 1], P + m.dec[i - 1].gamma_off, P + m.dec[i - 1].beta_off, w.cl[cl], F, s));
       VAENPVC_TIMED(tgemm, s, cv_gemm<NPL>(site, w.scratch + Pk::cvw + cv_woff(site), w.cl[cl], w.dec_a[i], P + m.dec[i].b_off, F, s));
     });
   };
+  auto dec_stats = [&](int i, int next_site, int cl, const char* tag) {
+    const bool fuse = fwd_on(8 + i) && cv_fwd(next_site, F);
+    if (fuse)
+      for_dense_planes([&](auto npl) {
+        VAENPVC_TIMED(tag, s, cv_stats_split<decltype(npl)::value>(cl, w.dec_a[i], w.dec_st[i], P + m.dec[i].gamma_off, P + m.dec[i].beta_off,
+                                                                   w.cl[cl], F, s));
+      });
+    return fuse;
+  };
+  bool have_yd0 = false, have_yd1 = false;
   if (fwd_on(7) && cv_fwd(CV_D0F, F)) {
-    dec_view(CV_D0F, CL_H, 0, w.h, "dec0_split", "dec0_fwd");
-    stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
+    dec_view(CV_D0F, CL_H, 0, false, w.h, "dec0_split", "dec0_fwd");
+    if (!(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
   } else if (fwd_on(7)) {
     VAENPVC_TIMED("dec0_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<D0Fs>(conv_args(w.h, nullptr, nullptr, nullptr, w.scratch + Pk::d0f,
                                                                 P + m.dec[0].b_off, w.dec_a[0], F), nsplit_for<D0Fs>(F), s) : launch_convgemm<D0F>(conv_args(w.h, nullptr, nullptr, nullptr, w.scratch + Pk::d0f,
                                                                 P + m.dec[0].b_off, w.dec_a[0], F), nsplit_for<D0F>(F), s)));
-    stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
+    if (!(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 0);
   if (fwd_on(8) && cv_fwd(CV_D1F, F)) {
-    dec_view(CV_D1F, CL_YD0, 1, w.dec_a[0], "dec1_split", "dec1_fwd");
-    stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
+    dec_view(CV_D1F, CL_YD0, 1, have_yd0, w.dec_a[0], "dec1_split", "dec1_fwd");
+    if (!(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
   } else if (fwd_on(8)) {
     VAENPVC_TIMED("dec1_fwd", s, launch_convgemm<D1F>(conv_args(w.dec_a[0], w.dec_st[0], P + m.dec[0].gamma_off,
                                                                 P + m.dec[0].beta_off, w.scratch + Pk::d1f,
                                                                 P + m.dec[1].b_off, w.dec_a[1], F), nsplit_for<D1F>(F), s));
-    stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
+    if (!(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 1);
   if (fwd_on(9)) {
-    if (cv_fwd(CV_D2F, F)) dec_view(CV_D2F, CL_YD1, 2, w.dec_a[1], "dec2_split", "dec2_fwd");
+    if (cv_fwd(CV_D2F, F)) dec_view(CV_D2F, CL_YD1, 2, have_yd1, w.dec_a[1], "dec2_split", "dec2_fwd");
     else
     VAENPVC_TIMED("dec2_fwd", s, launch_convgemm<D2F>(conv_args(w.dec_a[1], w.dec_st[1], P + m.dec[1].gamma_off,
                                                                 P + m.dec[1].beta_off, w.scratch + Pk::d2f,

@@ -504,7 +504,12 @@ __global__ void __launch_bounds__(512, 2) k_gemm_tn(TnpArgs a) {
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = mfma_bf16(fa[i][PR::A[t]], fbq[j][PR::B[t]], acc[i][j]);
+        for (int j = 0; j < TJ; ++j) {
+          // TRANS: the tile is accumulated transposed (rows = n, lanes = m) so that the atomics of a wave fall on
+          // consecutive addresses of C[n*ldc + m]
+          if constexpr (EPI == TN_EPI_TRANS) acc[i][j] = mfma_bf16(fbq[j][PR::B[t]], fa[i][PR::A[t]], acc[i][j]);
+          else acc[i][j] = mfma_bf16(fa[i][PR::A[t]], fbq[j][PR::B[t]], acc[i][j]);
+        }
   };
   if (fb < fe) {
     gload(fb);
@@ -523,7 +528,22 @@ __global__ void __launch_bounds__(512, 2) k_gemm_tn(TnpArgs a) {
     if (more) lstore(f0 + TP_KF, (nq + 1) & 1);
     __syncthreads();
   }
-  // epilogue: acc[i][j][reg] = C[m0 + 32 TI wr + 32 i + acc_row(reg)][n0 + 32 TJ wc + 32 j + l31]
+  // epilogue: acc[i][j][reg] = C[m0 + 32 TI wr + 32 i + acc_row(reg)][n0 + 32 TJ wc + 32 j + l31]  (TRANS: transposed)
+  if constexpr (EPI == TN_EPI_TRANS) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int m = m0 + 32 * TI * wr + 32 * i + l31;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int n = n0 + 32 * TJ * wc + 32 * j + acc_row(reg, lane);
+          if (n < a.N) atomicAdd(a.C + (int64_t)n * a.ldc + m, acc[i][j][reg]);
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -535,9 +555,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_tn(TnpArgs a) {
         const int m = m0 + 32 * TI * wr + 32 * i + acc_row(reg, lane);
         if (m >= a.M) continue;
         const float v = acc[i][j][reg];
-        if constexpr (EPI == TN_EPI_TRANS) {
-          atomicAdd(a.C + (int64_t)n * a.ldc + m, v);
-        } else if constexpr (EPI == TN_EPI_ENC4) {
+        if constexpr (EPI == TN_EPI_ENC4) {
           // m = (c, h) = c*7 + h, n = (o, j3) = o*3 + j3: dW[t][c][o] with t = h - 3*j3 + 3
           const int c = m / 7, h = m - 7 * c, o = n / 3, j3 = n - 3 * o, t = h - 3 * j3 + 3;
           if (t >= 0 && t < 7) atomicAdd(a.C + ((t * 128 + c) * 256 + o), v);
@@ -735,10 +753,14 @@ struct ClArgs {
   int F;
   unsigned short* dst;  // [NPL][plane]: [F][HP][CP] then a zero tail
   int64_t plane;        // elements between planes (>= F*HP*CP; the remainder is zeroed)
+  float* st_out;        // LN == 2: the statistics are computed here (two-pass over the staged frame) and stored
 };
-template <int NPL, bool LN>
+// LN: 0 = plain copy, 1 = LayerNorm + lrelu with given statistics, 2 = ... with statistics computed in the same pass
+// (replaces k_ln_stats_fast + a second read of the tensor)
+template <int NPL, int LN>
 __global__ void __launch_bounds__(256) k_split_cl(ClArgs a) {
   extern __shared__ __attribute__((aligned(16))) float tile[];   // [C][H + 1]
+  __shared__ float red[8];
   const int tid = threadIdx.x;
   const int HS = a.H + 1;
   const int g8 = a.CP >> 3;
@@ -751,16 +773,39 @@ __global__ void __launch_bounds__(256) k_split_cl(ClArgs a) {
   for (int f = blockIdx.x; f < a.F; f += gridDim.x) {
     const float* sf = a.src + (int64_t)f * a.C * a.H;
     float mean = 0.f, rstd = 1.f;
-    if constexpr (LN) {
+    if constexpr (LN == 1) {
       mean = a.st[2 * f];
       rstd = a.st[2 * f + 1];
     }
     __syncthreads();
+    float sum = 0.f;
     for (int i = tid; i < a.C * a.H; i += 256) {
       const int c = i / a.H, h = i - c * a.H;
       float v = sf[i];
-      if constexpr (LN) v = lnact_v(v, mean, rstd, a.gamma[c], a.beta[c]);
+      if constexpr (LN == 1) v = lnact_v(v, mean, rstd, a.gamma[c], a.beta[c]);
+      if constexpr (LN == 2) sum += v;
       tile[c * HS + h] = v;
+    }
+    if constexpr (LN == 2) {
+      const int n = a.C * a.H;
+      sum = wave_sum(sum);
+      if ((tid & 63) == 0) red[tid >> 6] = sum;
+      __syncthreads();
+      mean = (red[0] + red[1] + red[2] + red[3]) / n;
+      float q = 0.f;
+      for (int i = tid; i < n; i += 256) {
+        const int c = i / a.H, h = i - c * a.H;
+        const float d = tile[c * HS + h] - mean;
+        q += d * d;
+      }
+      q = wave_sum(q);
+      if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
+      __syncthreads();
+      rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / n + LN_EPS);
+      if (tid == 0) {
+        a.st_out[2 * f] = mean;
+        a.st_out[2 * f + 1] = rstd;
+      }
     }
     __syncthreads();
     // one item = (padded position hp, group of 8 channels)
@@ -771,7 +816,9 @@ __global__ void __launch_bounds__(256) k_split_cl(ClArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = cg * 8 + j;
-        const float v = (h >= 0 && h < a.H && c < a.C) ? tile[c * HS + h] : 0.f;
+        float v = (h >= 0 && h < a.H && c < a.C) ? tile[c * HS + h] : 0.f;
+        if constexpr (LN == 2)
+          if (h >= 0 && h < a.H && c < a.C) v = lnact_v(v, mean, rstd, a.gamma[c], a.beta[c]);
         split_n<NPL>(v, t[j]);
       }
 #pragma unroll
@@ -788,12 +835,15 @@ template <int NPL>
 inline void launch_split_cl(const ClArgs& a, hipStream_t s) {
   const int lds = a.C * (a.H + 1) * 4;
   const unsigned blocks = (unsigned)cmin_(a.F, 4096);
-  if (a.st) {
-    rt().ensure_lds(reinterpret_cast<const void*>(&k_split_cl<NPL, true>), lds);
-    hipLaunchKernelGGL((k_split_cl<NPL, true>), dim3(blocks), dim3(256), lds, s, a);
+  if (a.st_out) {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_split_cl<NPL, 2>), lds);
+    hipLaunchKernelGGL((k_split_cl<NPL, 2>), dim3(blocks), dim3(256), lds, s, a);
+  } else if (a.st) {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_split_cl<NPL, 1>), lds);
+    hipLaunchKernelGGL((k_split_cl<NPL, 1>), dim3(blocks), dim3(256), lds, s, a);
   } else {
-    rt().ensure_lds(reinterpret_cast<const void*>(&k_split_cl<NPL, false>), lds);
-    hipLaunchKernelGGL((k_split_cl<NPL, false>), dim3(blocks), dim3(256), lds, s, a);
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_split_cl<NPL, 0>), lds);
+    hipLaunchKernelGGL((k_split_cl<NPL, 0>), dim3(blocks), dim3(256), lds, s, a);
   }
 }
 

@@ -23,6 +23,137 @@
 namespace vaenpvc {
 namespace tuned {
 
+// ---------------------------------------------------------------- producers of the channel-last planes
+// One WAVE per frame: the fp32 frame ([C][H], N = C*H floats) is read once with 16-byte loads into registers, the
+// LayerNorm statistics are taken there (LN = 2: two-pass, as k_ln_stats_fast), the activated values go to the wave's
+// LDS tile in the source order, and the tile is read back transposed -- 8 channels of one position per lane (row
+// stride H is odd: conflict-free) -- split into bf16 terms and stored as 16-byte pieces of the contiguous [HP][CP]
+// frame of every plane.  No workgroup barrier; four frames in flight per workgroup.
+//   LN: 0 plain copy (gradients, merge output), 1 LayerNorm + lrelu with given statistics, 2 ... computing them here.
+struct CpArgs {
+  const float* src;
+  const float* st;      // LN == 1
+  float* st_out;        // LN == 2
+  const float* gamma;
+  const float* beta;
+  unsigned short* dst;
+  int64_t plane;
+  int F;
+};
+template <int NPL, int LN, int ID>
+__global__ void __launch_bounds__(256) k_cl_produce(CpArgs a) {
+  constexpr ClDesc D = CLD[ID];
+  constexpr int C = D.C, H = D.H, CP = D.CP, HLO = D.HLO, HP = D.HP, N = C * H, G8 = CP / 8;
+  constexpr bool V4 = (N % 4 == 0);
+  constexpr int NV = cdiv(N, 4), PER = cdiv(NV, 64);
+  extern __shared__ __attribute__((aligned(16))) float tiles[];   // [4 waves][N rounded up to 4]
+  constexpr int TS = NV * 4;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* tile = tiles + wv * TS;
+  if (blockIdx.x == 0) {  // zero tails behind the planes
+    const int64_t used = (int64_t)a.F * HP * CP;
+    for (int64_t i = used + threadIdx.x; i < a.plane; i += 256)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) a.dst[p * a.plane + i] = 0;
+  }
+  for (int f = blockIdx.x * 4 + wv; f < a.F; f += gridDim.x * 4) {
+    const float* sf = a.src + (int64_t)f * N;
+    float v[PER][4];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = lane + 64 * i;
+      if constexpr (V4) {
+        const float4 t = idx < NV ? reinterpret_cast<const float4*>(sf)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i][0] = t.x, v[i][1] = t.y, v[i][2] = t.z, v[i][3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] = 4 * idx + j < N ? sf[4 * idx + j] : 0.f;
+      }
+    }
+    float mean = 0.f, rstd = 1.f;
+    if constexpr (LN == 1) {
+      mean = a.st[2 * f];
+      rstd = a.st[2 * f + 1];
+    }
+    if constexpr (LN == 2) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      mean = wave_sum(s) / N;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < PER; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * (lane + 64 * i) + j < N) {
+            const float d = v[i][j] - mean;
+            q += d * d;
+          }
+      rstd = 1.0f / sqrtf(wave_sum(q) / N + LN_EPS);
+      if (lane == 0) {
+        a.st_out[2 * f] = mean;
+        a.st_out[2 * f + 1] = rstd;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < NV) {
+        float4 o;
+        if constexpr (LN != 0) {
+          const int e = 4 * idx;
+          o.x = lnact_v(v[i][0], mean, rstd, a.gamma[min(e / H, C - 1)], a.beta[min(e / H, C - 1)]);
+          o.y = lnact_v(v[i][1], mean, rstd, a.gamma[min((e + 1) / H, C - 1)], a.beta[min((e + 1) / H, C - 1)]);
+          o.z = lnact_v(v[i][2], mean, rstd, a.gamma[min((e + 2) / H, C - 1)], a.beta[min((e + 2) / H, C - 1)]);
+          o.w = lnact_v(v[i][3], mean, rstd, a.gamma[min((e + 3) / H, C - 1)], a.beta[min((e + 3) / H, C - 1)]);
+        } else {
+          o = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+        }
+        reinterpret_cast<float4*>(tile)[idx] = o;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // one item = (padded position hp, group of 8 channels); consecutive items are consecutive 16-byte pieces
+    unsigned short* df = a.dst + (int64_t)f * HP * CP;
+    for (int it = lane; it < HP * G8; it += 64) {
+      const int hp = it / G8, cg = it - hp * G8, h = hp - HLO;
+      unsigned t[8][NPL];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+        const float x = (h >= 0 && h < H && c < C) ? tile[c * H + h] : 0.f;
+        split_n<NPL>(x, t[j]);
+      }
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        u32x4 pk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pk[q] = t[2 * q][p] | (t[2 * q + 1][p] << 16);
+        *reinterpret_cast<u32x4*>(df + p * a.plane + (int64_t)it * 8) = pk;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+template <int NPL, int LN, int ID>
+static void launch_cl_produce_id(const CpArgs& a, hipStream_t s) {
+  constexpr int lds = 4 * cdiv(CLD[ID].C * CLD[ID].H, 4) * 4 * 4;
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_cl_produce<NPL, LN, ID>), lds);
+  const unsigned blocks = (unsigned)cmin_(cdiv(a.F, 4), 2048);
+  hipLaunchKernelGGL((k_cl_produce<NPL, LN, ID>), dim3(blocks), dim3(256), lds, s, a);
+}
+template <int NPL, int LN>
+static void launch_cl_produce(int id, const CpArgs& a, hipStream_t s) {
+  switch (id) {
+#define VAENPVC_CLP(ID) case ID: launch_cl_produce_id<NPL, LN, ID>(a, s); break;
+    VAENPVC_CLP(CL_Y0) VAENPVC_CLP(CL_Y1) VAENPVC_CLP(CL_Y2) VAENPVC_CLP(CL_H) VAENPVC_CLP(CL_YD0) VAENPVC_CLP(CL_YD1)
+    VAENPVC_CLP(CL_GE1) VAENPVC_CLP(CL_GE2) VAENPVC_CLP(CL_GE3) VAENPVC_CLP(CL_GD0) VAENPVC_CLP(CL_GD1) VAENPVC_CLP(CL_GD2)
+#undef VAENPVC_CLP
+  }
+}
+
 // weight planes of a site: B[m][k], m = pim*mdiv + o, k = dd*CP + c; element W[t*s_t + o*s_o + c*s_c]
 struct WView {
   const float* W;
@@ -87,9 +218,16 @@ static PackPlanesJob<WView, NPL> cv_job(int site, const float* W, int s_t, int s
 template <int NPL>
 static void cv_split(int id, const float* src, const float* st, const float* gamma, const float* beta, float* dst, int F,
                      hipStream_t s) {
-  const ClDesc& d = CLD[id];
-  ClArgs a{src, st, gamma, beta, d.C, d.H, d.CP, d.HLO, d.HP, F, reinterpret_cast<unsigned short*>(dst), cl_plane(id, F)};
-  launch_split_cl<NPL>(a, s);
+  CpArgs a{src, st, nullptr, gamma, beta, reinterpret_cast<unsigned short*>(dst), cl_plane(id, F), F};
+  if (st) launch_cl_produce<NPL, 1>(id, a, s);
+  else launch_cl_produce<NPL, 0>(id, a, s);
+}
+// the same, computing the LayerNorm statistics of `src` on the way (stored to st_out)
+template <int NPL>
+static void cv_stats_split(int id, const float* src, float* st_out, const float* gamma, const float* beta, float* dst, int F,
+                           hipStream_t s) {
+  CpArgs a{src, nullptr, st_out, gamma, beta, reinterpret_cast<unsigned short*>(dst), cl_plane(id, F), F};
+  launch_cl_produce<NPL, 2>(id, a, s);
 }
 
 template <int NPL>
