@@ -231,6 +231,9 @@ static TnpArgs tnp_args(const float* Ap, int lda, const float* Bp, int ldb, int 
   a.F = F;
   a.C = C;
   a.ldc = ldc;
+  // XCD-aware tile order: measured -15 % where a row chunk has many tiles sharing both operands (layer 4: 7 x 3), +5..10 %
+  // on the one-dimensional tilings (merge 1 x 7, heads 6 x 1)
+  a.xcd = rt().tn_xcd >= 0 ? rt().tn_xcd : (cdiv(M, 128) > 1 && cdiv(N, 256) > 1 ? 1 : 0);
   return a;
 }
 // layers whose TF kernel tensor IS the packed operand (no copy)

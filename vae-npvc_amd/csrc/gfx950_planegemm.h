@@ -266,6 +266,14 @@ struct NtArgs {
   int nrb, ldrb;
 };
 constexpr int NT_BM = 128, NT_BN = 128;
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order), each XCD has its own L2.  The linear
+// id is remapped (bijectively, any grid size) so that every XCD walks a CONTIGUOUS range of tiles; with the column
+// tile as the fast index the workgroups resident on one XCD share their 128 rows of A, which are then fetched into
+// that L2 once instead of once per column tile from HBM / Infinity Cache.
+__device__ __forceinline__ int xcd_contiguous(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
 // K chunk: 64 with up to two planes, 32 with three (LDS and prefetch registers stay at two workgroups per CU; the
 // MFMAs between two barriers are the same 48 per wave either way)
 #ifndef VAENPVC_NT_BK2
@@ -286,7 +294,8 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
   unsigned char* sB = smem + NPL * APL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * NT_BM, n0 = blockIdx.y * NT_BN;
+  const int ntn = cdiv(a.N, NT_BN), tile = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int m0 = (tile / ntn) * NT_BM, n0 = (tile % ntn) * NT_BN;
   // staging: thread -> (row tid >> 1, half tid & 1 of the row's chunk) of both tiles: NQ pieces of 16 bytes per plane and operand
   const int srow = tid >> 1, shalf = tid & 1;
   const int arow = m0 + srow < a.M ? m0 + srow : a.M - 1;  // rows past the end: duplicates, never stored
@@ -393,9 +402,14 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
 template <int NPL>
 inline void launch_gemm_nt(const NtArgs& a, hipStream_t s) {
   rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_nt<NPL>), nt_lds(NPL));
-  dim3 grid((unsigned)cdiv(a.M, NT_BM), (unsigned)cdiv(a.N, NT_BN));
+  dim3 grid((unsigned)(cdiv(a.M, NT_BM) * cdiv(a.N, NT_BN)));
   hipLaunchKernelGGL(k_gemm_nt<NPL>, grid, dim3(256), nt_lds(NPL), s, a);
 }
+
+// (An LDS-DMA variant of this kernel -- global_load_lds_dwordx4 into a ring of 2-4 unpadded, XOR-swizzled stage
+//  buffers, counted vmcnt waits, bare s_barrier -- was measured and dropped: with two workgroups per CU it ran within
+//  +-3 % of the register-staged loop on all six sites (2 and 1 planes), with one workgroup per CU and 3-4 stages 30-50 %
+//  slower.  The staging method is not the limit of the 128 x 128 two-barrier structure)
 
 // ---------------------------------------------------------------- C += A^T B   (reduction over frames)
 // Workgroup = 128 (m) x 256 (n) tile over the frames [z*fchunk, (z+1)*fchunk); 8 waves as 2 x 4, wave tile 64 x 64.
@@ -409,6 +423,7 @@ struct TnpArgs {
   int64_t a_plane, b_plane;
   RowView av, bv;
   int lda, ldb;   // readable elements per row (loads are clamped to the row: ragged last column tile)
+  int xcd;               // 1: XCD-aware tile order (the tiles of a row chunk on one XCD)
   int M, N, F, fchunk;   // F = number of reduction rows
   float* C;   // PLAIN: C[m*ldc + n] (n < split) ; ENC4: the TF kernel tensor [7][128][256] ; TRANS: C[n*ldc + m]
   float* C2;  // PLAIN: columns n >= split at n - split
@@ -426,15 +441,20 @@ struct TnTile {
   static constexpr int APC = BM / 8, BPC = BN / 8;   // 16-byte pieces per row
 };
 
+// (second launch bound = waves per SIMD: 4 = two 8-wave workgroups per CU, i.e. at most 128 registers per lane)
 template <int NPL, int EPI, int TI = 2, int TJ = 2>
-__global__ void __launch_bounds__(512, 2) k_gemm_tn(TnpArgs a) {
+__global__ void __launch_bounds__(512, NPL <= 2 ? 4 : 2) k_gemm_tn(TnpArgs a) {
   using T = TnTile<NPL, TI, TJ>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BUF = T::BUF;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lh = lane >> 5, l31 = lane & 31;
   const int wr = wave >> 2, wc = wave & 3;
-  const int m0 = blockIdx.x * T::BM, n0 = blockIdx.y * T::BN;
-  const int fb = blockIdx.z * a.fchunk, fe = min(a.F, fb + a.fchunk);
+  // XCD-aware order: the tiles of one row chunk read the same rows of A and B -- they run on one XCD (one L2)
+  const int ntm = cdiv(a.M, T::BM), ntt = ntm * cdiv(a.N, T::BN);
+  const int wg = a.xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int zc = wg / ntt, tl = wg - zc * ntt;
+  const int m0 = (tl % ntm) * T::BM, n0 = (tl / ntm) * T::BN;
+  const int fb = zc * a.fchunk, fe = min(a.F, fb + a.fchunk);
   // staging of one 16-row chunk: A 16 rows x APC pieces, B 16 rows x BPC pieces (the first 16*APC / 16*BPC threads)
   const bool a_thr = tid < TP_KF * T::APC, b_thr = tid < TP_KF * T::BPC;
   const int arow = (tid / T::APC) & 15, apc = tid % T::APC;
@@ -446,19 +466,39 @@ __global__ void __launch_bounds__(512, 2) k_gemm_tn(TnpArgs a) {
   const unsigned char* A8 = reinterpret_cast<const unsigned char*>(a.A);
   const unsigned char* B8 = reinterpret_cast<const unsigned char*>(a.B);
   u32x4 sta[NPL], stb[NPL];
-  auto gload = [&](int f0) __attribute__((always_inline)) {
-    int fa_ = f0 + arow, fb_ = f0 + brow;
-    fa_ = fa_ < a.F ? fa_ : a.F - 1;
-    fb_ = fb_ < a.F ? fb_ : a.F - 1;
+  // Row addresses advance incrementally: 16 rows on = df whole frames + dq rows (uniform) + one conditional carry, no
+  // division and no branch in the loop.  An iterator stops at its last valid row (rows past the end of the tensor
+  // re-read it: finite data, and their products vanish because the A rows are zeroed in lstore).
+  struct RowIt {   // (byte offsets within a plane fit 32 bits)
+    unsigned off;  // row offset + column, bytes
+    int q;         // row within the frame
+  };
+  auto row_init = [&](const RowView& v, int r, int colbytes) {
+    RowIt it;
+    const int f = r / v.R;
+    it.q = r - f * v.R;
+    it.off = (unsigned)(f * v.fs + v.x0 + it.q * v.step) * 2u + (unsigned)colbytes;
+    return it;
+  };
+  const int adf = TP_KF / a.av.R, adq = TP_KF - adf * a.av.R, bdf = TP_KF / a.bv.R, bdq = TP_KF - bdf * a.bv.R;
+  auto row_next = [&](const RowView& v, int df, int dq, RowIt& it) __attribute__((always_inline)) {
+    int q = it.q + dq;
+    const int carry = q >= v.R ? 1 : 0;
+    q -= carry ? v.R : 0;
+    it.off += (unsigned)(((df + carry) * v.fs + (q - it.q) * v.step) * 2);
+    it.q = q;
+  };
+  RowIt ia = row_init(a.av, min(fb + arow, a.F - 1), acol), ib = row_init(a.bv, min(fb + brow, a.F - 1), bcol);
+  auto gload = [&](int f0) __attribute__((always_inline)) {   // rows f0 + arow / f0 + brow: loads, then advances the iterators
     if (a_thr) {
-      const size_t ra = (size_t)view_off(a.av, fa_);
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) sta[p] = *reinterpret_cast<const u32x4*>(A8 + ((size_t)p * a.a_plane + ra) * 2 + acol);
+      for (int p = 0; p < NPL; ++p) sta[p] = *reinterpret_cast<const u32x4*>(A8 + (size_t)p * a.a_plane * 2 + ia.off);
+      if (f0 + TP_KF + arow < a.F) row_next(a.av, adf, adq, ia);
     }
     if (b_thr) {
-      const size_t rb = (size_t)view_off(a.bv, fb_);
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) stb[p] = *reinterpret_cast<const u32x4*>(B8 + ((size_t)p * a.b_plane + rb) * 2 + bcol);
+      for (int p = 0; p < NPL; ++p) stb[p] = *reinterpret_cast<const u32x4*>(B8 + (size_t)p * a.b_plane * 2 + ib.off);
+      if (f0 + TP_KF + brow < a.F) row_next(a.bv, bdf, bdq, ib);
     }
   };
   auto lstore = [&](int f0, int buf) __attribute__((always_inline)) {
@@ -574,7 +614,7 @@ inline void launch_gemm_tn(TnpArgs a, int target_wgs, hipStream_t s) {
   const int tiles = cdiv(a.M, T::BM) * cdiv(a.N, T::BN);
   const int zc = cmax(1, cmin_(cdiv(a.F, 64), cdiv(target_wgs, tiles)));
   a.fchunk = rup(cdiv(a.F, zc), TP_KF);
-  dim3 grid((unsigned)cdiv(a.M, T::BM), (unsigned)cdiv(a.N, T::BN), (unsigned)cdiv(a.F, a.fchunk));
+  dim3 grid((unsigned)(cdiv(a.M, T::BM) * cdiv(a.N, T::BN) * cdiv(a.F, a.fchunk)));
   hipLaunchKernelGGL((k_gemm_tn<NPL, EPI, TI, TJ>), grid, dim3(512), T::LDS, s, a);
 }
 
@@ -625,7 +665,8 @@ __global__ void __launch_bounds__(256, 2) k_cgemm(CgArgs a) {
   constexpr int PPR = T::BK * 2 / 16;    // 16-byte pieces per row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int wm = wave / T::WN, wn = wave % T::WN;
-  const int n0 = blockIdx.x * T::BN, m0 = blockIdx.y * T::BM;
+  const int ntm = cdiv(a.M, T::BM), wg = xcd_contiguous(blockIdx.x, gridDim.x);   // neighbours on one XCD: adjacent view rows
+  const int n0 = (wg / ntm) * T::BN, m0 = (wg % ntm) * T::BM;
   // staging: piece id = tid + 256*i -> (row id / PPR, piece id % PPR)
   const unsigned char* gp[T::PPT];
   int gplane2[T::PPT];   // bytes between planes / 2 (fits an int: planes are < 4 GB apart in elements)
@@ -730,7 +771,7 @@ template <int NPL, int WM, int MT>
 inline void launch_cgemm(const CgArgs& a, hipStream_t s) {
   using T = CgTile<NPL, WM, MT>;
   rt().ensure_lds(reinterpret_cast<const void*>(&k_cgemm<NPL, WM, MT>), T::LDS);
-  dim3 grid((unsigned)cdiv(a.N, T::BN), (unsigned)cdiv(a.M, T::BM));
+  dim3 grid((unsigned)(cdiv(a.N, T::BN) * cdiv(a.M, T::BM)));
   hipLaunchKernelGGL((k_cgemm<NPL, WM, MT>), grid, dim3(256), T::LDS, s, a);
 }
 // tile by the number of GEMM rows

@@ -291,6 +291,7 @@ static void cv_wgrad(int site, const float* aplanes, const float* bplanes, float
   t.F = F * v.R;
   t.C = dW;
   t.ldc = v.M;
+  t.xcd = rt().tn_xcd >= 0 ? rt().tn_xcd : (v.M > 64 ? 1 : 0);   // measured: pays with >= 2 tiles of 128 x 256 per row chunk
   if (v.M > 64) launch_gemm_tn<NPL, TN_EPI_TRANS, 2, 2>(t, target_wgs, s);
   else if (t.N > 128) launch_gemm_tn<NPL, TN_EPI_TRANS, 1, 2>(t, target_wgs, s);
   else launch_gemm_tn<NPL, TN_EPI_TRANS, 1, 1>(t, target_wgs, s);
