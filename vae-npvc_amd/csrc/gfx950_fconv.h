@@ -1,0 +1,268 @@
+// gfx950_fconv.h -- the THIN conv / conv_transpose sites (<= 64 GEMM rows, K <= 128) as fused view GEMMs on the bf16
+// matrix cores: the geometry of gfx950_viewconv.h (overlapping-row view of channel-last planes), but the planes never
+// exist in HBM.  A workgroup owns TF whole frames:
+//   1. the fp32 frames ([C][H], optionally LayerNorm + lrelu with the stored statistics) are read ONCE, coalesced along
+//      H -- a lane owns one position and walks the channels in registers -- split into NPL bf16 terms and written as
+//      channel-last rows with zero halo into LDS (16-byte stores, no transposition scratch);
+//   2. the site's weight planes ([M][K], a few KB) are copied into LDS once;
+//   3. every wave then walks its share of the TF * R GEMM rows with NO barrier: A fragments from the resident weights,
+//      B fragments straight from the resident frames at (row, tap, channel) offsets -- the overlap between neighbouring
+//      rows (7/3 for a stride-3 conv, 3x for a transposed-conv phase stack) costs LDS reads, not HBM or L1 traffic;
+//   4. results leave the accumulators as canonical fp32 [F][C][H] (+ bias), as from the exact-fp32 engines.
+// HBM traffic = input + output, once.  These layers are HBM-bound: the exact-fp32 engines they
+// replace reach 2.1 - 3.8 TB/s because 32x32x2 MFMA tiles are mostly padding at 8 - 32 channels.
+// Reference: util/layers.py:56-64 (conv2d SAME), model/vae.py:96-99 (conv2d_transpose SAME) and their autodiff.
+#pragma once
+#include "gfx950_viewconv.h"
+
+namespace vaenpvc {
+namespace tuned {
+
+// frames per workgroup and 32-row tiles per wave step, per site (0 = site not served by this kernel)
+constexpr int fc_tf(int site) {
+  return site == CV_E1F || site == CV_D1F || site == CV_D2F || site == CV_E1G || site == CV_D1G ? 4 : site == CV_D2G ? 2 : 0;
+}
+constexpr int fc_nj(int site) { return site == CV_D2G ? 1 : 2; }
+
+template <int NPL, int SITE>
+struct FcCfg {
+  static constexpr CvSite V = CVS[SITE];
+  static constexpr ClDesc X = CLD[V.x];
+  static constexpr int C = X.C, H = X.H, CP = X.CP, HLO = X.HLO, HP = X.HP;
+  // LDS row pitch: +8 elements where the row stride would otherwise be a multiple of 64 bytes (bank conflicts)
+  static constexpr int CPL = (CP == 32 || CP == 64 || CP == 128) ? CP + 8 : CP;
+  static constexpr int FS = HP * CPL;                  // elements per frame
+  static constexpr int TF = fc_tf(SITE), NJ = fc_nj(SITE), SROWS = 32 * NJ;
+  static constexpr int XPL = TF * FS + 64;             // elements per plane (+ zero tail: K runs rounded up to 16)
+  static constexpr int K = V.NT * CP, KS = cdiv(K, 16);
+  static constexpr int MT = cdiv(V.M, 32), WP = V.Kp + 8, WPL = MT * 32 * WP;   // weight rows padded by 16 bytes
+  static constexpr int RSTEP = (V.step / CP) * CPL;    // elements between GEMM rows
+  static constexpr int LDS = NPL * (XPL + WPL) * 2;
+  static_assert(TF > 0 && C <= 32 && KS * 16 <= V.Kp, "site not served");
+};
+
+struct FcArgs {
+  const float* src;     // [F][C][H] fp32
+  const float* st;      // LN statistics (mean, rstd) per frame, or nullptr
+  const float* gamma;
+  const float* beta;
+  const unsigned short* W;   // weight planes [NPL][Mp][Kp] (cv_job)
+  const float* bias;    // [O] or nullptr
+  float* out;           // [F][OC][OH]
+  int F;
+};
+
+template <int CP, int CPL>
+__device__ __forceinline__ int fc_koff(int ks, int lh) {
+  const int k0 = 16 * ks + 8 * lh;
+  if constexpr (CPL == CP) return k0;
+  else return (k0 / CP) * CPL + (k0 % CP);
+}
+
+template <int NPL, int SITE, bool LN>
+__global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
+  using T = FcCfg<NPL, SITE>;
+  constexpr CvSite V = T::V;
+  extern __shared__ __attribute__((aligned(16))) unsigned short fsm[];
+  unsigned short* xs = fsm;                       // [NPL][XPL]
+  unsigned short* ws = fsm + NPL * T::XPL;        // [NPL][MT*32][WP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  constexpr int NCH = cdiv(T::H, 64);
+  const int ngroups = cdiv(a.F, T::TF);
+  // staging items = (frame of the group, 64-position chunk), dealt round-robin to the four waves; an item's C coalesced
+  // 256-byte loads go to registers one step ahead: the loads of group g + 1 fly during the GEMM of group g, the
+  // conversion and the 16-byte LDS stores happen at the top of the next iteration
+  constexpr int NIT = T::TF * NCH, IPW = cdiv(NIT, 4);
+  float v[IPW][T::CP];
+  float mean[IPW], rstd[IPW];
+  auto fload = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < IPW; ++u) {
+      const int it = wave + 4 * u, fl = it / NCH, k = it - fl * NCH;
+      const int f = g * T::TF + fl, h = 64 * k + lane;
+      const bool fok = it < NIT && f < a.F;
+      const float* sf = a.src + (int64_t)(fok ? f : 0) * (T::C * T::H);
+      if constexpr (LN) {
+        mean[u] = a.st[2 * (fok ? f : 0)];
+        rstd[u] = a.st[2 * (fok ? f : 0) + 1];
+      }
+#pragma unroll
+      for (int c = 0; c < T::CP; ++c) v[u][c] = (c < T::C && h < T::H && fok) ? sf[c * T::H + h] : 0.f;
+    }
+  };
+  auto fstore = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < IPW; ++u) {
+      const int it = wave + 4 * u, fl = it / NCH, k = it - fl * NCH;
+      const int h = 64 * k + lane;
+      if (!(it < NIT && g * T::TF + fl < a.F && h < T::H)) continue;
+      if constexpr (LN) {
+#pragma unroll
+        for (int c = 0; c < T::C; ++c) v[u][c] = lnact_v(v[u][c], mean[u], rstd[u], a.gamma[c], a.beta[c]);
+      }
+      unsigned short* dx = xs + fl * T::FS + (T::HLO + h) * T::CPL;
+#pragma unroll
+      for (int g8 = 0; g8 < T::CP / 8; ++g8) {
+        unsigned t[8][NPL];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split_n<NPL>(v[u][8 * g8 + j], t[j]);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+          u32x4 pk;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pk[q] = t[2 * q][p] | (t[2 * q + 1][p] << 16);
+          *reinterpret_cast<u32x4*>(dx + p * T::XPL + 8 * g8) = pk;
+        }
+      }
+    }
+  };
+  int g = blockIdx.x;
+  if (g < ngroups) fload(g);
+  // ---- once per workgroup: zero the frame tile (halo rows, channel padding, tail stay zero), copy the weights
+  {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int i = tid; i < NPL * T::XPL / 8; i += 256) reinterpret_cast<u32x4*>(xs)[i] = z;
+    constexpr int WROW8 = V.Kp / 8, WPIECES = NPL * T::MT * 32 * WROW8, WPT = cdiv(WPIECES, 256);
+    u32x4 wr[WPT];
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+      int i = tid + 256 * u;
+      i = i < WPIECES ? i : WPIECES - 1;
+      const int p = i / (T::MT * 32 * WROW8), r = i - p * (T::MT * 32 * WROW8), m = r / WROW8, c8 = r - m * WROW8;
+      wr[u] = *reinterpret_cast<const u32x4*>(a.W + ((size_t)p * V.Mp + m) * V.Kp + c8 * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+      int i = tid + 256 * u;
+      i = i < WPIECES ? i : WPIECES - 1;
+      const int p = i / (T::MT * 32 * WROW8), r = i - p * (T::MT * 32 * WROW8), m = r / WROW8, c8 = r - m * WROW8;
+      *reinterpret_cast<u32x4*>(ws + p * T::WPL + m * T::WP + c8 * 8) = wr[u];
+    }
+  }
+  __syncthreads();
+  const int woff = l31 * T::WP + lh * 8;
+  for (; g < ngroups; g += gridDim.x) {
+    const int f0 = g * T::TF, nf = min(T::TF, a.F - f0);
+    fstore(g);
+    __syncthreads();   // the group's frames are in LDS
+    if (g + (int)gridDim.x < ngroups) fload(g + gridDim.x);
+    // ---- GEMM rows n = fl * R + q, SROWS per step, steps dealt round-robin to the waves
+    const int nrows = nf * V.R, nsteps = cdiv(nrows, T::SROWS);
+    for (int s = wave; s < nsteps; s += 4) {
+      int xoff[T::NJ];
+#pragma unroll
+      for (int j = 0; j < T::NJ; ++j) {
+        int n = s * T::SROWS + j * 32 + l31;
+        n = n < nrows ? n : 0;                       // rows past the end: duplicates, never stored
+        const int fl = n / V.R, q = n - fl * V.R;
+        xoff[j] = fl * T::FS + q * T::RSTEP;
+      }
+      f32x16 acc[T::MT][T::NJ];
+#pragma unroll
+      for (int i = 0; i < T::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < T::NJ; ++j) acc[i][j] = zero16();
+#pragma unroll
+      for (int ks = 0; ks < T::KS; ++ks) {
+        u32x4 fa[T::MT][NPL], fb[T::NJ][NPL];
+        const int ko = fc_koff<T::CP, T::CPL>(ks, lh);
+#pragma unroll
+        for (int i = 0; i < T::MT; ++i)
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) fa[i][p] = *reinterpret_cast<const u32x4*>(ws + p * T::WPL + i * 32 * T::WP + woff + ks * 16);
+#pragma unroll
+        for (int j = 0; j < T::NJ; ++j)
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) fb[j][p] = *reinterpret_cast<const u32x4*>(xs + p * T::XPL + xoff[j] + ko);
+        using PR = Prod<NPL>;
+#pragma unroll
+        for (int t = 0; t < PR::N; ++t)
+#pragma unroll
+          for (int i = 0; i < T::MT; ++i)
+#pragma unroll
+            for (int j = 0; j < T::NJ; ++j) acc[i][j] = mfma_bf16(fa[i][PR::A[t]], fb[j][PR::B[t]], acc[i][j]);
+      }
+      // epilogue: accumulator rows = GEMM rows m (phase * mdiv + channel), lanes = 32 consecutive (frame, position) rows
+#pragma unroll
+      for (int j = 0; j < T::NJ; ++j) {
+        const int n = s * T::SROWS + j * 32 + l31;
+        if (n >= nrows) continue;
+        const int fl = n / V.R, q = n - fl * V.R;
+        float* ob = a.out + (int64_t)(f0 + fl) * (V.OC * V.OH);
+        const int pbase = q * V.oq + V.o0;
+        if constexpr (V.PH) {
+          // transposed conv: the three output phases of (channel, row q) sit in three registers of the SAME lane
+          // (mdiv is a multiple of 8) and are three consecutive positions: one 12-byte store per (lane, channel), 32
+          // lanes = 384 contiguous bytes, instead of three 4-byte stores at a 12-byte stride
+          static_assert(V.S == 3 && V.mdiv % 8 == 0 && V.O == V.mdiv, "phase-stacked epilogue");
+          struct __attribute__((packed, aligned(4))) f3 { float x, y, z; };
+          const bool inner = pbase >= 0 && pbase + 2 < V.OH;
+#pragma unroll
+          for (int cs = 0; cs < V.mdiv / 2; ++cs) {
+            const int chb = (cs & 3) + 8 * (cs >> 2);        // + 4 * lh
+            const int ch = chb + 4 * lh;
+            float ph[3];
+#pragma unroll
+            for (int p3 = 0; p3 < 3; ++p3) {
+              constexpr int dummy = 0;
+              (void)dummy;
+              const int mb = p3 * V.mdiv + chb;               // row of the lh = 0 lanes; lh = 1: + 4 (same tile, same register)
+              const int ti = mb / 32, row = mb % 32, reg = (row & 3) + 4 * (row >> 3);
+              ph[p3] = acc[ti][j][reg] + (a.bias ? a.bias[ch] : 0.f);
+            }
+            float* o = ob + ch * V.OH + pbase;
+            if (inner) {
+              *reinterpret_cast<f3*>(o) = f3{ph[0], ph[1], ph[2]};
+            } else {
+#pragma unroll
+              for (int p3 = 0; p3 < 3; ++p3)
+                if (pbase + p3 >= 0 && pbase + p3 < V.OH) o[p3] = ph[p3];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < T::MT; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const int m = i * 32 + acc_row(reg, lane);
+              if (m >= V.M) continue;
+              const int pim = m / V.mdiv, ch = m - pim * V.mdiv;
+              const int pos = pbase + pim;
+              if (ch < V.O && pos >= 0 && pos < V.OH) ob[ch * V.OH + pos] = acc[i][j][reg] + (a.bias ? a.bias[ch] : 0.f);
+            }
+        }
+      }
+    }
+    __syncthreads();   // all fragment reads of this group are done before the next one overwrites the tile
+  }
+}
+
+template <int NPL, int SITE>
+static void launch_fconv(const FcArgs& a, hipStream_t s) {
+  using T = FcCfg<NPL, SITE>;
+  const unsigned grid = (unsigned)cmin_(cdiv(a.F, T::TF), 512);   // persistent: two workgroups per CU walk the frame groups
+  if (a.st) {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, true>), T::LDS);
+    hipLaunchKernelGGL((k_fconv<NPL, SITE, true>), dim3(grid), dim3(256), T::LDS, s, a);
+  } else {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, false>), T::LDS);
+    hipLaunchKernelGGL((k_fconv<NPL, SITE, false>), dim3(grid), dim3(256), T::LDS, s, a);
+  }
+}
+// site dispatch (only the thin sites are instantiated)
+template <int NPL>
+static bool fconv(int site, const FcArgs& a, hipStream_t s) {
+  switch (site) {
+    case CV_E1F: launch_fconv<NPL, CV_E1F>(a, s); return true;
+    case CV_D1F: launch_fconv<NPL, CV_D1F>(a, s); return true;
+    case CV_D2F: launch_fconv<NPL, CV_D2F>(a, s); return true;
+    case CV_E1G: launch_fconv<NPL, CV_E1G>(a, s); return true;
+    case CV_D1G: launch_fconv<NPL, CV_D1G>(a, s); return true;
+    case CV_D2G: launch_fconv<NPL, CV_D2G>(a, s); return true;
+  }
+  return false;
+}
+constexpr bool fconv_serves(int site) { return fc_tf(site) > 0; }
+
+}  // namespace tuned
+}  // namespace vaenpvc

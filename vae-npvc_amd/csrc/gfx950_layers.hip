@@ -23,6 +23,7 @@
 #include "gfx950_toep_bf16.h"
 #include "gfx950_planegemm.h"
 #include "gfx950_viewconv.h"
+#include "gfx950_fconv.h"
 #include "kernels.h"
 
 namespace vaenpvc {
@@ -199,6 +200,21 @@ static inline bool pg_bwd(int64_t F) { return pg_on(rt().bwd_mask, F); }
 static inline bool cv_sel(unsigned mask, int site) { return !((mask >> 26) & 1u) || ((rt().cv_sites() >> site) & 1u); }
 static inline bool cv_fwd(int site, int64_t F) { return cg_fwd(F) && cv_sel(rt().fwd_mask, site); }
 static inline bool cv_bwd(int site, int64_t F) { return cg_bwd(F) && cv_sel(rt().bwd_mask, site); }
+// thin conv sites on the fused kernel (gfx950_fconv.h): the context's site set from FCONV_MIN_FRAMES frames on, or every
+// served site at any batch size when bit 25 of the mask is cleared (parity tests)
+constexpr int64_t FCONV_MIN_FRAMES = 1024;
+static inline bool fc_on(unsigned mask, int site, int64_t F) {
+  if (!fconv_serves(site)) return false;
+  if (!((mask >> 25) & 1u)) return true;
+  return ((rt().fc_sites() >> site) & 1u) && F >= FCONV_MIN_FRAMES;
+}
+static inline bool fc_fwd(int site, int64_t F) { return fc_on(rt().fwd_mask, site, F); }
+static inline bool fc_bwd(int site, int64_t F) { return fc_on(rt().bwd_mask, site, F); }
+static inline bool fc_any(int64_t F) {
+  for (int i = 0; i < CV_COUNT; ++i)
+    if (fc_fwd(i, F) || fc_bwd(i, F)) return true;
+  return false;
+}
 static inline bool cw_bwd(int site, int64_t F) { return cg_bwd(F) && cv_sel(rt().bwd_mask, CV_COUNT + site); }
 static inline unsigned short* us(float* p) { return reinterpret_cast<unsigned short*>(p); }
 static NtArgs nt_args(const float* Ap, int M, int Kp, const float* Bp, int Np, int N, float* C, int ldc) {
@@ -334,7 +350,7 @@ static void prep(const Model& m, const float* P, const Ws& w, int64_t F, hipStre
       pack_job(PackRepeat3{P + m.enc[4].b_off}, S + Pk::pg_bias4, 768));
   // weight planes of the conv view-GEMM sites.  TF layouts: conv [T][Cin][Cout], conv_transpose [T][Cout][Cin];
   // (s_t, s_o, s_c) = strides of (tap, GEMM output channel, contracted channel)
-  if (cg_fwd(F) || cg_bwd(F)) {
+  if (cg_fwd(F) || cg_bwd(F) || fc_any(F)) {
     auto ef = [&](int site, int i) { const ConvL& l = m.enc[i]; return cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, 1, l.cout, S + Pk::cvw + cv_woff(site)); };
     auto eg = [&](int site, int i) { const ConvL& l = m.enc[i]; return cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, l.cout, 1, S + Pk::cvw + cv_woff(site)); };
     auto df = [&](int site, int i) { const ConvL& l = m.dec[i]; return cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, l.cin, 1, S + Pk::cvw + cv_woff(site)); };
@@ -431,7 +447,7 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
   // LayerNorm statistics of layer i's output; when the next layer is a view-GEMM site its activated input planes are
   // written in the same pass over the tensor
   auto enc_stats = [&](int i, int next_site, int cl, const char* tag) {
-    const bool fuse = fwd_on(i + 1) && cv_fwd(next_site, F);
+    const bool fuse = fwd_on(i + 1) && cv_fwd(next_site, F) && !fc_fwd(next_site, F);
     if (fuse)
       for_dense_planes([&](auto npl) {
         VAENPVC_TIMED(tag, s, cv_stats_split<decltype(npl)::value>(cl, w.enc_a[i], w.enc_st[i], P + m.enc[i].gamma_off, P + m.enc[i].beta_off,
@@ -439,9 +455,18 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
       });
     return fuse;
   };
+  // thin site on the fused kernel: fp32 input (+ LayerNorm + lrelu of layer `ln`) -> fp32 output, no planes in HBM
+  auto fused = [&](int site, const float* src, const float* st, const ConvL* ln, const float* bias, float* out, const char* tag) {
+    for_dense_planes([&](auto npl) {
+      FcArgs fa{src, st, ln ? P + ln->gamma_off : nullptr, ln ? P + ln->beta_off : nullptr,
+                reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvw + cv_woff(site)), bias, out, F};
+      VAENPVC_TIMED(tag, s, fconv<decltype(npl)::value>(site, fa, s));
+    });
+  };
   bool have_y1 = false, have_y2 = false;
   if (fwd_on(1)) {
-    if (cv_fwd(CV_E1F, F)) enc_view(CV_E1F, CL_Y0, 1, false, "enc1_split", "enc1_fwd");
+    if (fc_fwd(CV_E1F, F)) fused(CV_E1F, w.enc_a[0], w.enc_st[0], &m.enc[0], P + m.enc[1].b_off, w.enc_a[1], "enc1_fwd");
+    else if (cv_fwd(CV_E1F, F)) enc_view(CV_E1F, CL_Y0, 1, false, "enc1_split", "enc1_fwd");
     else VAENPVC_TIMED("enc1_fwd", s, launch_convgemm<E1F>(lnp(1), nsplit_for<E1F>(F), s));
     if (!(have_y1 = enc_stats(1, CV_E2F, CL_Y1, "enc2_split"))) stats<1824>(w.enc_a[1], w.enc_st[1], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 1);
@@ -534,6 +559,13 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     a.nrb = MERGE_NY;
     VAENPVC_TIMED("merge_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<MergeFs>(a, s) : launch_densegemm<MergeF>(a, s)));
   } else generic::merge_fwd(m, P, z, y, F, w, s);
+  auto fused = [&](int site, const float* src, const float* st, const ConvL* ln, const float* bias, float* out, const char* tag) {
+    for_dense_planes([&](auto npl) {
+      FcArgs fa{src, st, ln ? P + ln->gamma_off : nullptr, ln ? P + ln->beta_off : nullptr,
+                reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvw + cv_woff(site)), bias, out, F};
+      VAENPVC_TIMED(tag, s, fconv<decltype(npl)::value>(site, fa, s));
+    });
+  };
   auto dec_view = [&](int site, int cl, int i, bool have, const float* src, const char* tsplit, const char* tgemm) {
     for_dense_planes([&](auto npl) {
       constexpr int NPL = decltype(npl)::value;
@@ -544,7 +576,7 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     });
   };
   auto dec_stats = [&](int i, int next_site, int cl, const char* tag) {
-    const bool fuse = fwd_on(8 + i) && cv_fwd(next_site, F);
+    const bool fuse = fwd_on(8 + i) && cv_fwd(next_site, F) && !fc_fwd(next_site, F);
     if (fuse)
       for_dense_planes([&](auto npl) {
         VAENPVC_TIMED(tag, s, cv_stats_split<decltype(npl)::value>(cl, w.dec_a[i], w.dec_st[i], P + m.dec[i].gamma_off, P + m.dec[i].beta_off,
@@ -562,7 +594,10 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
                                                                 P + m.dec[0].b_off, w.dec_a[0], F), nsplit_for<D0F>(F), s)));
     if (!(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 0);
-  if (fwd_on(8) && cv_fwd(CV_D1F, F)) {
+  if (fwd_on(8) && fc_fwd(CV_D1F, F)) {
+    fused(CV_D1F, w.dec_a[0], w.dec_st[0], &m.dec[0], P + m.dec[1].b_off, w.dec_a[1], "dec1_fwd");
+    if (!(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
+  } else if (fwd_on(8) && cv_fwd(CV_D1F, F)) {
     dec_view(CV_D1F, CL_YD0, 1, have_yd0, w.dec_a[0], "dec1_split", "dec1_fwd");
     if (!(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
   } else if (fwd_on(8)) {
@@ -572,7 +607,8 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     if (!(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 1);
   if (fwd_on(9)) {
-    if (cv_fwd(CV_D2F, F)) dec_view(CV_D2F, CL_YD1, 2, have_yd1, w.dec_a[1], "dec2_split", "dec2_fwd");
+    if (fc_fwd(CV_D2F, F)) fused(CV_D2F, w.dec_a[1], w.dec_st[1], &m.dec[1], P + m.dec[2].b_off, w.dec_a[2], "dec2_fwd");
+    else if (cv_fwd(CV_D2F, F)) dec_view(CV_D2F, CL_YD1, 2, have_yd1, w.dec_a[1], "dec2_split", "dec2_fwd");
     else
     VAENPVC_TIMED("dec2_fwd", s, launch_convgemm<D2F>(conv_args(w.dec_a[1], w.dec_st[1], P + m.dec[1].gamma_off,
                                                                 P + m.dec[1].beta_off, w.scratch + Pk::d2f,
@@ -696,6 +732,12 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       VAENPVC_TIMED(tag, s2, cv_wgrad<decltype(npl)::value>(wsite, w.cl[CWS[wsite].a], w.cl[CWS[wsite].b], dW, F, 512, s2));
     });
   };
+  auto fdgrad = [&](int site, const float* grad, float* out, const char* tag) {   // thin site on the fused kernel
+    for_dense_planes([&](auto npl) {
+      FcArgs fa{grad, nullptr, nullptr, nullptr, reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvw + cv_woff(site)), nullptr, out, F};
+      VAENPVC_TIMED(tag, s, fconv<decltype(npl)::value>(site, fa, s));
+    });
+  };
   auto vdgrad = [&](int site, float* out, const char* tag) {
     for_dense_planes([&](auto npl) {
       VAENPVC_TIMED(tag, s, cv_gemm<decltype(npl)::value>(site, w.scratch + Pk::cvw + cv_woff(site), w.cl[CVS[site].x], out, nullptr, F, s));
@@ -765,14 +807,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const ConvL &l = m.dec[2], &pl = m.dec[1];
     WgArgs a{w.d_dec_a[2], nullptr, nullptr, nullptr, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off,
              G + l.w_off, F, 0};
-    const bool vg = cv_bwd(CV_D2G, F), vw = cw_bwd(CW_D2, F);
+    const bool fg = fc_bwd(CV_D2G, F), vg = !fg && cv_bwd(CV_D2G, F), vw = cw_bwd(CW_D2, F);
     if (vg || vw) gsplit(CL_GD2, w.d_dec_a[2], "dec2_gsplit");
     if (vw && !(fwd_on(9) && cv_fwd(CV_D2F, F))) asplit(CL_YD1, w.dec_a[1], w.dec_st[1], &pl, "dec2_asplit");
     ready();
     if (vw) vwgrad(CW_D2, G + l.w_off, "dec2_wgrad");
     else VAENPVC_TIMED("dec2_wgrad", s2, launch_convwgrad<WD2>(a, WGS, s2));
     if (!dec_bias_done[2]) generic::bias_grad(w.d_dec_a[2], G + l.b_off, F, l.cout, l.hout, s);
-    if (vg) vdgrad(CV_D2G, w.dy_tmp, "dec2_dgrad");
+    if (fg) fdgrad(CV_D2G, w.d_dec_a[2], w.dy_tmp, "dec2_dgrad");
+    else if (vg) vdgrad(CV_D2G, w.dy_tmp, "dec2_dgrad");
     else
     VAENPVC_TIMED("dec2_dgrad", s, launch_convgemm<GD2>(conv_args(w.d_dec_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::gd2,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GD2>(F), s));
@@ -786,14 +829,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const ConvL &l = m.dec[1], &pl = m.dec[0];
     WgArgs a{w.d_dec_a[1], nullptr, nullptr, nullptr, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off,
              G + l.w_off, F, 0};
-    const bool vg = cv_bwd(CV_D1G, F), vw = cw_bwd(CW_D1, F);
+    const bool fg = fc_bwd(CV_D1G, F), vg = !fg && cv_bwd(CV_D1G, F), vw = cw_bwd(CW_D1, F);
     if (vg || vw) gsplit(CL_GD1, w.d_dec_a[1], "dec1_gsplit");
     if (vw && !(fwd_on(8) && cv_fwd(CV_D1F, F))) asplit(CL_YD0, w.dec_a[0], w.dec_st[0], &pl, "dec1_asplit");
     ready();
     if (vw) vwgrad(CW_D1, G + l.w_off, "dec1_wgrad");
     else VAENPVC_TIMED("dec1_wgrad", s2, launch_convwgrad<WD1>(a, WGS, s2));
     if (!dec_bias_done[1]) generic::bias_grad(w.d_dec_a[1], G + l.b_off, F, l.cout, l.hout, s);
-    if (vg) vdgrad(CV_D1G, w.dy_tmp, "dec1_dgrad");
+    if (fg) fdgrad(CV_D1G, w.d_dec_a[1], w.dy_tmp, "dec1_dgrad");
+    else if (vg) vdgrad(CV_D1G, w.dy_tmp, "dec1_dgrad");
     else
     VAENPVC_TIMED("dec1_dgrad", s, launch_convgemm<GD1>(conv_args(w.d_dec_a[1], nullptr, nullptr, nullptr, P + l.w_off, nullptr,
                                                                   w.dy_tmp, F), nsplit_for<GD1>(F), s));
@@ -983,14 +1027,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 2);
   if (bwd_on(1)) {
     const ConvL &l = m.enc[1], &pl = m.enc[0];
-    const bool vg = cv_bwd(CV_E1G, F), vw = cw_bwd(CW_E1, F);
+    const bool fg = fc_bwd(CV_E1G, F), vg = !fg && cv_bwd(CV_E1G, F), vw = cw_bwd(CW_E1, F);
     if (vg || vw) gsplit(CL_GE1, w.d_enc_a[1], "enc1_gsplit");
     if (vw && !(fwd_on(1) && cv_fwd(CV_E1F, F))) asplit(CL_Y0, w.enc_a[0], w.enc_st[0], &pl, "enc1_asplit");
     ready();
     if (vw) vwgrad(CW_E1, G + l.w_off, "enc1_wgrad");
     else VAENPVC_TIMED("enc1_wgrad", s2, launch_convwgrad<WE1>(wg_enc(1), WGS, s2));
     if (!enc_bias_done[1]) generic::bias_grad(w.d_enc_a[1], G + l.b_off, F, l.cout, l.hout, s);
-    if (vg) vdgrad(CV_E1G, w.dy_tmp, "enc1_dgrad");
+    if (fg) fdgrad(CV_E1G, w.d_enc_a[1], w.dy_tmp, "enc1_dgrad");
+    else if (vg) vdgrad(CV_E1G, w.dy_tmp, "enc1_dgrad");
     else
     VAENPVC_TIMED("enc1_dgrad", s, launch_convgemm<GE1>(conv_args(w.d_enc_a[1], nullptr, nullptr, nullptr, w.scratch + Pk::ge1,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE1>(F), s));
