@@ -20,9 +20,14 @@ namespace tuned {
 
 // frames per workgroup and 32-row tiles per wave step, per site (0 = site not served by this kernel)
 constexpr int fc_tf(int site) {
-  return site == CV_E1F || site == CV_D1F || site == CV_D2F || site == CV_E1G || site == CV_D1G ? 4 : site == CV_D2G ? 2 : 0;
+  return site == CV_E1F || site == CV_D1F || site == CV_D2F || site == CV_E1G || site == CV_D1G ? 4
+         : site == CV_D2G ? 2
+         : site == CV_E2G ? 6   // a medium site: weights + frames fill most of the LDS (one workgroup per CU with 2 planes)
+                          : 0;
 }
-constexpr int fc_nj(int site) { return site == CV_D2G ? 1 : 2; }
+// (encoder layer 2 FORWARD was tried the same way and dropped: 417 us against 255 us on the fp32 engine -- K = 224
+//  against 64 rows: two waves per M tile re-read every B fragment, one workgroup per CU)
+constexpr int fc_nj(int site) { return site == CV_D2G || site == CV_E2G ? 1 : 2; }
 
 template <int NPL, int SITE>
 struct FcCfg {
@@ -38,7 +43,7 @@ struct FcCfg {
   static constexpr int MT = cdiv(V.M, 32), WP = V.Kp + 8, WPL = MT * 32 * WP;   // weight rows padded by 16 bytes
   static constexpr int RSTEP = (V.step / CP) * CPL;    // elements between GEMM rows
   static constexpr int LDS = NPL * (XPL + WPL) * 2;
-  static_assert(TF > 0 && C <= 32 && KS * 16 <= V.Kp, "site not served");
+  static_assert(TF > 0 && C <= 64 && KS * 16 <= V.Kp, "site not served");
 };
 
 struct FcArgs {
@@ -240,7 +245,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
 template <int NPL, int SITE>
 static void launch_fconv(const FcArgs& a, hipStream_t s) {
   using T = FcCfg<NPL, SITE>;
-  const unsigned grid = (unsigned)cmin_(cdiv(a.F, T::TF), 512);   // persistent: two workgroups per CU walk the frame groups
+  const unsigned grid = (unsigned)cmin_(cdiv(a.F, T::TF), T::LDS > 80 * 1024 ? 256 : 512);   // persistent: two workgroups per CU walk the frame groups
   if (a.st) {
     rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, true>), T::LDS);
     hipLaunchKernelGGL((k_fconv<NPL, SITE, true>), dim3(grid), dim3(256), T::LDS, s, a);
@@ -259,10 +264,17 @@ static bool fconv(int site, const FcArgs& a, hipStream_t s) {
     case CV_E1G: launch_fconv<NPL, CV_E1G>(a, s); return true;
     case CV_D1G: launch_fconv<NPL, CV_D1G>(a, s); return true;
     case CV_D2G: launch_fconv<NPL, CV_D2G>(a, s); return true;
+    case CV_E2G:
+      if constexpr (NPL <= 2) {
+        launch_fconv<NPL, CV_E2G>(a, s);
+        return true;
+      }
+      return false;
   }
   return false;
 }
-constexpr bool fconv_serves(int site) { return fc_tf(site) > 0; }
+// served with `npl` operand planes (the medium site does not fit the LDS with three)
+constexpr bool fconv_serves(int site, int npl) { return fc_tf(site) > 0 && !(site == CV_E2G && npl > 2); }
 
 }  // namespace tuned
 }  // namespace vaenpvc

@@ -204,7 +204,7 @@ static inline bool cv_bwd(int site, int64_t F) { return cg_bwd(F) && cv_sel(rt()
 // served site at any batch size when bit 25 of the mask is cleared (parity tests)
 constexpr int64_t FCONV_MIN_FRAMES = 1024;
 static inline bool fc_on(unsigned mask, int site, int64_t F) {
-  if (!fconv_serves(site)) return false;
+  if (!fconv_serves(site, rt().dense_planes ? rt().dense_planes : rt().planes)) return false;
   if (!((mask >> 25) & 1u)) return true;
   return ((rt().fc_sites() >> site) & 1u) && F >= FCONV_MIN_FRAMES;
 }
@@ -215,6 +215,8 @@ static inline bool fc_any(int64_t F) {
     if (fc_fwd(i, F) || fc_bwd(i, F)) return true;
   return false;
 }
+// the forward pass left the channel-last planes of a site's input behind (view GEMM selected and not overridden by the fused kernel)
+static inline bool fwd_planes(int bit, int site, int64_t F) { return ((rt().fwd_mask >> bit) & 1u) && cv_fwd(site, F) && !fc_fwd(site, F); }
 static inline bool cw_bwd(int site, int64_t F) { return cg_bwd(F) && cv_sel(rt().bwd_mask, CV_COUNT + site); }
 static inline unsigned short* us(float* p) { return reinterpret_cast<unsigned short*>(p); }
 static NtArgs nt_args(const float* Ap, int M, int Kp, const float* Bp, int Np, int N, float* C, int ldc) {
@@ -809,7 +811,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
              G + l.w_off, F, 0};
     const bool fg = fc_bwd(CV_D2G, F), vg = !fg && cv_bwd(CV_D2G, F), vw = cw_bwd(CW_D2, F);
     if (vg || vw) gsplit(CL_GD2, w.d_dec_a[2], "dec2_gsplit");
-    if (vw && !(fwd_on(9) && cv_fwd(CV_D2F, F))) asplit(CL_YD1, w.dec_a[1], w.dec_st[1], &pl, "dec2_asplit");
+    if (vw && !fwd_planes(9, CV_D2F, F)) asplit(CL_YD1, w.dec_a[1], w.dec_st[1], &pl, "dec2_asplit");
     ready();
     if (vw) vwgrad(CW_D2, G + l.w_off, "dec2_wgrad");
     else VAENPVC_TIMED("dec2_wgrad", s2, launch_convwgrad<WD2>(a, WGS, s2));
@@ -831,7 +833,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
              G + l.w_off, F, 0};
     const bool fg = fc_bwd(CV_D1G, F), vg = !fg && cv_bwd(CV_D1G, F), vw = cw_bwd(CW_D1, F);
     if (vg || vw) gsplit(CL_GD1, w.d_dec_a[1], "dec1_gsplit");
-    if (vw && !(fwd_on(8) && cv_fwd(CV_D1F, F))) asplit(CL_YD0, w.dec_a[0], w.dec_st[0], &pl, "dec1_asplit");
+    if (vw && !fwd_planes(8, CV_D1F, F)) asplit(CL_YD0, w.dec_a[0], w.dec_st[0], &pl, "dec1_asplit");
     ready();
     if (vw) vwgrad(CW_D1, G + l.w_off, "dec1_wgrad");
     else VAENPVC_TIMED("dec1_wgrad", s2, launch_convwgrad<WD1>(a, WGS, s2));
@@ -852,7 +854,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     WgArgs a{w.d_dec_a[0], nullptr, nullptr, nullptr, w.h, nullptr, nullptr, nullptr, G + l.w_off, F, 0};
     const bool vg = cv_bwd(CV_D0G, F), vw = cw_bwd(CW_D0, F);
     if (vg || vw) gsplit(CL_GD0, w.d_dec_a[0], "dec0_gsplit");
-    if (vw && !(fwd_on(7) && cv_fwd(CV_D0F, F))) asplit(CL_H, w.h, nullptr, nullptr, "dec0_asplit");
+    if (vw && !fwd_planes(7, CV_D0F, F)) asplit(CL_H, w.h, nullptr, nullptr, "dec0_asplit");
     ready();
     if (vw) vwgrad(CW_D0, G + l.w_off, "dec0_wgrad");
     else VAENPVC_TIMED("dec0_wgrad", s2, launch_convwgrad<WD0>(a, WGS, s2));
@@ -993,7 +995,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const ConvL &l = m.enc[3], &pl = m.enc[2];
     const bool vg = cv_bwd(CV_E3G, F), vw = cw_bwd(CW_E3, F);
     if (vg || vw) gsplit(CL_GE3, w.d_enc_a[3], "enc3_gsplit");
-    if (vw && !(fwd_on(3) && cv_fwd(CV_E3F, F))) asplit(CL_Y2, w.enc_a[2], w.enc_st[2], &pl, "enc3_asplit");
+    if (vw && !fwd_planes(3, CV_E3F, F)) asplit(CL_Y2, w.enc_a[2], w.enc_st[2], &pl, "enc3_asplit");
     ready();
     if (vw) vwgrad(CW_E3, G + l.w_off, "enc3_wgrad");
     else VAENPVC_TIMED("enc3_wgrad", s2, launch_convwgrad<WE3>(wg_enc(3), WGS, s2));
@@ -1009,14 +1011,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 3);
   if (bwd_on(2)) {
     const ConvL &l = m.enc[2], &pl = m.enc[1];
-    const bool vg = cv_bwd(CV_E2G, F), vw = cw_bwd(CW_E2, F);
+    const bool fg = fc_bwd(CV_E2G, F), vg = !fg && cv_bwd(CV_E2G, F), vw = cw_bwd(CW_E2, F);
     if (vg || vw) gsplit(CL_GE2, w.d_enc_a[2], "enc2_gsplit");
-    if (vw && !(fwd_on(2) && cv_fwd(CV_E2F, F))) asplit(CL_Y1, w.enc_a[1], w.enc_st[1], &pl, "enc2_asplit");
+    if (vw && !fwd_planes(2, CV_E2F, F)) asplit(CL_Y1, w.enc_a[1], w.enc_st[1], &pl, "enc2_asplit");
     ready();
     if (vw) vwgrad(CW_E2, G + l.w_off, "enc2_wgrad");
     else VAENPVC_TIMED("enc2_wgrad", s2, launch_convwgrad<WE2>(wg_enc(2), WGS, s2));
     if (!enc_bias_done[2]) generic::bias_grad(w.d_enc_a[2], G + l.b_off, F, l.cout, l.hout, s);
-    if (vg) vdgrad(CV_E2G, w.dy_tmp, "enc2_dgrad");
+    if (fg) fdgrad(CV_E2G, w.d_enc_a[2], w.dy_tmp, "enc2_dgrad");
+    else if (vg) vdgrad(CV_E2G, w.dy_tmp, "enc2_dgrad");
     else
     VAENPVC_TIMED("enc2_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<GE2s>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE2s>(F), s) : launch_convgemm<GE2>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
@@ -1029,7 +1032,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const ConvL &l = m.enc[1], &pl = m.enc[0];
     const bool fg = fc_bwd(CV_E1G, F), vg = !fg && cv_bwd(CV_E1G, F), vw = cw_bwd(CW_E1, F);
     if (vg || vw) gsplit(CL_GE1, w.d_enc_a[1], "enc1_gsplit");
-    if (vw && !(fwd_on(1) && cv_fwd(CV_E1F, F))) asplit(CL_Y0, w.enc_a[0], w.enc_st[0], &pl, "enc1_asplit");
+    if (vw && !fwd_planes(1, CV_E1F, F)) asplit(CL_Y0, w.enc_a[0], w.enc_st[0], &pl, "enc1_asplit");
     ready();
     if (vw) vwgrad(CW_E1, G + l.w_off, "enc1_wgrad");
     else VAENPVC_TIMED("enc1_wgrad", s2, launch_convwgrad<WE1>(wg_enc(1), WGS, s2));

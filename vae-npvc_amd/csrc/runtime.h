@@ -27,7 +27,7 @@ struct Runtime {
   // weight-gradient sites 12..17); -1 = the measured default of the precision (VAENPVC_CV_SITES overrides)
   long cv_sites_env = -1, fc_sites_env = -1;   // (VAENPVC_FC_SITES: thin sites on the fused kernel, gfx950_fconv.h)
   unsigned fc_sites() const { return fc_sites_env >= 0 ? (unsigned)fc_sites_env : planes == 1 ? FC_SITES_BF16 : FC_SITES; }
-  static constexpr unsigned FC_SITES = 0xd31u, FC_SITES_BF16 = 0xd31u;   // by measurement
+  static constexpr unsigned FC_SITES = 0xdb1u, FC_SITES_BF16 = 0xdb1u;   // by measurement
   unsigned cv_sites() const { return cv_sites_env >= 0 ? (unsigned)cv_sites_env : planes == 1 ? CV_SITES_BF16 : planes == 2 ? CV_SITES_X2 : CV_SITES_X3; }
   static constexpr unsigned CV_SITES_BF16 = 0xe2ceu, CV_SITES_X2 = 0xc244u, CV_SITES_X3 = 0x4u;  // by measurement
   int tn_xcd = -1;              // VAENPVC_TN_XCD=0|1: tile order of the C += A^T B plane GEMM (experiments; -1 = per site)
