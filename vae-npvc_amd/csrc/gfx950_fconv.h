@@ -49,6 +49,8 @@ struct FcCfg {
 struct FcArgs {
   const float* src;     // [F][C][H] fp32
   const float* st;      // LN statistics (mean, rstd) per frame, or nullptr
+  float* st_out;        // non-null: the statistics are computed HERE from the staged frames (two-pass, in registers) and
+                        // stored -- the workgroup owns whole frames, so the separate statistics pass over the tensor goes away
   const float* gamma;
   const float* beta;
   const unsigned short* W;   // weight planes [NPL][Mp][Kp] (cv_job)
@@ -64,11 +66,13 @@ __device__ __forceinline__ int fc_koff(int ks, int lh) {
   else return (k0 / CP) * CPL + (k0 % CP);
 }
 
-template <int NPL, int SITE, bool LN>
+// LN: 0 plain input, 1 LayerNorm + lrelu with given statistics, 2 ... with statistics computed here
+template <int NPL, int SITE, int LN>
 __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
   using T = FcCfg<NPL, SITE>;
   constexpr CvSite V = T::V;
   extern __shared__ __attribute__((aligned(16))) unsigned short fsm[];
+  __shared__ float part[2][FcCfg<NPL, SITE>::TF * cdiv(FcCfg<NPL, SITE>::H, 64)];   // per staging item: sum, sum of squared deviations
   unsigned short* xs = fsm;                       // [NPL][XPL]
   unsigned short* ws = fsm + NPL * T::XPL;        // [NPL][MT*32][WP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -87,7 +91,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
       const int f = g * T::TF + fl, h = 64 * k + lane;
       const bool fok = it < NIT && f < a.F;
       const float* sf = a.src + (int64_t)(fok ? f : 0) * (T::C * T::H);
-      if constexpr (LN) {
+      if constexpr (LN == 1) {
         mean[u] = a.st[2 * (fok ? f : 0)];
         rstd[u] = a.st[2 * (fok ? f : 0) + 1];
       }
@@ -95,13 +99,60 @@ __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
       for (int c = 0; c < T::CP; ++c) v[u][c] = (c < T::C && h < T::H && fok) ? sf[c * T::H + h] : 0.f;
     }
   };
+  // LayerNorm statistics of the group's frames from the registers (LN == 2): per item partial sums through LDS, two
+  // workgroup barriers; mean first, then the centred second moment (as k_ln_stats_fast)
+  auto fstats = [&](int g) __attribute__((always_inline)) {
+    constexpr float INVN = 1.0f / (T::C * T::H);
+#pragma unroll
+    for (int u = 0; u < IPW; ++u) {
+      const int it = wave + 4 * u;
+      float sm = 0.f;
+#pragma unroll
+      for (int c = 0; c < T::C; ++c) sm += v[u][c];       // (invalid lanes / frames hold zeros)
+      sm = wave_sum(sm);
+      if (lane == 0 && it < NIT) part[0][it] = sm;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < IPW; ++u) {
+      const int it = wave + 4 * u, fl = (it < NIT ? it : 0) / NCH, k = it - fl * NCH;
+      float sm = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < NCH; ++kk) sm += part[0][fl * NCH + kk];
+      mean[u] = sm * INVN;
+      const bool ok = 64 * k + lane < T::H;
+      float q = 0.f;
+#pragma unroll
+      for (int c = 0; c < T::C; ++c) {
+        const float d = v[u][c] - mean[u];
+        q += ok ? d * d : 0.f;
+      }
+      q = wave_sum(q);
+      if (lane == 0 && it < NIT) part[1][it] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < IPW; ++u) {
+      const int it = wave + 4 * u, fl = (it < NIT ? it : 0) / NCH, k = it - fl * NCH;
+      float q = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < NCH; ++kk) q += part[1][fl * NCH + kk];
+      rstd[u] = 1.0f / sqrtf(q * INVN + LN_EPS);
+      const int f = g * T::TF + fl;
+      if (lane == 0 && it < NIT && k == 0 && f < a.F) {
+        a.st_out[2 * f] = mean[u];
+        a.st_out[2 * f + 1] = rstd[u];
+      }
+    }
+  };
   auto fstore = [&](int g) __attribute__((always_inline)) {
+    if constexpr (LN == 2) fstats(g);
 #pragma unroll
     for (int u = 0; u < IPW; ++u) {
       const int it = wave + 4 * u, fl = it / NCH, k = it - fl * NCH;
       const int h = 64 * k + lane;
       if (!(it < NIT && g * T::TF + fl < a.F && h < T::H)) continue;
-      if constexpr (LN) {
+      if constexpr (LN != 0) {
 #pragma unroll
         for (int c = 0; c < T::C; ++c) v[u][c] = lnact_v(v[u][c], mean[u], rstd[u], a.gamma[c], a.beta[c]);
       }
@@ -246,12 +297,15 @@ template <int NPL, int SITE>
 static void launch_fconv(const FcArgs& a, hipStream_t s) {
   using T = FcCfg<NPL, SITE>;
   const unsigned grid = (unsigned)cmin_(cdiv(a.F, T::TF), T::LDS > 80 * 1024 ? 256 : 512);   // persistent: two workgroups per CU walk the frame groups
-  if (a.st) {
-    rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, true>), T::LDS);
-    hipLaunchKernelGGL((k_fconv<NPL, SITE, true>), dim3(grid), dim3(256), T::LDS, s, a);
+  if (a.st_out) {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, 2>), T::LDS);
+    hipLaunchKernelGGL((k_fconv<NPL, SITE, 2>), dim3(grid), dim3(256), T::LDS, s, a);
+  } else if (a.st) {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, 1>), T::LDS);
+    hipLaunchKernelGGL((k_fconv<NPL, SITE, 1>), dim3(grid), dim3(256), T::LDS, s, a);
   } else {
-    rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, false>), T::LDS);
-    hipLaunchKernelGGL((k_fconv<NPL, SITE, false>), dim3(grid), dim3(256), T::LDS, s, a);
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, 0>), T::LDS);
+    hipLaunchKernelGGL((k_fconv<NPL, SITE, 0>), dim3(grid), dim3(256), T::LDS, s, a);
   }
 }
 // site dispatch (only the thin sites are instantiated)

@@ -317,6 +317,12 @@ static void prep(const Model& m, const float* P, const Ws& w, int64_t F, hipStre
   constexpr int NPL = decltype(npl)::value;
   for_dense_planes([&](auto npd) {
   constexpr int NPD = decltype(npd)::value;
+  // (plane copies of the dense-shaped layers only when the plane GEMMs run at this batch size)
+  const bool dense_planes_used = pg_fwd(F) || pg_bwd(F);
+  auto pj = [&](auto j) {
+    if (!dense_planes_used) j.count = 0;
+    return j;
+  };
   launch_pack_multi(
       s,
       pack_job(PackDense{P + m.wmu_off, P + m.wlv_off, 0, 768, 256, HeadsF::NP, 128, 128}, S + Pk::heads_f, HeadsF::KP * HeadsF::NP),
@@ -343,20 +349,29 @@ static void prep(const Model& m, const float* P, const Ws& w, int64_t F, hipStre
       PackToepBf16Job<false, NPL>{P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wdg), !rt().toep_f32 ? NTB : 0},
       PackToepBf16Job<true, NPL>{P + m.dec[3].w_off, reinterpret_cast<unsigned short*>(S + Pk::wfw), !rt().toep_f32 ? NTB : 0},
       // weight planes of the dense-shaped layers
-      planes_job<NPD>(WHeadsF{P + m.wmu_off, P + m.wlv_off}, S + Pk::pg_headsf, 256, 768),
-      planes_job<NPD>(WHeadsB{P + m.wmu_off, P + m.wlv_off}, S + Pk::pg_headsb, 768, 256),
-      planes_job<NPD>(WMergeF{P + m.wz_off, 1539}, S + Pk::pg_mergef, 1664, 128),
-      planes_job<NPD>(WMergeB{P + m.wz_off, 1539}, S + Pk::pg_mergeb, 128, 1600),
-      planes_job<NPD>(WEnc4F{P + m.enc[4].w_off}, S + Pk::pg_enc4f, 768, 896),
-      planes_job<NPD>(WEnc4B{P + m.enc[4].w_off}, S + Pk::pg_enc4b, 896, 768),
+      pj(planes_job<NPD>(WHeadsF{P + m.wmu_off, P + m.wlv_off}, S + Pk::pg_headsf, 256, 768)),
+      pj(planes_job<NPD>(WHeadsB{P + m.wmu_off, P + m.wlv_off}, S + Pk::pg_headsb, 768, 256)),
+      pj(planes_job<NPD>(WMergeF{P + m.wz_off, 1539}, S + Pk::pg_mergef, 1664, 128)),
+      pj(planes_job<NPD>(WMergeB{P + m.wz_off, 1539}, S + Pk::pg_mergeb, 128, 1600)),
+      pj(planes_job<NPD>(WEnc4F{P + m.enc[4].w_off}, S + Pk::pg_enc4f, 768, 896)),
+      pj(planes_job<NPD>(WEnc4B{P + m.enc[4].w_off}, S + Pk::pg_enc4b, 896, 768)),
       pack_job(PackRepeat3{P + m.enc[4].b_off}, S + Pk::pg_bias4, 768));
   // weight planes of the conv view-GEMM sites.  TF layouts: conv [T][Cin][Cout], conv_transpose [T][Cout][Cin];
   // (s_t, s_o, s_c) = strides of (tap, GEMM output channel, contracted channel)
   if (cg_fwd(F) || cg_bwd(F) || fc_any(F)) {
-    auto ef = [&](int site, int i) { const ConvL& l = m.enc[i]; return cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, 1, l.cout, S + Pk::cvw + cv_woff(site)); };
-    auto eg = [&](int site, int i) { const ConvL& l = m.enc[i]; return cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, l.cout, 1, S + Pk::cvw + cv_woff(site)); };
-    auto df = [&](int site, int i) { const ConvL& l = m.dec[i]; return cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, l.cin, 1, S + Pk::cvw + cv_woff(site)); };
-    auto dg = [&](int site, int i) { const ConvL& l = m.dec[i]; return cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, 1, l.cin, S + Pk::cvw + cv_woff(site)); };
+    // only the sites some kernel of this step reads (count 0 = job skipped)
+    auto used = [&](int site, bool fwd_dir) {
+      return fwd_dir ? (cv_fwd(site, F) || fc_fwd(site, F)) : (cv_bwd(site, F) || fc_bwd(site, F));
+    };
+    auto job = [&](int site, bool fwd_dir, const ConvL& l, int s_o, int s_c) {
+      auto j = cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, s_o, s_c, S + Pk::cvw + cv_woff(site));
+      if (!used(site, fwd_dir)) j.count = 0;
+      return j;
+    };
+    auto ef = [&](int site, int i) { const ConvL& l = m.enc[i]; return job(site, true, l, 1, l.cout); };
+    auto eg = [&](int site, int i) { const ConvL& l = m.enc[i]; return job(site, false, l, l.cout, 1); };
+    auto df = [&](int site, int i) { const ConvL& l = m.dec[i]; return job(site, true, l, l.cin, 1); };
+    auto dg = [&](int site, int i) { const ConvL& l = m.dec[i]; return job(site, false, l, 1, l.cin); };
     launch_pack_multi(s, ef(CV_E1F, 1), ef(CV_E2F, 2), ef(CV_E3F, 3), df(CV_D0F, 0), df(CV_D1F, 1), df(CV_D2F, 2),
                       eg(CV_E3G, 3), eg(CV_E2G, 2), eg(CV_E1G, 1), dg(CV_D0G, 0), dg(CV_D1G, 1), dg(CV_D2G, 2));
   }
@@ -458,16 +473,16 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
     return fuse;
   };
   // thin site on the fused kernel: fp32 input (+ LayerNorm + lrelu of layer `ln`) -> fp32 output, no planes in HBM
-  auto fused = [&](int site, const float* src, const float* st, const ConvL* ln, const float* bias, float* out, const char* tag) {
+  auto fused = [&](int site, const float* src, const float* st, float* st_out, const ConvL* ln, const float* bias, float* out, const char* tag) {
     for_dense_planes([&](auto npl) {
-      FcArgs fa{src, st, ln ? P + ln->gamma_off : nullptr, ln ? P + ln->beta_off : nullptr,
+      FcArgs fa{src, st, st_out, ln ? P + ln->gamma_off : nullptr, ln ? P + ln->beta_off : nullptr,
                 reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvw + cv_woff(site)), bias, out, F};
       VAENPVC_TIMED(tag, s, fconv<decltype(npl)::value>(site, fa, s));
     });
   };
   bool have_y1 = false, have_y2 = false;
   if (fwd_on(1)) {
-    if (fc_fwd(CV_E1F, F)) fused(CV_E1F, w.enc_a[0], w.enc_st[0], &m.enc[0], P + m.enc[1].b_off, w.enc_a[1], "enc1_fwd");
+    if (fc_fwd(CV_E1F, F)) fused(CV_E1F, w.enc_a[0], w.enc_st[0], nullptr, &m.enc[0], P + m.enc[1].b_off, w.enc_a[1], "enc1_fwd");
     else if (cv_fwd(CV_E1F, F)) enc_view(CV_E1F, CL_Y0, 1, false, "enc1_split", "enc1_fwd");
     else VAENPVC_TIMED("enc1_fwd", s, launch_convgemm<E1F>(lnp(1), nsplit_for<E1F>(F), s));
     if (!(have_y1 = enc_stats(1, CV_E2F, CL_Y1, "enc2_split"))) stats<1824>(w.enc_a[1], w.enc_st[1], F, s);
@@ -561,9 +576,9 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     a.nrb = MERGE_NY;
     VAENPVC_TIMED("merge_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<MergeFs>(a, s) : launch_densegemm<MergeF>(a, s)));
   } else generic::merge_fwd(m, P, z, y, F, w, s);
-  auto fused = [&](int site, const float* src, const float* st, const ConvL* ln, const float* bias, float* out, const char* tag) {
+  auto fused = [&](int site, const float* src, const float* st, float* st_out, const ConvL* ln, const float* bias, float* out, const char* tag) {
     for_dense_planes([&](auto npl) {
-      FcArgs fa{src, st, ln ? P + ln->gamma_off : nullptr, ln ? P + ln->beta_off : nullptr,
+      FcArgs fa{src, st, st_out, ln ? P + ln->gamma_off : nullptr, ln ? P + ln->beta_off : nullptr,
                 reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvw + cv_woff(site)), bias, out, F};
       VAENPVC_TIMED(tag, s, fconv<decltype(npl)::value>(site, fa, s));
     });
@@ -587,29 +602,31 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     return fuse;
   };
   bool have_yd0 = false, have_yd1 = false;
+  // a fused consumer takes the LayerNorm statistics of its input itself (it owns whole frames): no statistics pass
+  const bool d1_fused = fwd_on(8) && fc_fwd(CV_D1F, F), d2_fused = fwd_on(9) && fc_fwd(CV_D2F, F);
   if (fwd_on(7) && cv_fwd(CV_D0F, F)) {
     dec_view(CV_D0F, CL_H, 0, false, w.h, "dec0_split", "dec0_fwd");
-    if (!(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
+    if (!d1_fused && !(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
   } else if (fwd_on(7)) {
     VAENPVC_TIMED("dec0_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<D0Fs>(conv_args(w.h, nullptr, nullptr, nullptr, w.scratch + Pk::d0f,
                                                                 P + m.dec[0].b_off, w.dec_a[0], F), nsplit_for<D0Fs>(F), s) : launch_convgemm<D0F>(conv_args(w.h, nullptr, nullptr, nullptr, w.scratch + Pk::d0f,
                                                                 P + m.dec[0].b_off, w.dec_a[0], F), nsplit_for<D0F>(F), s)));
-    if (!(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
+    if (!d1_fused && !(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 0);
   if (fwd_on(8) && fc_fwd(CV_D1F, F)) {
-    fused(CV_D1F, w.dec_a[0], w.dec_st[0], &m.dec[0], P + m.dec[1].b_off, w.dec_a[1], "dec1_fwd");
-    if (!(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
+    fused(CV_D1F, w.dec_a[0], nullptr, w.dec_st[0], &m.dec[0], P + m.dec[1].b_off, w.dec_a[1], "dec1_fwd");
+    if (!d2_fused && !(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
   } else if (fwd_on(8) && cv_fwd(CV_D1F, F)) {
     dec_view(CV_D1F, CL_YD0, 1, have_yd0, w.dec_a[0], "dec1_split", "dec1_fwd");
-    if (!(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
+    if (!d2_fused && !(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
   } else if (fwd_on(8)) {
     VAENPVC_TIMED("dec1_fwd", s, launch_convgemm<D1F>(conv_args(w.dec_a[0], w.dec_st[0], P + m.dec[0].gamma_off,
                                                                 P + m.dec[0].beta_off, w.scratch + Pk::d1f,
                                                                 P + m.dec[1].b_off, w.dec_a[1], F), nsplit_for<D1F>(F), s));
-    if (!(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
+    if (!d2_fused && !(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 1);
   if (fwd_on(9)) {
-    if (fc_fwd(CV_D2F, F)) fused(CV_D2F, w.dec_a[1], w.dec_st[1], &m.dec[1], P + m.dec[2].b_off, w.dec_a[2], "dec2_fwd");
+    if (fc_fwd(CV_D2F, F)) fused(CV_D2F, w.dec_a[1], nullptr, w.dec_st[1], &m.dec[1], P + m.dec[2].b_off, w.dec_a[2], "dec2_fwd");
     else if (cv_fwd(CV_D2F, F)) dec_view(CV_D2F, CL_YD1, 2, have_yd1, w.dec_a[1], "dec2_split", "dec2_fwd");
     else
     VAENPVC_TIMED("dec2_fwd", s, launch_convgemm<D2F>(conv_args(w.dec_a[1], w.dec_st[1], P + m.dec[1].gamma_off,
@@ -736,7 +753,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   };
   auto fdgrad = [&](int site, const float* grad, float* out, const char* tag) {   // thin site on the fused kernel
     for_dense_planes([&](auto npl) {
-      FcArgs fa{grad, nullptr, nullptr, nullptr, reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvw + cv_woff(site)), nullptr, out, F};
+      FcArgs fa{grad, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvw + cv_woff(site)), nullptr, out, F};
       VAENPVC_TIMED(tag, s, fconv<decltype(npl)::value>(site, fa, s));
     });
   };
@@ -760,7 +777,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
           if (!rt().toep_wgrad_k16) {   // 32-frame chunks: two k-steps per barrier
             const int fch32 = rup(cdiv((int)F, zc), W2_KF);
             rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_wgrad_bf16_k32<NPL>), w2_lds(NPL));
-            VAENPVC_TIMED("dec3_wgrad", s2, hipLaunchKernelGGL(k_toep_wgrad_bf16_k32<NPL>, dim3(8, TB_C, (unsigned)cdiv((int)F, fch32)), dim3(512),
+            VAENPVC_TIMED("dec3_wgrad", s2, hipLaunchKernelGGL(k_toep_wgrad_bf16_k32<NPL>, dim3(8 * TB_C * (unsigned)cdiv((int)F, fch32)), dim3(512),
                                                               w2_lds(NPL), s2, reinterpret_cast<const unsigned short*>(w.toep_yp), gp,
                                                               G + m.dec[3].w_off, (int)F, fch32));
             return;

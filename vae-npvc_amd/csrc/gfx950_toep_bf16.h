@@ -775,9 +775,13 @@ __global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16_k32(const unsigned s
   constexpr int APL = W2_KF * WG_RSA, BPL = W2_KF * WG_RSB, BUF = w2_buf(NPL);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int wr = wave >> 2, wc = wave & 3;
-  const int i0 = (blockIdx.x >> 1) * 128, q0 = (blockIdx.x & 1) * 256, c = blockIdx.y;
-  const bool strip = (blockIdx.x & 1) != 0;  // uniform: this workgroup also owns q = 512
-  const int fb = blockIdx.z * fchunk, fe = min(F, fb + fchunk);
+  // XCD-aware order (1-D grid; workgroup b runs on XCD b % 8): XCD = channel, and on an XCD the 8 tiles of one frame
+  // chunk run back to back -- a channel's y planes are then fetched into ONE L2 (both q tiles of an i range share
+  // them there) instead of two; the small d(xh) planes are fetched by every XCD from the Infinity Cache
+  const int c = blockIdx.x & 7, tl = (blockIdx.x >> 3) & 7, zc = blockIdx.x >> 6;
+  const int i0 = (tl >> 1) * 128, q0 = (tl & 1) * 256;
+  const bool strip = (tl & 1) != 0;  // uniform: this workgroup also owns q = 512
+  const int fb = zc * fchunk, fe = min(F, fb + fchunk);
   // staging of one 32-frame chunk (16-byte pieces): A 32 rows x 16 pieces: one per thread and plane;
   // B 32 rows x 32 pieces: two per thread and plane (rows brow, brow + 16); strip: 32 rows x 2 pieces x NPL: threads < 64*NPL
   const int arow = tid >> 4, apc = tid & 15;

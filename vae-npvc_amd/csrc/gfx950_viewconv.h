@@ -207,12 +207,39 @@ constexpr int cv_woff(int site) {
 }
 constexpr int CV_WTOTAL = cv_woff(CV_COUNT);
 
-// weight-plane pack job of a site; (s_t, s_o, s_c) address the TF kernel tensor by (tap, GEMM output channel, contracted channel)
+// weight-plane pack job of a site (a job of k_pack_multi); (s_t, s_o, s_c) address the TF kernel tensor by (tap, GEMM
+// output channel, contracted channel).  One work item = 8 consecutive k of one row (they share tap and phase: CP is a
+// multiple of 8): one 16-byte store per plane, the index arithmetic once per 8 elements.
 template <int NPL>
-static PackPlanesJob<WView, NPL> cv_job(int site, const float* W, int s_t, int s_o, int s_c, float* dst) {
+struct PackViewJob {
+  WView w;
+  unsigned short* dst;
+  int Mp, Kp;
+  int count;   // Mp * Kp / 8
+  __device__ void run(int i) const {
+    const int k8 = Kp >> 3, m = i / k8, k0 = (i - m * k8) << 3;
+    const int pim = m / w.mdiv, o = m - pim * w.mdiv, dd = k0 / w.CP, c0 = k0 - dd * w.CP;
+    const int tap = w.PH ? w.S * (w.NT - 1 - dd) + pim : dd;
+    const bool ok = o < w.O && tap >= 0 && tap < w.T && (w.PH ? (pim < w.S && dd < w.NT) : pim == 0);
+    const float* src = w.W + (int64_t)(ok ? tap : 0) * w.s_t + o * w.s_o;
+    unsigned t[8][NPL];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split_n<NPL>((ok && c0 + j < w.C) ? src[(c0 + j) * w.s_c] : 0.f, t[j]);
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+      u32x4 pk;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pk[q] = t[2 * q][p] | (t[2 * q + 1][p] << 16);
+      *reinterpret_cast<u32x4*>(dst + (size_t)p * Mp * Kp + (size_t)m * Kp + k0) = pk;
+    }
+  }
+};
+template <int NPL>
+static PackViewJob<NPL> cv_job(int site, const float* W, int s_t, int s_o, int s_c, float* dst) {
   const CvSite& v = CVS[site];
   const ClDesc& x = CLD[v.x];
-  return planes_job<NPL>(WView{W, s_t, s_o, s_c, v.T, v.NT, v.S, v.PH, v.mdiv, v.O, x.C, x.CP}, dst, v.Mp, v.Kp);
+  return PackViewJob<NPL>{WView{W, s_t, s_o, s_c, v.T, v.NT, v.S, v.PH, v.mdiv, v.O, x.C, x.CP},
+                          reinterpret_cast<unsigned short*>(dst), v.Mp, v.Kp, v.Mp * v.Kp / 8};
 }
 
 template <int NPL>
