@@ -210,8 +210,10 @@ constexpr int dg_lds(int npl) { return npl * DG_APL + tb_wch(npl); }  // NPL = 3
 //     xh[f][p] = bias + sum_c sum_i y[f][c][i] * W[p - i + 512][c]        (p < 512; column 512: the plane producer)
 // k = input bin i, column = output bin p, taps read from the REVERSED copies (u = 512 - p + i); the A
 // planes are per channel ([F][3][8][528]) and the accumulators run over all 8 channels.
+// (second launch bound = waves per SIMD.  One plane: two workgroups per CU, -10..13 %; two planes need 344 - 388
+//  registers and spill at 256: measured equal or slower, so they keep one workgroup per CU)
 template <bool FWD, int NPL>
-__global__ void __launch_bounds__(256, 1) k_toep_gemm_bf16(const unsigned short* __restrict__ gp,   // A planes
+__global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(const unsigned short* __restrict__ gp,   // A planes
                                                             const unsigned short* __restrict__ wcp,  // packed tap copies
                                                             const float* __restrict__ bias,          // FWD: [1]
                                                             float* __restrict__ dY,  // dgrad: [F][8][513]; fwd: [F][513]
@@ -765,6 +767,20 @@ constexpr int W2_KF = 32;
 constexpr int w2_buf(int npl) { return npl * W2_KF * (WG_RSA + WG_RSB); }
 constexpr int w2_lds(int npl) { return 2 * w2_buf(npl); }   // 114 688 bytes at NPL = 2
 
+#ifndef VAENPVC_WG_FENCE
+#define VAENPVC_WG_FENCE 1
+#endif
+// scheduling hint for the regions of the pipelined loop below: N times (one MFMA, then CNT instructions of class MASK:
+// 0x100 LDS read, 0x200 LDS write) -- LDS traffic issues in the shadow of the 32-cycle MFMAs instead of between their bursts
+#if VAENPVC_WG_FENCE
+#define WG_INTERLEAVE(N, MASK, CNT)                          \
+  _Pragma("unroll") for (int _i = 0; _i < (N); ++_i) {       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        \
+    __builtin_amdgcn_sched_group_barrier((MASK), (CNT), 0);   \
+  }
+#else
+#define WG_INTERLEAVE(N, MASK, CNT)
+#endif
 template <int NPL>
 __global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16_k32(const unsigned short* __restrict__ yp,  // [F][NPL][8][528]
                                                                  const unsigned short* __restrict__ gp,  // [F][NPL][528]
@@ -817,6 +833,9 @@ __global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16_k32(const unsigned s
       *reinterpret_cast<u32x4*>(sB + pl * BPL + brow * WG_RSB + bpc * 16) = stb[pl][0];
       *reinterpret_cast<u32x4*>(sB + pl * BPL + (brow + 16) * WG_RSB + bpc * 16) = stb[pl][1];
     }
+  };
+  auto lstore_strip = [&](int buf) __attribute__((always_inline)) {   // (a divergent branch: kept out of the interleaved regions)
+    unsigned char* sB = smem + buf * BUF + NPL * APL;
     if (strip && tid < 64 * NPL) *reinterpret_cast<u32x4*>(sB + epl * BPL + erow * WG_RSB + (32 + epc) * 16) = ste;
   };
   // fragment addresses (transpose reads) inside a 16-frame half of the chunk
@@ -831,55 +850,89 @@ __global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16_k32(const unsigned s
 #pragma unroll
     for (int cj = 0; cj < 2; ++cj) acc[ri][cj] = zero16();
   acce = zero16();
-  u32x4 fa[2][NPL], fbq[2][NPL], fe3[NPL];
-  auto step = [&](int buf, int ks) __attribute__((always_inline)) {
+  // Software pipeline.  Measured by ablation on the plain loop (load / 2 k-steps / store / barrier): with every wave of
+  // the workgroup in the same phase at the same time the phases simply ADD -- 186 us MFMA + 101 fragment reads + 57 LDS
+  // stores + 119 waiting for the prefetched chunk + 123 prologue / epilogue = 587.  Here: two fragment sets, so that
+  // the transposed reads of the next k-step are in flight during the MFMAs of the current one, across the barrier
+  // too; the staging registers are refilled right after they were written to LDS (a chunk is requested more than a full
+  // iteration ahead); and inside a region the LDS instructions are issued BETWEEN the MFMAs (sched_group_barrier), which
+  // needs straight-line code: iterations with a successor run in a branch-free loop body, the strip column's three
+  // MFMAs and its 16-byte store sit at the region boundaries.
+  u32x4 fa[2][2][NPL], fbq[2][2][NPL], fe3[2][NPL];
+  int n = 0;   // chunk counter
+  const bool mine0 = strip && (wc >> 1) == 0, mine1 = strip && (wc >> 1) == 1;   // wave-uniform: owner of the strip tile on k-step 0 / 1
+  auto readF = [&](int set, int buf, int ks) __attribute__((always_inline)) {
     const unsigned char* sb = smem + buf * BUF;
-    const bool mine = strip && (wc >> 1) == ks;   // wave-uniform
 #pragma unroll
     for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) fa[ri][pl] = tr_read8(sb + pl * APL + ks * 16 * WG_RSA + aoff + ri * 64, 4 * WG_RSA);
+      for (int pl = 0; pl < NPL; ++pl) fa[set][ri][pl] = tr_read8(sb + pl * APL + ks * 16 * WG_RSA + aoff + ri * 64, 4 * WG_RSA);
 #pragma unroll
     for (int cj = 0; cj < 2; ++cj)
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) fbq[cj][pl] = tr_read8(sb + pl * BPL + ks * 16 * WG_RSB + boff + cj * 64, 4 * WG_RSB);
-    if (mine) {
+      for (int pl = 0; pl < NPL; ++pl) fbq[set][cj][pl] = tr_read8(sb + pl * BPL + ks * 16 * WG_RSB + boff + cj * 64, 4 * WG_RSB);
+    // (read by every wave: the strip columns of non-strip workgroups are ordinary finite LDS contents, never used)
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) fe3[pl] = tr_read8(sb + pl * BPL + ks * 16 * WG_RSB + eoff, 4 * WG_RSB);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    for (int pl = 0; pl < NPL; ++pl) fe3[set][pl] = tr_read8(sb + pl * BPL + ks * 16 * WG_RSB + eoff, 4 * WG_RSB);
+  };
+  // MFMAs of one k-step for the row tiles [r0, r1)
+  auto mma = [&](int set, int r0, int r1) __attribute__((always_inline)) {
     using PR = Prod<NPL>;
 #pragma unroll
     for (int t = 0; t < PR::N; ++t)
 #pragma unroll
-      for (int ri = 0; ri < 2; ++ri)
+      for (int ri = r0; ri < r1; ++ri)
 #pragma unroll
-        for (int cj = 0; cj < 2; ++cj) acc[ri][cj] = mfma_bf16(fa[ri][PR::A[t]], fbq[cj][PR::B[t]], acc[ri][cj]);
-    if (mine) {
-      u32x4 af[NPL];
+        for (int cj = 0; cj < 2; ++cj) acc[ri][cj] = mfma_bf16(fa[set][ri][PR::A[t]], fbq[set][cj][PR::B[t]], acc[ri][cj]);
+  };
+  auto mma_strip = [&](int set) __attribute__((always_inline)) {
+    using PR = Prod<NPL>;
+    u32x4 af[NPL];
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) af[pl] = eri == 0 ? fa[0][pl] : fa[1][pl];
+    for (int pl = 0; pl < NPL; ++pl) af[pl] = eri == 0 ? fa[set][0][pl] : fa[set][1][pl];
 #pragma unroll
-      for (int t = 0; t < PR::N; ++t) acce = mfma_bf16(af[PR::A[t]], fe3[PR::B[t]], acce);
-    }
+    for (int t = 0; t < PR::N; ++t) acce = mfma_bf16(af[PR::A[t]], fe3[set][PR::B[t]], acce);
   };
   if (fb < fe) {
     gload(fb);
     lstore(fb, 0);
+    lstore_strip(0);
+    if (fb + W2_KF < fe) gload(fb + W2_KF);   // registers: chunk 1
   }
   __syncthreads();
-  int n = 0;
-  for (int f0 = fb; f0 < fe; f0 += W2_KF, ++n) {
-    const bool more = f0 + W2_KF < fe;
-    if (more) gload(f0 + W2_KF);
+  if (fb < fe) readF(0, 0, 0);
+  int f0 = fb;
+  for (; f0 + W2_KF < fe; f0 += W2_KF, ++n) {   // iterations with a successor
+    const int buf = n & 1;
+    // region A: fragment reads of k-step 1 under the MFMAs of k-step 0
+    readF(1, buf, 1);
+    mma(0, 0, 2);
+    WG_INTERLEAVE(12, 0x100, 2);
     __builtin_amdgcn_sched_barrier(0);
-    step(n & 1, 0);
+    if (mine0) mma_strip(0);
+    lstore_strip(buf ^ 1);
+    // region B: LDS stores of the next chunk (requested one iteration ago) under the first half of k-step 1
+    lstore(f0 + W2_KF, buf ^ 1);
+    mma(1, 0, 1);
+    WG_INTERLEAVE(6, 0x200, 2);
     __builtin_amdgcn_sched_barrier(0);
-    step(n & 1, 1);
+    if (f0 + 2 * W2_KF < fe) gload(f0 + 2 * W2_KF);   // the staging registers go straight back to work
+    __syncthreads();   // chunk n + 1 is in LDS; every wave holds its fragments of chunk n in registers
+    // region C: fragment reads of the next chunk's k-step 0 under the second half of k-step 1
+    readF(0, buf ^ 1, 0);
+    mma(1, 1, 2);
+    WG_INTERLEAVE(6, 0x100, 3);
     __builtin_amdgcn_sched_barrier(0);
-    if (more) lstore(f0 + W2_KF, (n + 1) & 1);
-    __syncthreads();
+    if (mine1) mma_strip(1);
   }
+  if (f0 < fe) {   // last chunk
+    readF(1, n & 1, 1);
+    mma(0, 0, 2);
+    if (mine0) mma_strip(0);
+    mma(1, 0, 2);
+    if (mine1) mma_strip(1);
+  }
+  __syncthreads();
   // ---- epilogue (as k_toep_wgrad_bf16): 383 diagonals reduced in LDS, one global atomic per diagonal and workgroup
   float* dg = reinterpret_cast<float*>(smem);
   if (tid < 384) dg[tid] = 0.f;

@@ -27,6 +27,7 @@ void Runtime::read_env() {
   if (const char* e = getenv("VAENPVC_SIDE_STREAM")) side_enabled = e[0] != '0';
   if (const char* e = getenv("VAENPVC_TOEP")) toep_f32 = !strcmp(e, "f32");
   toep_wgrad_f32 = getenv("VAENPVC_TOEP_WGRAD_F32") != nullptr;
+  if (const char* e = getenv("VAENPVC_TOEP_ZC")) toep_zc = atoi(e) > 0 ? atoi(e) : 4;
   if (const char* e = getenv("VAENPVC_TN_XCD")) tn_xcd = atoi(e);
   toep_wgrad_k16 = getenv("VAENPVC_TOEP_WGRAD_K16") != nullptr;
   if (const char* e = getenv("VAENPVC_CV_SITES")) cv_sites_env = (long)strtoul(e, nullptr, 0);
