@@ -1,5 +1,4 @@
 mkdir -p gpurun_out/$1
-python scripts/site_times.py --tags dec3_wgrad,dec3_fwd,dec3_dgrad --steps 8 > gpurun_out/$1/base.txt 2>&1
-VAENPVC_LIB=variants/dg2/libvaenpvc_hip.so python scripts/site_times.py --tags dec3_wgrad,dec3_fwd,dec3_dgrad --steps 8 > gpurun_out/$1/dg2.txt 2>&1
-VAENPVC_LIB=variants/dg2/libvaenpvc_hip.so python scripts/site_times.py --tags dec3_wgrad,dec3_fwd,dec3_dgrad --steps 8 --precision bf16 > gpurun_out/$1/dg2_bf16.txt 2>&1
-python scripts/site_times.py --tags dec3_wgrad,dec3_fwd,dec3_dgrad --steps 8 --precision bf16 > gpurun_out/$1/base_bf16.txt 2>&1
+T=enc4_fwd,heads_fwd,merge_fwd,merge_dgrad,heads_dgrad,enc4_dgrad
+python scripts/site_times.py --tags $T --steps 8 > gpurun_out/$1/x2.txt 2>&1
+python scripts/site_times.py --tags $T --steps 8 --precision bf16 > gpurun_out/$1/bf16.txt 2>&1
