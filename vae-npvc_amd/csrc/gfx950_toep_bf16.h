@@ -301,25 +301,38 @@ __global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(cons
   // forward direction then accumulates its partial sums over channel groups with atomics into a zeroed output)
   const int cpg = TB_C / (int)gridDim.y, c_lo = (int)blockIdx.y * cpg, c_hi = c_lo + cpg;
   const bool split_out = FWD && gridDim.y > 1;
-  gload(c_lo, 0);
+  // Input gradient: the channels are independent outputs, so every workgroup starts at a different one (rotation by
+  // its index): neighbouring workgroups then write different channel rows at the same time.  (Forward: the channels
+  // accumulate, order kept.)  Spreading the stores of a channel over the next channel's k-steps (a second accumulator
+  // set) was tried and dropped: 128 more live registers and the unrolled chunk loop spill ~100 registers, 340 -> 394 us.
+  const int crot = FWD ? 0 : (int)(blockIdx.x % (unsigned)cpg);
+  auto chan = [&](int ci) { return c_lo + (ci - c_lo + crot) % cpg; };   // ci = loop position -> channel
+  gload(chan(c_lo), 0);
+  // tap copies of a channel: the global loads are issued one channel ahead, BEFORE the epilogue stores of the channel
+  // in front (vector memory completes in order and loads and stores share one counter on this ISA: loads issued behind
+  // 64 stores per lane wait for all of them -- measured: the input-gradient epilogue, 538 MB, cost its full 100 us on
+  // top of the MFMA time); the LDS stores follow after the barrier at the top of the channel
+  constexpr int NW16 = TB_WCH / 16, WPT = (NW16 + 255) / 256;  // NPL = 3: 3192 pieces, 13 per thread
+  u32x4 wv[WPT];
+  auto wload = [&](int c) __attribute__((always_inline)) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wcp) + (size_t)c * TB_WCH);
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+      int i = tid + 256 * k;
+      wv[k] = src[i < NW16 ? i : NW16 - 1];
+    }
+  };
+  if constexpr (!FWD) wload(chan(c_lo));
 #pragma unroll 1
-  for (int c = c_lo; c < c_hi; ++c) {
+  for (int ci = c_lo; ci < c_hi; ++ci) {
+    const int c = chan(ci);
     TBPROF_T(t0);
     __syncthreads();  // previous channel fully consumed (tap copies and A tile)
-    {  // tap copies of channel c: all loads first (one L2 latency), then the LDS stores
-      constexpr int NW16 = TB_WCH / 16, WPT = (NW16 + 255) / 256;  // NPL = 3: 3192 pieces, 13 per thread
-      const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wcp) + (size_t)c * TB_WCH);
-      u32x4 wv[WPT];
+    if constexpr (FWD) wload(c);   // (forward: no epilogue between the channels; loading here keeps the registers short-lived)
 #pragma unroll
-      for (int k = 0; k < WPT; ++k) {
-        int i = tid + 256 * k;
-        wv[k] = src[i < NW16 ? i : NW16 - 1];
-      }
-#pragma unroll
-      for (int k = 0; k < WPT; ++k) {
-        int i = tid + 256 * k;
-        if (i < NW16) reinterpret_cast<u32x4*>(sW)[i] = wv[k];
-      }
+    for (int k = 0; k < WPT; ++k) {
+      int i = tid + 256 * k;
+      if (i < NW16) reinterpret_cast<u32x4*>(sW)[i] = wv[k];
     }
     if (!FWD || c == c_lo) {
 #pragma unroll
@@ -338,7 +351,7 @@ __global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(cons
       TBPROF_T(t3);
       {  // prefetch the next chunk (same rows, next bins; wraps to chunk 0 for the next channel)
         int kn = kc + 1 < DG_NKC ? kc + 1 : 0;
-        int cn = kc + 1 < DG_NKC ? c : (c + 1 < c_hi ? c + 1 : c);
+        int cn = kc + 1 < DG_NKC ? c : (ci + 1 < c_hi ? chan(ci + 1) : c);
         gload(cn, kn);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -372,7 +385,8 @@ __global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(cons
 #endif
     }
     TBPROF_T(t6);
-    if (FWD && c + 1 < c_hi) continue;
+    if (!FWD && ci + 1 < c_hi) wload(chan(ci + 1));
+    if (FWD && ci + 1 < c_hi) continue;
     // epilogue: rows = frames, lanes = 32 consecutive bins -> 128-byte stores; one uniform base
     // per workgroup and channel, 32-bit lane offsets, column tiles through the immediate offset
     {
