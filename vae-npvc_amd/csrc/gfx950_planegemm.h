@@ -804,111 +804,7 @@ inline void launch_cgemm_auto(const CgArgs& a, hipStream_t s) {
   else launch_cgemm<NPL, 2, 2>(a, s);
 }
 
-// fp32 canonical [F][C][H] (+ LayerNorm + lrelu) -> channel-last planes [NPL][F][HP][CP] with zero halo rows and zero
-// channel padding.  One workgroup per frame chunk; a frame is transposed through LDS: coalesced reads along H,
-// 16-byte stores along C.
-struct ClArgs {
-  const float* src;    // [F][C][H]
-  const float* st;     // LN: (mean, rstd) per frame, or nullptr
-  const float* gamma;
-  const float* beta;
-  int C, H, CP, HLO, HP;
-  int F;
-  unsigned short* dst;  // [NPL][plane]: [F][HP][CP] then a zero tail
-  int64_t plane;        // elements between planes (>= F*HP*CP; the remainder is zeroed)
-  float* st_out;        // LN == 2: the statistics are computed here (two-pass over the staged frame) and stored
-};
-// LN: 0 = plain copy, 1 = LayerNorm + lrelu with given statistics, 2 = ... with statistics computed in the same pass
-// (replaces k_ln_stats_fast + a second read of the tensor)
-template <int NPL, int LN>
-__global__ void __launch_bounds__(256) k_split_cl(ClArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // [C][H + 1]
-  __shared__ float red[8];
-  const int tid = threadIdx.x;
-  const int HS = a.H + 1;
-  const int g8 = a.CP >> 3;
-  if (blockIdx.x == 0) {  // zero tails (K runs padded to the chunk size are read into them)
-    const int64_t used = (int64_t)a.F * a.HP * a.CP;
-    for (int64_t i = used + tid; i < a.plane; i += 256)
-#pragma unroll
-      for (int p = 0; p < NPL; ++p) a.dst[p * a.plane + i] = 0;
-  }
-  for (int f = blockIdx.x; f < a.F; f += gridDim.x) {
-    const float* sf = a.src + (int64_t)f * a.C * a.H;
-    float mean = 0.f, rstd = 1.f;
-    if constexpr (LN == 1) {
-      mean = a.st[2 * f];
-      rstd = a.st[2 * f + 1];
-    }
-    __syncthreads();
-    float sum = 0.f;
-    for (int i = tid; i < a.C * a.H; i += 256) {
-      const int c = i / a.H, h = i - c * a.H;
-      float v = sf[i];
-      if constexpr (LN == 1) v = lnact_v(v, mean, rstd, a.gamma[c], a.beta[c]);
-      if constexpr (LN == 2) sum += v;
-      tile[c * HS + h] = v;
-    }
-    if constexpr (LN == 2) {
-      const int n = a.C * a.H;
-      sum = wave_sum(sum);
-      if ((tid & 63) == 0) red[tid >> 6] = sum;
-      __syncthreads();
-      mean = (red[0] + red[1] + red[2] + red[3]) / n;
-      float q = 0.f;
-      for (int i = tid; i < n; i += 256) {
-        const int c = i / a.H, h = i - c * a.H;
-        const float d = tile[c * HS + h] - mean;
-        q += d * d;
-      }
-      q = wave_sum(q);
-      if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
-      __syncthreads();
-      rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / n + LN_EPS);
-      if (tid == 0) {
-        a.st_out[2 * f] = mean;
-        a.st_out[2 * f + 1] = rstd;
-      }
-    }
-    __syncthreads();
-    // one item = (padded position hp, group of 8 channels)
-    for (int i = tid; i < a.HP * g8; i += 256) {
-      const int hp = i / g8, cg = i - hp * g8;
-      const int h = hp - a.HLO;
-      unsigned t[8][NPL];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = cg * 8 + j;
-        float v = (h >= 0 && h < a.H && c < a.C) ? tile[c * HS + h] : 0.f;
-        if constexpr (LN == 2)
-          if (h >= 0 && h < a.H && c < a.C) v = lnact_v(v, mean, rstd, a.gamma[c], a.beta[c]);
-        split_n<NPL>(v, t[j]);
-      }
-#pragma unroll
-      for (int p = 0; p < NPL; ++p) {
-        u32x4 pk;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pk[q] = t[2 * q][p] | (t[2 * q + 1][p] << 16);
-        *reinterpret_cast<u32x4*>(a.dst + p * a.plane + ((int64_t)f * a.HP + hp) * a.CP + cg * 8) = pk;
-      }
-    }
-  }
-}
-template <int NPL>
-inline void launch_split_cl(const ClArgs& a, hipStream_t s) {
-  const int lds = a.C * (a.H + 1) * 4;
-  const unsigned blocks = (unsigned)cmin_(a.F, 4096);
-  if (a.st_out) {
-    rt().ensure_lds(reinterpret_cast<const void*>(&k_split_cl<NPL, 2>), lds);
-    hipLaunchKernelGGL((k_split_cl<NPL, 2>), dim3(blocks), dim3(256), lds, s, a);
-  } else if (a.st) {
-    rt().ensure_lds(reinterpret_cast<const void*>(&k_split_cl<NPL, 1>), lds);
-    hipLaunchKernelGGL((k_split_cl<NPL, 1>), dim3(blocks), dim3(256), lds, s, a);
-  } else {
-    rt().ensure_lds(reinterpret_cast<const void*>(&k_split_cl<NPL, 0>), lds);
-    hipLaunchKernelGGL((k_split_cl<NPL, 0>), dim3(blocks), dim3(256), lds, s, a);
-  }
-}
+// (the producers of the channel-last planes live in gfx950_viewconv.h: k_cl_produce)
 
 }  // namespace tuned
 }  // namespace vaenpvc

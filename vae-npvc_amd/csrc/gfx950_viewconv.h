@@ -2,7 +2,7 @@
 // (kernels: gfx950_planegemm.h; the idea: section "Convs as GEMMs over overlapping rows" of DESIGN.md).
 //
 // Every activation / gradient tensor a conv site reads is kept as CHANNEL-LAST planes with zero halo rows
-// (unsigned short [NPL][F][HP][CP] + a zero tail), produced by k_split_cl from the canonical fp32 [F][C][H] tensor.
+// (unsigned short [NPL][F][HP][CP] + a zero tail), produced by k_cl_produce (below) from the canonical fp32 [F][C][H] tensor.
 // With one plane (precision "bf16") these planes ARE bf16 activation storage: the conv sites then read 2 bytes per
 // element instead of 4 and run at the bf16 MFMA rate -- the bf16 training mode of BASELINE.json config 2.
 // With 2 or 3 planes the same code is the fp32-class variant (used by the parity tests to pin the indexing against the
