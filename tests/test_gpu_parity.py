@@ -416,15 +416,17 @@ def test_view_conv_layers_against_oracle(F, seed, precision):
     assert not fails, '\n'.join(fails)
 
 
-FUSED_CONV = (0xfdffffff, 0xfdffffff)   # bit 25 cleared: the thin conv sites on the fused kernel at any batch size
+FUSED_CONV = (0xfdffffff, 0xfcffffff)   # bits 25 (and 24, backward): the thin conv sites / weight gradients on the fused kernels at any batch size
 
 
 @pytest.mark.parametrize('precision', ['bf16x2', 'bf16x3'])
 @pytest.mark.parametrize('F,seed', [(37, 5), (130, 9), (1, 7), (257, 12)])
 def test_fused_thin_conv_layers_against_oracle(F, seed, precision):
-    """Encoder layer 1 and decoder layers 1-2, forward and input gradient, on the fused view-GEMM kernel
+    """Encoder layers 1-2 and decoder layers 1-2, forward / input gradient on the fused view-GEMM kernel
     (csrc/gfx950_fconv.h: fp32 frames converted to bf16 terms on their way into LDS, weights resident, no planes in
-    HBM) against the float64 oracle; batch sizes with ragged 4-frame / 2-frame workgroups."""
+    HBM) and weight gradients on its counterpart (csrc/gfx950_fwgrad.h: both operands staged in LDS, the whole gradient
+    tile in one workgroup's accumulators, one flush) against the float64 oracle; batch sizes with ragged 4-frame /
+    2-frame workgroups.  (Three operand planes: the weight gradients and the medium site fall back.)"""
     eng = make_engine('vcc', 'auto', FUSED_CONV, precision=precision)
     fails = compare_everything(eng, F, seed, '%s fused-conv F%d ' % (precision, F))
     assert not fails, '\n'.join(fails)

@@ -159,16 +159,13 @@ __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
       unsigned short* dx = xs + fl * T::FS + (T::HLO + h) * T::CPL;
 #pragma unroll
       for (int g8 = 0; g8 < T::CP / 8; ++g8) {
-        unsigned t[8][NPL];
+        float v8[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) split_n<NPL>(v[u][8 * g8 + j], t[j]);
+        for (int j = 0; j < 8; ++j) v8[j] = v[u][8 * g8 + j];
+        u32x4 pk[NPL];
+        pack8<NPL>(v8, pk);
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) {
-          u32x4 pk;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) pk[q] = t[2 * q][p] | (t[2 * q + 1][p] << 16);
-          *reinterpret_cast<u32x4*>(dx + p * T::XPL + 8 * g8) = pk;
-        }
+        for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(dx + p * T::XPL + 8 * g8) = pk[p];
       }
     }
   };

@@ -24,6 +24,7 @@
 #include "gfx950_planegemm.h"
 #include "gfx950_viewconv.h"
 #include "gfx950_fconv.h"
+#include "gfx950_fwgrad.h"
 #include "kernels.h"
 
 namespace vaenpvc {
@@ -210,6 +211,13 @@ static inline bool fc_on(unsigned mask, int site, int64_t F) {
 }
 static inline bool fc_fwd(int site, int64_t F) { return fc_on(rt().fwd_mask, site, F); }
 static inline bool fc_bwd(int site, int64_t F) { return fc_on(rt().bwd_mask, site, F); }
+// thin weight gradients on the fused kernel (gfx950_fwgrad.h): bit 24 of the backward mask cleared = every served site at
+// any batch size (parity tests)
+static inline bool fw_bwd(int wsite, int64_t F) {
+  if (!fwgrad_serves(wsite) || (rt().dense_planes ? rt().dense_planes : rt().planes) > 2) return false;
+  if (!((rt().bwd_mask >> 24) & 1u)) return true;
+  return ((rt().fw_sites() >> wsite) & 1u) && F >= FCONV_MIN_FRAMES;
+}
 static inline bool fc_any(int64_t F) {
   for (int i = 0; i < CV_COUNT; ++i)
     if (fc_fwd(i, F) || fc_bwd(i, F)) return true;
@@ -757,6 +765,18 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       VAENPVC_TIMED(tag, s, fconv<decltype(npl)::value>(site, fa, s));
     });
   };
+  // thin weight gradient on the fused kernel: A = plain operand (gradient or activation), B = view operand
+  auto fwg = [&](int wsite, const float* asrc, const float* ast, const ConvL* aln, const float* bsrc, const float* bst, const ConvL* bln,
+                 float* dW, const char* tag) {
+    for_dense_planes([&](auto npl) {
+      constexpr int NPL = decltype(npl)::value;
+      if constexpr (NPL <= 2) {
+        FwArgs fa{asrc, ast, aln ? P + aln->gamma_off : nullptr, aln ? P + aln->beta_off : nullptr,
+                  bsrc, bst, bln ? P + bln->gamma_off : nullptr, bln ? P + bln->beta_off : nullptr, dW, F};
+        VAENPVC_TIMED(tag, s2, fwgrad<NPL>(wsite, fa, s2));
+      }
+    });
+  };
   auto vdgrad = [&](int site, float* out, const char* tag) {
     for_dense_planes([&](auto npl) {
       VAENPVC_TIMED(tag, s, cv_gemm<decltype(npl)::value>(site, w.scratch + Pk::cvw + cv_woff(site), w.cl[CVS[site].x], out, nullptr, F, s));
@@ -826,11 +846,12 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const ConvL &l = m.dec[2], &pl = m.dec[1];
     WgArgs a{w.d_dec_a[2], nullptr, nullptr, nullptr, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off,
              G + l.w_off, F, 0};
-    const bool fg = fc_bwd(CV_D2G, F), vg = !fg && cv_bwd(CV_D2G, F), vw = cw_bwd(CW_D2, F);
+    const bool fg = fc_bwd(CV_D2G, F), vg = !fg && cv_bwd(CV_D2G, F), fw = fw_bwd(CW_D2, F), vw = !fw && cw_bwd(CW_D2, F);
     if (vg || vw) gsplit(CL_GD2, w.d_dec_a[2], "dec2_gsplit");
     if (vw && !fwd_planes(9, CV_D2F, F)) asplit(CL_YD1, w.dec_a[1], w.dec_st[1], &pl, "dec2_asplit");
     ready();
-    if (vw) vwgrad(CW_D2, G + l.w_off, "dec2_wgrad");
+    if (fw) fwg(CW_D2, w.dec_a[1], w.dec_st[1], &pl, w.d_dec_a[2], nullptr, nullptr, G + l.w_off, "dec2_wgrad");
+    else if (vw) vwgrad(CW_D2, G + l.w_off, "dec2_wgrad");
     else VAENPVC_TIMED("dec2_wgrad", s2, launch_convwgrad<WD2>(a, WGS, s2));
     if (!dec_bias_done[2]) generic::bias_grad(w.d_dec_a[2], G + l.b_off, F, l.cout, l.hout, s);
     if (fg) fdgrad(CV_D2G, w.d_dec_a[2], w.dy_tmp, "dec2_dgrad");
@@ -848,11 +869,12 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const ConvL &l = m.dec[1], &pl = m.dec[0];
     WgArgs a{w.d_dec_a[1], nullptr, nullptr, nullptr, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off,
              G + l.w_off, F, 0};
-    const bool fg = fc_bwd(CV_D1G, F), vg = !fg && cv_bwd(CV_D1G, F), vw = cw_bwd(CW_D1, F);
+    const bool fg = fc_bwd(CV_D1G, F), vg = !fg && cv_bwd(CV_D1G, F), fw = fw_bwd(CW_D1, F), vw = !fw && cw_bwd(CW_D1, F);
     if (vg || vw) gsplit(CL_GD1, w.d_dec_a[1], "dec1_gsplit");
     if (vw && !fwd_planes(8, CV_D1F, F)) asplit(CL_YD0, w.dec_a[0], w.dec_st[0], &pl, "dec1_asplit");
     ready();
-    if (vw) vwgrad(CW_D1, G + l.w_off, "dec1_wgrad");
+    if (fw) fwg(CW_D1, w.dec_a[0], w.dec_st[0], &pl, w.d_dec_a[1], nullptr, nullptr, G + l.w_off, "dec1_wgrad");
+    else if (vw) vwgrad(CW_D1, G + l.w_off, "dec1_wgrad");
     else VAENPVC_TIMED("dec1_wgrad", s2, launch_convwgrad<WD1>(a, WGS, s2));
     if (!dec_bias_done[1]) generic::bias_grad(w.d_dec_a[1], G + l.b_off, F, l.cout, l.hout, s);
     if (fg) fdgrad(CV_D1G, w.d_dec_a[1], w.dy_tmp, "dec1_dgrad");
@@ -1028,11 +1050,12 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 3);
   if (bwd_on(2)) {
     const ConvL &l = m.enc[2], &pl = m.enc[1];
-    const bool fg = fc_bwd(CV_E2G, F), vg = !fg && cv_bwd(CV_E2G, F), vw = cw_bwd(CW_E2, F);
+    const bool fg = fc_bwd(CV_E2G, F), vg = !fg && cv_bwd(CV_E2G, F), fw = fw_bwd(CW_E2, F), vw = !fw && cw_bwd(CW_E2, F);
     if (vg || vw) gsplit(CL_GE2, w.d_enc_a[2], "enc2_gsplit");
     if (vw && !fwd_planes(2, CV_E2F, F)) asplit(CL_Y1, w.enc_a[1], w.enc_st[1], &pl, "enc2_asplit");
     ready();
-    if (vw) vwgrad(CW_E2, G + l.w_off, "enc2_wgrad");
+    if (fw) fwg(CW_E2, w.d_enc_a[2], nullptr, nullptr, w.enc_a[1], w.enc_st[1], &pl, G + l.w_off, "enc2_wgrad");
+    else if (vw) vwgrad(CW_E2, G + l.w_off, "enc2_wgrad");
     else VAENPVC_TIMED("enc2_wgrad", s2, launch_convwgrad<WE2>(wg_enc(2), WGS, s2));
     if (!enc_bias_done[2]) generic::bias_grad(w.d_enc_a[2], G + l.b_off, F, l.cout, l.hout, s);
     if (fg) fdgrad(CV_E2G, w.d_enc_a[2], w.dy_tmp, "enc2_dgrad");
@@ -1047,11 +1070,12 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 2);
   if (bwd_on(1)) {
     const ConvL &l = m.enc[1], &pl = m.enc[0];
-    const bool fg = fc_bwd(CV_E1G, F), vg = !fg && cv_bwd(CV_E1G, F), vw = cw_bwd(CW_E1, F);
+    const bool fg = fc_bwd(CV_E1G, F), vg = !fg && cv_bwd(CV_E1G, F), fw = fw_bwd(CW_E1, F), vw = !fw && cw_bwd(CW_E1, F);
     if (vg || vw) gsplit(CL_GE1, w.d_enc_a[1], "enc1_gsplit");
     if (vw && !fwd_planes(1, CV_E1F, F)) asplit(CL_Y0, w.enc_a[0], w.enc_st[0], &pl, "enc1_asplit");
     ready();
-    if (vw) vwgrad(CW_E1, G + l.w_off, "enc1_wgrad");
+    if (fw) fwg(CW_E1, w.d_enc_a[1], nullptr, nullptr, w.enc_a[0], w.enc_st[0], &pl, G + l.w_off, "enc1_wgrad");
+    else if (vw) vwgrad(CW_E1, G + l.w_off, "enc1_wgrad");
     else VAENPVC_TIMED("enc1_wgrad", s2, launch_convwgrad<WE1>(wg_enc(1), WGS, s2));
     if (!enc_bias_done[1]) generic::bias_grad(w.d_enc_a[1], G + l.b_off, F, l.cout, l.hout, s);
     if (fg) fdgrad(CV_E1G, w.d_enc_a[1], w.dy_tmp, "enc1_dgrad");

@@ -84,16 +84,10 @@ __global__ void __launch_bounds__(256) k_split_planes(SplitArgs a) {
         v[j] = k < a.K ? y : 0.f;
       }
     }
-    unsigned t[8][NPL];
+    u32x4 pk[NPL];
+    pack8<NPL>(v, pk);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) split_n<NPL>(v[j], t[j]);
-#pragma unroll
-    for (int p = 0; p < NPL; ++p) {
-      u32x4 pk;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) pk[q] = t[2 * q][p] | (t[2 * q + 1][p] << 16);
-      *reinterpret_cast<u32x4*>(a.dst + ((int64_t)p * a.rows + r) * a.Kp + k0) = pk;
-    }
+    for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(a.dst + ((int64_t)p * a.rows + r) * a.Kp + k0) = pk[p];
   }
 }
 
@@ -141,14 +135,14 @@ __global__ void __launch_bounds__(256) k_ln_stats_planes(const float* __restrict
                            lnact_v(v[i].y, mean, rstd, gamma[(e + 1) / H], beta[(e + 1) / H]),
                            lnact_v(v[i].z, mean, rstd, gamma[(e + 2) / H], beta[(e + 2) / H]),
                            lnact_v(v[i].w, mean, rstd, gamma[(e + 3) / H], beta[(e + 3) / H])};
-      unsigned t[4][NPL];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) split_n<NPL>(y4[j], t[j]);
+      unsigned t01[NPL], t23[NPL];
+      split_pair<NPL>(y4[0], y4[1], t01);
+      split_pair<NPL>(y4[2], y4[3], t23);
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
         uint2 pk;
-        pk.x = t[0][pl] | (t[1][pl] << 16);
-        pk.y = t[2][pl] | (t[3][pl] << 16);
+        pk.x = t01[pl];
+        pk.y = t23[pl];
         *reinterpret_cast<uint2*>(dst + ((int64_t)pl * F + f) * N + e) = pk;
       }
     }

@@ -48,10 +48,38 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-__device__ __forceinline__ unsigned bf16_rn(float x) {  // round to nearest even, as 16 bits
-  unsigned u = __float_as_uint(x);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
+// fp32 -> bf16, round to nearest even: v_cvt_pk_bf16_f32 converts TWO values in one instruction (the integer recipe
+// u += 0x7fff + ((u >> 16) & 1); u >>= 16 costs four; in the conversion-heavy fused kernels the VALU was the limit)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ unsigned bf16_rn(float x) { return cvt_pk_bf16(x, 0.f); }   // as 16 bits (upper half zero)
+// (x, y) -> per plane one packed pair (x's term in the low half): 3 instructions per element with two planes
+template <int NPL>
+__device__ __forceinline__ void split_pair(float x, float y, unsigned (&pk)[NPL]) {
+  float rx = x, ry = y;
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) {
+    pk[p] = cvt_pk_bf16(rx, ry);
+    if (p + 1 < NPL) {
+      rx -= __uint_as_float(pk[p] << 16);
+      ry -= __uint_as_float(pk[p] & 0xffff0000u);
+    }
+  }
+}
+// eight consecutive values -> one 16-byte piece per plane
+template <int NPL>
+__device__ __forceinline__ void pack8(const float (&v)[8], u32x4 (&out)[NPL]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned pk[NPL];
+    split_pair<NPL>(v[2 * q], v[2 * q + 1], pk);
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) out[p][q] = pk[p];
+  }
 }
 // x = t[0] + t[1] + ... (each term the bf16 rounding of what the previous terms left over)
 template <int NPL>
@@ -494,19 +522,15 @@ __global__ void __launch_bounds__(256) k_ln_stats_act_planes(const float* __rest
     for (int j = 0; j < 8; ++j) {
       o[j] = lnact_v(v[c][j], mean, rstd, g, b);
       dot += o[j] * wr[j];
-      split_n<NPL>(o[j], tm[j]);
     }
     if (write_y) {  // uniform; the fp32 copy is only read by the exact-fp32 weight-gradient kernel
       *reinterpret_cast<packed4*>(yf + c * TB_H + 8 * lane) = packed4{o[0], o[1], o[2], o[3]};
       *reinterpret_cast<packed4*>(yf + c * TB_H + 8 * lane + 4) = packed4{o[4], o[5], o[6], o[7]};
     }
+    u32x4 pkv[NPL];
+    pack8<NPL>(o, pkv);
 #pragma unroll
-    for (int p = 0; p < NPL; ++p) {
-      u32x4 pk;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) pk[k] = tm[2 * k][p] | (tm[2 * k + 1][p] << 16);
-      *reinterpret_cast<u32x4*>(ypf + (p * TB_C + c) * TB_KP + 8 * lane) = pk;
-    }
+    for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(ypf + (p * TB_C + c) * TB_KP + 8 * lane) = pkv[p];
   }
   if (lane < TB_C) {  // bin 512 of channel `lane`, and the zero padding 513..527 of its plane rows
     const int c = lane;

@@ -119,20 +119,16 @@ __global__ void __launch_bounds__(256) k_cl_produce(CpArgs a) {
     unsigned short* df = a.dst + (int64_t)f * HP * CP;
     for (int it = lane; it < HP * G8; it += 64) {
       const int hp = it / G8, cg = it - hp * G8, h = hp - HLO;
-      unsigned t[8][NPL];
+      float v8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = cg * 8 + j;
-        const float x = (h >= 0 && h < H && c < C) ? tile[c * H + h] : 0.f;
-        split_n<NPL>(x, t[j]);
+        v8[j] = (h >= 0 && h < H && c < C) ? tile[c * H + h] : 0.f;
       }
+      u32x4 pk[NPL];
+      pack8<NPL>(v8, pk);
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) {
-        u32x4 pk;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pk[q] = t[2 * q][p] | (t[2 * q + 1][p] << 16);
-        *reinterpret_cast<u32x4*>(df + p * a.plane + (int64_t)it * 8) = pk;
-      }
+      for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(df + p * a.plane + (int64_t)it * 8) = pk[p];
     }
     __builtin_amdgcn_wave_barrier();
   }

@@ -26,6 +26,9 @@ struct Runtime {
   // conv layers on the view GEMMs (gfx950_viewconv.h): one bit per site (CV_* forward / input-gradient sites 0..11,
   // weight-gradient sites 12..17); -1 = the measured default of the precision (VAENPVC_CV_SITES overrides)
   long cv_sites_env = -1, fc_sites_env = -1;   // (VAENPVC_FC_SITES: thin sites on the fused kernel, gfx950_fconv.h)
+  long fw_sites_env = -1;       // VAENPVC_FW_SITES: thin weight gradients on the fused kernel (gfx950_fwgrad.h; bit = CW_* site)
+  unsigned fw_sites() const { return fw_sites_env >= 0 ? (unsigned)fw_sites_env : planes == 1 ? FW_SITES_BF16 : FW_SITES; }
+  static constexpr unsigned FW_SITES = 0x3fu, FW_SITES_BF16 = 0x3du;   // (bf16 mode: encoder layer 2 keeps the view GEMM, its planes exist anyway)
   unsigned fc_sites() const { return fc_sites_env >= 0 ? (unsigned)fc_sites_env : planes == 1 ? FC_SITES_BF16 : FC_SITES; }
   static constexpr unsigned FC_SITES = 0xdb1u, FC_SITES_BF16 = 0xdb1u;   // by measurement
   unsigned cv_sites() const { return cv_sites_env >= 0 ? (unsigned)cv_sites_env : planes == 1 ? CV_SITES_BF16 : planes == 2 ? CV_SITES_X2 : CV_SITES_X3; }
