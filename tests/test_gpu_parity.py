@@ -416,7 +416,8 @@ def test_view_conv_layers_against_oracle(F, seed, precision):
     assert not fails, '\n'.join(fails)
 
 
-FUSED_CONV = (0xfdffffff, 0xfcffffff)   # bits 25 (and 24, backward): the thin conv sites / weight gradients on the fused kernels at any batch size
+FUSED_CONV = (0xfd7fffff, 0xfc7fffff)   # bits 25, 23 (and 24, backward): the thin conv sites / weight gradients on the fused kernels and
+                                        # encoder layer 0 on its wave-per-frame kernels at any batch size
 
 
 @pytest.mark.parametrize('precision', ['bf16x2', 'bf16x3'])

@@ -161,6 +161,119 @@ __global__ void __launch_bounds__(256) k_enc0_fwd(const float* __restrict__ x, c
   }
 }
 
+// ---------------------------------------------------------------- encoder layer 0, one wave per frame
+// The same layer without workgroup barriers (the kernel above needs four per frame and divides per output): a lane
+// owns the output positions j = lane, lane + 64, lane + 128 and walks the 16 output channels in registers, so every
+// store instruction covers 256 contiguous bytes of one channel row; the 7 taps of a position come straight from the
+// frame's 2 KB input row (stride-3 loads, L1-resident after the first touch), the weights through uniform (scalar)
+// loads; the LayerNorm statistics are two wave reductions over the 48 outputs a lane holds.
+__global__ void __launch_bounds__(256) k_enc0_fwd_wave(const float* __restrict__ x, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ a,
+                                                       float* __restrict__ st, int F) {
+  constexpr int H = 513, HO = 171, CO = 16, N = CO * HO;
+  const int lane = threadIdx.x & 63;
+  for (int f = blockIdx.x * 4 + (threadIdx.x >> 6); f < F; f += gridDim.x * 4) {
+    const float* xf = x + (int64_t)f * H;
+    float v[3][CO];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int j = lane + 64 * k;
+      float xt[7];
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const int i = 3 * j + t - 2;
+        xt[t] = (j < HO && i >= 0 && i < H) ? xf[i] : 0.f;
+      }
+#pragma unroll
+      for (int o = 0; o < CO; ++o) {
+        float acc = bias[o];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) acc += W[t * CO + o] * xt[t];
+        v[k][o] = j < HO ? acc : 0.f;
+        s += v[k][o];
+      }
+    }
+    const float mean = wave_sum(s) * (1.0f / N);
+    float q = 0.f;
+    float* af = a + (int64_t)f * N;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int j = lane + 64 * k;
+      if (j < HO) {
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+          af[o * HO + j] = v[k][o];
+          const float d = v[k][o] - mean;
+          q += d * d;
+        }
+      }
+    }
+    q = wave_sum(q);
+    if (lane == 0) {
+      st[2 * f] = mean;
+      st[2 * f + 1] = 1.0f / sqrtf(q * (1.0f / N) + LN_EPS);
+    }
+  }
+}
+
+// Its weight gradient dW[t][o] = sum_{f,j} x[f][3j + t - 2] * d[f][o][j] the same way: a lane owns positions, keeps the
+// 7 x 16 partial sums in registers over all frames of its wave, and the waves' sums are reduced once at the end (wave
+// reduction, then one row of partials per workgroup; k_colsum_part adds the rows).
+__global__ void __launch_bounds__(256) k_enc0_wgrad_wave(const float* __restrict__ x, const float* __restrict__ d,
+                                                         float* __restrict__ part, int F) {
+  constexpr int H = 513, HO = 171, CO = 16, N = CO * HO;
+  __shared__ float red[4][7 * CO];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[7][CO];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[t][o] = 0.f;
+  for (int f = blockIdx.x * 4 + wave; f < F; f += gridDim.x * 4) {
+    const float* xf = x + (int64_t)f * H;
+    const float* df = d + (int64_t)f * N;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int j = lane + 64 * k;
+      float xt[7], dv[CO];
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const int i = 3 * j + t - 2;
+        xt[t] = (j < HO && i >= 0 && i < H) ? xf[i] : 0.f;
+      }
+#pragma unroll
+      for (int o = 0; o < CO; ++o) dv[o] = j < HO ? df[o * HO + j] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[t][o] += xt[t] * dv[o];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      const float r = wave_sum(acc[t][o]);
+      if (lane == 0) red[wave][t * CO + o] = r;
+    }
+  __syncthreads();
+  if (threadIdx.x < 7 * CO)
+    part[(int64_t)blockIdx.x * (7 * CO) + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// out[col] += sum over rows of part[row][col]  (one workgroup per column)
+__global__ void __launch_bounds__(256) k_colsum_part(const float* __restrict__ part, int rows, int cols, float* __restrict__ out) {
+  __shared__ float sm[4];
+  const int col = blockIdx.x;
+  float s = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 256) s += part[(int64_t)r * cols + col];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out + col, (sm[0] + sm[1]) + (sm[2] + sm[3]));
+}
+
 // ---------------------------------------------------------------- LayerNorm + lrelu backward
 // autodiff of util/layers.py:32-44,149 for one layer with C channels x H positions:
 //   n = gamma*xhat+beta ; dn = dy*(n>=0 ? 1 : leak) ; dxh = dn*gamma

@@ -184,7 +184,8 @@ struct Pk {
   static constexpr int pg_enc4b = pg_enc4f + 3 * 768 * 896 / 2;     // [896][768]
   static constexpr int pg_bias4 = pg_enc4b + 3 * 896 * 768 / 2;     // bias of layer 4 per dense column (o, j)
   static constexpr int cvw = pg_bias4 + 768;                        // weight planes of the conv view-GEMM sites
-  static constexpr int total = cvw + CV_WTOTAL;
+  static constexpr int enc0part = cvw + CV_WTOTAL;                  // [512][7*16] partial weight gradients of encoder layer 0
+  static constexpr int total = enc0part + 512 * 7 * 16;
 };
 static_assert(Pk::total <= 8 * 939162 + 65536, "packed weights must fit the scratch region");
 // the dense-shaped layers (heads, merge, encoder layer 4) on the plane GEMM kernels: bit 29 of the masks, and enough
@@ -204,6 +205,9 @@ static inline bool cv_bwd(int site, int64_t F) { return cg_bwd(F) && cv_sel(rt()
 // thin conv sites on the fused kernel (gfx950_fconv.h): the context's site set from FCONV_MIN_FRAMES frames on, or every
 // served site at any batch size when bit 25 of the mask is cleared (parity tests)
 constexpr int64_t FCONV_MIN_FRAMES = 1024;
+constexpr int64_t ENC0_WAVE_MIN_FRAMES = 1024;   // encoder layer 0 on the wave-per-frame kernels (fewer frames: too few waves)
+// (bit 23 of a mask cleared: at any batch size -- parity tests)
+static inline bool enc0_wave(unsigned mask, int64_t F) { return F >= ENC0_WAVE_MIN_FRAMES || !((mask >> 23) & 1u); }
 static inline bool fc_on(unsigned mask, int site, int64_t F) {
   if (!fconv_serves(site, rt().dense_planes ? rt().dense_planes : rt().planes)) return false;
   if (!((mask >> 25) & 1u)) return true;
@@ -451,6 +455,10 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
   // e0: Cin = 1, K = 7 -- 0.4 % of the MACs, HBM-bound: VALU conv fused with its LN statistics
   if (fwd_on(0)) {
     int fch = cmax(1, cdiv(F, 4096));
+    if (enc0_wave(rt().fwd_mask, F)) {   // one wave per frame, no workgroup barriers
+      VAENPVC_TIMED("enc0_fwd", s, hipLaunchKernelGGL(k_enc0_fwd_wave, dim3((unsigned)cmin_(cdiv(F, 4), 2048)), dim3(256), 0, s, x,
+                                                      P + m.enc[0].w_off, P + m.enc[0].b_off, w.enc_a[0], w.enc_st[0], F));
+    } else
     VAENPVC_TIMED("enc0_fwd", s, hipLaunchKernelGGL(k_enc0_fwd, dim3((unsigned)cdiv(F, fch)), dim3(256), 0, s, x, P + m.enc[0].w_off,
                                                     P + m.enc[0].b_off, w.enc_a[0], w.enc_st[0], F, fch));
   } else {
@@ -1091,6 +1099,12 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const ConvL& l = m.enc[0];
     WgArgs a{x, nullptr, nullptr, nullptr, w.d_enc_a[0], nullptr, nullptr, nullptr, G + l.w_off, F, 0};
     ready();
+    if (enc0_wave(rt().bwd_mask, F)) {   // register-resident partial sums, one row of partials per workgroup, one column-sum pass
+      const int nwg = cmin_(cdiv(F, 128), 256);   // >= 32 frames per wave: the 112 wave reductions at the end stay below 10 % of a wave's work
+      VAENPVC_TIMED("enc0_wgrad", s2, hipLaunchKernelGGL(k_enc0_wgrad_wave, dim3((unsigned)nwg), dim3(256), 0, s2, x, w.d_enc_a[0],
+                                                        w.scratch + Pk::enc0part, F));
+      hipLaunchKernelGGL(k_colsum_part, dim3(7 * 16), dim3(256), 0, s2, w.scratch + Pk::enc0part, nwg, 7 * 16, G + l.w_off);
+    } else
     VAENPVC_TIMED("enc0_wgrad", s2, launch_convwgrad<WE0>(a, WGS, s2));
     if (!enc_bias_done[0]) generic::bias_grad(w.d_enc_a[0], G + l.b_off, F, l.cout, l.hout, s);
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 0);
