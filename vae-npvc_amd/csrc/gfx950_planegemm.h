@@ -623,8 +623,16 @@ __global__ void __launch_bounds__(512, NPL <= 2 ? 4 : 2) k_gemm_tn(TnpArgs a) {
     }
 }
 
+template <int NPL, int EPI, int TI, int TJ>
+inline void launch_gemm_tn32(TnpArgs a, int target_wgs, hipStream_t s);
 template <int NPL, int EPI, int TI = 2, int TJ = 2>
 inline void launch_gemm_tn(TnpArgs a, int target_wgs, hipStream_t s) {
+  if constexpr (NPL <= 2) {
+    // measured (32 768 frames): one plane -27 % over six sites; two planes -17..24 % on the sites with few tiles per row
+    // chunk (merge, heads, encoder layer 3), equal on decoder layer 0, +10 % on encoder layer 4 (21 tiles: stays here)
+    const bool many_tiles = cdiv(a.M, 64 * TI) * cdiv(a.N, 128 * TJ) > 8;
+    if (!rt().tn_k16 && (NPL == 1 || !many_tiles)) return launch_gemm_tn32<NPL, EPI, TI, TJ>(a, target_wgs, s);
+  }
   using T = TnTile<NPL, TI, TJ>;
   rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_tn<NPL, EPI, TI, TJ>), T::LDS);
   const int tiles = cdiv(a.M, T::BM) * cdiv(a.N, T::BN);
@@ -632,6 +640,225 @@ inline void launch_gemm_tn(TnpArgs a, int target_wgs, hipStream_t s) {
   a.fchunk = rup(cdiv(a.F, zc), TP_KF);
   dim3 grid((unsigned)(cdiv(a.M, T::BM) * cdiv(a.N, T::BN) * cdiv(a.F, a.fchunk)));
   hipLaunchKernelGGL((k_gemm_tn<NPL, EPI, TI, TJ>), grid, dim3(512), T::LDS, s, a);
+}
+
+// ---------------------------------------------------------------- C += A^T B, pipelined (up to two planes)
+// The same tile and epilogues on the schedule of the Toeplitz weight gradient (gfx950_toep_bf16.h:
+// k_toep_wgrad_bf16_k32), chosen after the same ablation (five sites, 820 us: prologue / epilogue / atomics 356, MFMAs
+// 243, waiting for the one-chunk prefetch 177, LDS stores 83 -- all additive): 32-row chunks (two k-steps per barrier),
+// two fragment sets with the transposed reads issued between the MFMAs, the staging registers refilled right after
+// they were written to LDS, one 8-wave workgroup per CU and HALF as many workgroups (half the atomics).
+constexpr int TP32_KF = 32;
+template <int NPL, int TI, int TJ>
+struct Tn32Tile {
+  static constexpr int BM = 64 * TI, BN = 128 * TJ;
+  static constexpr int RSA = BM * 2 + 64, RSB = BN * 2 + 64;
+  static constexpr int APL = TP32_KF * RSA, BPL = TP32_KF * RSB;
+  static constexpr int BUF = NPL * (APL + BPL), LDS = 2 * BUF;
+  static constexpr int APC = BM / 8, BPC = BN / 8;   // 16-byte pieces per row
+};
+#define TN32_INTERLEAVE(N, MASK, CNT)                        \
+  _Pragma("unroll") for (int _i = 0; _i < (N); ++_i) {       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        \
+    __builtin_amdgcn_sched_group_barrier((MASK), (CNT), 0);   \
+  }
+
+template <int NPL, int EPI, int TI = 2, int TJ = 2>
+__global__ void __launch_bounds__(512, 2) k_gemm_tn32(TnpArgs a) {
+  static_assert(NPL <= 2, "three planes do not fit two 32-row buffers");
+  using T = Tn32Tile<NPL, TI, TJ>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BUF = T::BUF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lh = lane >> 5, l31 = lane & 31;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int ntm = cdiv(a.M, T::BM), ntt = ntm * cdiv(a.N, T::BN);
+  const int wg = a.xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int zc = wg / ntt, tl = wg - zc * ntt;
+  const int m0 = (tl % ntm) * T::BM, n0 = (tl / ntm) * T::BN;
+  const int fb = zc * a.fchunk, fe = min(a.F, fb + a.fchunk);
+  // staging of one 32-row chunk: A 32 rows x APC pieces (one per thread), B 32 rows x BPC pieces (rows brow and brow + 16)
+  const bool a_thr = tid < TP32_KF * T::APC, b_thr = tid < 16 * T::BPC;
+  const int arow = (tid / T::APC) & 31, apc = tid % T::APC;
+  const int brow = (tid / T::BPC) & 15, bpc = tid % T::BPC;
+  const int acol = cmin_(m0 * 2 + apc * 16, a.lda * 2 - 16);
+  const int bcol = cmin_(n0 * 2 + bpc * 16, a.ldb * 2 - 16);
+  const unsigned char* A8 = reinterpret_cast<const unsigned char*>(a.A);
+  const unsigned char* B8 = reinterpret_cast<const unsigned char*>(a.B);
+  u32x4 sta[NPL], stb[NPL][2];
+  struct RowIt {
+    unsigned off;
+    int q;
+  };
+  auto row_init = [&](const RowView& v, int r, int colbytes) {
+    RowIt it;
+    const int f = r / v.R;
+    it.q = r - f * v.R;
+    it.off = (unsigned)(f * v.fs + v.x0 + it.q * v.step) * 2u + (unsigned)colbytes;
+    return it;
+  };
+  const int adf = TP32_KF / a.av.R, adq = TP32_KF - adf * a.av.R, bdf = TP32_KF / a.bv.R, bdq = TP32_KF - bdf * a.bv.R;
+  auto row_next = [&](const RowView& v, int df, int dq, RowIt& it) __attribute__((always_inline)) {
+    int q = it.q + dq;
+    const int carry = q >= v.R ? 1 : 0;
+    q -= carry ? v.R : 0;
+    it.off += (unsigned)(((df + carry) * v.fs + (q - it.q) * v.step) * 2);
+    it.q = q;
+  };
+  RowIt ia = row_init(a.av, min(fb + arow, a.F - 1), acol);
+  RowIt ib0 = row_init(a.bv, min(fb + brow, a.F - 1), bcol), ib1 = row_init(a.bv, min(fb + brow + 16, a.F - 1), bcol);
+  auto gload = [&](int f0) __attribute__((always_inline)) {   // rows of chunk f0: loads, then advances the iterators
+    if (a_thr) {
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) sta[p] = *reinterpret_cast<const u32x4*>(A8 + (size_t)p * a.a_plane * 2 + ia.off);
+      if (f0 + TP32_KF + arow < a.F) row_next(a.av, adf, adq, ia);
+    }
+    if (b_thr) {
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        stb[p][0] = *reinterpret_cast<const u32x4*>(B8 + (size_t)p * a.b_plane * 2 + ib0.off);
+        stb[p][1] = *reinterpret_cast<const u32x4*>(B8 + (size_t)p * a.b_plane * 2 + ib1.off);
+      }
+      if (f0 + TP32_KF + brow < a.F) row_next(a.bv, bdf, bdq, ib0);
+      if (f0 + TP32_KF + brow + 16 < a.F) row_next(a.bv, bdf, bdq, ib1);
+    }
+  };
+  auto lstore = [&](int f0, int buf) __attribute__((always_inline)) {
+    unsigned char* sA = smem + buf * BUF;
+    unsigned char* sB = sA + NPL * T::APL;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    if (a_thr) {
+      const bool zero = f0 + arow >= fe;   // rows past the chunk contribute zero (A rows zeroed)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(sA + p * T::APL + arow * T::RSA + apc * 16) = zero ? z : sta[p];
+    }
+    if (b_thr) {
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        *reinterpret_cast<u32x4*>(sB + p * T::BPL + brow * T::RSB + bpc * 16) = stb[p][0];
+        *reinterpret_cast<u32x4*>(sB + p * T::BPL + (brow + 16) * T::RSB + bpc * 16) = stb[p][1];
+      }
+    }
+  };
+  const int trow = ((lane & 15) >> 2) + 8 * lh, tcol = 4 * (lane & 3) + 16 * ((lane >> 4) & 1);
+  const int aoff = trow * T::RSA + (32 * TI * wr + tcol) * 2;
+  const int boff = NPL * T::APL + trow * T::RSB + (32 * TJ * wc + tcol) * 2;
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = zero16();
+  u32x4 fa[2][TI][NPL], fbq[2][TJ][NPL];
+  auto readF = [&](int set, int buf, int ks) __attribute__((always_inline)) {
+    const unsigned char* sb = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) fa[set][i][p] = tr_read8(sb + p * T::APL + ks * 16 * T::RSA + aoff + i * 64, 4 * T::RSA);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) fbq[set][j][p] = tr_read8(sb + p * T::BPL + ks * 16 * T::RSB + boff + j * 64, 4 * T::RSB);
+  };
+  // MFMAs of one k-step for the tiles of parity `half` (all tiles when the wave owns a single one and half == 0)
+  constexpr int NTILE = TI * TJ, NHALF = NTILE >= 2 ? NTILE / 2 : 1;
+  auto mma = [&](int set, int half) __attribute__((always_inline)) {
+    using PR = Prod<NPL>;
+#pragma unroll
+    for (int t = 0; t < PR::N; ++t)
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          const int id = i * TJ + j;
+          if (NTILE >= 2 ? ((id & 1) != half) : (half != 0)) continue;
+          if constexpr (EPI == TN_EPI_TRANS) acc[i][j] = mfma_bf16(fbq[set][j][PR::B[t]], fa[set][i][PR::A[t]], acc[i][j]);
+          else acc[i][j] = mfma_bf16(fa[set][i][PR::A[t]], fbq[set][j][PR::B[t]], acc[i][j]);
+        }
+  };
+  constexpr int NPROD = Prod<NPL>::N, NRD = (TI + TJ) * NPL * 2;   // MFMAs per tile and k-step; LDS reads per fragment set
+  if (fb < fe) {
+    gload(fb);
+    lstore(fb, 0);
+    if (fb + TP32_KF < fe) gload(fb + TP32_KF);
+  }
+  __syncthreads();
+  if (fb < fe) readF(0, 0, 0);
+  int n = 0, f0 = fb;
+  for (; f0 + TP32_KF < fe; f0 += TP32_KF, ++n) {   // iterations with a successor: branch-free regions
+    const int buf = n & 1;
+    // region A: fragment reads of k-step 1 under the MFMAs of k-step 0
+    readF(1, buf, 1);
+    mma(0, 0);
+    mma(0, 1);
+    TN32_INTERLEAVE(NTILE * NPROD, 0x100, cdiv(NRD, NTILE * NPROD));
+    __builtin_amdgcn_sched_barrier(0);
+    // region B: LDS stores of the next chunk under the first half of k-step 1
+    lstore(f0 + TP32_KF, buf ^ 1);
+    mma(1, 0);
+    TN32_INTERLEAVE(NHALF * NPROD, 0x200, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (f0 + 2 * TP32_KF < fe) gload(f0 + 2 * TP32_KF);   // the staging registers go straight back to work
+    __syncthreads();
+    // region C: fragment reads of the next chunk's k-step 0 under the second half of k-step 1
+    readF(0, buf ^ 1, 0);
+    mma(1, 1);
+    TN32_INTERLEAVE(NHALF * NPROD, 0x100, cdiv(NRD, NHALF * NPROD));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (f0 < fe) {   // last chunk
+    readF(1, n & 1, 1);
+    mma(0, 0);
+    mma(0, 1);
+    mma(1, 0);
+    mma(1, 1);
+  }
+  // epilogue: acc[i][j][reg] = C[m0 + 32 TI wr + 32 i + acc_row(reg)][n0 + 32 TJ wc + 32 j + l31]  (TRANS: transposed)
+  if constexpr (EPI == TN_EPI_TRANS) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int m = m0 + 32 * TI * wr + 32 * i + l31;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int nn = n0 + 32 * TJ * wc + 32 * j + acc_row(reg, lane);
+          if (nn < a.N) atomicAdd(a.C + (int64_t)nn * a.ldc + m, acc[i][j][reg]);
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int nn = n0 + 32 * TJ * wc + 32 * j + l31;
+      if (nn >= a.N) continue;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + 32 * TI * wr + 32 * i + acc_row(reg, lane);
+        if (m >= a.M) continue;
+        const float v = acc[i][j][reg];
+        if constexpr (EPI == TN_EPI_ENC4) {
+          const int c = m / 7, h = m - 7 * c, o = nn / 3, j3 = nn - 3 * o, t = h - 3 * j3 + 3;
+          if (t >= 0 && t < 7) atomicAdd(a.C + ((t * 128 + c) * 256 + o), v);
+        } else {
+          if (a.C2 && nn >= a.split) atomicAdd(a.C2 + (int64_t)m * a.ldc + (nn - a.split), v);
+          else atomicAdd(a.C + (int64_t)m * a.ldc + nn, v);
+        }
+      }
+    }
+}
+
+template <int NPL, int EPI, int TI, int TJ>
+inline void launch_gemm_tn32(TnpArgs a, int target_wgs, hipStream_t s) {
+  using T = Tn32Tile<NPL, TI, TJ>;
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_tn32<NPL, EPI, TI, TJ>), T::LDS);
+  const int tiles = cdiv(a.M, T::BM) * cdiv(a.N, T::BN);
+  const int zc = cmax(1, cmin_(cdiv(a.F, 128), cdiv(cmax(target_wgs / 2, 1), tiles)));   // one workgroup per CU
+  a.fchunk = rup(cdiv(a.F, zc), TP32_KF);
+  dim3 grid((unsigned)(tiles * cdiv(a.F, a.fchunk)));
+  hipLaunchKernelGGL((k_gemm_tn32<NPL, EPI, TI, TJ>), grid, dim3(512), T::LDS, s, a);
 }
 
 // =====================================================================================================

@@ -29,6 +29,7 @@ void Runtime::read_env() {
   toep_wgrad_f32 = getenv("VAENPVC_TOEP_WGRAD_F32") != nullptr;
   if (const char* e = getenv("VAENPVC_TOEP_ZC")) toep_zc = atoi(e) > 0 ? atoi(e) : 4;
   if (const char* e = getenv("VAENPVC_TN_XCD")) tn_xcd = atoi(e);
+  tn_k16 = getenv("VAENPVC_TN_K16") != nullptr;
   toep_wgrad_k16 = getenv("VAENPVC_TOEP_WGRAD_K16") != nullptr;
   if (const char* e = getenv("VAENPVC_CV_SITES")) cv_sites_env = (long)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_FW_SITES")) fw_sites_env = (long)strtoul(e, nullptr, 0);
