@@ -1,0 +1,248 @@
+// gfx950_fconv_r.h -- the MEDIUM conv sites (64 - 96 GEMM rows, K = 192 - 288) fused like gfx950_fconv.h, with the
+// weights in REGISTERS instead of LDS: a wave owns one 32-row tile of the weight matrix for the whole launch (its A
+// fragments for every k-step: K/16 x NPL x 4 registers) and multiplies it with every row step of the frames the
+// workgroup has staged; LDS holds only the frames (8 per group), so two workgroups fit a CU although the weight matrix
+// alone (100 - 130 KB as two planes) would not fit beside them.
+//   * transposed-conv sites stack their 3 output phases PER 8 CHANNELS (tile row = phase * 8 + channel % 8, 24 of 32
+//     rows used): the three phases of a (channel, position) sit in three registers of one lane and leave as one
+//     12-byte store (see k_fconv); every wave has a tile;
+//   * tensors with few positions and many channels (19 x 64, 19 x 81) are staged with lanes = (position, channel
+//     third) instead of lane = position.
+// Sites: decoder layer 0 forward / input gradient, encoder layer 2 forward / input gradient.  Up to two planes.
+// Reference: util/layers.py:56-64, model/vae.py:96-99 and their autodiff.
+#pragma once
+#include "gfx950_fconv.h"
+
+namespace vaenpvc {
+namespace tuned {
+
+constexpr bool fcr_serves_site(int site) { return site == CV_D0F || site == CV_D0G || site == CV_E2F || site == CV_E2G; }
+// frames per group: 4 where the weight tile takes 136 - 144 registers with two planes (one staging item per wave)
+constexpr int fcr_tf(int site, int npl) {
+  return site == CV_D0F ? (npl == 1 ? 8 : 4) : site == CV_D0G ? (npl == 1 ? 6 : 4) : site == CV_E2G ? 8 : 6;
+}
+
+template <int NPL, int SITE>
+struct FrCfg {
+  static constexpr CvSite V = CVS[SITE];
+  static constexpr ClDesc X = CLD[V.x];
+  static constexpr int C = X.C, H = X.H, CP = X.CP, HLO = X.HLO, HP = X.HP;
+  static constexpr bool PERM = V.PH != 0;             // phase-stacked per 8 channels
+  static constexpr int MTR = PERM ? V.O / 8 : cdiv(V.M, 32);   // 32-row tiles of the (permuted) weight matrix
+  static constexpr int MP = MTR * 32;
+  static constexpr int WPT = MTR >= 4 ? 1 : MTR == 3 ? 1 : 4 / MTR;   // waves per tile (3 tiles: the fourth wave only stages)
+  static constexpr int CPL = (CP == 32 || CP == 64 || CP == 128) ? CP + 8 : (CP == 88 ? 104 : CP);
+  static constexpr int FS = HP * CPL;
+  static constexpr int TF = fcr_tf(SITE, NPL);
+  static constexpr int XPL = TF * FS + 64;
+  static constexpr int K = V.NT * CP, KS = cdiv(K, 16);
+  static constexpr int RSTEP = (V.step / CP) * CPL;
+  static constexpr int LDS = NPL * XPL * 2;
+  // staging: lane = position (H >= 32) or lane = (position, channel third) (H < 32)
+  static constexpr bool POS = H >= 32;
+  static constexpr int NCH = POS ? cdiv(H, 64) : 1;
+  static constexpr int CG = POS ? CP : rup(cdiv(CP, 3), 8);   // channels a lane collects
+  static constexpr int NIT = TF * NCH, IPW = cdiv(NIT, 4);
+  static_assert(KS * 16 <= V.Kp && (POS || (3 * H <= 64 && 3 * CG <= CPL + 8)), "site not served");
+};
+
+// weight planes with the rows of FrCfg: plain sites as cv_job; PERM: row = tile * 32 + phase * 8 + (channel % 8)
+template <int NPL>
+struct PackViewPermJob {
+  WView w;
+  unsigned short* dst;
+  int Mp, Kp;
+  int count;   // Mp * Kp / 8
+  __device__ void run(int i) const {
+    const int k8 = Kp >> 3, m = i / k8, k0 = (i - m * k8) << 3;
+    const int tile = m >> 5, r = m & 31, pim = r >> 3, o = tile * 8 + (r & 7);
+    const int dd = k0 / w.CP, c0 = k0 - dd * w.CP;
+    const int tap = w.S * (w.NT - 1 - dd) + pim;
+    const bool ok = pim < w.S && o < w.O && dd < w.NT && tap >= 0 && tap < w.T;
+    const float* src = w.W + (int64_t)(ok ? tap : 0) * w.s_t + o * w.s_o;
+    float v8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v8[j] = (ok && c0 + j < w.C) ? src[(c0 + j) * w.s_c] : 0.f;
+    u32x4 pk[NPL];
+    pack8<NPL>(v8, pk);
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(dst + (size_t)p * Mp * Kp + (size_t)m * Kp + k0) = pk[p];
+  }
+};
+constexpr int fcr_mp(int site) { return CVS[site].PH ? (CVS[site].O / 8) * 32 : CVS[site].Mp; }
+constexpr int fcr_wfloats(int site) { return 3 * fcr_mp(site) * CVS[site].Kp / 2; }
+template <int NPL>
+static PackViewPermJob<NPL> fcr_perm_job(int site, const float* W, int s_t, int s_o, int s_c, float* dst) {
+  const CvSite& v = CVS[site];
+  const ClDesc& x = CLD[v.x];
+  const int mp = fcr_mp(site);
+  return PackViewPermJob<NPL>{WView{W, s_t, s_o, s_c, v.T, v.NT, v.S, v.PH, v.mdiv, v.O, x.C, x.CP},
+                              reinterpret_cast<unsigned short*>(dst), mp, v.Kp, mp * v.Kp / 8};
+}
+
+template <int NPL, int SITE, int LN>
+__global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
+  using T = FrCfg<NPL, SITE>;
+  constexpr CvSite V = T::V;
+  extern __shared__ __attribute__((aligned(16))) unsigned short rsm[];
+  unsigned short* xs = rsm;   // [NPL][XPL]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int ngroups = cdiv(a.F, T::TF);
+  // ---- staging registers (one group ahead, as k_fconv)
+  float v[T::IPW][T::CG];
+  float mean[T::IPW], rstd[T::IPW];
+  const int pg_p = lane % (T::POS ? 64 : T::H), pg_g = T::POS ? 0 : lane / T::H;   // (position, channel third) of this lane
+  auto fload = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < T::IPW; ++u) {
+      const int it = wave + 4 * u, fl = it / T::NCH, k = it - fl * T::NCH;
+      const int f = g * T::TF + fl;
+      const bool fok = it < T::NIT && f < a.F;
+      const float* sf = a.src + (int64_t)(fok ? f : 0) * (T::C * T::H);
+      if constexpr (LN == 1) {
+        mean[u] = a.st[2 * (fok ? f : 0)];
+        rstd[u] = a.st[2 * (fok ? f : 0) + 1];
+      }
+      if constexpr (T::POS) {
+        const int h = 64 * k + lane;
+#pragma unroll
+        for (int c = 0; c < T::CG; ++c) v[u][c] = (c < T::C && h < T::H && fok) ? sf[c * T::H + h] : 0.f;
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < T::CG; ++cc) {
+          const int c = pg_g * T::CG + cc;
+          v[u][cc] = (c < T::C && pg_g < 3 && fok) ? sf[c * T::H + pg_p] : 0.f;
+        }
+      }
+    }
+  };
+  auto fstore = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < T::IPW; ++u) {
+      const int it = wave + 4 * u, fl = it / T::NCH, k = it - fl * T::NCH;
+      const int h = T::POS ? 64 * k + lane : pg_p;
+      const int cbase = T::POS ? 0 : pg_g * T::CG;
+      const bool live = it < T::NIT && g * T::TF + fl < a.F && h < T::H && (T::POS || pg_g < 3);
+      if (!live) continue;
+      if constexpr (LN != 0) {
+#pragma unroll
+        for (int cc = 0; cc < T::CG; ++cc) {
+          const int c = cbase + cc;
+          if (c < T::C) v[u][cc] = lnact_v(v[u][cc], mean[u], rstd[u], a.gamma[c], a.beta[c]);
+        }
+      }
+      unsigned short* dx = xs + fl * T::FS + (T::HLO + h) * T::CPL + cbase;
+#pragma unroll
+      for (int g8 = 0; g8 < T::CG / 8; ++g8) {
+        if (cbase + 8 * g8 >= T::CPL) continue;   // (the last third's tail beyond the padded row)
+        float v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = v[u][8 * g8 + j];
+        u32x4 pk[NPL];
+        pack8<NPL>(v8, pk);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(dx + p * T::XPL + 8 * g8) = pk[p];
+      }
+    }
+  };
+  int g = blockIdx.x;
+  if (g < ngroups) fload(g);
+  // ---- once: zero the frame tile; this wave's weight tile into registers
+  {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int i = tid; i < NPL * T::XPL / 8; i += 256) reinterpret_cast<u32x4*>(xs)[i] = z;
+  }
+  const int tile = wave % T::MTR, sub = wave / T::MTR;      // (3 tiles: wave 3 -> tile 0, sub 1: no steps)
+  const bool gemm_wave = sub < T::WPT;
+  u32x4 wreg[T::KS][NPL];
+#pragma unroll
+  for (int ks = 0; ks < T::KS; ++ks)
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+      wreg[ks][p] = *reinterpret_cast<const u32x4*>(a.W + ((size_t)p * fcr_mp(SITE) + tile * 32 + l31) * V.Kp + ks * 16 + lh * 8);
+  __syncthreads();
+  for (; g < ngroups; g += gridDim.x) {
+    const int f0 = g * T::TF, nf = min(T::TF, a.F - f0);
+    fstore(g);
+    __syncthreads();
+    if (g + (int)gridDim.x < ngroups) fload(g + gridDim.x);
+    const int nrows = nf * V.R, nsteps = cdiv(nrows, 32);
+    if (gemm_wave) {
+      for (int s = sub; s < nsteps; s += T::WPT) {
+        int n = s * 32 + l31;
+        const bool nok = n < nrows;
+        n = nok ? n : 0;
+        const int fl = n / V.R, q = n - fl * V.R;
+        const int xoff = fl * T::FS + q * T::RSTEP;
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int ks = 0; ks < T::KS; ++ks) {
+          u32x4 fb[NPL];
+          const int ko = fc_koff<T::CP, T::CPL>(ks, lh);
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) fb[p] = *reinterpret_cast<const u32x4*>(xs + p * T::XPL + xoff + ko);
+          using PR = Prod<NPL>;
+#pragma unroll
+          for (int t = 0; t < PR::N; ++t) acc = mfma_bf16(wreg[ks][PR::A[t]], fb[PR::B[t]], acc);
+        }
+        if (!nok) continue;
+        float* ob = a.out + (int64_t)(f0 + fl) * (V.OC * V.OH);
+        const int pbase = q * V.oq + V.o0;
+        if constexpr (T::PERM) {
+          // tile row = phase * 8 + channel % 8: registers cs, cs + 4, cs + 8 of this lane are the three phases
+          struct __attribute__((packed, aligned(4))) f3 { float x, y, z; };
+          const bool inner = pbase >= 0 && pbase + 2 < V.OH;
+#pragma unroll
+          for (int cs = 0; cs < 4; ++cs) {
+            const int ch = tile * 8 + cs + 4 * lh;
+            const float bb = a.bias ? a.bias[ch] : 0.f;
+            const float p0 = acc[cs] + bb, p1 = acc[cs + 4] + bb, p2 = acc[cs + 8] + bb;
+            float* o = ob + ch * V.OH + pbase;
+            if (inner) {
+              *reinterpret_cast<f3*>(o) = f3{p0, p1, p2};
+            } else {
+              if (pbase >= 0 && pbase < V.OH) o[0] = p0;
+              if (pbase + 1 >= 0 && pbase + 1 < V.OH) o[1] = p1;
+              if (pbase + 2 >= 0 && pbase + 2 < V.OH) o[2] = p2;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int ch = tile * 32 + acc_row(reg, lane);
+            if (ch < V.O && pbase >= 0 && pbase < V.OH) ob[ch * V.OH + pbase] = acc[reg] + (a.bias ? a.bias[ch] : 0.f);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int NPL, int SITE>
+static void launch_fconv_r(const FcArgs& a, hipStream_t s) {
+  using T = FrCfg<NPL, SITE>;
+  const unsigned grid = (unsigned)cmin_(cdiv(a.F, T::TF), T::LDS > 80 * 1024 ? 256 : 512);
+  if (a.st) {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv_r<NPL, SITE, 1>), T::LDS);
+    hipLaunchKernelGGL((k_fconv_r<NPL, SITE, 1>), dim3(grid), dim3(256), T::LDS, s, a);
+  } else {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv_r<NPL, SITE, 0>), T::LDS);
+    hipLaunchKernelGGL((k_fconv_r<NPL, SITE, 0>), dim3(grid), dim3(256), T::LDS, s, a);
+  }
+}
+template <int NPL>
+static bool fconv_r(int site, const FcArgs& a, hipStream_t s) {
+  if constexpr (NPL <= 2) {
+    switch (site) {
+      case CV_D0F: launch_fconv_r<NPL, CV_D0F>(a, s); return true;
+      case CV_D0G: launch_fconv_r<NPL, CV_D0G>(a, s); return true;
+      case CV_E2F: launch_fconv_r<NPL, CV_E2F>(a, s); return true;
+      case CV_E2G: launch_fconv_r<NPL, CV_E2G>(a, s); return true;
+    }
+  }
+  return false;
+}
+
+}  // namespace tuned
+}  // namespace vaenpvc

@@ -25,6 +25,7 @@
 #include "gfx950_viewconv.h"
 #include "gfx950_fconv.h"
 #include "gfx950_fwgrad.h"
+#include "gfx950_fconv_r.h"
 #include "kernels.h"
 
 namespace vaenpvc {
@@ -184,7 +185,10 @@ struct Pk {
   static constexpr int pg_enc4b = pg_enc4f + 3 * 768 * 896 / 2;     // [896][768]
   static constexpr int pg_bias4 = pg_enc4b + 3 * 896 * 768 / 2;     // bias of layer 4 per dense column (o, j)
   static constexpr int cvw = pg_bias4 + 768;                        // weight planes of the conv view-GEMM sites
-  static constexpr int enc0part = cvw + CV_WTOTAL;                  // [512][7*16] partial weight gradients of encoder layer 0
+  static constexpr int cvwr_d0f = cvw + CV_WTOTAL;                  // phase-permuted weight planes of the register-weight fused kernel
+  static constexpr int cvwr_e2g = cvwr_d0f + fcr_wfloats(CV_D0F);
+  static constexpr int enc0part_ = cvwr_e2g + fcr_wfloats(CV_E2G);
+  static constexpr int enc0part = enc0part_;                  // [512][7*16] partial weight gradients of encoder layer 0
   static constexpr int total = enc0part + 512 * 7 * 16;
 };
 static_assert(Pk::total <= 8 * 939162 + 65536, "packed weights must fit the scratch region");
@@ -213,8 +217,16 @@ static inline bool fc_on(unsigned mask, int site, int64_t F) {
   if (!((mask >> 25) & 1u)) return true;
   return ((rt().fc_sites() >> site) & 1u) && F >= FCONV_MIN_FRAMES;
 }
-static inline bool fc_fwd(int site, int64_t F) { return fc_on(rt().fwd_mask, site, F); }
-static inline bool fc_bwd(int site, int64_t F) { return fc_on(rt().bwd_mask, site, F); }
+// medium sites on the register-weight fused kernel (gfx950_fconv_r.h): bit 22 of a mask cleared = at any batch size
+static inline bool fcr_on(unsigned mask, int site, int64_t F) {
+  if (!fcr_serves_site(site) || (rt().dense_planes ? rt().dense_planes : rt().planes) > 2) return false;
+  if (!((mask >> 22) & 1u)) return true;
+  return ((rt().fcr_sites() >> site) & 1u) && F >= FCONV_MIN_FRAMES;
+}
+static inline bool fcr_fwd(int site, int64_t F) { return fcr_on(rt().fwd_mask, site, F); }
+static inline bool fcr_bwd(int site, int64_t F) { return fcr_on(rt().bwd_mask, site, F); }
+static inline bool fc_fwd(int site, int64_t F) { return !fcr_fwd(site, F) && fc_on(rt().fwd_mask, site, F); }
+static inline bool fc_bwd(int site, int64_t F) { return !fcr_bwd(site, F) && fc_on(rt().bwd_mask, site, F); }
 // thin weight gradients on the fused kernel (gfx950_fwgrad.h): bit 24 of the backward mask cleared = every served site at
 // any batch size (parity tests)
 static inline bool fw_bwd(int wsite, int64_t F) {
@@ -224,11 +236,13 @@ static inline bool fw_bwd(int wsite, int64_t F) {
 }
 static inline bool fc_any(int64_t F) {
   for (int i = 0; i < CV_COUNT; ++i)
-    if (fc_fwd(i, F) || fc_bwd(i, F)) return true;
+    if (fc_fwd(i, F) || fc_bwd(i, F) || fcr_fwd(i, F) || fcr_bwd(i, F)) return true;
   return false;
 }
 // the forward pass left the channel-last planes of a site's input behind (view GEMM selected and not overridden by the fused kernel)
-static inline bool fwd_planes(int bit, int site, int64_t F) { return ((rt().fwd_mask >> bit) & 1u) && cv_fwd(site, F) && !fc_fwd(site, F); }
+static inline bool fwd_planes(int bit, int site, int64_t F) {
+  return ((rt().fwd_mask >> bit) & 1u) && cv_fwd(site, F) && !fc_fwd(site, F) && !fcr_fwd(site, F);
+}
 static inline bool cw_bwd(int site, int64_t F) { return cg_bwd(F) && cv_sel(rt().bwd_mask, CV_COUNT + site); }
 static inline unsigned short* us(float* p) { return reinterpret_cast<unsigned short*>(p); }
 static NtArgs nt_args(const float* Ap, int M, int Kp, const float* Bp, int Np, int N, float* C, int ldc) {
@@ -373,7 +387,7 @@ static void prep(const Model& m, const float* P, const Ws& w, int64_t F, hipStre
   if (cg_fwd(F) || cg_bwd(F) || fc_any(F)) {
     // only the sites some kernel of this step reads (count 0 = job skipped)
     auto used = [&](int site, bool fwd_dir) {
-      return fwd_dir ? (cv_fwd(site, F) || fc_fwd(site, F)) : (cv_bwd(site, F) || fc_bwd(site, F));
+      return fwd_dir ? (cv_fwd(site, F) || fc_fwd(site, F) || fcr_fwd(site, F)) : (cv_bwd(site, F) || fc_bwd(site, F) || fcr_bwd(site, F));
     };
     auto job = [&](int site, bool fwd_dir, const ConvL& l, int s_o, int s_c) {
       auto j = cv_job<NPD>(site, P + l.w_off, l.cin * l.cout, s_o, s_c, S + Pk::cvw + cv_woff(site));
@@ -384,6 +398,13 @@ static void prep(const Model& m, const float* P, const Ws& w, int64_t F, hipStre
     auto eg = [&](int site, int i) { const ConvL& l = m.enc[i]; return job(site, false, l, l.cout, 1); };
     auto df = [&](int site, int i) { const ConvL& l = m.dec[i]; return job(site, true, l, l.cin, 1); };
     auto dg = [&](int site, int i) { const ConvL& l = m.dec[i]; return job(site, false, l, 1, l.cin); };
+    {  // phase-permuted copies for the register-weight kernel
+      auto pd = fcr_perm_job<NPD>(CV_D0F, P + m.dec[0].w_off, m.dec[0].cin * m.dec[0].cout, m.dec[0].cin, 1, S + Pk::cvwr_d0f);
+      auto pe = fcr_perm_job<NPD>(CV_E2G, P + m.enc[2].w_off, m.enc[2].cin * m.enc[2].cout, m.enc[2].cout, 1, S + Pk::cvwr_e2g);
+      if (!fcr_fwd(CV_D0F, F)) pd.count = 0;
+      if (!fcr_bwd(CV_E2G, F)) pe.count = 0;
+      if (pd.count || pe.count) launch_pack_multi(s, pd, pe);
+    }
     launch_pack_multi(s, ef(CV_E1F, 1), ef(CV_E2F, 2), ef(CV_E3F, 3), df(CV_D0F, 0), df(CV_D1F, 1), df(CV_D2F, 2),
                       eg(CV_E3G, 3), eg(CV_E2G, 2), eg(CV_E1G, 1), dg(CV_D0G, 0), dg(CV_D1G, 1), dg(CV_D2G, 2));
   }
@@ -480,7 +501,7 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
   // LayerNorm statistics of layer i's output; when the next layer is a view-GEMM site its activated input planes are
   // written in the same pass over the tensor
   auto enc_stats = [&](int i, int next_site, int cl, const char* tag) {
-    const bool fuse = fwd_on(i + 1) && cv_fwd(next_site, F) && !fc_fwd(next_site, F);
+    const bool fuse = fwd_on(i + 1) && cv_fwd(next_site, F) && !fc_fwd(next_site, F) && !fcr_fwd(next_site, F);
     if (fuse)
       for_dense_planes([&](auto npl) {
         VAENPVC_TIMED(tag, s, cv_stats_split<decltype(npl)::value>(cl, w.enc_a[i], w.enc_st[i], P + m.enc[i].gamma_off, P + m.enc[i].beta_off,
@@ -496,6 +517,13 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
       VAENPVC_TIMED(tag, s, fconv<decltype(npl)::value>(site, fa, s));
     });
   };
+  auto fused_r = [&](int site, const float* wpl, const float* src, const float* st, const ConvL* ln, const float* bias, float* out, const char* tag) {
+    for_dense_planes([&](auto npl) {
+      FcArgs fa{src, st, nullptr, ln ? P + ln->gamma_off : nullptr, ln ? P + ln->beta_off : nullptr,
+                reinterpret_cast<const unsigned short*>(wpl), bias, out, F};
+      VAENPVC_TIMED(tag, s, fconv_r<decltype(npl)::value>(site, fa, s));
+    });
+  };
   bool have_y1 = false, have_y2 = false;
   if (fwd_on(1)) {
     if (fc_fwd(CV_E1F, F)) fused(CV_E1F, w.enc_a[0], w.enc_st[0], nullptr, &m.enc[0], P + m.enc[1].b_off, w.enc_a[1], "enc1_fwd");
@@ -504,7 +532,8 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
     if (!(have_y1 = enc_stats(1, CV_E2F, CL_Y1, "enc2_split"))) stats<1824>(w.enc_a[1], w.enc_st[1], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 1);
   if (fwd_on(2)) {
-    if (cv_fwd(CV_E2F, F)) enc_view(CV_E2F, CL_Y1, 2, have_y1, "enc2_split", "enc2_fwd");
+    if (fcr_fwd(CV_E2F, F)) fused_r(CV_E2F, w.scratch + Pk::cvw + cv_woff(CV_E2F), w.enc_a[1], w.enc_st[1], &m.enc[1], P + m.enc[2].b_off, w.enc_a[2], "enc2_fwd");
+    else if (cv_fwd(CV_E2F, F)) enc_view(CV_E2F, CL_Y1, 2, have_y1, "enc2_split", "enc2_fwd");
     else VAENPVC_TIMED("enc2_fwd", s, launch_convgemm<E2F>(lnp(2), nsplit_for<E2F>(F), s));
     if (!(have_y2 = enc_stats(2, CV_E3F, CL_Y2, "enc3_split"))) stats<1216>(w.enc_a[2], w.enc_st[2], F, s);
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 2);
@@ -620,7 +649,14 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
   bool have_yd0 = false, have_yd1 = false;
   // a fused consumer takes the LayerNorm statistics of its input itself (it owns whole frames): no statistics pass
   const bool d1_fused = fwd_on(8) && fc_fwd(CV_D1F, F), d2_fused = fwd_on(9) && fc_fwd(CV_D2F, F);
-  if (fwd_on(7) && cv_fwd(CV_D0F, F)) {
+  if (fwd_on(7) && fcr_fwd(CV_D0F, F)) {
+    for_dense_planes([&](auto npl) {
+      FcArgs fa{w.h, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvwr_d0f),
+                P + m.dec[0].b_off, w.dec_a[0], F};
+      VAENPVC_TIMED("dec0_fwd", s, fconv_r<decltype(npl)::value>(CV_D0F, fa, s));
+    });
+    if (!d1_fused && !(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
+  } else if (fwd_on(7) && cv_fwd(CV_D0F, F)) {
     dec_view(CV_D0F, CL_H, 0, false, w.h, "dec0_split", "dec0_fwd");
     if (!d1_fused && !(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
   } else if (fwd_on(7)) {
@@ -785,6 +821,12 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       }
     });
   };
+  auto rdgrad = [&](int site, const float* wpl, const float* grad, float* out, const char* tag) {   // medium site, register-weight fused kernel
+    for_dense_planes([&](auto npl) {
+      FcArgs fa{grad, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const unsigned short*>(wpl), nullptr, out, F};
+      VAENPVC_TIMED(tag, s, fconv_r<decltype(npl)::value>(site, fa, s));
+    });
+  };
   auto vdgrad = [&](int site, float* out, const char* tag) {
     for_dense_planes([&](auto npl) {
       VAENPVC_TIMED(tag, s, cv_gemm<decltype(npl)::value>(site, w.scratch + Pk::cvw + cv_woff(site), w.cl[CVS[site].x], out, nullptr, F, s));
@@ -899,14 +941,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   if (bwd_on(7)) {
     const ConvL& l = m.dec[0];
     WgArgs a{w.d_dec_a[0], nullptr, nullptr, nullptr, w.h, nullptr, nullptr, nullptr, G + l.w_off, F, 0};
-    const bool vg = cv_bwd(CV_D0G, F), vw = cw_bwd(CW_D0, F);
+    const bool rg = fcr_bwd(CV_D0G, F), vg = !rg && cv_bwd(CV_D0G, F), vw = cw_bwd(CW_D0, F);
     if (vg || vw) gsplit(CL_GD0, w.d_dec_a[0], "dec0_gsplit");
     if (vw && !fwd_planes(7, CV_D0F, F)) asplit(CL_H, w.h, nullptr, nullptr, "dec0_asplit");
     ready();
     if (vw) vwgrad(CW_D0, G + l.w_off, "dec0_wgrad");
     else VAENPVC_TIMED("dec0_wgrad", s2, launch_convwgrad<WD0>(a, WGS, s2));
     if (!dec_bias_done[0]) generic::bias_grad(w.d_dec_a[0], G + l.b_off, F, l.cout, l.hout, s);
-    if (vg) vdgrad(CV_D0G, w.d_h, "dec0_dgrad");
+    if (rg) rdgrad(CV_D0G, w.scratch + Pk::cvw + cv_woff(CV_D0G), w.d_dec_a[0], w.d_h, "dec0_dgrad");
+    else if (vg) vdgrad(CV_D0G, w.d_h, "dec0_dgrad");
     else
     VAENPVC_TIMED("dec0_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<GD0s>(conv_args(w.d_dec_a[0], nullptr, nullptr, nullptr, w.scratch + Pk::gd0,
                                                                   nullptr, w.d_h, F), nsplit_for<GD0s>(F), s) : launch_convgemm<GD0>(conv_args(w.d_dec_a[0], nullptr, nullptr, nullptr, w.scratch + Pk::gd0,
@@ -1058,7 +1101,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 3);
   if (bwd_on(2)) {
     const ConvL &l = m.enc[2], &pl = m.enc[1];
-    const bool fg = fc_bwd(CV_E2G, F), vg = !fg && cv_bwd(CV_E2G, F), fw = fw_bwd(CW_E2, F), vw = !fw && cw_bwd(CW_E2, F);
+    const bool rg = fcr_bwd(CV_E2G, F), fg = !rg && fc_bwd(CV_E2G, F), vg = !rg && !fg && cv_bwd(CV_E2G, F), fw = fw_bwd(CW_E2, F), vw = !fw && cw_bwd(CW_E2, F);
     if (vg || vw) gsplit(CL_GE2, w.d_enc_a[2], "enc2_gsplit");
     if (vw && !fwd_planes(2, CV_E2F, F)) asplit(CL_Y1, w.enc_a[1], w.enc_st[1], &pl, "enc2_asplit");
     ready();
@@ -1066,7 +1109,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     else if (vw) vwgrad(CW_E2, G + l.w_off, "enc2_wgrad");
     else VAENPVC_TIMED("enc2_wgrad", s2, launch_convwgrad<WE2>(wg_enc(2), WGS, s2));
     if (!enc_bias_done[2]) generic::bias_grad(w.d_enc_a[2], G + l.b_off, F, l.cout, l.hout, s);
-    if (fg) fdgrad(CV_E2G, w.d_enc_a[2], w.dy_tmp, "enc2_dgrad");
+    if (rg) rdgrad(CV_E2G, w.scratch + Pk::cvwr_e2g, w.d_enc_a[2], w.dy_tmp, "enc2_dgrad");
+    else if (fg) fdgrad(CV_E2G, w.d_enc_a[2], w.dy_tmp, "enc2_dgrad");
     else if (vg) vdgrad(CV_E2G, w.dy_tmp, "enc2_dgrad");
     else
     VAENPVC_TIMED("enc2_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<GE2s>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,

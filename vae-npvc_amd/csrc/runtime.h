@@ -26,6 +26,9 @@ struct Runtime {
   // conv layers on the view GEMMs (gfx950_viewconv.h): one bit per site (CV_* forward / input-gradient sites 0..11,
   // weight-gradient sites 12..17); -1 = the measured default of the precision (VAENPVC_CV_SITES overrides)
   long cv_sites_env = -1, fc_sites_env = -1;   // (VAENPVC_FC_SITES: thin sites on the fused kernel, gfx950_fconv.h)
+  long fcr_sites_env = -1;      // VAENPVC_FCR_SITES: medium sites on the register-weight fused kernel (gfx950_fconv_r.h; bit = CV_* site)
+  unsigned fcr_sites() const { return fcr_sites_env >= 0 ? (unsigned)fcr_sites_env : planes == 1 ? FCR_SITES_BF16 : FCR_SITES; }
+  static constexpr unsigned FCR_SITES = 0x28au, FCR_SITES_BF16 = 0x08au;   // CV_E2F (1), CV_D0F (3), CV_E2G (7), CV_D0G (9; view GEMM with one plane)
   long fw_sites_env = -1;       // VAENPVC_FW_SITES: thin weight gradients on the fused kernel (gfx950_fwgrad.h; bit = CW_* site)
   unsigned fw_sites() const { return fw_sites_env >= 0 ? (unsigned)fw_sites_env : planes == 1 ? FW_SITES_BF16 : FW_SITES; }
   static constexpr unsigned FW_SITES = 0x3fu, FW_SITES_BF16 = 0x3du;   // (bf16 mode: encoder layer 2 keeps the view GEMM, its planes exist anyway)

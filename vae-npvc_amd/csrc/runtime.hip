@@ -32,6 +32,7 @@ void Runtime::read_env() {
   tn_k16 = getenv("VAENPVC_TN_K16") != nullptr;
   toep_wgrad_k16 = getenv("VAENPVC_TOEP_WGRAD_K16") != nullptr;
   if (const char* e = getenv("VAENPVC_CV_SITES")) cv_sites_env = (long)strtoul(e, nullptr, 0);
+  if (const char* e = getenv("VAENPVC_FCR_SITES")) fcr_sites_env = (long)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_FW_SITES")) fw_sites_env = (long)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_FC_SITES")) fc_sites_env = (long)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_DENSE_PLANES")) {
