@@ -233,12 +233,18 @@ int vaenpvc_summary(const float* d_data, int64_t n, const float* d_edges, int32_
  * 5 = heads, 6 = merge, 7..10 = decoder layer i; one mask for forward steps, one for
  * backward steps.  Default: all ones.  State of THIS context.
  * Bit 30 of the forward mask (default set): cleared = use the bf16-split kernels of the last decoder layer at
- * any batch size (they are selected at >= 8192 frames otherwise; parity tests).  Bit 30 of the backward mask
+ * any batch size (they are selected at >= 16 frames otherwise; parity tests).  Bit 30 of the backward mask
  * (default set): cleared = launch the weight-gradient kernels on the caller's stream instead of the context's
  * helper stream (serialised kernels; used by bench.py to time single kernels).
  * Bit 29 of either mask (default set): cleared = keep the dense-shaped layers (heads, merge, encoder layer 4) on the
  * exact-fp32 MFMA kernels instead of the bf16-split plane GEMM kernels, which are selected at >= 1024 frames;
- * bit 28 (default set): cleared = select them at any batch size (parity tests). */
+ * bit 28 (default set): cleared = select them at any batch size (parity tests).
+ * Bit 27 (default set): cleared = no conv site on the view-GEMM kernels; bit 26 (default set): cleared = EVERY conv
+ * site of encoder layers 1-3 / decoder layers 0-2 on the view GEMMs instead of the measured per-precision site set.
+ * Bits 25 / 22 (default set): cleared = every thin / medium conv site on the fused kernels (gfx950_fconv.h,
+ * gfx950_fconv_r.h) at any batch size; bit 24 of the backward mask: the thin weight gradients on gfx950_fwgrad.h;
+ * bit 23: encoder layer 0 on its wave-per-frame kernels.  (The bits 22-28 exist for the parity tests, which pin every
+ * kernel family against the float64 restatement at small batch sizes; defaults select by measurement.) */
 int vaenpvc_set_tuned_masks(vaenpvc_ctx* ctx, uint32_t fwd_mask, uint32_t bwd_mask);
 
 /* Measurement hook (no reference counterpart): brackets every launch of ONE tagged

@@ -20,7 +20,10 @@ RtScope::~RtScope() { tl_rt = prev; }
 //   VAENPVC_TOEP_WGRAD_F32                exact-fp32 weight gradient of that layer only
 //   VAENPVC_PLANES=1|2|3                  bf16 terms per fp32 operand (vaenpvc_set_precision)
 //   VAENPVC_DENSE_PLANES=1|2|3            terms on the dense-shaped layers regardless of the precision rule (experiments)
-//   VAENPVC_CV_SITES=<mask>               conv sites on the view GEMMs (runtime.h: cv_sites)
+//   VAENPVC_CV_SITES=<mask>               conv sites on the view GEMMs (runtime.h: cv_sites; bit = CV_* / 12 + CW_* site)
+//   VAENPVC_FC_SITES / _FCR_SITES / _FW_SITES=<mask>   thin / medium conv sites and thin weight gradients on the fused kernels
+//   VAENPVC_TOEP_ZC=<n>                   frame chunks of the Toeplitz weight gradient (A/B measurements)
+//   VAENPVC_TOEP_WGRAD_K16, VAENPVC_TN_K16, VAENPVC_TN_XCD=0|1   earlier schedules / tile orders of the weight-gradient GEMMs (A/B)
 void Runtime::read_env() {
   if (const char* e = getenv("VAENPVC_FWD_MASK")) fwd_mask = (unsigned)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_BWD_MASK")) bwd_mask = (unsigned)strtoul(e, nullptr, 0);
