@@ -308,6 +308,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(arch, args.cpu_seconds)
     if rank == 0:
+        # anything native libraries left in the C stdio buffer (RCCL prints a version banner with printf when a
+        # communicator is created) goes out FIRST: the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
