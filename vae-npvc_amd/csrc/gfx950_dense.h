@@ -60,7 +60,10 @@ __global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
     for (int nb = 0; nb < C::NBW; ++nb) acc[mb][nb] = zero16();
   const float* ap = tA + l31 * C::ASTR + lh;
   constexpr int U = 8;
-  for (int ch = 0; ch < C::NCHUNK; ++ch) {
+  // gridDim.z > 1 (small batches): the K chunks are dealt to gridDim.z workgroups per tile; the partial results are
+  // added with atomics into an output the caller zeroed, biases by the first one
+  const bool ksplit = gridDim.z > 1;
+  for (int ch = blockIdx.z; ch < C::NCHUNK; ch += gridDim.z) {
     const int kc0 = ch * C::KCH;
     __syncthreads();
     if constexpr (C::INKIND != IN_LN && C::KCH == 256) {
@@ -187,8 +190,9 @@ __global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
     }
   }
   // row offsets into the per-row bias table (merge: the speaker's row of T), fetched once for all column tiles
+  const bool first = blockIdx.z == 0;
   int rbo[C::MB][16];
-  if (a.rowbias) {  // uniform
+  if (a.rowbias && first) {  // uniform
 #pragma unroll
     for (int mb = 0; mb < C::MB; ++mb)
 #pragma unroll
@@ -203,20 +207,20 @@ __global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
   for (int nb = 0; nb < C::NBW; ++nb) {
     int n = (nt0 + nb) * 32 + l31;
     if (nt0 + nb < C::NT && n < C::N) {
-      float bb = a.bias ? a.bias[n] : 0.f;
+      float bb = (a.bias && first) ? a.bias[n] : 0.f;
 #pragma unroll
       for (int mb = 0; mb < C::MB; ++mb) {
         float rb[16];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) rb[reg] = a.rowbias ? a.rowbias[rbo[mb][reg] + n] : 0.f;
+        for (int reg = 0; reg < 16; ++reg) rb[reg] = (a.rowbias && first) ? a.rowbias[rbo[mb][reg] + n] : 0.f;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           int f = f0 + mb * 32 + acc_row(reg, lane);
           if (f < a.F) {
-            if (a.out2 && n >= a.split)
-              a.out2[(int64_t)f * a.ldo + (n - a.split)] = acc[mb][nb][reg] + bb;
-            else
-              a.out[(int64_t)f * a.ldo + n] = acc[mb][nb][reg] + bb + rb[reg];
+            float* o = (a.out2 && n >= a.split) ? a.out2 + (int64_t)f * a.ldo + (n - a.split) : a.out + (int64_t)f * a.ldo + n;
+            const float v = acc[mb][nb][reg] + bb + ((a.out2 && n >= a.split) ? 0.f : rb[reg]);
+            if (ksplit) atomicAdd(o, v);
+            else *o = v;
           }
         }
       }
@@ -224,10 +228,11 @@ __global__ void __launch_bounds__(256) k_densegemm(DenseArgs a) {
   }
 }
 
+// ksplit > 1: the caller has zeroed the output(s)
 template <class C>
-inline void launch_densegemm(const DenseArgs& a, hipStream_t s) {
+inline void launch_densegemm(const DenseArgs& a, hipStream_t s, int ksplit = 1) {
   rt().ensure_lds(reinterpret_cast<const void*>(&k_densegemm<C>), C::LDS_BYTES);
-  dim3 grid((unsigned)cdiv(a.F, C::ROWS), (unsigned)C::NSPLIT);
+  dim3 grid((unsigned)cdiv(a.F, C::ROWS), (unsigned)C::NSPLIT, (unsigned)cmax(1, cmin_(ksplit, C::NCHUNK)));
   hipLaunchKernelGGL(k_densegemm<C>, grid, dim3(256), C::LDS_BYTES, s, a);
 }
 

@@ -433,13 +433,66 @@ __global__ void __launch_bounds__(256) k_ln_bwd_reduce(const float* __restrict__
   }
 }
 
+// Deferred second stages: at small batches the per-layer reduction launch (4.8 us, eight per step) costs more than its
+// work; the layers then write their partial rows to DISJOINT ranges of the scratch region and one launch per gradient
+// bucket adds them all (k_ln_bwd_reduce_multi).
+struct LnReduceEntry {
+  const float* part;
+  int nwg, C;
+  float *dgamma, *dbeta, *dbias;
+};
+struct LnReduceList {
+  static constexpr int MAXN = 8;
+  LnReduceEntry e[MAXN];
+  int n;
+  int64_t used;       // floats of the scratch region handed out so far
+  int64_t capacity;   // floats available
+};
+__global__ void __launch_bounds__(256) k_ln_bwd_reduce_multi(LnReduceList l) {
+  __shared__ float sm[4];
+  int col = blockIdx.x, k = 0;
+  while (k + 1 < l.n && col >= 3 * l.e[k].C) {
+    col -= 3 * l.e[k].C;
+    ++k;
+  }
+  const LnReduceEntry en = l.e[k];
+  if (col >= 3 * en.C) return;
+  float s = 0.f;
+  for (int w = threadIdx.x; w < en.nwg; w += 256) s += en.part[(int64_t)w * (3 * en.C) + col];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    float* o = col < en.C ? en.dgamma + col : (col < 2 * en.C ? en.dbeta + (col - en.C) : en.dbias + (col - 2 * en.C));
+    atomicAdd(o, t);
+  }
+}
+inline void flush_ln_reduce(LnReduceList& l, hipStream_t s) {
+  if (!l.n) return;
+  int cols = 0;
+  for (int i = 0; i < l.n; ++i) cols += 3 * l.e[i].C;
+  hipLaunchKernelGGL(k_ln_bwd_reduce_multi, dim3((unsigned)cols), dim3(256), 0, s, l);
+  l.n = 0;
+  l.used = 0;
+}
+
+// `defer` (may be null): the second stage is queued there instead of launched when its partial rows fit the region
 template <class L>
 inline void launch_ln_bwd(const float* dy, const float* a, const float* st, const float* gamma, const float* beta,
                           float* da, float* dgamma, float* dbeta, float* dbias, float* part, int F, int target_wgs,
-                          hipStream_t s) {
+                          hipStream_t s, LnReduceList* defer = nullptr) {
   rt().ensure_lds(reinterpret_cast<const void*>(&k_ln_bwd_fused<L>), L::LDS_BYTES);
   int fchunk = cmax(1, cdiv(F, target_wgs));
   int nwg = cdiv(F, fchunk);
+  if (defer && nwg > 8 && defer->n < LnReduceList::MAXN && defer->used + (int64_t)nwg * 3 * L::C <= defer->capacity) {
+    float* mine = part + defer->used;
+    hipLaunchKernelGGL(k_ln_bwd_fused<L>, dim3((unsigned)nwg), dim3(256), L::LDS_BYTES, s, dy, a, st, gamma, beta, da, mine, F,
+                       fchunk, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+    defer->e[defer->n++] = LnReduceEntry{mine, nwg, L::C, dgamma, dbeta, dbias};
+    defer->used += (int64_t)nwg * 3 * L::C;
+    return;
+  }
   if (nwg <= 8) {  // tiny batches only: same-address atomics from many workgroups serialise (256 workgroups: 104 us against 7 + 5)
     hipLaunchKernelGGL(k_ln_bwd_fused<L>, dim3((unsigned)nwg), dim3(256), L::LDS_BYTES, s, dy, a, st, gamma, beta, da, part, F,
                        fchunk, dgamma, dbeta, dbias);

@@ -112,8 +112,8 @@ using HeadsB = DenseCfg<256, 768, 256, 3, IN_CONCAT2, 1>;
 // merge: h = z Wz + T[y] (K = 128, the speaker's table row added in the epilogue); dz = dh Wz^T (N = 128)
 using MergeF = DenseCfg<128, 1539, 128, 2, IN_PLAIN, 1>;
 using MergeB = DenseCfg<1539, 128, 256, 1, IN_PLAIN, 1>;
-using HeadsFs = DenseCfg<768, 256, 256, 2, IN_LN, 3, 1>;
-using HeadsBs = DenseCfg<256, 768, 256, 3, IN_CONCAT2, 1, 1>;
+using HeadsFs = DenseCfg<768, 256, 128, 2, IN_LN, 3, 1>;   // (K chunks of 128: six-way split-K at small batches)
+using HeadsBs = DenseCfg<256, 768, 64, 3, IN_CONCAT2, 1, 1>;    // (K chunks of 64: four-way split-K)
 using MergeFs = DenseCfg<128, 1539, 128, 2, IN_PLAIN, 1, 1>;
 using MergeBs = DenseCfg<1539, 128, 256, 1, IN_PLAIN, 1, 1>;
 constexpr int MERGE_NY = 10;   // speakers of the VCC2016 geometry (the tuned path is selected for it only)
@@ -594,7 +594,16 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
     a.out2 = w.z_lv;
     a.split = 128;
     a.bias = w.scratch + Pk::heads_bias;  // [b_mu | b_lv], packed by prep()
-    VAENPVC_TIMED("heads_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<HeadsFs>(a, s) : launch_densegemm<HeadsF>(a, s)));
+    if (F < SMALL_BATCH_FRAMES) {   // few frames: the three K chunks on three workgroups per tile (split-K into zeroed outputs)
+      if (w.z_lv == w.z_mu + (size_t)F * 128) {   // (adjacent workspace regions: one fill)
+        (void)hipMemsetAsync(w.z_mu, 0, (size_t)F * 256 * 4, s);
+      } else {
+        (void)hipMemsetAsync(w.z_mu, 0, (size_t)F * 128 * 4, s);
+        (void)hipMemsetAsync(w.z_lv, 0, (size_t)F * 128 * 4, s);
+      }
+      VAENPVC_TIMED("heads_fwd", s, launch_densegemm<HeadsFs>(a, s, 6));
+    } else
+    VAENPVC_TIMED("heads_fwd", s, launch_densegemm<HeadsF>(a, s));
   } else generic::heads_fwd(m, P, F, w, s);
 }
 
@@ -785,6 +794,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   const int WGS = 512;    // workgroups of the chunked weight-gradient reductions: 2 per CU (LDS-bound residency);
                           // more chunks only deepen the same-address atomic chains on the small weight tensors
   const int LWGS = 2048;  // ... of the HBM-bound LayerNorm backward
+  // second stages of the LayerNorm backward kernels: queued and flushed once per gradient bucket at small batches (the
+  // partial rows of all queued layers must fit the scratch region: <= 2048 * 3 * 256 floats; large batches need it per layer)
+  LnReduceList lnq_store;
+  lnq_store.n = 0;
+  lnq_store.used = 0;
+  lnq_store.capacity = (int64_t)2048 * 3 * 256;
+  // (only when every step runs its tuned kernel: a generic fallback STORES the bias gradient its layer's LayerNorm
+  //  backward has added to, which is only right if that addition happened first)
+  LnReduceList* lnq = (F <= 512 && (rt().bwd_mask & 0x7ffu) == 0x7ffu) ? &lnq_store : nullptr;
 
   // ---- conv layers on the view GEMMs (gfx950_viewconv.h): producers / consumers of the channel-last planes
   auto gsplit = [&](int cl, const float* src, const char* tag) {   // gradient tensor -> planes
@@ -887,7 +905,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
                                                         w.scratch + Pk::wc, w.dy_tmp, F));
     }
     launch_ln_bwd<LnbCfg<8, 513>>(w.dy_tmp, w.dec_a[2], w.dec_st[2], P + l2.gamma_off, P + l2.beta_off, w.d_dec_a[2],
-                                     G + l2.gamma_off, G + l2.beta_off, G + l2.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
+                                     G + l2.gamma_off, G + l2.beta_off, G + l2.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
     dec_bias_done[2] = true;
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 3);
 
@@ -910,7 +928,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("dec2_dgrad", s, launch_convgemm<GD2>(conv_args(w.d_dec_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::gd2,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GD2>(F), s));
     launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[1],
-                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
+                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
     dec_bias_done[1] = true;
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 2);
 
@@ -933,7 +951,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("dec1_dgrad", s, launch_convgemm<GD1>(conv_args(w.d_dec_a[1], nullptr, nullptr, nullptr, P + l.w_off, nullptr,
                                                                   w.dy_tmp, F), nsplit_for<GD1>(F), s));
     launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[0],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
     dec_bias_done[0] = true;
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 1);
 
@@ -955,6 +973,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
                                                                   nullptr, w.d_h, F), nsplit_for<GD0s>(F), s) : launch_convgemm<GD0>(conv_args(w.d_dec_a[0], nullptr, nullptr, nullptr, w.scratch + Pk::gd0,
                                                                   nullptr, w.d_h, F), nsplit_for<GD0>(F), s)));
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 0);
+  if (lnq) flush_ln_reduce(*lnq, s);
   bucket(m.dec[0].w_off, m.n_params);  // all decoder conv layers (kernels, biases, LayerNorm parameters)
 
   // ---- merge + embedding
@@ -992,7 +1011,11 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       });
     } else {
       DenseArgs d = dense_args(w.d_h, w.scratch + Pk::merge_b, w.d_z, 128, F);
-      VAENPVC_TIMED("merge_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<MergeBs>(d, s) : launch_densegemm<MergeB>(d, s)));
+      if (F < SMALL_BATCH_FRAMES) {   // K = 1539 in seven chunks on seven workgroups per tile
+        (void)hipMemsetAsync(w.d_z, 0, (size_t)F * 128 * 4, s);
+        VAENPVC_TIMED("merge_dgrad", s, launch_densegemm<MergeBs>(d, s, 7));
+      } else
+      VAENPVC_TIMED("merge_dgrad", s, launch_densegemm<MergeB>(d, s));
     }
   } else generic::bwd_merge(m, P, y, F, w, G, s);
   bucket(m.wz_off, m.dec[0].w_off);  // the two merge FCs and the three merge biases (the embedding goes last)
@@ -1024,7 +1047,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       VAENPVC_TIMED("heads_dgrad", s, launch_gemm_nt<NPL>(a, s));
     });
     launch_ln_bwd<LnbCfg<256, 3>>(w.dy_tmp, w.enc_a[4], w.enc_st[4], P + l4.gamma_off, P + l4.beta_off, w.d_enc_a[4],
-                                     G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
+                                     G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
     enc_bias_done[4] = true;
   } else if (bwd_on(5)) {
     const ConvL& l4 = m.enc[4];
@@ -1041,9 +1064,13 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     // (the two head-bias gradients were accumulated by k_reparam_bwd_colsum)
     DenseArgs d = dense_args(w.d_z_mu, w.scratch + Pk::heads_b, w.dy_tmp, 768, F);
     d.in2 = w.d_z_lv;
-    VAENPVC_TIMED("heads_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<HeadsBs>(d, s) : launch_densegemm<HeadsB>(d, s)));
+    if (F < SMALL_BATCH_FRAMES) {
+      (void)hipMemsetAsync(w.dy_tmp, 0, (size_t)F * 768 * 4, s);
+      VAENPVC_TIMED("heads_dgrad", s, launch_densegemm<HeadsBs>(d, s, 4));
+    } else
+    VAENPVC_TIMED("heads_dgrad", s, launch_densegemm<HeadsB>(d, s));
     launch_ln_bwd<LnbCfg<256, 3>>(w.dy_tmp, w.enc_a[4], w.enc_st[4], P + l4.gamma_off, P + l4.beta_off, w.d_enc_a[4],
-                                     G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
+                                     G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
     enc_bias_done[4] = true;
   } else generic::bwd_heads(m, P, F, w, G, s);
   bucket(m.wmu_off, m.wz_off);  // the two dense heads
@@ -1068,7 +1095,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     });
     if (!enc_bias_done[4]) generic::bias_grad(w.d_enc_a[4], G + l.b_off, F, l.cout, l.hout, s);
     launch_ln_bwd<LnbCfg<128, 7>>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[3],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
     enc_bias_done[3] = true;
   } else if (bwd_on(4)) {
     const ConvL &l = m.enc[4], &pl = m.enc[3];
@@ -1078,7 +1105,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc4_dgrad", s, launch_convgemm<GE4>(conv_args(w.d_enc_a[4], nullptr, nullptr, nullptr, w.scratch + Pk::ge4,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE4>(F), s));
     launch_ln_bwd<LnbCfg<128, 7>>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[3],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
     enc_bias_done[3] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 4);
   if (bwd_on(3)) {
@@ -1096,7 +1123,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE3s>(F), s) : launch_convgemm<GE3>(conv_args(w.d_enc_a[3], nullptr, nullptr, nullptr, w.scratch + Pk::ge3,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE3>(F), s)));
     launch_ln_bwd<LnbCfg<64, 19>>(w.dy_tmp, w.enc_a[2], w.enc_st[2], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[2],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
     enc_bias_done[2] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 3);
   if (bwd_on(2)) {
@@ -1117,7 +1144,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE2s>(F), s) : launch_convgemm<GE2>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE2>(F), s)));
     launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.enc_a[1], w.enc_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[1],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
     enc_bias_done[1] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 2);
   if (bwd_on(1)) {
@@ -1136,7 +1163,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc1_dgrad", s, launch_convgemm<GE1>(conv_args(w.d_enc_a[1], nullptr, nullptr, nullptr, w.scratch + Pk::ge1,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE1>(F), s));
     launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.enc_a[0], w.enc_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[0],
-                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s);
+                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
     enc_bias_done[0] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 1);
   if (bwd_on(0)) {
@@ -1152,6 +1179,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc0_wgrad", s2, launch_convwgrad<WE0>(a, WGS, s2));
     if (!enc_bias_done[0]) generic::bias_grad(w.d_enc_a[0], G + l.b_off, F, l.cout, l.hout, s);
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 0);
+  if (lnq) flush_ln_reduce(*lnq, s);
   bucket(0, m.wmu_off);  // speaker embedding + encoder convs
   if (fork) rt().stream_dep(s2, s);  // join: everything after backward (Adam) sees all gradients
 }
