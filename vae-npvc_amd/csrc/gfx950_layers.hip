@@ -857,7 +857,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     if (toep_wgrad_bf16_for(F)) {
       // bf16 planes of both operands exist (forward producer, k_dxh_post above)
       unsigned short* gp = reinterpret_cast<unsigned short*>(w.toep_gp);
-      const int zc = (int)cmax(1, cmin_(rt().toep_zc, cdiv(F, 1024)));  // 8 x 8 x zc workgroups
+      const int zc = (int)cmax(1, cmin_(rt().toep_zc, cdiv(F, 1024)));  // 8 x 8 x zc workgroups (more chunks at small batches measured slower: more epilogues)
       const int fch = rup(cdiv((int)F, zc), WG_KF);
       for_planes([&](auto npl) {
         constexpr int NPL = decltype(npl)::value;
