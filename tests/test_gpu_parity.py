@@ -401,6 +401,7 @@ def test_plane_gemm_dense_layers_against_oracle(F, seed, precision):
     assert not fails, '\n'.join(fails)
 
 
+BF16_TOL_ACT, BF16_TOL_GRAD = 3e-2, 6e-2   # bf16 MODE (one bf16 term per operand, ~3 significant digits)
 VIEW_CONV = (0xebffffff, 0xebffffff)    # ... and bit 26: every conv site on the view GEMMs (csrc/gfx950_viewconv.h)
 
 
@@ -430,6 +431,29 @@ def test_fused_thin_conv_layers_against_oracle(F, seed, precision):
     2-frame workgroups.  (Three operand planes: the weight gradients and the medium site fall back.)"""
     eng = make_engine('vcc', 'auto', FUSED_CONV, precision=precision)
     fails = compare_everything(eng, F, seed, '%s fused-conv F%d ' % (precision, F))
+    assert not fails, '\n'.join(fails)
+
+
+@pytest.mark.parametrize('precision', ['bf16x2', 'bf16'])
+def test_default_selection_at_a_ragged_large_batch(precision):
+    """The DEFAULT kernel selection just above its thresholds, at a batch size that is a multiple of nothing the kernels
+    tile by (1027 frames: last frame groups of 3, 1 and 7 frames for the fused kernels' groups of 4, 2 and 8; 128-row
+    GEMM tiles with 3 rows; 32-row reduction chunks with odd tails) against the float64 oracle run inside the test:
+    every activation and every gradient, lrelu kink units pinned."""
+    F, seed = 1027, 31
+    eng = make_engine('vcc', 'auto', precision=precision)
+    if precision == 'bf16':
+        fails = []
+        P, x, y, eps, R = oracle_case(F, seed)
+        l3, grads = run_train(eng, P, x, y, eps)
+        _, G = oracle_grads(eng, ARCHS['vcc'], P, x, y, eps)
+        assert np.isfinite(grads).all()
+        check('bf16 ragged F1027 loss3', l3, np.array([R['G'], R['D_KL'], R['logP']]), BF16_TOL_ACT, fails)
+        for name, (off, shape) in eng.layout.items():
+            n = int(np.prod(shape))
+            check('bf16 ragged F1027 grad ' + name, grads[off:off + n].reshape(shape), G[name], BF16_TOL_GRAD, fails)
+    else:
+        fails = compare_everything(eng, F, seed, '%s ragged F%d ' % (precision, F))
     assert not fails, '\n'.join(fails)
 
 
@@ -484,7 +508,6 @@ def test_benchmarked_batch_sizes_against_oracle_fixture(F, seed, precision):
     assert not fails, '\n'.join(fails)
 
 
-BF16_TOL_ACT, BF16_TOL_GRAD = 3e-2, 6e-2   # bf16 MODE (one bf16 term per operand, ~3 significant digits)
 
 
 def test_bf16_mode_against_oracle_fixture():
