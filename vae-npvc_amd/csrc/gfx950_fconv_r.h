@@ -166,51 +166,70 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
     fstore(g);
     __syncthreads();
     if (g + (int)gridDim.x < ngroups) fload(g + gridDim.x);
-    const int nrows = nf * V.R, nsteps = cdiv(nrows, 32);
+    // CHN 32-row steps at a time = CHN independent accumulator chains sharing the wave's weight fragments (a single chain
+    // leaves the matrix pipe idle for most of an MFMA's latency).  Two planes: the weight tile leaves no registers for
+    // a second chain (it spilled 50 - 118 registers), one chain.
+    constexpr int CHN = NPL == 1 ? 2 : 1;
+    const int nrows = nf * V.R, npairs = cdiv(nrows, 32 * CHN);
     if (gemm_wave) {
-      for (int s = sub; s < nsteps; s += T::WPT) {
-        int n = s * 32 + l31;
-        const bool nok = n < nrows;
-        n = nok ? n : 0;
-        const int fl = n / V.R, q = n - fl * V.R;
-        const int xoff = fl * T::FS + q * T::RSTEP;
-        f32x16 acc = zero16();
+      for (int sp = sub; sp < npairs; sp += T::WPT) {
+        int nn[CHN], xoff[CHN];
+        bool nok[CHN];
+#pragma unroll
+        for (int h = 0; h < CHN; ++h) {
+          nn[h] = sp * (32 * CHN) + h * 32 + l31;
+          nok[h] = nn[h] < nrows;
+          const int n = nok[h] ? nn[h] : 0;
+          const int fl = n / V.R, q = n - fl * V.R;
+          xoff[h] = fl * T::FS + q * T::RSTEP;
+        }
+        f32x16 acc[CHN];
+#pragma unroll
+        for (int h = 0; h < CHN; ++h) acc[h] = zero16();
 #pragma unroll
         for (int ks = 0; ks < T::KS; ++ks) {
-          u32x4 fb[NPL];
+          u32x4 fb[CHN][NPL];
           const int ko = fc_koff<T::CP, T::CPL>(ks, lh);
 #pragma unroll
-          for (int p = 0; p < NPL; ++p) fb[p] = *reinterpret_cast<const u32x4*>(xs + p * T::XPL + xoff + ko);
+          for (int h = 0; h < CHN; ++h)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) fb[h][p] = *reinterpret_cast<const u32x4*>(xs + p * T::XPL + xoff[h] + ko);
           using PR = Prod<NPL>;
 #pragma unroll
-          for (int t = 0; t < PR::N; ++t) acc = mfma_bf16(wreg[ks][PR::A[t]], fb[PR::B[t]], acc);
+          for (int t = 0; t < PR::N; ++t)
+#pragma unroll
+            for (int h = 0; h < CHN; ++h) acc[h] = mfma_bf16(wreg[ks][PR::A[t]], fb[h][PR::B[t]], acc[h]);
         }
-        if (!nok) continue;
-        float* ob = a.out + (int64_t)(f0 + fl) * (V.OC * V.OH);
-        const int pbase = q * V.oq + V.o0;
-        if constexpr (T::PERM) {
-          // tile row = phase * 8 + channel % 8: registers cs, cs + 4, cs + 8 of this lane are the three phases
-          struct __attribute__((packed, aligned(4))) f3 { float x, y, z; };
-          const bool inner = pbase >= 0 && pbase + 2 < V.OH;
 #pragma unroll
-          for (int cs = 0; cs < 4; ++cs) {
-            const int ch = tile * 8 + cs + 4 * lh;
-            const float bb = a.bias ? a.bias[ch] : 0.f;
-            const float p0 = acc[cs] + bb, p1 = acc[cs + 4] + bb, p2 = acc[cs + 8] + bb;
-            float* o = ob + ch * V.OH + pbase;
-            if (inner) {
-              *reinterpret_cast<f3*>(o) = f3{p0, p1, p2};
-            } else {
-              if (pbase >= 0 && pbase < V.OH) o[0] = p0;
-              if (pbase + 1 >= 0 && pbase + 1 < V.OH) o[1] = p1;
-              if (pbase + 2 >= 0 && pbase + 2 < V.OH) o[2] = p2;
+        for (int h = 0; h < CHN; ++h) {
+          if (!nok[h]) continue;
+          const int fl = nn[h] / V.R, q = nn[h] - fl * V.R;
+          float* ob = a.out + (int64_t)(f0 + fl) * (V.OC * V.OH);
+          const int pbase = q * V.oq + V.o0;
+          if constexpr (T::PERM) {
+            // tile row = phase * 8 + channel % 8: registers cs, cs + 4, cs + 8 of this lane are the three phases
+            struct __attribute__((packed, aligned(4))) f3 { float x, y, z; };
+            const bool inner = pbase >= 0 && pbase + 2 < V.OH;
+#pragma unroll
+            for (int cs = 0; cs < 4; ++cs) {
+              const int ch = tile * 8 + cs + 4 * lh;
+              const float bb = a.bias ? a.bias[ch] : 0.f;
+              const float p0 = acc[h][cs] + bb, p1 = acc[h][cs + 4] + bb, p2 = acc[h][cs + 8] + bb;
+              float* o = ob + ch * V.OH + pbase;
+              if (inner) {
+                *reinterpret_cast<f3*>(o) = f3{p0, p1, p2};
+              } else {
+                if (pbase >= 0 && pbase < V.OH) o[0] = p0;
+                if (pbase + 1 >= 0 && pbase + 1 < V.OH) o[1] = p1;
+                if (pbase + 2 >= 0 && pbase + 2 < V.OH) o[2] = p2;
+              }
             }
-          }
-        } else {
+          } else {
 #pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const int ch = tile * 32 + acc_row(reg, lane);
-            if (ch < V.O && pbase >= 0 && pbase < V.OH) ob[ch * V.OH + pbase] = acc[reg] + (a.bias ? a.bias[ch] : 0.f);
+            for (int reg = 0; reg < 16; ++reg) {
+              const int ch = tile * 32 + acc_row(reg, lane);
+              if (ch < V.O && pbase >= 0 && pbase < V.OH) ob[ch * V.OH + pbase] = acc[h][reg] + (a.bias ? a.bias[ch] : 0.f);
+            }
           }
         }
       }
