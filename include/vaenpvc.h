@@ -156,6 +156,17 @@ int vaenpvc_train_fwd_bwd_seeded(vaenpvc_ctx* ctx, const float* d_params, const 
                                  const int64_t* d_offset, int64_t F, float* d_grads,
                                  float* d_loss3, void* d_ws, size_t ws_bytes, void* stream);
 int vaenpvc_philox_normal(uint64_t seed, uint64_t offset, float* d_out, int64_t n, void* stream);
+/* U[0,1) from the same generator (element e = top 24 bits of word e & 3 of counter (e >> 2, offset)): the
+ * per-frame interpolation coefficients of the gradient penalty (tf.random_uniform in WGAN-GP critics). */
+int vaenpvc_philox_uniform(uint64_t seed, uint64_t offset, float* d_out, int64_t n, void* stream);
+
+/* The same step with the log-density evaluated against d_target [F,H] instead of d_x (the encoder still reads
+ * d_x): d G / d xh becomes (xh - target) / ((1 + 1e-6) F).  With target = x + alpha (1 + 1e-6) dD(xh)/dxh
+ * (vaenpvc_disc_generator_target) the 'Generator' and 'y_emb' ranges of d_grads hold the gradient of
+ * l_G = -logP + alpha W_dist of the VAWGAN trainer (trainer/vae.py:141-145); d_loss3 is then meaningless. */
+int vaenpvc_train_fwd_bwd_target(vaenpvc_ctx* ctx, const float* d_params, const float* d_x,
+                                 const int64_t* d_y, const float* d_eps, const float* d_target, int64_t F,
+                                 float* d_grads, float* d_loss3, void* d_ws, size_t ws_bytes, void* stream);
 
 /* Gradient buckets for data-parallel overlap (no reference counterpart: the reference is single
  * GPU).  The backward pass finishes the flat gradient buffer back to front -- decoder convs,
@@ -192,6 +203,48 @@ int vaenpvc_adam_step(float* d_params, const float* d_grads, float* d_m, float* 
 int vaenpvc_adam_step_dev(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n,
                           int64_t* d_step, float lr, float beta1, float beta2, float eps,
                           float grad_scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * VAWGAN branch (trainer/vae.py:115-218, architecture-vawgan-vcc2016.json).  The reference tree holds the
+ * trainer and the architecture file but not the model class (README.md:3 points at another git branch), so
+ * the critic is SPECIFIED in DESIGN.md section 9 from what the tree pins down: convs of
+ * arch["discriminator"] built with the tree's conv + LayerNorm + lrelu block (util/layers.py:47-66,147-149),
+ * one dense unit, WGAN-GP losses
+ *     W_dist = mean D(x) - mean D(xh),  gp = mean_f (|dD(xi_f)/dxi_f| - 1)^2,  xi = x + t (xh - x),
+ *     l_D = -W_dist + lambda gp,  l_E = -logP + D_KL,  l_G = -logP + alpha W_dist.
+ * The critic owns its own flat parameter buffer (14 tensors for the VCC2016 file, names
+ * Discriminator/Conv2d-<i>/{kernel,bias,layernorm.offset,layernorm.scale}, Discriminator/dense/{kernel,bias});
+ * the object holds geometry only, no device memory and no mutable state. */
+typedef struct vaenpvc_disc_arch {
+  int32_t H; /* arch["hwc"][0] */
+  int32_t n_layers;
+  int32_t kernel[VAENPVC_MAX_LAYERS]; /* arch["discriminator"]["kernel"][i][0] */
+  int32_t stride[VAENPVC_MAX_LAYERS];
+  int32_t output[VAENPVC_MAX_LAYERS];
+} vaenpvc_disc_arch;
+typedef struct vaenpvc_disc vaenpvc_disc;
+int vaenpvc_disc_create(const vaenpvc_disc_arch* arch, vaenpvc_disc** out);
+void vaenpvc_disc_destroy(vaenpvc_disc* disc);
+int vaenpvc_disc_param_count(const vaenpvc_disc* disc);
+int64_t vaenpvc_disc_param_floats(const vaenpvc_disc* disc);
+int vaenpvc_disc_param_info(const vaenpvc_disc* disc, int index, char* name, int name_cap,
+                            int64_t* offset_floats, int32_t* ndim, int64_t* shape);
+int64_t vaenpvc_disc_workspace_bytes(const vaenpvc_disc* disc, int64_t F); /* 1 <= F <= 65536 */
+/* Critic values of x and xh: d_out (may be NULL) float[2F] = D(x) | D(xh); d_loss2 (may be NULL) = {W_dist, 0}. */
+int vaenpvc_disc_fwd(const vaenpvc_disc* disc, const float* d_dparams, const float* d_x, const float* d_xh,
+                     int64_t F, float* d_out, float* d_loss2, void* d_ws, size_t ws_bytes, void* stream);
+/* `optimizer.minimize(loss['l_D'], var_list=d_vars)` gradient half (trainer/vae.py:141): d_t float[F] are the
+ * interpolation coefficients; d_dgrads (critic layout) is OVERWRITTEN with d l_D / d critic parameters
+ * (first and second order terms: the penalty differentiates the critic's input gradient);
+ * d_loss2 = {W_dist, gp} (the trainer's status line, trainer/vae.py:196-201). */
+int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* disc, const float* d_dparams, const float* d_x,
+                                const float* d_xh, const float* d_t, int64_t F, float lambda,
+                                float* d_dgrads, float* d_loss2, void* d_ws, size_t ws_bytes, void* stream);
+/* Generator side of the adversarial term: d_target [F,H] = x + alpha (1 + 1e-6) dD(xh)/dxh, to be passed to
+ * vaenpvc_train_fwd_bwd_target; d_loss2 (may be NULL) = {W_dist, 0}. */
+int vaenpvc_disc_generator_target(const vaenpvc_disc* disc, const float* d_dparams, const float* d_x,
+                                  const float* d_xh, int64_t F, float alpha, float* d_target, float* d_loss2,
+                                  void* d_ws, size_t ws_bytes, void* stream);
 
 /* Tanhize.forward_process / backward_process (analyzer.py:82-87), per bin:
  * fwd: clip((x-xmin)/(xmax-xmin),0,1)*2-1 ; bwd: (x*.5+.5)*(xmax-xmin)+xmin.

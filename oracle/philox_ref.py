@@ -46,3 +46,15 @@ def normal(n, seed, offset=0):
         out[:, o] = r * np.cos(ang).astype(np.float32)
         out[:, o + 1] = r * np.sin(ang).astype(np.float32)
     return out.reshape(-1)[:n]
+
+
+def uniform(n, seed, offset=0):
+    """The first n elements of the device U[0,1) draw for (seed, offset), float32: word e & 3 of counter
+    (e >> 2, offset), top 24 bits."""
+    nq = (n + 3) // 4
+    q = np.arange(nq, dtype=np.uint64)
+    ctr = np.stack([(q & MASK).astype(np.uint32), (q >> np.uint64(32)).astype(np.uint32),
+                    np.full(nq, offset & 0xFFFFFFFF, np.uint32), np.full(nq, (offset >> 32) & 0xFFFFFFFF, np.uint32)], -1)
+    key = np.broadcast_to(np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], np.uint32), (nq, 2))
+    x = philox4x32_10(ctr, key)
+    return ((x >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)).reshape(-1)[:n]

@@ -1,0 +1,226 @@
+"""VAWGAN branch on the GPU against the float64 autograd oracle (oracle/vawgan_oracle.py):
+critic step (first and second order terms), the generator-side adversarial gradient through the ConvVAE
+backward, and iterations of the trainer's schedule.  The model is a specification (the reference tree holds
+only its trainer): PARITY UNPINNED, see the oracle's header."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import PKG, rel_err
+from oracle import convvae_oracle as O
+from oracle import vawgan_oracle as V
+from oracle import philox_ref
+
+pytestmark = pytest.mark.gpu
+
+TOL_VALUE = 1e-4     # losses, critic values
+TOL_GRAD = 3e-4      # gradients, relative to the tensor's largest entry (second-order terms included)
+
+
+def vawgan_arch():
+    with open(os.path.join(PKG, 'architecture-vawgan-vcc2016.json')) as fp:
+        return json.load(fp)
+
+
+def critic_inputs(F, seed):
+    rng = np.random.RandomState(seed)
+    x = np.tanh(rng.randn(F, 513)).astype(np.float32)
+    xh = np.tanh(0.7 * rng.randn(F, 513) + 0.2).astype(np.float32)
+    t = rng.rand(F).astype(np.float32)
+    return x, xh, t
+
+
+def make_critic(arch, seed):
+    from hipvae.critic import Critic
+    cr = Critic(arch)
+    D = V.disc_init_params(arch, seed)
+    assert list(cr.layout.keys()) == list(D.keys())
+    for k, (off, shape) in cr.layout.items():
+        assert tuple(shape) == D[k].shape, k
+    cr.load_flat(V.flatten(D))
+    return cr, D
+
+
+@pytest.mark.parametrize('F', [1, 5, 16])
+def test_critic_step_matches_autograd_oracle(F):
+    arch = vawgan_arch()
+    cr, D = make_critic(arch, 3)
+    x, xh, t = critic_inputs(F, 10 + F)
+    want, gw = V.critic_loss_and_grads(arch, D, x.astype(np.float64), xh.astype(np.float64), t.astype(np.float64), 10.0)
+    dev = cr.device
+    grads = torch.full((cr.n_params,), float('nan'), device=dev)
+    l2 = cr.critic_fwd_bwd(torch.tensor(x, device=dev), torch.tensor(xh, device=dev), torch.tensor(t, device=dev), 10.0,
+                           grads).cpu().numpy()
+    vals, _ = cr.values(torch.tensor(x, device=dev), torch.tensor(xh, device=dev))
+    vals = vals.cpu().numpy()
+    assert rel_err(vals[:F], want['d_real']) < TOL_VALUE and rel_err(vals[F:], want['d_fake']) < TOL_VALUE
+    assert abs(l2[0] - want['W_dist']) < TOL_VALUE * max(1.0, abs(want['W_dist']))
+    assert abs(l2[1] - want['gp']) < 2e-4 * max(1.0, abs(want['gp']))
+    got = cr.param_views(grads.cpu())
+    worst = {}
+    for k in gw:
+        g = got[k].numpy().reshape(gw[k].shape)
+        assert np.isfinite(g).all(), k
+        worst[k] = float(np.abs(g - gw[k]).max() / max(np.abs(gw[k]).max(), 1e-3))
+    assert max(worst.values()) < TOL_GRAD, worst
+
+
+def test_critic_step_is_deterministic_and_linear_in_lambda():
+    """Bitwise repeatable (no atomics), and grad(lambda) is affine in lambda: g(20) - g(10) == g(10) - g(0)."""
+    arch = vawgan_arch()
+    cr, _ = make_critic(arch, 4)
+    x, xh, t = (torch.tensor(a, device=cr.device) for a in critic_inputs(7, 2))
+    g = [torch.empty(cr.n_params, device=cr.device) for _ in range(4)]
+    for gi, lam in zip(g, (0.0, 10.0, 20.0, 10.0)):
+        cr.critic_fwd_bwd(x, xh, t, lam, gi)
+    assert torch.equal(g[1], g[3])
+    d1, d2 = (g[2] - g[1]).cpu().numpy(), (g[1] - g[0]).cpu().numpy()
+    assert np.abs(d1 - d2).max() < 1e-4 * np.abs(d2).max()
+
+
+def test_generator_step_gradients_match_oracle():
+    """l_E on 'Encoder', l_G = -logP + alpha W_dist on 'Generator' + 'y_emb', from the two ConvVAE passes."""
+    from hipvae.engine import Engine
+    from hipvae.adversarial import AdvStepper, name_ranges
+    arch = vawgan_arch()
+    F, alpha = 16, 50.0
+    eng = Engine(arch, precision='bf16x3')
+    P = O.init_params(arch, 7)
+    eng.load_flat(O.flatten_params(P))
+    cr, D = make_critic(arch, 5)
+    x, y, eps = O.make_inputs(arch, F, 9)
+    want, gw = V.encoder_generator_grads(arch, P, D, x, y, eps, alpha)
+    st = AdvStepper(eng, cr, 1e-4, 0.5, 0.999, alpha, 10.0)
+    p0 = eng.params.clone()
+    dev = eng.device
+    out = st.generator_step(torch.tensor(x, dtype=torch.float32, device=dev), torch.tensor(y, device=dev),
+                            torch.tensor(eps, dtype=torch.float32, device=dev))
+    assert abs(float(out['W_dist']) - want['W_dist']) < TOL_VALUE * max(1.0, abs(want['W_dist']))
+    assert abs(float(out['logP']) - want['logP']) < 1e-4 * abs(want['logP'])
+    assert abs(float(out['D_KL']) - want['D_KL']) < 1e-4 * abs(want['D_KL'])
+    ge, gg = eng.param_views(st.g_e.cpu()), eng.param_views(st.g_g.cpu())
+    worst = {}
+    for k, g in gw.items():
+        got = (ge if 'Encoder' in k else gg)[k].numpy().reshape(g.shape)
+        worst[k] = float(np.abs(got - g).max() / max(np.abs(g).max(), 1e-6))
+    assert max(worst.values()) < TOL_GRAD, worst
+    # the applies touched exactly the three groups, Encoder with t = 1 and Generator / y_emb with t = 2
+    assert st.applies == 2 and st.step_count == 1
+    changed = (eng.params != p0).cpu().numpy()
+    cover = np.zeros(eng.n_params, bool)
+    for lo, hi in name_ranges(eng.layout, lambda n: True):
+        cover[lo:hi] = True
+    assert cover.all() and changed.mean() > 0.99
+    pv, p0v = eng.param_views(eng.params.cpu()), eng.param_views(p0.cpu())
+    for k, t in (('Encoder/Conv2d-2/kernel', 1), ('Generator/conv2d_transpose_1/kernel', 2), ('y_embedding/y_emb', 2)):
+        wantp, _, _ = O.tf_adam_step(P[k], gw[k], 0.0, 0.0, t, 1e-4, 0.5, 0.999)
+        got_delta = (pv[k] - p0v[k]).numpy().reshape(P[k].shape)
+        assert rel_err(got_delta, wantp - P[k]) < 2e-3, k
+
+
+def test_two_iterations_follow_the_oracle_trajectory():
+    """trainer/vae.py:176-179 with nIterD = 2: critic, critic, generator (encoder then generator apply), twice;
+    every step on its own batch; one Adam apply counter across the three groups."""
+    from hipvae.engine import Engine
+    from hipvae.adversarial import AdvStepper
+    arch = vawgan_arch()
+    F, n_d, iters = 8, 2, 2
+    lr, b1, b2, alpha, lam = 1e-4, 0.5, 0.999, 50.0, 10.0
+    eng = Engine(arch, precision='bf16x3')
+    P = O.init_params(arch, 11)
+    eng.load_flat(O.flatten_params(P))
+    cr, D = make_critic(arch, 12)
+    batches = []
+    for i in range(iters * (n_d + 1)):
+        x, y, eps = O.make_inputs(arch, F, 100 + i)
+        batches.append(dict(x=x, y=y, eps=eps, u=np.random.RandomState(200 + i).rand(F)))
+    Pw, Dw, log, strong = V.train_iterations(arch, P, D, batches, lr, b1, b2, alpha, lam, n_d)
+    st = AdvStepper(eng, cr, lr, b1, b2, alpha, lam)
+    dev = eng.device
+    tt = lambda a, dt=torch.float32: torch.tensor(np.asarray(a), dtype=dt, device=dev)
+    it = iter(batches)
+    for _ in range(iters):
+        for _ in range(n_d):
+            b = next(it)
+            st.critic_step(tt(b['x']), tt(b['y'], torch.int64), tt(b['eps']), tt(b['u']))
+        b = next(it)
+        out = st.generator_step(tt(b['x']), tt(b['y'], torch.int64), tt(b['eps']))
+    assert st.applies == iters * (n_d + 2) and st.step_count == iters
+    assert abs(float(out['W_dist']) - log[-1]['W_dist']) < 5e-3 * max(1.0, abs(log[-1]['W_dist']))
+    # Compare the parameter MOVES.  Adam divides every entry by its own gradient history (and here starts at t = 3,
+    # where sqrt(v) is only ~0.03 |g| against eps = 1e-8), so entries near a float32 implementation's noise floor
+    # follow no particular trajectory: the tight bar applies where the gradient was well above it in every apply
+    # (as in tests/test_gpu_plugins.py), a loose statistical bar everywhere.
+    dv, pv = cr.param_views(cr.params.cpu()), eng.param_views(eng.params.cpu())
+    n_strong = 0
+    for got, want, start in ((dv, Dw, D), (pv, Pw, P)):
+        for k in want:
+            move = np.abs(want[k] - start[k]).max()
+            if move < 1e-9:                              # the critic's dense bias: its gradient is identically zero
+                continue
+            dev = np.abs(got[k].numpy().reshape(want[k].shape) - want[k])
+            ok = strong[k]
+            n_strong += int(ok.sum())
+            if ok.any():
+                assert dev[ok].mean() < 0.03 * move and np.quantile(dev[ok], 0.99) < 0.15 * move, (k, dev[ok].mean() / move)
+                assert dev[ok].max() < 1.1 * move, (k, dev[ok].max() / move)   # (m = 0.25 g1 + 0.5 g2 can cancel)
+            assert dev.mean() < 0.08 * move, (k, dev.mean() / move)
+    assert n_strong > 20000
+
+
+def test_uniform_draw_matches_numpy_philox():
+    from hipvae.engine import Engine
+    eng = Engine(vawgan_arch())
+    got = eng.philox_uniform(1000, 77, 5).cpu().numpy()
+    assert np.array_equal(got, philox_ref.uniform(1000, 77, 5))
+    assert got.min() >= 0.0 and got.max() < 1.0
+
+
+def test_vawgan_plugins_train_and_checkpoint(tmp_path):
+    """main.py wiring with --model VAWGAN --trainer VAWGANTrainer on synthetic .bin data: loss keys, schedule
+    (nIterD critic batches + 1 generator batch per iteration), status line, checkpoint round trip."""
+    import analyzer
+    from model.vawgan import VAWGAN
+    from trainer.vae import VAWGANTrainer
+    from test_gpu_plugins import make_dataset
+    arch = vawgan_arch()
+    arch['training'].update(max_iter=2, batch_size=16, nIterD=3)
+    allr, xmin, xmax = make_dataset(str(tmp_path))
+    arch['training']['datadir'] = [os.path.join(str(tmp_path), 'bin', 'Training Set', s, '*.bin') for s in ('SF1', 'TM3')]
+    image, label = analyzer.read(arch['training']['datadir'], 16, normalizer=analyzer.Tanhize(xmax=xmax, xmin=xmin), seed=3)
+    machine = VAWGAN(arch, seed=5)
+    n_batches = [0]
+    orig = image.source.next_batch
+    def spy():
+        n_batches[0] += 1
+        return orig()
+    image.source.next_batch = spy
+    loss = machine.loss(image, label)
+    assert set(loss.keys()) == {'l_D', 'l_E', 'l_G', 'D_KL', 'logP', 'W_dist', 'gp'}
+    dirs = {'logdir': os.path.join(str(tmp_path), 'logdir', 'train', 'stamp')}
+    trainer = VAWGANTrainer(loss, arch, types.SimpleNamespace(seed=17, restore_from=None, ckpt=None), dirs)
+    assert set(trainer.opt.keys()) == {'d', 'g', 'e', 'global_step'}
+    d0, p0 = machine.critic.params.clone(), machine.engine.params.clone()
+    path = trainer.train(nIter=2)
+    st = trainer.opt['g']
+    assert n_batches[0] == 2 * 4 and st.step_count == 2 and st.applies == 2 * 5
+    assert os.path.basename(path) == 'model.ckpt-2'
+    assert not torch.equal(d0, machine.critic.params) and not torch.equal(p0, machine.engine.params)
+    msg = trainer._refresh_status()
+    assert msg.startswith('Iter 00002: W_dist = ') and 'GP = ' in msg and 'D_KL(z) = ' in msg
+    assert all(np.isfinite(float(v)) for v in st.status.values())
+    # eager loss on tensors
+    x, y = orig()
+    ev = machine.loss(x, y)
+    assert abs(float(ev['l_D']) - (-float(ev['W_dist']) + 10 * float(ev['gp']))) < 1e-3 * (1 + abs(float(ev['l_D'])))
+    # restore into a fresh machine
+    m2 = VAWGAN(arch, seed=99)
+    t2 = VAWGANTrainer(m2.loss(image, label), arch, types.SimpleNamespace(seed=17, restore_from=None, ckpt=None),
+                       {'logdir': dirs['logdir']})
+    assert t2.restore(dirs['logdir']) == 2
+    assert torch.equal(m2.critic.params, machine.critic.params) and torch.equal(m2.engine.params, machine.engine.params)
+    assert t2.opt['g'].applies == st.applies

@@ -174,9 +174,10 @@ def read(file_pattern, batch_size, record_bytes=RECORD_BYTES, capacity=256, min_
     `num_threads` is meaningless here (no reader threads: the records live in HBM)."""
     if record_bytes != RECORD_BYTES:
         raise ValueError('records are %d bytes' % RECORD_BYTES)
-    files = sorted(glob.glob(file_pattern))
+    patterns = [file_pattern] if isinstance(file_pattern, str) else list(file_pattern)   # (the VAWGAN file lists two)
+    files = sorted({f for p in patterns for f in glob.glob(p)})
     if not files:
-        raise FileNotFoundError('no files match %r' % file_pattern)
+        raise FileNotFoundError('no files match %r' % (file_pattern,))
     recs = [np.fromfile(f, '<f4').reshape(-1, FEAT_DIM) for f in files]
     store = FrameStore(np.concatenate(recs, 0), batch_size, normalizer, seed=seed, rank=rank, world=world,
                        capacity=capacity, min_after_dequeue=min_after_dequeue, file_sizes=[len(r) for r in recs])

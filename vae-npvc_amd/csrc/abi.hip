@@ -37,6 +37,10 @@ static int fail(int code, const char* f, ...) {
   return code;
 }
 
+namespace vaenpvc {
+int abi_error(int code, const char* msg) { return fail(code, "%s", msg); }
+}  // namespace vaenpvc
+
 // shared ownership: a layout handed out stays valid even if the cache is trimmed meanwhile
 static std::shared_ptr<const Layout> layout_of(vaenpvc_ctx* c, int64_t F, int mode) {
   std::lock_guard<std::recursive_mutex> lk(c->mu);
@@ -163,7 +167,7 @@ int vaenpvc_timer_read(vaenpvc_ctx* ctx, double* total_ms, int64_t* launches) {
   return 0;
 }
 
-int vaenpvc_abi_version(void) { return 2; }
+int vaenpvc_abi_version(void) { return 3; }
 const char* vaenpvc_last_error(void) { return g_err; }
 
 int vaenpvc_ctx_create(const vaenpvc_arch* arch, vaenpvc_ctx** out) {
@@ -269,13 +273,14 @@ int vaenpvc_decode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_z
 }
 
 static int fwd_all(vaenpvc_ctx* ctx, const float* P, const float* x, const int64_t* y, const float* eps,
-                   const PhiloxKey* key, int64_t F, const Ws& w, bool want_grad, float* loss3, hipStream_t s) {
+                   const PhiloxKey* key, int64_t F, const Ws& w, bool want_grad, float* loss3, hipStream_t s,
+                   const float* target = nullptr) {
   if (use_tuned(ctx)) tuned::encoder_fwd(ctx->m, P, x, F, w, s);
   else generic::encoder_fwd(ctx->m, P, x, F, w, s);
   generic::reparam_fwd(ctx->m, eps, key, F, w, s);
   if (use_tuned(ctx)) tuned::decoder_fwd(ctx->m, P, w.z, y, F, w, w.xh, s, /*weights_packed=*/true);
   else generic::decoder_fwd(ctx->m, P, w.z, y, F, w, w.xh, s);
-  generic::loss_fwd(ctx->m, x, F, w, want_grad, loss3, s);
+  generic::loss_fwd(ctx->m, target ? target : x, F, w, want_grad, loss3, s);   // (the density's data argument)
   return 0;
 }
 
@@ -307,14 +312,14 @@ int vaenpvc_loss_fwd_seeded(vaenpvc_ctx* ctx, const float* d_params, const float
 
 static int train_impl(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, const int64_t* d_y,
                       const float* d_eps, const PhiloxKey* key, int64_t F, float* d_grads, float* d_loss3, void* d_ws,
-                      size_t ws_bytes, void* stream) {
+                      size_t ws_bytes, void* stream, const float* d_target = nullptr) {
   if (!ctx || !d_params || !d_x || !d_y || (!d_eps && !key) || !d_grads || !d_loss3) return fail(VAENPVC_E_ARG, "null argument");
   Call call(ctx);
   Ws w;
   int rc = resolve(ctx, F, VAENPVC_MODE_TRAIN, d_ws, ws_bytes, &w);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  fwd_all(ctx, d_params, d_x, d_y, d_eps, key, F, w, true, d_loss3, s);
+  fwd_all(ctx, d_params, d_x, d_y, d_eps, key, F, w, true, d_loss3, s, d_target);
   const float* eps_bwd = key ? w.eps : d_eps;   // (the seeded sampler stored its draw in the workspace)
   ctx->rt.bucket_next = 0;
   if (use_tuned(ctx)) {
@@ -339,10 +344,22 @@ int vaenpvc_train_fwd_bwd_seeded(vaenpvc_ctx* ctx, const float* d_params, const 
   return train_impl(ctx, d_params, d_x, d_y, nullptr, &k, F, d_grads, d_loss3, d_ws, ws_bytes, stream);
 }
 
+int vaenpvc_train_fwd_bwd_target(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, const int64_t* d_y,
+                                 const float* d_eps, const float* d_target, int64_t F, float* d_grads,
+                                 float* d_loss3, void* d_ws, size_t ws_bytes, void* stream) {
+  if (!d_target) return fail(VAENPVC_E_ARG, "null argument");
+  return train_impl(ctx, d_params, d_x, d_y, d_eps, nullptr, F, d_grads, d_loss3, d_ws, ws_bytes, stream, d_target);
+}
+
 int vaenpvc_philox_normal(uint64_t seed, uint64_t offset, float* d_out, int64_t n, void* stream) {
   if (!d_out || n < 1) return fail(VAENPVC_E_ARG, "bad argument");
   launch_philox_normal(d_out, n, make_key(seed, offset), (hipStream_t)stream);
   return check_launch("philox_normal");
+}
+int vaenpvc_philox_uniform(uint64_t seed, uint64_t offset, float* d_out, int64_t n, void* stream) {
+  if (!d_out || n < 1) return fail(VAENPVC_E_ARG, "bad argument");
+  launch_philox_uniform(d_out, n, make_key(seed, offset), (hipStream_t)stream);
+  return check_launch("philox_uniform");
 }
 
 int vaenpvc_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n, int64_t step,

@@ -1,0 +1,649 @@
+// disc.hip -- the critic ("Discriminator") of the VAWGAN branch: forward, the WGAN-GP critic step with its
+// double backward, and the input gradient the generator step needs.  trainer/vae.py:115-218 is the consumer
+// in the reference; the model is specified in DESIGN.md section 9 (the reference tree does not hold it).
+//
+// The branch trains 16-frame batches (architecture-vawgan-vcc2016.json:33), 48 frames through three small
+// convolutions: launch-bound, so the kernels here are one-thread-per-output with sequential inner loops
+// (deterministic: no atomics; every gradient tensor is accumulated by exactly one thread per element, pass
+// after pass on one stream).  Conventions follow generic_kernels.hip: frames-major [B, C, H] float32, the
+// PRE-LN conv output `u` plus per-frame (mean, rstd) is what is kept, consumers apply lrelu(LN(u)) on load.
+//
+// Critic step for F frames, B = 3F rows (x | xh | xi = x + t (xh - x)):
+//   pass 1  forward of all rows                                  -> d[B]
+//   pass 2  backward of sum_f d_f w.r.t. the INPUT, rows xi only -> g_f, keeps abar_l (gradient at the
+//           activations) and ubar_l (gradient at the pre-LN outputs)
+//           gp_f = (|g_f| - 1)^2 ,  gt_f = (2 lambda / F)(|g_f| - 1) g_f / |g_f|
+//   pass 3  adjoint of pass 2, bottom-up, rows xi only: q_l = conv_l(adjoint of abar_{l-1}); the conv input
+//           gradient is bilinear in (W_l, ubar_l), so dW_l += wgrad(adjoint of abar_{l-1}, ubar_l); the
+//           LayerNorm backward is linear in its upstream (adjoint = the same operator applied to q) and
+//           depends on u through xhat and rstd (adjoint `udir_l`, injected into pass 4)
+//   pass 4  ordinary backward of all rows with upstream -1/F (x), +1/F (xh), 0 (xi) plus udir_l on rows xi.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace vaenpvc {
+namespace disc {
+
+#define LN_EPS 1e-5f
+#define LEAK 0.02f
+#define EPSILON 1e-6f
+
+struct G {
+  int cin, hin, cout, hout, k, s, pad;
+};
+struct Act {  // LN-on-load descriptor; st == nullptr -> identity
+  const float* st;
+  const float* gamma;
+  const float* beta;
+};
+static const Act kNoAct{nullptr, nullptr, nullptr};
+
+__device__ __forceinline__ float lnact(float v, const Act& a, int64_t f, int c) {
+  if (a.st == nullptr) return v;
+  float n = (v - a.st[2 * f]) * a.st[2 * f + 1] * a.gamma[c] + a.beta[c];
+  return fmaxf(n, LEAK * n);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// all threads receive the block total; blockDim.x a multiple of 64, <= 1024
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sm[i];
+  return r;
+}
+static inline dim3 grid1(int64_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+// ------------------------------------------------------------------------------------------- forward
+// rows [x | xh | xi]: xi_f = x_f + t_f (xh_f - x_f); t == nullptr: two groups only
+__global__ void k_rows(const float* __restrict__ x, const float* __restrict__ xh, const float* __restrict__ t,
+                       float* __restrict__ rows, int64_t F, int H) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= F * H) return;
+  float a = x[idx], b = xh[idx];
+  rows[idx] = a;
+  rows[F * H + idx] = b;
+  if (t) rows[2 * F * H + idx] = a + t[idx / H] * (b - a);
+}
+
+// util/layers.py:56-64 : out[f,o,j] = b[o] + sum_c sum_t W[t,c,o] * act(in)[f,c,s*j-pad+t]   (b may be null)
+__global__ void k_conv_fwd(const float* __restrict__ in, Act ai, const float* __restrict__ W,
+                           const float* __restrict__ b, float* __restrict__ out, int64_t B, G g) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * g.cout * g.hout) return;
+  int j = (int)(idx % g.hout);
+  int o = (int)((idx / g.hout) % g.cout);
+  int64_t f = idx / ((int64_t)g.hout * g.cout);
+  float acc = b ? b[o] : 0.f;
+  int t0 = max(0, g.pad - g.s * j), t1 = min(g.k, g.hin + g.pad - g.s * j);
+  for (int c = 0; c < g.cin; ++c) {
+    const float* row = in + (f * g.cin + c) * g.hin + (g.s * j - g.pad);
+    for (int t = t0; t < t1; ++t) acc += lnact(row[t], ai, f, c) * W[((int64_t)t * g.cin + c) * g.cout + o];
+  }
+  out[idx] = acc;
+}
+
+// util/layers.py:32 : per-frame mean and biased variance over all C*H -> (mean, rstd)
+__global__ void k_ln_stats(const float* __restrict__ a, float* __restrict__ st, int n) {
+  __shared__ float sm[16];
+  int64_t f = blockIdx.x;
+  const float* p = a + f * n;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += p[i];
+  float mean = block_sum(s, sm) / n;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float d = p[i] - mean;
+    q += d * d;
+  }
+  float var = block_sum(q, sm) / n;
+  if (threadIdx.x == 0) {
+    st[2 * f] = mean;
+    st[2 * f + 1] = 1.0f / sqrtf(var + LN_EPS);
+  }
+}
+
+// d[f] = c + sum_k act(u)[f,k] w[k]     (flatten is C-major = memory order)
+__global__ void k_dense_fwd(const float* __restrict__ u, Act ai, int hlast, const float* __restrict__ w,
+                            const float* __restrict__ c, float* __restrict__ d, int flat) {
+  __shared__ float sm[16];
+  int64_t f = blockIdx.x;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < flat; k += blockDim.x) s += lnact(u[f * flat + k], ai, f, k / hlast) * w[k];
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) d[f] = s + c[0];
+}
+
+// ------------------------------------------------------------------------------------------ backward
+// upstream of the dense unit: da[f,k] = coef(f) w[k]; rows [0,F0) get c0, [F0,2F0) c1, the rest c2
+__global__ void k_dense_bwd_data(const float* __restrict__ w, float* __restrict__ da, int64_t B, int flat, int64_t F0,
+                                 float c0, float c1, float c2) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * flat) return;
+  int64_t f = idx / flat;
+  float c = f < F0 ? c0 : (f < 2 * F0 ? c1 : c2);
+  da[idx] = c * w[idx % flat];
+}
+// dw[k] += sum_f coef(f) act(u)[f,k] ; db += sum_f coef(f)      (one thread per k; thread `flat` does the bias)
+__global__ void k_dense_bwd_w(const float* __restrict__ u, Act ai, int hlast, float* __restrict__ dw,
+                              float* __restrict__ dc, int64_t B, int flat, int64_t F0, float c0, float c1, float c2) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > flat) return;
+  float s = 0.f;
+  for (int64_t f = 0; f < B; ++f) {
+    float c = f < F0 ? c0 : (f < 2 * F0 ? c1 : c2);
+    s += k < flat ? c * lnact(u[f * flat + k], ai, f, k / hlast) : c;
+  }
+  if (k < flat) dw[k] += s;
+  else dc[0] += s;
+}
+
+// LayerNorm + lrelu backward (autodiff of util/layers.py:32-44,149); one block per frame.
+//   n = gamma xhat + beta ; p = dy lrelu'(n) gamma ; du = rstd (p - mean p - xhat mean(p xhat)) (+ add)
+__global__ void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ u, const float* __restrict__ st,
+                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                         const float* __restrict__ add, float* __restrict__ du, int C, int H) {
+  __shared__ float sm[16];
+  int64_t f = blockIdx.x;
+  int n = C * H;
+  float mean = st[2 * f], rstd = st[2 * f + 1];
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int c = i / H;
+    float xh = (u[f * n + i] - mean) * rstd;
+    float nn = xh * gamma[c] + beta[c];
+    float p = dy[f * n + i] * (nn >= 0.f ? 1.0f : LEAK) * gamma[c];
+    s1 += p;
+    s2 += p * xh;
+  }
+  s1 = block_sum(s1, sm) / n;
+  s2 = block_sum(s2, sm) / n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int c = i / H;
+    float xh = (u[f * n + i] - mean) * rstd;
+    float nn = xh * gamma[c] + beta[c];
+    float p = dy[f * n + i] * (nn >= 0.f ? 1.0f : LEAK) * gamma[c];
+    float r = rstd * (p - s1 - xh * s2);
+    du[f * n + i] = add ? r + add[f * n + i] : r;
+  }
+}
+
+// Adjoint of k_ln_bwd (one block per frame).  Inputs: q = adjoint of its result, dy = its upstream (abar),
+// u / st / gamma / beta of the layer.  Outputs:
+//   at   = adjoint of dy            = P(q) gamma lrelu'(n)         with P(v) = rstd (v - mean v - xhat mean(v xhat))
+//   udir = adjoint of u             = rstd (xt - mean xt - xhat mean(q ubar + xt xhat)),
+//                                     xt = -rstd (mean(p xhat) q + mean(q xhat) p),  ubar = P(p)
+//   pn   = P(q) dy lrelu'(n)        (its per-channel sum is the adjoint of gamma)
+// lrelu'' = 0 almost everywhere, so n contributes nothing.
+__global__ void k_ln_bwd_bwd(const float* __restrict__ q, const float* __restrict__ dy, const float* __restrict__ u,
+                             const float* __restrict__ st, const float* __restrict__ gamma,
+                             const float* __restrict__ beta, float* __restrict__ at, float* __restrict__ udir,
+                             float* __restrict__ pn, int C, int H) {
+  __shared__ float sm[16];
+  int64_t f = blockIdx.x;
+  int n = C * H;
+  float mean = st[2 * f], rstd = st[2 * f + 1];
+  float sp = 0.f, spx = 0.f, sq = 0.f, sqx = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int c = i / H;
+    float xh = (u[f * n + i] - mean) * rstd;
+    float nn = xh * gamma[c] + beta[c];
+    float p = dy[f * n + i] * (nn >= 0.f ? 1.0f : LEAK) * gamma[c];
+    float qq = q[f * n + i];
+    sp += p;
+    spx += p * xh;
+    sq += qq;
+    sqx += qq * xh;
+  }
+  sp = block_sum(sp, sm) / n;
+  spx = block_sum(spx, sm) / n;
+  sq = block_sum(sq, sm) / n;
+  sqx = block_sum(sqx, sm) / n;
+  float sx = 0.f, ss = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int c = i / H;
+    float xh = (u[f * n + i] - mean) * rstd;
+    float nn = xh * gamma[c] + beta[c];
+    float p = dy[f * n + i] * (nn >= 0.f ? 1.0f : LEAK) * gamma[c];
+    float qq = q[f * n + i];
+    float ub = rstd * (p - sp - xh * spx);
+    float xt = -rstd * (spx * qq + sqx * p);
+    sx += xt;
+    ss += qq * ub + xt * xh;
+  }
+  sx = block_sum(sx, sm) / n;
+  ss = block_sum(ss, sm) / n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int c = i / H;
+    float xh = (u[f * n + i] - mean) * rstd;
+    float nn = xh * gamma[c] + beta[c];
+    float sl = nn >= 0.f ? 1.0f : LEAK;
+    float dyv = dy[f * n + i];
+    float p = dyv * sl * gamma[c];
+    float qq = q[f * n + i];
+    float xt = -rstd * (spx * qq + sqx * p);
+    float pt = rstd * (qq - sq - xh * sqx);
+    at[f * n + i] = pt * gamma[c] * sl;
+    udir[f * n + i] = rstd * (xt - sx - xh * ss);
+    pn[f * n + i] = pt * dyv * sl;
+  }
+}
+
+// dgamma[c] += sum_{f,h} dn xhat ; dbeta[c] += sum_{f,h} dn ; one block per channel
+__global__ void k_ln_param_grad(const float* __restrict__ dy, const float* __restrict__ u,
+                                const float* __restrict__ st, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* __restrict__ dgamma,
+                                float* __restrict__ dbeta, int64_t B, int C, int H) {
+  __shared__ float sm[16];
+  int c = blockIdx.x;
+  float g = gamma[c], b = beta[c];
+  float sg = 0.f, sb = 0.f;
+  for (int64_t i = threadIdx.x; i < B * H; i += blockDim.x) {
+    int64_t f = i / H;
+    int64_t e = (f * C + c) * H + (int)(i % H);
+    float xh = (u[e] - st[2 * f]) * st[2 * f + 1];
+    float nn = xh * g + b;
+    float dn = dy[e] * (nn >= 0.f ? 1.0f : LEAK);
+    sg += dn * xh;
+    sb += dn;
+  }
+  sg = block_sum(sg, sm);
+  sb = block_sum(sb, sm);
+  if (threadIdx.x == 0) {
+    dgamma[c] += sg;
+    dbeta[c] += sb;
+  }
+}
+
+// db[o] += sum_{f,h} d[f,o,h] ; one block per channel
+__global__ void k_chan_sum(const float* __restrict__ d, float* __restrict__ db, int64_t B, int C, int H) {
+  __shared__ float sm[16];
+  int o = blockIdx.x;
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < B * H; i += blockDim.x) s += d[((i / H) * C + o) * H + (int)(i % H)];
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) db[o] += s;
+}
+
+// din[f,c,i] = sum_o sum_t W[t,c,o] dout[f,o,j], s*j - pad + t = i       (conv input gradient)
+__global__ void k_conv_bwd_data(const float* __restrict__ dout, const float* __restrict__ W, float* __restrict__ din,
+                                int64_t B, G g) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * g.cin * g.hin) return;
+  int i = (int)(idx % g.hin);
+  int c = (int)((idx / g.hin) % g.cin);
+  int64_t f = idx / ((int64_t)g.hin * g.cin);
+  float acc = 0.f;
+  for (int j = 0; j < g.hout; ++j) {
+    int t = i + g.pad - g.s * j;
+    if (t < 0 || t >= g.k) continue;
+    const float* wr = W + ((int64_t)t * g.cin + c) * g.cout;
+    for (int o = 0; o < g.cout; ++o) acc += wr[o] * dout[(f * g.cout + o) * g.hout + j];
+  }
+  din[idx] = acc;
+}
+
+// dW[t,c,o] += sum_f sum_j act(in)[f,c,s*j-pad+t] dout[f,o,j]
+__global__ void k_conv_bwd_w(const float* __restrict__ in, Act ai, const float* __restrict__ dout,
+                             float* __restrict__ dW, int64_t B, G g) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)g.k * g.cin * g.cout) return;
+  int o = (int)(idx % g.cout);
+  int c = (int)((idx / g.cout) % g.cin);
+  int t = (int)(idx / ((int64_t)g.cout * g.cin));
+  const int hi = g.hin - 1 + g.pad - t;  // s*j <= hi
+  int j0 = max(0, (g.pad - t + g.s - 1) / g.s), j1 = hi < 0 ? 0 : min(g.hout, hi / g.s + 1);
+  float acc = 0.f;
+  for (int64_t f = 0; f < B; ++f) {
+    const float* row = in + (f * g.cin + c) * g.hin - g.pad + t;
+    const float* dr = dout + (f * g.cout + o) * g.hout;
+    for (int j = j0; j < j1; ++j) acc += lnact(row[g.s * j], ai, f, c) * dr[j];
+  }
+  dW[idx] += acc;
+}
+
+// per-frame gradient norm, penalty and the adjoint of g: gt = coef (|g| - 1) g / |g|   (coef = 2 lambda / F)
+__global__ void k_gp(const float* __restrict__ g, float* __restrict__ gt, float* __restrict__ gp_f, int H, float coef) {
+  __shared__ float sm[16];
+  int64_t f = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < H; i += blockDim.x) s += g[f * H + i] * g[f * H + i];
+  float nrm = sqrtf(block_sum(s, sm));
+  float k = coef * (nrm - 1.0f) / nrm;
+  for (int i = threadIdx.x; i < H; i += blockDim.x) gt[f * H + i] = k * g[f * H + i];
+  if (threadIdx.x == 0) gp_f[f] = (nrm - 1.0f) * (nrm - 1.0f);
+}
+
+// loss2 = { W_dist = mean d[0:F) - mean d[F:2F) , gp = mean gp_f (0 when gp_f is null) }; single block
+__global__ void k_losses(const float* __restrict__ d, const float* __restrict__ gp_f, int64_t F, float* __restrict__ loss2) {
+  __shared__ float sm[16];
+  float a = 0.f, b = 0.f;
+  for (int64_t i = threadIdx.x; i < F; i += blockDim.x) {
+    a += d[i] - d[F + i];
+    if (gp_f) b += gp_f[i];
+  }
+  a = block_sum(a, sm);
+  b = block_sum(b, sm);
+  if (threadIdx.x == 0) {
+    loss2[0] = a / (float)F;
+    loss2[1] = b / (float)F;
+  }
+}
+
+// target of the generator step: x' = x + alpha (1 + 1e-6) dD(xh)/dxh, so that the reconstruction gradient
+// (xh - x') / ((1 + 1e-6) F) of the ConvVAE backward equals d(-logP + alpha W_dist)/dxh
+__global__ void k_adv_target(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ out, int64_t n,
+                             float alpha) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) out[idx] = x[idx] + alpha * (1.0f + EPSILON) * g[idx];
+}
+
+}  // namespace disc
+}  // namespace vaenpvc
+
+// ============================================================================================ host
+using namespace vaenpvc;
+using namespace vaenpvc::disc;
+
+struct DiscL {
+  int cin, hin, cout, hout, k, s, pad;
+  int64_t w_off, b_off, beta_off, gamma_off;
+  int n() const { return cout * hout; }
+};
+struct vaenpvc_disc {
+  int H, n_layers, flat;
+  DiscL l[VAENPVC_MAX_LAYERS];
+  int64_t wd_off, bd_off, n_params;
+  std::vector<ParamInfo> table;
+};
+
+static G mk(const DiscL& l) { return G{l.cin, l.hin, l.cout, l.hout, l.k, l.s, l.pad}; }
+static Act act_of(const DiscL& l, const float* P, const float* st) { return Act{st, P + l.gamma_off, P + l.beta_off}; }
+
+namespace {
+struct DWs {  // resolved workspace of one call; B rows in the forward tensors, R rows in the per-range ones
+  float* rows;
+  float* u[VAENPVC_MAX_LAYERS];
+  float* st[VAENPVC_MAX_LAYERS];
+  float* d;
+  float* abar[VAENPVC_MAX_LAYERS];
+  float* ubar[VAENPVC_MAX_LAYERS];
+  float* q[VAENPVC_MAX_LAYERS];
+  float* at[VAENPVC_MAX_LAYERS];
+  float* udir[VAENPVC_MAX_LAYERS];
+  float* pn;
+  float *g, *gt, *gp_f;
+  float *da, *du;
+};
+int64_t al(int64_t n) { return (n + 63) & ~int64_t(63); }
+
+// carve (base == nullptr: size only).  `critic`: three row groups and the double-backward tensors
+int64_t carve(const vaenpvc_disc& m, int64_t F, bool critic, float* base, DWs* w) {
+  int64_t off = 0;
+  auto take = [&](int64_t n) {
+    float* p = base ? base + off : nullptr;
+    off += al(n);
+    return p;
+  };
+  const int64_t B = (critic ? 3 : 2) * F;
+  int nmax = m.H;
+  for (int i = 0; i < m.n_layers; ++i) nmax = std::max(nmax, m.l[i].n());
+  DWs t;
+  memset(&t, 0, sizeof t);
+  t.rows = take(B * m.H);
+  for (int i = 0; i < m.n_layers; ++i) {
+    t.u[i] = take(B * m.l[i].n());
+    t.st[i] = take(B * 2);
+  }
+  t.d = take(B);
+  for (int i = 0; i < m.n_layers; ++i) {
+    t.abar[i] = take(F * m.l[i].n());
+    t.ubar[i] = take(F * m.l[i].n());
+  }
+  t.g = take(F * m.H);
+  if (critic) {
+    for (int i = 0; i < m.n_layers; ++i) {
+      t.q[i] = take(F * m.l[i].n());
+      t.at[i] = take(F * m.l[i].n());
+      t.udir[i] = take(F * m.l[i].n());
+    }
+    t.pn = take(F * nmax);
+    t.gt = take(F * m.H);
+    t.gp_f = take(F);
+    t.da = take(B * nmax);
+    t.du = take(B * nmax);
+  }
+  if (w) *w = t;
+  return off;
+}
+
+void forward(const vaenpvc_disc& m, const float* P, int64_t B, const DWs& w, hipStream_t s) {
+  for (int i = 0; i < m.n_layers; ++i) {
+    const DiscL& l = m.l[i];
+    Act ai = i == 0 ? kNoAct : act_of(m.l[i - 1], P, w.st[i - 1]);
+    hipLaunchKernelGGL(k_conv_fwd, grid1(B * l.n()), dim3(256), 0, s, i == 0 ? w.rows : w.u[i - 1], ai, P + l.w_off,
+                       P + l.b_off, w.u[i], B, mk(l));
+    hipLaunchKernelGGL(k_ln_stats, dim3((unsigned)B), dim3(256), 0, s, w.u[i], w.st[i], l.n());
+  }
+  const DiscL& last = m.l[m.n_layers - 1];
+  hipLaunchKernelGGL(k_dense_fwd, dim3((unsigned)B), dim3(256), 0, s, w.u[m.n_layers - 1],
+                     act_of(last, P, w.st[m.n_layers - 1]), last.hout, P + m.wd_off, P + m.bd_off, w.d, m.flat);
+}
+
+// pass 2: g = d(sum_f d_f)/d(rows) for R rows starting at row r0; keeps abar_l / ubar_l
+void input_gradient(const vaenpvc_disc& m, const float* P, int64_t r0, int64_t R, const DWs& w, hipStream_t s) {
+  const int L = m.n_layers;
+  hipLaunchKernelGGL(k_dense_bwd_data, grid1(R * m.flat), dim3(256), 0, s, P + m.wd_off, w.abar[L - 1], R, m.flat, R, 1.0f,
+                     1.0f, 1.0f);
+  for (int i = L - 1; i >= 0; --i) {
+    const DiscL& l = m.l[i];
+    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)R), dim3(256), 0, s, w.abar[i], w.u[i] + r0 * l.n(), w.st[i] + 2 * r0,
+                       P + l.gamma_off, P + l.beta_off, (const float*)nullptr, w.ubar[i], l.cout, l.hout);
+    hipLaunchKernelGGL(k_conv_bwd_data, grid1(R * l.cin * l.hin), dim3(256), 0, s, w.ubar[i], P + l.w_off,
+                       i == 0 ? w.g : w.abar[i - 1], R, mk(l));
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int vaenpvc_disc_create(const vaenpvc_disc_arch* a, vaenpvc_disc** out) {
+  if (!a || !out) return abi_error(VAENPVC_E_ARG, "null argument");
+  if (a->n_layers < 1 || a->n_layers > VAENPVC_MAX_LAYERS) return abi_error(VAENPVC_E_ARG, "discriminator: need 1..8 layers");
+  if (a->H < 1) return abi_error(VAENPVC_E_ARG, "H must be positive");
+  vaenpvc_disc* m = new vaenpvc_disc();
+  m->H = a->H;
+  m->n_layers = a->n_layers;
+  int64_t off = 0;
+  auto add = [&](const std::string& name, std::initializer_list<int64_t> shp) {
+    ParamInfo p;
+    p.name = name;
+    p.offset = off;
+    p.ndim = (int)shp.size();
+    p.count = 1;
+    int i = 0;
+    for (int64_t s : shp) {
+      p.shape[i++] = s;
+      p.count *= s;
+    }
+    for (; i < 4; ++i) p.shape[i] = 1;
+    off += p.count;
+    m->table.push_back(p);
+    return p.offset;
+  };
+  int c = 1, h = a->H;
+  for (int i = 0; i < a->n_layers; ++i) {
+    DiscL& l = m->l[i];
+    int k = a->kernel[i], s = a->stride[i], o = a->output[i];
+    if (k < 1 || s < 1 || o < 1) {
+      delete m;
+      return abi_error(VAENPVC_E_ARG, "discriminator: kernel/stride/output must be positive");
+    }
+    l.cin = c;
+    l.hin = h;
+    l.cout = o;
+    l.k = k;
+    l.s = s;
+    l.hout = (h + s - 1) / s;  // TF SAME
+    l.pad = std::max((l.hout - 1) * s + k - h, 0) / 2;
+    std::string p = "Discriminator/Conv2d-" + std::to_string(i) + "/";
+    l.w_off = add(p + "kernel", {k, 1, c, o});
+    l.b_off = add(p + "bias", {o});
+    l.beta_off = add(p + "layernorm.offset", {o, 1, 1});
+    l.gamma_off = add(p + "layernorm.scale", {o, 1, 1});
+    c = o;
+    h = l.hout;
+  }
+  m->flat = c * h;
+  m->wd_off = add("Discriminator/dense/kernel", {m->flat, 1});
+  m->bd_off = add("Discriminator/dense/bias", {1});
+  m->n_params = off;
+  *out = m;
+  return 0;
+}
+
+void vaenpvc_disc_destroy(vaenpvc_disc* d) { delete d; }
+int vaenpvc_disc_param_count(const vaenpvc_disc* d) { return d ? (int)d->table.size() : VAENPVC_E_ARG; }
+int64_t vaenpvc_disc_param_floats(const vaenpvc_disc* d) { return d ? d->n_params : VAENPVC_E_ARG; }
+
+int vaenpvc_disc_param_info(const vaenpvc_disc* d, int index, char* name, int name_cap, int64_t* offset_floats,
+                            int32_t* ndim, int64_t* shape) {
+  if (!d || index < 0 || index >= (int)d->table.size()) return abi_error(VAENPVC_E_ARG, "bad parameter index");
+  const ParamInfo& p = d->table[index];
+  if (name && name_cap > 0) {
+    strncpy(name, p.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (offset_floats) *offset_floats = p.offset;
+  if (ndim) *ndim = p.ndim;
+  if (shape)
+    for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+  return 0;
+}
+
+int64_t vaenpvc_disc_workspace_bytes(const vaenpvc_disc* d, int64_t F) {
+  if (!d || F < 1 || F > (1LL << 16)) return abi_error(VAENPVC_E_ARG, "bad argument (1 <= F <= 65536)");
+  return carve(*d, F, true, nullptr, nullptr) * 4;
+}
+
+static int disc_args(const vaenpvc_disc* d, int64_t F, const void* d_ws, size_t ws_bytes) {
+  if (F < 1 || F > (1LL << 16)) return abi_error(VAENPVC_E_ARG, "F must be in [1, 65536]");
+  if (!d_ws || ws_bytes < (size_t)carve(*d, F, true, nullptr, nullptr) * 4)
+    return abi_error(VAENPVC_E_WORKSPACE, "discriminator workspace too small");
+  if (((uintptr_t)d_ws & 15) != 0) return abi_error(VAENPVC_E_ARG, "workspace must be 16-byte aligned");
+  return 0;
+}
+static int disc_check(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    return abi_error(VAENPVC_E_HIP, buf);
+  }
+  return 0;
+}
+
+int vaenpvc_disc_fwd(const vaenpvc_disc* d, const float* d_dparams, const float* d_x, const float* d_xh, int64_t F,
+                     float* d_out, float* d_loss2, void* d_ws, size_t ws_bytes, void* stream) {
+  if (!d || !d_dparams || !d_x || !d_xh) return abi_error(VAENPVC_E_ARG, "null argument");
+  int rc = disc_args(d, F, d_ws, ws_bytes);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  DWs w;
+  carve(*d, F, false, (float*)d_ws, &w);
+  hipLaunchKernelGGL(k_rows, grid1(F * d->H), dim3(256), 0, s, d_x, d_xh, (const float*)nullptr, w.rows, F, d->H);
+  forward(*d, d_dparams, 2 * F, w, s);
+  if (d_out) (void)hipMemcpyAsync(d_out, w.d, 2 * F * sizeof(float), hipMemcpyDeviceToDevice, s);
+  if (d_loss2) hipLaunchKernelGGL(k_losses, dim3(1), dim3(256), 0, s, w.d, (const float*)nullptr, F, d_loss2);
+  return disc_check("disc_fwd");
+}
+
+int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, const float* d_x, const float* d_xh,
+                                const float* d_t, int64_t F, float lambda, float* d_dgrads, float* d_loss2,
+                                void* d_ws, size_t ws_bytes, void* stream) {
+  if (!d || !d_dparams || !d_x || !d_xh || !d_t || !d_dgrads || !d_loss2) return abi_error(VAENPVC_E_ARG, "null argument");
+  int rc = disc_args(d, F, d_ws, ws_bytes);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const vaenpvc_disc& m = *d;
+  const float* P = d_dparams;
+  float* Gd = d_dgrads;
+  const int L = m.n_layers;
+  const int64_t B = 3 * F;
+  DWs w;
+  carve(m, F, true, (float*)d_ws, &w);
+  (void)hipMemsetAsync(Gd, 0, m.n_params * sizeof(float), s);
+  // pass 1
+  hipLaunchKernelGGL(k_rows, grid1(F * m.H), dim3(256), 0, s, d_x, d_xh, d_t, w.rows, F, m.H);
+  forward(m, P, B, w, s);
+  // pass 2 (rows xi) and the penalty
+  input_gradient(m, P, 2 * F, F, w, s);
+  hipLaunchKernelGGL(k_gp, dim3((unsigned)F), dim3(256), 0, s, w.g, w.gt, w.gp_f, m.H, 2.0f * lambda / (float)F);
+  hipLaunchKernelGGL(k_losses, dim3(1), dim3(256), 0, s, w.d, w.gp_f, F, d_loss2);
+  // pass 3, bottom-up over rows xi
+  for (int i = 0; i < L; ++i) {
+    const DiscL& l = m.l[i];
+    const float* src = i == 0 ? w.gt : w.at[i - 1];  // adjoint of abar_{i-1} (of g for the first layer)
+    hipLaunchKernelGGL(k_conv_fwd, grid1(F * l.n()), dim3(256), 0, s, src, kNoAct, P + l.w_off, (const float*)nullptr,
+                       w.q[i], F, mk(l));
+    hipLaunchKernelGGL(k_conv_bwd_w, grid1((int64_t)l.k * l.cin * l.cout), dim3(256), 0, s, src, kNoAct, w.ubar[i],
+                       Gd + l.w_off, F, mk(l));
+    hipLaunchKernelGGL(k_ln_bwd_bwd, dim3((unsigned)F), dim3(256), 0, s, w.q[i], w.abar[i], w.u[i] + 2 * F * l.n(),
+                       w.st[i] + 4 * F, P + l.gamma_off, P + l.beta_off, w.at[i], w.udir[i], w.pn, l.cout, l.hout);
+    hipLaunchKernelGGL(k_chan_sum, dim3(l.cout), dim3(256), 0, s, w.pn, Gd + l.gamma_off, F, l.cout, l.hout);
+  }
+  hipLaunchKernelGGL(k_chan_sum, dim3(m.flat), dim3(64), 0, s, w.at[L - 1], Gd + m.wd_off, F, m.flat, 1);  // abar_top = w
+  // pass 4, all rows: upstream -1/F (x), +1/F (xh), 0 (xi)
+  const float cr = -1.0f / (float)F, cf = 1.0f / (float)F;
+  const DiscL& last = m.l[L - 1];
+  hipLaunchKernelGGL(k_dense_bwd_w, grid1(m.flat + 1), dim3(256), 0, s, w.u[L - 1], act_of(last, P, w.st[L - 1]), last.hout,
+                     Gd + m.wd_off, Gd + m.bd_off, B, m.flat, F, cr, cf, 0.0f);
+  hipLaunchKernelGGL(k_dense_bwd_data, grid1(B * m.flat), dim3(256), 0, s, P + m.wd_off, w.da, B, m.flat, F, cr, cf, 0.0f);
+  for (int i = L - 1; i >= 0; --i) {
+    const DiscL& l = m.l[i];
+    hipLaunchKernelGGL(k_ln_param_grad, dim3(l.cout), dim3(256), 0, s, w.da, w.u[i], w.st[i], P + l.gamma_off,
+                       P + l.beta_off, Gd + l.gamma_off, Gd + l.beta_off, B, l.cout, l.hout);
+    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)(2 * F)), dim3(256), 0, s, w.da, w.u[i], w.st[i], P + l.gamma_off,
+                       P + l.beta_off, (const float*)nullptr, w.du, l.cout, l.hout);
+    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)F), dim3(256), 0, s, w.da + 2 * F * l.n(), w.u[i] + 2 * F * l.n(),
+                       w.st[i] + 4 * F, P + l.gamma_off, P + l.beta_off, w.udir[i], w.du + 2 * F * l.n(), l.cout, l.hout);
+    Act ai = i == 0 ? kNoAct : act_of(m.l[i - 1], P, w.st[i - 1]);
+    hipLaunchKernelGGL(k_conv_bwd_w, grid1((int64_t)l.k * l.cin * l.cout), dim3(256), 0, s, i == 0 ? w.rows : w.u[i - 1], ai,
+                       w.du, Gd + l.w_off, B, mk(l));
+    hipLaunchKernelGGL(k_chan_sum, dim3(l.cout), dim3(256), 0, s, w.du, Gd + l.b_off, B, l.cout, l.hout);
+    if (i > 0)
+      hipLaunchKernelGGL(k_conv_bwd_data, grid1(B * l.cin * l.hin), dim3(256), 0, s, w.du, P + l.w_off, w.da, B, mk(l));
+  }
+  return disc_check("disc_critic_fwd_bwd");
+}
+
+int vaenpvc_disc_generator_target(const vaenpvc_disc* d, const float* d_dparams, const float* d_x, const float* d_xh,
+                                  int64_t F, float alpha, float* d_target, float* d_loss2, void* d_ws,
+                                  size_t ws_bytes, void* stream) {
+  if (!d || !d_dparams || !d_x || !d_xh || !d_target) return abi_error(VAENPVC_E_ARG, "null argument");
+  int rc = disc_args(d, F, d_ws, ws_bytes);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  DWs w;
+  carve(*d, F, false, (float*)d_ws, &w);
+  hipLaunchKernelGGL(k_rows, grid1(F * d->H), dim3(256), 0, s, d_x, d_xh, (const float*)nullptr, w.rows, F, d->H);
+  forward(*d, d_dparams, 2 * F, w, s);
+  input_gradient(*d, d_dparams, F, F, w, s);  // rows xh
+  hipLaunchKernelGGL(k_adv_target, grid1(F * d->H), dim3(256), 0, s, d_x, w.g, d_target, F * d->H, alpha);
+  if (d_loss2) hipLaunchKernelGGL(k_losses, dim3(1), dim3(256), 0, s, w.d, (const float*)nullptr, F, d_loss2);
+  return disc_check("disc_generator_target");
+}
+
+}  // extern "C"

@@ -32,6 +32,9 @@ struct Ws {  // resolved workspace pointers (see workspace_layout)
   int64_t scratch_floats;
 };
 
+// sets the thread-local message vaenpvc_last_error() returns; returns `code` (abi.hip)
+int abi_error(int code, const char* msg);
+
 // ---- single-kernel event timer (state in the context's Runtime, runtime.h) --------
 #define VAENPVC_TIMED(tag, stream, stmt)              \
   do {                                                \
@@ -80,6 +83,7 @@ void launch_unpack(const float* rec, const int64_t* idx, int64_t F, int rec_floa
                    const float* xmax, float* x, int64_t* y, hipStream_t s);
 void launch_check_ids(const int64_t* y, int64_t F, int ny, int* flag, hipStream_t s);
 void launch_philox_normal(float* out, int64_t n, PhiloxKey key, hipStream_t s);
+void launch_philox_uniform(float* out, int64_t n, PhiloxKey key, hipStream_t s);
 // min, max, sum, sum of squares (double[4]) and counts per bucket (uint64[n_edges + 1]; bucket b holds
 // edges[b-1] <= v < edges[b]) of `n` floats; the outputs must be zeroed by the caller (stats[0..1] = +-inf)
 void launch_summary(const float* d, int64_t n, const float* edges, int n_edges, double* stats, unsigned long long* counts,

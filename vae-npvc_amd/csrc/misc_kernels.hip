@@ -140,6 +140,13 @@ __global__ void k_philox_normal(float* __restrict__ out, int64_t n, PhiloxKey ke
 void launch_philox_normal(float* out, int64_t n, PhiloxKey key, hipStream_t s) {
   hipLaunchKernelGGL(k_philox_normal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, key);
 }
+__global__ void k_philox_uniform(float* __restrict__ out, int64_t n, PhiloxKey key) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = philox_uniform(philox_resolve(key), (uint64_t)i);
+}
+void launch_philox_uniform(float* out, int64_t n, PhiloxKey key, hipStream_t s) {
+  hipLaunchKernelGGL(k_philox_uniform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, key);
+}
 
 // tf.summary.histogram payload of model/vae.py:134-135 (x, xh): min / max / sum / sum of squares and bucket
 // counts over caller-supplied ascending bucket limits.  Edges sit in LDS; a workgroup keeps a private

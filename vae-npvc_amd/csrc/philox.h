@@ -60,4 +60,12 @@ __device__ __forceinline__ float philox_normal(const PhiloxKey& k, uint64_t e) {
   return r * ((j & 1) ? sn : cs);
 }
 
+// U[0,1) of flat element index e (tf.random_uniform's range): word e & 3 of counter (e >> 2, offset), 24 bits
+__device__ __forceinline__ float philox_uniform(const PhiloxKey& k, uint64_t e) {
+  const uint64_t q = e >> 2;
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), k.off_lo, k.off_hi};
+  philox4x32_10(c, k.seed_lo, k.seed_hi);
+  return (float)(c[e & 3] >> 8) * (1.0f / 16777216.0f);
+}
+
 }  // namespace vaenpvc

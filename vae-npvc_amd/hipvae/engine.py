@@ -287,6 +287,43 @@ class Engine(object):
                                                        ws.data_ptr(), nb, self._stream()), 'train_fwd_bwd')
         return out
 
+    def train_fwd_bwd_target(self, x, y, eps, target, grads, out=None):
+        """train_fwd_bwd with the log-density evaluated against `target` [F, H] (vaenpvc_train_fwd_bwd_target)."""
+        x = self._chk_x(x)
+        F = x.shape[0]
+        y = self._chk_y(y, F)
+        eps = self._chk_eps(eps, F)
+        target = self._chk_x(target)
+        if target.shape[0] != F:
+            raise ValueError('target must have one row per frame')
+        if grads.dtype != torch.float32 or grads.numel() != self.n_params or not grads.is_cuda:
+            raise TypeError('grads must be a flat float32 CUDA buffer of %d elements' % self.n_params)
+        out = self._loss3 if out is None else out
+        ws, nb = self._workspace(F, L.MODE_TRAIN)
+        with self._on_device():
+            L.check(self.lib.vaenpvc_train_fwd_bwd_target(self.ctx, self.params.data_ptr(), x.data_ptr(), y.data_ptr(),
+                                                          eps.data_ptr(), target.data_ptr(), F, grads.data_ptr(),
+                                                          out.data_ptr(), ws.data_ptr(), nb, self._stream()),
+                    'train_fwd_bwd_target')
+        return out
+
+    def philox_uniform(self, n, seed, offset=0):
+        """float32 [n] U[0,1) draw for (seed, offset) (vaenpvc_philox_uniform)."""
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        with self._on_device():
+            L.check(self.lib.vaenpvc_philox_uniform(int(seed) & (2 ** 64 - 1), int(offset), out.data_ptr(), n,
+                                                    self._stream()), 'philox_uniform')
+        return out
+
+    def adam_range(self, params, grads, m, v, lo, hi, step, lr, beta1, beta2, eps=1e-8, grad_scale=1.0):
+        """TF-Adam apply on elements [lo, hi) of four congruent flat buffers (a `var_list` that is a contiguous range
+        of the table: trainer/vae.py:128-130 groups variables by name)."""
+        with self._on_device():
+            L.check(self.lib.vaenpvc_adam_step(params.data_ptr() + 4 * lo, grads.data_ptr() + 4 * lo,
+                                               m.data_ptr() + 4 * lo, v.data_ptr() + 4 * lo, hi - lo, int(step),
+                                               float(lr), float(beta1), float(beta2), float(eps), float(grad_scale),
+                                               self._stream()), 'adam_step')
+
     def philox_normal(self, rows, seed, offset=0):
         """The N(0,1) tensor [rows, z_dim] the seeded entry points draw for (seed, offset)."""
         out = torch.empty(rows, self.z_dim, dtype=torch.float32, device=self.device)

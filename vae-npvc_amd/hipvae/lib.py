@@ -8,7 +8,7 @@ CSRC = os.path.normpath(os.path.join(_HERE, '..', 'csrc'))
 # VAENPVC_LIB: developer override used by scripts/build_variant.sh (kernel experiments)
 LIB_PATH = os.environ.get('VAENPVC_LIB') or os.path.join(CSRC, 'libvaenpvc_hip.so')
 MAX_LAYERS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 MODE_INFER, MODE_TRAIN = 0, 1
 IMPL_AUTO, IMPL_GENERIC = 0, 1
@@ -32,6 +32,13 @@ class Arch(C.Structure):
         ('n_dec', C.c_int32),
         ('dec_kernel', C.c_int32 * MAX_LAYERS), ('dec_stride', C.c_int32 * MAX_LAYERS),
         ('dec_output', C.c_int32 * MAX_LAYERS),
+    ]
+
+
+class DiscArch(C.Structure):
+    _fields_ = [
+        ('H', C.c_int32), ('n_layers', C.c_int32),
+        ('kernel', C.c_int32 * MAX_LAYERS), ('stride', C.c_int32 * MAX_LAYERS), ('output', C.c_int32 * MAX_LAYERS),
     ]
 
 
@@ -73,6 +80,18 @@ SIGNATURES = {
     'vaenpvc_set_bucket_callback': (C.c_int, [_P, BUCKET_CB, _P]),
     'vaenpvc_validate_ids': (C.c_int, [_P, _P, _I64, _P, _P]),
     'vaenpvc_summary': (C.c_int, [_P, _I64, _P, _I32, _P, _P, _P]),
+    'vaenpvc_philox_uniform': (C.c_int, [_U64, _U64, _P, _I64, _P]),
+    'vaenpvc_train_fwd_bwd_target': (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, C.c_size_t, _P]),
+    'vaenpvc_disc_create': (C.c_int, [C.POINTER(DiscArch), C.POINTER(_P)]),
+    'vaenpvc_disc_destroy': (None, [_P]),
+    'vaenpvc_disc_param_count': (C.c_int, [_P]),
+    'vaenpvc_disc_param_floats': (_I64, [_P]),
+    'vaenpvc_disc_param_info': (C.c_int, [_P, C.c_int, C.c_char_p, C.c_int, C.POINTER(_I64), C.POINTER(_I32),
+                                          C.POINTER(_I64)]),
+    'vaenpvc_disc_workspace_bytes': (_I64, [_P, _I64]),
+    'vaenpvc_disc_fwd': (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, C.c_size_t, _P]),
+    'vaenpvc_disc_critic_fwd_bwd': (C.c_int, [_P, _P, _P, _P, _P, _I64, _F, _P, _P, _P, C.c_size_t, _P]),
+    'vaenpvc_disc_generator_target': (C.c_int, [_P, _P, _P, _P, _I64, _F, _P, _P, _P, C.c_size_t, _P]),
 }
 
 _lib = None

@@ -1,5 +1,5 @@
-"""`--trainer_module trainer.vae --trainer VAETrainer` plugin (drop-in for the
-reference's trainer/vae.py:9-111 + the GANTrainer base ctor trainer/gan.py:13-23).
+"""`--trainer_module trainer.vae --trainer VAETrainer | VAWGANTrainer` plugins (drop-in for the
+reference's trainer/vae.py:9-111 and 115-218 + the GANTrainer base ctor trainer/gan.py:13-23).
 
 Adam(lr, beta1, beta2 from arch['training']) over ALL trainables as one fused HIP
 kernel; data-parallel over torch.distributed when WORLD_SIZE > 1.
@@ -115,4 +115,88 @@ class VAETrainer(object):
                 t_save = now
         if l3 is not None:
             self._refresh_status(l3)
+        return self.save()
+
+
+class VAWGANTrainer(VAETrainer):
+    """trainer/vae.py:115-218: three minimize ops on name-filtered variable lists, nIterD critic steps per
+    generator step, each `sess.run` on its own batch.  `loss` comes from model.vawgan.VAWGAN.loss."""
+
+    def _optimize(self):                                  # trainer/vae.py:116-147
+        from hipvae.adversarial import AdvStepper
+        t = self.arch['training']
+        machine = getattr(self.loss, 'machine', None)
+        if machine is None or not hasattr(machine, 'critic'):
+            raise ValueError('loss must come from VAWGAN.loss (it carries the machine and its critic)')
+        st = AdvStepper(machine.engine, machine.critic, t['lr'], t['beta1'], t['beta2'], t['alpha'], t['lambda'],
+                        seed=getattr(self.args, 'seed', 0) or 0)
+        return {'d': st.critic_step, 'g': st, 'e': st.generator_step, 'global_step': lambda: st.step_count}
+
+    def _status_message(self, step, W_dist, logP, D_KL, gp):      # trainer/vae.py:212-216
+        msg = 'Iter {:05d}: '.format(step)
+        msg += 'W_dist = {:.4e} '.format(W_dist)
+        msg += 'log P(x|z, y) = {:.4e} '.format(logP)
+        msg += 'D_KL(z) = {:.4e} '.format(D_KL)
+        msg += 'GP = {:.4e} '.format(gp)
+        return msg
+
+    def _refresh_status(self, l3=None):                           # trainer/vae.py:195-218
+        """Status line from the LAST critic / generator steps (the reference evaluates the losses on one more
+        dequeued batch; reusing the steps' own values costs no batch and no extra launches)."""
+        st = self.opt['g']
+        v = {k: float(t) for k, t in st.status.items()}
+        msg = self._status_message(st.step_count, v['W_dist'], v['logP'], v['D_KL'], v['gp'])
+        if st.rank == 0:
+            print('\r{}'.format(msg), end='', flush=True)
+            self.log.info(msg)
+        return msg
+
+    def save(self, step=None):
+        st = self.opt['g']
+        if st.rank != 0:
+            return None
+        path = os.path.join(self.dirs['logdir'], 'model.ckpt-{}'.format(st.step_count if step is None else step))
+        sd = st.state_dict()
+        sd['layout'] = list(st.backend.layout.items())
+        sd['d_layout'] = list(st.critic.layout.items())
+        torch.save(sd, path)
+        return path
+
+    def restore(self, restore_from, ckpt=None):
+        from util.wrapper import find_ckpt, read_ckpt
+        path = find_ckpt(restore_from, ckpt)
+        if path is None:
+            return None
+        self.opt["g"].load_state_dict(read_ckpt(path))
+        return self.opt['g'].step_count
+
+    def train(self, nIter, machine=None, summary_op=None, status_secs=60, save_secs=300):
+        """trainer/vae.py:150-179: `max_iter` iterations of nIterD critic steps + one generator step."""
+        st = self.opt['g']
+        source = self.loss.source
+        if source is None:
+            raise ValueError('loss was not built from analyzer.read() handles')
+        restore_from = self.dirs.get('restore_from')
+        if restore_from and os.path.isdir(restore_from) and (getattr(self.args, 'restore_from', None)
+                                                              or getattr(self.args, 'ckpt', None)):
+            step = self.restore(restore_from, getattr(self.args, 'ckpt', None))
+            if st.rank == 0 and step is not None:
+                self.log.info('restored step {} from {}'.format(step, restore_from))
+        st.broadcast_params()
+        t = self.arch['training']
+        t_status = t_save = time.time()
+        while st.step_count < t['max_iter']:
+            for _ in range(t['nIterD']):                  # trainer/vae.py:177-178
+                x, y = source.next_batch()
+                st.critic_step(x, y)
+            x, y = source.next_batch()                    # trainer/vae.py:179
+            st.generator_step(x, y)
+            now = time.time()
+            if now - t_status >= status_secs:
+                self._refresh_status()
+                t_status = now
+            if now - t_save >= save_secs:
+                self.save()
+                t_save = now
+        self._refresh_status()
         return self.save()
