@@ -147,6 +147,32 @@ def run_trainer(rank, world, F, steps, out):
         np.save(out, be.params.numpy())
 
 
+def run_adv(rank, world, F, iters, out):
+    """AdvStepper (hipvae/adversarial.py) under N ranks on the oracle-backed stand-ins: different initial parameters
+    per rank (the broadcast must fix it), frames sharded, every gradient buffer all-reduced before its apply."""
+    from adv_standin import SMALL_VAWGAN, EngineStandIn, CriticStandIn, adv_batches
+    from hipvae.adversarial import AdvStepper
+    from hipvae.dp import shard_range
+    be, cr = EngineStandIn(SMALL_VAWGAN, 10 + rank), CriticStandIn(SMALL_VAWGAN, 20 + rank)
+    st = AdvStepper(be, cr, 1e-3, 0.5, 0.999, 50.0, 10.0)
+    assert st.world == world and st.rank == rank
+    st.broadcast_params()
+    p0 = torch.cat([be.params, cr.params]).clone()
+    n_d = 2
+    lo, hi = shard_range(F, rank, world)
+    tt = lambda a: torch.tensor(a[lo:hi])
+    it = iter(adv_batches(SMALL_VAWGAN, F, iters * (n_d + 1), 70))
+    for _ in range(iters):
+        for _ in range(n_d):
+            b = next(it)
+            st.critic_step(tt(b['x']), tt(b['y']), tt(b['eps']), tt(b['u']))
+        b = next(it)
+        st.generator_step(tt(b['x']), tt(b['y']), tt(b['eps']))
+    if rank == 0:
+        tail = np.array([float(st.status[k]) for k in ('D_KL', 'logP', 'W_dist', 'gp')])
+        np.save(out, np.concatenate([(torch.cat([be.params, cr.params]) - p0).numpy(), tail]))
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
     rank, world, port, F, steps, out = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]),
@@ -159,6 +185,8 @@ if __name__ == '__main__':
         dist.init_process_group('gloo', rank=rank, world_size=world)
     if mode == 'trainer':
         run_trainer(rank, world, F, steps, out)
+    elif mode == 'adv':
+        run_adv(rank, world, F, steps, out)
     else:
         run(rank, world, F, steps, out, mode)
     if world > 1:

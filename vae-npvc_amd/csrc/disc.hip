@@ -79,20 +79,61 @@ __global__ void k_rows(const float* __restrict__ x, const float* __restrict__ xh
 }
 
 // util/layers.py:56-64 : out[f,o,j] = b[o] + sum_c sum_t W[t,c,o] * act(in)[f,c,s*j-pad+t]   (b may be null)
-__global__ void k_conv_fwd(const float* __restrict__ in, Act ai, const float* __restrict__ W,
-                           const float* __restrict__ b, float* __restrict__ out, int64_t B, G g) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * g.cout * g.hout) return;
-  int j = (int)(idx % g.hout);
-  int o = (int)((idx / g.hout) % g.cout);
-  int64_t f = idx / ((int64_t)g.hout * g.cout);
-  float acc = b ? b[o] : 0.f;
-  int t0 = max(0, g.pad - g.s * j), t1 = min(g.k, g.hin + g.pad - g.s * j);
-  for (int c = 0; c < g.cin; ++c) {
-    const float* row = in + (f * g.cin + c) * g.hin + (g.s * j - g.pad);
-    for (int t = t0; t < t1; ++t) acc += lnact(row[t], ai, f, c) * W[((int64_t)t * g.cin + c) * g.cout + o];
+// One workgroup per (frame, block of OB output channels): the frame's activated input is staged in LDS once,
+// lanes take consecutive output channels (weight reads coalesced, input reads broadcast).  With four or more input
+// channels the four waves take every fourth channel each and their partial sums meet in LDS (the loop is bound by
+// load latency with one wave per SIMD, so the channel loop is what is worth spreading).
+constexpr int FWD_OB = 8;
+__global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ in, Act ai, const float* __restrict__ W,
+                                                  const float* __restrict__ b, float* __restrict__ out, G g) {
+  extern __shared__ float sIn[];  // [cin][hin], then [4][64] partial sums
+  float* sPart = sIn + g.cin * g.hin;
+  const int64_t f = blockIdx.x;
+  const int o0 = blockIdx.y * FWD_OB, ob = min(FWD_OB, g.cout - o0);
+  for (int e = threadIdx.x; e < g.cin * g.hin; e += blockDim.x) sIn[e] = lnact(in[f * g.cin * g.hin + e], ai, f, e / g.hin);
+  __syncthreads();
+  const int cs = g.cin >= 4 ? 4 : 1;                      // channel split over the waves
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cpart = cs == 4 ? wave : 0, nloc = cs == 4 ? 64 : 256, loc = cs == 4 ? lane : (int)threadIdx.x;
+  const int items = ob * g.hout;
+  const int64_t ws = (int64_t)g.cin * g.cout;
+  for (int base = 0; base < items; base += nloc) {       // uniform trip count: barriers inside
+    const int idx = base + loc;
+    const bool on = idx < items;
+    const int o = o0 + (on ? idx % ob : 0), j = on ? idx / ob : 0;
+    float acc = 0.f;
+    if (on) {
+      const int t0 = max(0, g.pad - g.s * j), t1 = min(g.k, g.hin + g.pad - g.s * j);
+      for (int c = cpart; c < g.cin; c += cs) {
+        const float* row = sIn + c * g.hin + (g.s * j - g.pad);
+        const float* wp = W + (int64_t)c * g.cout + o;
+        // eight weight loads in flight, two chains
+        float a0 = 0.f, a1 = 0.f;
+        int t = t0;
+        for (; t + 8 <= t1; t += 8) {
+          float wv[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) wv[q] = wp[(t + q) * ws];
+#pragma unroll
+          for (int q = 0; q < 8; q += 2) {
+            a0 += row[t + q] * wv[q];
+            a1 += row[t + q + 1] * wv[q + 1];
+          }
+        }
+        for (; t < t1; ++t) a0 += row[t] * wp[t * ws];
+        acc += a0 + a1;
+      }
+    }
+    if (cs == 4) {
+      sPart[wave * 64 + lane] = acc;
+      __syncthreads();
+      if (wave == 0 && on)
+        out[(f * g.cout + o) * g.hout + j] = ((sPart[lane] + sPart[64 + lane]) + (sPart[128 + lane] + sPart[192 + lane])) + (b ? b[o] : 0.f);
+      __syncthreads();
+    } else if (on) {
+      out[(f * g.cout + o) * g.hout + j] = acc + (b ? b[o] : 0.f);
+    }
   }
-  out[idx] = acc;
 }
 
 // util/layers.py:32 : per-frame mean and biased variance over all C*H -> (mean, rstd)
@@ -278,40 +319,123 @@ __global__ void k_chan_sum(const float* __restrict__ d, float* __restrict__ db, 
 }
 
 // din[f,c,i] = sum_o sum_t W[t,c,o] dout[f,o,j], s*j - pad + t = i       (conv input gradient)
-__global__ void k_conv_bwd_data(const float* __restrict__ dout, const float* __restrict__ W, float* __restrict__ din,
-                                int64_t B, G g) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * g.cin * g.hin) return;
-  int i = (int)(idx % g.hin);
-  int c = (int)((idx / g.hin) % g.cin);
-  int64_t f = idx / ((int64_t)g.hin * g.cin);
-  float acc = 0.f;
-  for (int j = 0; j < g.hout; ++j) {
-    int t = i + g.pad - g.s * j;
-    if (t < 0 || t >= g.k) continue;
-    const float* wr = W + ((int64_t)t * g.cin + c) * g.cout;
-    for (int o = 0; o < g.cout; ++o) acc += wr[o] * dout[(f * g.cout + o) * g.hout + j];
+// One workgroup per (frame, block of CB input channels): the frame's dout is staged in LDS, every item walks the
+// (at most ceil(k/s)) output positions that reach it and the contiguous cout weights of each.
+constexpr int BWD_CB = 8;
+__global__ void __launch_bounds__(256) k_conv_bwd_data(const float* __restrict__ dout, const float* __restrict__ W,
+                                                       float* __restrict__ din, G g) {
+  extern __shared__ float sD[];  // [cout][hout]
+  const int64_t f = blockIdx.x;
+  const int c0 = blockIdx.y * BWD_CB, cb = min(BWD_CB, g.cin - c0);
+  for (int e = threadIdx.x; e < g.cout * g.hout; e += blockDim.x) sD[e] = dout[f * g.cout * g.hout + e];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < cb * g.hin; idx += blockDim.x) {
+    const int c = c0 + idx % cb, i = idx / cb;
+    float acc = 0.f;
+    // t = i + pad - s j in [0, k)
+    const int jlo = max(0, (i + g.pad - g.k + g.s) / g.s), jhi = min(g.hout - 1, (i + g.pad) / g.s);
+    for (int j = jlo; j <= jhi; ++j) {
+      const int t = i + g.pad - g.s * j;
+      const float* wr = W + ((int64_t)t * g.cin + c) * g.cout;
+      const float* dc = sD + j;
+      if ((g.cout & 3) == 0) {  // rows of cout floats are 16-byte aligned: four weights per load, four chains
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+        for (int o = 0; o < g.cout; o += 4) {
+          const float4 w4 = *reinterpret_cast<const float4*>(wr + o);
+          a0 += w4.x * dc[o * g.hout];
+          a1 += w4.y * dc[(o + 1) * g.hout];
+          a2 += w4.z * dc[(o + 2) * g.hout];
+          a3 += w4.w * dc[(o + 3) * g.hout];
+        }
+        acc += (a0 + a1) + (a2 + a3);
+      } else {
+        for (int o = 0; o < g.cout; ++o) acc += wr[o] * dc[o * g.hout];
+      }
+    }
+    din[(f * g.cin + c) * g.hin + i] = acc;
   }
-  din[idx] = acc;
 }
 
 // dW[t,c,o] += sum_f sum_j act(in)[f,c,s*j-pad+t] dout[f,o,j]
-__global__ void k_conv_bwd_w(const float* __restrict__ in, Act ai, const float* __restrict__ dout,
-                             float* __restrict__ dW, int64_t B, G g) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)g.k * g.cin * g.cout) return;
-  int o = (int)(idx % g.cout);
-  int c = (int)((idx / g.cout) % g.cin);
-  int t = (int)(idx / ((int64_t)g.cout * g.cin));
-  const int hi = g.hin - 1 + g.pad - t;  // s*j <= hi
-  int j0 = max(0, (g.pad - t + g.s - 1) / g.s), j1 = hi < 0 ? 0 : min(g.hout, hi / g.s + 1);
-  float acc = 0.f;
-  for (int64_t f = 0; f < B; ++f) {
-    const float* row = in + (f * g.cin + c) * g.hin - g.pad + t;
-    const float* dr = dout + (f * g.cout + o) * g.hout;
-    for (int j = j0; j < j1; ++j) acc += lnact(row[g.s * j], ai, f, c) * dr[j];
+// One workgroup per (input channel c, chunk of WG_TC taps); thread = (output channel, tap subset), its weights in
+// registers over the whole frame loop; per frame the input row of channel c and dout are staged in LDS
+// (dout rows have odd length in every layer of the VCC2016 file: conflict-free across output channels).
+constexpr int WG_TC = 16, WG_MAXT = 16;
+__global__ void __launch_bounds__(256) k_conv_bwd_w(const float* __restrict__ in, Act ai, const float* __restrict__ dout,
+                                                    float* __restrict__ dW, int64_t B, G g, int FB, int64_t fper,
+                                                    int accumulate) {
+  extern __shared__ float sm[];
+  const int nD = g.cout * g.hout, nF = nD + g.hin;  // per staged frame: dout [cout][hout], then the input row [hin]
+  const int c = blockIdx.x, tbase = blockIdx.y * WG_TC;
+  const int o = threadIdx.x % g.cout, tq = threadIdx.x / g.cout, ntq = blockDim.x / g.cout;  // (cout <= 256)
+  float acc[WG_MAXT];
+#pragma unroll
+  for (int m = 0; m < WG_MAXT; ++m) acc[m] = 0.f;
+  const bool live = tq < ntq;
+  // blockIdx.z owns frames [z fper, (z + 1) fper) and its own copy of dW (summed afterwards in a fixed order)
+  const int64_t fbeg = blockIdx.z * fper, fend = min(B, fbeg + fper);
+  dW += (int64_t)blockIdx.z * g.k * g.cin * g.cout;
+  for (int64_t f0 = fbeg; f0 < fend; f0 += FB) {  // FB frames per barrier pair: the staging latency is paid once for all
+    const int nf = (int)min((int64_t)FB, fend - f0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nf * nD; e += blockDim.x) sm[(e / nD) * nF + e % nD] = dout[f0 * nD + e];
+    for (int e = threadIdx.x; e < nf * g.hin; e += blockDim.x) {
+      const int64_t f = f0 + e / g.hin;
+      sm[(e / g.hin) * nF + nD + e % g.hin] = lnact(in[(f * g.cin + c) * g.hin + e % g.hin], ai, f, c);
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+      for (int m = 0; m < WG_MAXT; ++m) {
+        const int t = tbase + tq + m * ntq;
+        if (tq + m * ntq < WG_TC && t < g.k) {
+          const int hi = g.hin - 1 + g.pad - t;  // s*j <= hi
+          const int j0 = max(0, (g.pad - t + g.s - 1) / g.s), j1 = hi < 0 ? 0 : min(g.hout, hi / g.s + 1);
+          float a0 = 0.f, a1 = 0.f;
+          for (int ff = 0; ff < nf; ++ff) {
+            const float* dr = sm + ff * nF + o * g.hout;
+            const float* sRow = sm + ff * nF + nD - g.pad + t;
+            int j = j0;
+            for (; j + 8 <= j1; j += 8) {  // one wave per SIMD: eight LDS read pairs in flight or the loop is latency
+              float x[8], d[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                x[q] = sRow[g.s * (j + q)];
+                d[q] = dr[j + q];
+              }
+#pragma unroll
+              for (int q = 0; q < 8; q += 2) {
+                a0 += x[q] * d[q];
+                a1 += x[q + 1] * d[q + 1];
+              }
+            }
+            for (; j < j1; ++j) a0 += sRow[g.s * j] * dr[j];
+          }
+          acc[m] += a0 + a1;
+        }
+      }
+    }
   }
-  dW[idx] += acc;
+  if (live) {
+#pragma unroll
+    for (int m = 0; m < WG_MAXT; ++m) {
+      const int t = tbase + tq + m * ntq;
+      if (tq + m * ntq < WG_TC && t < g.k) {
+        float* p = dW + ((int64_t)t * g.cin + c) * g.cout + o;
+        *p = accumulate ? *p + acc[m] : acc[m];
+      }
+    }
+  }
+}
+
+// dW[i] += sum_z part[z][i], z ascending
+__global__ void k_sum_parts(const float* __restrict__ part, float* __restrict__ dW, int n, int nz) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < nz; ++z) s += part[(int64_t)z * n + i];
+  dW[i] += s;
 }
 
 // per-frame gradient norm, penalty and the adjoint of g: gt = coef (|g| - 1) g / |g|   (coef = 2 lambda / F)
@@ -373,6 +497,30 @@ static G mk(const DiscL& l) { return G{l.cin, l.hin, l.cout, l.hout, l.k, l.s, l
 static Act act_of(const DiscL& l, const float* P, const float* st) { return Act{st, P + l.gamma_off, P + l.beta_off}; }
 
 namespace {
+void conv_fwd(const float* in, Act ai, const float* W, const float* b, float* out, int64_t B, const DiscL& l, hipStream_t s) {
+  hipLaunchKernelGGL(k_conv_fwd, dim3((unsigned)B, (unsigned)((l.cout + FWD_OB - 1) / FWD_OB)), dim3(256),
+                     ((size_t)l.cin * l.hin + 256) * sizeof(float), s, in, ai, W, b, out, mk(l));
+}
+void conv_bwd_data(const float* dout, const float* W, float* din, int64_t B, const DiscL& l, hipStream_t s) {
+  hipLaunchKernelGGL(k_conv_bwd_data, dim3((unsigned)B, (unsigned)((l.cin + BWD_CB - 1) / BWD_CB)), dim3(256),
+                     (size_t)l.cout * l.hout * sizeof(float), s, dout, W, din, mk(l));
+}
+constexpr int WG_SPLIT_MAX_W = 16384, WG_SPLIT = 16;  // small layers: the frame loop is dealt to up to 16 workgroups
+void conv_bwd_w(const float* in, Act ai, const float* dout, float* dW, int64_t B, const DiscL& l, float* part, hipStream_t s) {
+  const int per = l.cout * l.hout + l.hin;
+  const int FB = std::max(1, std::min(8, 14000 / per));  // staged frames (<= 56 KB of LDS)
+  const int nw = l.k * l.cin * l.cout;
+  const dim3 grid((unsigned)l.cin, (unsigned)((l.k + WG_TC - 1) / WG_TC));
+  const size_t lds = (size_t)FB * per * sizeof(float);
+  if (nw <= WG_SPLIT_MAX_W && B > FB) {
+    const int nz = (int)std::min<int64_t>(WG_SPLIT, (B + FB - 1) / FB);
+    const int64_t fper = (B + nz - 1) / nz;
+    hipLaunchKernelGGL(k_conv_bwd_w, dim3(grid.x, grid.y, (unsigned)nz), dim3(256), lds, s, in, ai, dout, part, B, mk(l), FB, fper, 0);
+    hipLaunchKernelGGL(k_sum_parts, grid1(nw), dim3(256), 0, s, part, dW, nw, nz);
+  } else {
+    hipLaunchKernelGGL(k_conv_bwd_w, grid, dim3(256), lds, s, in, ai, dout, dW, B, mk(l), FB, B, 1);
+  }
+}
 struct DWs {  // resolved workspace of one call; B rows in the forward tensors, R rows in the per-range ones
   float* rows;
   float* u[VAENPVC_MAX_LAYERS];
@@ -386,6 +534,7 @@ struct DWs {  // resolved workspace of one call; B rows in the forward tensors, 
   float* pn;
   float *g, *gt, *gp_f;
   float *da, *du;
+  float* part;  // per-workgroup copies of a small layer's weight gradient
 };
 int64_t al(int64_t n) { return (n + 63) & ~int64_t(63); }
 
@@ -424,6 +573,7 @@ int64_t carve(const vaenpvc_disc& m, int64_t F, bool critic, float* base, DWs* w
     t.gp_f = take(F);
     t.da = take(B * nmax);
     t.du = take(B * nmax);
+    t.part = take((int64_t)WG_SPLIT * WG_SPLIT_MAX_W);
   }
   if (w) *w = t;
   return off;
@@ -433,8 +583,7 @@ void forward(const vaenpvc_disc& m, const float* P, int64_t B, const DWs& w, hip
   for (int i = 0; i < m.n_layers; ++i) {
     const DiscL& l = m.l[i];
     Act ai = i == 0 ? kNoAct : act_of(m.l[i - 1], P, w.st[i - 1]);
-    hipLaunchKernelGGL(k_conv_fwd, grid1(B * l.n()), dim3(256), 0, s, i == 0 ? w.rows : w.u[i - 1], ai, P + l.w_off,
-                       P + l.b_off, w.u[i], B, mk(l));
+    conv_fwd(i == 0 ? w.rows : w.u[i - 1], ai, P + l.w_off, P + l.b_off, w.u[i], B, l, s);
     hipLaunchKernelGGL(k_ln_stats, dim3((unsigned)B), dim3(256), 0, s, w.u[i], w.st[i], l.n());
   }
   const DiscL& last = m.l[m.n_layers - 1];
@@ -451,8 +600,7 @@ void input_gradient(const vaenpvc_disc& m, const float* P, int64_t r0, int64_t R
     const DiscL& l = m.l[i];
     hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)R), dim3(256), 0, s, w.abar[i], w.u[i] + r0 * l.n(), w.st[i] + 2 * r0,
                        P + l.gamma_off, P + l.beta_off, (const float*)nullptr, w.ubar[i], l.cout, l.hout);
-    hipLaunchKernelGGL(k_conv_bwd_data, grid1(R * l.cin * l.hin), dim3(256), 0, s, w.ubar[i], P + l.w_off,
-                       i == 0 ? w.g : w.abar[i - 1], R, mk(l));
+    conv_bwd_data(w.ubar[i], P + l.w_off, i == 0 ? w.g : w.abar[i - 1], R, l, s);
   }
 }
 }  // namespace
@@ -503,6 +651,12 @@ int vaenpvc_disc_create(const vaenpvc_disc_arch* a, vaenpvc_disc** out) {
     l.b_off = add(p + "bias", {o});
     l.beta_off = add(p + "layernorm.offset", {o, 1, 1});
     l.gamma_off = add(p + "layernorm.scale", {o, 1, 1});
+    // kernel limits (disc.hip): one thread per output channel in the weight gradient, a frame's layer input /
+    // output staged in LDS
+    if (o > 256 || (int64_t)l.cin * l.hin > 16000 || (int64_t)l.cout * l.hout + l.hin > 16000) {
+      delete m;
+      return abi_error(VAENPVC_E_UNSUPPORTED, "discriminator: a layer exceeds 256 channels or 16000 values per frame");
+    }
     c = o;
     h = l.hout;
   }
@@ -596,10 +750,8 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
   for (int i = 0; i < L; ++i) {
     const DiscL& l = m.l[i];
     const float* src = i == 0 ? w.gt : w.at[i - 1];  // adjoint of abar_{i-1} (of g for the first layer)
-    hipLaunchKernelGGL(k_conv_fwd, grid1(F * l.n()), dim3(256), 0, s, src, kNoAct, P + l.w_off, (const float*)nullptr,
-                       w.q[i], F, mk(l));
-    hipLaunchKernelGGL(k_conv_bwd_w, grid1((int64_t)l.k * l.cin * l.cout), dim3(256), 0, s, src, kNoAct, w.ubar[i],
-                       Gd + l.w_off, F, mk(l));
+    conv_fwd(src, kNoAct, P + l.w_off, nullptr, w.q[i], F, l, s);
+    conv_bwd_w(src, kNoAct, w.ubar[i], Gd + l.w_off, F, l, w.part, s);
     hipLaunchKernelGGL(k_ln_bwd_bwd, dim3((unsigned)F), dim3(256), 0, s, w.q[i], w.abar[i], w.u[i] + 2 * F * l.n(),
                        w.st[i] + 4 * F, P + l.gamma_off, P + l.beta_off, w.at[i], w.udir[i], w.pn, l.cout, l.hout);
     hipLaunchKernelGGL(k_chan_sum, dim3(l.cout), dim3(256), 0, s, w.pn, Gd + l.gamma_off, F, l.cout, l.hout);
@@ -620,11 +772,9 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
     hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)F), dim3(256), 0, s, w.da + 2 * F * l.n(), w.u[i] + 2 * F * l.n(),
                        w.st[i] + 4 * F, P + l.gamma_off, P + l.beta_off, w.udir[i], w.du + 2 * F * l.n(), l.cout, l.hout);
     Act ai = i == 0 ? kNoAct : act_of(m.l[i - 1], P, w.st[i - 1]);
-    hipLaunchKernelGGL(k_conv_bwd_w, grid1((int64_t)l.k * l.cin * l.cout), dim3(256), 0, s, i == 0 ? w.rows : w.u[i - 1], ai,
-                       w.du, Gd + l.w_off, B, mk(l));
+    conv_bwd_w(i == 0 ? w.rows : w.u[i - 1], ai, w.du, Gd + l.w_off, B, l, w.part, s);
     hipLaunchKernelGGL(k_chan_sum, dim3(l.cout), dim3(256), 0, s, w.du, Gd + l.b_off, B, l.cout, l.hout);
-    if (i > 0)
-      hipLaunchKernelGGL(k_conv_bwd_data, grid1(B * l.cin * l.hin), dim3(256), 0, s, w.du, P + l.w_off, w.da, B, mk(l));
+    if (i > 0) conv_bwd_data(w.du, P + l.w_off, w.da, B, l, s);
   }
   return disc_check("disc_critic_fwd_bwd");
 }

@@ -69,3 +69,12 @@ class ConvVAE(object):
     def decode(self, z, y):                      # vae.py:143-145 : NHWC [F, H, 1, 1]
         xh = self.engine.decode(z, y)
         return xh.view(xh.shape[0], xh.shape[1], 1, 1)
+
+
+def __getattr__(name):
+    """`--model VAWGAN` with the default `--model_module model.vae` (main.py:27-31 of the reference loads the model
+    class from this module by name); the class lives in model/vawgan.py."""
+    if name == 'VAWGAN':
+        from model.vawgan import VAWGAN
+        return VAWGAN
+    raise AttributeError(name)
