@@ -167,6 +167,13 @@ int vaenpvc_philox_uniform(uint64_t seed, uint64_t offset, float* d_out, int64_t
 int vaenpvc_train_fwd_bwd_target(vaenpvc_ctx* ctx, const float* d_params, const float* d_x,
                                  const int64_t* d_y, const float* d_eps, const float* d_target, int64_t F,
                                  float* d_grads, float* d_loss3, void* d_ws, size_t ws_bytes, void* stream);
+/* Backward pass only, against d_target, on the activations a preceding vaenpvc_train_fwd_bwd / _target call
+ * left in d_ws: same context, parameters, x, y, eps, F and workspace, nothing else run on that workspace in
+ * between.  The backward pass reads the forward tensors and writes only gradient regions, so the second gradient
+ * of the VAWGAN generator step (l_G after l_E) costs one backward instead of a whole step. */
+int vaenpvc_train_bwd_target(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, const int64_t* d_y,
+                             const float* d_eps, const float* d_target, int64_t F, float* d_grads,
+                             float* d_loss3, void* d_ws, size_t ws_bytes, void* stream);
 
 /* Gradient buckets for data-parallel overlap (no reference counterpart: the reference is single
  * GPU).  The backward pass finishes the flat gradient buffer back to front -- decoder convs,

@@ -172,6 +172,36 @@ def test_two_iterations_follow_the_oracle_trajectory():
     assert n_strong > 20000
 
 
+@pytest.mark.parametrize('F,precision', [(16, 'bf16x2'), (256, 'bf16x2'), (1027, 'bf16x2'), (2048, 'bf16'), (2048, 'bf16x3')])
+def test_backward_only_pass_equals_the_full_step(F, precision):
+    """vaenpvc_train_bwd_target on the activations of a preceding step == vaenpvc_train_fwd_bwd_target (the backward
+    pass must not have overwritten anything a second backward reads), at batch sizes of every kernel family."""
+    from hipvae.engine import Engine
+    arch = vawgan_arch()
+    eng = Engine(arch, precision=precision)
+    eng.init_params(3)
+    dev = eng.device
+    g = torch.Generator(device='cpu').manual_seed(F)
+    x = torch.tanh(torch.randn(F, 513, generator=g)).to(dev)
+    y = torch.randint(0, 10, (F,), generator=g).to(dev)
+    eps = torch.randn(F, 128, generator=g).to(dev)
+    target = (x + 0.3 * torch.randn(F, 513, generator=g).to(dev)).contiguous()
+    g0, g1, g2 = (torch.empty(eng.n_params, device=dev) for _ in range(3))
+    l3 = torch.zeros(3, device=dev)
+    eng.train_fwd_bwd_target(x, y, eps, target, g1, out=l3)
+    want_l3 = l3.clone()
+    eng.train_fwd_bwd(x, y, eps, g0)
+    eng.train_bwd_target(x, y, eps, target, g2, out=l3)
+    assert torch.equal(l3, want_l3)
+    scale = g1.abs().max()
+    # (several weight gradients accumulate with atomics -- split-K, frame chunks -- so runs differ by rounding; a
+    #  tensor the backward pass had overwritten would be off by O(1))
+    assert (g2 - g1).abs().max() <= 5e-5 * scale, float((g2 - g1).abs().max() / scale)
+    assert (g0 - g1).abs().max() > 1e-3 * scale          # and the target does matter
+    eng.train_bwd_target(x, y, eps, x, g2, out=l3)        # target = x: the plain step's gradient again
+    assert (g2 - g0).abs().max() <= 5e-5 * g0.abs().max(), float((g2 - g0).abs().max() / g0.abs().max())
+
+
 def test_uniform_draw_matches_numpy_philox():
     from hipvae.engine import Engine
     eng = Engine(vawgan_arch())

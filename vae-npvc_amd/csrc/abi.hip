@@ -351,6 +351,26 @@ int vaenpvc_train_fwd_bwd_target(vaenpvc_ctx* ctx, const float* d_params, const 
   return train_impl(ctx, d_params, d_x, d_y, d_eps, nullptr, F, d_grads, d_loss3, d_ws, ws_bytes, stream, d_target);
 }
 
+int vaenpvc_train_bwd_target(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, const int64_t* d_y,
+                             const float* d_eps, const float* d_target, int64_t F, float* d_grads, float* d_loss3,
+                             void* d_ws, size_t ws_bytes, void* stream) {
+  if (!ctx || !d_params || !d_x || !d_y || !d_eps || !d_target || !d_grads || !d_loss3) return fail(VAENPVC_E_ARG, "null argument");
+  Call call(ctx);
+  Ws w;
+  int rc = resolve(ctx, F, VAENPVC_MODE_TRAIN, d_ws, ws_bytes, &w);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  generic::loss_fwd(ctx->m, d_target, F, w, true, d_loss3, s);   // new d(xh) from the activations already in place
+  ctx->rt.bucket_next = 0;
+  if (use_tuned(ctx)) {
+    tuned::backward(ctx->m, d_params, d_x, d_y, d_eps, F, w, d_grads, s);
+  } else {
+    generic::backward(ctx->m, d_params, d_x, d_y, d_eps, F, w, d_grads, s);
+    if (ctx->rt.bucket_cb) ctx->rt.bucket_cb(ctx->rt.bucket_user, 0, 0, ctx->m.n_params, (void*)s);
+  }
+  return check_launch("train_bwd_target");
+}
+
 int vaenpvc_philox_normal(uint64_t seed, uint64_t offset, float* d_out, int64_t n, void* stream) {
   if (!d_out || n < 1) return fail(VAENPVC_E_ARG, "bad argument");
   launch_philox_normal(d_out, n, make_key(seed, offset), (hipStream_t)stream);

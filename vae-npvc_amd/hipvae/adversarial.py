@@ -11,9 +11,9 @@ accumulators, so the t of Adam's bias correction counts applies (TF 1.2 semantic
 The gradient of l_G reuses the ConvVAE backward unchanged: the adversarial term enters through the
 reconstruction gradient, d l_G / d xh = (xh - x) / ((1 + 1e-6) F) - (alpha / F) dD(xh)/dxh, which is what the
 backward computes for the shifted target x' = x + alpha (1 + 1e-6) dD(xh)/dxh
-(vaenpvc_disc_generator_target + vaenpvc_train_fwd_bwd_target).  The generator step therefore runs the
-ConvVAE step twice on the same batch and noise (first for l_E, then for l_G); at the branch's 16-frame
-batches both are launch-bound.
+(vaenpvc_disc_generator_target + vaenpvc_train_bwd_target).  The generator step is therefore one ConvVAE
+step (gradient of l_E), the critic's forward + input gradient, and one more ConvVAE BACKWARD pass on the same
+activations (gradient of l_G).
 
 Data parallel: frames are independent in every term (the penalty is per frame), so ranks shard frames and
 all-reduce (SUM) each gradient buffer before its apply; 1/world goes into Adam's grad_scale.
@@ -119,7 +119,8 @@ class AdvStepper(object):
         be.train_fwd_bwd(x, y, eps, self.g_e, out=self._l3)          # l_E = G of the ConvVAE
         xh = be.ws_region(F, L.MODE_TRAIN, 'xh').view(F, -1)
         target, _ = cr.generator_target(x, xh, self.alpha, out=self._l2)
-        be.train_fwd_bwd_target(x, y, eps, target, self.g_g, out=self._l3b)
+        # second gradient on the activations of the first pass (a backend without the backward-only entry reruns the step)
+        getattr(be, 'train_bwd_target', be.train_fwd_bwd_target)(x, y, eps, target, self.g_g, out=self._l3b)
         self._reduce(self.g_e, self.g_g)
         gs = 1.0 / self.world
         self.applies += 1                                            # opt_e

@@ -287,7 +287,12 @@ class Engine(object):
                                                        ws.data_ptr(), nb, self._stream()), 'train_fwd_bwd')
         return out
 
-    def train_fwd_bwd_target(self, x, y, eps, target, grads, out=None):
+    def train_bwd_target(self, x, y, eps, target, grads, out=None):
+        """Backward pass only against `target`, on the activations the preceding train_fwd_bwd call of the SAME
+        (x, y, eps) left in the workspace (vaenpvc_train_bwd_target)."""
+        return self.train_fwd_bwd_target(x, y, eps, target, grads, out=out, _entry='vaenpvc_train_bwd_target')
+
+    def train_fwd_bwd_target(self, x, y, eps, target, grads, out=None, _entry='vaenpvc_train_fwd_bwd_target'):
         """train_fwd_bwd with the log-density evaluated against `target` [F, H] (vaenpvc_train_fwd_bwd_target)."""
         x = self._chk_x(x)
         F = x.shape[0]
@@ -301,10 +306,9 @@ class Engine(object):
         out = self._loss3 if out is None else out
         ws, nb = self._workspace(F, L.MODE_TRAIN)
         with self._on_device():
-            L.check(self.lib.vaenpvc_train_fwd_bwd_target(self.ctx, self.params.data_ptr(), x.data_ptr(), y.data_ptr(),
-                                                          eps.data_ptr(), target.data_ptr(), F, grads.data_ptr(),
-                                                          out.data_ptr(), ws.data_ptr(), nb, self._stream()),
-                    'train_fwd_bwd_target')
+            L.check(getattr(self.lib, _entry)(self.ctx, self.params.data_ptr(), x.data_ptr(), y.data_ptr(),
+                                              eps.data_ptr(), target.data_ptr(), F, grads.data_ptr(),
+                                              out.data_ptr(), ws.data_ptr(), nb, self._stream()), _entry)
         return out
 
     def philox_uniform(self, n, seed, offset=0):

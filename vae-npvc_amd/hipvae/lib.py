@@ -82,6 +82,7 @@ SIGNATURES = {
     'vaenpvc_summary': (C.c_int, [_P, _I64, _P, _I32, _P, _P, _P]),
     'vaenpvc_philox_uniform': (C.c_int, [_U64, _U64, _P, _I64, _P]),
     'vaenpvc_train_fwd_bwd_target': (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, C.c_size_t, _P]),
+    'vaenpvc_train_bwd_target': (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, C.c_size_t, _P]),
     'vaenpvc_disc_create': (C.c_int, [C.POINTER(DiscArch), C.POINTER(_P)]),
     'vaenpvc_disc_destroy': (None, [_P]),
     'vaenpvc_disc_param_count': (C.c_int, [_P]),
