@@ -4,13 +4,15 @@ backward, and iterations of the trainer's schedule.  The model is a specificatio
 only its trainer): PARITY UNPINNED, see the oracle's header."""
 import json
 import os
+import subprocess
+import sys
 import types
 
 import numpy as np
 import pytest
 import torch
 
-from helpers import PKG, rel_err
+from helpers import PKG, ROOT, rel_err
 from oracle import convvae_oracle as O
 from oracle import vawgan_oracle as V
 from oracle import philox_ref
@@ -292,3 +294,49 @@ def test_critic_argument_errors():
     from hipvae.critic import Critic
     with pytest.raises(HipVaeError):
         Critic(bad)                                       # more than 256 channels: VAENPVC_E_UNSUPPORTED, not a wrong result
+
+
+RCCL_ADV = r"""
+import os, sys, json
+sys.path.insert(0, os.path.join(%(root)r, 'vae-npvc_amd')); sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29643', RANK='0', WORLD_SIZE='1')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+from hipvae import Engine
+from hipvae.critic import Critic
+from hipvae.adversarial import AdvStepper
+arch = json.load(open(os.path.join(%(root)r, 'vae-npvc_amd', 'architecture-vawgan-vcc2016.json')))
+g = torch.Generator().manual_seed(1)
+x = torch.tanh(torch.randn(16, 513, generator=g)).cuda(); y = torch.randint(0, 10, (16,), generator=g).cuda()
+eps = torch.randn(16, 128, generator=g).cuda(); t = torch.rand(16, generator=g).cuda()
+out = {}
+for mode in ('plain', 'rccl'):
+    os.environ['VAENPVC_FORCE_DIST'] = '1' if mode == 'rccl' else '0'
+    eng, cr = Engine(arch), Critic(arch)
+    eng.init_params(2); cr.init_params(3)
+    st = AdvStepper(eng, cr, 1e-4, 0.5, 0.999, 50.0, 10.0)
+    assert st.collective == (mode == 'rccl')
+    st.broadcast_params()
+    for _ in range(2):
+        l2 = st.critic_step(x, y, eps, t)
+    l = st.generator_step(x, y, eps)
+    torch.cuda.synchronize()
+    out[mode] = (eng.params.cpu().numpy(), cr.params.cpu().numpy(), st.g_d.cpu().numpy(), st.g_g.cpu().numpy(),
+                 np.array([float(l2[0]), float(l2[1]), float(l['W_dist']), float(l['logP'])]))
+a, b = out['plain'], out['rccl']
+for i in (2, 3):      # gradients of the last steps: equal up to the order of fp32 atomics / earlier Adam moves
+    assert np.abs(a[i] - b[i]).max() <= 1e-3 * np.abs(a[i]).max(), i
+assert np.allclose(a[4], b[4], rtol=1e-3), (a[4], b[4])
+assert np.abs(a[0] - b[0]).mean() <= 2e-5 and np.abs(a[1] - b[1]).mean() <= 2e-5
+dist.destroy_process_group()
+print('RCCL_ADV_OK')
+"""
+
+
+def test_single_rank_rccl_adversarial_steps():
+    """hipvae.adversarial over the real "nccl" (RCCL) backend with one rank (VAENPVC_FORCE_DIST=1): the all-reduces of the
+    critic and of both ConvVAE gradient buffers, the broadcast of both parameter sets and the loss means run through
+    RCCL and follow the collective-free trajectory."""
+    r = subprocess.run([sys.executable, '-c', RCCL_ADV % {'root': ROOT}], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'RCCL_ADV_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -18,6 +18,8 @@ activations (gradient of l_G).
 Data parallel: frames are independent in every term (the penalty is per frame), so ranks shard frames and
 all-reduce (SUM) each gradient buffer before its apply; 1/world goes into Adam's grad_scale.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -48,7 +50,9 @@ class AdvStepper(object):
         self.alpha, self.lam = float(alpha), float(lam)
         self.group = group
         self.rank, self.world = world_info(group)
-        self.collective = self.world > 1
+        # VAENPVC_FORCE_DIST=1: run the collectives even with one rank (smoke-tests the RCCL path, as hipvae.dp)
+        self.collective = self.world > 1 or (os.environ.get('VAENPVC_FORCE_DIST') == '1' and dist.is_available()
+                                             and dist.is_initialized())
         p, d = engine.params, critic.params
         self.g_e = torch.zeros_like(p)          # gradient of l_E (all tensors; the 'Encoder' ranges are applied)
         self.g_g = torch.zeros_like(p)          # gradient of l_G (the 'Generator' / 'y_emb' ranges are applied)
