@@ -71,6 +71,31 @@ def test_critic_step_matches_autograd_oracle(F):
     assert max(worst.values()) < TOL_GRAD, worst
 
 
+def test_critic_step_on_a_generic_geometry():
+    """A shrunk critic (54 bins, kernels 5 / 4, 3 and 4 channels: channel counts that divide nothing, even kernel with
+    asymmetric SAME padding) through the same kernels."""
+    from adv_standin import SMALL_VAWGAN as arch
+    cr, D = make_critic(arch, 8)
+    rng = np.random.RandomState(5)
+    F, H = 9, arch['hwc'][0]
+    x, xh, t = np.tanh(rng.randn(F, H)).astype(np.float32), np.tanh(rng.randn(F, H)).astype(np.float32), rng.rand(F).astype(np.float32)
+    want, gw = V.critic_loss_and_grads(arch, D, x.astype(np.float64), xh.astype(np.float64), t.astype(np.float64), 10.0)
+    dev = cr.device
+    grads = torch.full((cr.n_params,), float('nan'), device=dev)
+    l2 = cr.critic_fwd_bwd(torch.tensor(x, device=dev), torch.tensor(xh, device=dev), torch.tensor(t, device=dev), 10.0,
+                           grads).cpu().numpy()
+    assert abs(l2[0] - want['W_dist']) < TOL_VALUE * max(1.0, abs(want['W_dist'])) and abs(l2[1] - want['gp']) < 2e-4 * max(1.0, want['gp'])
+    got = cr.param_views(grads.cpu())
+    worst = {k: float(np.abs(got[k].numpy().reshape(gw[k].shape) - gw[k]).max() / max(np.abs(gw[k]).max(), 1e-3)) for k in gw}
+    assert max(worst.values()) < TOL_GRAD, worst
+    target, _ = cr.generator_target(torch.tensor(x, device=dev), torch.tensor(xh, device=dev), 50.0)
+    import torch as T
+    Dt = O.torch_params(D, T.float64)
+    xht = T.tensor(xh.astype(np.float64), requires_grad=True)
+    g, = T.autograd.grad(V.torch_discriminate(arch, Dt, xht).sum(), xht)
+    assert rel_err(target.cpu().numpy() - x, 50.0 * (1 + 1e-6) * g.numpy()) < TOL_VALUE
+
+
 def test_critic_step_is_deterministic_and_linear_in_lambda():
     """Bitwise repeatable (no atomics), and grad(lambda) is affine in lambda: g(20) - g(10) == g(10) - g(0)."""
     arch = vawgan_arch()
