@@ -6,7 +6,8 @@ in HBM: forward + backward (vaenpvc_train_fwd_bwd_seeded: the sampler's N(0,1) d
 on the device, Philox) [+ RCCL all-reduce of the gradient buckets when N > 1] + fused TF-Adam.
 Workload at N = 1 (BASELINE.json configs[1], north_star "batch 256 x [1,513,128]"): 256*128 =
 32768 independent 513-bin frames per step per GPU (weak scaling: fixed per-GPU work).  The literal
-F = 256 and F = 16 (configs[0]) readings are reported in `config.literal_batches`.
+F = 256 and F = 16 (configs[0]) readings are reported in `config.literal_batches`, one iteration of the VAWGAN branch
+(configs[4]: 5 critic steps + 1 generator step at 16 frames per step) in `config.vawgan_config5`.
 
 Arithmetic: fp32 tensors everywhere; the GEMM-shaped kernels that run on the bf16 matrix cores split
 every fp32 operand into bf16 terms with fp32 accumulation.  The default (`value`, "bf16x2") uses 2 terms
@@ -305,6 +306,46 @@ def main():
             lits['F%d' % Fl] = lit
         out['config']['literal_batches'] = lits
         out['config']['literal_batch256'] = lits['F256']
+    if not args.no_literal:
+        # BASELINE.json configs[4]: the VAWGAN branch (nIterD critic steps + one generator step per iteration, 16 frames per
+        # step and GPU; hipvae/adversarial.py, data parallel over the same process group).  Reported beside the headline.
+        try:
+            from hipvae.critic import Critic
+            from hipvae.adversarial import AdvStepper
+            with open(os.path.join(ROOT, 'vae-npvc_amd', 'architecture-vawgan-vcc2016.json')) as fp:
+                varch = json.load(fp)
+            vt = varch['training']
+            veng, vcr = Engine(varch, precision=args.precision), Critic(varch)
+            veng.init_params(seed=0)
+            vcr.init_params(seed=1)
+            vst = AdvStepper(veng, vcr, vt['lr'], vt['beta1'], vt['beta2'], vt['alpha'], vt['lambda'], seed=0)
+            vst.broadcast_params()
+            Fv = vt['batch_size']
+            g = torch.Generator(device='cpu').manual_seed(7 + rank)
+            xv = torch.rand(Fv, eng.H, generator=g).mul_(2).sub_(1).cuda()
+            yv = torch.randint(0, varch['y_dim'], (Fv,), generator=g).cuda()
+
+            def iteration():
+                for _ in range(vt['nIterD']):
+                    vst.critic_step(xv, yv)
+                vst.generator_step(xv, yv)
+            for _ in range(3):
+                iteration()
+            barrier()
+            t0 = time.perf_counter()
+            nit = 30
+            for _ in range(nit):
+                iteration()
+            barrier()
+            dtv = time.perf_counter() - t0
+            out['config']['vawgan_config5'] = {
+                'ms_per_iteration': dtv / nit * 1e3, 'frames_per_s': world * Fv * (vt['nIterD'] + 1) * nit / dtv,
+                'frames_per_step_per_gpu': Fv, 'nIterD': vt['nIterD'],
+                'status': {k: float(v) for k, v in vst.status.items()},
+                'note': 'model specified in DESIGN.md section 9 (the reference tree holds only its trainer)'}
+            del veng, vcr, vst
+        except Exception as ex:       # noqa: BLE001
+            out['config']['vawgan_config5'] = {'error': str(ex)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(arch, args.cpu_seconds)
     if rank == 0:
