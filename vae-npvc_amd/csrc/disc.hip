@@ -86,7 +86,7 @@ __global__ void k_rows(const float* __restrict__ x, const float* __restrict__ xh
 constexpr int FWD_OB = 8;
 __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ in, Act ai, const float* __restrict__ W,
                                                   const float* __restrict__ b, float* __restrict__ out, G g) {
-  extern __shared__ float sIn[];  // [cin][hin], then [4][64] partial sums
+  extern __shared__ float sIn[];  // [cin][hin], then [4 outputs][4 waves][64] partial sums
   float* sPart = sIn + g.cin * g.hin;
   const int64_t f = blockIdx.x;
   const int o0 = blockIdx.y * FWD_OB, ob = min(FWD_OB, g.cout - o0);
@@ -95,43 +95,76 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ in, 
   const int cs = g.cin >= 4 ? 4 : 1;                      // channel split over the waves
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int cpart = cs == 4 ? wave : 0, nloc = cs == 4 ? 64 : 256, loc = cs == 4 ? lane : (int)threadIdx.x;
-  const int items = ob * g.hout;
   const int64_t ws = (int64_t)g.cin * g.cout;
+  // OV output channels per item: four when the rows of cout weights can be read 16 bytes at a time (one load then
+  // feeds four chains), else one
+  const bool v4 = (g.cout & 3) == 0 && (ob & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+  const int OV = v4 ? 4 : 1;
+  const int og = ob / OV, items = og * g.hout;
   for (int base = 0; base < items; base += nloc) {       // uniform trip count: barriers inside
     const int idx = base + loc;
     const bool on = idx < items;
-    const int o = o0 + (on ? idx % ob : 0), j = on ? idx / ob : 0;
-    float acc = 0.f;
+    const int o = o0 + OV * (on ? idx % og : 0), j = on ? idx / og : 0;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (on) {
       const int t0 = max(0, g.pad - g.s * j), t1 = min(g.k, g.hin + g.pad - g.s * j);
       for (int c = cpart; c < g.cin; c += cs) {
         const float* row = sIn + c * g.hin + (g.s * j - g.pad);
         const float* wp = W + (int64_t)c * g.cout + o;
-        // eight weight loads in flight, two chains
-        float a0 = 0.f, a1 = 0.f;
         int t = t0;
-        for (; t + 8 <= t1; t += 8) {
-          float wv[8];
+        if (v4) {
+          for (; t + 4 <= t1; t += 4) {                  // four 16-byte weight loads in flight
+            float4 wv[4];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) wv[q] = wp[(t + q) * ws];
+            for (int q = 0; q < 4; ++q) wv[q] = *reinterpret_cast<const float4*>(wp + (t + q) * ws);
 #pragma unroll
-          for (int q = 0; q < 8; q += 2) {
-            a0 += row[t + q] * wv[q];
-            a1 += row[t + q + 1] * wv[q + 1];
+            for (int q = 0; q < 4; ++q) {
+              const float x = row[t + q];
+              acc[0] += x * wv[q].x;
+              acc[1] += x * wv[q].y;
+              acc[2] += x * wv[q].z;
+              acc[3] += x * wv[q].w;
+            }
           }
+          for (; t < t1; ++t) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wp + t * ws);
+            const float x = row[t];
+            acc[0] += x * w4.x;
+            acc[1] += x * w4.y;
+            acc[2] += x * w4.z;
+            acc[3] += x * w4.w;
+          }
+        } else {
+          float a0 = 0.f, a1 = 0.f;                      // eight weight loads in flight, two chains
+          for (; t + 8 <= t1; t += 8) {
+            float wv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wv[q] = wp[(t + q) * ws];
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+              a0 += row[t + q] * wv[q];
+              a1 += row[t + q + 1] * wv[q + 1];
+            }
+          }
+          for (; t < t1; ++t) a0 += row[t] * wp[t * ws];
+          acc[0] += a0 + a1;
         }
-        for (; t < t1; ++t) a0 += row[t] * wp[t * ws];
-        acc += a0 + a1;
       }
     }
     if (cs == 4) {
-      sPart[wave * 64 + lane] = acc;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (v < OV) sPart[(v * 4 + wave) * 64 + lane] = acc[v];
       __syncthreads();
-      if (wave == 0 && on)
-        out[(f * g.cout + o) * g.hout + j] = ((sPart[lane] + sPart[64 + lane]) + (sPart[128 + lane] + sPart[192 + lane])) + (b ? b[o] : 0.f);
+      if (wave == 0 && on) {
+        for (int v = 0; v < OV; ++v) {
+          const float* sp = sPart + v * 256 + lane;
+          out[(f * g.cout + o + v) * g.hout + j] = ((sp[0] + sp[64]) + (sp[128] + sp[192])) + (b ? b[o + v] : 0.f);
+        }
+      }
       __syncthreads();
     } else if (on) {
-      out[(f * g.cout + o) * g.hout + j] = acc + (b ? b[o] : 0.f);
+      for (int v = 0; v < OV; ++v) out[(f * g.cout + o + v) * g.hout + j] = acc[v] + (b ? b[o + v] : 0.f);
     }
   }
 }
@@ -321,7 +354,7 @@ __global__ void k_chan_sum(const float* __restrict__ d, float* __restrict__ db, 
 // din[f,c,i] = sum_o sum_t W[t,c,o] dout[f,o,j], s*j - pad + t = i       (conv input gradient)
 // One workgroup per (frame, block of CB input channels): the frame's dout is staged in LDS, every item walks the
 // (at most ceil(k/s)) output positions that reach it and the contiguous cout weights of each.
-constexpr int BWD_CB = 8;
+constexpr int BWD_CB = 4;
 __global__ void __launch_bounds__(256) k_conv_bwd_data(const float* __restrict__ dout, const float* __restrict__ W,
                                                        float* __restrict__ din, G g) {
   extern __shared__ float sD[];  // [cout][hout]
@@ -340,7 +373,7 @@ __global__ void __launch_bounds__(256) k_conv_bwd_data(const float* __restrict__
       const float* dc = sD + j;
       if ((g.cout & 3) == 0) {  // rows of cout floats are 16-byte aligned: four weights per load, four chains
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 4
+#pragma unroll 8
         for (int o = 0; o < g.cout; o += 4) {
           const float4 w4 = *reinterpret_cast<const float4*>(wr + o);
           a0 += w4.x * dc[o * g.hout];
@@ -379,10 +412,11 @@ __global__ void __launch_bounds__(256) k_conv_bwd_w(const float* __restrict__ in
   for (int64_t f0 = fbeg; f0 < fend; f0 += FB) {  // FB frames per barrier pair: the staging latency is paid once for all
     const int nf = (int)min((int64_t)FB, fend - f0);
     __syncthreads();
-    for (int e = threadIdx.x; e < nf * nD; e += blockDim.x) sm[(e / nD) * nF + e % nD] = dout[f0 * nD + e];
-    for (int e = threadIdx.x; e < nf * g.hin; e += blockDim.x) {
-      const int64_t f = f0 + e / g.hin;
-      sm[(e / g.hin) * nF + nD + e % g.hin] = lnact(in[(f * g.cin + c) * g.hin + e % g.hin], ai, f, c);
+    for (int ff = 0; ff < nf; ++ff) {
+      const float* dsrc = dout + (f0 + ff) * nD;
+      for (int e = threadIdx.x; e < nD; e += blockDim.x) sm[ff * nF + e] = dsrc[e];
+      const float* isrc = in + ((f0 + ff) * g.cin + c) * g.hin;
+      for (int e = threadIdx.x; e < g.hin; e += blockDim.x) sm[ff * nF + nD + e] = lnact(isrc[e], ai, f0 + ff, c);
     }
     __syncthreads();
     if (live) {
@@ -499,13 +533,14 @@ static Act act_of(const DiscL& l, const float* P, const float* st) { return Act{
 namespace {
 void conv_fwd(const float* in, Act ai, const float* W, const float* b, float* out, int64_t B, const DiscL& l, hipStream_t s) {
   hipLaunchKernelGGL(k_conv_fwd, dim3((unsigned)B, (unsigned)((l.cout + FWD_OB - 1) / FWD_OB)), dim3(256),
-                     ((size_t)l.cin * l.hin + 256) * sizeof(float), s, in, ai, W, b, out, mk(l));
+                     ((size_t)l.cin * l.hin + 1024) * sizeof(float), s, in, ai, W, b, out, mk(l));
 }
 void conv_bwd_data(const float* dout, const float* W, float* din, int64_t B, const DiscL& l, hipStream_t s) {
   hipLaunchKernelGGL(k_conv_bwd_data, dim3((unsigned)B, (unsigned)((l.cin + BWD_CB - 1) / BWD_CB)), dim3(256),
                      (size_t)l.cout * l.hout * sizeof(float), s, dout, W, din, mk(l));
 }
-constexpr int WG_SPLIT_MAX_W = 16384, WG_SPLIT = 16;  // small layers: the frame loop is dealt to up to 16 workgroups
+// the frame loop is dealt to several workgroups with private copies of dW: up to 16 for small layers, up to 6 for larger ones
+constexpr int WG_SPLIT_MAX_W = 262144, WG_SPLIT_SMALL_W = 16384, WG_SPLIT = 16, WG_SPLIT_BIG = 6;
 void conv_bwd_w(const float* in, Act ai, const float* dout, float* dW, int64_t B, const DiscL& l, float* part, hipStream_t s) {
   const int per = l.cout * l.hout + l.hin;
   const int FB = std::max(1, std::min(8, 14000 / per));  // staged frames (<= 56 KB of LDS)
@@ -513,7 +548,7 @@ void conv_bwd_w(const float* in, Act ai, const float* dout, float* dW, int64_t B
   const dim3 grid((unsigned)l.cin, (unsigned)((l.k + WG_TC - 1) / WG_TC));
   const size_t lds = (size_t)FB * per * sizeof(float);
   if (nw <= WG_SPLIT_MAX_W && B > FB) {
-    const int nz = (int)std::min<int64_t>(WG_SPLIT, (B + FB - 1) / FB);
+    const int nz = (int)std::min<int64_t>(nw <= WG_SPLIT_SMALL_W ? WG_SPLIT : WG_SPLIT_BIG, (B + FB - 1) / FB);
     const int64_t fper = (B + nz - 1) / nz;
     hipLaunchKernelGGL(k_conv_bwd_w, dim3(grid.x, grid.y, (unsigned)nz), dim3(256), lds, s, in, ai, dout, part, B, mk(l), FB, fper, 0);
     hipLaunchKernelGGL(k_sum_parts, grid1(nw), dim3(256), 0, s, part, dW, nw, nz);
@@ -573,7 +608,7 @@ int64_t carve(const vaenpvc_disc& m, int64_t F, bool critic, float* base, DWs* w
     t.gp_f = take(F);
     t.da = take(B * nmax);
     t.du = take(B * nmax);
-    t.part = take((int64_t)WG_SPLIT * WG_SPLIT_MAX_W);
+    t.part = take(std::max((int64_t)WG_SPLIT * WG_SPLIT_SMALL_W, (int64_t)WG_SPLIT_BIG * WG_SPLIT_MAX_W));
   }
   if (w) *w = t;
   return off;
