@@ -326,8 +326,7 @@ def main():
             yv = torch.randint(0, varch['y_dim'], (Fv,), generator=g).cuda()
 
             def iteration():
-                for _ in range(vt['nIterD']):
-                    vst.critic_step(xv, yv)
+                vst.critic_steps([(xv, yv)] * vt['nIterD'])
                 vst.generator_step(xv, yv)
             for _ in range(3):
                 iteration()

@@ -38,8 +38,7 @@ def main():
         return (time.perf_counter() - t0) / n * 1e3
 
     def iteration():
-        for _ in range(t['nIterD']):
-            st.critic_step(x, y)
+        st.critic_steps([(x, y)] * t['nIterD'])
         st.generator_step(x, y)
     ms_d = timed(lambda: st.critic_step(x, y), a.iters)
     ms_g = timed(lambda: st.generator_step(x, y), a.iters)

@@ -171,9 +171,8 @@ def test_two_iterations_follow_the_oracle_trajectory():
     tt = lambda a, dt=torch.float32: torch.tensor(np.asarray(a), dtype=dt, device=dev)
     it = iter(batches)
     for _ in range(iters):
-        for _ in range(n_d):
-            b = next(it)
-            st.critic_step(tt(b['x']), tt(b['y'], torch.int64), tt(b['eps']), tt(b['u']))
+        bs = [next(it) for _ in range(n_d)]     # one generator forward for the n_d critic batches
+        st.critic_steps([(tt(b['x']), tt(b['y'], torch.int64)) for b in bs], [tt(b['eps']) for b in bs], [tt(b['u']) for b in bs])
         b = next(it)
         out = st.generator_step(tt(b['x']), tt(b['y'], torch.int64), tt(b['eps']))
     assert st.applies == iters * (n_d + 2) and st.step_count == iters

@@ -140,9 +140,8 @@ def test_stepper_iteration_matches_direct_autograd_trajectory():
     it = iter(batches)
     tt = torch.tensor
     for _ in range(iters):
-        for _ in range(n_d):
-            b = next(it)
-            l2 = st.critic_step(tt(b['x']), tt(b['y']), tt(b['eps']), tt(b['u']))
+        bs = [next(it) for _ in range(n_d)]     # one generator forward for the n_d critic batches
+        l2 = st.critic_steps([(tt(b['x']), tt(b['y'])) for b in bs], [tt(b['eps']) for b in bs], [tt(b['u']) for b in bs])
         b = next(it)
         out = st.generator_step(tt(b['x']), tt(b['y']), tt(b['eps']))
     assert st.applies == iters * (n_d + 2) and st.step_count == iters

@@ -97,19 +97,33 @@ class AdvStepper(object):
 
     # ------------------------------------------------------------------ sess.run(opt['d'])
     def critic_step(self, x, y, eps=None, t=None):
+        return self.critic_steps([(x, y)], None if eps is None else [eps], None if t is None else [t])
+
+    def critic_steps(self, batches, eps=None, t=None):
+        """len(batches) consecutive `sess.run(opt['d'])` (trainer/vae.py:177-178), each on its own batch (x, y).  The
+        encoder and the generator do not change between critic steps, so their forward pass runs ONCE over the
+        concatenated batches (same kernels, more frames each) and every critic step takes its rows of xh: at 16
+        frames per batch the device time is the number of kernels, and the generator forward was 60 of a critic
+        step's ~130.  eps / t: optional lists of injected draws, one per batch."""
         be, cr = self.backend, self.critic
-        F = x.shape[0]
+        n, F = len(batches), batches[0][0].shape[0]
+        if any(b[0].shape[0] != F for b in batches):
+            raise ValueError('critic batches must have one size')
+        X = batches[0][0].reshape(F, -1) if n == 1 else torch.cat([b[0].reshape(F, -1) for b in batches])
+        Y = batches[0][1].reshape(-1) if n == 1 else torch.cat([b[1].reshape(-1) for b in batches])
         if eps is None or t is None:
-            e2, t2 = self._draw(F)
-            eps = e2 if eps is None else eps
-            t = t2 if t is None else t
-        be.loss_fwd(x, y, eps, out=self._l3)                         # forward only: xh of the current generator
-        xh = be.ws_region(F, L.MODE_INFER, 'xh').view(F, -1)
-        cr.critic_fwd_bwd(x, xh, t, self.lam, self.g_d, out=self._l2)
-        self._reduce(self.g_d)
-        self.applies += 1
-        be.adam_range(cr.params, self.g_d, self.m_d, self.v_d, 0, cr.n_params, self.applies, self.lr, self.beta1,
-                      self.beta2, self.eps, 1.0 / self.world)
+            e2, t2 = self._draw(n * F)
+        eps = e2 if eps is None else (eps[0] if n == 1 else torch.cat(list(eps)))
+        t = t2 if t is None else (t[0] if n == 1 else torch.cat(list(t)))
+        be.loss_fwd(X, Y, eps, out=self._l3)                         # forward only: xh of the current generator
+        xh = be.ws_region(n * F, L.MODE_INFER, 'xh').view(n * F, -1)
+        for i in range(n):
+            lo, hi = i * F, (i + 1) * F
+            cr.critic_fwd_bwd(X[lo:hi], xh[lo:hi], t[lo:hi], self.lam, self.g_d, out=self._l2)
+            self._reduce(self.g_d)
+            self.applies += 1
+            be.adam_range(cr.params, self.g_d, self.m_d, self.v_d, 0, cr.n_params, self.applies, self.lr, self.beta1,
+                          self.beta2, self.eps, 1.0 / self.world)
         l2 = self._mean(self._l2)
         self.status['W_dist'], self.status['gp'] = l2[0], l2[1]
         return l2

@@ -186,9 +186,9 @@ class VAWGANTrainer(VAETrainer):
         t = self.arch['training']
         t_status = t_save = time.time()
         while st.step_count < t['max_iter']:
-            for _ in range(t['nIterD']):                  # trainer/vae.py:177-178
-                x, y = source.next_batch()
-                st.critic_step(x, y)
+            # trainer/vae.py:177-178: nIterD critic steps, each on its own batch (dequeued in the same order; the
+            # generator's forward pass of all of them runs as one, see AdvStepper.critic_steps)
+            st.critic_steps([source.next_batch() for _ in range(t['nIterD'])])
             x, y = source.next_batch()                    # trainer/vae.py:179
             st.generator_step(x, y)
             now = time.time()
