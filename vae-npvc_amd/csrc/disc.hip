@@ -225,14 +225,16 @@ __global__ void k_dense_bwd_w(const float* __restrict__ u, Act ai, int hlast, fl
 }
 
 // LayerNorm + lrelu backward (autodiff of util/layers.py:32-44,149); one block per frame.
-//   n = gamma xhat + beta ; p = dy lrelu'(n) gamma ; du = rstd (p - mean p - xhat mean(p xhat)) (+ add)
+//   n = gamma xhat + beta ; p = dy lrelu'(n) gamma ; du = rstd (p - mean p - xhat mean(p xhat)) (+ add, a tensor whose
+//   row 0 belongs to frame add_row0)
 __global__ void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ u, const float* __restrict__ st,
                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                         const float* __restrict__ add, float* __restrict__ du, int C, int H) {
+                         const float* __restrict__ add, int64_t add_row0, float* __restrict__ du, int C, int H) {
   __shared__ float sm[16];
   int64_t f = blockIdx.x;
   int n = C * H;
   float mean = st[2 * f], rstd = st[2 * f + 1];
+  add = (add && f >= add_row0) ? add + (f - add_row0) * n - f * n : nullptr;   // rows [add_row0, ..) carry the injected term
   float s1 = 0.f, s2 = 0.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     int c = i / H;
@@ -463,13 +465,27 @@ __global__ void __launch_bounds__(256) k_conv_bwd_w(const float* __restrict__ in
   }
 }
 
-// dW[i] += sum_z part[z][i], z ascending
-__global__ void k_sum_parts(const float* __restrict__ part, float* __restrict__ dW, int n, int nz) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int z = 0; z < nz; ++z) s += part[(int64_t)z * n + i];
-  dW[i] += s;
+// dW[i] += sum_z part[z][i], z ascending, for up to 8 (weight gradient, copies) pairs in one launch
+struct PartSum {
+  const float* part;
+  float* dW;
+  int n, nz;
+};
+struct PartSums {
+  PartSum e[8];
+  int count;
+};
+// (a thread walks the pairs in order: two pairs of the same layer -- passes 3 and 4 -- update element i from the same thread)
+__global__ void k_sum_parts(PartSums ps, int nmax) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nmax; i += gridDim.x * blockDim.x) {
+    for (int e = 0; e < ps.count; ++e) {
+      const PartSum& p = ps.e[e];
+      if (i >= p.n) continue;
+      float s = 0.f;
+      for (int z = 0; z < p.nz; ++z) s += p.part[(int64_t)z * p.n + i];
+      p.dW[i] += s;
+    }
+  }
 }
 
 // per-frame gradient norm, penalty and the adjoint of g: gt = coef (|g| - 1) g / |g|   (coef = 2 lambda / F)
@@ -541,17 +557,19 @@ void conv_bwd_data(const float* dout, const float* W, float* din, int64_t B, con
 }
 // the frame loop is dealt to several workgroups with private copies of dW: up to 16 for small layers, up to 6 for larger ones
 constexpr int WG_SPLIT_MAX_W = 262144, WG_SPLIT_SMALL_W = 16384, WG_SPLIT = 16, WG_SPLIT_BIG = 6;
-void conv_bwd_w(const float* in, Act ai, const float* dout, float* dW, int64_t B, const DiscL& l, float* part, hipStream_t s) {
+// `part` / `sums`: where this call may put per-workgroup copies of dW and the list the final k_sum_parts works through
+void conv_bwd_w(const float* in, Act ai, const float* dout, float* dW, int64_t B, const DiscL& l, float* part, PartSums* sums,
+                hipStream_t s) {
   const int per = l.cout * l.hout + l.hin;
   const int FB = std::max(1, std::min(8, 14000 / per));  // staged frames (<= 56 KB of LDS)
   const int nw = l.k * l.cin * l.cout;
   const dim3 grid((unsigned)l.cin, (unsigned)((l.k + WG_TC - 1) / WG_TC));
   const size_t lds = (size_t)FB * per * sizeof(float);
-  if (nw <= WG_SPLIT_MAX_W && B > FB) {
+  if (nw <= WG_SPLIT_MAX_W && B > FB && sums->count < 8) {
     const int nz = (int)std::min<int64_t>(nw <= WG_SPLIT_SMALL_W ? WG_SPLIT : WG_SPLIT_BIG, (B + FB - 1) / FB);
     const int64_t fper = (B + nz - 1) / nz;
     hipLaunchKernelGGL(k_conv_bwd_w, dim3(grid.x, grid.y, (unsigned)nz), dim3(256), lds, s, in, ai, dout, part, B, mk(l), FB, fper, 0);
-    hipLaunchKernelGGL(k_sum_parts, grid1(nw), dim3(256), 0, s, part, dW, nw, nz);
+    sums->e[sums->count++] = PartSum{part, dW, nw, nz};
   } else {
     hipLaunchKernelGGL(k_conv_bwd_w, grid, dim3(256), lds, s, in, ai, dout, dW, B, mk(l), FB, B, 1);
   }
@@ -569,7 +587,7 @@ struct DWs {  // resolved workspace of one call; B rows in the forward tensors, 
   float* pn;
   float *g, *gt, *gp_f;
   float *da, *du;
-  float* part;  // per-workgroup copies of a small layer's weight gradient
+  float* part[2][VAENPVC_MAX_LAYERS];  // per-workgroup copies of a layer's weight gradient, per pass (3, 4)
 };
 int64_t al(int64_t n) { return (n + 63) & ~int64_t(63); }
 
@@ -608,7 +626,11 @@ int64_t carve(const vaenpvc_disc& m, int64_t F, bool critic, float* base, DWs* w
     t.gp_f = take(F);
     t.da = take(B * nmax);
     t.du = take(B * nmax);
-    t.part = take(std::max((int64_t)WG_SPLIT * WG_SPLIT_SMALL_W, (int64_t)WG_SPLIT_BIG * WG_SPLIT_MAX_W));
+    for (int p = 0; p < 2; ++p)
+      for (int i = 0; i < m.n_layers; ++i) {
+        const int64_t nw = (int64_t)m.l[i].k * m.l[i].cin * m.l[i].cout;
+        t.part[p][i] = nw <= WG_SPLIT_MAX_W ? take(nw * (nw <= WG_SPLIT_SMALL_W ? WG_SPLIT : WG_SPLIT_BIG)) : nullptr;
+      }
   }
   if (w) *w = t;
   return off;
@@ -634,7 +656,7 @@ void input_gradient(const vaenpvc_disc& m, const float* P, int64_t r0, int64_t R
   for (int i = L - 1; i >= 0; --i) {
     const DiscL& l = m.l[i];
     hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)R), dim3(256), 0, s, w.abar[i], w.u[i] + r0 * l.n(), w.st[i] + 2 * r0,
-                       P + l.gamma_off, P + l.beta_off, (const float*)nullptr, w.ubar[i], l.cout, l.hout);
+                       P + l.gamma_off, P + l.beta_off, (const float*)nullptr, (int64_t)0, w.ubar[i], l.cout, l.hout);
     conv_bwd_data(w.ubar[i], P + l.w_off, i == 0 ? w.g : w.abar[i - 1], R, l, s);
   }
 }
@@ -774,6 +796,8 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
   DWs w;
   carve(m, F, true, (float*)d_ws, &w);
   (void)hipMemsetAsync(Gd, 0, m.n_params * sizeof(float), s);
+  PartSums sums;
+  sums.count = 0;
   // pass 1
   hipLaunchKernelGGL(k_rows, grid1(F * m.H), dim3(256), 0, s, d_x, d_xh, d_t, w.rows, F, m.H);
   forward(m, P, B, w, s);
@@ -786,7 +810,7 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
     const DiscL& l = m.l[i];
     const float* src = i == 0 ? w.gt : w.at[i - 1];  // adjoint of abar_{i-1} (of g for the first layer)
     conv_fwd(src, kNoAct, P + l.w_off, nullptr, w.q[i], F, l, s);
-    conv_bwd_w(src, kNoAct, w.ubar[i], Gd + l.w_off, F, l, w.part, s);
+    conv_bwd_w(src, kNoAct, w.ubar[i], Gd + l.w_off, F, l, w.part[0][i], &sums, s);
     hipLaunchKernelGGL(k_ln_bwd_bwd, dim3((unsigned)F), dim3(256), 0, s, w.q[i], w.abar[i], w.u[i] + 2 * F * l.n(),
                        w.st[i] + 4 * F, P + l.gamma_off, P + l.beta_off, w.at[i], w.udir[i], w.pn, l.cout, l.hout);
     hipLaunchKernelGGL(k_chan_sum, dim3(l.cout), dim3(256), 0, s, w.pn, Gd + l.gamma_off, F, l.cout, l.hout);
@@ -802,14 +826,17 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
     const DiscL& l = m.l[i];
     hipLaunchKernelGGL(k_ln_param_grad, dim3(l.cout), dim3(256), 0, s, w.da, w.u[i], w.st[i], P + l.gamma_off,
                        P + l.beta_off, Gd + l.gamma_off, Gd + l.beta_off, B, l.cout, l.hout);
-    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)(2 * F)), dim3(256), 0, s, w.da, w.u[i], w.st[i], P + l.gamma_off,
-                       P + l.beta_off, (const float*)nullptr, w.du, l.cout, l.hout);
-    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)F), dim3(256), 0, s, w.da + 2 * F * l.n(), w.u[i] + 2 * F * l.n(),
-                       w.st[i] + 4 * F, P + l.gamma_off, P + l.beta_off, w.udir[i], w.du + 2 * F * l.n(), l.cout, l.hout);
+    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)B), dim3(256), 0, s, w.da, w.u[i], w.st[i], P + l.gamma_off,
+                       P + l.beta_off, w.udir[i], 2 * F, w.du, l.cout, l.hout);   // udir on the rows xi
     Act ai = i == 0 ? kNoAct : act_of(m.l[i - 1], P, w.st[i - 1]);
-    conv_bwd_w(i == 0 ? w.rows : w.u[i - 1], ai, w.du, Gd + l.w_off, B, l, w.part, s);
+    conv_bwd_w(i == 0 ? w.rows : w.u[i - 1], ai, w.du, Gd + l.w_off, B, l, w.part[1][i], &sums, s);
     hipLaunchKernelGGL(k_chan_sum, dim3(l.cout), dim3(256), 0, s, w.du, Gd + l.b_off, B, l.cout, l.hout);
     if (i > 0) conv_bwd_data(w.du, P + l.w_off, w.da, B, l, s);
+  }
+  if (sums.count > 0) {  // the weight-gradient copies of both passes, one launch
+    int nmax = 0;
+    for (int e = 0; e < sums.count; ++e) nmax = std::max(nmax, sums.e[e].n);
+    hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)std::min(256, (nmax + 255) / 256)), dim3(256), 0, s, sums, nmax);
   }
   return disc_check("disc_critic_fwd_bwd");
 }
