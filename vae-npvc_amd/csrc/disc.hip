@@ -353,6 +353,29 @@ __global__ void k_chan_sum(const float* __restrict__ d, float* __restrict__ db, 
   if (threadIdx.x == 0) db[o] += s;
 }
 
+// the same reduction for up to 2 * 8 + 1 (tensor, destination) pairs in one launch: blockIdx.y = pair, blockIdx.x = channel.
+// Destinations are distinct tensors (no two pairs share one).
+struct ChanSum {
+  const float* d;
+  float* db;
+  int64_t B;
+  int C, H;
+};
+struct ChanSums {
+  ChanSum e[2 * VAENPVC_MAX_LAYERS + 1];
+  int count;
+};
+__global__ void k_chan_sum_multi(ChanSums cs) {
+  __shared__ float sm[16];
+  const ChanSum p = cs.e[blockIdx.y];
+  const int o = blockIdx.x;
+  if (o >= p.C) return;   // (uniform per block)
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < p.B * p.H; i += blockDim.x) s += p.d[((i / p.H) * p.C + o) * p.H + (int)(i % p.H)];
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) p.db[o] += s;
+}
+
 // din[f,c,i] = sum_o sum_t W[t,c,o] dout[f,o,j], s*j - pad + t = i       (conv input gradient)
 // One workgroup per (frame, block of CB input channels): the frame's dout is staged in LDS, every item walks the
 // (at most ceil(k/s)) output positions that reach it and the contiguous cout weights of each.
@@ -584,9 +607,10 @@ struct DWs {  // resolved workspace of one call; B rows in the forward tensors, 
   float* q[VAENPVC_MAX_LAYERS];
   float* at[VAENPVC_MAX_LAYERS];
   float* udir[VAENPVC_MAX_LAYERS];
-  float* pn;
+  float* pn[VAENPVC_MAX_LAYERS];
   float *g, *gt, *gp_f;
-  float *da, *du;
+  float* da;
+  float* du[VAENPVC_MAX_LAYERS];
   float* part[2][VAENPVC_MAX_LAYERS];  // per-workgroup copies of a layer's weight gradient, per pass (3, 4)
 };
 int64_t al(int64_t n) { return (n + 63) & ~int64_t(63); }
@@ -621,11 +645,11 @@ int64_t carve(const vaenpvc_disc& m, int64_t F, bool critic, float* base, DWs* w
       t.at[i] = take(F * m.l[i].n());
       t.udir[i] = take(F * m.l[i].n());
     }
-    t.pn = take(F * nmax);
+    for (int i = 0; i < m.n_layers; ++i) t.pn[i] = take(F * m.l[i].n());
     t.gt = take(F * m.H);
     t.gp_f = take(F);
     t.da = take(B * nmax);
-    t.du = take(B * nmax);
+    for (int i = 0; i < m.n_layers; ++i) t.du[i] = take(B * m.l[i].n());
     for (int p = 0; p < 2; ++p)
       for (int i = 0; i < m.n_layers; ++i) {
         const int64_t nw = (int64_t)m.l[i].k * m.l[i].cin * m.l[i].cout;
@@ -798,6 +822,8 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
   (void)hipMemsetAsync(Gd, 0, m.n_params * sizeof(float), s);
   PartSums sums;
   sums.count = 0;
+  ChanSums csums;   // per-channel reductions of both passes, one launch at the end
+  csums.count = 0;
   // pass 1
   hipLaunchKernelGGL(k_rows, grid1(F * m.H), dim3(256), 0, s, d_x, d_xh, d_t, w.rows, F, m.H);
   forward(m, P, B, w, s);
@@ -812,10 +838,10 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
     conv_fwd(src, kNoAct, P + l.w_off, nullptr, w.q[i], F, l, s);
     conv_bwd_w(src, kNoAct, w.ubar[i], Gd + l.w_off, F, l, w.part[0][i], &sums, s);
     hipLaunchKernelGGL(k_ln_bwd_bwd, dim3((unsigned)F), dim3(256), 0, s, w.q[i], w.abar[i], w.u[i] + 2 * F * l.n(),
-                       w.st[i] + 4 * F, P + l.gamma_off, P + l.beta_off, w.at[i], w.udir[i], w.pn, l.cout, l.hout);
-    hipLaunchKernelGGL(k_chan_sum, dim3(l.cout), dim3(256), 0, s, w.pn, Gd + l.gamma_off, F, l.cout, l.hout);
+                       w.st[i] + 4 * F, P + l.gamma_off, P + l.beta_off, w.at[i], w.udir[i], w.pn[i], l.cout, l.hout);
+    csums.e[csums.count++] = ChanSum{w.pn[i], Gd + l.gamma_off, F, l.cout, l.hout};   // adjoint of gamma
   }
-  hipLaunchKernelGGL(k_chan_sum, dim3(m.flat), dim3(64), 0, s, w.at[L - 1], Gd + m.wd_off, F, m.flat, 1);  // abar_top = w
+  csums.e[csums.count++] = ChanSum{w.at[L - 1], Gd + m.wd_off, F, m.flat, 1};   // abar_top = w
   // pass 4, all rows: upstream -1/F (x), +1/F (xh), 0 (xi)
   const float cr = -1.0f / (float)F, cf = 1.0f / (float)F;
   const DiscL& last = m.l[L - 1];
@@ -827,11 +853,16 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
     hipLaunchKernelGGL(k_ln_param_grad, dim3(l.cout), dim3(256), 0, s, w.da, w.u[i], w.st[i], P + l.gamma_off,
                        P + l.beta_off, Gd + l.gamma_off, Gd + l.beta_off, B, l.cout, l.hout);
     hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)B), dim3(256), 0, s, w.da, w.u[i], w.st[i], P + l.gamma_off,
-                       P + l.beta_off, w.udir[i], 2 * F, w.du, l.cout, l.hout);   // udir on the rows xi
+                       P + l.beta_off, w.udir[i], 2 * F, w.du[i], l.cout, l.hout);   // udir on the rows xi
     Act ai = i == 0 ? kNoAct : act_of(m.l[i - 1], P, w.st[i - 1]);
-    conv_bwd_w(i == 0 ? w.rows : w.u[i - 1], ai, w.du, Gd + l.w_off, B, l, w.part[1][i], &sums, s);
-    hipLaunchKernelGGL(k_chan_sum, dim3(l.cout), dim3(256), 0, s, w.du, Gd + l.b_off, B, l.cout, l.hout);
-    if (i > 0) conv_bwd_data(w.du, P + l.w_off, w.da, B, l, s);
+    conv_bwd_w(i == 0 ? w.rows : w.u[i - 1], ai, w.du[i], Gd + l.w_off, B, l, w.part[1][i], &sums, s);
+    csums.e[csums.count++] = ChanSum{w.du[i], Gd + l.b_off, B, l.cout, l.hout};   // conv bias
+    if (i > 0) conv_bwd_data(w.du[i], P + l.w_off, w.da, B, l, s);
+  }
+  {
+    int cmax = 0;
+    for (int e = 0; e < csums.count; ++e) cmax = std::max(cmax, csums.e[e].C);
+    hipLaunchKernelGGL(k_chan_sum_multi, dim3((unsigned)cmax, (unsigned)csums.count), dim3(256), 0, s, csums);
   }
   if (sums.count > 0) {  // the weight-gradient copies of both passes, one launch
     int nmax = 0;
