@@ -64,6 +64,7 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
   for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sm[i];
   return r;
 }
+__device__ __forceinline__ int ch_of(int k, int hlast) { return k / hlast; }
 static inline dim3 grid1(int64_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 // ------------------------------------------------------------------------------------------- forward
@@ -85,12 +86,42 @@ __global__ void k_rows(const float* __restrict__ x, const float* __restrict__ xh
 // load latency with one wave per SIMD, so the channel loop is what is worth spreading).
 constexpr int FWD_OB = 8;
 __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ in, Act ai, const float* __restrict__ W,
-                                                  const float* __restrict__ b, float* __restrict__ out, G g) {
+                                                  const float* __restrict__ b, float* __restrict__ out, G g,
+                                                  float* __restrict__ st_new) {
   extern __shared__ float sIn[];  // [cin][hin], then [4 outputs][4 waves][64] partial sums
+  __shared__ float red[16];
   float* sPart = sIn + g.cin * g.hin;
   const int64_t f = blockIdx.x;
   const int o0 = blockIdx.y * FWD_OB, ob = min(FWD_OB, g.cout - o0);
-  for (int e = threadIdx.x; e < g.cin * g.hin; e += blockDim.x) sIn[e] = lnact(in[f * g.cin * g.hin + e], ai, f, e / g.hin);
+  const int nin = g.cin * g.hin;
+  if (st_new) {
+    // the LayerNorm statistics of the input tensor (the layer in front) are taken HERE, from the staged frame (every
+    // workgroup of the frame computes them, the first one stores them for the backward passes): no statistics kernel
+    float sm = 0.f;
+    for (int e = threadIdx.x; e < nin; e += blockDim.x) {
+      const float v = in[f * nin + e];
+      sIn[e] = v;
+      sm += v;
+    }
+    const float mean = block_sum(sm, red) / nin;
+    float q = 0.f;
+    for (int e = threadIdx.x; e < nin; e += blockDim.x) {
+      const float d = sIn[e] - mean;
+      q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(block_sum(q, red) / nin + LN_EPS);
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+      st_new[2 * f] = mean;
+      st_new[2 * f + 1] = rstd;
+    }
+    for (int e = threadIdx.x; e < nin; e += blockDim.x) {
+      const int c = e / g.hin;
+      const float n = (sIn[e] - mean) * rstd * ai.gamma[c] + ai.beta[c];
+      sIn[e] = fmaxf(n, LEAK * n);
+    }
+  } else {
+    for (int e = threadIdx.x; e < nin; e += blockDim.x) sIn[e] = lnact(in[f * nin + e], ai, f, e / g.hin);
+  }
   __syncthreads();
   const int cs = g.cin >= 4 ? 4 : 1;                      // channel split over the waves
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -169,51 +200,60 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ in, 
   }
 }
 
-// util/layers.py:32 : per-frame mean and biased variance over all C*H -> (mean, rstd)
-__global__ void k_ln_stats(const float* __restrict__ a, float* __restrict__ st, int n) {
-  __shared__ float sm[16];
-  int64_t f = blockIdx.x;
-  const float* p = a + f * n;
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) s += p[i];
-  float mean = block_sum(s, sm) / n;
-  float q = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    float d = p[i] - mean;
-    q += d * d;
-  }
-  float var = block_sum(q, sm) / n;
-  if (threadIdx.x == 0) {
-    st[2 * f] = mean;
-    st[2 * f + 1] = 1.0f / sqrtf(var + LN_EPS);
-  }
-}
-
 // d[f] = c + sum_k act(u)[f,k] w[k]     (flatten is C-major = memory order)
 __global__ void k_dense_fwd(const float* __restrict__ u, Act ai, int hlast, const float* __restrict__ w,
-                            const float* __restrict__ c, float* __restrict__ d, int flat) {
+                            const float* __restrict__ c, float* __restrict__ d, int flat, float* __restrict__ st_new) {
   __shared__ float sm[16];
   int64_t f = blockIdx.x;
+  float mean = 0.f, rstd = 0.f;
+  if (st_new) {   // statistics of the last conv layer, taken here (see k_conv_fwd)
+    float a = 0.f;
+    for (int k = threadIdx.x; k < flat; k += blockDim.x) a += u[f * flat + k];
+    mean = block_sum(a, sm) / flat;
+    float q = 0.f;
+    for (int k = threadIdx.x; k < flat; k += blockDim.x) {
+      const float dv = u[f * flat + k] - mean;
+      q += dv * dv;
+    }
+    rstd = 1.0f / sqrtf(block_sum(q, sm) / flat + LN_EPS);
+    if (threadIdx.x == 0) {
+      st_new[2 * f] = mean;
+      st_new[2 * f + 1] = rstd;
+    }
+  }
   float s = 0.f;
-  for (int k = threadIdx.x; k < flat; k += blockDim.x) s += lnact(u[f * flat + k], ai, f, k / hlast) * w[k];
+  for (int k = threadIdx.x; k < flat; k += blockDim.x) {
+    float v;
+    if (st_new) {
+      const int ch = k / hlast;
+      const float n = (u[f * flat + k] - mean) * rstd * ai.gamma[ch] + ai.beta[ch];
+      v = fmaxf(n, LEAK * n);
+    } else {
+      v = lnact(u[f * flat + k], ai, f, ch_of(k, hlast));
+    }
+    s += v * w[k];
+  }
   s = block_sum(s, sm);
   if (threadIdx.x == 0) d[f] = s + c[0];
 }
 
 // ------------------------------------------------------------------------------------------ backward
-// upstream of the dense unit: da[f,k] = coef(f) w[k]; rows [0,F0) get c0, [F0,2F0) c1, the rest c2
-__global__ void k_dense_bwd_data(const float* __restrict__ w, float* __restrict__ da, int64_t B, int flat, int64_t F0,
-                                 float c0, float c1, float c2) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * flat) return;
-  int64_t f = idx / flat;
-  float c = f < F0 ? c0 : (f < 2 * F0 ? c1 : c2);
-  da[idx] = c * w[idx % flat];
-}
-// dw[k] += sum_f coef(f) act(u)[f,k] ; db += sum_f coef(f)      (one thread per k; thread `flat` does the bias)
-__global__ void k_dense_bwd_w(const float* __restrict__ u, Act ai, int hlast, float* __restrict__ dw,
-                              float* __restrict__ dc, int64_t B, int flat, int64_t F0, float c0, float c1, float c2) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
+// dense unit backward, one launch.  coef(f): rows [0,F0) get c0, [F0,2F0) c1, the rest c2.
+//   blocks [0, nb_d)  : upstream of the last conv layer   da[f,k] = coef(f) w[k]
+//   blocks [nb_d, ..) : dw[k] += sum_f coef(f) act(u)[f,k] ; dc += sum_f coef(f)   (one thread per k; thread `flat` does the
+//                       bias); skipped when dw == nullptr
+__global__ void k_dense_bwd(const float* __restrict__ w, float* __restrict__ da, const float* __restrict__ u, Act ai, int hlast,
+                            float* __restrict__ dw, float* __restrict__ dc, int64_t B, int flat, int64_t F0, float c0, float c1,
+                            float c2, int nb_d) {
+  if ((int)blockIdx.x < nb_d) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * flat) return;
+    int64_t f = idx / flat;
+    float c = f < F0 ? c0 : (f < 2 * F0 ? c1 : c2);
+    da[idx] = c * w[idx % flat];
+    return;
+  }
+  int k = ((int)blockIdx.x - nb_d) * blockDim.x + threadIdx.x;
   if (k > flat) return;
   float s = 0.f;
   for (int64_t f = 0; f < B; ++f) {
@@ -317,29 +357,38 @@ __global__ void k_ln_bwd_bwd(const float* __restrict__ q, const float* __restric
   }
 }
 
-// dgamma[c] += sum_{f,h} dn xhat ; dbeta[c] += sum_{f,h} dn ; one block per channel
-__global__ void k_ln_param_grad(const float* __restrict__ dy, const float* __restrict__ u,
-                                const float* __restrict__ st, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, float* __restrict__ dgamma,
-                                float* __restrict__ dbeta, int64_t B, int C, int H) {
+// dgamma[c] += sum_{f,h} dn xhat ; dbeta[c] += sum_{f,h} dn ; one block per (layer, channel): blockIdx.y = layer entry
+struct ParamGrad {
+  const float *dy, *u, *st, *gamma, *beta;
+  float *dgamma, *dbeta;
+  int64_t B;
+  int C, H;
+};
+struct ParamGrads {
+  ParamGrad e[VAENPVC_MAX_LAYERS];
+  int count;
+};
+__global__ void k_ln_param_grad(ParamGrads pg) {
   __shared__ float sm[16];
-  int c = blockIdx.x;
-  float g = gamma[c], b = beta[c];
+  const ParamGrad p = pg.e[blockIdx.y];
+  const int c = blockIdx.x;
+  if (c >= p.C) return;   // (uniform per block)
+  float g = p.gamma[c], b = p.beta[c];
   float sg = 0.f, sb = 0.f;
-  for (int64_t i = threadIdx.x; i < B * H; i += blockDim.x) {
-    int64_t f = i / H;
-    int64_t e = (f * C + c) * H + (int)(i % H);
-    float xh = (u[e] - st[2 * f]) * st[2 * f + 1];
+  for (int64_t i = threadIdx.x; i < p.B * p.H; i += blockDim.x) {
+    int64_t f = i / p.H;
+    int64_t e = (f * p.C + c) * p.H + (int)(i % p.H);
+    float xh = (p.u[e] - p.st[2 * f]) * p.st[2 * f + 1];
     float nn = xh * g + b;
-    float dn = dy[e] * (nn >= 0.f ? 1.0f : LEAK);
+    float dn = p.dy[e] * (nn >= 0.f ? 1.0f : LEAK);
     sg += dn * xh;
     sb += dn;
   }
   sg = block_sum(sg, sm);
   sb = block_sum(sb, sm);
   if (threadIdx.x == 0) {
-    dgamma[c] += sg;
-    dbeta[c] += sb;
+    p.dgamma[c] += sg;
+    p.dbeta[c] += sb;
   }
 }
 
@@ -570,9 +619,11 @@ static G mk(const DiscL& l) { return G{l.cin, l.hin, l.cout, l.hout, l.k, l.s, l
 static Act act_of(const DiscL& l, const float* P, const float* st) { return Act{st, P + l.gamma_off, P + l.beta_off}; }
 
 namespace {
-void conv_fwd(const float* in, Act ai, const float* W, const float* b, float* out, int64_t B, const DiscL& l, hipStream_t s) {
+// st_new != nullptr: the statistics `ai` would read do not exist yet -- the kernel takes them from the staged input and stores them there
+void conv_fwd(const float* in, Act ai, const float* W, const float* b, float* out, int64_t B, const DiscL& l, hipStream_t s,
+              float* st_new = nullptr) {
   hipLaunchKernelGGL(k_conv_fwd, dim3((unsigned)B, (unsigned)((l.cout + FWD_OB - 1) / FWD_OB)), dim3(256),
-                     ((size_t)l.cin * l.hin + 1024) * sizeof(float), s, in, ai, W, b, out, mk(l));
+                     ((size_t)l.cin * l.hin + 1024) * sizeof(float), s, in, ai, W, b, out, mk(l), st_new);
 }
 void conv_bwd_data(const float* dout, const float* W, float* din, int64_t B, const DiscL& l, hipStream_t s) {
   hipLaunchKernelGGL(k_conv_bwd_data, dim3((unsigned)B, (unsigned)((l.cin + BWD_CB - 1) / BWD_CB)), dim3(256),
@@ -609,7 +660,7 @@ struct DWs {  // resolved workspace of one call; B rows in the forward tensors, 
   float* udir[VAENPVC_MAX_LAYERS];
   float* pn[VAENPVC_MAX_LAYERS];
   float *g, *gt, *gp_f;
-  float* da;
+  float* da[VAENPVC_MAX_LAYERS];   // gradient at the activations of layer i (pass 4)
   float* du[VAENPVC_MAX_LAYERS];
   float* part[2][VAENPVC_MAX_LAYERS];  // per-workgroup copies of a layer's weight gradient, per pass (3, 4)
 };
@@ -648,7 +699,7 @@ int64_t carve(const vaenpvc_disc& m, int64_t F, bool critic, float* base, DWs* w
     for (int i = 0; i < m.n_layers; ++i) t.pn[i] = take(F * m.l[i].n());
     t.gt = take(F * m.H);
     t.gp_f = take(F);
-    t.da = take(B * nmax);
+    for (int i = 0; i < m.n_layers; ++i) t.da[i] = take(B * m.l[i].n());
     for (int i = 0; i < m.n_layers; ++i) t.du[i] = take(B * m.l[i].n());
     for (int p = 0; p < 2; ++p)
       for (int i = 0; i < m.n_layers; ++i) {
@@ -664,19 +715,22 @@ void forward(const vaenpvc_disc& m, const float* P, int64_t B, const DWs& w, hip
   for (int i = 0; i < m.n_layers; ++i) {
     const DiscL& l = m.l[i];
     Act ai = i == 0 ? kNoAct : act_of(m.l[i - 1], P, w.st[i - 1]);
-    conv_fwd(i == 0 ? w.rows : w.u[i - 1], ai, P + l.w_off, P + l.b_off, w.u[i], B, l, s);
-    hipLaunchKernelGGL(k_ln_stats, dim3((unsigned)B), dim3(256), 0, s, w.u[i], w.st[i], l.n());
+    conv_fwd(i == 0 ? w.rows : w.u[i - 1], ai, P + l.w_off, P + l.b_off, w.u[i], B, l, s, i == 0 ? nullptr : w.st[i - 1]);
   }
   const DiscL& last = m.l[m.n_layers - 1];
   hipLaunchKernelGGL(k_dense_fwd, dim3((unsigned)B), dim3(256), 0, s, w.u[m.n_layers - 1],
-                     act_of(last, P, w.st[m.n_layers - 1]), last.hout, P + m.wd_off, P + m.bd_off, w.d, m.flat);
+                     act_of(last, P, w.st[m.n_layers - 1]), last.hout, P + m.wd_off, P + m.bd_off, w.d, m.flat,
+                     w.st[m.n_layers - 1]);
 }
 
 // pass 2: g = d(sum_f d_f)/d(rows) for R rows starting at row r0; keeps abar_l / ubar_l
 void input_gradient(const vaenpvc_disc& m, const float* P, int64_t r0, int64_t R, const DWs& w, hipStream_t s) {
   const int L = m.n_layers;
-  hipLaunchKernelGGL(k_dense_bwd_data, grid1(R * m.flat), dim3(256), 0, s, P + m.wd_off, w.abar[L - 1], R, m.flat, R, 1.0f,
-                     1.0f, 1.0f);
+  {
+    const int nb_d = (int)((R * m.flat + 255) / 256);
+    hipLaunchKernelGGL(k_dense_bwd, dim3((unsigned)nb_d), dim3(256), 0, s, P + m.wd_off, w.abar[L - 1], (const float*)nullptr, kNoAct,
+                       1, (float*)nullptr, (float*)nullptr, R, m.flat, R, 1.0f, 1.0f, 1.0f, nb_d);
+  }
   for (int i = L - 1; i >= 0; --i) {
     const DiscL& l = m.l[i];
     hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)R), dim3(256), 0, s, w.abar[i], w.u[i] + r0 * l.n(), w.st[i] + 2 * r0,
@@ -845,19 +899,28 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
   // pass 4, all rows: upstream -1/F (x), +1/F (xh), 0 (xi)
   const float cr = -1.0f / (float)F, cf = 1.0f / (float)F;
   const DiscL& last = m.l[L - 1];
-  hipLaunchKernelGGL(k_dense_bwd_w, grid1(m.flat + 1), dim3(256), 0, s, w.u[L - 1], act_of(last, P, w.st[L - 1]), last.hout,
-                     Gd + m.wd_off, Gd + m.bd_off, B, m.flat, F, cr, cf, 0.0f);
-  hipLaunchKernelGGL(k_dense_bwd_data, grid1(B * m.flat), dim3(256), 0, s, P + m.wd_off, w.da, B, m.flat, F, cr, cf, 0.0f);
+  {
+    const int nb_d = (int)((B * m.flat + 255) / 256), nb_w = (m.flat + 1 + 255) / 256;
+    hipLaunchKernelGGL(k_dense_bwd, dim3((unsigned)(nb_d + nb_w)), dim3(256), 0, s, P + m.wd_off, w.da[L - 1], w.u[L - 1],
+                       act_of(last, P, w.st[L - 1]), last.hout, Gd + m.wd_off, Gd + m.bd_off, B, m.flat, F, cr, cf, 0.0f, nb_d);
+  }
+  ParamGrads pgs;   // LayerNorm parameter gradients of all layers: one launch at the end
+  pgs.count = 0;
   for (int i = L - 1; i >= 0; --i) {
     const DiscL& l = m.l[i];
-    hipLaunchKernelGGL(k_ln_param_grad, dim3(l.cout), dim3(256), 0, s, w.da, w.u[i], w.st[i], P + l.gamma_off,
-                       P + l.beta_off, Gd + l.gamma_off, Gd + l.beta_off, B, l.cout, l.hout);
-    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)B), dim3(256), 0, s, w.da, w.u[i], w.st[i], P + l.gamma_off,
+    pgs.e[pgs.count++] = ParamGrad{w.da[i], w.u[i], w.st[i], P + l.gamma_off, P + l.beta_off, Gd + l.gamma_off, Gd + l.beta_off, B,
+                                   l.cout, l.hout};
+    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)B), dim3(256), 0, s, w.da[i], w.u[i], w.st[i], P + l.gamma_off,
                        P + l.beta_off, w.udir[i], 2 * F, w.du[i], l.cout, l.hout);   // udir on the rows xi
     Act ai = i == 0 ? kNoAct : act_of(m.l[i - 1], P, w.st[i - 1]);
     conv_bwd_w(i == 0 ? w.rows : w.u[i - 1], ai, w.du[i], Gd + l.w_off, B, l, w.part[1][i], &sums, s);
     csums.e[csums.count++] = ChanSum{w.du[i], Gd + l.b_off, B, l.cout, l.hout};   // conv bias
-    if (i > 0) conv_bwd_data(w.du[i], P + l.w_off, w.da, B, l, s);
+    if (i > 0) conv_bwd_data(w.du[i], P + l.w_off, w.da[i - 1], B, l, s);
+  }
+  {
+    int cmax = 0;
+    for (int e = 0; e < pgs.count; ++e) cmax = std::max(cmax, pgs.e[e].C);
+    hipLaunchKernelGGL(k_ln_param_grad, dim3((unsigned)cmax, (unsigned)pgs.count), dim3(256), 0, s, pgs);
   }
   {
     int cmax = 0;
