@@ -3,10 +3,14 @@
 // in the reference; the model is specified in DESIGN.md section 9 (the reference tree does not hold it).
 //
 // The branch trains 16-frame batches (architecture-vawgan-vcc2016.json:33), 48 frames through three small
-// convolutions: launch-bound, so the kernels here are one-thread-per-output with sequential inner loops
-// (deterministic: no atomics; every gradient tensor is accumulated by exactly one thread per element, pass
-// after pass on one stream).  Conventions follow generic_kernels.hip: frames-major [B, C, H] float32, the
-// PRE-LN conv output `u` plus per-frame (mean, rstd) is what is kept, consumers apply lrelu(LN(u)) on load.
+// convolutions.  At that size the device time of a step is (number of kernels) x ~6.5 us plus what the three conv
+// kernels take, so: one thread per output with a frame's layer input / output staged in LDS, lanes along the
+// contiguous weight dimension, several loads in flight per thread (one wave per SIMD: latency-bound loops); the
+// LayerNorm statistics are taken by the consumer while it stages the frame; every per-channel reduction, every
+// LayerNorm parameter gradient and every sum of weight-gradient copies of a step runs in ONE launch at the end.
+// Deterministic: no atomics, every gradient element is accumulated by exactly one thread, pass after pass on one
+// stream.  Conventions follow generic_kernels.hip: frames-major [B, C, H] float32, the PRE-LN conv output `u` plus
+// per-frame (mean, rstd) is what is kept, consumers apply lrelu(LN(u)) on load.
 //
 // Critic step for F frames, B = 3F rows (x | xh | xi = x + t (xh - x)):
 //   pass 1  forward of all rows                                  -> d[B]
@@ -392,17 +396,8 @@ __global__ void k_ln_param_grad(ParamGrads pg) {
   }
 }
 
-// db[o] += sum_{f,h} d[f,o,h] ; one block per channel
-__global__ void k_chan_sum(const float* __restrict__ d, float* __restrict__ db, int64_t B, int C, int H) {
-  __shared__ float sm[16];
-  int o = blockIdx.x;
-  float s = 0.f;
-  for (int64_t i = threadIdx.x; i < B * H; i += blockDim.x) s += d[((i / H) * C + o) * H + (int)(i % H)];
-  s = block_sum(s, sm);
-  if (threadIdx.x == 0) db[o] += s;
-}
-
-// the same reduction for up to 2 * 8 + 1 (tensor, destination) pairs in one launch: blockIdx.y = pair, blockIdx.x = channel.
+// db[o] += sum_{f,h} d[f,o,h], one block per channel,
+// for up to 2 * 8 + 1 (tensor, destination) pairs in one launch: blockIdx.y = pair, blockIdx.x = channel.
 // Destinations are distinct tensors (no two pairs share one).
 struct ChanSum {
   const float* d;
@@ -675,8 +670,6 @@ int64_t carve(const vaenpvc_disc& m, int64_t F, bool critic, float* base, DWs* w
     return p;
   };
   const int64_t B = (critic ? 3 : 2) * F;
-  int nmax = m.H;
-  for (int i = 0; i < m.n_layers; ++i) nmax = std::max(nmax, m.l[i].n());
   DWs t;
   memset(&t, 0, sizeof t);
   t.rows = take(B * m.H);
