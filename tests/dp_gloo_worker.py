@@ -173,6 +173,60 @@ def run_adv(rank, world, F, iters, out):
         np.save(out, np.concatenate([(torch.cat([be.params, cr.params]) - p0).numpy(), tail]))
 
 
+def run_adv_trainer(rank, world, F, iters, out):
+    """VAWGANTrainer.train under N ranks on the stand-ins: nIterD + 1 batches per iteration, rank-dependent status
+    intervals, status line format, checkpoint name, restore + continue == uninterrupted run (both parameter sets, the Adam
+    slots and the shared apply counter travel in the checkpoint)."""
+    import types
+    from adv_standin import SMALL_VAWGAN, EngineStandIn, CriticStandIn
+    from trainer.vae import VAWGANTrainer
+    from model.vae import LossDict
+
+    class Source(object):
+        def __init__(self):
+            self.t = 0
+
+        def next_batch(self):
+            x, y, _ = O.make_inputs(SMALL_VAWGAN, F, 80 + self.t)
+            self.t += 1
+            lo, hi = (rank * F // world, (rank + 1) * F // world)
+            return torch.tensor(x[lo:hi]), torch.tensor(y[lo:hi])
+
+    def make(seed_e, seed_c, max_iter, logdir, restore_from=None, t0=0):
+        be, cr = EngineStandIn(SMALL_VAWGAN, seed_e), CriticStandIn(SMALL_VAWGAN, seed_c)
+        loss = LossDict()
+        loss.machine = types.SimpleNamespace(engine=be, critic=cr)
+        loss.source = Source()
+        loss.source.t = t0
+        arch = dict(SMALL_VAWGAN)
+        arch['training'] = dict(SMALL_VAWGAN['training'], max_iter=max_iter, lr=1e-3)
+        args = types.SimpleNamespace(seed=0, restore_from=restore_from, ckpt=None)
+        tr = VAWGANTrainer(loss, arch, args, {'logdir': logdir, 'logdir_root': logdir, 'restore_from': restore_from or logdir})
+        return tr, be, cr, loss
+    n_d = SMALL_VAWGAN['training']['nIterD']
+    logdir = out + '.logdir'
+    tr, be, cr, loss = make(10 + rank, 20 + rank, iters, logdir)     # different init per rank: the broadcast fixes it
+    ck = tr.train(iters, status_secs=0 if rank % 2 else 1e9, save_secs=1e9)
+    st = tr.opt['g']
+    assert loss.source.t == iters * (n_d + 1) and st.step_count == iters and st.applies == iters * (n_d + 2)
+    if rank == 0:
+        assert os.path.basename(ck) == 'model.ckpt-%d' % iters
+        msgs = open(os.path.join(logdir, 'training.log')).read().strip().splitlines()
+        assert msgs and msgs[-1].startswith('Iter %05d: W_dist = ' % iters) and ' GP = ' in msgs[-1]
+    if world > 1:
+        dist.barrier()
+    # restore into differently initialised stand-ins and continue one iteration == the uninterrupted run
+    tr2, be2, cr2, loss2 = make(98, 99, iters + 1, logdir + '2', restore_from=logdir, t0=iters * (n_d + 1))
+    tr2.train(iters + 1, status_secs=1e9, save_secs=1e9)
+    assert tr2.opt['g'].step_count == iters + 1 and tr2.opt['g'].applies == (iters + 1) * (n_d + 2)
+    tr.arch['training']['max_iter'] = iters + 1
+    tr.train(iters + 1, status_secs=1e9, save_secs=1e9)
+    assert np.abs(be.params.numpy() - be2.params.numpy()).max() < 1e-12
+    assert np.abs(cr.params.numpy() - cr2.params.numpy()).max() < 1e-12
+    if rank == 0:
+        np.save(out, np.concatenate([be.params.numpy(), cr.params.numpy()]))
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
     rank, world, port, F, steps, out = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]),
@@ -187,6 +241,8 @@ if __name__ == '__main__':
         run_trainer(rank, world, F, steps, out)
     elif mode == 'adv':
         run_adv(rank, world, F, steps, out)
+    elif mode == 'adv_trainer':
+        run_adv_trainer(rank, world, F, steps, out)
     else:
         run(rank, world, F, steps, out, mode)
     if world > 1:

@@ -170,3 +170,21 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path):
     move = np.abs(res[1][:-4]).max()
     assert np.abs(res[2][:-4] - res[1][:-4]).max() < 1e-6 * move
     assert np.allclose(res[2][-4:], res[1][-4:], rtol=1e-8)      # D_KL, logP, W_dist, gp: means over ranks == global
+
+
+@pytest.mark.parametrize('world', [1, 2])
+def test_vawgan_trainer_loop_schedule_status_and_restore(tmp_path, world):
+    """VAWGANTrainer.train on the stand-ins (tests/dp_gloo_worker.py:run_adv_trainer): batches consumed per iteration,
+    status line, checkpoint, restore-and-continue; with two ranks the status path must not issue collectives of its own."""
+    port = 33000 + os.getpid() % 2000 + world
+    out = str(tmp_path / 'advt.npy')
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), '8', '2', out, 'adv_trainer'])
+             for r in range(world)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert os.path.exists(out)

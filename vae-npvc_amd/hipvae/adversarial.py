@@ -158,7 +158,7 @@ class AdvStepper(object):
     def state_dict(self):
         return {'params': self.backend.params.detach().cpu(), 'm': self.m.cpu(), 'v': self.v.cpu(),
                 'd_params': self.critic.params.detach().cpu(), 'd_m': self.m_d.cpu(), 'd_v': self.v_d.cpu(),
-                'step': self.step_count, 'applies': self.applies}
+                'step': self.step_count, 'applies': self.applies, 'draws': self._draws}
 
     def load_state_dict(self, sd):
         dev = self.backend.params.device
@@ -169,3 +169,4 @@ class AdvStepper(object):
         self.m_d.copy_(sd['d_m'].to(dev))
         self.v_d.copy_(sd['d_v'].to(dev))
         self.step_count, self.applies = int(sd['step']), int(sd['applies'])
+        self._draws = int(sd.get('draws', 0))       # the sampler / interpolation streams continue where they stopped
