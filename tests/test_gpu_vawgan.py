@@ -71,6 +71,54 @@ def test_critic_step_matches_autograd_oracle(F):
     assert max(worst.values()) < TOL_GRAD, worst
 
 
+def test_critic_and_generator_steps_against_the_golden_fixture():
+    """The committed fixture tests/golden/vawgan_F4_seed21.npz (float64 oracle outputs; inputs regenerated from seeds)."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import make_golden_vawgan as M
+    from helpers import sample_idx
+    from hipvae.engine import Engine
+    from hipvae.adversarial import AdvStepper
+    gold = np.load(os.path.join(ROOT, 'tests', 'golden', 'vawgan_F4_seed21.npz'))
+    arch = vawgan_arch()
+    x, y, eps, xh, u = M.inputs(arch)
+    P = O.init_params(arch, M.SEED_P)
+    cr, D = make_critic(arch, M.SEED_D)
+    dev = cr.device
+    tt = lambda a, dt=torch.float32: torch.tensor(np.asarray(a), dtype=dt, device=dev)
+    grads = torch.empty(cr.n_params, device=dev)
+    l2 = cr.critic_fwd_bwd(tt(x), tt(xh), tt(u), M.LAM, grads).cpu().numpy()
+    assert abs(l2[0] - gold['critic_losses'][0]) < TOL_VALUE * max(1, abs(gold['critic_losses'][0]))
+    assert abs(l2[1] - gold['critic_losses'][1]) < 2e-4 * max(1, gold['critic_losses'][1])
+    got = cr.param_views(grads.cpu())
+    for i, k in enumerate(cr.layout):
+        g = got[k].numpy().astype(np.float64).ravel()
+        amax = gold['critic_grad_absmax'][i]
+        if amax < 1e-12:
+            assert np.abs(g).max() < 1e-6, k          # the dense bias: identically zero
+            continue
+        assert abs(np.sqrt((g ** 2).sum()) / gold['critic_grad_l2'][i] - 1) < TOL_GRAD, k
+        idx = sample_idx(g.size)
+        assert np.abs(g[idx] - gold['critic_grad_samples'][i][:len(idx)]).max() < TOL_GRAD * amax, k
+        key = 'critic_grad_' + k.replace('/', '__')
+        if key in gold.files:
+            assert np.abs(g - gold[key].ravel()).max() < TOL_GRAD * amax, k
+    eng = Engine(arch, precision='bf16x3')
+    eng.load_flat(O.flatten_params(P))
+    st = AdvStepper(eng, cr, 1e-4, 0.5, 0.999, M.ALPHA, M.LAM)
+    out = st.generator_step(tt(x), tt(y, torch.int64), tt(eps))
+    gl = gold['gen_losses']
+    assert abs(float(out['D_KL']) / gl[0] - 1) < 1e-4 and abs(float(out['logP']) / gl[1] - 1) < 1e-4
+    assert abs(float(out['W_dist']) - gl[2]) < TOL_VALUE * max(1, abs(gl[2]))
+    ge, gg = eng.param_views(st.g_e.cpu()), eng.param_views(st.g_g.cpu())
+    for i, k in enumerate(eng.layout):
+        g = (ge if 'Encoder' in k else gg)[k].numpy().astype(np.float64).ravel()
+        amax = gold['gen_grad_absmax'][i]
+        assert abs(np.sqrt((g ** 2).sum()) / gold['gen_grad_l2'][i] - 1) < TOL_GRAD, k
+        idx = sample_idx(g.size)
+        assert np.abs(g[idx] - gold['gen_grad_samples'][i][:len(idx)]).max() < TOL_GRAD * amax, k
+
+
 def test_critic_step_on_a_generic_geometry():
     """A shrunk critic (54 bins, kernels 5 / 4, 3 and 4 channels: channel counts that divide nothing, even kernel with
     asymmetric SAME padding) through the same kernels."""

@@ -188,3 +188,15 @@ def test_vawgan_trainer_loop_schedule_status_and_restore(tmp_path, world):
             if p.poll() is None:
                 p.kill()
     assert os.path.exists(out)
+
+
+def test_golden_fixture_reproduced_by_the_oracle():
+    """tests/golden/vawgan_F4_seed21.npz (made by tests/golden/make_golden_vawgan.py) pins the specification against
+    accidental changes of the oracle; the GPU suite compares the HIP path with the same file."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_golden_vawgan as M
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'vawgan_F4_seed21.npz'))
+    now = M.run()
+    assert set(now.keys()) == set(gold.files)
+    for k in gold.files:
+        assert np.allclose(now[k], gold[k], rtol=1e-9, atol=1e-12), k
