@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -555,6 +556,133 @@ __global__ void k_sum_parts(PartSums ps, int nmax) {
   }
 }
 
+// ---------------------------------------------------------------------------------- dense-like layers
+// A conv layer whose every output position sees the whole input (k >= 2 hin - 1 taps around it: the critic's 115-tap
+// layer on 57 positions) IS a dense layer [cin hin] -> [cout hout] with the weight matrix
+//     Wd[(c, i)][(o, j)] = W[i - s j + pad][c][o]
+// expanded once per call (k_expand_dense).  Forward, input gradient and weight gradient are then plain GEMMs on the fp32
+// matrix cores (v_mfma_f32_32x32x2_f32: exact fp32; operand maps A: lane l holds A[i = l & 31][k = l >> 5], B: lane l
+// holds B[k = l >> 5][j = l & 31], C: 16 registers, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5), column = l & 31);
+// the weight gradient is computed against Wd and folded back over the positions (k_fold_dense).  The reduction
+// dimension is dealt to several workgroups (blockIdx.z) writing private results that k_mm_reduce adds in order.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct MmArgs {
+  const float* A;     // A(m, r) = A[m * a_m + r * a_r]
+  int64_t a_m, a_r;
+  const float* B;     // B(r, n) = B[r * b_r + n * b_n]
+  int64_t b_r, b_n;
+  float* C;           // split z writes the row-major [M][N] matrix at C + z * M * N
+  int M, N, R, rper;  // rper: reduction elements per split (a multiple of 32)
+};
+// 64 x 64 tile per workgroup, four waves of 32 x 32, reduction chunks of 32 staged through LDS (pitches 33 / 65: odd).
+// A_FAST_R / B_FAST_N: which index is contiguous in memory -- the staging lanes run along it.
+template <bool A_FAST_R, bool B_FAST_N>
+__global__ void __launch_bounds__(256) k_mm(MmArgs a) {
+  __shared__ float sA[64 * 33];
+  __shared__ float sB[32 * 65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int r_lo = blockIdx.z * a.rper, r_hi = min(a.R, r_lo + a.rper);
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int rc = r_lo; rc < r_hi; rc += 32) {
+    float va[8], vb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = tid + 256 * q;
+      const int ma = A_FAST_R ? e >> 5 : e & 63, ka = A_FAST_R ? e & 31 : e >> 6;
+      const int gm = m0 + ma, gra = rc + ka;
+      va[q] = (gm < a.M && gra < r_hi) ? a.A[gm * a.a_m + gra * a.a_r] : 0.f;
+      const int nb = B_FAST_N ? e & 63 : e >> 5, kb = B_FAST_N ? e >> 6 : e & 31;
+      const int gn = n0 + nb, grb = rc + kb;
+      vb[q] = (gn < a.N && grb < r_hi) ? a.B[grb * a.b_r + gn * a.b_n] : 0.f;
+    }
+    __syncthreads();   // the previous chunk is consumed
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = tid + 256 * q;
+      const int ma = A_FAST_R ? e >> 5 : e & 63, ka = A_FAST_R ? e & 31 : e >> 6;
+      sA[ma * 33 + ka] = va[q];
+      const int nb = B_FAST_N ? e & 63 : e >> 5, kb = B_FAST_N ? e >> 6 : e & 31;
+      sB[kb * 65 + nb] = vb[q];
+    }
+    __syncthreads();
+    const float* pa = sA + (wm * 32 + l31) * 33 + lh;
+    const float* pb = sB + lh * 65 + wn * 32 + l31;
+#pragma unroll
+    for (int st = 0; st < 16; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * st], pb[2 * st * 65], acc, 0, 0, 0);
+  }
+  float* C = a.C + (int64_t)blockIdx.z * a.M * a.N;
+  const int col = n0 + wn * 32 + l31;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+    if (row < a.M && col < a.N) C[(int64_t)row * a.N + col] = acc[reg];
+  }
+}
+// out[i] = sum_z part[z][i] (+ bias[(i % N) / hdiv]), z ascending
+__global__ void k_mm_reduce(const float* __restrict__ part, int nz, int64_t mn, float* __restrict__ out,
+                            const float* __restrict__ bias, int N, int hdiv) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= mn) return;
+  float s = 0.f;
+  for (int z = 0; z < nz; ++z) s += part[z * mn + i];
+  if (bias) s += bias[(int)(i % N) / hdiv];
+  out[i] = s;
+}
+// Wd[(c, i)][(o, j)] = W[i - s j + pad][c][o]  (zero where the tap index leaves the kernel)
+__global__ void k_expand_dense(const float* __restrict__ W, float* __restrict__ Wd, G g) {
+  const int N = g.cout * g.hout;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)g.cin * g.hin * N) return;
+  const int n = (int)(idx % N), kk = (int)(idx / N);
+  const int o = n / g.hout, j = n - o * g.hout, c = kk / g.hin, i = kk - c * g.hin;
+  const int t = i - g.s * j + g.pad;
+  Wd[idx] = (t >= 0 && t < g.k) ? W[((int64_t)t * g.cin + c) * g.cout + o] : 0.f;
+}
+// dW[t][c][o] += sum_j dWd[(c, t + s j - pad)][(o, j)]
+__global__ void k_fold_dense(const float* __restrict__ dWd, float* __restrict__ dW, G g) {
+  const int N = g.cout * g.hout;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)g.k * g.cin * g.cout) return;
+  const int o = (int)(idx % g.cout), c = (int)((idx / g.cout) % g.cin), t = (int)(idx / ((int64_t)g.cout * g.cin));
+  float s = 0.f;
+  for (int j = 0; j < g.hout; ++j) {
+    const int i = t + g.s * j - g.pad;
+    if (i >= 0 && i < g.hin) s += dWd[((int64_t)c * g.hin + i) * N + o * g.hout + j];
+  }
+  dW[idx] += s;
+}
+// LayerNorm statistics of u (one block per frame, stored) and its activated copy a = lrelu(LN(u)): the A operand of a
+// dense-like layer's GEMMs
+__global__ void k_act_stats(const float* __restrict__ u, const float* __restrict__ gamma, const float* __restrict__ beta,
+                            float* __restrict__ st, float* __restrict__ aout, int C, int H) {
+  __shared__ float sm[16];
+  const int64_t f = blockIdx.x;
+  const int n = C * H;
+  const float* p = u + f * n;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += p[i];
+  const float mean = block_sum(s, sm) / n;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float d = p[i] - mean;
+    q += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(block_sum(q, sm) / n + LN_EPS);
+  if (threadIdx.x == 0) {
+    st[2 * f] = mean;
+    st[2 * f + 1] = rstd;
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int c = i / H;
+    const float v = (p[i] - mean) * rstd * gamma[c] + beta[c];
+    aout[f * n + i] = fmaxf(v, LEAK * v);
+  }
+}
+
 // per-frame gradient norm, penalty and the adjoint of g: gt = coef (|g| - 1) g / |g|   (coef = 2 lambda / F)
 __global__ void k_gp(const float* __restrict__ g, float* __restrict__ gt, float* __restrict__ gp_f, int H, float coef) {
   __shared__ float sm[16];
@@ -601,7 +729,9 @@ using namespace vaenpvc::disc;
 struct DiscL {
   int cin, hin, cout, hout, k, s, pad;
   int64_t w_off, b_off, beta_off, gamma_off;
+  bool dense;  // every output position sees the whole input: run as a dense layer on the matrix cores
   int n() const { return cout * hout; }
+  int kin() const { return cin * hin; }
 };
 struct vaenpvc_disc {
   int H, n_layers, flat;
@@ -643,6 +773,7 @@ void conv_bwd_w(const float* in, Act ai, const float* dout, float* dW, int64_t B
     hipLaunchKernelGGL(k_conv_bwd_w, grid, dim3(256), lds, s, in, ai, dout, dW, B, mk(l), FB, B, 1);
   }
 }
+constexpr int MM_MAX_SPLIT = 8;   // reduction splits of a dense-like layer's GEMMs
 struct DWs {  // resolved workspace of one call; B rows in the forward tensors, R rows in the per-range ones
   float* rows;
   float* u[VAENPVC_MAX_LAYERS];
@@ -658,6 +789,11 @@ struct DWs {  // resolved workspace of one call; B rows in the forward tensors, 
   float* da[VAENPVC_MAX_LAYERS];   // gradient at the activations of layer i (pass 4)
   float* du[VAENPVC_MAX_LAYERS];
   float* part[2][VAENPVC_MAX_LAYERS];  // per-workgroup copies of a layer's weight gradient, per pass (3, 4)
+  // dense-like layers: expanded weights, activated input of all rows, split results of the GEMMs, gradient of Wd
+  float* Wd[VAENPVC_MAX_LAYERS];
+  float* ain[VAENPVC_MAX_LAYERS];
+  float* mmpart;
+  float* dWd;
 };
 int64_t al(int64_t n) { return (n + 63) & ~int64_t(63); }
 
@@ -683,6 +819,19 @@ int64_t carve(const vaenpvc_disc& m, int64_t F, bool critic, float* base, DWs* w
     t.ubar[i] = take(F * m.l[i].n());
   }
   t.g = take(F * m.H);
+  {
+    int64_t mmax = 0, wmax = 0;
+    for (int i = 0; i < m.n_layers; ++i)
+      if (m.l[i].dense) {
+        const int64_t K = m.l[i].kin(), N = m.l[i].n();
+        t.Wd[i] = take(K * N);
+        t.ain[i] = take(B * K);
+        mmax = std::max(mmax, (int64_t)MM_MAX_SPLIT * B * std::max(K, N));
+        wmax = std::max(wmax, K * N);
+      }
+    if (mmax) t.mmpart = take(mmax);
+    if (wmax && critic) t.dWd = take(wmax);
+  }
   if (critic) {
     for (int i = 0; i < m.n_layers; ++i) {
       t.q[i] = take(F * m.l[i].n());
@@ -704,10 +853,60 @@ int64_t carve(const vaenpvc_disc& m, int64_t F, bool critic, float* base, DWs* w
   return off;
 }
 
+// ---- dense-like layers (k_mm): host side
+struct MmPlan {
+  int splits, rper;
+};
+MmPlan mm_plan(int M, int N, int R) {
+  const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  int splits = std::max(1, std::min(MM_MAX_SPLIT, 256 / std::max(1, tiles)));
+  splits = std::min(splits, (R + 31) / 32);
+  const int rper = (((R + splits - 1) / splits) + 31) / 32 * 32;
+  return MmPlan{(R + rper - 1) / rper, rper};
+}
+template <bool AF, bool BF>
+void mm_launch(const float* A, int64_t a_m, int64_t a_r, const float* Bm, int64_t b_r, int64_t b_n, float* C, int M, int N, int R,
+               MmPlan p, hipStream_t s) {
+  MmArgs a{A, a_m, a_r, Bm, b_r, b_n, C, M, N, R, p.rper};
+  hipLaunchKernelGGL((k_mm<AF, BF>), dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)p.splits), dim3(256), 0, s, a);
+}
+// out[rows][N] = in[rows][K] Wd (+ bias per output channel)
+void dense_fwd(const float* in, const float* Wd, const float* bias, float* out, int64_t rows, const DiscL& l, float* part, hipStream_t s) {
+  const int K = l.kin(), N = l.n();
+  const MmPlan p = mm_plan((int)rows, N, K);
+  mm_launch<true, true>(in, K, 1, Wd, N, 1, part, (int)rows, N, K, p, s);
+  hipLaunchKernelGGL(k_mm_reduce, grid1(rows * N), dim3(256), 0, s, part, p.splits, rows * N, out, bias, N, l.hout);
+}
+// din[rows][K] = dout[rows][N] Wd^T
+void dense_dgrad(const float* dout, const float* Wd, float* din, int64_t rows, const DiscL& l, float* part, hipStream_t s) {
+  const int K = l.kin(), N = l.n();
+  const MmPlan p = mm_plan((int)rows, K, N);
+  mm_launch<true, false>(dout, N, 1, Wd, 1, N, part, (int)rows, K, N, p, s);
+  hipLaunchKernelGGL(k_mm_reduce, grid1(rows * K), dim3(256), 0, s, part, p.splits, rows * (int64_t)K, din, (const float*)nullptr, K, 1);
+}
+// dW += fold(in^T dout)
+void dense_wgrad(const float* in, const float* dout, float* dWd, float* dW, int64_t rows, const DiscL& l, hipStream_t s) {
+  const int K = l.kin(), N = l.n();
+  mm_launch<false, true>(in, 1, K, dout, N, 1, dWd, K, N, (int)rows, MmPlan{1, (int)((rows + 31) / 32 * 32)}, s);
+  hipLaunchKernelGGL(k_fold_dense, grid1((int64_t)l.k * l.cin * l.cout), dim3(256), 0, s, dWd, dW, mk(l));
+}
+void expand_dense(const vaenpvc_disc& m, const float* P, const DWs& w, hipStream_t s) {
+  for (int i = 0; i < m.n_layers; ++i)
+    if (m.l[i].dense)
+      hipLaunchKernelGGL(k_expand_dense, grid1((int64_t)m.l[i].kin() * m.l[i].n()), dim3(256), 0, s, P + m.l[i].w_off, w.Wd[i], mk(m.l[i]));
+}
+
 void forward(const vaenpvc_disc& m, const float* P, int64_t B, const DWs& w, hipStream_t s) {
   for (int i = 0; i < m.n_layers; ++i) {
     const DiscL& l = m.l[i];
     Act ai = i == 0 ? kNoAct : act_of(m.l[i - 1], P, w.st[i - 1]);
+    if (l.dense) {  // statistics + activated copy of the input, then one GEMM
+      const DiscL& pl = m.l[i - 1];
+      hipLaunchKernelGGL(k_act_stats, dim3((unsigned)B), dim3(256), 0, s, w.u[i - 1], P + pl.gamma_off, P + pl.beta_off, w.st[i - 1],
+                         w.ain[i], pl.cout, pl.hout);
+      dense_fwd(w.ain[i], w.Wd[i], P + l.b_off, w.u[i], B, l, w.mmpart, s);
+      continue;
+    }
     conv_fwd(i == 0 ? w.rows : w.u[i - 1], ai, P + l.w_off, P + l.b_off, w.u[i], B, l, s, i == 0 ? nullptr : w.st[i - 1]);
   }
   const DiscL& last = m.l[m.n_layers - 1];
@@ -728,7 +927,8 @@ void input_gradient(const vaenpvc_disc& m, const float* P, int64_t r0, int64_t R
     const DiscL& l = m.l[i];
     hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)R), dim3(256), 0, s, w.abar[i], w.u[i] + r0 * l.n(), w.st[i] + 2 * r0,
                        P + l.gamma_off, P + l.beta_off, (const float*)nullptr, (int64_t)0, w.ubar[i], l.cout, l.hout);
-    conv_bwd_data(w.ubar[i], P + l.w_off, i == 0 ? w.g : w.abar[i - 1], R, l, s);
+    if (l.dense) dense_dgrad(w.ubar[i], w.Wd[i], w.abar[i - 1], R, l, w.mmpart, s);
+    else conv_bwd_data(w.ubar[i], P + l.w_off, i == 0 ? w.g : w.abar[i - 1], R, l, s);
   }
 }
 }  // namespace
@@ -784,6 +984,13 @@ int vaenpvc_disc_create(const vaenpvc_disc_arch* a, vaenpvc_disc** out) {
     if (o > 256 || (int64_t)l.cin * l.hin > 16000 || (int64_t)l.cout * l.hout + l.hin > 16000) {
       delete m;
       return abi_error(VAENPVC_E_UNSUPPORTED, "discriminator: a layer exceeds 256 channels or 16000 values per frame");
+    }
+    // dense-like: every (input position, output position) pair has a tap, the layer has an activated input, and the
+    // matrices are big enough for the matrix cores to matter (VAENPVC_DISC_DENSE=0: keep the conv kernels, for A/B)
+    {
+      const char* e = getenv("VAENPVC_DISC_DENSE");
+      l.dense = i > 0 && l.pad - s * (l.hout - 1) >= 0 && l.hin - 1 + l.pad < k && (int64_t)l.cin * l.hin >= 512 &&
+                (int64_t)l.cout * l.hout >= 512 && !(e && e[0] == '0');
     }
     c = o;
     h = l.hout;
@@ -846,6 +1053,7 @@ int vaenpvc_disc_fwd(const vaenpvc_disc* d, const float* d_dparams, const float*
   DWs w;
   carve(*d, F, false, (float*)d_ws, &w);
   hipLaunchKernelGGL(k_rows, grid1(F * d->H), dim3(256), 0, s, d_x, d_xh, (const float*)nullptr, w.rows, F, d->H);
+  expand_dense(*d, d_dparams, w, s);
   forward(*d, d_dparams, 2 * F, w, s);
   if (d_out) (void)hipMemcpyAsync(d_out, w.d, 2 * F * sizeof(float), hipMemcpyDeviceToDevice, s);
   if (d_loss2) hipLaunchKernelGGL(k_losses, dim3(1), dim3(256), 0, s, w.d, (const float*)nullptr, F, d_loss2);
@@ -873,6 +1081,7 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
   csums.count = 0;
   // pass 1
   hipLaunchKernelGGL(k_rows, grid1(F * m.H), dim3(256), 0, s, d_x, d_xh, d_t, w.rows, F, m.H);
+  expand_dense(m, P, w, s);
   forward(m, P, B, w, s);
   // pass 2 (rows xi) and the penalty
   input_gradient(m, P, 2 * F, F, w, s);
@@ -882,8 +1091,13 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
   for (int i = 0; i < L; ++i) {
     const DiscL& l = m.l[i];
     const float* src = i == 0 ? w.gt : w.at[i - 1];  // adjoint of abar_{i-1} (of g for the first layer)
-    conv_fwd(src, kNoAct, P + l.w_off, nullptr, w.q[i], F, l, s);
-    conv_bwd_w(src, kNoAct, w.ubar[i], Gd + l.w_off, F, l, w.part[0][i], &sums, s);
+    if (l.dense) {
+      dense_fwd(src, w.Wd[i], nullptr, w.q[i], F, l, w.mmpart, s);
+      dense_wgrad(src, w.ubar[i], w.dWd, Gd + l.w_off, F, l, s);
+    } else {
+      conv_fwd(src, kNoAct, P + l.w_off, nullptr, w.q[i], F, l, s);
+      conv_bwd_w(src, kNoAct, w.ubar[i], Gd + l.w_off, F, l, w.part[0][i], &sums, s);
+    }
     hipLaunchKernelGGL(k_ln_bwd_bwd, dim3((unsigned)F), dim3(256), 0, s, w.q[i], w.abar[i], w.u[i] + 2 * F * l.n(),
                        w.st[i] + 4 * F, P + l.gamma_off, P + l.beta_off, w.at[i], w.udir[i], w.pn[i], l.cout, l.hout);
     csums.e[csums.count++] = ChanSum{w.pn[i], Gd + l.gamma_off, F, l.cout, l.hout};   // adjoint of gamma
@@ -906,9 +1120,13 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
     hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)B), dim3(256), 0, s, w.da[i], w.u[i], w.st[i], P + l.gamma_off,
                        P + l.beta_off, w.udir[i], 2 * F, w.du[i], l.cout, l.hout);   // udir on the rows xi
     Act ai = i == 0 ? kNoAct : act_of(m.l[i - 1], P, w.st[i - 1]);
-    conv_bwd_w(i == 0 ? w.rows : w.u[i - 1], ai, w.du[i], Gd + l.w_off, B, l, w.part[1][i], &sums, s);
+    if (l.dense) dense_wgrad(w.ain[i], w.du[i], w.dWd, Gd + l.w_off, B, l, s);   // (ain: the activated input kept by pass 1)
+    else conv_bwd_w(i == 0 ? w.rows : w.u[i - 1], ai, w.du[i], Gd + l.w_off, B, l, w.part[1][i], &sums, s);
     csums.e[csums.count++] = ChanSum{w.du[i], Gd + l.b_off, B, l.cout, l.hout};   // conv bias
-    if (i > 0) conv_bwd_data(w.du[i], P + l.w_off, w.da[i - 1], B, l, s);
+    if (i > 0) {
+      if (l.dense) dense_dgrad(w.du[i], w.Wd[i], w.da[i - 1], B, l, w.mmpart, s);
+      else conv_bwd_data(w.du[i], P + l.w_off, w.da[i - 1], B, l, s);
+    }
   }
   {
     int cmax = 0;
@@ -938,6 +1156,7 @@ int vaenpvc_disc_generator_target(const vaenpvc_disc* d, const float* d_dparams,
   DWs w;
   carve(*d, F, false, (float*)d_ws, &w);
   hipLaunchKernelGGL(k_rows, grid1(F * d->H), dim3(256), 0, s, d_x, d_xh, (const float*)nullptr, w.rows, F, d->H);
+  expand_dense(*d, d_dparams, w, s);
   forward(*d, d_dparams, 2 * F, w, s);
   input_gradient(*d, d_dparams, F, F, w, s);  // rows xh
   hipLaunchKernelGGL(k_adv_target, grid1(F * d->H), dim3(256), 0, s, d_x, w.g, d_target, F * d->H, alpha);
