@@ -144,6 +144,38 @@ def test_critic_step_on_a_generic_geometry():
     assert rel_err(target.cpu().numpy() - x, 50.0 * (1 + 1e-6) * g.numpy()) < TOL_VALUE
 
 
+def test_large_batch_dense_layer_agrees_with_the_conv_kernels(monkeypatch):
+    """F = 1024 (3072 rows through every critic kernel: many GEMM tiles, frame-split weight gradients): finite, bitwise
+    repeatable, and the 115-tap layer as a dense layer on the matrix cores == the same layer on the thread-per-output
+    conv kernels (VAENPVC_DISC_DENSE=0, read when the critic is created) up to fp32 summation order."""
+    from hipvae.critic import Critic
+    arch = vawgan_arch()
+    F = 1024
+    cr, _ = make_critic(arch, 6)
+    g = torch.Generator().manual_seed(3)
+    dev = cr.device
+    x = torch.tanh(torch.randn(F, 513, generator=g)).to(dev)
+    xh = torch.tanh(0.7 * torch.randn(F, 513, generator=g) + 0.2).to(dev)
+    t = torch.rand(F, generator=g).to(dev)
+    g1, g2, g3 = (torch.empty(cr.n_params, device=dev) for _ in range(3))
+    l_a = cr.critic_fwd_bwd(x, xh, t, 10.0, g1).clone()
+    l_b = cr.critic_fwd_bwd(x, xh, t, 10.0, g2).clone()
+    assert torch.isfinite(g1).all() and torch.equal(g1, g2) and torch.equal(l_a, l_b)
+    monkeypatch.setenv('VAENPVC_DISC_DENSE', '0')
+    c2 = Critic(arch)
+    monkeypatch.delenv('VAENPVC_DISC_DENSE')
+    c2.params.copy_(cr.params)
+    l_c = c2.critic_fwd_bwd(x, xh, t, 10.0, g3).clone()
+    assert torch.allclose(l_a, l_c, rtol=1e-5, atol=1e-6)
+    for k, (off, shp) in cr.layout.items():
+        n = int(np.prod(shp))
+        a, b = g1[off:off + n], g3[off:off + n]
+        assert float((a - b).abs().max()) <= 3e-4 * max(float(b.abs().max()), 1e-6), k
+    tgt1, _ = cr.generator_target(x, xh, 50.0)
+    tgt2, _ = c2.generator_target(x, xh, 50.0)
+    assert float((tgt1 - tgt2).abs().max()) <= 1e-4 * float((tgt2 - x).abs().max())
+
+
 def test_critic_step_is_deterministic_and_linear_in_lambda():
     """Bitwise repeatable (no atomics), and grad(lambda) is affine in lambda: g(20) - g(10) == g(10) - g(0)."""
     arch = vawgan_arch()
