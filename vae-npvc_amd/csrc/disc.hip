@@ -1131,12 +1131,12 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
   {
     int cmax = 0;
     for (int e = 0; e < pgs.count; ++e) cmax = std::max(cmax, pgs.e[e].C);
-    hipLaunchKernelGGL(k_ln_param_grad, dim3((unsigned)cmax, (unsigned)pgs.count), dim3(256), 0, s, pgs);
+    hipLaunchKernelGGL(k_ln_param_grad, dim3((unsigned)cmax, (unsigned)pgs.count), dim3(B * 16 >= 4096 ? 1024 : 256), 0, s, pgs);   // one workgroup per channel walks all rows
   }
   {
     int cmax = 0;
     for (int e = 0; e < csums.count; ++e) cmax = std::max(cmax, csums.e[e].C);
-    hipLaunchKernelGGL(k_chan_sum_multi, dim3((unsigned)cmax, (unsigned)csums.count), dim3(256), 0, s, csums);
+    hipLaunchKernelGGL(k_chan_sum_multi, dim3((unsigned)cmax, (unsigned)csums.count), dim3(B * 16 >= 4096 ? 1024 : 256), 0, s, csums);
   }
   if (sums.count > 0) {  // the weight-gradient copies of both passes, one launch
     int nmax = 0;
