@@ -683,6 +683,11 @@ __global__ void k_act_stats(const float* __restrict__ u, const float* __restrict
   }
 }
 
+__global__ void k_zero(float* __restrict__ p, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 // per-frame gradient norm, penalty and the adjoint of g: gt = coef (|g| - 1) g / |g|   (coef = 2 lambda / F)
 __global__ void k_gp(const float* __restrict__ g, float* __restrict__ gt, float* __restrict__ gp_f, int H, float coef) {
   __shared__ float sm[16];
@@ -1074,7 +1079,9 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
   const int64_t B = 3 * F;
   DWs w;
   carve(m, F, true, (float*)d_ws, &w);
-  (void)hipMemsetAsync(Gd, 0, m.n_params * sizeof(float), s);
+  // (a kernel, not hipMemsetAsync: the step is replayed from hipGraphs by hipvae/adversarial.py, and a fill node next to
+  //  other fill nodes in one graph was observed to misbehave on replay)
+  hipLaunchKernelGGL(k_zero, grid1(m.n_params), dim3(256), 0, s, Gd, m.n_params);
   PartSums sums;
   sums.count = 0;
   ChanSums csums;   // per-channel reductions of both passes, one launch at the end
