@@ -70,6 +70,24 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
   return r;
 }
 __device__ __forceinline__ int ch_of(int k, int hlast) { return k / hlast; }
+// Cooperative copy global -> (functor) with BATCH independent loads in flight per thread: with one wave per SIMD a plain
+// `for (e = tid; e < n; e += 256) dst[e] = src[e]` waits for every load before the next one is issued.
+template <int BATCH, class Put>
+__device__ __forceinline__ void stage_copy(const float* __restrict__ src, int n, Put&& put) {
+  for (int e0 = threadIdx.x; e0 < n; e0 += BATCH * blockDim.x) {
+    float v[BATCH];
+#pragma unroll
+    for (int b = 0; b < BATCH; ++b) {
+      const int e = e0 + b * blockDim.x;
+      v[b] = e < n ? src[e] : 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < BATCH; ++b) {
+      const int e = e0 + b * blockDim.x;
+      if (e < n) put(e, v[b]);
+    }
+  }
+}
 static inline dim3 grid1(int64_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 // ------------------------------------------------------------------------------------------- forward
@@ -103,11 +121,10 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ in, 
     // the LayerNorm statistics of the input tensor (the layer in front) are taken HERE, from the staged frame (every
     // workgroup of the frame computes them, the first one stores them for the backward passes): no statistics kernel
     float sm = 0.f;
-    for (int e = threadIdx.x; e < nin; e += blockDim.x) {
-      const float v = in[f * nin + e];
+    stage_copy<12>(in + f * nin, nin, [&](int e, float v) {
       sIn[e] = v;
       sm += v;
-    }
+    });
     const float mean = block_sum(sm, red) / nin;
     float q = 0.f;
     for (int e = threadIdx.x; e < nin; e += blockDim.x) {
@@ -125,7 +142,7 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ in, 
       sIn[e] = fmaxf(n, LEAK * n);
     }
   } else {
-    for (int e = threadIdx.x; e < nin; e += blockDim.x) sIn[e] = lnact(in[f * nin + e], ai, f, e / g.hin);
+    stage_copy<12>(in + f * nin, nin, [&](int e, float v) { sIn[e] = lnact(v, ai, f, e / g.hin); });
   }
   __syncthreads();
   const int cs = g.cin >= 4 ? 4 : 1;                      // channel split over the waves
@@ -430,7 +447,7 @@ __global__ void __launch_bounds__(256) k_conv_bwd_data(const float* __restrict__
   extern __shared__ float sD[];  // [cout][hout]
   const int64_t f = blockIdx.x;
   const int c0 = blockIdx.y * BWD_CB, cb = min(BWD_CB, g.cin - c0);
-  for (int e = threadIdx.x; e < g.cout * g.hout; e += blockDim.x) sD[e] = dout[f * g.cout * g.hout + e];
+  stage_copy<12>(dout + f * g.cout * g.hout, g.cout * g.hout, [&](int e, float v) { sD[e] = v; });
   __syncthreads();
   for (int idx = threadIdx.x; idx < cb * g.hin; idx += blockDim.x) {
     const int c = c0 + idx % cb, i = idx / cb;
@@ -482,11 +499,14 @@ __global__ void __launch_bounds__(256) k_conv_bwd_w(const float* __restrict__ in
   for (int64_t f0 = fbeg; f0 < fend; f0 += FB) {  // FB frames per barrier pair: the staging latency is paid once for all
     const int nf = (int)min((int64_t)FB, fend - f0);
     __syncthreads();
+    // (the nf frames of dout are contiguous in memory: one batched copy; the LDS frame pitch nF differs from nD)
+    stage_copy<16>(dout + f0 * nD, nf * nD, [&](int e, float v) {
+      const int ff = e / nD;
+      sm[ff * nF + (e - ff * nD)] = v;
+    });
     for (int ff = 0; ff < nf; ++ff) {
-      const float* dsrc = dout + (f0 + ff) * nD;
-      for (int e = threadIdx.x; e < nD; e += blockDim.x) sm[ff * nF + e] = dsrc[e];
       const float* isrc = in + ((f0 + ff) * g.cin + c) * g.hin;
-      for (int e = threadIdx.x; e < g.hin; e += blockDim.x) sm[ff * nF + nD + e] = lnact(isrc[e], ai, f0 + ff, c);
+      stage_copy<4>(isrc, g.hin, [&](int e, float v) { sm[ff * nF + nD + e] = lnact(v, ai, f0 + ff, c); });
     }
     __syncthreads();
     if (live) {
