@@ -13,11 +13,18 @@ Arithmetic: fp32 tensors everywhere; the GEMM-shaped kernels that run on the bf1
 every fp32 operand into bf16 terms with fp32 accumulation.  The default (`value`, "bf16x2") uses 2 terms
 (16 mantissa bits per operand, three products): it holds the parity bars of north_star at the benchmarked
 size (tests/test_gpu_parity.py::test_benchmarked_batch_sizes_against_oracle_fixture: 1e-4 activations /
-losses, 2e-4 gradients; measured ~7e-6 / <= 1.5e-5).  `modes` reports the fp32-exact 3-term variant and the
-plain-bf16 mode (BASELINE config 2's literal dtype; tolerance 3e-2, stated in the tests) beside it.
+losses, 2e-4 gradients; measured 1.4e-5 / <= 3.0e-5 at 32 768 frames, gpurun_out/parity_report.txt).  `modes`
+reports the fp32-exact 3-term variant (with its own `roofline`) and the plain-bf16 mode (BASELINE config 2's
+literal dtype; tolerance 3e-2, stated in the tests) beside it.  `config.convert_config4` = the conversion
+path (encode -> decode, configs[3]) on the GPU next to the CPU leg of `cpu_baseline`.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: bench.py launches its N ranks ITSELF
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...`,
+one process per GPU, RCCL).  It refuses to run (non-zero exit status) when fewer than N devices are visible
+or when the process group does not have exactly N ranks.  Launched by torch.distributed.run directly (the
+driver's form) it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.
 
 Prints ONE JSON line on rank 0.
 """
@@ -46,7 +53,7 @@ PRODUCTS = {3: 6, 2: 3, 1: 1}           # bf16 MFMA products per fp32 product fo
 PREC_NAME = {3: 'bf16x3', 2: 'bf16x2', 1: 'bf16'}
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=100)
@@ -59,7 +66,12 @@ def parse():
     p.add_argument('--cpu-seconds', type=float, default=24.0, help='total budget of the CPU legs')
     p.add_argument('--no-literal', action='store_true', help='skip the extra F=256 / F=16 measurements')
     p.add_argument('--no-modes', action='store_true', help='skip the other precisions')
-    return p.parse_args()
+    p.add_argument('--no-convert', action='store_true', help='skip the conversion-path (config 4) measurement')
+    p.add_argument('--master-port', type=int, default=0, help='rendezvous port of the self-launched ranks (0 = pick a free one)')
+    p.add_argument('--standin', default=None,
+                   help='TEST ONLY: python file providing make_engine(arch, args) -> CPU stand-in engine; the ranks then use '
+                        'the gloo backend and only the launcher / process-group / timing logic of this file runs')
+    return p.parse_args(argv)
 
 
 def cpu_model():
@@ -137,47 +149,132 @@ def cpu_baseline(arch, seconds):
             'cpu_model': cpu_model(), 'host_threads': os.cpu_count(), 'legs': legs}
 
 
-def main():
-    args = parse()
+# algorithmic figures of the conversion path: encode (z_mu only) + decode, forward only
+FLOP_PER_FRAME_CONVERT = 9.419e6
+BYTES_PER_FRAME_CONVERT = 150384.0
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def visible_devices(args):
+    if args.standin:
+        return args.gpus          # the CPU stand-in ranks need no device
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE): start the N ranks with torch.distributed.run and
+    hand its exit status back.  The child ranks run this same file with WORLD_SIZE set."""
+    import subprocess
+    nvis = visible_devices(args)
+    if nvis < args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but only %d device(s) visible: refusing to run\n' % (args.gpus, nvis))
+        return 3
+    port = args.master_port or free_port()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC only on this driver (RCCL needs it)
+    env['VAENPVC_BENCH_SELF_LAUNCHED'] = '1'
+    return subprocess.call(cmd, env=env)
+
+
+def load_standin(path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_standin', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args, argv))
     import torch
     import torch.distributed as dist
-    from hipvae import Engine
-    from hipvae import lib as L
     from hipvae.dp import Stepper
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
-    torch.cuda.set_device(local)
+    if world != args.gpus:
+        # one rank asked for N, or N ranks asked for another N: never print a line that claims a size it did not run
+        sys.stderr.write('bench.py: --gpus %d does not match WORLD_SIZE %d: refusing to run\n' % (args.gpus, world))
+        raise SystemExit(3)
+    standin = load_standin(args.standin) if args.standin else None
+    if standin is None:
+        from hipvae import Engine
+        from hipvae import lib as L
+        nvis = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if nvis < world or local >= nvis:
+            sys.stderr.write('bench.py: %d rank(s) but %d device(s) visible: refusing to run\n' % (world, nvis))
+            raise SystemExit(3)
+        torch.cuda.set_device(local)
     force_dist = os.environ.get('VAENPVC_FORCE_DIST') == '1'      # exercise the RCCL path with one rank
+    backend = 'gloo' if standin else 'nccl'
     if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if standin:
+            dist.init_process_group(backend)
+        else:
+            dist.init_process_group(backend, device_id=torch.device('cuda', local))
+        if dist.get_world_size() != args.gpus:
+            sys.stderr.write('bench.py: process group has %d ranks, --gpus %d: refusing to run\n' % (dist.get_world_size(), args.gpus))
+            raise SystemExit(3)
 
     with open(os.path.join(ROOT, 'vae-npvc_amd', 'architecture-vae-vcc2016.json')) as fp:
         arch = json.load(fp)
     t = arch['training']
-    eng = Engine(arch, impl=args.impl, precision=args.precision)
-    eng.init_params(seed=0)
+    if standin:
+        arch = standin.ARCH if hasattr(standin, 'ARCH') else arch
+        t = arch['training']
+        eng = standin.make_engine(arch, args)
+        planes = 2
+    else:
+        eng = Engine(arch, impl=args.impl, precision=args.precision)
+        eng.init_params(seed=0)
+        planes = L.PRECISIONS[args.precision]
     st = Stepper(eng, t['lr'], t['beta1'], t['beta2'], seed=0)
     st.broadcast_params()
-    planes = L.PRECISIONS[args.precision]
+    dev = eng.params.device
+    H = arch['hwc'][0]
 
     def make_batch(F, seed):
         g = torch.Generator(device='cpu').manual_seed(seed)
-        x = (torch.rand(F, 513, generator=g) * 2 - 1).to(eng.device)
-        y = torch.randint(0, 10, (F,), generator=g, dtype=torch.int64).to(eng.device)
+        x = (torch.rand(F, H, generator=g) * 2 - 1).to(dev).to(eng.params.dtype)
+        y = torch.randint(0, arch['y_dim'], (F,), generator=g, dtype=torch.int64).to(dev)
         return x, y
+
+    def sync():
+        if dev.type == 'cuda':
+            torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
+
+    def max_over_ranks(dt):
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
 
     def timed(F, steps, warmup, tag=None):
         x, y = make_batch(F, 1234 + rank)
@@ -197,34 +294,59 @@ def main():
             eng.timer_select(None)
             if n:
                 kern = (ms / n, n)
-        if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=eng.device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt, kern
+        return max_over_ranks(dt), kern
 
     F = args.frames
-    dt, kern = timed(F, args.steps, args.warmup, None if args.impl == 'auto' else args.timer_tag)
+    dt, kern = timed(F, args.steps, args.warmup, None if (args.impl == 'auto' or standin) else args.timer_tag)
     frames_per_s = world * F * args.steps / dt
     steps_per_s = args.steps / dt
     out = {
         'metric': 'SP frames/sec (train step: fwd+bwd+Adam%s)' % ('+RCCL all-reduce' if world > 1 else ''),
         'value': frames_per_s, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32',
+        'dtype': {3: 'f32 (tensors and accumulation; matrix-core operands split into 3 bf16 terms = fp32-exact)',
+                  2: 'f32 tensors and accumulation / bf16x2 operands (16 mantissa bits) on the matrix cores',
+                  1: 'bf16 operands on the matrix cores, f32 tensors and accumulation'}[planes],
         'arithmetic': ('fp32 tensors, fp32 accumulation; GEMM operands on the bf16 matrix cores split into bf16 terms: %s'
                        % {3: '3 terms (fp32-exact)',
-                          2: '2 terms (16 mantissa bits per operand; holds the 1e-4 / 2e-4 parity bars with >10x margin)',
+                          2: '2 terms (16 mantissa bits per operand; holds the 1e-4 / 2e-4 parity bars at 32 768 frames: measured 1.4e-5 / 3.0e-5)',
                           1: 'plain bf16 operands: the reduced-precision bf16 mode'}[planes]),
         'data': 'synthetic (x~U(-1,1), y~randint(10) resident in HBM; eps~N(0,1) drawn on the device per step, Philox4x32-10; random-init weights)',
+        'rccl_ranks': (dist.get_world_size() if dist.is_initialized() else 1),
+        'launch': ('self-launched torch.distributed.run' if os.environ.get('VAENPVC_BENCH_SELF_LAUNCHED') == '1'
+                   else 'torch.distributed.run (external)' if world > 1 else 'single process'),
         'config': {'workload': 'ConvVAE architecture-vae-vcc2016 train step, 256x[1,513,128] = %d frames/step/GPU' % F,
                    'frames_per_step_per_gpu': F, 'global_frames_per_step': F * world, 'impl': args.impl,
-                   'precision': args.precision, 'parallelism': 'dp%d' % world,
-                   'all_reduce': 'four gradient buckets overlapped with the backward pass' if world > 1 else None},
+                   'precision': args.precision, 'parallelism': 'dp%d' % world, 'backend': backend if (world > 1 or force_dist) else None,
+                   'all_reduce': ('four gradient buckets (3.76 MB fp32 in all, SUM) started from a library callback while the backward pass runs, '
+                                  '1/N folded into Adam; losses ride in the buffer tail') if world > 1 else None},
         'step_fraction_of_rooflines': {
             'hbm_model_B': (frames_per_s / world * BYTES_PER_FRAME_TRAIN + steps_per_s * BYTES_PER_STEP_PARAMS) / HBM_PEAK,
-            'fp32_flops': frames_per_s / world * FLOP_PER_FRAME_TRAIN / FP32_PEAK},
+            'fp32_flops': frames_per_s / world * FLOP_PER_FRAME_TRAIN / FP32_PEAK,
+            'mfma_%s' % PREC_NAME[planes]: frames_per_s / world * FLOP_PER_FRAME_TRAIN / (BF16_PEAK / PRODUCTS[planes])},
     }
+    if standin:
+        out['data'] = 'CPU stand-in engine (test of the launcher / process-group logic only; not a measurement)'
+        out['config']['workload'] = 'stand-in'
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
+    # whole-step HBM traffic from the committed PMC passes of this command (sum over all kernels of
+    # 2 x FETCH_SIZE + WRITE_SIZE; profiles/README.md), next to the layer-materialised algorithmic bytes
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fp:
+            tj = json.load(fp).get('step/%s' % ('bf16x2' if args.precision == 'auto' else args.precision))
+        if tj and tj.get('frames') == F:
+            out['step_traffic_bytes'] = tj['hbm_bytes_per_step']
+            out['step_traffic'] = {'hbm_bytes_per_step': tj['hbm_bytes_per_step'],
+                                   'algorithmic_bytes_model_B': F * BYTES_PER_FRAME_TRAIN + BYTES_PER_STEP_PARAMS,
+                                   'ratio': tj['hbm_bytes_per_step'] / (F * BYTES_PER_FRAME_TRAIN + BYTES_PER_STEP_PARAMS),
+                                   'source': tj.get('source')}
+    except (OSError, ValueError):
+        pass
+
     # ---- roofline of the dominant kernel: a separate short pass with the weight-gradient stream
     #      serialised (backward-mask bit 30 cleared), so that the HIP-event duration of a kernel is
     #      not inflated by kernels running concurrently on the other stream.  Not part of `value`.
@@ -235,8 +357,8 @@ def main():
         finally:
             eng.set_tuned_masks(0xffffffff, 0xffffffff)
         return k
-    kern = kernel_ms(args.timer_tag) if args.impl == 'auto' else kern
-    if kern:
+
+    def roofline_of(prec_name, npl, kern):
         avg_ms, n = kern
         ach = DEC3_FLOP_PER_FRAME * F / (avg_ms * 1e-3) / 1e12
         # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (separate
@@ -244,21 +366,24 @@ def main():
         traffic = None
         try:
             with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fp:
-                tj = json.load(fp).get('%s/%s' % (args.timer_tag, args.precision))
+                tj = json.load(fp).get('%s/%s' % (args.timer_tag, prec_name))
                 if tj and tj.get('frames') == F:
                     traffic = tj['hbm_bytes_per_launch']
         except (OSError, ValueError):
             pass
-        bf16 = args.timer_tag in ('dec3_fwd', 'dec3_dgrad', 'dec3_wgrad') and F >= 8192 and args.impl == 'auto'
-        peak = (BF16_PEAK / PRODUCTS[planes] if bf16 else FP32_PEAK) / 1e12
-        out['roofline'] = {'bound': 'mfma', 'kernel': args.timer_tag, 'achieved': ach, 'peak': peak,
-                           'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
-                           'avg_kernel_ms': avg_ms, 'launches': n,
-                           'algorithmic_flops_per_launch': DEC3_FLOP_PER_FRAME * F,
-                           'peak_basis': ('dense bf16 MFMA peak / %d (%d-term operand split: %d bf16 products per fp32 product)'
-                                          % (PRODUCTS[planes], planes, PRODUCTS[planes]) if bf16
-                                          else 'exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'),
-                           'measured': 'HIP events on the launch stream, side stream serialised'}
+        bf16 = args.timer_tag in ('dec3_fwd', 'dec3_dgrad', 'dec3_wgrad') and F >= 16 and args.impl == 'auto'
+        peak = (BF16_PEAK / PRODUCTS[npl] if bf16 else FP32_PEAK) / 1e12
+        return {'bound': 'mfma', 'kernel': args.timer_tag, 'precision': prec_name, 'achieved': ach, 'peak': peak,
+                'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
+                'avg_kernel_ms': avg_ms, 'launches': n,
+                'algorithmic_flops_per_launch': DEC3_FLOP_PER_FRAME * F,
+                'peak_basis': ('dense bf16 MFMA peak / %d (%d-term operand split: %d bf16 products per fp32 product)'
+                               % (PRODUCTS[npl], npl, PRODUCTS[npl]) if bf16
+                               else 'exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'),
+                'measured': 'HIP events on the launch stream, side stream serialised'}
+    kern = kernel_ms(args.timer_tag) if args.impl == 'auto' else kern
+    if kern:
+        out['roofline'] = roofline_of('bf16x2' if args.precision == 'auto' else args.precision, planes, kern)
         if args.impl == 'auto' and F >= 8192 and args.timer_tag == 'dec3_wgrad':
             # the two sibling GEMMs of the same layer (same algorithmic flops)
             sib = {}
@@ -266,28 +391,42 @@ def main():
                 k = kernel_ms(tag, 4)
                 if k:
                     a2 = DEC3_FLOP_PER_FRAME * F / (k[0] * 1e-3) / 1e12
-                    sib[tag] = {'avg_kernel_ms': k[0], 'achieved_tflops_fp32_equiv': a2, 'peak': peak, 'frac': a2 / peak}
+                    sib[tag] = {'avg_kernel_ms': k[0], 'achieved_tflops_fp32_equiv': a2, 'peak': out['roofline']['peak'],
+                                'frac': a2 / out['roofline']['peak']}
             out['roofline']['sibling_kernels'] = sib
     # ---- the other precisions beside the default (never instead of it)
     if not args.no_modes and args.impl == 'auto':
-        modes = {('bf16x2' if args.precision == 'auto' else args.precision): {'ms_per_step': dt / args.steps * 1e3, 'frames_per_s': frames_per_s}}
+        cur = 'bf16x2' if args.precision == 'auto' else args.precision
+        modes = {cur: {'ms_per_step': dt / args.steps * 1e3, 'frames_per_s': frames_per_s}}
         for prec in ('bf16x2', 'bf16x3', 'bf16'):
             if prec in modes:
                 continue
             eng.set_precision(prec)
-            d2, _ = timed(F, max(10, args.steps // 4), 3)
             n2 = max(10, args.steps // 4)
-            modes[prec] = {'ms_per_step': d2 / n2 * 1e3, 'frames_per_s': world * F * n2 / d2}
+            d2, _ = timed(F, n2, 3)
+            fps2 = world * F * n2 / d2
+            modes[prec] = {'ms_per_step': d2 / n2 * 1e3, 'frames_per_s': fps2,
+                           'fraction_of_hbm_model_B': (fps2 / world * BYTES_PER_FRAME_TRAIN + n2 / d2 * BYTES_PER_STEP_PARAMS) / HBM_PEAK}
+            if prec == 'bf16':
+                # the bf16-activation reading of the layer-materialised model (152 432 B/frame)
+                modes[prec]['fraction_of_hbm_model_B_bf16_activations'] = (fps2 / world * 152432.0 + n2 / d2 * BYTES_PER_STEP_PARAMS) / HBM_PEAK
+            if prec == 'bf16x3' and args.timer_tag == 'dec3_wgrad':
+                k3 = kernel_ms(args.timer_tag, 4)      # the fp32-exact mode's own roofline line
+                if k3:
+                    out['roofline_bf16x3'] = roofline_of('bf16x3', 3, k3)
         eng.set_precision(args.precision)
         modes['note'] = ('bf16x2 (default): 2-term operand split; bf16x3: 3 terms, fp32-exact; '
                          'bf16: plain bf16 operands on the kernels that run on the bf16 matrix cores (tolerance 3e-2, tests)')
         out['modes'] = modes
     if not args.no_literal:
+        # the literal batch sizes: 256 frames per GPU (configs[1]; with N = 8 ranks the global batch is configs[2]'s
+        # 2048) and 16 (configs[0], the reference's own batch_size)
         lits = {}
         for Fl, nst in ((256, 200), (16, 200)):
             dt2, _ = timed(Fl, nst, 10)
-            lit = {'frames_per_s': world * Fl * nst / dt2, 'ms_per_step': dt2 / nst * 1e3, 'launch': 'eager'}
-            # same step captured in a hipGraph (one launch per step instead of ~130); with N > 1 the
+            lit = {'frames_per_s': world * Fl * nst / dt2, 'ms_per_step': dt2 / nst * 1e3, 'launch': 'eager',
+                   'frames_per_step_per_gpu': Fl, 'global_frames_per_step': Fl * world}
+            # same step captured in a hipGraph (one launch per step instead of one per kernel); with N > 1 the
             # (unbucketed) gradient all-reduce is captured with it
             try:
                 x, y = make_batch(Fl, 99)
@@ -299,13 +438,36 @@ def main():
                 for _ in range(nst):
                     st.replay()
                 barrier()
-                dtg = time.perf_counter() - t0
+                dtg = max_over_ranks(time.perf_counter() - t0)
                 lit['hipgraph'] = {'frames_per_s': world * Fl * nst / dtg, 'ms_per_step': dtg / nst * 1e3}
             except Exception as ex:       # noqa: BLE001  (capture support differs between RCCL builds)
                 lit['hipgraph'] = {'error': str(ex)[:200]}
             lits['F%d' % Fl] = lit
         out['config']['literal_batches'] = lits
         out['config']['literal_batch256'] = lits['F256']
+    if not args.no_convert and args.impl == 'auto':
+        # BASELINE.json configs[3]: the conversion path convert.py:79-89 (encode -> z_mu, decode towards speaker 9 = TM3),
+        # forward only, frames resident in HBM; every rank converts its own frames
+        conv = {}
+        for Fc, nit in ((1024, 50), (32768, 10)):
+            xc, _ = make_batch(Fc, 4321 + rank)
+            yc = torch.full((Fc,), 9, dtype=torch.int64, device=dev)
+            for _ in range(3):
+                eng.decode(eng.encode(xc), yc)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(nit):
+                eng.decode(eng.encode(xc), yc)
+            barrier()
+            dtc = max_over_ranks(time.perf_counter() - t0) / nit
+            fps = world * Fc / dtc
+            conv['F%d' % Fc] = {'frames': Fc, 'ms': dtc * 1e3, 'frames_per_s': fps,
+                                'fraction_of_fp32_flops': fps / world * FLOP_PER_FRAME_CONVERT / FP32_PEAK,
+                                'fraction_of_mfma_%s' % PREC_NAME[planes]: fps / world * FLOP_PER_FRAME_CONVERT / (BF16_PEAK / PRODUCTS[planes]),
+                                'fraction_of_hbm_model_B': fps / world * BYTES_PER_FRAME_CONVERT / HBM_PEAK}
+        conv['note'] = ('encode (z_mu) + decode, 9.419 MFLOP and 150 384 layer-materialised bytes per frame (SURVEY 8d); '
+                        'the CPU leg of the same path is cpu_baseline.legs.convert_fwd_F1024')
+        out['config']['convert_config4'] = conv
     if not args.no_literal:
         # BASELINE.json configs[4]: the VAWGAN branch (nIterD critic steps + one generator step per iteration, 16 frames per
         # step and GPU; hipvae/adversarial.py, data parallel over the same process group).  Reported beside the headline.
@@ -336,7 +498,7 @@ def main():
             for _ in range(nit):
                 iteration()
             barrier()
-            dtv = time.perf_counter() - t0
+            dtv = max_over_ranks(time.perf_counter() - t0)
             out['config']['vawgan_config5'] = {
                 'ms_per_iteration': dtv / nit * 1e3, 'frames_per_s': world * Fv * (vt['nIterD'] + 1) * nit / dtv,
                 'frames_per_step_per_gpu': Fv, 'nIterD': vt['nIterD'],
