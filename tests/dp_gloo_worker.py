@@ -93,6 +93,54 @@ def run(rank, world, F, steps, out, mode):
         np.save(out, np.concatenate([be.params.numpy(), gl.numpy()]))
 
 
+def run_cb_error(rank, world, F, out):
+    """An exception inside the library's bucket callback (ctypes would print and swallow it) must surface from
+    Stepper.step() with the optimiser step NOT applied; a backend that reports ranges which do not tile the
+    gradient buffer must be refused too (advisor finding, round 2)."""
+    from hipvae.dp import Stepper, shard_range
+    be = OracleBackend(SMALL_ARCH, seed=10)
+    st = Stepper(be, 1e-3, 0.5, 0.999, seed=3)
+    st.broadcast_params()
+    x, y, eps = O.make_inputs(SMALL_ARCH, F, 50)
+    lo, hi = shard_range(F, rank, world)
+    args = (torch.tensor(x[lo:hi]), torch.tensor(y[lo:hi]), torch.tensor(eps[lo:hi]))
+    st.step(*args)                                   # a good step first
+    p1, step1 = be.params.clone(), st.step_count
+    # (1) the third range's callback fails on every rank (after two all-reduces were started)
+    real = st._bucket_ready_impl
+    calls = []
+
+    def failing(bucket, off, cnt, stream):
+        calls.append(bucket)
+        if len(calls) == 3:
+            raise ValueError('injected failure in bucket %d' % bucket)
+        real(bucket, off, cnt, stream)
+    st._bucket_ready_impl = failing
+    try:
+        st.step(*args)
+        raise AssertionError('step() swallowed the callback failure')
+    except RuntimeError as ex:
+        assert 'NOT applied' in str(ex) and isinstance(ex.__cause__, ValueError)
+    assert torch.equal(be.params, p1) and st.step_count == step1
+    st._bucket_ready_impl = real
+    if world > 1:
+        dist.barrier()
+    # (2) a backend that forgets one range
+    ranges = be.ranges
+    be.ranges = ranges[:2] + ranges[3:]
+    try:
+        st.step(*args)
+        raise AssertionError('a missing gradient range went unnoticed')
+    except RuntimeError as ex:
+        assert 'tile' in str(ex) or 'cover' in str(ex)
+    assert torch.equal(be.params, p1)
+    be.ranges = ranges
+    st.step(*args)                                   # and the stepper still works afterwards
+    assert st.step_count == step1 + 1 and not torch.equal(be.params, p1)
+    if rank == 0:
+        np.save(out, be.params.numpy())
+
+
 def run_trainer(rank, world, F, steps, out):
     """VAETrainer.train under N ranks with a status interval of ZERO seconds on odd ranks and 'never' on even
     ones: any collective inside the status path would pair with a gradient all-reduce of another rank
@@ -239,6 +287,8 @@ if __name__ == '__main__':
         dist.init_process_group('gloo', rank=rank, world_size=world)
     if mode == 'trainer':
         run_trainer(rank, world, F, steps, out)
+    elif mode == 'cb_error':
+        run_cb_error(rank, world, F, out)
     elif mode == 'adv':
         run_adv(rank, world, F, steps, out)
     elif mode == 'adv_trainer':

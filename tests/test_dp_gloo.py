@@ -76,3 +76,9 @@ def test_trainer_loop_status_is_collective_free_and_restore_continues(tmp_path, 
     """VAETrainer.train with rank-dependent status intervals (a collective in the status path would pair with
     another rank's gradient all-reduce), training.log line format, checkpoint name, restore + continue."""
     launch(world, 8, 3, str(tmp_path / 't.npy'), 'trainer')
+
+
+def test_callback_failure_surfaces_and_nothing_is_applied(tmp_path):
+    """ctypes swallows exceptions raised in the bucket callback: the stepper must re-raise them after the library call,
+    leave parameters and step counter untouched, and refuse reported ranges that do not tile the gradient buffer."""
+    launch(2, 8, 1, str(tmp_path / 'c.npy'), 'cb_error')

@@ -264,7 +264,12 @@ def test_tf_checkpoint_bundle_roundtrip_and_import(tmp_path):
     p2 = str(tmp_path / 'tf' / 'model.ckpt-77')
     T.export_checkpoint(p2, layout, state)
     names = T.read_bundle(p2)
-    assert 'Encoder/Conv2d-0/kernel' in names and 'Encoder/Conv2d-0/kernel/Adam_1' in names and int(names['global_step']) == 77
+    # names as the reference's graph creates them: conv2d_nchw_layernorm opens variable_scope(name) AND names the conv layer
+    # `name` (util/layers.py:55-64), so the conv variables are doubly scoped while the LayerNorm pair is not (layers.py:65)
+    assert 'Encoder/Conv2d-0/Conv2d-0/kernel' in names and 'Encoder/Conv2d-0/Conv2d-0/kernel/Adam_1' in names
+    assert 'Encoder/Conv2d-1/Conv2d-1/bias' in names and 'Encoder/Conv2d-0/kernel' not in names
+    assert 'Encoder/Conv2d-0/layernorm.scale' in names and 'Generator/conv2d_transpose_1/kernel' in names
+    assert int(names['global_step']) == 77 and names['global_step'].dtype == np.int32      # tf.Variable(0) is int32
     assert names['Generator/fully_connected/weights'].shape == tuple(lay['Generator/fully_connected/weights'])
     back = T.import_checkpoint(p2, layout)
     for k in ('params', 'm', 'v'):
@@ -279,3 +284,40 @@ def test_tf_checkpoint_bundle_roundtrip_and_import(tmp_path):
     T.write_bundle(p2, names)
     with pytest.raises(KeyError, match='lacks'):
         T.import_checkpoint(p2, layout)
+    # a kernel stored transposed (same element count, other shape) is refused instead of loaded silently
+    p3 = str(tmp_path / 'tf3' / 'model.ckpt-77')
+    T.export_checkpoint(p3, layout, state)
+    names = T.read_bundle(p3)
+    k0 = 'Encoder/Conv2d-1/Conv2d-1/kernel'
+    names[k0] = np.ascontiguousarray(np.swapaxes(names[k0], 2, 3))
+    T.write_bundle(p3, names)
+    with pytest.raises(ValueError, match='shape'):
+        T.import_checkpoint(p3, layout)
+    # parameters without Adam slots (a Saver over the trainable variables only): the optimiser restarts at step 0
+    p4 = str(tmp_path / 'tf4' / 'model.ckpt-77')
+    T.export_checkpoint(p4, layout, state)
+    names = {k: v for k, v in T.read_bundle(p4).items() if not (k.endswith('/Adam') or k.endswith('/Adam_1'))}
+    T.write_bundle(p4, names)
+    with pytest.warns(UserWarning, match='no Adam slots'):
+        back = T.import_checkpoint(p4, layout)
+    assert back['step'] == 0 and torch.equal(back['params'], state['params']) and float(back['m'].abs().max()) == 0.0
+
+
+def test_bounded_shuffler_state_roundtrip():
+    """A checkpointed shuffler continues the SAME record sequence (round-2 advisor: a restored run replayed the first
+    batches of the original one)."""
+    import pickle
+    from analyzer import BoundedShuffler
+    a = BoundedShuffler([50, 70, 30], capacity=64, min_after_dequeue=32, seed=5)
+    for _ in range(7):
+        a.next(16)
+    sd = pickle.loads(pickle.dumps(a.state_dict()))       # survives torch.save / pickle
+    want = [a.next(16) for _ in range(20)]
+    b = BoundedShuffler([50, 70, 30], capacity=64, min_after_dequeue=32, seed=999)   # another seed: the state decides
+    b.load_state_dict(sd)
+    got = [b.next(16) for _ in range(20)]
+    assert all(np.array_equal(x, y) for x, y in zip(want, got))
+    fresh = BoundedShuffler([50, 70, 30], capacity=64, min_after_dequeue=32, seed=5)
+    assert not np.array_equal(fresh.next(16), want[0])    # (and it is not simply the start of the stream again)
+    with pytest.raises(ValueError):
+        BoundedShuffler([50, 70], capacity=64, min_after_dequeue=32).load_state_dict(sd)

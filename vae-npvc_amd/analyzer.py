@@ -120,6 +120,21 @@ class BoundedShuffler(object):
             n -= k
         return np.concatenate(out)
 
+    def state_dict(self):
+        """Everything the next draw depends on: a restored run continues the SAME record sequence instead of replaying
+        the first batches of the original run (the reference's queues are not checkpointed either, but they are not
+        seeded: a restarted TF run sees fresh shuffles, never the same ones again)."""
+        return {'rng_files': self.rng_files.bit_generator.state, 'rng': self.rng.bit_generator.state,
+                'pool': self.pool.copy(), 'pending': self._pending.copy(), 'sizes': list(self.sizes)}
+
+    def load_state_dict(self, sd):
+        if list(sd['sizes']) != self.sizes:
+            raise ValueError('shuffler state belongs to another file list')
+        self.rng_files.bit_generator.state = sd['rng_files']
+        self.rng.bit_generator.state = sd['rng']
+        self.pool = np.asarray(sd['pool'], np.int64).copy()
+        self._pending = np.asarray(sd['pending'], np.int64).copy()
+
 
 class FrameStore(object):
     """All records resident in HBM; `next_batch()` = the shuffle_batch dequeue (analyzer.py:128-135): the
@@ -148,6 +163,16 @@ class FrameStore(object):
         bad = int(((spk < 0) | (spk >= ny) | (spk != spk.floor())).sum().item())
         if bad:
             raise ValueError('%d record(s) carry a speaker id outside [0, %d)' % (bad, ny))
+
+    def state_dict(self):
+        return {'shuffler': self.shuffler.state_dict(), 'batch_size': self.batch_size, 'world': self.world}
+
+    def load_state_dict(self, sd):
+        if (sd.get('batch_size'), sd.get('world')) != (self.batch_size, self.world):
+            # another global batch: the draw sequence cannot line up; keep the fresh stream
+            return False
+        self.shuffler.load_state_dict(sd['shuffler'])
+        return True
 
     def next_batch(self):
         idx = self.shuffler.next(self.batch_size * self.world)

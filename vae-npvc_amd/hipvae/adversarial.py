@@ -54,9 +54,19 @@ class AdvStepper(object):
         self.collective = self.world > 1 or (os.environ.get('VAENPVC_FORCE_DIST') == '1' and dist.is_available()
                                              and dist.is_initialized())
         p, d = engine.params, critic.params
-        self.g_e = torch.zeros_like(p)          # gradient of l_E (all tensors; the 'Encoder' ranges are applied)
-        self.g_g = torch.zeros_like(p)          # gradient of l_G (the 'Generator' / 'y_emb' ranges are applied)
-        self.g_d = torch.zeros_like(d)
+        # Gradient buffers with the step's loss scalars in their tails (as hipvae.dp.Stepper): ONE all-reduce per
+        # generator step (both ConvVAE gradients + {G, D_KL, logP} + W_dist) and ONE per critic step (gradient +
+        # {W_dist, gp}); no collective of its own for any loss, so an exception between collectives cannot leave the
+        # ranks with different numbers of pending all-reduces (round-2 advisor finding).
+        al = lambda k: (k + 63) // 64 * 64
+        n, nd = p.numel(), d.numel()
+        self._gbuf = torch.zeros(2 * al(n) + 64, dtype=p.dtype, device=p.device)
+        self.g_e = self._gbuf[:n]               # gradient of l_E (all tensors; the 'Encoder' ranges are applied)
+        self.g_g = self._gbuf[al(n):al(n) + n]  # gradient of l_G (the 'Generator' / 'y_emb' ranges are applied)
+        self._gtail = self._gbuf[2 * al(n):2 * al(n) + 8]
+        self._dbuf = torch.zeros(al(nd) + 64, dtype=d.dtype, device=d.device)
+        self.g_d = self._dbuf[:nd]
+        self._dtail = self._dbuf[al(nd):al(nd) + 4]
         self.m, self.v = torch.zeros_like(p), torch.zeros_like(p)
         self.m_d, self.v_d = torch.zeros_like(d), torch.zeros_like(d)
         self.enc_ranges = name_ranges(engine.layout, lambda n: 'Encoder' in n)
@@ -67,9 +77,11 @@ class AdvStepper(object):
         self._draws = 0
         # last values of the status line (trainer/vae.py:196-201); device tensors
         self.status = {k: torch.zeros((), device=p.device) for k in ('D_KL', 'logP', 'W_dist', 'gp')}
-        self._l3 = torch.zeros(3, dtype=torch.float32, device=p.device)
-        self._l3b = torch.zeros(3, dtype=torch.float32, device=p.device)
-        self._l2 = torch.zeros(2, dtype=torch.float32, device=p.device)
+        self._l3 = self._gtail[0:3]             # {G, D_KL, logP} of the generator step's first pass
+        self._l2 = self._gtail[4:6]             # {W_dist, -} of the generator step (critic forward on xh)
+        self._l2d = self._dtail[0:2]            # {W_dist, gp} of a critic step
+        self._l3b = torch.zeros(3, dtype=p.dtype, device=p.device)   # losses against the shifted target (not reported)
+        self._l3f = torch.zeros(3, dtype=p.dtype, device=p.device)   # forward-only pass of the critic steps
 
     def broadcast_params(self, src=0):
         if self.world > 1:
@@ -82,16 +94,15 @@ class AdvStepper(object):
         be = self.backend
         return be.philox_normal(F, self.seed, self._draws), be.philox_uniform(F, self.seed ^ 0x7157, self._draws)
 
-    def _reduce(self, *bufs):
+    def _reduce(self, buf):
         if self.collective:
-            for b in bufs:
-                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
 
     def _mean(self, t):
-        """A loss vector averaged over ranks (new tensor)."""
+        """A loss vector from a gradient buffer's tail averaged over ranks (new tensor; the SUM arrived with the
+        gradient all-reduce -- no collective here)."""
         t = t.clone()
         if self.collective:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             t /= float(self.world)
         return t
 
@@ -115,16 +126,16 @@ class AdvStepper(object):
             e2, t2 = self._draw(n * F)
         eps = e2 if eps is None else (eps[0] if n == 1 else torch.cat(list(eps)))
         t = t2 if t is None else (t[0] if n == 1 else torch.cat(list(t)))
-        be.loss_fwd(X, Y, eps, out=self._l3)                         # forward only: xh of the current generator
+        be.loss_fwd(X, Y, eps, out=self._l3f)                        # forward only: xh of the current generator
         xh = be.ws_region(n * F, L.MODE_INFER, 'xh').view(n * F, -1)
         for i in range(n):
             lo, hi = i * F, (i + 1) * F
-            cr.critic_fwd_bwd(X[lo:hi], xh[lo:hi], t[lo:hi], self.lam, self.g_d, out=self._l2)
-            self._reduce(self.g_d)
+            cr.critic_fwd_bwd(X[lo:hi], xh[lo:hi], t[lo:hi], self.lam, self.g_d, out=self._l2d)
+            self._reduce(self._dbuf)                                 # gradient + {W_dist, gp}: one collective
             self.applies += 1
             be.adam_range(cr.params, self.g_d, self.m_d, self.v_d, 0, cr.n_params, self.applies, self.lr, self.beta1,
                           self.beta2, self.eps, 1.0 / self.world)
-        l2 = self._mean(self._l2)
+        l2 = self._mean(self._l2d)
         self.status['W_dist'], self.status['gp'] = l2[0], l2[1]
         return l2
 
@@ -139,7 +150,7 @@ class AdvStepper(object):
         target, _ = cr.generator_target(x, xh, self.alpha, out=self._l2)
         # second gradient on the activations of the first pass (a backend without the backward-only entry reruns the step)
         getattr(be, 'train_bwd_target', be.train_fwd_bwd_target)(x, y, eps, target, self.g_g, out=self._l3b)
-        self._reduce(self.g_e, self.g_g)
+        self._reduce(self._gbuf)                                     # both gradients and the loss scalars: one collective
         gs = 1.0 / self.world
         self.applies += 1                                            # opt_e
         for lo, hi in self.enc_ranges:

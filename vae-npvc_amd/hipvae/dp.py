@@ -68,6 +68,8 @@ class Stepper(object):
         self.seed = rank_seed(seed, self.rank, self.world)
         self.overlap = bool(overlap) and hasattr(backend, 'set_bucket_callback')
         self._works = []
+        self._covered = []
+        self._cb_error = None
         self._cb_on = False
 
     def broadcast_params(self, src=0):
@@ -76,6 +78,16 @@ class Stepper(object):
 
     # ------------------------------------------------------------------ bucketed all-reduce
     def _bucket_ready(self, bucket, off, cnt, ready_stream):
+        # This runs as a ctypes callback INSIDE vaenpvc_train_fwd_bwd: ctypes prints and swallows anything raised
+        # here, which would leave step() with a short work list and Adam applied to un-reduced gradients (ranks
+        # diverge silently).  Keep the first exception and re-raise it from step() after the library call returns.
+        try:
+            self._bucket_ready_impl(bucket, off, cnt, ready_stream)
+        except BaseException as ex:       # noqa: BLE001
+            if self._cb_error is None:
+                self._cb_error = ex
+
+    def _bucket_ready_impl(self, bucket, off, cnt, ready_stream):
         n = self.grads.numel()
         if off + cnt == n:
             cnt += self.TAIL                   # the losses travel with the range that ends the buffer
@@ -89,6 +101,19 @@ class Stepper(object):
         else:
             w = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._works.append(w)
+        self._covered.append((off, off + cnt))
+
+    def _check_coverage(self):
+        """The ranges handed to the all-reduce must tile [0, n + TAIL) exactly once (a missed or doubled range would
+        leave part of the gradient un-reduced while Adam still scales it by 1/world)."""
+        end = self.grads.numel() + self.TAIL
+        pos = 0
+        for lo, hi in sorted(self._covered):
+            if lo != pos:
+                raise RuntimeError('gradient all-reduce ranges do not tile the buffer: gap or overlap at %d (next range starts at %d)' % (pos, lo))
+            pos = hi
+        if pos != end:
+            raise RuntimeError('gradient all-reduce ranges cover [0, %d) of %d elements' % (pos, end))
 
     def _set_cb(self, on):
         if on != self._cb_on:
@@ -103,13 +128,25 @@ class Stepper(object):
         use_cb = self.collective and self.overlap
         self._set_cb(use_cb)
         self._works = []
+        self._covered = []
+        self._cb_error = None
         if eps is None:
             loss3 = be.train_fwd_bwd(x, y, None, self.grads, out=self._loss_tail, seed=self.seed,
                                      offset=self.step_count)
         else:
             loss3 = be.train_fwd_bwd(x, y, eps, self.grads, out=self._loss_tail)
+        if self._cb_error is not None:         # raised inside the library callback: nothing may be applied
+            err, self._cb_error = self._cb_error, None
+            for w in self._works:              # (collectives already started still have to be waited for)
+                try:
+                    w.wait()
+                except Exception:              # noqa: BLE001
+                    pass
+            self._works = []
+            raise RuntimeError('gradient-bucket callback failed; the optimiser step was NOT applied') from err
         if self.collective:
             if use_cb:
+                self._check_coverage()
                 for w in self._works:          # current stream waits for every range
                     w.wait()
                 self._works = []

@@ -63,8 +63,21 @@ class VAETrainer(object):
         path = os.path.join(self.dirs['logdir'], 'model.ckpt-{}'.format(st.step_count if step is None else step))
         sd = st.state_dict()
         sd['layout'] = list(st.backend.layout.items()) if hasattr(st.backend, 'layout') else None
+        self._save_source(sd)
         torch.save(sd, path)
         return path
+
+    def _save_source(self, sd):
+        """The input pipeline's state travels with the checkpoint (every rank draws the same global index sequence, so
+        rank 0's state is everybody's): a restored run continues the record sequence instead of replaying it."""
+        src = getattr(self.loss, 'source', None)
+        if src is not None and hasattr(src, 'state_dict'):
+            sd['source'] = src.state_dict()
+
+    def _restore_source(self, sd):
+        src = getattr(self.loss, 'source', None)
+        if src is not None and hasattr(src, 'load_state_dict') and sd.get('source') is not None:
+            src.load_state_dict(sd['source'])
 
     def restore(self, restore_from, ckpt=None):
         """tf.train.Supervisor restore (trainer/vae.py:77-84 + util/wrapper.py:32-62): parameters, the Adam
@@ -74,7 +87,9 @@ class VAETrainer(object):
         path = find_ckpt(restore_from, ckpt)
         if path is None:
             return None
-        self.opt['g'].load_state_dict(read_ckpt(path, getattr(self.opt['g'].backend, 'layout', None)))
+        sd = read_ckpt(path, getattr(self.opt['g'].backend, 'layout', None))
+        self.opt['g'].load_state_dict(sd)
+        self._restore_source(sd)
         return self.opt['g'].step_count
 
     def train(self, nIter, machine=None, summary_op=None, status_secs=60, save_secs=300, summary_secs=120):
@@ -159,6 +174,7 @@ class VAWGANTrainer(VAETrainer):
         sd = st.state_dict()
         sd['layout'] = list(st.backend.layout.items())
         sd['d_layout'] = list(st.critic.layout.items())
+        self._save_source(sd)
         torch.save(sd, path)
         return path
 
@@ -167,10 +183,12 @@ class VAWGANTrainer(VAETrainer):
         path = find_ckpt(restore_from, ckpt)
         if path is None:
             return None
-        self.opt["g"].load_state_dict(read_ckpt(path))
+        sd = read_ckpt(path)
+        self.opt["g"].load_state_dict(sd)
+        self._restore_source(sd)
         return self.opt['g'].step_count
 
-    def train(self, nIter, machine=None, summary_op=None, status_secs=60, save_secs=300):
+    def train(self, nIter, machine=None, summary_op=None, status_secs=60, save_secs=300, summary_secs=120):
         """trainer/vae.py:150-179: `max_iter` iterations of nIterD critic steps + one generator step."""
         st = self.opt['g']
         source = self.loss.source
@@ -184,6 +202,9 @@ class VAWGANTrainer(VAETrainer):
                 self.log.info('restored step {} from {}'.format(step, restore_from))
         st.broadcast_params()
         t = self.arch['training']
+        if st.rank == 0 and self.summary is None and hasattr(st.backend, 'summary'):
+            from util.summary import SummaryWriter          # the Supervisor's summary thread serves this trainer too (trainer/vae.py:160-166)
+            self.summary = SummaryWriter(self.dirs['logdir'], st.backend, secs=summary_secs)
         t_status = t_save = time.time()
         while st.step_count < t['max_iter']:
             # trainer/vae.py:177-178: nIterD critic steps, each on its own batch (dequeued in the same order; the
@@ -192,6 +213,13 @@ class VAWGANTrainer(VAETrainer):
             x, y = source.next_batch()                    # trainer/vae.py:179
             st.generator_step(x, y)
             now = time.time()
+            if self.summary is not None and self.summary.due(now):      # model/vae.py:132-136 summaries, rank 0 only
+                from hipvae import lib as L
+                xh = st.backend.ws_region(x.shape[0], L.MODE_TRAIN, 'xh')
+                v = st.status
+                # SummaryWriter takes {G, D_KL, logP}; this branch has no single G: l_E = -logP + D_KL stands in its place
+                l3 = [float(v['D_KL']) - float(v['logP']), float(v['D_KL']), float(v['logP'])]
+                self.summary.write(st.step_count, l3, x, xh)
             if now - t_status >= status_secs:
                 self._refresh_status()
                 t_status = now

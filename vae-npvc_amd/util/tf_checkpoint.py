@@ -177,6 +177,18 @@ def write_bundle(prefix, tensors):
 
 
 # ---------------------------------------------------------------------------- reference variables <-> flat buffer
+_ENC_CONV = re.compile(r'^(Encoder/Conv2d-(\d+))/(kernel|bias)$')
+
+
+def tf_name(name):
+    """Name of an engine-layout tensor in the reference's TF graph.  They differ only for the encoder convs:
+    conv2d_nchw_layernorm (util/layers.py:55-64) opens tf.variable_scope(name) AND passes name=name to tf.layers.conv2d, so
+    the conv variables are `Encoder/Conv2d-i/Conv2d-i/{kernel,bias}` while the LayerNorm pair sits one scope higher
+    (`Encoder/Conv2d-i/layernorm.{offset,scale}`, util/layers.py:65)."""
+    m = _ENC_CONV.match(name)
+    return '%s/Conv2d-%s/%s' % (m.group(1), m.group(2), m.group(3)) if m else name
+
+
 def import_checkpoint(prefix, layout):
     """TF variables of the reference's graph -> state dict of hipvae.dp.Stepper.  `layout` = Engine.layout
     ({name: (offset, shape)}, names = tf.trainable_variables() of model/vae.py).  Adam slots (`<name>/Adam`,
@@ -185,19 +197,31 @@ def import_checkpoint(prefix, layout):
     t = read_bundle(prefix)
     n = sum(int(np.prod(shape)) for _, shape in layout.values())
     flat = {k: np.zeros(n, np.float32) for k in ('params', 'm', 'v')}
-    missing = [name for name in layout if name not in t]
+    missing = [tf_name(name) for name in layout if tf_name(name) not in t]
     if missing:
         raise KeyError('checkpoint %s lacks %d variables of the ConvVAE, e.g. %s' % (prefix, len(missing), missing[:3]))
+    slots = 0
     for name, (off, shape) in layout.items():
         k = int(np.prod(shape))
-        for dst, key in (('params', name), ('m', name + '/Adam'), ('v', name + '/Adam_1')):
+        tn = tf_name(name)
+        for dst, key in (('params', tn), ('m', tn + '/Adam'), ('v', tn + '/Adam_1')):
             if key in t:
-                a = np.asarray(t[key], np.float32)
-                if a.size != k:
-                    raise ValueError('%s: checkpoint shape %s, model shape %s' % (key, a.shape, shape))
-                flat[dst][off:off + k] = a.reshape(-1)
+                a = np.asarray(t[key])
+                # the SHAPE must match, not only the element count: a transposed kernel would load silently otherwise
+                if tuple(a.shape) != tuple(shape):
+                    raise ValueError('%s: checkpoint shape %s, model shape %s' % (key, tuple(a.shape), tuple(shape)))
+                flat[dst][off:off + k] = a.astype(np.float32).reshape(-1)
+                slots += dst != 'params'
     m = re.search(r'-(\d+)$', prefix)
     step = int(t['global_step']) if 'global_step' in t else (int(m.group(1)) if m else 0)
+    if slots == 0 and step != 0:
+        # parameters only (e.g. a Saver over tf.trainable_variables()): bias-correcting zero moments for t = step would
+        # shrink the first updates by sqrt(1 - b2^t) / (1 - b1^t) of a run that never happened -- restart the optimiser
+        import warnings
+        warnings.warn('checkpoint %s holds no Adam slots: optimiser state reset (step %d -> 0)' % (prefix, step))
+        step = 0
+    elif 0 < slots < 2 * len(layout):
+        raise KeyError('checkpoint %s holds Adam slots for only %d of %d tensors' % (prefix, slots // 2, len(layout)))
     return {'params': torch.from_numpy(flat['params']), 'm': torch.from_numpy(flat['m']), 'v': torch.from_numpy(flat['v']),
             'step': step}
 
@@ -208,11 +232,12 @@ def export_checkpoint(prefix, layout, state, lr_betas=(0.5, 0.999)):
     p, m, v = (np.asarray(state[k], np.float32).reshape(-1) for k in ('params', 'm', 'v'))
     for name, (off, shape) in layout.items():
         k = int(np.prod(shape))
-        tensors[name] = p[off:off + k].reshape(shape)
-        tensors[name + '/Adam'] = m[off:off + k].reshape(shape)
-        tensors[name + '/Adam_1'] = v[off:off + k].reshape(shape)
+        tn = tf_name(name)
+        tensors[tn] = p[off:off + k].reshape(shape)
+        tensors[tn + '/Adam'] = m[off:off + k].reshape(shape)
+        tensors[tn + '/Adam_1'] = v[off:off + k].reshape(shape)
     step = int(state.get('step', 0))
-    tensors['global_step'] = np.array(step, np.int64)
+    tensors['global_step'] = np.array(step, np.int32)      # tf.Variable(0, name='global_step') is int32 (trainer/vae.py:15)
     tensors['beta1_power'] = np.array(lr_betas[0] ** (step + 1), np.float32)     # tf.train.AdamOptimizer non-slot variables
     tensors['beta2_power'] = np.array(lr_betas[1] ** (step + 1), np.float32)
     write_bundle(prefix, tensors)
