@@ -1,0 +1,50 @@
+/*
+ * vaenpvc_debug.h -- developer hooks of libvaenpvc_hip.so (no reference counterpart).
+ *
+ * NOT part of the drop-in boundary (include/vaenpvc.h): a maintainer binding the ConvVAE path needs none of
+ * this.  The parity tests use the selection masks to pin every kernel family against the float64 oracle at
+ * small batch sizes, bench.py uses the timer to report the duration of one kernel site.  The bit assignments
+ * below are per-round tuning state and may change without an ABI version bump.
+ */
+#ifndef VAENPVC_DEBUG_H_
+#define VAENPVC_DEBUG_H_
+
+#include "vaenpvc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Debug/validation hook (no reference counterpart): per-step selection between the tuned
+ * gfx950 kernel (bit set) and the geometry-generic kernel (bit clear) when the context
+ * runs in VAENPVC_IMPL_AUTO on the VCC2016 geometry.  Bits 0..4 = encoder conv i,
+ * 5 = heads, 6 = merge, 7..10 = decoder layer i; one mask for forward steps, one for
+ * backward steps.  Default: all ones.  State of THIS context.
+ * Bit 30 of the forward mask (default set): cleared = use the bf16-split kernels of the last decoder layer at
+ * any batch size (they are selected at >= 16 frames otherwise; parity tests).  Bit 30 of the backward mask
+ * (default set): cleared = launch the weight-gradient kernels on the caller's stream instead of the context's
+ * helper stream (serialised kernels; used by bench.py to time single kernels).
+ * Bit 29 of either mask (default set): cleared = keep the dense-shaped layers (heads, merge, encoder layer 4) on the
+ * exact-fp32 MFMA kernels instead of the bf16-split plane GEMM kernels, which are selected at >= 1024 frames;
+ * bit 28 (default set): cleared = select them at any batch size (parity tests).
+ * Bit 27 (default set): cleared = no conv site on the view-GEMM kernels; bit 26 (default set): cleared = EVERY conv
+ * site of encoder layers 1-3 / decoder layers 0-2 on the view GEMMs instead of the measured per-precision site set.
+ * Bits 25 / 22 (default set): cleared = every thin / medium conv site on the fused kernels (gfx950_fconv.h,
+ * gfx950_fconv_r.h) at any batch size; bit 24 of the backward mask: the thin weight gradients on gfx950_fwgrad.h;
+ * bit 23: encoder layer 0 on its wave-per-frame kernels.  (The bits 22-28 exist for the parity tests, which pin every
+ * kernel family against the float64 restatement at small batch sizes; defaults select by measurement.) */
+int vaenpvc_set_tuned_masks(vaenpvc_ctx* ctx, uint32_t fwd_mask, uint32_t bwd_mask);
+
+/* Measurement hook (no reference counterpart): brackets every launch of ONE tagged
+ * kernel with a hipEvent pair on the launch stream, so bench.py can report that
+ * kernel's average duration over the timed region.  Tags are the kernel-site names
+ * listed in DESIGN.md (e.g. "dec3_fwd").  NULL or "" disables.  State of THIS context. */
+int vaenpvc_timer_select(vaenpvc_ctx* ctx, const char* tag);
+/* Synchronises the recorded events (blocks the host), returns the summed milliseconds and the
+ * number of launches since the last read, and resets the accumulator. */
+int vaenpvc_timer_read(vaenpvc_ctx* ctx, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAENPVC_DEBUG_H_ */

@@ -16,7 +16,7 @@ echo "bench rc=$?" >> $OUT/bench.err
 trace() {  # name, bench args
   local name=$1; shift
   rm -rf /tmp/rp_$name
-  (cd /tmp && VAENPVC_SIDE_STREAM=0 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/rp_$name -- python $ROOT/bench.py --no-cpu-baseline --no-literal --no-modes "$@" > $OUT/$name.log 2>&1)
+  (cd /tmp && VAENPVC_SIDE_STREAM=0 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/rp_$name -- python $ROOT/bench.py --no-cpu-baseline --no-literal --no-modes --no-convert "$@" > $OUT/$name.log 2>&1)
   local db=$(find /tmp/rp_$name -name '*.db' | head -1)
   if [ -n "$db" ]; then python $ROOT/scripts/rocpd_stats.py $db 80 > $OUT/trace_$name.txt; else echo "no db for $name" > $OUT/trace_$name.txt; fi
 }

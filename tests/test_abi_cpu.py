@@ -13,8 +13,8 @@ from hipvae.engine import arch_to_struct, glorot_init
 from oracle import convvae_oracle as O
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, 'include', 'vaenpvc.h')).read()
+def header_functions(name='vaenpvc.h'):
+    src = open(os.path.join(ROOT, 'include', name)).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     return sorted(set(re.findall(r'\b(vaenpvc_[a-z0-9_]+)\s*\(', src)))
 
@@ -27,6 +27,12 @@ def test_library_loads_and_exports_every_header_symbol():
         assert hasattr(lib, n), 'missing export %s' % n
         assert n in L.SIGNATURES, 'binding table lacks %s' % n
     assert lib.vaenpvc_abi_version() == L.ABI_VERSION
+    # the developer hooks live in their own header (round-2 verdict: tuning bits do not belong in the public one)
+    dbg = header_functions('vaenpvc_debug.h')
+    assert dbg == ['vaenpvc_set_tuned_masks', 'vaenpvc_timer_read', 'vaenpvc_timer_select']
+    assert not set(dbg) & set(names)
+    for n in dbg:
+        assert hasattr(lib, n) and n in L.SIGNATURES
 
 
 def make_ctx(arch):

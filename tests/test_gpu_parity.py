@@ -487,13 +487,11 @@ def _golden_large(F, seed, precision, tag, tol_act=TOL_ACT, tol_grad=TOL_GRAD):
             fails.append('grad_l2 %s %.3e' % (name, e))
         k = min(64, n)
         e = np.abs(gi[sample_idx(n, 64)] - gold['grad_samples'][i][:k]).max() / max(gold['grad_absmax'][i], 1e-12)
-        # ONE bar for every batch size.  Where float32 arithmetic itself cannot meet it -- the fixture records the error
-        # of the float32 CPU restatement (the stand-in for the reference's fp32 path) on the same entries, which is
-        # 1e-4 .. 1e-3 on the first encoder layers at these sizes -- at most HALF of that stand-in's error is allowed.
-        bar = max(tol_grad, 0.5 * float(gold['ref32_grad_err'][i]))
-        report(tag + 'grad_samples ' + name + ' (fp32 stand-in: %.1e)' % gold['ref32_grad_err'][i], e, bar)
-        if e > bar:
-            fails.append('grad_samples %s %.3e > %.3e' % (name, e, bar))
+        # ONE bar for every batch size (the fixture's frames are kink-safe: the float32 CPU restatement's own error on
+        # these entries, recorded as ref32_grad_err, is <= 4e-7, so nothing but arithmetic is being compared)
+        report(tag + 'grad_samples ' + name + ' (fp32 stand-in: %.1e)' % gold['ref32_grad_err'][i], e, tol_grad)
+        if e > tol_grad:
+            fails.append('grad_samples %s %.3e > %.3e' % (name, e, tol_grad))
     return fails
 
 
@@ -510,11 +508,74 @@ def test_benchmarked_batch_sizes_against_oracle_fixture(F, seed, precision):
 
 
 
-def test_bf16_mode_against_oracle_fixture():
+UNFILTERED_SHARE_SLACK = 2e-4     # share of sampled entries (of ~100 k) the HIP path may have above the bar beyond the fp32 CPU restatement's share
+
+
+def test_unfiltered_benchmark_batch_statistics():
+    """The benchmarked batch size on PLAIN seeded inputs (32 768 frames, lrelu kink units included; fixture
+    tests/golden/make_golden_unfiltered.py).  A unit whose LayerNorm output lies within rounding of 0 takes slope 1 in
+    one evaluation and 0.02 in another, so on such a batch no float32-class implementation can be held to a fixed
+    max-norm gradient bar against float64.  The bound is therefore statistical and relative to
+    what float32 arithmetic itself does on the SAME batch -- the fixture holds, for up to 4096 sampled entries of
+    every gradient tensor, the float64 oracle and the oracle's float32 PyTorch-CPU restatement:
+      (1) losses and the sampled z_mu / z_lv / xh rows: the ordinary 1e-4 bar (a kink does not move activations);
+      (2) per tensor: max error of the HIP path on the sampled entries (relative to the tensor's largest entry)
+          <= max(2e-4, the float32 CPU restatement's max error on the same entries);
+      (3) over all sampled entries: the share of entries off by more than 2e-4 of their tensor's scale is at most
+          the float32 CPU restatement's share + UNFILTERED_SHARE_SLACK;
+      (4) the median error stays at rounding level (<= 2e-5): kinks are rare events, not a shift."""
+    from hipvae import lib as L
+    F, seed = 32768, 23
+    arch = ARCHS['vcc']
+    gold = np.load(os.path.join(GOLDEN, 'vcc2016_F%d_seed%d_unfiltered.npz' % (F, seed)))
+    eng = make_engine('vcc', 'auto', precision='bf16x2')
+    P = O.init_params(arch, seed)
+    x, y, eps = O.make_inputs(arch, F, seed)
+    l3, g = run_train(eng, P, x, y, eps)
+    fails, tag = [], 'unfiltered F%d ' % F
+    check(tag + 'loss3', l3, gold['loss3'], TOL_ACT, fails)
+    fidx = torch.as_tensor(gold['frame_idx'], device=eng.device)
+    for k, width in (('z_mu', 128), ('z_lv', 128), ('xh', 513)):
+        got = eng.ws_region(F, L.MODE_TRAIN, k).view(F, width)[fidx].cpu().numpy()
+        check(tag + k + ' rows', got, gold[k + '_rows'], TOL_ACT, fails)
+    assert np.isfinite(g).all()
+    off = 0
+    errs, errs32 = [], []
+    for i, (name, (poff, shape)) in enumerate(eng.layout.items()):
+        n = int(np.prod(shape))
+        c = int(gold['grad_sample_counts'][i])
+        idx = sample_idx(n, 4096)
+        assert idx.size == c
+        want = gold['grad_samples'][off:off + c]
+        scale = max(float(gold['grad_absmax'][i]), 1e-300)
+        e = np.abs(g[poff:poff + n].astype(np.float64)[idx] - want) / scale
+        e32 = np.abs(gold['grad_samples_ref32'][off:off + c] - want) / scale
+        bar = max(TOL_GRAD, float(e32.max()))
+        report(tag + 'grad ' + name + ' (fp32 CPU restatement: %.1e)' % e32.max(), float(e.max()), bar)
+        if e.max() > bar:
+            fails.append('grad %s %.3e > %.3e' % (name, e.max(), bar))
+        errs.append(e)
+        errs32.append(e32)
+        off += c
+    errs, errs32 = np.concatenate(errs), np.concatenate(errs32)
+    share, share32 = float((errs > TOL_GRAD).mean()), float((errs32 > TOL_GRAD).mean())
+    report(tag + 'share of entries over 2e-4 (fp32 CPU restatement: %.2e)' % share32, share, share32 + UNFILTERED_SHARE_SLACK)
+    if share > share32 + UNFILTERED_SHARE_SLACK:
+        fails.append('share over the bar %.3e > %.3e' % (share, share32 + UNFILTERED_SHARE_SLACK))
+    med = float(np.median(errs))
+    report(tag + 'median entry error (fp32 CPU restatement: %.1e)' % np.median(errs32), med, 2e-5)
+    if med > 2e-5:
+        fails.append('median error %.3e' % med)
+    assert not fails, '\n'.join(fails)
+
+
+@pytest.mark.parametrize('F,seed', [(8192, 21), (32768, 22)])
+def test_bf16_mode_against_oracle_fixture(F, seed):
     """BASELINE.json config 2 names bf16: the reduced-precision mode (plain bf16 operands on the GEMM-shaped
     kernels of the bf16 path, fp32 accumulation, fp32 LayerNorm statistics / losses / Adam) is reported beside the
-    fp32-class default, never instead of it, and its tolerance is stated separately."""
-    fails = _golden_large(8192, 21, 'bf16', 'golden F8192 bf16-mode ', BF16_TOL_ACT, BF16_TOL_GRAD)
+    fp32-class default, never instead of it, and its tolerance is stated separately (3e-2 activations / losses, 6e-2
+    gradients) -- at the benchmarked batch size too."""
+    fails = _golden_large(F, seed, 'bf16', 'golden F%d bf16-mode ' % F, BF16_TOL_ACT, BF16_TOL_GRAD)
     assert not fails, '\n'.join(fails)
 
 

@@ -1,4 +1,4 @@
-// abi.hip -- the extern "C" surface declared in include/vaenpvc.h.
+// abi.hip -- the extern "C" surface declared in include/vaenpvc.h (+ the developer hooks of include/vaenpvc_debug.h).
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -7,6 +7,7 @@
 #include <memory>
 #include <mutex>
 
+#include "../../include/vaenpvc_debug.h"
 #include "kernels.h"
 
 using namespace vaenpvc;

@@ -117,7 +117,7 @@ class Engine(object):
         return int(self.lib.vaenpvc_get_precision(self.ctx))
 
     def set_tuned_masks(self, fwd=0xffffffff, bwd=0xffffffff):
-        """Per-step tuned/generic kernel selection of THIS engine's context (include/vaenpvc.h)."""
+        """Per-step tuned/generic kernel selection of THIS engine's context (developer hook, include/vaenpvc_debug.h)."""
         L.check(self.lib.vaenpvc_set_tuned_masks(self.ctx, fwd & 0xffffffff, bwd & 0xffffffff), 'set_tuned_masks')
 
     def timer_select(self, tag):
