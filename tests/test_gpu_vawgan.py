@@ -20,7 +20,8 @@ from oracle import philox_ref
 pytestmark = pytest.mark.gpu
 
 TOL_VALUE = 1e-4     # losses, critic values
-TOL_GRAD = 3e-4      # gradients, relative to the tensor's largest entry (second-order terms included)
+TOL_GRAD = 2e-4      # gradients, relative to the tensor's largest entry (second-order terms included): the ConvVAE bar
+                     # (measured worst 4.5e-5, gpurun_out/parity_report.txt)
 
 
 def worst_ok(tag, worst, tol=None):

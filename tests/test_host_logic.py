@@ -306,12 +306,16 @@ def test_tf_checkpoint_bundle_roundtrip_and_import(tmp_path):
 def test_bounded_shuffler_state_roundtrip():
     """A checkpointed shuffler continues the SAME record sequence (round-2 advisor: a restored run replayed the first
     batches of the original one)."""
-    import pickle
     from analyzer import BoundedShuffler
     a = BoundedShuffler([50, 70, 30], capacity=64, min_after_dequeue=32, seed=5)
     for _ in range(7):
         a.next(16)
-    sd = pickle.loads(pickle.dumps(a.state_dict()))       # survives torch.save / pickle
+    import io
+    import torch
+    buf = io.BytesIO()
+    torch.save({'source': {'shuffler': a.state_dict()}}, buf)
+    buf.seek(0)
+    sd = torch.load(buf, map_location='cpu')['source']['shuffler']     # torch.load's weights_only default accepts it
     want = [a.next(16) for _ in range(20)]
     b = BoundedShuffler([50, 70, 30], capacity=64, min_after_dequeue=32, seed=999)   # another seed: the state decides
     b.load_state_dict(sd)

@@ -124,16 +124,18 @@ class BoundedShuffler(object):
         """Everything the next draw depends on: a restored run continues the SAME record sequence instead of replaying
         the first batches of the original run (the reference's queues are not checkpointed either, but they are not
         seeded: a restarted TF run sees fresh shuffles, never the same ones again)."""
+        # (builtin types and tensors only: the checkpoint stays loadable with torch.load's weights_only default)
         return {'rng_files': self.rng_files.bit_generator.state, 'rng': self.rng.bit_generator.state,
-                'pool': self.pool.copy(), 'pending': self._pending.copy(), 'sizes': list(self.sizes)}
+                'pool': torch.from_numpy(self.pool.copy()), 'pending': torch.from_numpy(self._pending.copy()),
+                'sizes': list(self.sizes)}
 
     def load_state_dict(self, sd):
         if list(sd['sizes']) != self.sizes:
             raise ValueError('shuffler state belongs to another file list')
         self.rng_files.bit_generator.state = sd['rng_files']
         self.rng.bit_generator.state = sd['rng']
-        self.pool = np.asarray(sd['pool'], np.int64).copy()
-        self._pending = np.asarray(sd['pending'], np.int64).copy()
+        self.pool = np.asarray(sd['pool'], dtype=np.int64).copy()
+        self._pending = np.asarray(sd['pending'], dtype=np.int64).copy()
 
 
 class FrameStore(object):
