@@ -1,0 +1,136 @@
+// frame_emu.cpp -- HOST emulation of the small-batch frame kernels (vae-npvc_amd/csrc/gfx950_frame.h), test
+// infrastructure only.  The header is written against a phase runner and a 16-byte load, so the very source the GPU
+// executes is compiled here with g++ (FRAME_EMU): a phase = a loop over the 1024 thread ids, LDS = a heap array.  The
+// CPU test-suite checks the emulated passes against the float64 oracle (tests/test_frame_emu.py): indexing, tilings,
+// halos and the algebra of every stage are pinned before a GPU ever runs them.  Nothing in the product links this file.
+#define FRAME_EMU 1
+#include "../../vae-npvc_amd/csrc/gfx950_frame.h"
+
+#include <vector>
+
+using namespace vaenpvc::frame;
+
+struct EmuRunner {
+  template <class F>
+  void phase(F&& f) {
+    for (int t = 0; t < NT; ++t) f(t);
+  }
+};
+
+static POff make_off(const int* p) {
+  POff o;
+  int i = 0;
+  o.emb = p[i++];
+  for (int l = 0; l < 5; ++l) {
+    o.ew[l] = p[i++];
+    o.eb[l] = p[i++];
+    o.ebeta[l] = p[i++];
+    o.egamma[l] = p[i++];
+  }
+  o.wmu = p[i++];
+  o.bmu = p[i++];
+  o.wlv = p[i++];
+  o.blv = p[i++];
+  o.wz = p[i++];
+  o.bz = p[i++];
+  o.wy = p[i++];
+  o.by = p[i++];
+  o.bm = p[i++];
+  for (int l = 0; l < 4; ++l) {
+    o.dw[l] = p[i++];
+    o.db[l] = p[i++];
+    if (l < 3) {
+      o.dbeta[l] = p[i++];
+      o.dgamma[l] = p[i++];
+    }
+  }
+  return o;
+}
+
+// tensor order of the offset table `t` (floats into `ws`)
+enum { T_ENC_A = 0, T_ENC_ST = 5, T_Z_MU = 10, T_Z_LV, T_Z, T_EPS_OUT, T_H, T_DEC_A, T_DEC_ST = T_DEC_A + 3, T_XH = T_DEC_ST + 3,
+       T_KL, T_NLL, T_D_XH, T_D_DEC_A, T_D_H = T_D_DEC_A + 3, T_D_Z_MU, T_D_Z_LV, T_D_ENC_A, T_LNP = T_D_ENC_A + 5, T_PK, T_G, T_COUNT };
+
+extern "C" {
+
+int frame_emu_tensor_count() { return T_COUNT; }
+int frame_emu_pack_floats() { return Pk::total; }
+int frame_emu_lnp_c() { return LNP_C; }
+int frame_emu_lds_floats() { return L_TOTAL; }
+
+void frame_emu_pack(const float* P, const int* poff, float* pk) {
+  POff o = make_off(poff);
+  for (int i = 0; i < Pk::total; ++i) pk[i] = pack_src(P, o, i);
+}
+
+// mode: FM_* bits of the forward pass; do_bwd: also run the backward pass
+int frame_emu_run(const float* P, const int* poff, const float* x, const float* target, const long long* y, const float* eps,
+                  const float* z_in, int ny, int F, int mode, int do_bwd, float* ws, const long long* t) {
+  POff o = make_off(poff);
+  std::vector<float> lds(L_TOTAL, 0.f);
+  EmuRunner run;
+  FwdArgs a{};
+  a.P = P;
+  a.pk = ws + t[T_PK];
+  a.off = o;
+  a.x = x;
+  a.target = target ? target : x;
+  a.y = reinterpret_cast<const int64_t*>(y);
+  a.eps = eps;
+  a.z_in = z_in;
+  a.ny = ny;
+  a.F = F;
+  a.mode = mode;
+  a.invF = 1.0f / (float)F;
+  for (int i = 0; i < 5; ++i) {
+    a.enc_a[i] = ws + t[T_ENC_A + i];
+    a.enc_st[i] = ws + t[T_ENC_ST + i];
+  }
+  a.z_mu = ws + t[T_Z_MU];
+  a.z_lv = ws + t[T_Z_LV];
+  a.z = ws + t[T_Z];
+  a.eps_out = ws + t[T_EPS_OUT];
+  a.h = ws + t[T_H];
+  for (int i = 0; i < 3; ++i) {
+    a.dec_a[i] = ws + t[T_DEC_A + i];
+    a.dec_st[i] = ws + t[T_DEC_ST + i];
+  }
+  a.xh = ws + t[T_XH];
+  a.kl_f = ws + t[T_KL];
+  a.nll_f = ws + t[T_NLL];
+  a.d_xh = ws + t[T_D_XH];
+  for (int f = 0; f < F; ++f)
+    frame_fwd(run, lds.data(), a, f, [&](int ff, int d) { return eps ? eps[(size_t)ff * 128 + d] : 0.f; });
+  if (!do_bwd) return 0;
+  BwdArgs b{};
+  b.P = P;
+  b.pk = a.pk;
+  b.off = o;
+  b.target = a.target;
+  b.eps = ws + t[T_EPS_OUT];
+  b.F = F;
+  b.invF = a.invF;
+  for (int i = 0; i < 5; ++i) {
+    b.enc_a[i] = a.enc_a[i];
+    b.enc_st[i] = a.enc_st[i];
+    b.d_enc_a[i] = ws + t[T_D_ENC_A + i];
+  }
+  b.z_mu = a.z_mu;
+  b.z_lv = a.z_lv;
+  for (int i = 0; i < 3; ++i) {
+    b.dec_a[i] = a.dec_a[i];
+    b.dec_st[i] = a.dec_st[i];
+    b.d_dec_a[i] = ws + t[T_D_DEC_A + i];
+  }
+  b.xh = a.xh;
+  b.d_xh = a.d_xh;
+  b.d_h = ws + t[T_D_H];
+  b.d_z = nullptr;
+  b.d_z_mu = ws + t[T_D_Z_MU];
+  b.d_z_lv = ws + t[T_D_Z_LV];
+  b.lnp = ws + t[T_LNP];
+  for (int f = 0; f < F; ++f) frame_bwd(run, lds.data(), b, f);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+"""GPU parity of the SMALL-BATCH path: whole frames per workgroup (vae-npvc_amd/csrc/gfx950_frame.h), the default for
+batches of <= 512 frames -- the reference's own batch sizes (16: architecture-vae-vcc2016.json:23-28; 256: BASELINE
+config 2).  Same bars as tests/test_gpu_parity.py, same float64 oracle; the host emulation of the same source is
+checked on the CPU by tests/test_frame_emu.py."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err
+from oracle import convvae_oracle as O
+from test_gpu_parity import (ARCHS, TOL_ACT, TOL_GRAD, check, compare_everything, make_engine, oracle_case, report,
+                             run_train, upload)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('F,seed', [(1, 7), (16, 3), (37, 5), (256, 2), (512, 11)])
+def test_frame_path_every_tensor_and_gradient(F, seed):
+    """forward tensors (pre-LN outputs, statistics, z, h, xh, losses) and all 44 gradients against the float64 oracle,
+    lrelu kink units pinned to the GPU's branch (as everywhere in the parity tests)"""
+    eng = make_engine('vcc', 'auto', frame=True)
+    fails = compare_everything(eng, F, seed, 'frame F%d ' % F)
+    assert not fails, '\n'.join(fails)
+
+
+def test_frame_path_is_what_runs_by_default_and_can_be_switched_off():
+    """default masks select the frame kernels at 16 frames; clearing bit 21 selects the layered ones; both meet the
+    oracle and each other (A/B on one engine)"""
+    from hipvae import Engine
+    F, seed = 16, 3
+    P, x, y, eps, R = oracle_case(F, seed)
+    eng = Engine(ARCHS['vcc'])
+    l_a, g_a = run_train(eng, P, x, y, eps)
+    eng.timer_select('frame_fwd')
+    run_train(eng, P, x, y, eps)
+    ms, n = eng.timer_read()
+    eng.timer_select(None)
+    assert n == 1, 'the frame forward kernel did not run at 16 frames with default settings'
+    eng.set_tuned_masks(0xffffffff & ~(1 << 21), 0xffffffff & ~(1 << 21))
+    eng.timer_select('frame_fwd')
+    l_b, g_b = run_train(eng, P, x, y, eps)
+    _, n = eng.timer_read()
+    eng.timer_select(None)
+    assert n == 0
+    assert rel_err(l_a, l_b) < 1e-5 and rel_err(g_a, g_b) < 2e-4
+
+
+@pytest.mark.parametrize('F', [1, 9, 300])
+def test_frame_conversion_path(F):
+    """convert.py:79-89 at small batches: encode -> z_mu, decode(z_mu, target speaker), and the forward-only loss"""
+    arch = ARCHS['vcc']
+    eng = make_engine('vcc', 'auto', frame=True)
+    P = O.init_params(arch, 7)
+    x, y, eps = O.make_inputs(arch, F, 7)
+    eng.load_flat(O.flatten_params(P))
+    xt = torch.tensor(x, device=eng.device)
+    z_mu, z_lv = eng.encode(xt.view(F, 1, -1, 1), want_lv=True)
+    trg = arch['y_dim'] - 1
+    yt = torch.full((F,), trg, dtype=torch.int64, device=eng.device)
+    xh = eng.decode(z_mu, yt)
+    R = O.np_forward(arch, P, x, np.full(F, trg), None)
+    fails = []
+    tag = 'frame convert F%d ' % F
+    check(tag + 'z_mu', z_mu.cpu().numpy(), R['z_mu'], TOL_ACT, fails)
+    check(tag + 'z_lv', z_lv.cpu().numpy(), R['z_lv'], TOL_ACT, fails)
+    check(tag + 'xh', xh.cpu().numpy(), R['xh'], TOL_ACT, fails)
+    R2 = O.np_forward(arch, P, x, y, eps)
+    l3 = eng.loss_fwd(xt, torch.tensor(y, device=eng.device), torch.tensor(eps, device=eng.device)).cpu().numpy()
+    check(tag + 'loss_fwd', l3, np.array([R2['G'], R2['D_KL'], R2['logP']]), TOL_ACT, fails)
+    assert not fails, '\n'.join(fails)
+
+
+def test_frame_backward_against_a_shifted_target():
+    """vaenpvc_train_fwd_bwd_target / _bwd_target (the VAWGAN generator step's second gradient) on the frame kernels:
+    the log-density is evaluated against `target`, the backward-only entry reuses the activations in place"""
+    arch = ARCHS['vcc']
+    F, seed = 16, 4
+    eng = make_engine('vcc', 'auto', frame=True)
+    P, x, y, eps, R = oracle_case(F, seed)
+    rng = np.random.default_rng(1)
+    tgt = (x + 0.1 * rng.standard_normal(x.shape)).astype(np.float32)
+    xt, yt, et = upload(eng, P, x, y, eps)
+    tt = torch.tensor(tgt, device=eng.device)
+    g1 = torch.full((eng.n_params,), float('nan'), device=eng.device)
+    g2 = torch.full((eng.n_params,), float('nan'), device=eng.device)
+    eng.train_fwd_bwd_target(xt, yt, et, tt, g1)
+    ga = torch.full((eng.n_params,), float('nan'), device=eng.device)
+    eng.train_fwd_bwd(xt, yt, et, ga)                 # plain step first ...
+    eng.train_bwd_target(xt, yt, et, tt, g2)          # ... then only the backward pass against the target
+    torch.cuda.synchronize()
+    assert torch.isfinite(g1).all() and torch.isfinite(g2).all()
+    assert rel_err(g2.cpu().numpy(), g1.cpu().numpy()) < 1e-5
+    # oracle: gradient of -logP(target | xh) + D_KL
+    Pt = O.torch_params(P, torch.float64, requires_grad=True)
+    X, Y, E, T = (torch.tensor(x, dtype=torch.float64), torch.tensor(y), torch.tensor(eps, dtype=torch.float64),
+                  torch.tensor(tgt, dtype=torch.float64))
+    z_mu, z_lv, _ = O.torch_encode(arch, Pt, X)
+    z = z_mu + E * torch.sqrt(torch.exp(z_lv))
+    xh, _ = O.torch_decode(arch, Pt, z, Y)
+    kld = 0.5 * ((0.0 - z_lv) + (torch.exp(z_lv) + z_mu ** 2) / (1.0 + O.EPSILON) - 1.0)
+    lp = -0.5 * (O.LOG_2PI + (T - xh) ** 2 / (1.0 + O.EPSILON))
+    (-lp.sum(-1).mean() + kld.sum(-1).mean()).backward()
+    fails = []
+    g = g1.cpu().numpy()
+    for name, (off, shape) in eng.layout.items():
+        n = int(np.prod(shape))
+        check('frame target grad ' + name, g[off:off + n].reshape(shape), Pt[name].grad.numpy(), TOL_GRAD, fails)
+    assert not fails, '\n'.join(fails)
+
+
+def test_frame_step_is_repeatable_and_graph_capturable():
+    """two runs of the same step give the same losses and forward tensors bit for bit (no atomics in the forward or the
+    input-gradient chain); a captured step replays"""
+    from hipvae.dp import Stepper
+    arch = ARCHS['vcc']
+    F = 16
+    eng = make_engine('vcc', 'auto', frame=True)
+    P, x, y, eps, R = oracle_case(F, 3)
+    l1, g1 = run_train(eng, P, x, y, eps)
+    from hipvae import lib as L
+    xh1 = eng.ws_region(F, L.MODE_TRAIN, 'xh').clone()
+    da1 = eng.ws_region(F, L.MODE_TRAIN, 'd_enc_a0').clone()
+    l2, g2 = run_train(eng, P, x, y, eps)
+    assert np.array_equal(l1, l2) and torch.equal(xh1, eng.ws_region(F, L.MODE_TRAIN, 'xh'))
+    assert torch.equal(da1, eng.ws_region(F, L.MODE_TRAIN, 'd_enc_a0'))
+    st = Stepper(eng, 1e-4, 0.5, 0.999, seed=5)
+    xt, yt = torch.tensor(x, device=eng.device), torch.tensor(y, device=eng.device)
+    p0 = eng.params.clone()
+    for _ in range(3):
+        st.step(xt, yt)
+    p_eager = eng.params.clone()
+    eng.params.copy_(p0)
+    st2 = Stepper(eng, 1e-4, 0.5, 0.999, seed=5)
+    st2.capture(xt, yt)
+    for _ in range(3):
+        st2.replay()
+    torch.cuda.synchronize()
+    d = (eng.params - p0).abs().max().item()
+    assert d > 0 and (eng.params - p_eager).abs().max().item() <= 2e-3 * d + 1e-9

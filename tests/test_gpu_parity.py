@@ -37,10 +37,16 @@ def check(tag, got, want, tol, fails):
 ARCHS = {'vcc': load_arch(), 'small': SMALL_ARCH}
 
 
-def make_engine(which, impl, masks=(0xffffffff, 0xffffffff), precision=None):
+FRAME_BIT = 1 << 21      # whole-frame-per-workgroup kernels for batches <= 512 (gfx950_frame.h); cleared = layered kernels
+
+
+def make_engine(which, impl, masks=(0xffffffff, 0xffffffff), precision=None, frame=False):
+    """frame=False (default here): the LAYERED kernels at every batch size -- the tests of this file pin each layered
+    kernel family at small batch sizes; the small-batch frame kernels have their own tests (tests/test_gpu_frame.py)."""
     from hipvae import Engine
     eng = Engine(ARCHS[which], impl=impl, precision=precision)
-    eng.set_tuned_masks(masks[0], masks[1])      # state of THIS engine's context (nothing process-global)
+    f, b = (masks[0], masks[1]) if frame else (masks[0] & ~FRAME_BIT, masks[1] & ~FRAME_BIT)
+    eng.set_tuned_masks(f, b)      # state of THIS engine's context (nothing process-global)
     return eng
 
 

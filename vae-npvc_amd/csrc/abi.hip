@@ -103,6 +103,8 @@ static int resolve(vaenpvc_ctx* c, int64_t F, int mode, void* d_ws, size_t ws_by
     else if (n == "pl_da4") w->pl_da4 = p;
     else if (n == "toep_yp") w->toep_yp = p;
     else if (n == "scratch") { w->scratch = p; w->scratch_floats = r.count; }
+    else if (n == "frame_pk") w->frame_pk = p;
+    else if (n == "frame_lnp") w->frame_lnp = p;
   }
   return 0;
 }
@@ -252,7 +254,10 @@ int vaenpvc_encode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_x
   int rc = resolve(ctx, F, VAENPVC_MODE_INFER, d_ws, ws_bytes, &w);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (use_tuned(ctx)) tuned::encoder_fwd(ctx->m, d_params, d_x, F, w, s);
+  if (use_tuned(ctx) && tuned::frame_fwd_on(F)) {
+    tuned::frame_pack(ctx->m, d_params, w, nullptr, s);
+    tuned::frame_forward(ctx->m, d_params, d_x, nullptr, nullptr, nullptr, nullptr, nullptr, F, w, nullptr, tuned::FRAME_ENC, nullptr, s);
+  } else if (use_tuned(ctx)) tuned::encoder_fwd(ctx->m, d_params, d_x, F, w, s);
   else generic::encoder_fwd(ctx->m, d_params, d_x, F, w, s);
   size_t nb = (size_t)F * ctx->m.z * 4;
   if (hipMemcpyAsync(d_z_mu, w.z_mu, nb, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(VAENPVC_E_HIP, "copy z_mu");
@@ -268,14 +273,25 @@ int vaenpvc_decode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_z
   int rc = resolve(ctx, F, VAENPVC_MODE_INFER, d_ws, ws_bytes, &w);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (use_tuned(ctx)) tuned::decoder_fwd(ctx->m, d_params, d_z, d_y, F, w, d_xh, s);
+  if (use_tuned(ctx) && tuned::frame_fwd_on(F)) {
+    tuned::frame_pack(ctx->m, d_params, w, nullptr, s);
+    tuned::frame_forward(ctx->m, d_params, nullptr, nullptr, d_y, nullptr, nullptr, d_z, F, w, d_xh, tuned::FRAME_DEC, nullptr, s);
+  } else if (use_tuned(ctx)) tuned::decoder_fwd(ctx->m, d_params, d_z, d_y, F, w, d_xh, s);
   else generic::decoder_fwd(ctx->m, d_params, d_z, d_y, F, w, d_xh, s);
   return check_launch("decode_fwd");
 }
 
 static int fwd_all(vaenpvc_ctx* ctx, const float* P, const float* x, const int64_t* y, const float* eps,
                    const PhiloxKey* key, int64_t F, const Ws& w, bool want_grad, float* loss3, hipStream_t s,
-                   const float* target = nullptr) {
+                   const float* target = nullptr, bool allow_frame = true) {
+  if (allow_frame && use_tuned(ctx) && tuned::frame_fwd_on(F)) {
+    // small batch: one workgroup per frame carries it through the whole forward pass (gfx950_frame.h)
+    tuned::frame_pack(ctx->m, P, w, nullptr, s);
+    tuned::frame_forward(ctx->m, P, x, target, y, eps, key, nullptr, F, w, nullptr,
+                         tuned::FRAME_ENC | tuned::FRAME_SAMPLE | tuned::FRAME_DEC | tuned::FRAME_LOSS | (want_grad ? tuned::FRAME_GRAD : 0),
+                         loss3, s);
+    return 0;
+  }
   if (use_tuned(ctx)) tuned::encoder_fwd(ctx->m, P, x, F, w, s);
   else generic::encoder_fwd(ctx->m, P, x, F, w, s);
   generic::reparam_fwd(ctx->m, eps, key, F, w, s);
@@ -320,10 +336,15 @@ static int train_impl(vaenpvc_ctx* ctx, const float* d_params, const float* d_x,
   int rc = resolve(ctx, F, VAENPVC_MODE_TRAIN, d_ws, ws_bytes, &w);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  fwd_all(ctx, d_params, d_x, d_y, d_eps, key, F, w, true, d_loss3, s, d_target);
+  // small batches: both passes on the whole-frame kernels, or neither (the layered backward pass reads operand copies
+  // only the layered forward pass leaves behind)
+  const bool frame = use_tuned(ctx) && tuned::frame_fwd_on(F) && tuned::frame_bwd_on(F);
+  fwd_all(ctx, d_params, d_x, d_y, d_eps, key, F, w, true, d_loss3, s, d_target, frame);
   const float* eps_bwd = key ? w.eps : d_eps;   // (the seeded sampler stored its draw in the workspace)
   ctx->rt.bucket_next = 0;
-  if (use_tuned(ctx)) {
+  if (frame) {
+    tuned::backward_frame(ctx->m, d_params, d_x, d_target, d_y, eps_bwd, F, w, d_grads, s);
+  } else if (use_tuned(ctx)) {
     tuned::backward(ctx->m, d_params, d_x, d_y, eps_bwd, F, w, d_grads, s);
   } else {
     generic::backward(ctx->m, d_params, d_x, d_y, eps_bwd, F, w, d_grads, s);
@@ -363,7 +384,10 @@ int vaenpvc_train_bwd_target(vaenpvc_ctx* ctx, const float* d_params, const floa
   hipStream_t s = (hipStream_t)stream;
   generic::loss_fwd(ctx->m, d_target, F, w, true, d_loss3, s);   // new d(xh) from the activations already in place
   ctx->rt.bucket_next = 0;
-  if (use_tuned(ctx)) {
+  if (use_tuned(ctx) && tuned::frame_fwd_on(F) && tuned::frame_bwd_on(F)) {
+    tuned::frame_pack(ctx->m, d_params, w, nullptr, s);      // (the forward pass ran in an earlier call: cheap to redo)
+    tuned::backward_frame(ctx->m, d_params, d_x, d_target, d_y, d_eps, F, w, d_grads, s);
+  } else if (use_tuned(ctx)) {
     tuned::backward(ctx->m, d_params, d_x, d_y, d_eps, F, w, d_grads, s);
   } else {
     generic::backward(ctx->m, d_params, d_x, d_y, d_eps, F, w, d_grads, s);

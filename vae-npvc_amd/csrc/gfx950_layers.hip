@@ -1184,6 +1184,85 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   if (fork) rt().stream_dep(s2, s);  // join: everything after backward (Adam) sees all gradients
 }
 
+
+// ---------------------------------------------------------------- backward of a small batch (gfx950_frame.h)
+// The input-gradient chain with every LayerNorm backward runs as ONE launch, one frame per workgroup (frame_backward);
+// what is left are the weight gradients, which depend on nothing but tensors that launch wrote: they are dealt to the
+// caller's stream and the context's helper stream and run next to each other.
+void backward_frame(const Model& m, const float* P, const float* x, const float* target, const int64_t* y, const float* eps,
+                    int64_t F64, const Ws& w, float* G, hipStream_t s) {
+  const int F = (int)F64;
+  (void)hipMemsetAsync(G, 0, (size_t)m.n_params * 4, s);
+  frame_backward(m, P, target ? target : x, eps, F, w, G, s);
+  hipStream_t side = bwd_on(30) ? rt().side_stream() : nullptr;
+  const bool fork = side != nullptr;
+  hipStream_t s2 = fork ? side : s;
+  if (fork) rt().stream_dep(s, s2);
+  const int WGS = 512;
+  // ---- helper stream: the decoder's weight gradients
+  {
+    TnArgs a = tn_args(w.dec_y, 4104, w.d_xh, 513, 4096, 512, F, G + m.dec[3].w_off, 0);
+    VAENPVC_TIMED("dec3_wgrad", s2, launch_tngemm(a, true, kchunks_for(F, 32 * 4), s2));
+    int ech = cmax(1, cmin_(cdiv(F, 64), 128));
+    int efc = rup(cdiv(F, ech), 64);
+    hipLaunchKernelGGL(k_toep_wgrad_row512, dim3((unsigned)cdiv(F, efc), 3), dim3(256), 0, s2, w.dec_y, w.d_xh, G + m.dec[3].w_off, F, efc);
+    hipLaunchKernelGGL(k_sum_all_atomic, dim3((unsigned)cmin_(1024, cdiv(F * 513, 1024))), dim3(256), 0, s2, w.d_xh,
+                       (int64_t)F * 513, G + m.dec[3].b_off);
+    for (int i = 2; i >= 0; --i) {
+      const ConvL& l = m.dec[i];
+      WgArgs a2{w.d_dec_a[i], nullptr, nullptr, nullptr, i ? w.dec_a[i - 1] : w.h, i ? w.dec_st[i - 1] : nullptr,
+                i ? P + m.dec[i - 1].gamma_off : nullptr, i ? P + m.dec[i - 1].beta_off : nullptr, G + l.w_off, F, 0};
+      if (i == 2) VAENPVC_TIMED("dec2_wgrad", s2, launch_convwgrad<WD2>(a2, WGS, s2));
+      else if (i == 1) VAENPVC_TIMED("dec1_wgrad", s2, launch_convwgrad<WD1>(a2, WGS, s2));
+      else VAENPVC_TIMED("dec0_wgrad", s2, launch_convwgrad<WD0>(a2, WGS, s2));
+    }
+  }
+  // ---- caller's stream: merge, heads, encoder
+  {
+    TnArgs a = tn_args(w.z, 128, w.d_h, 1539, 128, 1539, F, G + m.wz_off, 1539);
+    VAENPVC_TIMED("merge_wgrad", s, launch_tngemm(a, false, kchunks_for(F, 13), s));
+    float* Sg = w.scratch + Pk::merge_s;
+    (void)hipMemsetAsync(Sg, 0, (size_t)MERGE_NY * 1539 * 4, s);
+    int ch = cmax(1, cmin_(cdiv(F, 64), 128)), fc = cdiv(F, ch);
+    hipLaunchKernelGGL(k_segsum_atomic<MERGE_NY>, dim3((unsigned)cdiv(1539, 256), (unsigned)cdiv(F, fc)), dim3(256), 0, s, w.d_h, y, 1539, F, fc, Sg);
+    const int nb_w = cdiv(128 * 1539, 256), nb_e = cdiv(MERGE_NY * 128, 4), nb_b = cdiv(1539, 256);
+    hipLaunchKernelGGL(k_merge_small<MERGE_NY>, dim3((unsigned)(nb_w + nb_e + nb_b)), dim3(256), 0, s, Sg, P + m.emb_off, P + m.wy_off, 128,
+                       1539, G + m.wy_off, G + m.emb_off, G + m.bz_off, G + m.by_off, G + m.bm_off, nb_w, nb_e);
+    // (recomputes d(z_mu), d(z_lv) from d(z) exactly as the frame kernel did; what is needed here are the two bias sums)
+    const int rch = cmax(1, cmin_(cdiv(F, 32), 1024)), rfc = cdiv(F, rch);
+    hipLaunchKernelGGL(k_reparam_bwd_colsum, dim3((unsigned)cdiv(F, rfc)), dim3(256), 0, s, w.d_z, w.z_mu, w.z_lv, eps, w.d_z_mu,
+                       w.d_z_lv, G + m.bmu_off, G + m.blv_off, (int)F, rfc, 1.0f / (float)F);
+    const ConvL& l4 = m.enc[4];
+    TnArgs h = tn_args(w.enc_a[4], 768, w.d_z_mu, 128, 768, 128, F, G + m.wmu_off, 128);
+    h.st = w.enc_st[4];
+    h.gamma = P + l4.gamma_off;
+    h.beta = P + l4.beta_off;
+    h.lndiv = 3;
+    VAENPVC_TIMED("heads_wgrad", s, launch_tngemm(h, false, kchunks_for(F, 6), s));
+    h.Y = w.d_z_lv;
+    h.C = G + m.wlv_off;
+    launch_tngemm(h, false, kchunks_for(F, 6), s);
+    auto wg_enc = [&](int i) {
+      const ConvL &l = m.enc[i], &pl = m.enc[i - 1];
+      return WgArgs{w.enc_a[i - 1], w.enc_st[i - 1], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[i], nullptr, nullptr, nullptr,
+                    G + l.w_off, F, 0};
+    };
+    VAENPVC_TIMED("enc4_wgrad", s, launch_convwgrad<WE4>(wg_enc(4), WGS, s));
+    VAENPVC_TIMED("enc3_wgrad", s, launch_convwgrad<WE3>(wg_enc(3), WGS, s));
+    VAENPVC_TIMED("enc2_wgrad", s, launch_convwgrad<WE2>(wg_enc(2), WGS, s));
+    VAENPVC_TIMED("enc1_wgrad", s, launch_convwgrad<WE1>(wg_enc(1), WGS, s));
+    WgArgs a0{x, nullptr, nullptr, nullptr, w.d_enc_a[0], nullptr, nullptr, nullptr, G + m.enc[0].w_off, F, 0};
+    VAENPVC_TIMED("enc0_wgrad", s, launch_convwgrad<WE0>(a0, WGS, s));
+  }
+  if (fork) rt().stream_dep(s2, s);
+  // gradient ranges for the data-parallel host: everything is enqueued, report the four ranges on the caller's stream
+  Runtime& r = rt();
+  if (r.bucket_cb) {
+    const int64_t cut[5] = {m.n_params, m.dec[0].w_off, m.wz_off, m.wmu_off, 0};
+    for (int b = 0; b < 4; ++b) r.bucket_cb(r.bucket_user, r.bucket_next++, cut[b + 1], cut[b] - cut[b + 1], (void*)s);
+  }
+}
+
 }  // namespace tuned
 }  // namespace vaenpvc
 

@@ -30,6 +30,8 @@ struct Ws {  // resolved workspace pointers (see workspace_layout)
   float* toep_yp;  // bf16 planes of dec_y
   float* scratch;
   int64_t scratch_floats;
+  float* frame_pk;   // packed weight copies of the small-batch frame kernels (gfx950_frame.h: Pk)
+  float* frame_lnp;  // per-frame channel sums of their LayerNorm backward
 };
 
 // sets the thread-local message vaenpvc_last_error() returns; returns `code` (abi.hip)
@@ -102,6 +104,23 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
                  float* xh_out, hipStream_t s, bool weights_packed = false);
 void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F,
               const Ws& w, float* G, hipStream_t s);
+// ---- small-batch path: whole frames per workgroup (gfx950_frame.hip)
+constexpr int FRAME_ENC = 1, FRAME_SAMPLE = 2, FRAME_DEC = 4, FRAME_LOSS = 8, FRAME_GRAD = 16;   // = frame::FM_*
+constexpr int64_t FRAME_CAP = 1024;          // largest batch the workspace reserves its per-frame sums for
+int64_t frame_pack_floats();
+int64_t frame_lnp_floats(int64_t F);
+bool frame_fwd_on(int64_t F);
+bool frame_bwd_on(int64_t F);
+void frame_pack(const Model& m, const float* P, const Ws& w, float* G_zero, hipStream_t s);
+void frame_forward(const Model& m, const float* P, const float* x, const float* target, const int64_t* y, const float* eps,
+                   const PhiloxKey* key, const float* z_in, int64_t F, const Ws& w, float* xh_out, int mode, float* loss3,
+                   hipStream_t s);
+// input-gradient chain + LayerNorm parameter / conv-bias gradients (the weight gradients are the caller's)
+void frame_backward(const Model& m, const float* P, const float* target, const float* eps, int64_t F, const Ws& w, float* G,
+                    hipStream_t s);
+// the whole backward pass of a small batch: frame_backward + every weight gradient (gfx950_layers.hip)
+void backward_frame(const Model& m, const float* P, const float* x, const float* target, const int64_t* y, const float* eps,
+                    int64_t F, const Ws& w, float* G, hipStream_t s);
 }  // namespace tuned
 
 }  // namespace vaenpvc

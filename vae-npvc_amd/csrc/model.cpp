@@ -161,6 +161,10 @@ std::vector<Region> workspace_layout(const Model& m, int64_t F, int mode, int64_
   add("nll_f", F);
   // packed / transposed weight copies of the tuned kernels (F-independent)
   add("scratch", 8 * m.n_params + 65536);
+  if (m.is_vcc2016) {  // small-batch frame kernels (gfx950_frame.h): packed weight copies, per-frame LayerNorm channel sums
+    add("frame_pk", tuned::FRAME_PK_FLOATS);
+    add("frame_lnp", std::min<int64_t>(F, tuned::FRAME_LNP_CAP) * 3 * tuned::FRAME_LNP_C);
+  }
   if (mode == VAENPVC_MODE_TRAIN) {
     add("d_xh", F * m.H);
     for (int i = m.n_dec - 2; i >= 0; --i) add("d_dec_a" + std::to_string(i), F * m.dec[i].cout * m.dec[i].hout);

@@ -43,6 +43,8 @@ struct Runtime {
   bool toep_wgrad_f32 = false;  // VAENPVC_TOEP_WGRAD_F32
   bool toep_wgrad_k16 = false;  // VAENPVC_TOEP_WGRAD_K16: 16-frame chunks in the bf16 weight gradient (A/B measurements)
   bool side_enabled = true;     // VAENPVC_SIDE_STREAM=0 disables the internal weight-gradient stream
+  int frame_max = 512;          // VAENPVC_FRAME_MAX: largest batch on the whole-frame-per-workgroup kernels (gfx950_frame.h); 0 = never.
+                                // Bit 21 of a mask cleared = the layered kernels for that pass of this context (A/B, parity tests)
   // ---- device binding: created lazily on the device that is current at the first launch
   int device = -1;
   hipStream_t s2 = nullptr;

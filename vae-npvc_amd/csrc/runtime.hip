@@ -23,6 +23,7 @@ RtScope::~RtScope() { tl_rt = prev; }
 //   VAENPVC_CV_SITES=<mask>               conv sites on the view GEMMs (runtime.h: cv_sites; bit = CV_* / 12 + CW_* site)
 //   VAENPVC_FC_SITES / _FCR_SITES / _FW_SITES=<mask>   thin / medium conv sites and thin weight gradients on the fused kernels
 //   VAENPVC_TOEP_ZC=<n>                   frame chunks of the Toeplitz weight gradient (A/B measurements)
+//   VAENPVC_FRAME_MAX=<n>                 largest batch on the whole-frame-per-workgroup kernels (0 = never, <= 1024)
 //   VAENPVC_TOEP_WGRAD_K16, VAENPVC_TN_K16, VAENPVC_TN_XCD=0|1   earlier schedules / tile orders of the weight-gradient GEMMs (A/B)
 void Runtime::read_env() {
   if (const char* e = getenv("VAENPVC_FWD_MASK")) fwd_mask = (unsigned)strtoul(e, nullptr, 0);
@@ -32,6 +33,7 @@ void Runtime::read_env() {
   toep_wgrad_f32 = getenv("VAENPVC_TOEP_WGRAD_F32") != nullptr;
   if (const char* e = getenv("VAENPVC_TOEP_ZC")) toep_zc = atoi(e) > 0 ? atoi(e) : 4;
   if (const char* e = getenv("VAENPVC_TN_XCD")) tn_xcd = atoi(e);
+  if (const char* e = getenv("VAENPVC_FRAME_MAX")) frame_max = atoi(e) < 0 ? 0 : (atoi(e) > 1024 ? 1024 : atoi(e));
   tn_k16 = getenv("VAENPVC_TN_K16") != nullptr;
   toep_wgrad_k16 = getenv("VAENPVC_TOEP_WGRAD_K16") != nullptr;
   if (const char* e = getenv("VAENPVC_CV_SITES")) cv_sites_env = (long)strtoul(e, nullptr, 0);
