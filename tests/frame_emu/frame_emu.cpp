@@ -15,6 +15,36 @@ struct EmuRunner {
   void phase(F&& f) {
     for (int t = 0; t < NT; ++t) f(t);
   }
+  // dst[wave] = sum over the wave's 64 lanes of f(tid) (the device version does it with wave shuffles)
+  template <class F>
+  void reduce(float* dst, F&& f) {
+    float w[NW];
+    for (int wv = 0; wv < NW; ++wv) {
+      float s = 0.f;
+      for (int l = 0; l < 64; ++l) s += f(wv * 64 + l);
+      w[wv] = s;
+    }
+    for (int wv = 0; wv < NW; ++wv) dst[wv] = w[wv];      // (stored after every thread ran: as behind the device's barrier)
+  }
+  template <class F>
+  void reduce2(float* da, float* db, F&& f) {
+    float wa[NW], wb[NW];
+    for (int wv = 0; wv < NW; ++wv) {
+      float sa = 0.f, sb = 0.f;
+      for (int l = 0; l < 64; ++l) {
+        float a = 0.f, b = 0.f;
+        f(wv * 64 + l, a, b);
+        sa += a;
+        sb += b;
+      }
+      wa[wv] = sa;
+      wb[wv] = sb;
+    }
+    for (int wv = 0; wv < NW; ++wv) {
+      da[wv] = wa[wv];
+      db[wv] = wb[wv];
+    }
+  }
 };
 
 static POff make_off(const int* p) {
@@ -99,6 +129,7 @@ int frame_emu_run(const float* P, const int* poff, const float* x, const float* 
   a.kl_f = ws + t[T_KL];
   a.nll_f = ws + t[T_NLL];
   a.d_xh = ws + t[T_D_XH];
+  frame_prologue(run, lds.data(), P, o);
   for (int f = 0; f < F; ++f)
     frame_fwd(run, lds.data(), a, f, [&](int ff, int d) { return eps ? eps[(size_t)ff * 128 + d] : 0.f; });
   if (!do_bwd) return 0;

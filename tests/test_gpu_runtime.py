@@ -116,7 +116,7 @@ def test_two_contexts_on_two_host_threads():
     F = 96
     x, y, eps = O.make_inputs(arch, F, 4)
     L_, G = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64)
-    cfgs = [dict(masks=(0xffffffff, 0xffffffff), precision='bf16x2', tag='dec3_fwd'),
+    cfgs = [dict(masks=(0xffffffff, 0xffffffff), precision='bf16x2', tag='frame_fwd'),      # (96 frames: the whole-frame kernels)
             dict(masks=(0xbfffffff, 0x000007ff), precision='bf16x3', tag='enc4_fwd')]
     engines, results, errors = [], [None, None], []
     for c in cfgs:

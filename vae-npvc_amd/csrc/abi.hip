@@ -255,7 +255,7 @@ int vaenpvc_encode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_x
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (use_tuned(ctx) && tuned::frame_fwd_on(F)) {
-    tuned::frame_pack(ctx->m, d_params, w, nullptr, s);
+    tuned::frame_pack(ctx->m, d_params, w, nullptr, nullptr, 0, s);
     tuned::frame_forward(ctx->m, d_params, d_x, nullptr, nullptr, nullptr, nullptr, nullptr, F, w, nullptr, tuned::FRAME_ENC, nullptr, s);
   } else if (use_tuned(ctx)) tuned::encoder_fwd(ctx->m, d_params, d_x, F, w, s);
   else generic::encoder_fwd(ctx->m, d_params, d_x, F, w, s);
@@ -274,7 +274,7 @@ int vaenpvc_decode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_z
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (use_tuned(ctx) && tuned::frame_fwd_on(F)) {
-    tuned::frame_pack(ctx->m, d_params, w, nullptr, s);
+    tuned::frame_pack(ctx->m, d_params, w, nullptr, nullptr, 0, s);
     tuned::frame_forward(ctx->m, d_params, nullptr, nullptr, d_y, nullptr, nullptr, d_z, F, w, d_xh, tuned::FRAME_DEC, nullptr, s);
   } else if (use_tuned(ctx)) tuned::decoder_fwd(ctx->m, d_params, d_z, d_y, F, w, d_xh, s);
   else generic::decoder_fwd(ctx->m, d_params, d_z, d_y, F, w, d_xh, s);
@@ -283,10 +283,13 @@ int vaenpvc_decode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_z
 
 static int fwd_all(vaenpvc_ctx* ctx, const float* P, const float* x, const int64_t* y, const float* eps,
                    const PhiloxKey* key, int64_t F, const Ws& w, bool want_grad, float* loss3, hipStream_t s,
-                   const float* target = nullptr, bool allow_frame = true) {
+                   const float* target = nullptr, bool allow_frame = true, float* zero_g = nullptr) {
   if (allow_frame && use_tuned(ctx) && tuned::frame_fwd_on(F)) {
-    // small batch: one workgroup per frame carries it through the whole forward pass (gfx950_frame.h)
-    tuned::frame_pack(ctx->m, P, w, nullptr, s);
+    // small batch: one workgroup per frame carries it through the whole forward pass (gfx950_frame.h); the launch that
+    // packs the weights also zero-fills what the backward pass accumulates into
+    int nz2 = 0;
+    float* z2 = zero_g ? tuned::frame_zero_region(w, &nz2) : nullptr;
+    tuned::frame_pack(ctx->m, P, w, zero_g, z2, nz2, s);
     tuned::frame_forward(ctx->m, P, x, target, y, eps, key, nullptr, F, w, nullptr,
                          tuned::FRAME_ENC | tuned::FRAME_SAMPLE | tuned::FRAME_DEC | tuned::FRAME_LOSS | (want_grad ? tuned::FRAME_GRAD : 0),
                          loss3, s);
@@ -339,11 +342,11 @@ static int train_impl(vaenpvc_ctx* ctx, const float* d_params, const float* d_x,
   // small batches: both passes on the whole-frame kernels, or neither (the layered backward pass reads operand copies
   // only the layered forward pass leaves behind)
   const bool frame = use_tuned(ctx) && tuned::frame_fwd_on(F) && tuned::frame_bwd_on(F);
-  fwd_all(ctx, d_params, d_x, d_y, d_eps, key, F, w, true, d_loss3, s, d_target, frame);
+  fwd_all(ctx, d_params, d_x, d_y, d_eps, key, F, w, true, d_loss3, s, d_target, frame, frame ? d_grads : nullptr);
   const float* eps_bwd = key ? w.eps : d_eps;   // (the seeded sampler stored its draw in the workspace)
   ctx->rt.bucket_next = 0;
   if (frame) {
-    tuned::backward_frame(ctx->m, d_params, d_x, d_target, d_y, eps_bwd, F, w, d_grads, s);
+    tuned::backward_frame(ctx->m, d_params, d_x, d_target, d_y, eps_bwd, F, w, d_grads, s, /*g_zeroed=*/true);
   } else if (use_tuned(ctx)) {
     tuned::backward(ctx->m, d_params, d_x, d_y, eps_bwd, F, w, d_grads, s);
   } else {
@@ -385,8 +388,10 @@ int vaenpvc_train_bwd_target(vaenpvc_ctx* ctx, const float* d_params, const floa
   generic::loss_fwd(ctx->m, d_target, F, w, true, d_loss3, s);   // new d(xh) from the activations already in place
   ctx->rt.bucket_next = 0;
   if (use_tuned(ctx) && tuned::frame_fwd_on(F) && tuned::frame_bwd_on(F)) {
-    tuned::frame_pack(ctx->m, d_params, w, nullptr, s);      // (the forward pass ran in an earlier call: cheap to redo)
-    tuned::backward_frame(ctx->m, d_params, d_x, d_target, d_y, d_eps, F, w, d_grads, s);
+    int nz2 = 0;
+    float* z2 = tuned::frame_zero_region(w, &nz2);
+    tuned::frame_pack(ctx->m, d_params, w, d_grads, z2, nz2, s);      // (the forward pass ran in an earlier call: cheap to redo)
+    tuned::backward_frame(ctx->m, d_params, d_x, d_target, d_y, d_eps, F, w, d_grads, s, /*g_zeroed=*/true);
   } else if (use_tuned(ctx)) {
     tuned::backward(ctx->m, d_params, d_x, d_y, d_eps, F, w, d_grads, s);
   } else {

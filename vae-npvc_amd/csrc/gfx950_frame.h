@@ -31,11 +31,17 @@
 struct fr_f4 {
   float x, y, z, w;
 };
-FR_DEV fr_f4 fr_load4(const float* p) {
+FR_DEV fr_f4 fr_load4(const float* base, unsigned off) {
   fr_f4 v;
-  std::memcpy(&v, p, 16);
+  std::memcpy(&v, base + off, 16);
   return v;
 }
+#define FR_G(T) T*
+#define FR_UNIFORM(i) (i)
+template <class T>
+inline T* fr_g(T* p) { return p; }
+template <class T>
+inline T* fr_l(T* p) { return p; }
 #define FR_UNROLL
 #define FR_NOUNROLL
 #define FR_STAGE inline
@@ -48,12 +54,45 @@ FR_DEV fr_f4 fr_load4(const float* p) {
 #endif
 #define FR_RESTRICT __restrict__
 typedef float4 fr_f4;
-FR_DEV fr_f4 fr_load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// Address spaces.  The stages are real function calls, so a pointer read from the argument block is GENERIC to the
+// compiler and every access through it becomes a flat_load / flat_store (slower, and it ties the LDS and vector-memory
+// wait counters together: weight loads then serialise with LDS traffic).  Neither a cast round trip nor an assumption
+// survives to the address-space inference here, so the global pointers are TYPED: FR_G(T) is a pointer to T in global
+// memory (address space 1), fr_g() casts a generic pointer to it, fr_l() re-derives an LDS pointer.
+#define FR_G(T) T __attribute__((address_space(1)))*
+// (every pointer of the argument block is wave-uniform: through readfirstlane it lives in scalar registers instead of a
+//  VGPR pair that is spilled and re-read from scratch behind every barrier)
+template <class T>
+__device__ __forceinline__ FR_G(T) fr_g(T* p) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return (FR_G(T))(((unsigned long long)hi << 32) | lo);
+}
+#define FR_UNIFORM(i) ((int)__builtin_amdgcn_readfirstlane((unsigned)(i)))
+template <class T>
+__device__ __forceinline__ T* fr_l(T* p) {
+  return (T*)(__attribute__((address_space(3))) T*)p;
+}
+typedef float fr_v4 __attribute__((ext_vector_type(4)));
+// 16-byte load at a wave-UNIFORM base + a 32-bit per-lane element offset: one global_load_dwordx4 with the base in scalar
+// registers and ONE address VGPR (a 64-bit per-lane pointer per load costs two VGPRs each: the conv tiles spilled)
+__device__ __forceinline__ fr_f4 fr_load4(FR_G(const float) base, unsigned off) {
+  // (the byte offset is formed in 32 bits: a 64-bit scaled index cannot be proven to fit the instruction's 32-bit offset)
+  const fr_v4 v = *(FR_G(const fr_v4))((FR_G(const char))base + (off << 2));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 #define FR_UNROLL _Pragma("unroll")
 #define FR_NOUNROLL _Pragma("unroll 1")
 // a pass is a chain of STAGES (real function calls): inlined into one body, the compiler hoists every stage's address
 // arithmetic to the top of the kernel and spills ~250 registers; a call boundary keeps each stage's values its own
 #define FR_STAGE __device__ __attribute__((noinline))
+#endif
+
+// FR_PREFETCH=1: the conv tiles keep the next channel's taps in a second register set while the current channel's
+// products run.  Measured inside the passes (not in isolation) it does not pay: the second set pushes the stage functions
+// over 128 registers and the accumulators spill inside the channel loop (encoder layer 3: 14k -> 40k clocks).
+#ifndef FR_PREFETCH
+#define FR_PREFETCH 0
 #endif
 
 namespace vaenpvc {
@@ -72,10 +111,19 @@ constexpr int imin_(int a, int b) { return a < b ? a : b; }
 // ------------------------------------------------------------------------------------------------ LDS map (floats)
 constexpr int BUF = 4864;             // one activation buffer (largest: 8 x 513 outputs; inputs with halos: see *_HP below)
 constexpr int PART = 24576;           // partial sums of the K-split products / staged Toeplitz taps
-constexpr int L_BUFX = 0, L_BUFY = BUF, L_PART = 2 * BUF, L_RED = L_PART + PART, L_VEC = L_RED + 2048 + 128;
-constexpr int L_TOTAL = L_VEC + 1024;                 // 37 504 floats = 150 016 bytes: one workgroup per CU
-// inside the reduction scratch: [0,1024) and [1024,2048) first-stage partials, then second stages and {mean, rstd, s1/n, s2/n}
-constexpr int R_REDB = 1024, R_RED2 = 2048, R_RED2B = 2048 + 32, R_ST = 2048 + 64;
+constexpr int L_BUFX = 0, L_BUFY = BUF, L_PART = 2 * BUF, L_RED = L_PART + PART, L_VEC = L_RED + 128, L_ARGS = L_VEC + 1024;
+constexpr int ARGS_FLOATS = 160;                      // the pass's argument block, copied once from the kernel arguments
+constexpr int L_CH = L_ARGS + ARGS_FLOATS;            // per-channel vectors of the 8 normalised layers: [3][LNP_C] = bias | scale | offset
+constexpr int L_TOTAL = L_CH + 3 * 552;               // 37 400 floats = 149 600 bytes: one workgroup per CU
+// reduction scratch: per-wave sums of the wave-reduction phases (16 waves), two pairs of slots, and {mean, rstd}
+constexpr int NW = NT / 64;
+constexpr int R_S1 = 0, R_S2 = 16, R_S3 = 32, R_S4 = 48, R_ST = 64;
+FR_DEV float sum16(const float* p) {
+  float s = 0.f;
+  FR_UNROLL
+  for (int i = 0; i < NW; ++i) s += p[i];
+  return s;
+}
 
 // ------------------------------------------------------------------------------------------------ strided conv
 // out[o][j] = sum_{c} sum_{t} W[(t*CC + c)*OO + o] * in[c][S*j - PAD + t]
@@ -95,7 +143,7 @@ struct SConv {
 };
 
 template <class T>
-FR_DEV void sconv_part(int tid, const float* FR_RESTRICT in, const float* FR_RESTRICT W, float* FR_RESTRICT part) {
+FR_DEV void sconv_part(int tid, const float* FR_RESTRICT in, FR_G(const float) W, float* FR_RESTRICT part) {
   if (tid >= T::NTH) return;
   const int og = tid % T::OG, r = tid / T::OG, jg = r % T::JG, ks = r / T::JG;
   const int j0 = jg * T::JT;
@@ -105,23 +153,48 @@ FR_DEV void sconv_part(int tid, const float* FR_RESTRICT in, const float* FR_RES
     FR_UNROLL
     for (int jj = 0; jj < T::JT; ++jj) acc[q][jj] = 0.f;
   const int c0 = ks * T::CPS, c1 = imin_(T::CC, c0 + T::CPS);
-  FR_NOUNROLL      // (unrolled, the compiler hoists every channel's loads and spills: one channel's window + taps at a time)
-  for (int c = c0; c < c1; ++c) {
+  // one channel's taps are in registers while the previous channel's products run (the loop is otherwise a chain of
+  // L2 round trips: measured 2-3x the time of the FMAs at 2-4 waves per SIMD)
+  auto loadw = [&](int c, fr_f4 (&w)[T::K]) {
+    const unsigned off = (unsigned)(c * T::OO + 4 * og);      // per-lane part; the tap stride goes into the scalar base
+    FR_UNROLL
+    for (int t = 0; t < T::K; ++t) w[t] = fr_load4(W + (size_t)t * T::CC * T::OO, off);
+  };
+  auto comp = [&](int c, const fr_f4 (&w)[T::K]) {
     float win[T::WIN];
     const float* ir = in + c * T::HP + T::S * j0;
     FR_UNROLL
     for (int i = 0; i < T::WIN; ++i) win[i] = ir[i];
     FR_UNROLL
     for (int t = 0; t < T::K; ++t) {
-      const fr_f4 w = fr_load4(W + (size_t)(t * T::CC + c) * T::OO + 4 * og);
       FR_UNROLL
       for (int jj = 0; jj < T::JT; ++jj) {
         const float v = win[T::S * jj + t];
-        acc[0][jj] += w.x * v;
-        acc[1][jj] += w.y * v;
-        acc[2][jj] += w.z * v;
-        acc[3][jj] += w.w * v;
+        acc[0][jj] += w[t].x * v;
+        acc[1][jj] += w[t].y * v;
+        acc[2][jj] += w[t].z * v;
+        acc[3][jj] += w[t].w * v;
       }
+    }
+  };
+  if constexpr (FR_PREFETCH && T::K <= 7) {
+    fr_f4 wa[T::K], wb[T::K];
+    int c = c0;
+    if (c < c1) loadw(c, wa);
+    FR_NOUNROLL
+    for (; c + 2 <= c1; c += 2) {
+      loadw(c + 1, wb);
+      comp(c, wa);
+      if (c + 2 < c1) loadw(c + 2, wa);
+      comp(c + 1, wb);
+    }
+    if (c < c1) comp(c, wa);
+  } else {       // nine taps: two sets of them do not fit beside the accumulators (128 registers at 16 waves)
+    FR_NOUNROLL
+    for (int c = c0; c < c1; ++c) {
+      fr_f4 wa[T::K];
+      loadw(c, wa);
+      comp(c, wa);
     }
   }
   FR_UNROLL
@@ -171,7 +244,7 @@ struct TConv {
 };
 
 template <class T>
-FR_DEV void tconv_part(int tid, const float* FR_RESTRICT in, const float* FR_RESTRICT W, float* FR_RESTRICT part) {
+FR_DEV void tconv_part(int tid, const float* FR_RESTRICT in, FR_G(const float) W, float* FR_RESTRICT part) {
   if (tid >= T::NTH) return;
   using PH = typename T::PH;
   const int og = tid % T::OG, r_ = tid / T::OG, qg = r_ % T::QG, ks = r_ / T::QG;
@@ -184,8 +257,12 @@ FR_DEV void tconv_part(int tid, const float* FR_RESTRICT in, const float* FR_RES
       FR_UNROLL
       for (int e = 0; e < 4; ++e) acc[r][qq][e] = 0.f;
   const int c0 = ks * T::CPS, c1 = imin_(T::CC, c0 + T::CPS);
-  FR_NOUNROLL
-  for (int c = c0; c < c1; ++c) {
+  auto loadw = [&](int c, fr_f4 (&w)[T::K]) {
+    const unsigned off = (unsigned)(c * T::OO + 4 * og);      // per-lane part; the tap stride goes into the scalar base
+    FR_UNROLL
+    for (int t = 0; t < T::K; ++t) w[t] = fr_load4(W + (size_t)t * T::CC * T::OO, off);
+  };
+  auto comp = [&](int c, const fr_f4 (&w)[T::K]) {
     float win[T::WIN];                       // win[i] = in[c][q0 - HL + i]
     const float* ir = in + c * T::HP + q0;   // (row index of position j is j + HL)
     FR_UNROLL
@@ -195,16 +272,35 @@ FR_DEV void tconv_part(int tid, const float* FR_RESTRICT in, const float* FR_RES
       FR_UNROLL
       for (int m = 0; m < PH::cnt(r); ++m) {
         const int t = PH::u(r) + T::S * m;
-        const fr_f4 w = fr_load4(W + (size_t)(t * T::CC + c) * T::OO + 4 * og);
         FR_UNROLL
         for (int qq = 0; qq < T::QT; ++qq) {
           const float v = win[qq + PH::m0(r) - m + T::HL];
-          acc[r][qq][0] += w.x * v;
-          acc[r][qq][1] += w.y * v;
-          acc[r][qq][2] += w.z * v;
-          acc[r][qq][3] += w.w * v;
+          acc[r][qq][0] += w[t].x * v;
+          acc[r][qq][1] += w[t].y * v;
+          acc[r][qq][2] += w[t].z * v;
+          acc[r][qq][3] += w[t].w * v;
         }
       }
+    }
+  };
+  if constexpr (FR_PREFETCH && T::K <= 7) {
+    fr_f4 wa[T::K], wb[T::K];
+    int c = c0;
+    if (c < c1) loadw(c, wa);
+    FR_NOUNROLL
+    for (; c + 2 <= c1; c += 2) {
+      loadw(c + 1, wb);
+      comp(c, wa);
+      if (c + 2 < c1) loadw(c + 2, wa);
+      comp(c + 1, wb);
+    }
+    if (c < c1) comp(c, wa);
+  } else {       // nine taps: two sets of them do not fit beside the accumulators (128 registers at 16 waves)
+    FR_NOUNROLL
+    for (int c = c0; c < c1; ++c) {
+      fr_f4 wa[T::K];
+      loadw(c, wa);
+      comp(c, wa);
     }
   }
   FR_UNROLL
@@ -230,7 +326,7 @@ struct Dense4 {
   static_assert(NN % 4 == 0 && LDW % 4 == 0 && NTH <= NT && KS * NN <= PART, "Dense4 tiling");
 };
 template <class T>
-FR_DEV void dense4_part(int tid, const float* FR_RESTRICT v, const float* FR_RESTRICT W, float* FR_RESTRICT part) {
+FR_DEV void dense4_part(int tid, const float* FR_RESTRICT v, FR_G(const float) W, float* FR_RESTRICT part) {
   if (tid >= T::NTH) return;
   const int ng = tid % T::NG, ks = tid / T::NG;
   const int k0 = ks * T::KPS, k1 = imin_(T::KK, k0 + T::KPS);
@@ -239,7 +335,7 @@ FR_DEV void dense4_part(int tid, const float* FR_RESTRICT v, const float* FR_RES
   for (; k + 8 <= k1; k += 8) {          // eight independent 16-byte loads in flight per thread
     fr_f4 w[8];
     FR_UNROLL
-    for (int u = 0; u < 8; ++u) w[u] = fr_load4(W + (size_t)(k + u) * T::LDW + 4 * ng);
+    for (int u = 0; u < 8; ++u) w[u] = fr_load4(W, (unsigned)((k + u) * T::LDW + 4 * ng));
     FR_UNROLL
     for (int u = 0; u < 8; ++u) {
       const float x = v[k + u];
@@ -250,7 +346,7 @@ FR_DEV void dense4_part(int tid, const float* FR_RESTRICT v, const float* FR_RES
     }
   }
   for (; k < k1; ++k) {
-    const fr_f4 w = fr_load4(W + (size_t)k * T::LDW + 4 * ng);
+    const fr_f4 w = fr_load4(W, (unsigned)(k * T::LDW + 4 * ng));
     const float x = v[k];
     a0 += w.x * x;
     a1 += w.y * x;
@@ -264,26 +360,27 @@ FR_DEV void dense4_part(int tid, const float* FR_RESTRICT v, const float* FR_RES
   p[3] = a3;
 }
 
-// merge (model/vae.py:51-61): h[n] = sum_k z[k] Wz[k][n] + sum_k e[k] Wy[k][n]; rows of 1539 floats are not 16-byte
-// aligned, so lanes run along n with 4-byte loads (coalesced); a thread owns n = t, t + 512, t + 1024 (, t + 1536) and
-// one half of K = [z | e]
-constexpr int MERGE_N = 1539, MERGE_K = 128;
-FR_DEV void merge_part(int tid, const float* FR_RESTRICT ze /*[256] = z | e*/, const float* FR_RESTRICT Wz,
-                       const float* FR_RESTRICT Wy, float* FR_RESTRICT part /*[2][1539]*/) {
+// merge (model/vae.py:51-61): h[n] = sum_k z[k] Wz[k][n] + T[y][n], T = E Wy + (bz + by + b) built once per step by the
+// pack launch (the embedding term depends on the speaker only: half of the layer's 1.6 MB of weights never has to be
+// streamed per frame).  Rows of 1539 floats are not 16-byte aligned, so lanes run along n with 4-byte loads
+// (coalesced); a thread owns n = t, t + 512, t + 1024 (, t + 1536) and one half of k
+constexpr int MERGE_N = 1539, MERGE_K = 128, MERGE_NY = 10;
+FR_DEV void merge_part(int tid, const float* FR_RESTRICT z /*[128]*/, FR_G(const float) Wz, float* FR_RESTRICT part /*[2][1539]*/) {
   const int t = tid & 511, ks = tid >> 9;
-  const float* W = ks ? Wy : Wz;
-  const float* v = ze + ks * MERGE_K;
+  const unsigned wbase = (unsigned)(ks * 64 * MERGE_N + t);
+  const float* v = z + ks * 64;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
   const bool ok3 = t + 1536 < MERGE_N;
-  for (int k = 0; k < MERGE_K; k += 4) {
+  FR_NOUNROLL
+  for (int k = 0; k < 64; k += 4) {
     float w[4][4];
     FR_UNROLL
     for (int u = 0; u < 4; ++u) {
-      const float* wr = W + (size_t)(k + u) * MERGE_N + t;
-      w[u][0] = wr[0];
-      w[u][1] = wr[512];
-      w[u][2] = wr[1024];
-      w[u][3] = ok3 ? wr[1536] : 0.f;
+      const unsigned wo = wbase + (unsigned)((k + u) * MERGE_N);
+      w[u][0] = Wz[wo];
+      w[u][1] = Wz[wo + 512];
+      w[u][2] = Wz[wo + 1024];
+      w[u][3] = ok3 ? Wz[wo + 1536] : 0.f;
     }
     FR_UNROLL
     for (int u = 0; u < 4; ++u) {
@@ -393,22 +490,22 @@ FR_DEV void toep_dgrad_part(int tid, const float* FR_RESTRICT g /*[513]*/, const
 //                      CC   HIN  OO   OV   HO   K  S PAD JT  KS
 using E0F = SConv<1, 513, 16, 16, 171, 7, 3, 2, 3, 1>;
 using E1F = SConv<16, 171, 32, 32, 57, 7, 3, 2, 3, 4>;
-using E2F = SConv<32, 57, 64, 64, 19, 7, 3, 2, 5, 8>;
+using E2F = SConv<32, 57, 64, 64, 19, 7, 3, 2, 3, 8>;
 using E3F = SConv<64, 19, 128, 128, 7, 7, 3, 3, 4, 16>;
 using E4F = SConv<128, 7, 256, 256, 3, 7, 3, 3, 3, 16>;
 // input gradients of the transposed convs (contract over the layer's output channels; weights [t][o][c], c fastest)
 using D2G = SConv<8, 513, 16, 16, 171, 7, 3, 2, 3, 2>;
 using D1G = SConv<16, 171, 32, 32, 57, 7, 3, 2, 3, 4>;
-using D0G = SConv<32, 57, 84, 81, 19, 9, 3, 3, 5, 8>;
+using D0G = SConv<32, 57, 84, 81, 19, 9, 3, 3, 3, 6>;
 //                      CC   Q    OO   OV  HOUT  K  S PAD QT  KS
-using D0F = TConv<81, 19, 32, 32, 57, 9, 3, 3, 3, 12>;
-using D1F = TConv<32, 57, 16, 16, 171, 7, 3, 2, 3, 8>;
-using D2F = TConv<16, 171, 8, 8, 513, 7, 3, 2, 3, 4>;
+using D0F = TConv<81, 19, 32, 32, 57, 9, 3, 3, 2, 12>;
+using D1F = TConv<32, 57, 16, 16, 171, 7, 3, 2, 2, 8>;
+using D2F = TConv<16, 171, 8, 8, 513, 7, 3, 2, 2, 4>;
 // input gradients of the encoder convs (contract over the layer's output channels; weights packed [t][o][c])
 using E4G = TConv<256, 3, 128, 128, 7, 7, 3, 3, 3, 16>;
-using E3G = TConv<128, 7, 64, 64, 19, 7, 3, 3, 4, 16>;
-using E2G = TConv<64, 19, 32, 32, 57, 7, 3, 2, 4, 12>;
-using E1G = TConv<32, 57, 16, 16, 171, 7, 3, 2, 3, 8>;
+using E3G = TConv<128, 7, 64, 64, 19, 7, 3, 3, 2, 16>;
+using E2G = TConv<64, 19, 32, 32, 57, 7, 3, 2, 2, 12>;
+using E1G = TConv<32, 57, 16, 16, 171, 7, 3, 2, 2, 8>;
 using HeadsF = Dense4<768, 256, 256, 16>;     // [y4] x [Wmu | Wlv] (packed side by side: 256 columns)
 using HeadsG = Dense4<256, 768, 768, 4>;      // [dz_mu | dz_lv] x [Wmu | Wlv]^T
 using MergeG = Dense4<1539, 128, 128, 32>;    // d(h) x Wz^T
@@ -430,11 +527,12 @@ struct Pk {
   static constexpr int e2g = e3g + 7 * 128 * 64;
   static constexpr int e1g = e2g + 7 * 64 * 32;
   static constexpr int w3t = e1g + 7 * 32 * 16;                    // [8][1028]    taps of the last layer per channel
-  static constexpr int total = w3t + TP_C * TP_W;
+  static constexpr int mtab = w3t + TP_C * TP_W;                   // [10][1539]   T = E Wy + (bz + by + b) (+ 2 floats of padding)
+  static constexpr int total = mtab + MERGE_NY * MERGE_N + 2;
 };
 static_assert(Pk::heads % 4 == 0 && Pk::headsT % 4 == 0 && Pk::wzT % 4 == 0 && Pk::d0f % 4 == 0 && Pk::d1f % 4 == 0 &&
                   Pk::d2f % 4 == 0 && Pk::d0g % 4 == 0 && Pk::d1g % 4 == 0 && Pk::d2g % 4 == 0 && Pk::e4g % 4 == 0 &&
-                  Pk::e3g % 4 == 0 && Pk::e2g % 4 == 0 && Pk::e1g % 4 == 0 && Pk::w3t % 4 == 0,
+                  Pk::e3g % 4 == 0 && Pk::e2g % 4 == 0 && Pk::e1g % 4 == 0 && Pk::w3t % 4 == 0 && Pk::mtab % 4 == 0,
               "packed blocks must be 16-byte aligned");
 
 // parameter offsets of the 44 tensors (flat buffer, TF creation order; model.cpp fills it for the VCC2016 geometry)
@@ -485,77 +583,91 @@ FR_DEV float pack_src(const float* FR_RESTRICT P, const POff& o, int i) {
     const int c = j % C, oo = (j / C) % O, t = j / (C * O);
     return P[w + (t * C + c) * O + oo];
   }
-  {                                           // w3t [c][1028]: tap t of channel c (TF [t][1][1][8]); padding zero
+  if (i < Pk::mtab) {                         // w3t [c][1028]: tap t of channel c (TF [t][1][1][8]); padding zero
     const int j = i - Pk::w3t, c = j / TP_W, t = j % TP_W;
     return t < TP_K ? P[o.dw[3] + t * TP_C + c] : 0.f;
+  }
+  {                                           // merge table: T[k][n] = sum_i E[k][i] Wy[i][n] + bz[n] + by[n] + b[n]
+    const int j = i - Pk::mtab;
+    if (j >= MERGE_NY * MERGE_N) return 0.f;
+    const int k = j / MERGE_N, n = j % MERGE_N;
+    float s = P[o.bz + n] + P[o.by + n] + P[o.bm + n];
+    for (int e = 0; e < MERGE_K; ++e) s += P[o.emb + k * MERGE_K + e] * P[o.wy + (size_t)e * MERGE_N + n];
+    return s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ per-channel vectors
+// channel slots of the 8 normalised layers (order of the backward pass: dec2, dec1, dec0, enc4, enc3, enc2, enc1, enc0)
+constexpr int LNP_C = 552;
+constexpr int LNP_DEC2 = 0, LNP_DEC1 = 8, LNP_DEC0 = 24, LNP_ENC4 = 56, LNP_ENC3 = 312, LNP_ENC2 = 440, LNP_ENC1 = 504, LNP_ENC0 = 536;
+// conv bias, LayerNorm scale and offset of every channel, copied to LDS once per workgroup: the short phases between
+// the conv tiles then touch no global memory at all (a phase that waits for one L2 round trip costs ~1.5k clocks)
+FR_DEV void load_channel_vectors(int tid, FR_G(const float) P, const POff& o, float* FR_RESTRICT ch) {
+  for (int i = tid; i < LNP_C; i += NT) {
+    int b, g, be, c;
+    if (i < LNP_DEC1) { c = i - LNP_DEC2; b = o.db[2]; g = o.dgamma[2]; be = o.dbeta[2]; }
+    else if (i < LNP_DEC0) { c = i - LNP_DEC1; b = o.db[1]; g = o.dgamma[1]; be = o.dbeta[1]; }
+    else if (i < LNP_ENC4) { c = i - LNP_DEC0; b = o.db[0]; g = o.dgamma[0]; be = o.dbeta[0]; }
+    else if (i < LNP_ENC3) { c = i - LNP_ENC4; b = o.eb[4]; g = o.egamma[4]; be = o.ebeta[4]; }
+    else if (i < LNP_ENC2) { c = i - LNP_ENC3; b = o.eb[3]; g = o.egamma[3]; be = o.ebeta[3]; }
+    else if (i < LNP_ENC1) { c = i - LNP_ENC2; b = o.eb[2]; g = o.egamma[2]; be = o.ebeta[2]; }
+    else if (i < LNP_ENC0) { c = i - LNP_ENC1; b = o.eb[1]; g = o.egamma[1]; be = o.ebeta[1]; }
+    else { c = i - LNP_ENC0; b = o.eb[0]; g = o.egamma[0]; be = o.ebeta[0]; }
+    ch[i] = P[b + c];
+    ch[LNP_C + i] = P[g + c];
+    ch[2 * LNP_C + i] = P[be + c];
   }
 }
 
 // ------------------------------------------------------------------------------------------------ phases shared by both passes
-// sum of part[ks][idx] over the K slices (+ bias of the channel): the pre-LN conv output / the layer output
-template <int KS, int NOUT, int H>
-FR_DEV void reduce_out(int tid, const float* FR_RESTRICT part, const float* FR_RESTRICT bias, float* FR_RESTRICT out_lds,
-                       float* FR_RESTRICT out_g) {
-  for (int i = tid; i < NOUT; i += NT) {
-    float s = bias ? bias[i / H] : 0.f;
-    FR_UNROLL
-    for (int k = 0; k < KS; ++k) s += part[k * NOUT + i];
-    if (out_lds) out_lds[i] = s;
-    if (out_g) out_g[i] = s;
-  }
+// A runner offers   phase(f)            f(tid) for every thread, then a workgroup barrier
+//                   reduce(dst, f)      dst[wave] = sum over the wave's lanes of f(tid), then a barrier
+//                   reduce2(dA, dB, f)  the same for a pair of values, f(tid, a, b)
+// (device: wave shuffles; host emulation: plain loops).  A workgroup-wide sum is then sum16(dst) in the NEXT phase:
+// two barriers per LayerNorm statistic instead of six.
+
+// copy a tensor that sits in LDS to HBM.  The phase barriers do not wait for global stores (nothing written to HBM is read
+// again inside a pass), but loads return in order BEHIND older stores: a flush sits at the top of a phase that needs no
+// global data, as far ahead of the next weight loads as the data dependences allow
+FR_DEV void flush(int tid, const float* FR_RESTRICT src, FR_G(float) dst, int n) {
+  if (!dst) return;
+  for (int i = tid; i < n; i += NT) dst[i] = src[i];
 }
 
-// LayerNorm statistics of a[0..n) in LDS (util/layers.py:32: biased variance over the whole frame), two-pass like the
-// layered kernels: mean first, then the centred second moment.  Leaves {mean, rstd} in red[R_ST..] (and in st_g).
+// out[i] = sum over the K slices of part[k][i] (+ bias of the channel) -> `by`; per-wave sums of the outputs -> red[R_S1..]
+template <class R, int KS, int NOUT, int H>
+FR_DEV void reduce_sum(R& run, const float* part, const float* bias, float* by, float* red) {
+  run.reduce(red + R_S1, [&](int tid) {
+    float t = 0.f;
+    for (int i = tid; i < NOUT; i += NT) {
+      float s = bias ? bias[i / H] : 0.f;
+      FR_UNROLL
+      for (int k = 0; k < KS; ++k) s += part[k * NOUT + i];
+      by[i] = s;
+      t += s;
+    }
+    return t;
+  });
+}
+// centred second moment (util/layers.py:32: biased variance over the whole frame), two-pass like the layered kernels
 template <class R, int N>
-FR_DEV void ln_stats(R& run, const float* a, float* red, float* st_g) {
-  run.phase([&](int tid) {
-    float s = 0.f;
-    for (int i = tid; i < N; i += NT) s += a[i];
-    red[tid] = s;
-  });
-  run.phase([&](int tid) {
-    if (tid < 32) {
-      float s = 0.f;
-      for (int i = 0; i < 32; ++i) s += red[tid * 32 + i];
-      red[R_RED2 + tid] = s;
-    }
-  });
-  run.phase([&](int tid) {
-    if (tid == 0) {
-      float s = 0.f;
-      for (int i = 0; i < 32; ++i) s += red[R_RED2 + i];
-      red[R_ST] = s * (1.0f / N);
-    }
-  });
-  run.phase([&](int tid) {
-    const float mean = red[R_ST];
-    float s = 0.f;
+FR_DEV void var_sum(R& run, const float* a, float* red, FR_G(float) a_g) {
+  run.reduce(red + R_S2, [&](int tid) {
+    flush(tid, a, a_g, N);      // the pre-LN tensor leaves for HBM under two LDS-only phases (nothing waits for the stores)
+    const float mean = sum16(red + R_S1) * (1.0f / N);
+    float q = 0.f;
     for (int i = tid; i < N; i += NT) {
       const float d = a[i] - mean;
-      s += d * d;
+      q += d * d;
     }
-    red[tid] = s;
+    return q;
   });
-  run.phase([&](int tid) {
-    if (tid < 32) {
-      float s = 0.f;
-      for (int i = 0; i < 32; ++i) s += red[tid * 32 + i];
-      red[R_RED2 + tid] = s;
-    }
-  });
-  run.phase([&](int tid) {
-    if (tid == 0) {
-      float s = 0.f;
-      for (int i = 0; i < 32; ++i) s += red[R_RED2 + i];
-      const float rstd = 1.0f / sqrtf(s * (1.0f / N) + LN_EPS_F);
-      red[R_ST + 1] = rstd;
-      if (st_g) {
-        st_g[0] = red[R_ST];
-        st_g[1] = rstd;
-      }
-    }
-  });
+}
+template <int N>
+FR_DEV void ln_consts(const float* red, float& mean, float& rstd) {
+  mean = sum16(red + R_S1) * (1.0f / N);
+  rstd = 1.0f / sqrtf(sum16(red + R_S2) * (1.0f / N) + LN_EPS_F);
 }
 
 FR_DEV float lnact(float v, float mean, float rstd, float g, float b) {
@@ -564,19 +676,24 @@ FR_DEV float lnact(float v, float mean, float rstd, float g, float b) {
 }
 
 // y = lrelu(LN(a)) written as the next layer's LDS input: rows of HP floats, the valid positions at [HL, HL + H), zeros
-// elsewhere (the SAME-padding halo); HP == H and HL == 0 gives the plain [C][H] tensor
+// elsewhere (the SAME-padding halo); HP == H and HL == 0 gives the plain [C][H] tensor.  Also stores {mean, rstd}.
 template <int C, int H, int HP, int HL>
 FR_DEV void ln_apply(int tid, const float* FR_RESTRICT a, const float* FR_RESTRICT red, const float* FR_RESTRICT gamma,
-                     const float* FR_RESTRICT beta, float* FR_RESTRICT out) {
-  const float mean = red[R_ST], rstd = red[R_ST + 1];
+                     const float* FR_RESTRICT beta, float* FR_RESTRICT out, FR_G(float) st_g) {
+  float mean, rstd;
+  ln_consts<C * H>(red, mean, rstd);
+  if (tid == 0 && st_g) {
+    st_g[0] = mean;
+    st_g[1] = rstd;
+  }
   for (int i = tid; i < C * HP; i += NT) {
     const int c = i / HP, h = i % HP - HL;
     out[i] = (h >= 0 && h < H) ? lnact(a[c * H + h], mean, rstd, gamma[c], beta[c]) : 0.f;
   }
 }
 // plain tensor -> halo layout (no LayerNorm: the merge output, gradients)
-template <int C, int H, int HP, int HL>
-FR_DEV void halo_copy(int tid, const float* FR_RESTRICT a, float* FR_RESTRICT out) {
+template <int C, int H, int HP, int HL, class PT>
+FR_DEV void halo_copy(int tid, PT a, float* FR_RESTRICT out) {
   for (int i = tid; i < C * HP; i += NT) {
     const int c = i / HP, h = i % HP - HL;
     out[i] = (h >= 0 && h < H) ? a[c * H + h] : 0.f;
@@ -595,7 +712,7 @@ struct FwdArgs {
   const float* z_in;      // decode-only: z [F][128]
   int ny;
   int F;
-  int mode;               // bit 0: encoder + heads, bit 1: sampler, bit 2: decoder, bit 3: log-density (+ d(xh) when bit 4)
+  int mode;               // FM_* bits
   float invF;
   // workspace tensors of the layered path (any may be null when its stage is off)
   float* enc_a[5];
@@ -606,187 +723,183 @@ struct FwdArgs {
   float *xh, *kl_f, *nll_f, *d_xh;
   float* dec_y;           // optional: activated output of decoder layer 2 [F][8][513] (operand of the layered weight gradient)
 };
+static_assert(sizeof(FwdArgs) <= ARGS_FLOATS * 4, "argument block larger than its LDS slot");
 constexpr int FM_ENC = 1, FM_SAMPLE = 2, FM_DEC = 4, FM_LOSS = 8, FM_GRAD = 16;
 
+// one conv + LayerNorm + lrelu layer after its `part` phase: outputs + statistics + activated input of the next layer
+#define FR_LN_TAIL(CFG, NOUT_H, LOFF, C_, H_, NEXT_HP, NEXT_HL, a_g_, st_)                                                     \
+  reduce_sum<R, CFG::KS, CFG::NOUT, NOUT_H>(run, part, ch + LOFF, by, red);                                                   \
+  var_sum<R, CFG::NOUT>(run, by, red, a_g_);                                                                                  \
+  run.phase([&](int tid) { ln_apply<C_, H_, NEXT_HP, NEXT_HL>(tid, by, red, ch + LNP_C + LOFF, ch + 2 * LNP_C + LOFF, bx, st_); });
+
 template <class R>
-FR_STAGE void frame_fwd_enc(R& run, float* lds, const FwdArgs& a, int f) {
+FR_STAGE void frame_fwd_enc(R& run, float* lds_, const FwdArgs& a_, int f_) {
+  const int f = FR_UNIFORM(f_);
+  float* lds = fr_l(lds_);
+  const FwdArgs& a = *fr_l(&a_);
+  auto pk = fr_g(a.pk);
+  (void)pk;
   float* bx = lds + L_BUFX;
   float* by = lds + L_BUFY;
   float* part = lds + L_PART;
   float* red = lds + L_RED;
-  float* vec = lds + L_VEC;      // [0,256) z_mu | z_lv, [256,384) z, [384,512) e
-  const float* P = a.P;
+  float* vec = lds + L_VEC;      // [0,256) z_mu | z_lv, [256,384) z
+  const float* ch = lds + L_CH;
+  auto P = fr_g(a.P);
   const POff& o = a.off;
-  (void)bx; (void)by; (void)part; (void)red; (void)vec; (void)P; (void)o;
-    const float* xf = a.x + (size_t)f * 513;
-    run.phase([&](int tid) { halo_copy<1, 513, E0F::HP, E0F::PAD>(tid, xf, bx); });
-    // ---- e0 .. e4: conv + bias -> pre-LN output (kept for the backward pass), statistics, LN + lrelu into the next input
-    run.phase([&](int tid) { sconv_part<E0F>(tid, bx, P + o.ew[0], part); });
-    run.phase([&](int tid) { reduce_out<E0F::KS, E0F::NOUT, E0F::HO>(tid, part, P + o.eb[0], by, a.enc_a[0] + (size_t)f * E0F::NOUT); });
-    ln_stats<R, E0F::NOUT>(run, by, red, a.enc_st[0] + 2 * (size_t)f);
-    run.phase([&](int tid) { ln_apply<16, 171, E1F::HP, E1F::PAD>(tid, by, red, P + o.egamma[0], P + o.ebeta[0], bx); });
-
-    run.phase([&](int tid) { sconv_part<E1F>(tid, bx, P + o.ew[1], part); });
-    run.phase([&](int tid) { reduce_out<E1F::KS, E1F::NOUT, E1F::HO>(tid, part, P + o.eb[1], by, a.enc_a[1] + (size_t)f * E1F::NOUT); });
-    ln_stats<R, E1F::NOUT>(run, by, red, a.enc_st[1] + 2 * (size_t)f);
-    run.phase([&](int tid) { ln_apply<32, 57, E2F::HP, E2F::PAD>(tid, by, red, P + o.egamma[1], P + o.ebeta[1], bx); });
-
-    run.phase([&](int tid) { sconv_part<E2F>(tid, bx, P + o.ew[2], part); });
-    run.phase([&](int tid) { reduce_out<E2F::KS, E2F::NOUT, E2F::HO>(tid, part, P + o.eb[2], by, a.enc_a[2] + (size_t)f * E2F::NOUT); });
-    ln_stats<R, E2F::NOUT>(run, by, red, a.enc_st[2] + 2 * (size_t)f);
-    run.phase([&](int tid) { ln_apply<64, 19, E3F::HP, E3F::PAD>(tid, by, red, P + o.egamma[2], P + o.ebeta[2], bx); });
-
-    run.phase([&](int tid) { sconv_part<E3F>(tid, bx, P + o.ew[3], part); });
-    run.phase([&](int tid) { reduce_out<E3F::KS, E3F::NOUT, E3F::HO>(tid, part, P + o.eb[3], by, a.enc_a[3] + (size_t)f * E3F::NOUT); });
-    ln_stats<R, E3F::NOUT>(run, by, red, a.enc_st[3] + 2 * (size_t)f);
-    run.phase([&](int tid) { ln_apply<128, 7, E4F::HP, E4F::PAD>(tid, by, red, P + o.egamma[3], P + o.ebeta[3], bx); });
-
-    run.phase([&](int tid) { sconv_part<E4F>(tid, bx, P + o.ew[4], part); });
-    run.phase([&](int tid) { reduce_out<E4F::KS, E4F::NOUT, E4F::HO>(tid, part, P + o.eb[4], by, a.enc_a[4] + (size_t)f * E4F::NOUT); });
-    ln_stats<R, E4F::NOUT>(run, by, red, a.enc_st[4] + 2 * (size_t)f);
-    // C-major flatten (slim.flatten of the NCHW tensor, model/vae.py:79): index c*3 + h = the plain layout
-    run.phase([&](int tid) { ln_apply<256, 3, 3, 0>(tid, by, red, P + o.egamma[4], P + o.ebeta[4], bx); });
-    // ---- heads (model/vae.py:80-81)
-    run.phase([&](int tid) { dense4_part<HeadsF>(tid, bx, a.pk + Pk::heads, part); });
-    run.phase([&](int tid) {
-      if (tid < 256) {
-        float s = tid < 128 ? P[o.bmu + tid] : P[o.blv + tid - 128];
-        for (int k = 0; k < HeadsF::KS; ++k) s += part[k * 256 + tid];
-        vec[tid] = s;
-        if (tid < 128) a.z_mu[(size_t)f * 128 + tid] = s;
-        else a.z_lv[(size_t)f * 128 + tid - 128] = s;
-      }
-    });
-  }
+  auto xf = fr_g(a.x) + (size_t)f * 513;
+  run.phase([&](int tid) { halo_copy<1, 513, E0F::HP, E0F::PAD>(tid, xf, bx); });
+  // ---- e0 .. e4: conv + bias -> pre-LN output (kept for the backward pass), statistics, LN + lrelu into the next input
+  run.phase([&](int tid) { sconv_part<E0F>(tid, bx, P + FR_UNIFORM(o.ew[0]), part); });
+  FR_LN_TAIL(E0F, E0F::HO, LNP_ENC0, 16, 171, E1F::HP, E1F::PAD, fr_g(a.enc_a[0]) + (size_t)f * E0F::NOUT, fr_g(a.enc_st[0]) + 2 * (size_t)f)
+  run.phase([&](int tid) { sconv_part<E1F>(tid, bx, P + FR_UNIFORM(o.ew[1]), part); });
+  FR_LN_TAIL(E1F, E1F::HO, LNP_ENC1, 32, 57, E2F::HP, E2F::PAD, fr_g(a.enc_a[1]) + (size_t)f * E1F::NOUT, fr_g(a.enc_st[1]) + 2 * (size_t)f)
+  run.phase([&](int tid) { sconv_part<E2F>(tid, bx, P + FR_UNIFORM(o.ew[2]), part); });
+  FR_LN_TAIL(E2F, E2F::HO, LNP_ENC2, 64, 19, E3F::HP, E3F::PAD, fr_g(a.enc_a[2]) + (size_t)f * E2F::NOUT, fr_g(a.enc_st[2]) + 2 * (size_t)f)
+  run.phase([&](int tid) { sconv_part<E3F>(tid, bx, P + FR_UNIFORM(o.ew[3]), part); });
+  FR_LN_TAIL(E3F, E3F::HO, LNP_ENC3, 128, 7, E4F::HP, E4F::PAD, fr_g(a.enc_a[3]) + (size_t)f * E3F::NOUT, fr_g(a.enc_st[3]) + 2 * (size_t)f)
+  run.phase([&](int tid) { sconv_part<E4F>(tid, bx, P + FR_UNIFORM(o.ew[4]), part); });
+  // C-major flatten (slim.flatten of the NCHW tensor, model/vae.py:79): index c*3 + h = the plain layout
+  FR_LN_TAIL(E4F, E4F::HO, LNP_ENC4, 256, 3, 3, 0, fr_g(a.enc_a[4]) + (size_t)f * E4F::NOUT, fr_g(a.enc_st[4]) + 2 * (size_t)f)
+  // ---- heads (model/vae.py:80-81)
+  run.phase([&](int tid) { dense4_part<HeadsF>(tid, bx, pk + Pk::heads, part); });
+  run.phase([&](int tid) {
+    if (tid < 256) {
+      float s = tid < 128 ? P[FR_UNIFORM(o.bmu) + tid] : P[FR_UNIFORM(o.blv) + tid - 128];
+      for (int k = 0; k < HeadsF::KS; ++k) s += part[k * 256 + tid];
+      vec[tid] = s;
+      if (tid < 128) a.z_mu[(size_t)f * 128 + tid] = s;
+      else a.z_lv[(size_t)f * 128 + tid - 128] = s;
+    }
+  });
+}
 
 // eps of element (f, d): injected, or drawn by the caller-supplied functor (device: Philox; host emulation: injected only)
 template <class R, class Eps>
-FR_STAGE void frame_fwd_mid(R& run, float* lds, const FwdArgs& a, int f, Eps&& draw) {
+FR_STAGE void frame_fwd_mid(R& run, float* lds_, const FwdArgs& a_, int f_, Eps&& draw) {
+  const int f = FR_UNIFORM(f_);
+  float* lds = fr_l(lds_);
+  const FwdArgs& a = *fr_l(&a_);
+  auto pk = fr_g(a.pk);
+  (void)pk;
   float* bx = lds + L_BUFX;
   float* by = lds + L_BUFY;
   float* part = lds + L_PART;
   float* red = lds + L_RED;
-  float* vec = lds + L_VEC;      // [0,256) z_mu | z_lv, [256,384) z, [384,512) e
-  const float* P = a.P;
+  float* vec = lds + L_VEC;
+  auto P = fr_g(a.P);
   const POff& o = a.off;
-  (void)bx; (void)by; (void)part; (void)red; (void)vec; (void)P; (void)o;
   if (a.mode & FM_SAMPLE) {
     // ---- sampler + KL (util/layers.py:152-156, 170-183 with mu2 = lv2 = 0)
-    run.phase([&](int tid) {
-      if (tid < 128) {
-        const float mu = vec[tid], lv = vec[128 + tid], v = expf(lv);
-        const float e = draw(f, tid);
-        if (a.eps_out) a.eps_out[(size_t)f * 128 + tid] = e;
-        const float z = mu + e * sqrtf(v);
-        vec[256 + tid] = z;
-        a.z[(size_t)f * 128 + tid] = z;
-        red[tid] = 0.5f * ((0.f - lv) + (v + mu * mu) / (1.0f + EPSILON_F) - 1.0f);
-      }
-    });
-    run.phase([&](int tid) {
-      if (tid == 0) {
-        float s = 0.f;
-        for (int i = 0; i < 128; ++i) s += red[i];
-        a.kl_f[f] = s;
-      }
+    run.reduce(red + R_S3, [&](int tid) {
+      if (tid >= 128) return 0.f;
+      const float mu = vec[tid], lv = vec[128 + tid], v = expf(lv);
+      const float e = draw(f, tid);
+      if (fr_g(a.eps_out)) a.eps_out[(size_t)f * 128 + tid] = e;
+      const float z = mu + e * sqrtf(v);
+      vec[256 + tid] = z;
+      a.z[(size_t)f * 128 + tid] = z;
+      return 0.5f * ((0.f - lv) + (v + mu * mu) / (1.0f + EPSILON_F) - 1.0f);
     });
   } else if (a.mode & FM_DEC) {
     // decode-only / conversion path: z given (model/vae.py:139-145: encode returns z_mu, decode takes any z)
-    const float* zs = a.z_in ? a.z_in + (size_t)f * 128 : nullptr;
+    const bool has_z = a.z_in != nullptr;
+    auto zs = fr_g(a.z_in) + (size_t)f * 128;
     run.phase([&](int tid) {
-      if (tid < 128) vec[256 + tid] = zs ? zs[tid] : vec[tid];
+      if (tid < 128) vec[256 + tid] = has_z ? zs[tid] : vec[tid];
     });
   }
   if (a.mode & FM_DEC) {
-    // ---- embedding lookup + merge (model/vae.py:51-61, 89): three biases
+    // ---- embedding lookup + merge (model/vae.py:51-61, 89): h = z Wz + T[y]
+    run.phase([&](int tid) {
+      if (tid == 0 && (a.mode & FM_SAMPLE)) a.kl_f[f] = sum16(red + R_S3);
+      merge_part(tid, vec + 256, P + FR_UNIFORM(o.wz), part);
+    });
     int64_t yid = a.y[f];
     yid = yid < 0 ? 0 : (yid >= a.ny ? a.ny - 1 : yid);
-    run.phase([&](int tid) {
-      if (tid < 128) vec[384 + tid] = P[o.emb + (int)yid * 128 + tid];
-    });
-    run.phase([&](int tid) { merge_part(tid, vec + 256, P + o.wz, P + o.wy, part); });
+    auto T = pk + Pk::mtab + (size_t)yid * MERGE_N;
     run.phase([&](int tid) {
       for (int n = tid; n < MERGE_N; n += NT) {
-        const float s = part[n] + part[MERGE_N + n] + P[o.bz + n] + P[o.by + n] + P[o.bm + n];
+        const float s = part[n] + part[MERGE_N + n] + T[n];
         by[n] = s;
-        if (a.h) a.h[(size_t)f * MERGE_N + n] = s;
+        if (fr_g(a.h)) a.h[(size_t)f * MERGE_N + n] = s;
       }
     });
     run.phase([&](int tid) { halo_copy<81, 19, D0F::HP, D0F::HL>(tid, by, bx); });
+  } else if (a.mode & FM_SAMPLE) {
+    run.phase([&](int tid) {
+      if (tid == 0) a.kl_f[f] = sum16(red + R_S3);
+    });
   }
+  (void)bx;
 }
 
 template <class R>
-FR_STAGE void frame_fwd_dec(R& run, float* lds, const FwdArgs& a, int f) {
+FR_STAGE void frame_fwd_dec(R& run, float* lds_, const FwdArgs& a_, int f_) {
+  const int f = FR_UNIFORM(f_);
+  float* lds = fr_l(lds_);
+  const FwdArgs& a = *fr_l(&a_);
+  auto pk = fr_g(a.pk);
+  (void)pk;
   float* bx = lds + L_BUFX;
   float* by = lds + L_BUFY;
   float* part = lds + L_PART;
   float* red = lds + L_RED;
-  float* vec = lds + L_VEC;      // [0,256) z_mu | z_lv, [256,384) z, [384,512) e
-  const float* P = a.P;
+  const float* ch = lds + L_CH;
+  auto P = fr_g(a.P);
   const POff& o = a.off;
-  (void)bx; (void)by; (void)part; (void)red; (void)vec; (void)P; (void)o;
-  {
-    // ---- d0 .. d2: conv_transpose + bias, LayerNorm, lrelu (model/vae.py:96-102)
-    run.phase([&](int tid) { tconv_part<D0F>(tid, bx, a.pk + Pk::d0f, part); });
-    run.phase([&](int tid) { reduce_out<D0F::KS, D0F::NOUT, D0F::HOUT>(tid, part, P + o.db[0], by, a.dec_a[0] + (size_t)f * D0F::NOUT); });
-    ln_stats<R, D0F::NOUT>(run, by, red, a.dec_st[0] + 2 * (size_t)f);
-    run.phase([&](int tid) { ln_apply<32, 57, D1F::HP, D1F::HL>(tid, by, red, P + o.dgamma[0], P + o.dbeta[0], bx); });
-
-    run.phase([&](int tid) { tconv_part<D1F>(tid, bx, a.pk + Pk::d1f, part); });
-    run.phase([&](int tid) { reduce_out<D1F::KS, D1F::NOUT, D1F::HOUT>(tid, part, P + o.db[1], by, a.dec_a[1] + (size_t)f * D1F::NOUT); });
-    ln_stats<R, D1F::NOUT>(run, by, red, a.dec_st[1] + 2 * (size_t)f);
-    run.phase([&](int tid) { ln_apply<16, 171, D2F::HP, D2F::HL>(tid, by, red, P + o.dgamma[1], P + o.dbeta[1], bx); });
-
-    run.phase([&](int tid) { tconv_part<D2F>(tid, bx, a.pk + Pk::d2f, part); });
-    run.phase([&](int tid) { reduce_out<D2F::KS, D2F::NOUT, D2F::HOUT>(tid, part, P + o.db[2], by, a.dec_a[2] + (size_t)f * D2F::NOUT); });
-    ln_stats<R, D2F::NOUT>(run, by, red, a.dec_st[2] + 2 * (size_t)f);
-    run.phase([&](int tid) {
-      ln_apply<8, 513, 513, 0>(tid, by, red, P + o.dgamma[2], P + o.dbeta[2], bx);
-      if (a.dec_y) {        // (same thread, same elements as ln_apply: no barrier needed in between)
-        for (int i = tid; i < 8 * 513; i += NT) a.dec_y[(size_t)f * 4104 + i] = bx[i];
+  // ---- d0 .. d2: conv_transpose + bias, LayerNorm, lrelu (model/vae.py:96-102)
+  run.phase([&](int tid) { tconv_part<D0F>(tid, bx, pk + Pk::d0f, part); });
+  FR_LN_TAIL(D0F, D0F::HOUT, LNP_DEC0, 32, 57, D1F::HP, D1F::HL, fr_g(a.dec_a[0]) + (size_t)f * D0F::NOUT, fr_g(a.dec_st[0]) + 2 * (size_t)f)
+  run.phase([&](int tid) { tconv_part<D1F>(tid, bx, pk + Pk::d1f, part); });
+  FR_LN_TAIL(D1F, D1F::HOUT, LNP_DEC1, 16, 171, D2F::HP, D2F::HL, fr_g(a.dec_a[1]) + (size_t)f * D1F::NOUT, fr_g(a.dec_st[1]) + 2 * (size_t)f)
+  run.phase([&](int tid) { tconv_part<D2F>(tid, bx, pk + Pk::d2f, part); });
+  reduce_sum<R, D2F::KS, D2F::NOUT, D2F::HOUT>(run, part, ch + LNP_DEC2, by, red);
+  var_sum<R, D2F::NOUT>(run, by, red, fr_g(a.dec_a[2]) + (size_t)f * D2F::NOUT);
+  run.phase([&](int tid) {
+    // taps of the last layer, one contiguous row per channel (loads first: they must not queue behind the stores below)
+    for (int i = tid; i < TP_C * TP_W; i += NT) part[i] = pk[Pk::w3t + i];
+    ln_apply<8, 513, 513, 0>(tid, by, red, ch + LNP_C + LNP_DEC2, ch + 2 * LNP_C + LNP_DEC2, bx, fr_g(a.dec_st[2]) + 2 * (size_t)f);
+    if (fr_g(a.dec_y))      // (same thread, same elements as ln_apply wrote)
+      for (int i = tid; i < 4104; i += NT) a.dec_y[(size_t)f * 4104 + i] = bx[i];
+  });
+  // ---- d3: the 1025-tap layer, no LayerNorm, no activation (model/vae.py:96-103)
+  run.phase([&](int tid) { toep_fwd_part(tid, bx, part, part + TP_C * TP_W); });
+  const float b3 = P[FR_UNIFORM(o.db[3])];
+  if (a.mode & FM_LOSS) {
+    // ---- output + Gaussian log-density with unit variance (util/layers.py:159-167) and its gradient
+    auto tf = fr_g(a.target) + (size_t)f * TP_H;
+    run.reduce(red + R_S3, [&](int tid) {
+      float t = 0.f;
+      for (int p = tid; p < TP_H; p += NT) {
+        float s = b3;
+        for (int k = 0; k < 16; ++k) s += part[TP_C * TP_W + k * TP_H + p];
+        const float d = tf[p] - s;
+        t += -0.5f * (LOG_2PI_F + (d * d) / (1.0f + EPSILON_F));
+        a.xh[(size_t)f * TP_H + p] = s;
+        if (a.mode & FM_GRAD) a.d_xh[(size_t)f * TP_H + p] = -d / (1.0f + EPSILON_F) * a.invF;
       }
-      // taps of the last layer, one contiguous row per channel
-      for (int i = tid; i < TP_C * TP_W; i += NT) part[i] = a.pk[Pk::w3t + i];
+      return t;
     });
-    // ---- d3: the 1025-tap layer, no LayerNorm, no activation (model/vae.py:96-103)
-    run.phase([&](int tid) { toep_fwd_part(tid, bx, part, part + TP_C * TP_W); });
+    run.phase([&](int tid) {
+      if (tid == 0) a.nll_f[f] = sum16(red + R_S3);
+    });
+  } else {
     run.phase([&](int tid) {
       for (int p = tid; p < TP_H; p += NT) {
-        float s = P[o.db[3]];
+        float s = b3;
         for (int k = 0; k < 16; ++k) s += part[TP_C * TP_W + k * TP_H + p];
-        by[p] = s;
         a.xh[(size_t)f * TP_H + p] = s;
       }
     });
-    if (a.mode & FM_LOSS) {
-      // ---- Gaussian log-density with unit variance (util/layers.py:159-167) and its gradient
-      const float* tf = a.target + (size_t)f * TP_H;
-      run.phase([&](int tid) {
-        float s = 0.f;
-        for (int p = tid; p < TP_H; p += NT) {
-          const float d = tf[p] - by[p];
-          s += -0.5f * (LOG_2PI_F + (d * d) / (1.0f + EPSILON_F));
-          if (a.mode & FM_GRAD) a.d_xh[(size_t)f * TP_H + p] = -d / (1.0f + EPSILON_F) * a.invF;
-        }
-        red[tid] = s;
-      });
-      run.phase([&](int tid) {
-        if (tid < 32) {
-          float s = 0.f;
-          for (int i = 0; i < 32; ++i) s += red[tid * 32 + i];
-          red[R_RED2 + tid] = s;
-        }
-      });
-      run.phase([&](int tid) {
-        if (tid == 0) {
-          float s = 0.f;
-          for (int i = 0; i < 32; ++i) s += red[R_RED2 + i];
-          a.nll_f[f] = s;
-        }
-      });
-    }
-    }
+  }
+}
+
+// once per workgroup, before its first frame (both passes)
+template <class R>
+FR_DEV void frame_prologue(R& run, float* lds, const float* P, const POff& o) {
+  auto Pg = fr_g(P);
+  run.phase([&](int tid) { load_channel_vectors(tid, Pg, o, lds + L_CH); });
 }
 
 template <class R, class Eps>
@@ -800,9 +913,6 @@ FR_DEV void frame_fwd(R& run, float* lds, const FwdArgs& a, int f, Eps&& draw) {
 // per-frame, per-channel sums the LayerNorm backward leaves for the parameter gradients (reduced over frames by the
 // weight-gradient launch): lnp[(f*3 + k)*LNP_C + LNP_OFF[layer] + c], k = 0: d(offset) = sum_h dn, 1: d(scale) =
 // sum_h dn * xhat, 2: d(conv bias) = sum_h d(pre-LN output)
-constexpr int LNP_C = 552;
-// layer order of the backward pass: dec2, dec1, dec0, enc4, enc3, enc2, enc1, enc0
-constexpr int LNP_DEC2 = 0, LNP_DEC1 = 8, LNP_DEC0 = 24, LNP_ENC4 = 56, LNP_ENC3 = 312, LNP_ENC2 = 440, LNP_ENC1 = 504, LNP_ENC0 = 536;
 
 struct BwdArgs {
   const float* P;
@@ -827,60 +937,40 @@ struct BwdArgs {
   float* d_enc_a[5];
   float* lnp;             // [F][3][LNP_C]
 };
+static_assert(sizeof(BwdArgs) <= ARGS_FLOATS * 4, "argument block larger than its LDS slot");
 
 // LayerNorm + lrelu backward of one frame (autodiff of util/layers.py:32-44,149):
 //   n = gamma xhat + beta, dn = dy lrelu'(n), dx = dn gamma, da = rstd (dx - mean(dx) - xhat mean(dx xhat))
-// dy in `by` (plain [C][H]), pre-LN tensor a from HBM -> `bx`; result da in `by` (and HBM), channel sums -> lnp.
+// Entered after the phase that left dy in `by` (plain [C][H]) and the pre-LN tensor a in `bx` with {mean, rstd} in
+// red[R_ST..]; leaves da in `by` (the caller flushes it to HBM under its next long phase) and the channel sums in lnp.
+FR_DEV float ln_dn(float a, float dy, float mean, float rstd, float g, float b, float& xh) {
+  xh = (a - mean) * rstd;
+  const float nn = xh * g + b;
+  return dy * (nn >= 0.f ? 1.0f : LEAK_F);
+}
 template <class R, int C, int H>
-FR_DEV void ln_bwd(R& run, float* bx, float* by, float* part, float* red, const float* a_g, const float* st_g,
-                   const float* gamma, const float* beta, float* da_g, float* lnp_f /* + layer offset, stride LNP_C */) {
+FR_DEV void ln_bwd(R& run, float* bx, float* by, float* part, float* red, const float* gamma, const float* beta,
+                   FR_G(float) lnp_f /* + layer offset, stride LNP_C */) {   // (gamma / beta: the LDS copies)
   constexpr int N = C * H;
   constexpr int SEGS = imin_(NT / C, H), SLEN = cdiv_(H, SEGS);
-  run.phase([&](int tid) {
-    for (int i = tid; i < N; i += NT) bx[i] = a_g[i];
-    if (tid == 0) {
-      red[R_ST] = st_g[0];
-      red[R_ST + 1] = st_g[1];
-    }
-  });
-  run.phase([&](int tid) {
+  run.reduce2(red + R_S1, red + R_S2, [&](int tid, float& s1, float& s2) {
     const float mean = red[R_ST], rstd = red[R_ST + 1];
-    float s1 = 0.f, s2 = 0.f;
+    s1 = 0.f;
+    s2 = 0.f;
     for (int i = tid; i < N; i += NT) {
       const int c = i / H;
-      const float xh = (bx[i] - mean) * rstd;
-      const float nn = xh * gamma[c] + beta[c];
-      const float dn = by[i] * (nn >= 0.f ? 1.0f : LEAK_F);
-      by[i] = dn;
-      const float dx = dn * gamma[c];
+      float xh;
+      const float dx = ln_dn(bx[i], by[i], mean, rstd, gamma[c], beta[c], xh) * gamma[c];
       s1 += dx;
       s2 += dx * xh;
     }
-    red[tid] = s1;
-    red[R_REDB + tid] = s2;
-  });
-  run.phase([&](int tid) {
-    if (tid < 64) {
-      const float* src = red + (tid < 32 ? 0 : R_REDB) + (tid & 31) * 32;
-      float s = 0.f;
-      for (int i = 0; i < 32; ++i) s += src[i];
-      red[R_RED2 + tid] = s;      // [R_RED2, +32): s1 partials, [R_RED2B, +32): s2 partials
-    }
-  });
-  run.phase([&](int tid) {
-    if (tid < 2) {
-      float s = 0.f;
-      for (int i = 0; i < 32; ++i) s += red[R_RED2 + 32 * tid + i];
-      red[R_ST + 2 + tid] = s * (1.0f / N);
-    }
     // channel sums over position segments: A = sum dn, B = sum dn xhat, X = sum xhat
     if (tid < C * SEGS) {
-      const float mean = red[R_ST], rstd = red[R_ST + 1];
       const int c = tid / SEGS, sg = tid % SEGS;
       float sa = 0.f, sb = 0.f, sx = 0.f;
       for (int h = sg * SLEN; h < imin_(H, (sg + 1) * SLEN); ++h) {
-        const float xh = (bx[c * H + h] - mean) * rstd;
-        const float dn = by[c * H + h];
+        float xh;
+        const float dn = ln_dn(bx[c * H + h], by[c * H + h], mean, rstd, gamma[c], beta[c], xh);
         sa += dn;
         sb += dn * xh;
         sx += xh;
@@ -891,7 +981,8 @@ FR_DEV void ln_bwd(R& run, float* bx, float* by, float* part, float* red, const 
     }
   });
   run.phase([&](int tid) {
-    const float rstd = red[R_ST + 1], m1 = red[R_ST + 2], m2 = red[R_ST + 3];
+    const float mean = red[R_ST], rstd = red[R_ST + 1];
+    const float m1 = sum16(red + R_S1) * (1.0f / N), m2 = sum16(red + R_S2) * (1.0f / N);
     if (tid < C) {
       float sa = 0.f, sb = 0.f, sx = 0.f;
       for (int i = 0; i < SEGS; ++i) {
@@ -903,30 +994,46 @@ FR_DEV void ln_bwd(R& run, float* bx, float* by, float* part, float* red, const 
       lnp_f[LNP_C + tid] = sb;
       lnp_f[2 * LNP_C + tid] = rstd * (gamma[tid] * sa - (float)H * m1 - m2 * sx);
     }
-  });
-  run.phase([&](int tid) {
-    const float mean = red[R_ST], rstd = red[R_ST + 1], m1 = red[R_ST + 2], m2 = red[R_ST + 3];
     for (int i = tid; i < N; i += NT) {
       const int c = i / H;
-      const float xh = (bx[i] - mean) * rstd;
-      const float da = rstd * (by[i] * gamma[c] - m1 - xh * m2);
-      by[i] = da;
-      da_g[i] = da;
+      float xh;
+      const float dx = ln_dn(bx[i], by[i], mean, rstd, gamma[c], beta[c], xh) * gamma[c];
+      by[i] = rstd * (dx - m1 - xh * m2);
     }
   });
 }
+// the phase in front of ln_bwd: dy = sum of the K slices -> `by`, the layer's pre-LN tensor -> `bx`, its statistics
+template <int KS, int NOUT>
+FR_DEV void reduce_load(int tid, const float* part, float* by, FR_G(const float) a_g, float* bx, FR_G(const float) st_g, float* red) {
+  for (int i = tid; i < NOUT; i += NT) {
+    float s = 0.f;
+    FR_UNROLL
+    for (int k = 0; k < KS; ++k) s += part[k * NOUT + i];
+    by[i] = s;
+    bx[i] = a_g[i];
+  }
+  if (tid == 0) {
+    red[R_ST] = st_g[0];
+    red[R_ST + 1] = st_g[1];
+  }
+}
 
 template <class R>
-FR_STAGE void frame_bwd_dec(R& run, float* lds, const BwdArgs& a, int f) {
+FR_STAGE void frame_bwd_dec(R& run, float* lds_, const BwdArgs& a_, int f_) {
+  const int f = FR_UNIFORM(f_);
+  float* lds = fr_l(lds_);
+  const BwdArgs& a = *fr_l(&a_);
+  auto pk = fr_g(a.pk);
+  (void)pk;
   float* bx = lds + L_BUFX;
   float* by = lds + L_BUFY;
   float* part = lds + L_PART;
   float* red = lds + L_RED;
+  const float* ch = lds + L_CH;
   float* vec = lds + L_VEC;
-  const float* P = a.P;
+  auto P = fr_g(a.P);
   const POff& o = a.off;
-  float* lnp_f = a.lnp + (size_t)f * 3 * LNP_C;
-  (void)bx; (void)by; (void)part; (void)red; (void)vec; (void)P; (void)o; (void)lnp_f;
+  auto lnp_f = fr_g(a.lnp) + (size_t)f * 3 * LNP_C;
   // ---- d(xh) of G = -logP + D_KL (model/vae.py:128; util/layers.py:159-167): (xh - x) / ((1 + 1e-6) F)
   run.phase([&](int tid) {
     for (int p = tid; p < TP_H; p += NT) {
@@ -935,43 +1042,66 @@ FR_STAGE void frame_bwd_dec(R& run, float* lds, const BwdArgs& a, int f) {
       vec[p] = g;
       a.d_xh[(size_t)f * TP_H + p] = g;
     }
-    for (int i = tid; i < TP_C * TP_W; i += NT) part[i] = a.pk[Pk::w3t + i];
+    for (int i = tid; i < TP_C * TP_W; i += NT) part[i] = pk[Pk::w3t + i];
   });
   // ---- d3 input gradient, LayerNorm backward of decoder layer 2
   run.phase([&](int tid) { toep_dgrad_part(tid, vec, part, part + TP_C * TP_W); });
+  run.phase([&](int tid) { reduce_load<2, 4104>(tid, part + TP_C * TP_W, by, fr_g(a.dec_a[2]) + (size_t)f * 4104, bx, fr_g(a.dec_st[2]) + 2 * (size_t)f, red); });
+  ln_bwd<R, 8, 513>(run, bx, by, part, red, ch + LNP_C + LNP_DEC2, ch + 2 * LNP_C + LNP_DEC2, lnp_f + LNP_DEC2);
   run.phase([&](int tid) {
-    for (int i = tid; i < TP_C * TP_H; i += NT) by[i] = part[TP_C * TP_W + i] + part[TP_C * TP_W + TP_C * TP_H + i];
+    flush(tid, by, fr_g(a.d_dec_a[2]) + (size_t)f * 4104, 4104);
+    halo_copy<8, 513, D2G::HP, D2G::PAD>(tid, by, bx);
   });
-  ln_bwd<R, 8, 513>(run, bx, by, part, red, a.dec_a[2] + (size_t)f * 4104, a.dec_st[2] + 2 * (size_t)f, P + o.dgamma[2],
-                    P + o.dbeta[2], a.d_dec_a[2] + (size_t)f * 4104, lnp_f + LNP_DEC2);
-  run.phase([&](int tid) { halo_copy<8, 513, D2G::HP, D2G::PAD>(tid, by, bx); });
-  run.phase([&](int tid) { sconv_part<D2G>(tid, bx, a.pk + Pk::d2g, part); });
-  run.phase([&](int tid) { reduce_out<D2G::KS, D2G::NOUT, D2G::HO>(tid, part, nullptr, by, nullptr); });
-  ln_bwd<R, 16, 171>(run, bx, by, part, red, a.dec_a[1] + (size_t)f * 2736, a.dec_st[1] + 2 * (size_t)f, P + o.dgamma[1],
-                     P + o.dbeta[1], a.d_dec_a[1] + (size_t)f * 2736, lnp_f + LNP_DEC1);
-  run.phase([&](int tid) { halo_copy<16, 171, D1G::HP, D1G::PAD>(tid, by, bx); });
-  run.phase([&](int tid) { sconv_part<D1G>(tid, bx, a.pk + Pk::d1g, part); });
-  run.phase([&](int tid) { reduce_out<D1G::KS, D1G::NOUT, D1G::HO>(tid, part, nullptr, by, nullptr); });
-  ln_bwd<R, 32, 57>(run, bx, by, part, red, a.dec_a[0] + (size_t)f * 1824, a.dec_st[0] + 2 * (size_t)f, P + o.dgamma[0],
-                    P + o.dbeta[0], a.d_dec_a[0] + (size_t)f * 1824, lnp_f + LNP_DEC0);
-  run.phase([&](int tid) { halo_copy<32, 57, D0G::HP, D0G::PAD>(tid, by, bx); });
-  run.phase([&](int tid) { sconv_part<D0G>(tid, bx, a.pk + Pk::d0g, part); });
-  run.phase([&](int tid) { reduce_out<D0G::KS, D0G::NOUT, D0G::HO>(tid, part, nullptr, by, a.d_h + (size_t)f * MERGE_N); });
+  run.phase([&](int tid) {
+    sconv_part<D2G>(tid, bx, pk + Pk::d2g, part);
+  });
+  run.phase([&](int tid) { reduce_load<D2G::KS, D2G::NOUT>(tid, part, by, fr_g(a.dec_a[1]) + (size_t)f * 2736, bx, fr_g(a.dec_st[1]) + 2 * (size_t)f, red); });
+  ln_bwd<R, 16, 171>(run, bx, by, part, red, ch + LNP_C + LNP_DEC1, ch + 2 * LNP_C + LNP_DEC1, lnp_f + LNP_DEC1);
+  run.phase([&](int tid) {
+    flush(tid, by, fr_g(a.d_dec_a[1]) + (size_t)f * 2736, 2736);
+    halo_copy<16, 171, D1G::HP, D1G::PAD>(tid, by, bx);
+  });
+  run.phase([&](int tid) {
+    sconv_part<D1G>(tid, bx, pk + Pk::d1g, part);
+  });
+  run.phase([&](int tid) { reduce_load<D1G::KS, D1G::NOUT>(tid, part, by, fr_g(a.dec_a[0]) + (size_t)f * 1824, bx, fr_g(a.dec_st[0]) + 2 * (size_t)f, red); });
+  ln_bwd<R, 32, 57>(run, bx, by, part, red, ch + LNP_C + LNP_DEC0, ch + 2 * LNP_C + LNP_DEC0, lnp_f + LNP_DEC0);
+  run.phase([&](int tid) {
+    flush(tid, by, fr_g(a.d_dec_a[0]) + (size_t)f * 1824, 1824);
+    halo_copy<32, 57, D0G::HP, D0G::PAD>(tid, by, bx);
+  });
+  run.phase([&](int tid) {
+    sconv_part<D0G>(tid, bx, pk + Pk::d0g, part);
+  });
+  run.phase([&](int tid) {
+    for (int i = tid; i < MERGE_N; i += NT) {
+      float s = 0.f;
+      FR_UNROLL
+      for (int k = 0; k < D0G::KS; ++k) s += part[k * MERGE_N + i];
+      by[i] = s;
+      a.d_h[(size_t)f * MERGE_N + i] = s;
+    }
+  });
 }
 
 template <class R>
-FR_STAGE void frame_bwd_mid(R& run, float* lds, const BwdArgs& a, int f) {
+FR_STAGE void frame_bwd_mid(R& run, float* lds_, const BwdArgs& a_, int f_) {
+  const int f = FR_UNIFORM(f_);
+  float* lds = fr_l(lds_);
+  const BwdArgs& a = *fr_l(&a_);
+  auto pk = fr_g(a.pk);
+  (void)pk;
   float* bx = lds + L_BUFX;
   float* by = lds + L_BUFY;
   float* part = lds + L_PART;
   float* red = lds + L_RED;
+  const float* ch = lds + L_CH;
   float* vec = lds + L_VEC;
-  const float* P = a.P;
+  auto P = fr_g(a.P);
   const POff& o = a.off;
-  float* lnp_f = a.lnp + (size_t)f * 3 * LNP_C;
-  (void)bx; (void)by; (void)part; (void)red; (void)vec; (void)P; (void)o; (void)lnp_f;
+  auto lnp_f = fr_g(a.lnp) + (size_t)f * 3 * LNP_C;
   // ---- merge: d(z) = d(h) Wz^T; sampler + KL backward (util/layers.py:152-156, 170-183)
-  run.phase([&](int tid) { dense4_part<MergeG>(tid, by, a.pk + Pk::wzT, part); });
+  run.phase([&](int tid) { dense4_part<MergeG>(tid, by, pk + Pk::wzT, part); });
   run.phase([&](int tid) {
     if (tid < 128) {
       float dz = 0.f;
@@ -982,49 +1112,69 @@ FR_STAGE void frame_bwd_mid(R& run, float* lds, const BwdArgs& a, int f) {
       const float dlv = dz * (0.5f * a.eps[e] * sqrtf(v)) + 0.5f * (v / (1.0f + EPSILON_F) - 1.0f) * a.invF;
       vec[256 + tid] = dmu;
       vec[384 + tid] = dlv;
-      if (a.d_z) a.d_z[e] = dz;
+      if (fr_g(a.d_z)) a.d_z[e] = dz;
       a.d_z_mu[e] = dmu;
       a.d_z_lv[e] = dlv;
     }
   });
   // ---- heads: d(y4) = [dz_mu | dz_lv] [Wmu | Wlv]^T, LayerNorm backward of encoder layer 4
-  run.phase([&](int tid) { dense4_part<HeadsG>(tid, vec + 256, a.pk + Pk::headsT, part); });
-  run.phase([&](int tid) { reduce_out<HeadsG::KS, 768, 3>(tid, part, nullptr, by, nullptr); });
-  ln_bwd<R, 256, 3>(run, bx, by, part, red, a.enc_a[4] + (size_t)f * 768, a.enc_st[4] + 2 * (size_t)f, P + o.egamma[4],
-                    P + o.ebeta[4], a.d_enc_a[4] + (size_t)f * 768, lnp_f + LNP_ENC4);
+  run.phase([&](int tid) { dense4_part<HeadsG>(tid, vec + 256, pk + Pk::headsT, part); });
+  run.phase([&](int tid) { reduce_load<HeadsG::KS, 768>(tid, part, by, fr_g(a.enc_a[4]) + (size_t)f * 768, bx, fr_g(a.enc_st[4]) + 2 * (size_t)f, red); });
+  ln_bwd<R, 256, 3>(run, bx, by, part, red, ch + LNP_C + LNP_ENC4, ch + 2 * LNP_C + LNP_ENC4, lnp_f + LNP_ENC4);
+  run.phase([&](int tid) {
+    flush(tid, by, fr_g(a.d_enc_a[4]) + (size_t)f * 768, 768);
+    halo_copy<256, 3, E4G::HP, E4G::HL>(tid, by, bx);
+  });
 }
 
 template <class R>
-FR_STAGE void frame_bwd_enc(R& run, float* lds, const BwdArgs& a, int f) {
+FR_STAGE void frame_bwd_enc(R& run, float* lds_, const BwdArgs& a_, int f_) {
+  const int f = FR_UNIFORM(f_);
+  float* lds = fr_l(lds_);
+  const BwdArgs& a = *fr_l(&a_);
+  auto pk = fr_g(a.pk);
+  (void)pk;
   float* bx = lds + L_BUFX;
   float* by = lds + L_BUFY;
   float* part = lds + L_PART;
   float* red = lds + L_RED;
-  float* vec = lds + L_VEC;
-  const float* P = a.P;
+  const float* ch = lds + L_CH;
+  auto P = fr_g(a.P);
   const POff& o = a.off;
-  float* lnp_f = a.lnp + (size_t)f * 3 * LNP_C;
-  (void)bx; (void)by; (void)part; (void)red; (void)vec; (void)P; (void)o; (void)lnp_f;
-  run.phase([&](int tid) { halo_copy<256, 3, E4G::HP, E4G::HL>(tid, by, bx); });
-  run.phase([&](int tid) { tconv_part<E4G>(tid, bx, a.pk + Pk::e4g, part); });
-  run.phase([&](int tid) { reduce_out<E4G::KS, E4G::NOUT, E4G::HOUT>(tid, part, nullptr, by, nullptr); });
-  ln_bwd<R, 128, 7>(run, bx, by, part, red, a.enc_a[3] + (size_t)f * 896, a.enc_st[3] + 2 * (size_t)f, P + o.egamma[3],
-                    P + o.ebeta[3], a.d_enc_a[3] + (size_t)f * 896, lnp_f + LNP_ENC3);
-  run.phase([&](int tid) { halo_copy<128, 7, E3G::HP, E3G::HL>(tid, by, bx); });
-  run.phase([&](int tid) { tconv_part<E3G>(tid, bx, a.pk + Pk::e3g, part); });
-  run.phase([&](int tid) { reduce_out<E3G::KS, E3G::NOUT, E3G::HOUT>(tid, part, nullptr, by, nullptr); });
-  ln_bwd<R, 64, 19>(run, bx, by, part, red, a.enc_a[2] + (size_t)f * 1216, a.enc_st[2] + 2 * (size_t)f, P + o.egamma[2],
-                    P + o.ebeta[2], a.d_enc_a[2] + (size_t)f * 1216, lnp_f + LNP_ENC2);
-  run.phase([&](int tid) { halo_copy<64, 19, E2G::HP, E2G::HL>(tid, by, bx); });
-  run.phase([&](int tid) { tconv_part<E2G>(tid, bx, a.pk + Pk::e2g, part); });
-  run.phase([&](int tid) { reduce_out<E2G::KS, E2G::NOUT, E2G::HOUT>(tid, part, nullptr, by, nullptr); });
-  ln_bwd<R, 32, 57>(run, bx, by, part, red, a.enc_a[1] + (size_t)f * 1824, a.enc_st[1] + 2 * (size_t)f, P + o.egamma[1],
-                    P + o.ebeta[1], a.d_enc_a[1] + (size_t)f * 1824, lnp_f + LNP_ENC1);
-  run.phase([&](int tid) { halo_copy<32, 57, E1G::HP, E1G::HL>(tid, by, bx); });
-  run.phase([&](int tid) { tconv_part<E1G>(tid, bx, a.pk + Pk::e1g, part); });
-  run.phase([&](int tid) { reduce_out<E1G::KS, E1G::NOUT, E1G::HOUT>(tid, part, nullptr, by, nullptr); });
-  ln_bwd<R, 16, 171>(run, bx, by, part, red, a.enc_a[0] + (size_t)f * 2736, a.enc_st[0] + 2 * (size_t)f, P + o.egamma[0],
-                     P + o.ebeta[0], a.d_enc_a[0] + (size_t)f * 2736, lnp_f + LNP_ENC0);
+  auto lnp_f = fr_g(a.lnp) + (size_t)f * 3 * LNP_C;
+  run.phase([&](int tid) {
+    tconv_part<E4G>(tid, bx, pk + Pk::e4g, part);
+  });
+  run.phase([&](int tid) { reduce_load<E4G::KS, E4G::NOUT>(tid, part, by, fr_g(a.enc_a[3]) + (size_t)f * 896, bx, fr_g(a.enc_st[3]) + 2 * (size_t)f, red); });
+  ln_bwd<R, 128, 7>(run, bx, by, part, red, ch + LNP_C + LNP_ENC3, ch + 2 * LNP_C + LNP_ENC3, lnp_f + LNP_ENC3);
+  run.phase([&](int tid) {
+    flush(tid, by, fr_g(a.d_enc_a[3]) + (size_t)f * 896, 896);
+    halo_copy<128, 7, E3G::HP, E3G::HL>(tid, by, bx);
+  });
+  run.phase([&](int tid) {
+    tconv_part<E3G>(tid, bx, pk + Pk::e3g, part);
+  });
+  run.phase([&](int tid) { reduce_load<E3G::KS, E3G::NOUT>(tid, part, by, fr_g(a.enc_a[2]) + (size_t)f * 1216, bx, fr_g(a.enc_st[2]) + 2 * (size_t)f, red); });
+  ln_bwd<R, 64, 19>(run, bx, by, part, red, ch + LNP_C + LNP_ENC2, ch + 2 * LNP_C + LNP_ENC2, lnp_f + LNP_ENC2);
+  run.phase([&](int tid) {
+    flush(tid, by, fr_g(a.d_enc_a[2]) + (size_t)f * 1216, 1216);
+    halo_copy<64, 19, E2G::HP, E2G::HL>(tid, by, bx);
+  });
+  run.phase([&](int tid) {
+    tconv_part<E2G>(tid, bx, pk + Pk::e2g, part);
+  });
+  run.phase([&](int tid) { reduce_load<E2G::KS, E2G::NOUT>(tid, part, by, fr_g(a.enc_a[1]) + (size_t)f * 1824, bx, fr_g(a.enc_st[1]) + 2 * (size_t)f, red); });
+  ln_bwd<R, 32, 57>(run, bx, by, part, red, ch + LNP_C + LNP_ENC1, ch + 2 * LNP_C + LNP_ENC1, lnp_f + LNP_ENC1);
+  run.phase([&](int tid) {
+    flush(tid, by, fr_g(a.d_enc_a[1]) + (size_t)f * 1824, 1824);
+    halo_copy<32, 57, E1G::HP, E1G::HL>(tid, by, bx);
+  });
+  run.phase([&](int tid) {
+    tconv_part<E1G>(tid, bx, pk + Pk::e1g, part);
+  });
+  run.phase([&](int tid) { reduce_load<E1G::KS, E1G::NOUT>(tid, part, by, fr_g(a.enc_a[0]) + (size_t)f * 2736, bx, fr_g(a.enc_st[0]) + 2 * (size_t)f, red); });
+  ln_bwd<R, 16, 171>(run, bx, by, part, red, ch + LNP_C + LNP_ENC0, ch + 2 * LNP_C + LNP_ENC0, lnp_f + LNP_ENC0);
+  run.phase([&](int tid) { flush(tid, by, fr_g(a.d_enc_a[0]) + (size_t)f * 2736, 2736); });
 }
 
 template <class R>

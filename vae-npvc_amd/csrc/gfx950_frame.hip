@@ -6,6 +6,7 @@
 // Reference: model/vae.py:72-137 (forward), trainer/vae.py:24 (autodiff).
 #include "gfx950_frame.h"
 
+#include <cstdlib>
 #include <cstring>
 
 #include "cl_layout.h"
@@ -16,38 +17,127 @@ namespace tuned {
 using namespace frame;
 static_assert(Pk::total == FRAME_PK_FLOATS && LNP_C == FRAME_LNP_C, "workspace constants (cl_layout.h) out of date");
 static inline int cmin_i(int a, int b) { return a < b ? a : b; }
+// workgroups of a pass: one per frame up to 1024 (VAENPVC_FRAME_GRID: developer override for experiments)
+static int frame_grid(int F) {
+  static const int env = getenv("VAENPVC_FRAME_GRID") ? atoi(getenv("VAENPVC_FRAME_GRID")) : 0;
+  return env > 0 ? cmin_i(env, F) : cmin_i(F, 1024);
+}
 
-struct DevRunner {
+// PROF: developer instrumentation (VAENPVC_FRAME_PROF=1), a separate instantiation: shader-clock stamp of every phase
+// boundary of block 0.  The product instantiation has NO members: the runner is handed to the stage functions by
+// reference, and a member would be re-read from memory (scratch) behind every barrier.
+template <bool PROF>
+struct DevRunnerT;
+template <>
+struct DevRunnerT<false> {
+  __device__ __forceinline__ DevRunnerT(long long*, int) {}
+  __device__ __forceinline__ void stamp() {}
+};
+template <>
+struct DevRunnerT<true> {
+  long long* prof;
+  int n;
+  __device__ __forceinline__ DevRunnerT(long long* p, int n0) : prof(p), n(n0) {}
+  __device__ __forceinline__ void stamp() {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n < 511) prof[++n] = clock64();
+  }
+};
+template <bool PROF>
+struct DevRunner : DevRunnerT<PROF> {
+  __device__ __forceinline__ DevRunner(long long* p, int n0) : DevRunnerT<PROF>(p, n0) {}
+  using DevRunnerT<PROF>::stamp;
+  // Workgroup barrier that orders LDS only: __syncthreads() also waits for every outstanding global STORE (vmcnt(0)),
+  // i.e. a full HBM write round trip per phase, and nothing a pass writes to HBM is read again inside the pass.
+  __device__ __forceinline__ void sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    stamp();
+  }
   template <class F>
   __device__ __forceinline__ void phase(F&& f) {
     f((int)threadIdx.x);
-    __syncthreads();
+    sync();
+  }
+  // dst[wave] = sum over the wave's lanes of f(tid); a workgroup-wide sum is sum16(dst) in the next phase
+  template <class F>
+  __device__ __forceinline__ void reduce(float* dst, F&& f) {
+    float v = f((int)threadIdx.x);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) dst[threadIdx.x >> 6] = v;
+    sync();
+  }
+  template <class F>
+  __device__ __forceinline__ void reduce2(float* da, float* db, F&& f) {
+    float a = 0.f, b = 0.f;
+    f((int)threadIdx.x, a, b);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o);
+      b += __shfl_xor(b, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      da[threadIdx.x >> 6] = a;
+      db[threadIdx.x >> 6] = b;
+    }
+    sync();
   }
 };
-
-__global__ void __launch_bounds__(256) k_frame_pack(const float* __restrict__ P, POff off, float* __restrict__ pk,
-                                                    float* __restrict__ zero, int nzero) {
-  const int stride = gridDim.x * blockDim.x;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Pk::total; i += stride) pk[i] = pack_src(P, off, i);
-  if (zero)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += stride) zero[i] = 0.f;
+// The pass's argument block is copied ONCE from the kernel-argument segment into LDS and the stages read it there.
+// (Handing the by-value kernel argument to the stage functions by reference made every lane keep a private copy:
+//  ~0.6 MB of scratch writes per workgroup, 16 us at the head of each pass.)
+template <class A>
+__device__ __forceinline__ const A& args_to_lds(float* lds) {
+  static_assert(sizeof(A) % 4 == 0 && sizeof(A) <= ARGS_FLOATS * 4, "argument block");
+  const unsigned* ka = (const unsigned*)__builtin_amdgcn_kernarg_segment_ptr();   // first argument: offset 0
+  unsigned* la = reinterpret_cast<unsigned*>(lds + L_ARGS);
+  if (threadIdx.x < sizeof(A) / 4) la[threadIdx.x] = ka[threadIdx.x];
+  __syncthreads();
+  return *reinterpret_cast<const A*>(la);
+}
+static long long* g_prof_dev = nullptr;   // [2][512]: forward, backward (debug only; allocated on first use)
+static long long* prof_buf() {
+  if (!g_prof_dev && getenv("VAENPVC_FRAME_PROF")) {
+    if (hipMalloc(&g_prof_dev, 2 * 512 * sizeof(long long)) != hipSuccess) g_prof_dev = nullptr;
+    else (void)hipMemset(g_prof_dev, 0, 2 * 512 * sizeof(long long));
+  }
+  return g_prof_dev;
 }
 
-__global__ void __launch_bounds__(NT) k_frame_fwd(FwdArgs a, PhiloxKey key, int draw) {
+__global__ void __launch_bounds__(256) k_frame_pack(const float* __restrict__ P, POff off, float* __restrict__ pk,
+                                                    float* __restrict__ zero, int nzero, float* __restrict__ zero2, int nzero2) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Pk::total; i += stride) pk[i] = pack_src(P, off, i);
+  // the step's zero fills ride along (gradient buffer, per-speaker sums of the merge backward): no memset launches
+  if (zero)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += stride) zero[i] = 0.f;
+  if (zero2)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero2; i += stride) zero2[i] = 0.f;
+}
+
+template <bool PROF>
+__global__ void __launch_bounds__(NT) k_frame_fwd(FwdArgs a, PhiloxKey key, int draw, long long* prof) {
   extern __shared__ __attribute__((aligned(16))) float frame_lds[];
-  DevRunner run;
+  DevRunner<PROF> run(prof, 0);
+  if (PROF && blockIdx.x == 0 && threadIdx.x == 0) prof[0] = clock64();
+  const FwdArgs& la = args_to_lds<FwdArgs>(frame_lds);      // (`a` itself is never addressed: see args_to_lds)
   if (draw) key = philox_resolve(key);
-  for (int f = blockIdx.x; f < a.F; f += gridDim.x)
-    frame_fwd(run, frame_lds, a, f, [&](int ff, int d) -> float {
+  const float* eps = la.eps;
+  frame_prologue(run, frame_lds, la.P, la.off);
+  for (int f = blockIdx.x; f < la.F; f += gridDim.x)
+    frame_fwd(run, frame_lds, la, f, [&](int ff, int d) -> float {
       if (draw) return philox_normal(key, (uint64_t)ff * 128 + (uint64_t)d);
-      return a.eps ? a.eps[(size_t)ff * 128 + d] : 0.f;
+      return eps ? eps[(size_t)ff * 128 + d] : 0.f;
     });
 }
 
-__global__ void __launch_bounds__(NT) k_frame_bwd(BwdArgs a) {
+template <bool PROF>
+__global__ void __launch_bounds__(NT) k_frame_bwd(BwdArgs a, long long* prof) {
   extern __shared__ __attribute__((aligned(16))) float frame_lds[];
-  DevRunner run;
-  for (int f = blockIdx.x; f < a.F; f += gridDim.x) frame_bwd(run, frame_lds, a, f);
+  DevRunner<PROF> run(prof, 0);
+  if (PROF && blockIdx.x == 0 && threadIdx.x == 0) prof[0] = clock64();
+  const BwdArgs& la = args_to_lds<BwdArgs>(frame_lds);
+  frame_prologue(run, frame_lds, la.P, la.off);
+  for (int f = blockIdx.x; f < la.F; f += gridDim.x) frame_bwd(run, frame_lds, la, f);
 }
 
 // batch means {G, D_KL, logP} (model/vae.py:112-128), one block, fixed summation order
@@ -80,17 +170,31 @@ __global__ void __launch_bounds__(256) k_frame_loss(const float* __restrict__ kl
 struct LnpDst {
   int beta[8], gamma[8], bias[8];   // destination offsets in the gradient buffer, layer order of LNP_*
 };
-__global__ void __launch_bounds__(64) k_frame_lnp(const float* __restrict__ lnp, int F, LnpDst d, float* __restrict__ G) {
-  const int i = blockIdx.x * 64 + threadIdx.x;      // (k, channel slot)
-  if (i >= 3 * LNP_C) return;
-  const int k = i / LNP_C, cs = i % LNP_C;
-  constexpr int OFFS[9] = {LNP_DEC2, LNP_DEC1, LNP_DEC0, LNP_ENC4, LNP_ENC3, LNP_ENC2, LNP_ENC1, LNP_ENC0, LNP_C};
-  int l = 0;
-  while (cs >= OFFS[l + 1]) ++l;
+__global__ void __launch_bounds__(256) k_frame_lnp(const float* __restrict__ lnp, int F, LnpDst d, float* __restrict__ G) {
+  // block = 64 channel slots of one k; the four waves take every fourth frame, partial rows combined through LDS
+  __shared__ float sm[4][64];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;      // (k, channel slot), padded per k
+  constexpr int SLOTS = (LNP_C + 63) / 64 * 64;
+  const int k = i / SLOTS, cs = i % SLOTS;
   float s = 0.f;
-  for (int f = 0; f < F; ++f) s += lnp[((size_t)f * 3 + k) * LNP_C + cs];
-  const int c = cs - OFFS[l];
-  G[(k == 0 ? d.beta[l] : k == 1 ? d.gamma[l] : d.bias[l]) + c] = s;
+  if (cs < LNP_C)
+    for (int f = w; f < F; f += 4) s += lnp[((size_t)f * 3 + k) * LNP_C + cs];
+  sm[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && cs < LNP_C) {
+    s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    constexpr int OFFS[9] = {LNP_DEC2, LNP_DEC1, LNP_DEC0, LNP_ENC4, LNP_ENC3, LNP_ENC2, LNP_ENC1, LNP_ENC0, LNP_C};
+    int l = 0;
+    while (cs >= OFFS[l + 1]) ++l;
+    G[(k == 0 ? d.beta[l] : k == 1 ? d.gamma[l] : d.bias[l]) + cs - OFFS[l]] = s;
+  }
+}
+
+// developer read-out of the phase stamps (not part of include/vaenpvc.h)
+extern "C" int vaenpvc_debug_frame_prof(long long* out /*[2][512]*/) {
+  if (!g_prof_dev) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -3;
+  return hipMemcpy(out, g_prof_dev, 2 * 512 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -135,8 +239,8 @@ bool frame_bwd_on(int64_t F) {
   return r.frame_max > 0 && F <= r.frame_max && ((r.bwd_mask >> 21) & 1u);
 }
 
-void frame_pack(const Model& m, const float* P, const Ws& w, float* G, hipStream_t s) {
-  hipLaunchKernelGGL(k_frame_pack, dim3(512), dim3(256), 0, s, P, poff_of(m), w.frame_pk, G, G ? (int)m.n_params : 0);
+void frame_pack(const Model& m, const float* P, const Ws& w, float* G, float* zero2, int nzero2, hipStream_t s) {
+  hipLaunchKernelGGL(k_frame_pack, dim3(512), dim3(256), 0, s, P, poff_of(m), w.frame_pk, G, G ? (int)m.n_params : 0, zero2, nzero2);
 }
 
 // mode: FM_* bits.  x may be null for decode-only, z_in null unless decode-only.
@@ -177,8 +281,13 @@ void frame_forward(const Model& m, const float* P, const float* x, const float* 
   a.dec_y = (mode & FM_GRAD) ? w.dec_y : nullptr;      // (train step: the layered weight gradient of the last layer reads it)
   if (!a.d_xh) a.mode &= ~FM_GRAD;
   PhiloxKey k = key ? *key : PhiloxKey{0, 0, 0, 0, nullptr};
-  rt().ensure_lds(reinterpret_cast<const void*>(&k_frame_fwd), L_TOTAL * 4);
-  VAENPVC_TIMED("frame_fwd", s, hipLaunchKernelGGL(k_frame_fwd, dim3((unsigned)cmin_i((int)F, 1024)), dim3(NT), L_TOTAL * 4, s, a, k, key ? 1 : 0));
+  if (long long* pb = prof_buf()) {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_frame_fwd<true>), L_TOTAL * 4);
+    hipLaunchKernelGGL(k_frame_fwd<true>, dim3((unsigned)frame_grid((int)F)), dim3(NT), L_TOTAL * 4, s, a, k, key ? 1 : 0, pb);
+  } else {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_frame_fwd<false>), L_TOTAL * 4);
+    VAENPVC_TIMED("frame_fwd", s, hipLaunchKernelGGL(k_frame_fwd<false>, dim3((unsigned)frame_grid((int)F)), dim3(NT), L_TOTAL * 4, s, a, k, key ? 1 : 0, (long long*)nullptr));
+  }
   if (loss3 && (mode & FM_LOSS) && (mode & FM_SAMPLE))
     hipLaunchKernelGGL(k_frame_loss, dim3(1), dim3(256), 0, s, w.kl_f, w.nll_f, (int)F, loss3);
 }
@@ -213,8 +322,13 @@ void frame_backward(const Model& m, const float* P, const float* target, const f
   a.d_z_mu = w.d_z_mu;
   a.d_z_lv = w.d_z_lv;
   a.lnp = w.frame_lnp;
-  rt().ensure_lds(reinterpret_cast<const void*>(&k_frame_bwd), L_TOTAL * 4);
-  VAENPVC_TIMED("frame_bwd", s, hipLaunchKernelGGL(k_frame_bwd, dim3((unsigned)cmin_i((int)F, 1024)), dim3(NT), L_TOTAL * 4, s, a));
+  if (long long* pb = prof_buf()) {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_frame_bwd<true>), L_TOTAL * 4);
+    hipLaunchKernelGGL(k_frame_bwd<true>, dim3((unsigned)frame_grid((int)F)), dim3(NT), L_TOTAL * 4, s, a, pb + 512);
+  } else {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_frame_bwd<false>), L_TOTAL * 4);
+    VAENPVC_TIMED("frame_bwd", s, hipLaunchKernelGGL(k_frame_bwd<false>, dim3((unsigned)frame_grid((int)F)), dim3(NT), L_TOTAL * 4, s, a, (long long*)nullptr));
+  }
   // gradients of the LayerNorm parameters and conv biases of the eight normalised layers
   LnpDst d;
   const ConvL* L[8] = {&m.dec[2], &m.dec[1], &m.dec[0], &m.enc[4], &m.enc[3], &m.enc[2], &m.enc[1], &m.enc[0]};
@@ -223,7 +337,7 @@ void frame_backward(const Model& m, const float* P, const float* target, const f
     d.gamma[i] = (int)L[i]->gamma_off;
     d.bias[i] = (int)L[i]->b_off;
   }
-  hipLaunchKernelGGL(k_frame_lnp, dim3((unsigned)((3 * LNP_C + 63) / 64)), dim3(64), 0, s, w.frame_lnp, (int)F, d, G);
+  hipLaunchKernelGGL(k_frame_lnp, dim3((unsigned)(3 * ((LNP_C + 63) / 64))), dim3(256), 0, s, w.frame_lnp, (int)F, d, G);
 }
 
 }  // namespace tuned

@@ -1189,10 +1189,17 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
 // The input-gradient chain with every LayerNorm backward runs as ONE launch, one frame per workgroup (frame_backward);
 // what is left are the weight gradients, which depend on nothing but tensors that launch wrote: they are dealt to the
 // caller's stream and the context's helper stream and run next to each other.
+float* frame_zero_region(const Ws& w, int* count) {
+  *count = MERGE_NY * 1539;
+  return w.scratch + Pk::merge_s;
+}
 void backward_frame(const Model& m, const float* P, const float* x, const float* target, const int64_t* y, const float* eps,
-                    int64_t F64, const Ws& w, float* G, hipStream_t s) {
+                    int64_t F64, const Ws& w, float* G, hipStream_t s, bool g_zeroed) {
   const int F = (int)F64;
-  (void)hipMemsetAsync(G, 0, (size_t)m.n_params * 4, s);
+  if (!g_zeroed) {
+    (void)hipMemsetAsync(G, 0, (size_t)m.n_params * 4, s);
+    (void)hipMemsetAsync(w.scratch + Pk::merge_s, 0, (size_t)MERGE_NY * 1539 * 4, s);
+  }
   frame_backward(m, P, target ? target : x, eps, F, w, G, s);
   hipStream_t side = bwd_on(30) ? rt().side_stream() : nullptr;
   const bool fork = side != nullptr;
@@ -1221,8 +1228,7 @@ void backward_frame(const Model& m, const float* P, const float* x, const float*
   {
     TnArgs a = tn_args(w.z, 128, w.d_h, 1539, 128, 1539, F, G + m.wz_off, 1539);
     VAENPVC_TIMED("merge_wgrad", s, launch_tngemm(a, false, kchunks_for(F, 13), s));
-    float* Sg = w.scratch + Pk::merge_s;
-    (void)hipMemsetAsync(Sg, 0, (size_t)MERGE_NY * 1539 * 4, s);
+    float* Sg = w.scratch + Pk::merge_s;      // (zeroed by the step's frame_pack launch, or above)
     int ch = cmax(1, cmin_(cdiv(F, 64), 128)), fc = cdiv(F, ch);
     hipLaunchKernelGGL(k_segsum_atomic<MERGE_NY>, dim3((unsigned)cdiv(1539, 256), (unsigned)cdiv(F, fc)), dim3(256), 0, s, w.d_h, y, 1539, F, fc, Sg);
     const int nb_w = cdiv(128 * 1539, 256), nb_e = cdiv(MERGE_NY * 128, 4), nb_b = cdiv(1539, 256);

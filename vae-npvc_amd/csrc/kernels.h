@@ -111,7 +111,10 @@ int64_t frame_pack_floats();
 int64_t frame_lnp_floats(int64_t F);
 bool frame_fwd_on(int64_t F);
 bool frame_bwd_on(int64_t F);
-void frame_pack(const Model& m, const float* P, const Ws& w, float* G_zero, hipStream_t s);
+// packed weight copies; G_zero / zero2 (nullable): buffers zero-filled by the same launch
+void frame_pack(const Model& m, const float* P, const Ws& w, float* G_zero, float* zero2, int nzero2, hipStream_t s);
+// scratch region the small-batch backward wants zeroed before it runs (per-speaker sums of the merge backward)
+float* frame_zero_region(const Ws& w, int* count);
 void frame_forward(const Model& m, const float* P, const float* x, const float* target, const int64_t* y, const float* eps,
                    const PhiloxKey* key, const float* z_in, int64_t F, const Ws& w, float* xh_out, int mode, float* loss3,
                    hipStream_t s);
@@ -119,8 +122,9 @@ void frame_forward(const Model& m, const float* P, const float* x, const float* 
 void frame_backward(const Model& m, const float* P, const float* target, const float* eps, int64_t F, const Ws& w, float* G,
                     hipStream_t s);
 // the whole backward pass of a small batch: frame_backward + every weight gradient (gfx950_layers.hip)
+// (g_zeroed: the gradient buffer and frame_zero_region were zero-filled by this step's frame_pack)
 void backward_frame(const Model& m, const float* P, const float* x, const float* target, const int64_t* y, const float* eps,
-                    int64_t F, const Ws& w, float* G, hipStream_t s);
+                    int64_t F, const Ws& w, float* G, hipStream_t s, bool g_zeroed);
 }  // namespace tuned
 
 }  // namespace vaenpvc
