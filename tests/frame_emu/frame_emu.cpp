@@ -5,6 +5,7 @@
 // halos and the algebra of every stage are pinned before a GPU ever runs them.  Nothing in the product links this file.
 #define FRAME_EMU 1
 #include "../../vae-npvc_amd/csrc/gfx950_frame.h"
+#include "../../vae-npvc_amd/csrc/gfx950_frame_wgrad.h"
 
 #include <vector>
 
@@ -47,6 +48,28 @@ struct EmuRunner {
   }
 };
 
+// blocks of the weight-gradient launch (256 threads)
+struct EmuWRunner {
+  template <class F>
+  void phase(F&& f) {
+    for (int t = 0; t < WT; ++t) f(t);
+  }
+  template <class St, class Z, class Ac, class Sp, class AccT>
+  void frames(int f0, int f1, int fb, St&& st, Z&& z, Ac&& ac, Sp&& sp, AccT&) {
+    struct Box {
+      AccT a;
+    };
+    std::vector<Box> v(WT);
+    for (int t = 0; t < WT; ++t) z(t, v[t].a);
+    for (int f = f0; f < f1; f += fb) {
+      const int n = f1 - f < fb ? f1 - f : fb;
+      for (int t = 0; t < WT; ++t) st(t, f, n);
+      for (int t = 0; t < WT; ++t) ac(t, v[t].a, n);
+    }
+    for (int t = 0; t < WT; ++t) sp(t, v[t].a);
+  }
+};
+
 static POff make_off(const int* p) {
   POff o;
   int i = 0;
@@ -78,8 +101,8 @@ static POff make_off(const int* p) {
 }
 
 // tensor order of the offset table `t` (floats into `ws`)
-enum { T_ENC_A = 0, T_ENC_ST = 5, T_Z_MU = 10, T_Z_LV, T_Z, T_EPS_OUT, T_H, T_DEC_A, T_DEC_ST = T_DEC_A + 3, T_XH = T_DEC_ST + 3,
-       T_KL, T_NLL, T_D_XH, T_D_DEC_A, T_D_H = T_D_DEC_A + 3, T_D_Z_MU, T_D_Z_LV, T_D_ENC_A, T_LNP = T_D_ENC_A + 5, T_PK, T_G, T_COUNT };
+enum { T_Y = 39, T_ENC_A = 0, T_ENC_ST = 5, T_Z_MU = 10, T_Z_LV, T_Z, T_EPS_OUT, T_H, T_DEC_A, T_DEC_ST = T_DEC_A + 3, T_XH = T_DEC_ST + 3,
+       T_KL, T_NLL, T_D_XH, T_D_DEC_A, T_D_H = T_D_DEC_A + 3, T_D_Z_MU, T_D_Z_LV, T_D_ENC_A, T_LNP = T_D_ENC_A + 5, T_PK, T_G, T_YY, T_COUNT };
 
 extern "C" {
 
@@ -129,6 +152,19 @@ int frame_emu_run(const float* P, const int* poff, const float* x, const float* 
   a.kl_f = ws + t[T_KL];
   a.nll_f = ws + t[T_NLL];
   a.d_xh = ws + t[T_D_XH];
+  a.dec_y = ws + t[T_YY] + (size_t)F * 12000;
+  {
+    float* yb = ws + t[T_YY];
+    const int ne[5] = {2736, 1824, 1216, 896, 768}, nd[2] = {1824, 2736};
+    for (int i = 0; i < 5; ++i) {
+      a.y_enc[i] = yb;
+      yb += (size_t)F * ne[i];
+    }
+    for (int i = 0; i < 2; ++i) {
+      a.y_dec[i] = yb;
+      yb += (size_t)F * nd[i];
+    }
+  }
   frame_prologue(run, lds.data(), P, o);
   for (int f = 0; f < F; ++f)
     frame_fwd(run, lds.data(), a, f, [&](int ff, int d) { return eps ? eps[(size_t)ff * 128 + d] : 0.f; });
@@ -161,6 +197,35 @@ int frame_emu_run(const float* P, const int* poff, const float* x, const float* 
   b.d_z_lv = ws + t[T_D_Z_LV];
   b.lnp = ws + t[T_LNP];
   for (int f = 0; f < F; ++f) frame_bwd(run, lds.data(), b, f);
+  if (do_bwd < 2) return 0;
+  // ---- every parameter gradient: the job list of the one-launch kernel, block by block
+  WgArgs g{};
+  g.P = P;
+  g.off = o;
+  g.x = x;
+  g.y = a.y;
+  g.ny = ny;
+  g.F = F;
+  for (int i = 0; i < 5; ++i) {
+    g.y_enc[i] = a.y_enc[i];
+    g.d_enc_a[i] = b.d_enc_a[i];
+  }
+  for (int i = 0; i < 2; ++i) g.y_dec[i] = a.y_dec[i];
+  g.z = a.z;
+  g.h = a.h;
+  g.dec_y = a.dec_y;
+  g.d_xh = a.d_xh;
+  for (int i = 0; i < 3; ++i) g.d_dec_a[i] = b.d_dec_a[i];
+  g.d_h = b.d_h;
+  g.d_z_mu = b.d_z_mu;
+  g.d_z_lv = b.d_z_lv;
+  g.lnp = b.lnp;
+  g.pk = a.pk;
+  g.G = ws + t[T_G];
+  const WgPlan pl = make_wgplan(F, ny);
+  std::vector<float> wl(WG_LDS, 0.f);
+  EmuWRunner wr;
+  for (int blk = 0; blk < pl.start[pl.nseg]; ++blk) frame_wgrad_block(wr, wl.data(), g, pl, blk);
   return 0;
 }
 

@@ -62,10 +62,12 @@ DEC_N = [1824, 2736, 4104]
 def workspace(lib, F):
     sizes = ([F * n for n in ENC_N] + [2 * F] * 5 + [F * 128] * 4 + [F * 1539] + [F * n for n in DEC_N] + [2 * F] * 3
              + [F * 513, F, F, F * 513] + [F * n for n in DEC_N] + [F * 1539, F * 128, F * 128] + [F * n for n in ENC_N]
-             + [F * 3 * lib.frame_emu_lnp_c(), lib.frame_emu_pack_floats(), 0])
+             + [F * 3 * lib.frame_emu_lnp_c(), lib.frame_emu_pack_floats(), 939162, F * (12000 + 4104)])
     assert len(sizes) == lib.frame_emu_tensor_count()
     offs = np.concatenate([[0], np.cumsum([(s + 63) // 64 * 64 for s in sizes])]).astype(np.int64)
     ws = np.full(int(offs[-1]), np.nan, np.float32)
+    g0 = offs[len(sizes) - 2]
+    ws[g0:g0 + sizes[-2]] = 0.0            # the gradient buffer is zero-filled by the pack launch
     return ws, offs[:-1].copy(), sizes
 
 
@@ -73,12 +75,12 @@ def fptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def run_emu(lib, arch, P, x, y, eps, mode=31, bwd=True, target=None, z_in=None):
+def run_emu(lib, arch, P, x, y, eps, mode=31, bwd=True, target=None, z_in=None, wgrad=False):
     F = x.shape[0]
     po, _, _ = poff_table(arch)
     flat = O.flatten_params(P)
     ws, toff, sizes = workspace(lib, F)
-    T_PK = lib.frame_emu_tensor_count() - 2
+    T_PK = lib.frame_emu_tensor_count() - 3
     pk = ws[toff[T_PK]:toff[T_PK] + sizes[T_PK]]
     lib.frame_emu_pack(fptr(flat), fptr(po), fptr(pk))
     x = np.ascontiguousarray(x, np.float32)
@@ -86,7 +88,7 @@ def run_emu(lib, arch, P, x, y, eps, mode=31, bwd=True, target=None, z_in=None):
     eps = None if eps is None else np.ascontiguousarray(eps, np.float32)
     rc = lib.frame_emu_run(fptr(flat), fptr(po), fptr(x), fptr(target) if target is not None else None, fptr(y),
                            fptr(eps) if eps is not None else None, fptr(z_in) if z_in is not None else None,
-                           int(arch['y_dim']), F, mode, 1 if bwd else 0, fptr(ws), fptr(toff))
+                           int(arch['y_dim']), F, mode, (2 if wgrad else 1) if bwd else 0, fptr(ws), fptr(toff))
     assert rc == 0
 
     def t(i, shape):
@@ -190,4 +192,26 @@ def test_backward_pass_matches_autograd(emu, arch):
         errs[bias] = rel(lnp[2, off:off + c], GP[bias].ravel())
         off += c
     bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('F,seed', [(3, 12), (37, 13)])
+def test_one_launch_weight_gradient_matches_autograd(emu, arch, F, seed):
+    """the job list of the weight-gradient launch, block by block, after the emulated passes: all 44 gradients
+    (F = 37: more frames than the smaller jobs have frame chunks, ragged chunks)"""
+    P = O.init_params(arch, seed)
+    x, y, eps = O.make_inputs(arch, F, seed)
+    t, ws, toff = run_emu(emu, arch, P, x, y, eps, wgrad=True)
+    _, GP = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64)
+    T_G = emu.frame_emu_tensor_count() - 2
+    g = ws[toff[T_G]:toff[T_G] + 939162].astype(np.float64)
+    assert np.isfinite(g).all()
+    _, offs, n = poff_table(arch)
+    assert n == g.size
+    bad = {}
+    for name, want in GP.items():
+        got = g[offs[name]:offs[name] + want.size].reshape(want.shape)
+        e = rel(got, want)
+        if not e < 5e-5:
+            bad[name] = e
     assert not bad, bad

@@ -23,6 +23,14 @@ def test_frame_path_every_tensor_and_gradient(F, seed):
     assert not fails, '\n'.join(fails)
 
 
+def test_frame_passes_with_the_layered_weight_gradients():
+    """bit 20 of the backward mask cleared: the frame passes feed the LAYERED weight-gradient kernels (two streams)
+    instead of the one-launch job list -- the A/B partner of the default, kept correct"""
+    eng = make_engine('vcc', 'auto', masks=(0xffffffff, 0xffffffff & ~(1 << 20)), frame=True)
+    fails = compare_everything(eng, 16, 3, 'frame F16 layered-wgrad ')
+    assert not fails, '\n'.join(fails)
+
+
 def test_frame_path_is_what_runs_by_default_and_can_be_switched_off():
     """default masks select the frame kernels at 16 frames; clearing bit 21 selects the layered ones; both meet the
     oracle and each other (A/B on one engine)"""

@@ -105,6 +105,7 @@ static int resolve(vaenpvc_ctx* c, int64_t F, int mode, void* d_ws, size_t ws_by
     else if (n == "scratch") { w->scratch = p; w->scratch_floats = r.count; }
     else if (n == "frame_pk") w->frame_pk = p;
     else if (n == "frame_lnp") w->frame_lnp = p;
+    else if (n == "frame_y") w->frame_y = p;
   }
   return 0;
 }

@@ -34,7 +34,7 @@ inline int64_t cl_floats(int id, int64_t F) { return cl_plane(id, F) * 3 / 2 + 1
 
 // small-batch frame kernels (gfx950_frame.h; asserted equal there): floats of the packed weight copies, channel slots of
 // the per-frame LayerNorm sums, largest batch they are reserved for
-constexpr int64_t FRAME_PK_FLOATS = 959552 + 15392, FRAME_LNP_C = 552, FRAME_LNP_CAP = 1024;
+constexpr int64_t FRAME_PK_FLOATS = 959552 + 15392 + 1539 * 128, FRAME_Y_FLOATS = 12000, FRAME_LNP_C = 552, FRAME_LNP_CAP = 1024;
 
 }  // namespace tuned
 }  // namespace vaenpvc

@@ -112,9 +112,9 @@ constexpr int imin_(int a, int b) { return a < b ? a : b; }
 constexpr int BUF = 4864;             // one activation buffer (largest: 8 x 513 outputs; inputs with halos: see *_HP below)
 constexpr int PART = 24576;           // partial sums of the K-split products / staged Toeplitz taps
 constexpr int L_BUFX = 0, L_BUFY = BUF, L_PART = 2 * BUF, L_RED = L_PART + PART, L_VEC = L_RED + 128, L_ARGS = L_VEC + 1024;
-constexpr int ARGS_FLOATS = 160;                      // the pass's argument block, copied once from the kernel arguments
+constexpr int ARGS_FLOATS = 176;                      // the pass's argument block, copied once from the kernel arguments
 constexpr int L_CH = L_ARGS + ARGS_FLOATS;            // per-channel vectors of the 8 normalised layers: [3][LNP_C] = bias | scale | offset
-constexpr int L_TOTAL = L_CH + 3 * 552;               // 37 400 floats = 149 600 bytes: one workgroup per CU
+constexpr int L_TOTAL = L_CH + 3 * 552;               // 37 416 floats = 149 664 bytes: one workgroup per CU
 // reduction scratch: per-wave sums of the wave-reduction phases (16 waves), two pairs of slots, and {mean, rstd}
 constexpr int NW = NT / 64;
 constexpr int R_S1 = 0, R_S2 = 16, R_S3 = 32, R_S4 = 48, R_ST = 64;
@@ -528,11 +528,12 @@ struct Pk {
   static constexpr int e1g = e2g + 7 * 64 * 32;
   static constexpr int w3t = e1g + 7 * 32 * 16;                    // [8][1028]    taps of the last layer per channel
   static constexpr int mtab = w3t + TP_C * TP_W;                   // [10][1539]   T = E Wy + (bz + by + b) (+ 2 floats of padding)
-  static constexpr int total = mtab + MERGE_NY * MERGE_N + 2;
+  static constexpr int wyT = mtab + MERGE_NY * MERGE_N + 2;        // [1539][128]  Wy transposed (speaker-embedding gradient)
+  static constexpr int total = wyT + MERGE_N * MERGE_K;
 };
 static_assert(Pk::heads % 4 == 0 && Pk::headsT % 4 == 0 && Pk::wzT % 4 == 0 && Pk::d0f % 4 == 0 && Pk::d1f % 4 == 0 &&
                   Pk::d2f % 4 == 0 && Pk::d0g % 4 == 0 && Pk::d1g % 4 == 0 && Pk::d2g % 4 == 0 && Pk::e4g % 4 == 0 &&
-                  Pk::e3g % 4 == 0 && Pk::e2g % 4 == 0 && Pk::e1g % 4 == 0 && Pk::w3t % 4 == 0 && Pk::mtab % 4 == 0,
+                  Pk::e3g % 4 == 0 && Pk::e2g % 4 == 0 && Pk::e1g % 4 == 0 && Pk::w3t % 4 == 0 && Pk::mtab % 4 == 0 && Pk::wyT % 4 == 0,
               "packed blocks must be 16-byte aligned");
 
 // parameter offsets of the 44 tensors (flat buffer, TF creation order; model.cpp fills it for the VCC2016 geometry)
@@ -586,6 +587,10 @@ FR_DEV float pack_src(const float* FR_RESTRICT P, const POff& o, int i) {
   if (i < Pk::mtab) {                         // w3t [c][1028]: tap t of channel c (TF [t][1][1][8]); padding zero
     const int j = i - Pk::w3t, c = j / TP_W, t = j % TP_W;
     return t < TP_K ? P[o.dw[3] + t * TP_C + c] : 0.f;
+  }
+  if (i >= Pk::wyT) {                         // wyT [n][k] = Wy[k][n]
+    const int j = i - Pk::wyT, n = j / MERGE_K, k = j % MERGE_K;
+    return P[o.wy + (size_t)k * MERGE_N + n];
   }
   {                                           // merge table: T[k][n] = sum_i E[k][i] Wy[i][n] + bz[n] + by[n] + b[n]
     const int j = i - Pk::mtab;
@@ -679,7 +684,7 @@ FR_DEV float lnact(float v, float mean, float rstd, float g, float b) {
 // elsewhere (the SAME-padding halo); HP == H and HL == 0 gives the plain [C][H] tensor.  Also stores {mean, rstd}.
 template <int C, int H, int HP, int HL>
 FR_DEV void ln_apply(int tid, const float* FR_RESTRICT a, const float* FR_RESTRICT red, const float* FR_RESTRICT gamma,
-                     const float* FR_RESTRICT beta, float* FR_RESTRICT out, FR_G(float) st_g) {
+                     const float* FR_RESTRICT beta, float* FR_RESTRICT out, FR_G(float) st_g, FR_G(float) y_g) {
   float mean, rstd;
   ln_consts<C * H>(red, mean, rstd);
   if (tid == 0 && st_g) {
@@ -688,7 +693,10 @@ FR_DEV void ln_apply(int tid, const float* FR_RESTRICT a, const float* FR_RESTRI
   }
   for (int i = tid; i < C * HP; i += NT) {
     const int c = i / HP, h = i % HP - HL;
-    out[i] = (h >= 0 && h < H) ? lnact(a[c * H + h], mean, rstd, gamma[c], beta[c]) : 0.f;
+    const bool ok = h >= 0 && h < H;
+    const float v = ok ? lnact(a[c * H + h], mean, rstd, gamma[c], beta[c]) : 0.f;
+    out[i] = v;
+    if (ok && y_g) y_g[c * H + h] = v;      // the activated tensor, plain layout: operand of the weight-gradient launch
   }
 }
 // plain tensor -> halo layout (no LayerNorm: the merge output, gradients)
@@ -721,16 +729,23 @@ struct FwdArgs {
   float* dec_a[3];
   float* dec_st[3];
   float *xh, *kl_f, *nll_f, *d_xh;
-  float* dec_y;           // optional: activated output of decoder layer 2 [F][8][513] (operand of the layered weight gradient)
+  float* dec_y;           // optional: activated output of decoder layer 2 [F][8][513] (operand of the last layer's weight gradient)
+  float* y_enc[5];        // optional: activated outputs of the encoder layers / of decoder layers 0-1 (plain [F][C][H]):
+  float* y_dec[2];        //           operands of the weight-gradient launch
 };
 static_assert(sizeof(FwdArgs) <= ARGS_FLOATS * 4, "argument block larger than its LDS slot");
 constexpr int FM_ENC = 1, FM_SAMPLE = 2, FM_DEC = 4, FM_LOSS = 8, FM_GRAD = 16;
 
+// optional global output pointer + offset (null stays null)
+template <class T>
+FR_DEV FR_G(T) ygp(T* p, size_t off) {
+  return p ? fr_g(p) + off : (FR_G(T))nullptr;
+}
 // one conv + LayerNorm + lrelu layer after its `part` phase: outputs + statistics + activated input of the next layer
-#define FR_LN_TAIL(CFG, NOUT_H, LOFF, C_, H_, NEXT_HP, NEXT_HL, a_g_, st_)                                                     \
+#define FR_LN_TAIL(CFG, NOUT_H, LOFF, C_, H_, NEXT_HP, NEXT_HL, a_g_, st_, y_)                                                 \
   reduce_sum<R, CFG::KS, CFG::NOUT, NOUT_H>(run, part, ch + LOFF, by, red);                                                   \
   var_sum<R, CFG::NOUT>(run, by, red, a_g_);                                                                                  \
-  run.phase([&](int tid) { ln_apply<C_, H_, NEXT_HP, NEXT_HL>(tid, by, red, ch + LNP_C + LOFF, ch + 2 * LNP_C + LOFF, bx, st_); });
+  run.phase([&](int tid) { ln_apply<C_, H_, NEXT_HP, NEXT_HL>(tid, by, red, ch + LNP_C + LOFF, ch + 2 * LNP_C + LOFF, bx, st_, y_); });
 
 template <class R>
 FR_STAGE void frame_fwd_enc(R& run, float* lds_, const FwdArgs& a_, int f_) {
@@ -751,16 +766,16 @@ FR_STAGE void frame_fwd_enc(R& run, float* lds_, const FwdArgs& a_, int f_) {
   run.phase([&](int tid) { halo_copy<1, 513, E0F::HP, E0F::PAD>(tid, xf, bx); });
   // ---- e0 .. e4: conv + bias -> pre-LN output (kept for the backward pass), statistics, LN + lrelu into the next input
   run.phase([&](int tid) { sconv_part<E0F>(tid, bx, P + FR_UNIFORM(o.ew[0]), part); });
-  FR_LN_TAIL(E0F, E0F::HO, LNP_ENC0, 16, 171, E1F::HP, E1F::PAD, fr_g(a.enc_a[0]) + (size_t)f * E0F::NOUT, fr_g(a.enc_st[0]) + 2 * (size_t)f)
+  FR_LN_TAIL(E0F, E0F::HO, LNP_ENC0, 16, 171, E1F::HP, E1F::PAD, fr_g(a.enc_a[0]) + (size_t)f * E0F::NOUT, fr_g(a.enc_st[0]) + 2 * (size_t)f, ygp(a.y_enc[0], (size_t)f * E0F::NOUT))
   run.phase([&](int tid) { sconv_part<E1F>(tid, bx, P + FR_UNIFORM(o.ew[1]), part); });
-  FR_LN_TAIL(E1F, E1F::HO, LNP_ENC1, 32, 57, E2F::HP, E2F::PAD, fr_g(a.enc_a[1]) + (size_t)f * E1F::NOUT, fr_g(a.enc_st[1]) + 2 * (size_t)f)
+  FR_LN_TAIL(E1F, E1F::HO, LNP_ENC1, 32, 57, E2F::HP, E2F::PAD, fr_g(a.enc_a[1]) + (size_t)f * E1F::NOUT, fr_g(a.enc_st[1]) + 2 * (size_t)f, ygp(a.y_enc[1], (size_t)f * E1F::NOUT))
   run.phase([&](int tid) { sconv_part<E2F>(tid, bx, P + FR_UNIFORM(o.ew[2]), part); });
-  FR_LN_TAIL(E2F, E2F::HO, LNP_ENC2, 64, 19, E3F::HP, E3F::PAD, fr_g(a.enc_a[2]) + (size_t)f * E2F::NOUT, fr_g(a.enc_st[2]) + 2 * (size_t)f)
+  FR_LN_TAIL(E2F, E2F::HO, LNP_ENC2, 64, 19, E3F::HP, E3F::PAD, fr_g(a.enc_a[2]) + (size_t)f * E2F::NOUT, fr_g(a.enc_st[2]) + 2 * (size_t)f, ygp(a.y_enc[2], (size_t)f * E2F::NOUT))
   run.phase([&](int tid) { sconv_part<E3F>(tid, bx, P + FR_UNIFORM(o.ew[3]), part); });
-  FR_LN_TAIL(E3F, E3F::HO, LNP_ENC3, 128, 7, E4F::HP, E4F::PAD, fr_g(a.enc_a[3]) + (size_t)f * E3F::NOUT, fr_g(a.enc_st[3]) + 2 * (size_t)f)
+  FR_LN_TAIL(E3F, E3F::HO, LNP_ENC3, 128, 7, E4F::HP, E4F::PAD, fr_g(a.enc_a[3]) + (size_t)f * E3F::NOUT, fr_g(a.enc_st[3]) + 2 * (size_t)f, ygp(a.y_enc[3], (size_t)f * E3F::NOUT))
   run.phase([&](int tid) { sconv_part<E4F>(tid, bx, P + FR_UNIFORM(o.ew[4]), part); });
   // C-major flatten (slim.flatten of the NCHW tensor, model/vae.py:79): index c*3 + h = the plain layout
-  FR_LN_TAIL(E4F, E4F::HO, LNP_ENC4, 256, 3, 3, 0, fr_g(a.enc_a[4]) + (size_t)f * E4F::NOUT, fr_g(a.enc_st[4]) + 2 * (size_t)f)
+  FR_LN_TAIL(E4F, E4F::HO, LNP_ENC4, 256, 3, 3, 0, fr_g(a.enc_a[4]) + (size_t)f * E4F::NOUT, fr_g(a.enc_st[4]) + 2 * (size_t)f, ygp(a.y_enc[4], (size_t)f * E4F::NOUT))
   // ---- heads (model/vae.py:80-81)
   run.phase([&](int tid) { dense4_part<HeadsF>(tid, bx, pk + Pk::heads, part); });
   run.phase([&](int tid) {
@@ -850,16 +865,16 @@ FR_STAGE void frame_fwd_dec(R& run, float* lds_, const FwdArgs& a_, int f_) {
   const POff& o = a.off;
   // ---- d0 .. d2: conv_transpose + bias, LayerNorm, lrelu (model/vae.py:96-102)
   run.phase([&](int tid) { tconv_part<D0F>(tid, bx, pk + Pk::d0f, part); });
-  FR_LN_TAIL(D0F, D0F::HOUT, LNP_DEC0, 32, 57, D1F::HP, D1F::HL, fr_g(a.dec_a[0]) + (size_t)f * D0F::NOUT, fr_g(a.dec_st[0]) + 2 * (size_t)f)
+  FR_LN_TAIL(D0F, D0F::HOUT, LNP_DEC0, 32, 57, D1F::HP, D1F::HL, fr_g(a.dec_a[0]) + (size_t)f * D0F::NOUT, fr_g(a.dec_st[0]) + 2 * (size_t)f, ygp(a.y_dec[0], (size_t)f * D0F::NOUT))
   run.phase([&](int tid) { tconv_part<D1F>(tid, bx, pk + Pk::d1f, part); });
-  FR_LN_TAIL(D1F, D1F::HOUT, LNP_DEC1, 16, 171, D2F::HP, D2F::HL, fr_g(a.dec_a[1]) + (size_t)f * D1F::NOUT, fr_g(a.dec_st[1]) + 2 * (size_t)f)
+  FR_LN_TAIL(D1F, D1F::HOUT, LNP_DEC1, 16, 171, D2F::HP, D2F::HL, fr_g(a.dec_a[1]) + (size_t)f * D1F::NOUT, fr_g(a.dec_st[1]) + 2 * (size_t)f, ygp(a.y_dec[1], (size_t)f * D1F::NOUT))
   run.phase([&](int tid) { tconv_part<D2F>(tid, bx, pk + Pk::d2f, part); });
   reduce_sum<R, D2F::KS, D2F::NOUT, D2F::HOUT>(run, part, ch + LNP_DEC2, by, red);
   var_sum<R, D2F::NOUT>(run, by, red, fr_g(a.dec_a[2]) + (size_t)f * D2F::NOUT);
   run.phase([&](int tid) {
     // taps of the last layer, one contiguous row per channel (loads first: they must not queue behind the stores below)
     for (int i = tid; i < TP_C * TP_W; i += NT) part[i] = pk[Pk::w3t + i];
-    ln_apply<8, 513, 513, 0>(tid, by, red, ch + LNP_C + LNP_DEC2, ch + 2 * LNP_C + LNP_DEC2, bx, fr_g(a.dec_st[2]) + 2 * (size_t)f);
+    ln_apply<8, 513, 513, 0>(tid, by, red, ch + LNP_C + LNP_DEC2, ch + 2 * LNP_C + LNP_DEC2, bx, fr_g(a.dec_st[2]) + 2 * (size_t)f, ygp(a.dec_y, (size_t)f * 4104));
     if (fr_g(a.dec_y))      // (same thread, same elements as ln_apply wrote)
       for (int i = tid; i < 4104; i += NT) a.dec_y[(size_t)f * 4104 + i] = bx[i];
   });

@@ -5,6 +5,7 @@
 //   frame_lnp    per-frame channel sums -> gradients of the LayerNorm parameters and conv biases
 // Reference: model/vae.py:72-137 (forward), trainer/vae.py:24 (autodiff).
 #include "gfx950_frame.h"
+#include "gfx950_frame_wgrad.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -138,6 +139,36 @@ __global__ void __launch_bounds__(NT) k_frame_bwd(BwdArgs a, long long* prof) {
   const BwdArgs& la = args_to_lds<BwdArgs>(frame_lds);
   frame_prologue(run, frame_lds, la.P, la.off);
   for (int f = blockIdx.x; f < la.F; f += gridDim.x) frame_bwd(run, frame_lds, la, f);
+}
+
+// every parameter gradient of a small batch (gfx950_frame_wgrad.h): a block looks its job up by block index
+struct WRunner {
+  template <class F>
+  __device__ __forceinline__ void phase(F&& f) {
+    f((int)threadIdx.x);
+    __syncthreads();
+  }
+  // per-thread accumulators across a loop over trips of `fb` frames: stage (all threads) | barrier | accumulate | barrier;
+  // `spill` runs once per thread after the last trip, then a barrier
+  template <class St, class Z, class Ac, class Sp, class AccT>
+  __device__ __forceinline__ void frames(int f0, int f1, int fb, St&& st, Z&& z, Ac&& ac, Sp&& sp, AccT& acc) {
+    const int tid = (int)threadIdx.x;
+    z(tid, acc);
+    for (int f = f0; f < f1; f += fb) {
+      const int n = f1 - f < fb ? f1 - f : fb;
+      st(tid, f, n);
+      __syncthreads();
+      ac(tid, acc, n);
+      __syncthreads();
+    }
+    sp(tid, acc);
+    __syncthreads();
+  }
+};
+__global__ void __launch_bounds__(WT) k_frame_wgrad(WgArgs a, WgPlan pl) {
+  extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+  WRunner run;
+  frame_wgrad_block(run, wg_lds, a, pl, (int)blockIdx.x);
 }
 
 // batch means {G, D_KL, logP} (model/vae.py:112-128), one block, fixed summation order
@@ -278,7 +309,19 @@ void frame_forward(const Model& m, const float* P, const float* x, const float* 
   a.kl_f = w.kl_f;
   a.nll_f = w.nll_f;
   a.d_xh = w.d_xh;
-  a.dec_y = (mode & FM_GRAD) ? w.dec_y : nullptr;      // (train step: the layered weight gradient of the last layer reads it)
+  a.dec_y = (mode & FM_GRAD) ? w.dec_y : nullptr;      // (train step: operand of the last layer's weight gradient)
+  if ((mode & FM_GRAD) && w.frame_y) {                 // activated layer outputs for the weight-gradient launch
+    float* yb = w.frame_y;
+    const int64_t ne[5] = {2736, 1824, 1216, 896, 768}, nd[2] = {1824, 2736};
+    for (int i = 0; i < 5; ++i) {
+      a.y_enc[i] = yb;
+      yb += F * ne[i];
+    }
+    for (int i = 0; i < 2; ++i) {
+      a.y_dec[i] = yb;
+      yb += F * nd[i];
+    }
+  }
   if (!a.d_xh) a.mode &= ~FM_GRAD;
   PhiloxKey k = key ? *key : PhiloxKey{0, 0, 0, 0, nullptr};
   if (long long* pb = prof_buf()) {
@@ -293,7 +336,7 @@ void frame_forward(const Model& m, const float* P, const float* x, const float* 
 }
 
 void frame_backward(const Model& m, const float* P, const float* target, const float* eps, int64_t F, const Ws& w, float* G,
-                    hipStream_t s) {
+                    hipStream_t s, bool lnp_sums) {
   BwdArgs a;
   memset(&a, 0, sizeof a);
   a.P = P;
@@ -329,6 +372,7 @@ void frame_backward(const Model& m, const float* P, const float* target, const f
     rt().ensure_lds(reinterpret_cast<const void*>(&k_frame_bwd<false>), L_TOTAL * 4);
     VAENPVC_TIMED("frame_bwd", s, hipLaunchKernelGGL(k_frame_bwd<false>, dim3((unsigned)frame_grid((int)F)), dim3(NT), L_TOTAL * 4, s, a, (long long*)nullptr));
   }
+  if (!lnp_sums) return;     // (the one-launch weight gradient reduces them itself)
   // gradients of the LayerNorm parameters and conv biases of the eight normalised layers
   LnpDst d;
   const ConvL* L[8] = {&m.dec[2], &m.dec[1], &m.dec[0], &m.enc[4], &m.enc[3], &m.enc[2], &m.enc[1], &m.enc[0]};
@@ -338,6 +382,63 @@ void frame_backward(const Model& m, const float* P, const float* target, const f
     d.bias[i] = (int)L[i]->b_off;
   }
   hipLaunchKernelGGL(k_frame_lnp, dim3((unsigned)(3 * ((LNP_C + 63) / 64))), dim3(256), 0, s, w.frame_lnp, (int)F, d, G);
+}
+
+// developer switch (scripts/wgrad_prof.py): bit s cleared = segment s of the job list is left out of the launch
+static unsigned g_wg_seg_mask = 0xffffffffu;
+extern "C" void vaenpvc_debug_wg_segments(unsigned mask) { g_wg_seg_mask = mask; }
+
+void frame_wgrad(const Model& m, const float* P, const float* x, const int64_t* y, int64_t F, const Ws& w, float* G, hipStream_t s) {
+  WgArgs a;
+  memset(&a, 0, sizeof a);
+  a.P = P;
+  a.off = poff_of(m);
+  a.x = x;
+  a.y = y;
+  a.ny = m.ny;
+  a.F = (int)F;
+  const float* yb = w.frame_y;
+  const int64_t ne[5] = {2736, 1824, 1216, 896, 768}, nd[2] = {1824, 2736};
+  for (int i = 0; i < 5; ++i) {
+    a.y_enc[i] = yb;
+    yb += F * ne[i];
+    a.d_enc_a[i] = w.d_enc_a[i];
+  }
+  for (int i = 0; i < 2; ++i) {
+    a.y_dec[i] = yb;
+    yb += F * nd[i];
+  }
+  a.z = w.z;
+  a.h = w.h;
+  a.dec_y = w.dec_y;
+  a.d_xh = w.d_xh;
+  for (int i = 0; i < 3; ++i) a.d_dec_a[i] = w.d_dec_a[i];
+  a.d_h = w.d_h;
+  a.d_z_mu = w.d_z_mu;
+  a.d_z_lv = w.d_z_lv;
+  a.lnp = w.frame_lnp;
+  a.pk = w.frame_pk;
+  a.G = G;
+  WgPlan pl = make_wgplan((int)F, m.ny);
+  if (g_wg_seg_mask != 0xffffffffu) {      // developer: drop segments (blocks renumbered)
+    WgPlan q = pl;
+    int n = 0, blk = 0;
+    for (int i = 0; i < pl.nseg; ++i)
+      if ((g_wg_seg_mask >> i) & 1u) {
+        q.start[n] = blk;
+        q.kind[n] = pl.kind[i];
+        q.layer[n] = pl.layer[i];
+        q.tiles[n] = pl.tiles[i];
+        q.fc[n] = pl.fc[i];
+        blk += pl.start[i + 1] - pl.start[i];
+        ++n;
+      }
+    q.nseg = n;
+    q.start[n] = blk;
+    pl = q;
+    if (n == 0) return;
+  }
+  VAENPVC_TIMED("frame_wgrad", s, hipLaunchKernelGGL(k_frame_wgrad, dim3((unsigned)pl.start[pl.nseg]), dim3(WT), WG_LDS * 4, s, a, pl));
 }
 
 }  // namespace tuned

@@ -1200,7 +1200,19 @@ void backward_frame(const Model& m, const float* P, const float* x, const float*
     (void)hipMemsetAsync(G, 0, (size_t)m.n_params * 4, s);
     (void)hipMemsetAsync(w.scratch + Pk::merge_s, 0, (size_t)MERGE_NY * 1539 * 4, s);
   }
-  frame_backward(m, P, target ? target : x, eps, F, w, G, s);
+  // bit 20 of the backward mask (default set): every parameter gradient in ONE launch (gfx950_frame_wgrad.h); cleared = the
+  // layered weight-gradient kernels below on two streams (A/B, parity tests)
+  const bool one_launch = bwd_on(20) && w.frame_y != nullptr;
+  frame_backward(m, P, target ? target : x, eps, F, w, G, s, !one_launch);
+  if (one_launch) {
+    frame_wgrad(m, P, x, y, F, w, G, s);
+    Runtime& r0 = rt();
+    if (r0.bucket_cb) {
+      const int64_t cut[5] = {m.n_params, m.dec[0].w_off, m.wz_off, m.wmu_off, 0};
+      for (int b = 0; b < 4; ++b) r0.bucket_cb(r0.bucket_user, r0.bucket_next++, cut[b + 1], cut[b] - cut[b + 1], (void*)s);
+    }
+    return;
+  }
   hipStream_t side = bwd_on(30) ? rt().side_stream() : nullptr;
   const bool fork = side != nullptr;
   hipStream_t s2 = fork ? side : s;

@@ -32,6 +32,7 @@ struct Ws {  // resolved workspace pointers (see workspace_layout)
   int64_t scratch_floats;
   float* frame_pk;   // packed weight copies of the small-batch frame kernels (gfx950_frame.h: Pk)
   float* frame_lnp;  // per-frame channel sums of their LayerNorm backward
+  float* frame_y;    // activated layer outputs [F][12000] for their weight-gradient launch (train mode)
 };
 
 // sets the thread-local message vaenpvc_last_error() returns; returns `code` (abi.hip)
@@ -119,8 +120,11 @@ void frame_forward(const Model& m, const float* P, const float* x, const float* 
                    const PhiloxKey* key, const float* z_in, int64_t F, const Ws& w, float* xh_out, int mode, float* loss3,
                    hipStream_t s);
 // input-gradient chain + LayerNorm parameter / conv-bias gradients (the weight gradients are the caller's)
+// (lnp_sums: also launch the reduction of the LayerNorm parameter / conv-bias sums; false when frame_wgrad follows)
 void frame_backward(const Model& m, const float* P, const float* target, const float* eps, int64_t F, const Ws& w, float* G,
-                    hipStream_t s);
+                    hipStream_t s, bool lnp_sums);
+// every parameter gradient in one launch (gfx950_frame_wgrad.h); G must have been zero-filled
+void frame_wgrad(const Model& m, const float* P, const float* x, const int64_t* y, int64_t F, const Ws& w, float* G, hipStream_t s);
 // the whole backward pass of a small batch: frame_backward + every weight gradient (gfx950_layers.hip)
 // (g_zeroed: the gradient buffer and frame_zero_region were zero-filled by this step's frame_pack)
 void backward_frame(const Model& m, const float* P, const float* x, const float* target, const int64_t* y, const float* eps,

@@ -164,6 +164,8 @@ std::vector<Region> workspace_layout(const Model& m, int64_t F, int mode, int64_
   if (m.is_vcc2016) {  // small-batch frame kernels (gfx950_frame.h): packed weight copies, per-frame LayerNorm channel sums
     add("frame_pk", tuned::FRAME_PK_FLOATS);
     add("frame_lnp", std::min<int64_t>(F, tuned::FRAME_LNP_CAP) * 3 * tuned::FRAME_LNP_C);
+    // activated layer outputs the forward pass leaves for the weight-gradient launch (train mode only)
+    if (mode == VAENPVC_MODE_TRAIN) add("frame_y", std::min<int64_t>(F, tuned::FRAME_LNP_CAP) * tuned::FRAME_Y_FLOATS);
   }
   if (mode == VAENPVC_MODE_TRAIN) {
     add("d_xh", F * m.H);
