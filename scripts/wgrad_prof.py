@@ -43,3 +43,13 @@ for i, nm in enumerate(NAMES):
     print('  %-14s %8.1f us' % (nm, timed(1 << i)))
 for tag in ('frame_fwd', 'frame_bwd'):
     print('  %-14s %8.1f us' % (tag, timed(0xffffffff, tag)))
+
+# chunk caps (order: toeplitz, enc4, dec0, enc3, enc2, enc1, dec1, dec2, enc0): whole launch under a few settings
+lib.vaenpvc_debug_wg_caps.argtypes = [C.POINTER(C.c_int)]
+for caps in ([32, 16, 16, 16, 16, 32, 32, 32, 32], [64, 16, 64, 16, 16, 32, 32, 32, 32], [128, 16, 64, 16, 16, 32, 32, 32, 32],
+             [64, 32, 64, 32, 32, 32, 32, 32, 32], [64, 32, 64, 32, 32, 64, 64, 64, 64], [128, 32, 128, 32, 32, 64, 64, 64, 64],
+             [64, 8, 32, 8, 8, 16, 16, 16, 16]):
+    arr = (C.c_int * 9)(*caps)
+    lib.vaenpvc_debug_wg_caps(arr)
+    print('  caps %-44s ALL %8.1f us   toeplitz %8.1f us' % (caps, timed(0xffffffff), timed(1)))
+lib.vaenpvc_debug_wg_caps(None)

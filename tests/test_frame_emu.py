@@ -195,10 +195,10 @@ def test_backward_pass_matches_autograd(emu, arch):
     assert not bad, bad
 
 
-@pytest.mark.parametrize('F,seed', [(3, 12), (37, 13)])
+@pytest.mark.parametrize('F,seed', [(3, 12), (37, 13), (66, 14)])
 def test_one_launch_weight_gradient_matches_autograd(emu, arch, F, seed):
     """the job list of the weight-gradient launch, block by block, after the emulated passes: all 44 gradients
-    (F = 37: more frames than the smaller jobs have frame chunks, ragged chunks)"""
+    (F = 37: more frames than the smaller jobs have frame chunks, ragged chunks; F = 66: the two-slice form of the 1025-tap job)"""
     P = O.init_params(arch, seed)
     x, y, eps = O.make_inputs(arch, F, seed)
     t, ws, toff = run_emu(emu, arch, P, x, y, eps, wgrad=True)

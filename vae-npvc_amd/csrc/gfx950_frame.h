@@ -597,7 +597,16 @@ FR_DEV float pack_src(const float* FR_RESTRICT P, const POff& o, int i) {
     if (j >= MERGE_NY * MERGE_N) return 0.f;
     const int k = j / MERGE_N, n = j % MERGE_N;
     float s = P[o.bz + n] + P[o.by + n] + P[o.bm + n];
-    for (int e = 0; e < MERGE_K; ++e) s += P[o.emb + k * MERGE_K + e] * P[o.wy + (size_t)e * MERGE_N + n];
+    for (int e0 = 0; e0 < MERGE_K; e0 += 16) {      // 16 + 16 loads in flight, then the sum in the fixed order e = 0, 1, ...
+      float ev[16], wv[16];
+      FR_UNROLL
+      for (int u = 0; u < 16; ++u) {
+        ev[u] = P[o.emb + k * MERGE_K + e0 + u];
+        wv[u] = P[o.wy + (size_t)(e0 + u) * MERGE_N + n];
+      }
+      FR_UNROLL
+      for (int u = 0; u < 16; ++u) s += ev[u] * wv[u];
+    }
     return s;
   }
 }

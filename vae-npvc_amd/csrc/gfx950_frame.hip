@@ -271,7 +271,8 @@ bool frame_bwd_on(int64_t F) {
 }
 
 void frame_pack(const Model& m, const float* P, const Ws& w, float* G, float* zero2, int nzero2, hipStream_t s) {
-  hipLaunchKernelGGL(k_frame_pack, dim3(512), dim3(256), 0, s, P, poff_of(m), w.frame_pk, G, G ? (int)m.n_params : 0, zero2, nzero2);
+  // one packed element per thread: a thread that walks several elements pays an L2 round trip for each
+  hipLaunchKernelGGL(k_frame_pack, dim3((Pk::total + 255) / 256), dim3(256), 0, s, P, poff_of(m), w.frame_pk, G, G ? (int)m.n_params : 0, zero2, nzero2);
 }
 
 // mode: FM_* bits.  x may be null for decode-only, z_in null unless decode-only.
@@ -387,6 +388,13 @@ void frame_backward(const Model& m, const float* P, const float* target, const f
 // developer switch (scripts/wgrad_prof.py): bit s cleared = segment s of the job list is left out of the launch
 static unsigned g_wg_seg_mask = 0xffffffffu;
 extern "C" void vaenpvc_debug_wg_segments(unsigned mask) { g_wg_seg_mask = mask; }
+// developer switch: most frame chunks of the nine chunked jobs (null = defaults)
+static int g_wg_caps[9];
+static bool g_wg_caps_set = false;
+extern "C" void vaenpvc_debug_wg_caps(const int* caps) {
+  g_wg_caps_set = caps != nullptr;
+  if (caps) memcpy(g_wg_caps, caps, sizeof g_wg_caps);
+}
 
 void frame_wgrad(const Model& m, const float* P, const float* x, const int64_t* y, int64_t F, const Ws& w, float* G, hipStream_t s) {
   WgArgs a;
@@ -419,7 +427,7 @@ void frame_wgrad(const Model& m, const float* P, const float* x, const int64_t* 
   a.lnp = w.frame_lnp;
   a.pk = w.frame_pk;
   a.G = G;
-  WgPlan pl = make_wgplan((int)F, m.ny);
+  WgPlan pl = g_wg_caps_set ? make_wgplan((int)F, m.ny, g_wg_caps) : make_wgplan((int)F, m.ny);
   if (g_wg_seg_mask != 0xffffffffu) {      // developer: drop segments (blocks renumbered)
     WgPlan q = pl;
     int n = 0, blk = 0;

@@ -20,7 +20,7 @@ namespace vaenpvc {
 namespace frame {
 
 constexpr int WT = 256;           // threads per block of the weight-gradient launch
-constexpr int WG_LDS = 8192;      // floats of dynamic LDS (32 KB: several blocks per CU)
+constexpr int WG_LDS = 9216;      // floats of dynamic LDS (36 KB: several blocks per CU)
 
 struct WgArgs {
   const float* P;
@@ -70,6 +70,25 @@ FR_DEV void fr_atomic_add(float* p, float v) { atomicAdd(p, v); }
 //   transposed conv (TF kernel [t][o][c]):       a = output channel o, U = d(pre-LN output),             V = the layer's input
 // A thread owns all K taps x one a x four b x one slice of the positions j; a block stages, frame by frame, the U rows of
 // its AT channels (with the SAME-padding halo as zeros) and the whole V tensor in LDS.
+// Staging copy with UB loads in flight per thread (the plain strided loop compiles to load / wait / LDS store per element pair:
+// one L2 round trip each, which was most of every job's time)
+template <int UB, class L>
+FR_DEV void wg_stage(int tid, int n, float* dst, L&& ld) {
+  for (int b = 0; b < n; b += UB * WT) {
+    float v[UB];
+    FR_UNROLL
+    for (int u = 0; u < UB; ++u) {
+      const int i = b + u * WT + tid;
+      v[u] = i < n ? ld(i) : 0.f;
+    }
+    FR_UNROLL
+    for (int u = 0; u < UB; ++u) {
+      const int i = b + u * WT + tid;
+      if (i < n) dst[i] = v[u];
+    }
+  }
+}
+
 // FB frames are staged per trip (a trip costs a global round trip and two barriers whatever it carries); the JS position
 // slices of a tile are summed through LDS before the atomics (same-address atomics serialise at ~100 ns each: the first
 // version spent 109 us in the 112-element gradient of encoder layer 0).
@@ -80,7 +99,8 @@ struct ConvW {
   static constexpr int HUP = S * (HV - 1) + K;       // staged row: index 0 = position -PAD
   static constexpr int JL = cdiv_(HV, JS);
   static constexpr int FRAME = AT * HUP + CB * HV;   // staged floats per frame
-  static_assert(NTH <= WT && HUP >= PAD + HU && FB * FRAME <= WG_LDS && (JS == 1 || NTH * K * 4 <= WG_LDS), "ConvW tiling");
+  static constexpr bool VIA_LDS = NTH * K * 4 <= WG_LDS;      // the tile leaves through LDS (coalesced atomics)
+  static_assert(NTH <= WT && HUP >= PAD + HU && FB * FRAME <= WG_LDS && (JS == 1 || VIA_LDS), "ConvW tiling");
 };
 template <class T, class R>
 FR_DEV void convw_job(R& run, float* lds, const float* U, const float* V, float* dW, int F, int ablk, int fchunk, int nfc) {
@@ -90,15 +110,13 @@ FR_DEV void convw_job(R& run, float* lds, const float* U, const float* V, float*
   run.frames(f0, f1, T::FB,
              // ---- stage: per frame of the trip, the U rows of this block's channels (zero halo) and V
              [&](int tid, int f, int nfb) {
-               for (int i = tid; i < nfb * T::AT * T::HUP; i += WT) {
-                 const int fb = i / (T::AT * T::HUP), r = i % (T::AT * T::HUP);
+               constexpr int UB = cdiv_(cdiv_(T::FB * T::FRAME, WT), cdiv_(cdiv_(T::FB * T::FRAME, WT), 14));   // <= 14 in flight
+               wg_stage<UB>(tid, nfb * T::FRAME, lds, [&](int i) {
+                 const int fb = i / T::FRAME, r = i % T::FRAME;
+                 if (r >= T::AT * T::HUP) return V[(size_t)(f + fb) * T::CB * T::HV + (r - T::AT * T::HUP)];
                  const int al = r / T::HUP, p = r % T::HUP - T::PAD, a = a0 + al;
-                 lds[fb * T::FRAME + r] = (a < T::CA && p >= 0 && p < T::HU) ? U[((size_t)(f + fb) * T::CA + a) * T::HU + p] : 0.f;
-               }
-               for (int i = tid; i < nfb * T::CB * T::HV; i += WT) {
-                 const int fb = i / (T::CB * T::HV), r = i % (T::CB * T::HV);
-                 lds[fb * T::FRAME + T::AT * T::HUP + r] = V[(size_t)(f + fb) * T::CB * T::HV + r];
-               }
+                 return (a < T::CA && p >= 0 && p < T::HU) ? U[((size_t)(f + fb) * T::CA + a) * T::HU + p] : 0.f;
+               });
              },
              // ---- zero the accumulators
              [&](int tid, float (&ac)[T::K][4]) {
@@ -128,10 +146,10 @@ FR_DEV void convw_job(R& run, float* lds, const float* U, const float* V, float*
                  }
                }
              },
-             // ---- after the last trip: position slices meet in LDS (JS > 1), or the tile goes out directly
+             // ---- after the last trip: the tile (all position slices) goes to LDS, or straight out where LDS is too small
              [&](int tid, float (&ac)[T::K][4]) {
                if (tid >= T::NTH) return;
-               if constexpr (T::JS > 1) {
+               if constexpr (T::VIA_LDS) {
                  FR_UNROLL
                  for (int t = 0; t < T::K; ++t)
                    FR_UNROLL
@@ -147,11 +165,12 @@ FR_DEV void convw_job(R& run, float* lds, const float* U, const float* V, float*
                }
              },
              acc);
-  if constexpr (T::JS > 1) {
+  if constexpr (T::VIA_LDS) {
     run.phase([&](int tid) {
       // (tile, tap, q) triples dealt to the threads: one atomic per element and block
+      // (consecutive lanes: q, then bq, then al = consecutive addresses of dW[t][a][b])
       for (int e = tid; e < T::NTILE * T::K * 4; e += WT) {
-        const int tile = e / (T::K * 4), r = e % (T::K * 4), t = r / 4, q = r % 4;
+        const int t = e / (T::NTILE * 4), tile = (e / 4) % T::NTILE, q = e % 4, r = t * 4 + q;
         const int bq = tile % T::BQ, al = tile / T::BQ, a = a0 + al;
         if (a >= T::CA || 4 * bq + q >= T::CB) continue;
         float sm = 0.f;
@@ -175,30 +194,37 @@ using WD2 = ConvW<8, 513, 16, 171, 7, 3, 2, 8, 8, 1>;
 // ------------------------------------------------------------------------------------------------ the 1025-tap layer
 // dW[t][c] += sum_f sum_j y[f][c][j] * g[f][j + t - 512]; a thread owns nine consecutive taps of one channel and one half
 // of j; the nine values of g it needs slide by one per step (rotating register window, as in the forward direction)
-constexpr int TWG_TG = 114, TWG_JS = 2, TWG_TILES = TWG_TG * TP_C * TWG_JS, TWG_BLOCKS = cdiv_(TWG_TILES, WT);
+// A workgroup owns 16 tap groups (144 taps) x 8 channels x 2 position slices; the slices meet in LDS and the tile leaves
+// as 1152 atomics on consecutive addresses (device-scope atomics are executed at the memory side, one transaction per
+// touched line: four position slices with per-lane strided atomics took 45 us at 16 frames, two took 31)
+constexpr int TWG_TG = 114, TWG_JS = 2, TWG_TGB = 16, TWG_BLOCKS = cdiv_(TWG_TG, TWG_TGB);
+static_assert(TWG_TGB * TP_C * TWG_JS == WT, "Toeplitz weight-gradient tile");
 constexpr int TWG_GP = 512 + 513 + 512 + 16;      // zero-padded g
 static_assert(TP_C * TP_H + TWG_GP <= WG_LDS, "Toeplitz weight-gradient staging");
 template <class R>
 FR_DEV void toepw_job(R& run, float* lds, const float* Y, const float* Gx, float* dW, int F, int tblk, int fchunk, int nfc) {
+  constexpr int SL = cdiv_(TP_H, TWG_JS), TB = TWG_TGB * TP_R;      // taps per workgroup
   float* ys = lds;                  // [8][513]
   float* gp = lds + TP_C * TP_H;    // gp[i] = g[i - 512]
   const int fper = (F + nfc - 1) / nfc, f0 = fchunk * fper, f1 = imin_(F, f0 + fper);
   float acc[TP_R][1];
   run.frames(f0, f1, 1,
              [&](int tid, int f, int) {
-               for (int i = tid; i < TP_C * TP_H; i += WT) ys[i] = Y[(size_t)f * TP_C * TP_H + i];
-               for (int i = tid; i < TWG_GP; i += WT) gp[i] = (i >= 512 && i < 512 + TP_H) ? Gx[(size_t)f * TP_H + i - 512] : 0.f;
+               wg_stage<12>(tid, TP_C * TP_H + TWG_GP, lds, [&](int i) {
+                 if (i < TP_C * TP_H) return Y[(size_t)f * TP_C * TP_H + i];
+                 const int g = i - TP_C * TP_H - 512;
+                 return (g >= 0 && g < TP_H) ? Gx[(size_t)f * TP_H + g] : 0.f;
+               });
              },
              [&](int tid, float (&ac)[TP_R][1]) {
                FR_UNROLL
                for (int i = 0; i < TP_R; ++i) ac[i][0] = 0.f;
              },
              [&](int tid, float (&ac)[TP_R][1], int) {
-               const int til = tblk * WT + tid;
-               if (til >= TWG_TILES) return;
-               const int tg = til % TWG_TG, r = til / TWG_TG, c = r % TP_C, js = r / TP_C;
+               const int tg = tblk * TWG_TGB + tid % TWG_TGB, c = (tid / TWG_TGB) % TP_C, js = tid / (TWG_TGB * TP_C);
+               if (tg >= TWG_TG) return;
                const int t0 = tg * TP_R;
-               const int jb = js * TP_HALF, je = imin_(TP_H, jb + TP_HALF);
+               const int jb = js * SL, je = imin_(TP_H, jb + SL);
                const float* yc = ys + c * TP_H;
                const float* g0 = gp + t0;                 // value of tap i at step j: g0[j + i]
                float win[TP_R];
@@ -225,16 +251,21 @@ FR_DEV void toepw_job(R& run, float* lds, const float* Y, const float* Gx, float
                }
              },
              [&](int tid, float (&ac)[TP_R][1]) {
-               const int til = tblk * WT + tid;
-               if (til >= TWG_TILES) return;
-               const int tg = til % TWG_TG, c = (til / TWG_TG) % TP_C;
+               const int tgl = tid % TWG_TGB, r = tid / TWG_TGB;      // r = js * 8 + c
                FR_UNROLL
-               for (int i = 0; i < TP_R; ++i) {
-                 const int t = tg * TP_R + i;
-                 if (t < TP_K) fr_atomic_add(dW + t * TP_C + c, ac[i][0]);
-               }
+               for (int i = 0; i < TP_R; ++i) lds[r * TB + tgl * TP_R + i] = ac[i][0];
              },
              acc);
+  run.phase([&](int tid) {
+    for (int e = tid; e < TB * TP_C; e += WT) {
+      const int tl = e / TP_C, c = e % TP_C, t = tblk * TB + tl;
+      if (t >= TP_K) continue;
+      float sm = 0.f;
+      FR_UNROLL
+      for (int js = 0; js < TWG_JS; ++js) sm += lds[(js * TP_C + c) * TB + tl];
+      fr_atomic_add(dW + t * TP_C + c, sm);
+    }
+  });
 }
 
 // ------------------------------------------------------------------------------------------------ outer products
@@ -423,7 +454,9 @@ FR_DEV void frame_wgrad_block(R& run, float* lds, const WgArgs& a, const WgPlan&
 // ------------------------------------------------------------------------------------------------ job list (host)
 // frame chunks per job: enough blocks to spread a small batch over the chip, few enough that the fp32 atomics of the
 // big tensors stay cheap (a chunk adds one atomic per element)
-inline WgPlan make_wgplan(int F, int ny) {
+// caps: most frame chunks of the nine chunked jobs, in the order they are added below
+constexpr int WG_CAPS_DEFAULT[9] = {64, 16, 64, 16, 16, 32, 32, 32, 32};
+inline WgPlan make_wgplan(int F, int ny, const int* caps = WG_CAPS_DEFAULT) {
   WgPlan p;
   int n = 0, blk = 0;
   auto add = [&](int kind, int layer, int tiles, int fc) {
@@ -443,15 +476,15 @@ inline WgPlan make_wgplan(int F, int ny) {
     return (F + fpb - 1) / fpb;
   };
   // the long jobs first (they decide when the launch ends)
-  add(WJ_TOEP, 0, TWG_BLOCKS, fcs(1, 32));
-  add(WJ_CONV, 4, WE4::AB, fcs(WE4::FB, 16));
-  add(WJ_CONV, 5, WD0::AB, fcs(WD0::FB, 16));
-  add(WJ_CONV, 3, WE3::AB, fcs(WE3::FB, 16));
-  add(WJ_CONV, 2, WE2::AB, fcs(WE2::FB, 16));
-  add(WJ_CONV, 1, WE1::AB, fcs(WE1::FB, 32));
-  add(WJ_CONV, 6, WD1::AB, fcs(WD1::FB, 32));
-  add(WJ_CONV, 7, WD2::AB, fcs(WD2::FB, 32));
-  add(WJ_CONV, 0, WE0::AB, fcs(WE0::FB, 32));
+  add(WJ_TOEP, 0, TWG_BLOCKS, fcs(1, caps[0]));
+  add(WJ_CONV, 4, WE4::AB, fcs(WE4::FB, caps[1]));
+  add(WJ_CONV, 5, WD0::AB, fcs(WD0::FB, caps[2]));
+  add(WJ_CONV, 3, WE3::AB, fcs(WE3::FB, caps[3]));
+  add(WJ_CONV, 2, WE2::AB, fcs(WE2::FB, caps[4]));
+  add(WJ_CONV, 1, WE1::AB, fcs(WE1::FB, caps[5]));
+  add(WJ_CONV, 6, WD1::AB, fcs(WD1::FB, caps[6]));
+  add(WJ_CONV, 7, WD2::AB, fcs(WD2::FB, caps[7]));
+  add(WJ_CONV, 0, WE0::AB, fcs(WE0::FB, caps[8]));
   add(WJ_OUTER, 0, cdiv_(32 * MERGE_N, WT), 1);
   add(WJ_OUTER, 1, cdiv_(32 * MERGE_N, WT), 1);
   add(WJ_OUTER, 2, cdiv_(192 * 128, WT), 1);
