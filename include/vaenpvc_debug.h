@@ -32,7 +32,13 @@ extern "C" {
  * Bits 25 / 22 (default set): cleared = every thin / medium conv site on the fused kernels (gfx950_fconv.h,
  * gfx950_fconv_r.h) at any batch size; bit 24 of the backward mask: the thin weight gradients on gfx950_fwgrad.h;
  * bit 23: encoder layer 0 on its wave-per-frame kernels.  (The bits 22-28 exist for the parity tests, which pin every
- * kernel family against the float64 restatement at small batch sizes; defaults select by measurement.) */
+ * kernel family against the float64 restatement at small batch sizes; defaults select by measurement.)
+ * Bit 21 of either mask (default set): cleared = never use the small-batch frame kernels (gfx950_frame.h: one workgroup
+ * carries one frame through a whole pass; selected up to 512 frames per call, VAENPVC_FRAME_MAX); a train step uses them
+ * for both passes or for neither.  Bit 20 of the backward mask (default set): cleared = behind the frame kernels, the
+ * weight gradients come from the layered kernels on two streams instead of the one-launch job list
+ * (gfx950_frame_wgrad.h).  Bit 19 of the backward mask (default set): cleared = encoder layer 0's LayerNorm backward
+ * and weight gradient as two passes instead of the fused kernel (k_enc0_bwd_wave, from 1024 frames on). */
 int vaenpvc_set_tuned_masks(vaenpvc_ctx* ctx, uint32_t fwd_mask, uint32_t bwd_mask);
 
 /* Measurement hook (no reference counterpart): brackets every launch of ONE tagged
@@ -43,6 +49,14 @@ int vaenpvc_timer_select(vaenpvc_ctx* ctx, const char* tag);
 /* Synchronises the recorded events (blocks the host), returns the summed milliseconds and the
  * number of launches since the last read, and resets the accumulator. */
 int vaenpvc_timer_read(vaenpvc_ctx* ctx, double* total_ms, int64_t* launches);
+
+/* Process-wide developer switches of the small-batch path (scripts/frame_prof.py, scripts/wgrad_prof.py):
+ * per-phase shader clocks of the two frame kernels (environment VAENPVC_FRAME_PROF=1 selects the instrumented
+ * instantiations; copies 1024 counters, returns 0 or -1 when profiling is off); a bit set of the job-list segments of
+ * the one-launch weight gradient to leave in the launch; the most frame chunks of its nine chunked jobs (NULL = defaults). */
+int vaenpvc_debug_frame_prof(long long* out1024);
+void vaenpvc_debug_wg_segments(unsigned mask);
+void vaenpvc_debug_wg_caps(const int* caps9);
 
 #ifdef __cplusplus
 }

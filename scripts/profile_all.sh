@@ -28,5 +28,19 @@ if [ "$WHAT" = all ]; then
   (cd $ROOT && timeout 300 python scripts/site_times.py --frames 256 > $OUT/${TAG}_site_times_F256.txt 2>/dev/null)
   (cd /tmp && VAENPVC_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rp_f256 -- python $ROOT/bench.py --frames 256 --steps 100 --warmup 10 --no-cpu-baseline --no-literal --no-modes --no-convert > $OUT/f256.log 2>&1)
   db=$(find /tmp/rp_f256 -name '*.db' | head -1); [ -n "$db" ] && python $ROOT/scripts/rocpd_stats.py $db 70 > $OUT/${TAG}_kernel_trace_stats_F256.txt
+  (cd /tmp && VAENPVC_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rp_f16 -- python $ROOT/bench.py --frames 16 --steps 100 --warmup 10 --no-cpu-baseline --no-literal --no-modes --no-convert > $OUT/f16.log 2>&1)
+  db=$(find /tmp/rp_f16 -name '*.db' | head -1); [ -n "$db" ] && python $ROOT/scripts/rocpd_stats.py $db 70 > $OUT/${TAG}_kernel_trace_stats_F16.txt
+  # VAWGAN branch (config 5): wall times and kernel trace at 16 and 256 frames
+  for VF in 16 256; do
+    (cd $ROOT && timeout 300 python scripts/vawgan_bench.py --frames $VF --iters 50 2>/dev/null | tail -1 > $OUT/${TAG}_vawgan_bench_F$VF.json)
+  done
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rp_vw -- python $ROOT/scripts/vawgan_bench.py --frames 16 --iters 20 > $OUT/vw.log 2>&1)
+  db=$(find /tmp/rp_vw -name '*.db' | head -1); [ -n "$db" ] && python $ROOT/scripts/rocpd_stats.py $db 70 > $OUT/${TAG}_vawgan_kernel_trace_stats.txt
+  # conversion path (config 4): encode -> decode
+  (cd $ROOT && timeout 300 python scripts/bench_convert.py > $OUT/${TAG}_bench_convert.json 2> $OUT/bench_convert.err)
+  # small-batch path: per-phase clocks of the two frame kernels, per-segment times of the one-launch weight gradient
+  (cd $ROOT && VAENPVC_FRAME_PROF=1 timeout 300 python scripts/frame_prof.py > $OUT/${TAG}_frame_phases_F16.txt 2>/dev/null)
+  (cd $ROOT && timeout 300 python scripts/wgrad_prof.py 16 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_frame_wgrad_segments_F16.txt)
+  (cd $ROOT && timeout 300 python scripts/wgrad_prof.py 256 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_frame_wgrad_segments_F256.txt)
   (cd $ROOT && timeout 900 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err)
 fi

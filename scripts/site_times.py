@@ -9,7 +9,7 @@ from hipvae.dp import Stepper  # noqa: E402
 TAGS = ('enc0_fwd enc1_split enc1_fwd enc2_split enc2_fwd enc3_split enc3_fwd enc4_split enc4_fwd heads_split heads_fwd merge_split merge_fwd dec0_split dec0_fwd dec1_split dec1_fwd '
         'dec2_split dec2_fwd dec3_fwd dec3_wgrad dec3_dgrad dec2_gsplit dec2_asplit dec2_wgrad dec2_dgrad dec1_gsplit dec1_asplit dec1_wgrad dec1_dgrad dec0_gsplit dec0_asplit dec0_wgrad dec0_dgrad merge_dsplit '
         'merge_wgrad merge_segsum merge_dgrad heads_dsplit heads_wgrad heads_dgrad enc4_dsplit enc4_wgrad enc4_dgrad enc3_gsplit enc3_asplit enc3_wgrad '
-        'enc3_dgrad enc2_gsplit enc2_asplit enc2_wgrad enc2_dgrad enc1_gsplit enc1_asplit enc1_wgrad enc1_dgrad enc0_wgrad').split()
+        'enc3_dgrad enc2_gsplit enc2_asplit enc2_wgrad enc2_dgrad enc1_gsplit enc1_asplit enc1_wgrad enc1_dgrad enc0_wgrad enc0_bwd').split()
 ap = argparse.ArgumentParser()
 ap.add_argument('--frames', type=int, default=32768)
 ap.add_argument('--precision', default='auto')

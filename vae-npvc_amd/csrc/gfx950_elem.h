@@ -262,6 +262,130 @@ __global__ void __launch_bounds__(256) k_enc0_wgrad_wave(const float* __restrict
     part[(int64_t)blockIdx.x * (7 * CO) + threadIdx.x] =
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+// The whole backward of encoder layer 0 in one pass, one wave per frame: LayerNorm + lrelu backward (the autodiff written out
+// above k_ln_bwd_fused below), the weight gradient and the four per-channel parameter sums.  The layer's pre-LN output is
+// RECOMPUTED from the frame's 2 KB input row (7 FMAs per element) instead of read back (10.9 KB per frame), and the
+// gradient of the pre-LN output never goes to memory: HBM traffic = d(activated output) once + x, against two reads +
+// one write in the LayerNorm pass and two more reads in the weight-gradient pass.
+//   phase 1 (lane = positions j, j + 64, j + 128; 16 channels in registers): a = b + W x ; xhat, dn = dy * lrelu'(n) ;
+//            two wave reductions ; du -> the wave's LDS tile ; d gamma / d beta / d bias sums carried per lane;
+//   phase 2 (lane = channel o = lane & 15, quarter of the positions): dW[t][o] += x[3j + t - 2] * du[o][j] from LDS,
+//            seven accumulators per lane over all frames of the wave.
+// No workgroup barrier inside the frame loop (a wave only touches its own LDS tile).
+struct Enc0BwdCfg {
+  static constexpr int H = 513, HO = 171, CO = 16, N = CO * HO, DP = 172, XS = 528, WAVE_FLOATS = CO * DP + XS;
+  static constexpr int LDS_BYTES = 4 * WAVE_FLOATS * 4, NW = 7 * CO, NC = 3 * CO, JQ = 43;
+};
+__global__ void __launch_bounds__(256, 2) k_enc0_bwd_wave(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ st, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ part_w,
+                                                          float* __restrict__ part_c, int F) {
+  using E = Enc0BwdCfg;
+  constexpr int H = E::H, HO = E::HO, CO = E::CO, N = E::N, DP = E::DP;
+  extern __shared__ __attribute__((aligned(16))) float e0lds[];
+  __shared__ float red[4][E::NW + E::NC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* du = e0lds + wave * E::WAVE_FLOATS;   // [16][172]
+  float* xs = du + CO * DP;                    // xs[i] = x[i - 2], zero outside
+  for (int i = lane; i < E::XS; i += 64) xs[i] = 0.f;
+  const int wo = lane & 15, wq = lane >> 4;    // phase 2: channel, quarter of the positions
+  float acc[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) acc[t] = 0.f;
+  float su[CO], sw[CO], sd[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) su[o] = sw[o] = sd[o] = 0.f;
+  for (int f = blockIdx.x * 4 + wave; f < F; f += gridDim.x * 4) {
+    const float* xf = x + (int64_t)f * H;
+    const float* df = dy + (int64_t)f * N;
+    const float mean = st[2 * f], rstd = st[2 * f + 1];
+    float dn[3][CO], xh[3][CO];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int j = lane + 64 * k;
+#pragma unroll
+      for (int o = 0; o < CO; ++o) dn[k][o] = j < HO ? df[o * HO + j] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int i = lane + 64 * k;
+      if (i < H) xs[2 + i] = xf[i];
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int j = lane + 64 * k;
+      float xt[7];
+#pragma unroll
+      for (int t = 0; t < 7; ++t) xt[t] = xs[(j < HO ? 3 * j : 0) + t];
+#pragma unroll
+      for (int o = 0; o < CO; ++o) {
+        // (the 160 layer parameters are uniform values: the compiler keeps what the scalar file cannot hold in vector-register
+        //  lanes; reading them back from LDS as broadcasts instead was 45 % slower)
+        float a0 = bias[o];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) a0 += W[t * CO + o] * xt[t];
+        const float xv = j < HO ? (a0 - mean) * rstd : 0.f;
+        const float nn = xv * gamma[o] + beta[o];
+        const float dv = dn[k][o] * (nn >= 0.f ? 1.0f : LEAK);
+        const float dx = dv * gamma[o];
+        s1 += dx;
+        s2 += dx * xv;
+        dn[k][o] = dv;
+        xh[k][o] = xv;
+      }
+    }
+    s1 = wave_sum(s1) * (1.0f / N);
+    s2 = wave_sum(s2) * (1.0f / N);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int j = lane + 64 * k;
+      if (j < HO) {
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+          const float d = rstd * (dn[k][o] * gamma[o] - s1 - xh[k][o] * s2);
+          du[o * DP + j] = d;
+          su[o] += dn[k][o] * xh[k][o];
+          sw[o] += dn[k][o];
+          sd[o] += d;
+        }
+      }
+    }
+    // phase 2: the frame's weight-gradient contribution from the wave's own tile (LDS operations of a wave execute in order)
+    const int j0 = wq * E::JQ, j1 = j0 + E::JQ < HO ? j0 + E::JQ : HO;
+    const float* dr = du + wo * DP;
+    for (int j = j0; j < j1; ++j) {
+      const float dv = dr[j];
+#pragma unroll
+      for (int t = 0; t < 7; ++t) acc[t] += xs[3 * j + t] * dv;
+    }
+  }
+  // the quarters of a channel meet (lanes o, o + 16, o + 32, o + 48), then the four waves
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    float r = acc[t];
+    r += __shfl_xor(r, 16);
+    r += __shfl_xor(r, 32);
+    if (lane < CO) red[wave][t * CO + lane] = r;
+  }
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    const float u = wave_sum(su[o]), w = wave_sum(sw[o]), d = wave_sum(sd[o]);
+    if (lane == 0) {
+      red[wave][E::NW + o] = u;
+      red[wave][E::NW + CO + o] = w;
+      red[wave][E::NW + 2 * CO + o] = d;
+    }
+  }
+  __syncthreads();
+  const int tid = threadIdx.x;
+  if (tid < E::NW + E::NC) {
+    const float r = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (tid < E::NW) part_w[(int64_t)blockIdx.x * E::NW + tid] = r;
+    else part_c[(int64_t)blockIdx.x * E::NC + (tid - E::NW)] = r;
+  }
+}
 // out[col] += sum over rows of part[row][col]  (one workgroup per column)
 __global__ void __launch_bounds__(256) k_colsum_part(const float* __restrict__ part, int rows, int cols, float* __restrict__ out) {
   __shared__ float sm[4];

@@ -803,6 +803,9 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   // (only when every step runs its tuned kernel: a generic fallback STORES the bias gradient its layer's LayerNorm
   //  backward has added to, which is only right if that addition happened first)
   LnReduceList* lnq = (F <= 512 && (rt().bwd_mask & 0x7ffu) == 0x7ffu) ? &lnq_store : nullptr;
+  // encoder layer 0: one fused backward kernel (gfx950_elem.h: k_enc0_bwd_wave) from ENC0_WAVE_MIN_FRAMES frames on;
+  // bit 19 of the backward mask cleared = the separate LayerNorm-backward and weight-gradient passes
+  const bool enc0_fused = bwd_on(0) && bwd_on(1) && bwd_on(19) && F >= ENC0_WAVE_MIN_FRAMES && !lnq;
 
   // ---- conv layers on the view GEMMs (gfx950_viewconv.h): producers / consumers of the channel-last planes
   auto gsplit = [&](int cl, const float* src, const char* tag) {   // gradient tensor -> planes
@@ -1162,11 +1165,23 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     else
     VAENPVC_TIMED("enc1_dgrad", s, launch_convgemm<GE1>(conv_args(w.d_enc_a[1], nullptr, nullptr, nullptr, w.scratch + Pk::ge1,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE1>(F), s));
+    if (!enc0_fused)
     launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.enc_a[0], w.enc_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[0],
                                       G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
     enc_bias_done[0] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 1);
-  if (bwd_on(0)) {
+  if (enc0_fused) {
+    // LayerNorm backward + weight gradient + parameter sums of encoder layer 0 in one pass over d(activated output) and x
+    const ConvL& l = m.enc[0];
+    const int nwg = cmin_(cdiv(F, 64), 512);
+    float* pw = w.scratch + Pk::enc0part;
+    float* pc = w.scratch + Pk::lnpart;     // (no other LayerNorm partial rows are alive: the layers before flushed theirs)
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_enc0_bwd_wave), Enc0BwdCfg::LDS_BYTES);
+    VAENPVC_TIMED("enc0_bwd", s, hipLaunchKernelGGL(k_enc0_bwd_wave, dim3((unsigned)nwg), dim3(256), Enc0BwdCfg::LDS_BYTES, s, x, w.dy_tmp,
+                                                    w.enc_st[0], P + l.w_off, P + l.b_off, P + l.gamma_off, P + l.beta_off, pw, pc, F));
+    hipLaunchKernelGGL(k_colsum_part, dim3(7 * 16), dim3(256), 0, s, pw, nwg, 7 * 16, G + l.w_off);
+    hipLaunchKernelGGL(k_ln_bwd_reduce, dim3(3 * 16), dim3(256), 0, s, pc, nwg, 16, G + l.gamma_off, G + l.beta_off, G + l.b_off);
+  } else if (bwd_on(0)) {
     const ConvL& l = m.enc[0];
     WgArgs a{x, nullptr, nullptr, nullptr, w.d_enc_a[0], nullptr, nullptr, nullptr, G + l.w_off, F, 0};
     ready();
