@@ -67,6 +67,12 @@ def parse(argv=None):
     p.add_argument('--no-literal', action='store_true', help='skip the extra F=256 / F=16 measurements')
     p.add_argument('--no-modes', action='store_true', help='skip the other precisions')
     p.add_argument('--no-convert', action='store_true', help='skip the conversion-path (config 4) measurement')
+    p.add_argument('--all-legs', action='store_true',
+                   help='N > 1: also run the legs that no multi-rank RCCL run has exercised yet (hipGraph capture of a step with '
+                        'its all-reduce, the VAWGAN iteration); by default they are skipped there and said so in the line')
+    p.add_argument('--side-leg-seconds', type=float, default=900.0,
+                   help='watchdog of everything after the headline measurement: when it expires rank 0 prints the line it has '
+                        '(with "side_legs": "timed out ...") and every rank exits')
     p.add_argument('--master-port', type=int, default=0, help='rendezvous port of the self-launched ranks (0 = pick a free one)')
     p.add_argument('--standin', default=None,
                    help='TEST ONLY: python file providing make_engine(arch, args) -> CPU stand-in engine; the ranks then use '
@@ -333,6 +339,31 @@ def main(argv=None):
         if dist.is_initialized():
             dist.destroy_process_group()
         return
+    # ---- from here on: side legs.  The headline is measured; nothing below may swallow it.  A watchdog thread prints the line
+    #      as it stands and ends the process when the side legs take longer than --side-leg-seconds (a hung collective in a
+    #      leg that only one rank entered cannot be cancelled from Python)
+    import threading
+
+    def _emit(extra=None):
+        if extra:
+            out['side_legs'] = extra
+        if rank == 0:
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)      # (RCCL prints a banner with printf: the JSON line must be the LAST line)
+            except Exception:
+                pass
+            print(json.dumps(out), flush=True)
+
+    def _expired():
+        try:
+            _emit('timed out after %.0f s: the line holds what was measured until then' % args.side_leg_seconds)
+        finally:
+            os._exit(0)
+    watchdog = threading.Timer(args.side_leg_seconds, _expired)
+    watchdog.daemon = True
+    watchdog.start()
+    risky = world == 1 or args.all_legs      # legs never run under multi-rank RCCL (see --all-legs)
     # whole-step HBM traffic from the committed PMC passes of this command (sum over all kernels of
     # 2 x FETCH_SIZE + WRITE_SIZE; profiles/README.md), next to the layer-materialised algorithmic bytes
     try:
@@ -429,6 +460,8 @@ def main(argv=None):
             # same step captured in a hipGraph (one launch per step instead of one per kernel); with N > 1 the
             # (unbucketed) gradient all-reduce is captured with it
             try:
+                if not risky:
+                    raise RuntimeError('skipped at N > 1 (--all-legs runs it)')
                 x, y = make_batch(Fl, 99)
                 st.capture(x, y)
                 for _ in range(10):
@@ -472,6 +505,8 @@ def main(argv=None):
         # BASELINE.json configs[4]: the VAWGAN branch (nIterD critic steps + one generator step per iteration, 16 frames per
         # step and GPU; hipvae/adversarial.py, data parallel over the same process group).  Reported beside the headline.
         try:
+            if not risky:
+                raise RuntimeError('skipped at N > 1 (--all-legs runs it)')
             from hipvae.critic import Critic
             from hipvae.adversarial import AdvStepper
             with open(os.path.join(ROOT, 'vae-npvc_amd', 'architecture-vawgan-vcc2016.json')) as fp:
@@ -509,15 +544,8 @@ def main(argv=None):
             out['config']['vawgan_config5'] = {'error': str(ex)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(arch, args.cpu_seconds)
-    if rank == 0:
-        # anything native libraries left in the C stdio buffer (RCCL prints a version banner with printf when a
-        # communicator is created) goes out FIRST: the JSON line is the last line of stdout
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(out), flush=True)
+    watchdog.cancel()
+    _emit()
     if dist.is_initialized():
         dist.destroy_process_group()
 
