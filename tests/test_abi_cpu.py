@@ -89,6 +89,24 @@ def test_workspace_queries(arch):
     lib.vaenpvc_ctx_destroy(ctx)
 
 
+def test_tuned_geometry_requires_ten_speakers(arch):
+    """The gfx950 kernels size their merge table, per-speaker sums and frame-kernel scratch for VCC2016's 10 speakers:
+    the same layer table with another y_dim must select the geometry-generic kernels (visible in the workspace layout:
+    the regions of the tuned kernels are absent)."""
+    import copy
+    off = C.c_int64()
+    lib, ctx, rc = make_ctx(arch)
+    assert rc == 0 and lib.vaenpvc_ws_find(ctx, 16, L.MODE_TRAIN, b'frame_pk', C.byref(off), None) == 0
+    lib.vaenpvc_ctx_destroy(ctx)
+    other = copy.deepcopy(arch)
+    other['y_dim'] = 12
+    lib, ctx, rc = make_ctx(other)
+    assert rc == 0
+    assert lib.vaenpvc_ws_find(ctx, 16, L.MODE_TRAIN, b'frame_pk', C.byref(off), None) < 0
+    assert lib.vaenpvc_ws_find(ctx, 16, L.MODE_TRAIN, b'cl0', C.byref(off), None) < 0
+    lib.vaenpvc_ctx_destroy(ctx)
+
+
 def test_malformed_architecture_is_rejected(arch):
     import copy
     bad = copy.deepcopy(arch)

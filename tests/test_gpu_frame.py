@@ -145,3 +145,32 @@ def test_frame_step_is_repeatable_and_graph_capturable():
     torch.cuda.synchronize()
     d = (eng.params - p0).abs().max().item()
     assert d > 0 and (eng.params - p_eager).abs().max().item() <= 2e-3 * d + 1e-9
+
+
+def test_another_speaker_count_runs_on_the_generic_kernels():
+    """VCC2016 layer table with 12 speakers: the tuned kernels (sized for 10) must not be selected; losses and all
+    gradients against the float64 oracle at 16 frames"""
+    import copy
+    from hipvae import Engine
+    arch = copy.deepcopy(ARCHS['vcc'])
+    arch['y_dim'] = 12
+    F, seed = 16, 5
+    P = O.init_params(arch, seed)
+    x, y, eps = O.make_inputs(arch, F, seed)
+    y[:3] = (11, 10, 0)
+    eng = Engine(arch)
+    l3, grads = run_train(eng, P, x, y, eps)
+    eng.timer_select('frame_fwd')
+    run_train(eng, P, x, y, eps)
+    _, n = eng.timer_read()
+    eng.timer_select(None)
+    assert n == 0
+    R = O.np_forward(arch, P, x, y, eps)
+    from test_gpu_parity import oracle_grads
+    _, G = oracle_grads(eng, arch, P, x, y, eps)
+    fails = []
+    check('ny12 loss3', l3, np.array([R['G'], R['D_KL'], R['logP']]), TOL_ACT, fails)
+    for name, (off, shape) in eng.layout.items():
+        n = int(np.prod(shape))
+        check('ny12 grad ' + name, grads[off:off + n].reshape(shape), G[name], TOL_GRAD, fails)
+    assert not fails, '\n'.join(fails)

@@ -109,7 +109,8 @@ std::string build_model(const vaenpvc_arch& a, Model* m) {
 
   static const int ek[5] = {7, 7, 7, 7, 7}, eo[5] = {16, 32, 64, 128, 256};
   static const int dk[4] = {9, 7, 7, 1025}, ds[4] = {3, 3, 3, 1}, dout[4] = {32, 16, 8, 1};
-  bool v = a.H == 513 && a.z_dim == 128 && a.n_enc == 5 && a.n_dec == 4 && a.gen_h == 19 && a.gen_c == 81;
+  // (10 speakers: the merge table, the per-speaker segment sums and the frame kernels size their scratch for VCC2016's ten)
+  bool v = a.H == 513 && a.z_dim == 128 && a.y_dim == 10 && a.n_enc == 5 && a.n_dec == 4 && a.gen_h == 19 && a.gen_c == 81;
   if (v)
     for (int i = 0; i < 5; ++i) v = v && a.enc_kernel[i] == ek[i] && a.enc_stride[i] == 3 && a.enc_output[i] == eo[i];
   if (v)
