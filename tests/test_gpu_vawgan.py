@@ -157,6 +157,19 @@ def test_critic_step_on_a_generic_geometry():
     assert rel_err(target.cpu().numpy() - x, 50.0 * (1 + 1e-6) * g.numpy()) < TOL_VALUE
 
 
+def assert_repeatable(cr, ga, gb):
+    """Two runs of the same critic step: bitwise equal for every tensor whose gradient is accumulated by one thread per
+    element (the 115-tap layer, the dense unit); the two thin conv layers' gradients come from the job-list launch of
+    csrc/disc_frame.h, whose frame chunks meet through fp32 atomics: equal up to the order of a few additions."""
+    for k, (off, shp) in cr.layout.items():
+        n = int(np.prod(shp))
+        a, b = ga[off:off + n], gb[off:off + n]
+        if 'Conv2d-0' in k or 'Conv2d-1' in k:
+            assert float((a - b).abs().max()) <= 2e-6 * max(float(a.abs().max()), 1e-12), k
+        else:
+            assert torch.equal(a, b), k
+
+
 def test_large_batch_dense_layer_agrees_with_the_conv_kernels(monkeypatch):
     """F = 1024 (3072 rows through every critic kernel: many GEMM tiles, frame-split weight gradients): finite, bitwise
     repeatable, and the 115-tap layer as a dense layer on the matrix cores == the same layer on the thread-per-output
@@ -173,7 +186,8 @@ def test_large_batch_dense_layer_agrees_with_the_conv_kernels(monkeypatch):
     g1, g2, g3 = (torch.empty(cr.n_params, device=dev) for _ in range(3))
     l_a = cr.critic_fwd_bwd(x, xh, t, 10.0, g1).clone()
     l_b = cr.critic_fwd_bwd(x, xh, t, 10.0, g2).clone()
-    assert torch.isfinite(g1).all() and torch.equal(g1, g2) and torch.equal(l_a, l_b)
+    assert torch.isfinite(g1).all() and torch.equal(l_a, l_b)
+    assert_repeatable(cr, g1, g2)
     monkeypatch.setenv('VAENPVC_DISC_DENSE', '0')
     c2 = Critic(arch)
     monkeypatch.delenv('VAENPVC_DISC_DENSE')
@@ -190,14 +204,14 @@ def test_large_batch_dense_layer_agrees_with_the_conv_kernels(monkeypatch):
 
 
 def test_critic_step_is_deterministic_and_linear_in_lambda():
-    """Bitwise repeatable (no atomics), and grad(lambda) is affine in lambda: g(20) - g(10) == g(10) - g(0)."""
+    """Repeatable (see assert_repeatable), and grad(lambda) is affine in lambda: g(20) - g(10) == g(10) - g(0)."""
     arch = vawgan_arch()
     cr, _ = make_critic(arch, 4)
     x, xh, t = (torch.tensor(a, device=cr.device) for a in critic_inputs(7, 2))
     g = [torch.empty(cr.n_params, device=cr.device) for _ in range(4)]
     for gi, lam in zip(g, (0.0, 10.0, 20.0, 10.0)):
         cr.critic_fwd_bwd(x, xh, t, lam, gi)
-    assert torch.equal(g[1], g[3])
+    assert_repeatable(cr, g[1], g[3])
     d1, d2 = (g[2] - g[1]).cpu().numpy(), (g[1] - g[0]).cpu().numpy()
     assert np.abs(d1 - d2).max() < 1e-4 * np.abs(d2).max()
 

@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "disc_frame.h"
 
 namespace vaenpvc {
 namespace disc {
@@ -751,6 +752,13 @@ __global__ void k_adv_target(const float* __restrict__ x, const float* __restric
 using namespace vaenpvc;
 using namespace vaenpvc::disc;
 
+// every parameter gradient of the two thin conv layers (disc_frame.h): a workgroup finds its job from its block index
+__global__ void __launch_bounds__(frame::WT) k_critic_front_wgrad(front::CwArgs a, front::CwPlan pl) {
+  extern __shared__ __attribute__((aligned(16))) float cw_lds[];
+  tuned::WRunner run;
+  front::critic_front_wgrad_block(run, cw_lds, a, pl, (int)blockIdx.x);
+}
+
 struct DiscL {
   int cin, hin, cout, hout, k, s, pad;
   int64_t w_off, b_off, beta_off, gamma_off;
@@ -760,6 +768,7 @@ struct DiscL {
 };
 struct vaenpvc_disc {
   int H, n_layers, flat;
+  bool front;   // layers 0-1 have the VCC2016 geometry (1 -> 16 -> 32 channels, 7 taps, stride 3 on 513 bins): disc_frame.h serves them
   DiscL l[VAENPVC_MAX_LAYERS];
   int64_t wd_off, bd_off, n_params;
   std::vector<ParamInfo> table;
@@ -1020,6 +1029,12 @@ int vaenpvc_disc_create(const vaenpvc_disc_arch* a, vaenpvc_disc** out) {
     c = o;
     h = l.hout;
   }
+  {
+    const char* e = getenv("VAENPVC_DISC_FRONT");   // (=0: keep the per-layer kernels, for A/B)
+    const DiscL &l0 = m->l[0], &l1 = m->l[1];
+    m->front = a->n_layers >= 3 && a->H == 513 && l0.k == 7 && l0.s == 3 && l0.cout == 16 && l0.pad == 2 && l1.k == 7 && l1.s == 3 &&
+               l1.cout == 32 && l1.pad == 2 && !l1.dense && m->l[2].dense && !(e && e[0] == '0');
+  }
   m->flat = c * h;
   m->wd_off = add("Discriminator/dense/kernel", {m->flat, 1});
   m->bd_off = add("Discriminator/dense/bias", {1});
@@ -1123,11 +1138,11 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
       dense_wgrad(src, w.ubar[i], w.dWd, Gd + l.w_off, F, l, s);
     } else {
       conv_fwd(src, kNoAct, P + l.w_off, nullptr, w.q[i], F, l, s);
-      conv_bwd_w(src, kNoAct, w.ubar[i], Gd + l.w_off, F, l, w.part[0][i], &sums, s);
+      if (!(m.front && i < 2)) conv_bwd_w(src, kNoAct, w.ubar[i], Gd + l.w_off, F, l, w.part[0][i], &sums, s);
     }
     hipLaunchKernelGGL(k_ln_bwd_bwd, dim3((unsigned)F), dim3(256), 0, s, w.q[i], w.abar[i], w.u[i] + 2 * F * l.n(),
                        w.st[i] + 4 * F, P + l.gamma_off, P + l.beta_off, w.at[i], w.udir[i], w.pn[i], l.cout, l.hout);
-    csums.e[csums.count++] = ChanSum{w.pn[i], Gd + l.gamma_off, F, l.cout, l.hout};   // adjoint of gamma
+    if (!(m.front && i < 2)) csums.e[csums.count++] = ChanSum{w.pn[i], Gd + l.gamma_off, F, l.cout, l.hout};   // adjoint of gamma
   }
   csums.e[csums.count++] = ChanSum{w.at[L - 1], Gd + m.wd_off, F, m.flat, 1};   // abar_top = w
   // pass 4, all rows: upstream -1/F (x), +1/F (xh), 0 (xi)
@@ -1142,20 +1157,31 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
   pgs.count = 0;
   for (int i = L - 1; i >= 0; --i) {
     const DiscL& l = m.l[i];
+    const bool fr = m.front && i < 2;   // parameter gradients of this layer: the job-list launch below
+    if (!fr)
     pgs.e[pgs.count++] = ParamGrad{w.da[i], w.u[i], w.st[i], P + l.gamma_off, P + l.beta_off, Gd + l.gamma_off, Gd + l.beta_off, B,
                                    l.cout, l.hout};
     hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)B), dim3(256), 0, s, w.da[i], w.u[i], w.st[i], P + l.gamma_off,
                        P + l.beta_off, w.udir[i], 2 * F, w.du[i], l.cout, l.hout);   // udir on the rows xi
     Act ai = i == 0 ? kNoAct : act_of(m.l[i - 1], P, w.st[i - 1]);
     if (l.dense) dense_wgrad(w.ain[i], w.du[i], w.dWd, Gd + l.w_off, B, l, s);   // (ain: the activated input kept by pass 1)
-    else conv_bwd_w(i == 0 ? w.rows : w.u[i - 1], ai, w.du[i], Gd + l.w_off, B, l, w.part[1][i], &sums, s);
-    csums.e[csums.count++] = ChanSum{w.du[i], Gd + l.b_off, B, l.cout, l.hout};   // conv bias
+    else if (!fr) conv_bwd_w(i == 0 ? w.rows : w.u[i - 1], ai, w.du[i], Gd + l.w_off, B, l, w.part[1][i], &sums, s);
+    if (!fr) csums.e[csums.count++] = ChanSum{w.du[i], Gd + l.b_off, B, l.cout, l.hout};   // conv bias
     if (i > 0) {
       if (l.dense) dense_dgrad(w.du[i], w.Wd[i], w.da[i - 1], B, l, w.mmpart, s);
       else conv_bwd_data(w.du[i], P + l.w_off, w.da[i - 1], B, l, s);
     }
   }
-  {
+  if (m.front) {   // layers 0-1: weight, bias and LayerNorm-parameter gradients of passes 3 and 4 in one launch (atomics)
+    const DiscL &l0 = m.l[0], &l1 = m.l[1];
+    front::CwArgs ca{w.rows, w.gt, w.u[0], w.st[0], w.u[1], w.st[1], P + l0.gamma_off, P + l0.beta_off, P + l1.gamma_off, P + l1.beta_off,
+                     w.at[0], w.ubar[0], w.ubar[1], w.du[0], w.du[1], w.da[0], w.da[1], w.pn[0], w.pn[1],
+                     Gd + l0.w_off, Gd + l1.w_off, Gd + l0.b_off, Gd + l1.b_off, Gd + l0.gamma_off, Gd + l0.beta_off,
+                     Gd + l1.gamma_off, Gd + l1.beta_off, (int)F, (int)B};
+    const front::CwPlan cp = front::make_cwplan((int)F, (int)B);
+    hipLaunchKernelGGL(k_critic_front_wgrad, dim3((unsigned)cp.start[front::CW_SEGS]), dim3(frame::WT), frame::WG_LDS * 4, s, ca, cp);
+  }
+  if (pgs.count > 0) {
     int cmax = 0;
     for (int e = 0; e < pgs.count; ++e) cmax = std::max(cmax, pgs.e[e].C);
     hipLaunchKernelGGL(k_ln_param_grad, dim3((unsigned)cmax, (unsigned)pgs.count), dim3(B * 16 >= 4096 ? 1024 : 256), 0, s, pgs);   // one workgroup per channel walks all rows

@@ -102,8 +102,10 @@ struct ConvW {
   static constexpr bool VIA_LDS = NTH * K * 4 <= WG_LDS;      // the tile leaves through LDS (coalesced atomics)
   static_assert(NTH <= WT && HUP >= PAD + HU && FB * FRAME <= WG_LDS && (JS == 1 || VIA_LDS), "ConvW tiling");
 };
-template <class T, class R>
-FR_DEV void convw_job(R& run, float* lds, const float* U, const float* V, float* dW, int F, int ablk, int fchunk, int nfc) {
+// (`uld(f, a, p)` = element p of channel a of frame f of the strided operand: a plain tensor, or one with a LayerNorm +
+//  lrelu applied on load -- the critic's job list, disc_frame.h)
+template <class T, class R, class UL>
+FR_DEV void convw_job_u(R& run, float* lds, UL&& uld, const float* V, float* dW, int F, int ablk, int fchunk, int nfc) {
   const int a0 = ablk * T::AT;
   const int fper = (F + nfc - 1) / nfc, f0 = fchunk * fper, f1 = imin_(F, f0 + fper);
   float acc[T::K][4];
@@ -115,7 +117,7 @@ FR_DEV void convw_job(R& run, float* lds, const float* U, const float* V, float*
                  const int fb = i / T::FRAME, r = i % T::FRAME;
                  if (r >= T::AT * T::HUP) return V[(size_t)(f + fb) * T::CB * T::HV + (r - T::AT * T::HUP)];
                  const int al = r / T::HUP, p = r % T::HUP - T::PAD, a = a0 + al;
-                 return (a < T::CA && p >= 0 && p < T::HU) ? U[((size_t)(f + fb) * T::CA + a) * T::HU + p] : 0.f;
+                 return (a < T::CA && p >= 0 && p < T::HU) ? uld(f + fb, a, p) : 0.f;
                });
              },
              // ---- zero the accumulators
@@ -179,6 +181,11 @@ FR_DEV void convw_job(R& run, float* lds, const float* U, const float* V, float*
       }
     });
   }
+}
+
+template <class T, class R>
+FR_DEV void convw_job(R& run, float* lds, const float* U, const float* V, float* dW, int F, int ablk, int fchunk, int nfc) {
+  convw_job_u<T>(run, lds, [&](int f, int a, int p) { return U[((size_t)f * T::CA + a) * T::HU + p]; }, V, dW, F, ablk, fchunk, nfc);
 }
 
 //                 CA   HU   CB   HV   K  S PAD AT  JS  FB
