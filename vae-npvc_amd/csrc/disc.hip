@@ -93,9 +93,15 @@ static inline dim3 grid1(int64_t n, int bs = 256) { return dim3((unsigned)((n + 
 
 // ------------------------------------------------------------------------------------------- forward
 // rows [x | xh | xi]: xi_f = x_f + t_f (xh_f - x_f); t == nullptr: two groups only
+// (w1t != nullptr: the launch also leaves layer 1's kernel as [t][o][c] for the input-gradient tile of disc_frame.h)
 __global__ void k_rows(const float* __restrict__ x, const float* __restrict__ xh, const float* __restrict__ t,
-                       float* __restrict__ rows, int64_t F, int H) {
+                       float* __restrict__ rows, int64_t F, int H, const float* __restrict__ W1 = nullptr,
+                       float* __restrict__ w1t = nullptr) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w1t && idx < 7 * 16 * 32) {
+    const int c = (int)idx % 16, o = ((int)idx / 16) % 32, tt = (int)idx / 512;
+    w1t[idx] = W1[(tt * 16 + c) * 32 + o];
+  }
   if (idx >= F * H) return;
   float a = x[idx], b = xh[idx];
   rows[idx] = a;
@@ -759,6 +765,26 @@ __global__ void __launch_bounds__(frame::WT) k_critic_front_wgrad(front::CwArgs 
   front::critic_front_wgrad_block(run, cw_lds, a, pl, (int)blockIdx.x);
 }
 
+// one pass segment of the two thin conv layers, one workgroup per row (disc_frame.h)
+template <int MODE>
+__global__ void __launch_bounds__(frame::NT) k_critic_front(front::FrontArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float cf_lds[];
+  tuned::DevRunner<false> run(nullptr, 0);
+  const front::FrontArgs& la = tuned::args_to_lds<front::FrontArgs>(cf_lds);   // (`a` itself is never addressed)
+  front::critic_front_prologue(run, cf_lds, la);
+  for (int r = blockIdx.x; r < la.nrows; r += gridDim.x) front::critic_front_row<MODE>(run, cf_lds, la, r);
+}
+template <int MODE>
+static void launch_front(const front::FrontArgs& a, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_critic_front<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              frame::L_TOTAL * 4);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k_critic_front<MODE>, dim3((unsigned)std::min(a.nrows, 1024)), dim3(frame::NT), frame::L_TOTAL * 4, s, a);
+}
+
 struct DiscL {
   int cin, hin, cout, hout, k, s, pad;
   int64_t w_off, b_off, beta_off, gamma_off;
@@ -828,6 +854,7 @@ struct DWs {  // resolved workspace of one call; B rows in the forward tensors, 
   float* ain[VAENPVC_MAX_LAYERS];
   float* mmpart;
   float* dWd;
+  float* w1t;   // layer 1's kernel transposed (disc_frame.h), when the front kernels serve the model
 };
 int64_t al(int64_t n) { return (n + 63) & ~int64_t(63); }
 
@@ -843,6 +870,7 @@ int64_t carve(const vaenpvc_disc& m, int64_t F, bool critic, float* base, DWs* w
   DWs t;
   memset(&t, 0, sizeof t);
   t.rows = take(B * m.H);
+  if (m.front) t.w1t = take(7 * 16 * 32);
   for (int i = 0; i < m.n_layers; ++i) {
     t.u[i] = take(B * m.l[i].n());
     t.st[i] = take(B * 2);
@@ -930,12 +958,35 @@ void expand_dense(const vaenpvc_disc& m, const float* P, const DWs& w, hipStream
       hipLaunchKernelGGL(k_expand_dense, grid1((int64_t)m.l[i].kin() * m.l[i].n()), dim3(256), 0, s, P + m.l[i].w_off, w.Wd[i], mk(m.l[i]));
 }
 
+front::FrontArgs front_args(const vaenpvc_disc& m, const float* P, const DWs& w, int64_t rows0, int64_t nrows) {
+  front::FrontArgs a;
+  memset(&a, 0, sizeof a);
+  const DiscL &l0 = m.l[0], &l1 = m.l[1];
+  a.P = P;
+  a.w0 = (int)l0.w_off; a.b0 = (int)l0.b_off; a.g0 = (int)l0.gamma_off; a.bt0 = (int)l0.beta_off;
+  a.w1 = (int)l1.w_off; a.b1 = (int)l1.b_off; a.g1 = (int)l1.gamma_off; a.bt1 = (int)l1.beta_off;
+  a.w1t = w.w1t;
+  a.rows0 = (int)rows0;
+  a.nrows = (int)nrows;
+  a.rows = w.rows;
+  a.u0 = w.u[0]; a.st0 = w.st[0]; a.u1 = w.u[1]; a.st1 = w.st[1];
+  a.ain2 = w.ain[2];
+  a.abar1 = w.abar[1]; a.ubar1 = w.ubar[1]; a.abar0 = w.abar[0]; a.ubar0 = w.ubar[0];
+  a.g = w.g; a.gt = w.gt; a.gp_f = w.gp_f;
+  a.at0 = w.at[0]; a.udir0 = w.udir[0]; a.pn0 = w.pn[0]; a.at1 = w.at[1]; a.udir1 = w.udir[1]; a.pn1 = w.pn[1];
+  a.da1 = w.da[1]; a.du1 = w.du[1]; a.da0 = w.da[0]; a.du0 = w.du[0];
+  return a;
+}
+
 void forward(const vaenpvc_disc& m, const float* P, int64_t B, const DWs& w, hipStream_t s) {
+  if (m.front) launch_front<front::FP_FWD>(front_args(m, P, w, 0, B), s);   // layers 0-1: outputs, statistics, the 115-tap layer's input
   for (int i = 0; i < m.n_layers; ++i) {
     const DiscL& l = m.l[i];
     Act ai = i == 0 ? kNoAct : act_of(m.l[i - 1], P, w.st[i - 1]);
+    if (m.front && i < 2) continue;
     if (l.dense) {  // statistics + activated copy of the input, then one GEMM
       const DiscL& pl = m.l[i - 1];
+      if (!(m.front && i == 2))
       hipLaunchKernelGGL(k_act_stats, dim3((unsigned)B), dim3(256), 0, s, w.u[i - 1], P + pl.gamma_off, P + pl.beta_off, w.st[i - 1],
                          w.ain[i], pl.cout, pl.hout);
       dense_fwd(w.ain[i], w.Wd[i], P + l.b_off, w.u[i], B, l, w.mmpart, s);
@@ -950,7 +1001,8 @@ void forward(const vaenpvc_disc& m, const float* P, int64_t B, const DWs& w, hip
 }
 
 // pass 2: g = d(sum_f d_f)/d(rows) for R rows starting at row r0; keeps abar_l / ubar_l
-void input_gradient(const vaenpvc_disc& m, const float* P, int64_t r0, int64_t R, const DWs& w, hipStream_t s) {
+// (coef != 0: the front kernel also leaves the penalty and its adjoint gt -- the work of k_gp)
+void input_gradient(const vaenpvc_disc& m, const float* P, int64_t r0, int64_t R, const DWs& w, hipStream_t s, float coef = 0.f) {
   const int L = m.n_layers;
   {
     const int nb_d = (int)((R * m.flat + 255) / 256);
@@ -959,6 +1011,12 @@ void input_gradient(const vaenpvc_disc& m, const float* P, int64_t r0, int64_t R
   }
   for (int i = L - 1; i >= 0; --i) {
     const DiscL& l = m.l[i];
+    if (m.front && i == 1) {   // layers 1 and 0 (+ the penalty): one launch
+      front::FrontArgs fa = front_args(m, P, w, r0, R);
+      fa.coef = coef;
+      launch_front<front::FP_IGRAD>(fa, s);
+      break;
+    }
     hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)R), dim3(256), 0, s, w.abar[i], w.u[i] + r0 * l.n(), w.st[i] + 2 * r0,
                        P + l.gamma_off, P + l.beta_off, (const float*)nullptr, (int64_t)0, w.ubar[i], l.cout, l.hout);
     if (l.dense) dense_dgrad(w.ubar[i], w.Wd[i], w.abar[i - 1], R, l, w.mmpart, s);
@@ -1092,7 +1150,8 @@ int vaenpvc_disc_fwd(const vaenpvc_disc* d, const float* d_dparams, const float*
   hipStream_t s = (hipStream_t)stream;
   DWs w;
   carve(*d, F, false, (float*)d_ws, &w);
-  hipLaunchKernelGGL(k_rows, grid1(F * d->H), dim3(256), 0, s, d_x, d_xh, (const float*)nullptr, w.rows, F, d->H);
+  hipLaunchKernelGGL(k_rows, grid1(std::max<int64_t>(F * d->H, d->front ? 3584 : 0)), dim3(256), 0, s, d_x, d_xh, (const float*)nullptr, w.rows,
+                     F, d->H, d->front ? d_dparams + d->l[1].w_off : nullptr, w.w1t);
   expand_dense(*d, d_dparams, w, s);
   forward(*d, d_dparams, 2 * F, w, s);
   if (d_out) (void)hipMemcpyAsync(d_out, w.d, 2 * F * sizeof(float), hipMemcpyDeviceToDevice, s);
@@ -1122,15 +1181,17 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
   ChanSums csums;   // per-channel reductions of both passes, one launch at the end
   csums.count = 0;
   // pass 1
-  hipLaunchKernelGGL(k_rows, grid1(F * m.H), dim3(256), 0, s, d_x, d_xh, d_t, w.rows, F, m.H);
+  hipLaunchKernelGGL(k_rows, grid1(std::max<int64_t>(F * m.H, m.front ? 3584 : 0)), dim3(256), 0, s, d_x, d_xh, d_t, w.rows, F, m.H,
+                     m.front ? P + m.l[1].w_off : nullptr, w.w1t);
   expand_dense(m, P, w, s);
   forward(m, P, B, w, s);
   // pass 2 (rows xi) and the penalty
-  input_gradient(m, P, 2 * F, F, w, s);
-  hipLaunchKernelGGL(k_gp, dim3((unsigned)F), dim3(256), 0, s, w.g, w.gt, w.gp_f, m.H, 2.0f * lambda / (float)F);
+  input_gradient(m, P, 2 * F, F, w, s, m.front ? 2.0f * lambda / (float)F : 0.f);
+  if (!m.front) hipLaunchKernelGGL(k_gp, dim3((unsigned)F), dim3(256), 0, s, w.g, w.gt, w.gp_f, m.H, 2.0f * lambda / (float)F);
   hipLaunchKernelGGL(k_losses, dim3(1), dim3(256), 0, s, w.d, w.gp_f, F, d_loss2);
   // pass 3, bottom-up over rows xi
-  for (int i = 0; i < L; ++i) {
+  if (m.front) launch_front<front::FP_ADJ>(front_args(m, P, w, 2 * F, F), s);   // layers 0-1 of pass 3: q, at, udir, pn
+  for (int i = m.front ? 2 : 0; i < L; ++i) {
     const DiscL& l = m.l[i];
     const float* src = i == 0 ? w.gt : w.at[i - 1];  // adjoint of abar_{i-1} (of g for the first layer)
     if (l.dense) {
@@ -1157,7 +1218,15 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
   pgs.count = 0;
   for (int i = L - 1; i >= 0; --i) {
     const DiscL& l = m.l[i];
-    const bool fr = m.front && i < 2;   // parameter gradients of this layer: the job-list launch below
+    if (m.front && i == 1) {   // layers 1 and 0 of pass 4: LayerNorm backward (+ udir on the rows xi), input gradient
+      front::FrontArgs fa = front_args(m, P, w, 0, B);
+      fa.add1 = w.udir[1];
+      fa.add0 = w.udir[0];
+      fa.add_row0 = (int)(2 * F);
+      launch_front<front::FP_BWD>(fa, s);
+      break;   // (their parameter gradients: the job-list launch below)
+    }
+    const bool fr = false;
     if (!fr)
     pgs.e[pgs.count++] = ParamGrad{w.da[i], w.u[i], w.st[i], P + l.gamma_off, P + l.beta_off, Gd + l.gamma_off, Gd + l.beta_off, B,
                                    l.cout, l.hout};
@@ -1208,7 +1277,8 @@ int vaenpvc_disc_generator_target(const vaenpvc_disc* d, const float* d_dparams,
   hipStream_t s = (hipStream_t)stream;
   DWs w;
   carve(*d, F, false, (float*)d_ws, &w);
-  hipLaunchKernelGGL(k_rows, grid1(F * d->H), dim3(256), 0, s, d_x, d_xh, (const float*)nullptr, w.rows, F, d->H);
+  hipLaunchKernelGGL(k_rows, grid1(std::max<int64_t>(F * d->H, d->front ? 3584 : 0)), dim3(256), 0, s, d_x, d_xh, (const float*)nullptr, w.rows,
+                     F, d->H, d->front ? d_dparams + d->l[1].w_off : nullptr, w.w1t);
   expand_dense(*d, d_dparams, w, s);
   forward(*d, d_dparams, 2 * F, w, s);
   input_gradient(*d, d_dparams, F, F, w, s);  // rows xh

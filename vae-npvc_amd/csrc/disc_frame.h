@@ -4,7 +4,11 @@
 // gradient of these layers in one job-list launch).  At the branch's 16-frame batches a critic step is its launch count
 // (DESIGN.md section 9); the kernels below replace, per step,
 //   k_critic_front_wgrad : 4 x conv weight gradient (passes 3 and 4), and the layers' entries of the LayerNorm-parameter,
-//                          channel-sum and partial-sum launches.
+//                          channel-sum and partial-sum launches;
+//   k_critic_front<FWD>  : pass 1 of both layers (2 x conv forward + statistics / activation pass);
+//   k_critic_front<IGRAD>: pass 2 below the 115-tap layer (2 x LayerNorm backward, 2 x conv input gradient, the penalty);
+//   k_critic_front<ADJ>  : pass 3 of both layers (2 x conv forward of the adjoint, 2 x adjoint of the LayerNorm backward);
+//   k_critic_front<BWD>  : pass 4 below the 115-tap layer (2 x LayerNorm backward, conv input gradient).
 // The 115-tap layer stays a dense layer on the matrix cores (disc.hip): as a per-row GEMV it would stream its 8.9 MB of
 // expanded weights once per row.
 // Reference: trainer/vae.py:117-145 (WGAN-GP critic update), util/layers.py:47-66 (the conv block); DESIGN.md section 9 for
@@ -144,6 +148,298 @@ inline CwPlan make_cwplan(int F, int B) {
   add(C1, fcs(B, 8, 8));
   p.start[n] = blk;
   return p;
+}
+
+// ------------------------------------------------------------------------------------------------ per-row passes
+// One 1024-thread workgroup carries one row through a pass segment; LDS map and tiles of gfx950_frame.h (E0F / E1F: the
+// two forward convs, E1G: layer 1's input gradient).  Small per-channel data sits in LDS for the whole launch:
+//   ch[0,48) conv biases | [48,96) LayerNorm scales | [96,144) offsets (layer 0: 16, layer 1: 32) | [144,256) layer 0's kernel
+constexpr int CH_B = 0, CH_G = 48, CH_BT = 96, CH_W0 = 144;
+enum { FP_FWD = 0, FP_IGRAD = 1, FP_ADJ = 2, FP_BWD = 3 };
+struct FrontArgs {
+  const float* P;         // flat critic parameters
+  int w0, b0, g0, bt0, w1, b1, g1, bt1;   // offsets of the two layers' tensors
+  const float* w1t;       // layer 1's kernel as [t][o][c] (written by k_rows)
+  int rows0, nrows;       // the launch covers rows [rows0, rows0 + nrows) of the B-row tensors
+  // B-row tensors
+  const float* rows;      // [B][513]
+  float* u0;              // [B][16][171] pre-LN outputs (written by FWD, read by the others)
+  float* st0;
+  float* u1;
+  float* st1;
+  float* ain2;            // [B][1824] activated output of layer 1 = input of the 115-tap layer's GEMM
+  // pass 2 / 3 tensors, row r of the launch = row r of these
+  float* abar1;           // IGRAD: in (from the 115-tap layer's input gradient); ADJ: in
+  float* ubar1;           // IGRAD: out
+  float* abar0;           // IGRAD: out; ADJ: in
+  float* ubar0;           // IGRAD: out
+  float* g;               // IGRAD: out [.][513]
+  float* gt;              // IGRAD: out (coef != 0); ADJ: in
+  float* gp_f;            // IGRAD: out
+  float coef;             // 2 lambda / F, or 0: no penalty (generator step)
+  float *at0, *udir0, *pn0, *at1, *udir1, *pn1;     // ADJ: out
+  // pass 4 tensors (B rows)
+  const float* da1;       // BWD: in (from the 115-tap layer's input gradient)
+  float *du1, *da0, *du0; // BWD: out
+  const float *add1, *add0;   // BWD: the injected adjoints udir1 / udir0 (row r - add_row0 of them), rows >= add_row0 only
+  int add_row0;
+};
+static_assert(sizeof(FrontArgs) <= ARGS_FLOATS * 4, "argument block");
+
+// LayerNorm + lrelu backward of the row in place: u in `bx`, upstream in `by` -> gradient at the pre-LN tensor in `by`
+// (+ an injected term).  red[R_ST..] = {mean, rstd}.
+template <class R, int C, int H, class AP>
+FR_DEV void ln_bwd_row(R& run, const float* bx, float* by, float* red, const float* gamma, const float* beta, AP add) {
+  constexpr int N = C * H;
+  run.reduce2(red + R_S1, red + R_S2, [&](int tid, float& s1, float& s2) {
+    const float mean = red[R_ST], rstd = red[R_ST + 1];
+    for (int i = tid; i < N; i += NT) {
+      const int c = i / H;
+      float xh;
+      const float dx = ln_dn(bx[i], by[i], mean, rstd, gamma[c], beta[c], xh) * gamma[c];
+      s1 += dx;
+      s2 += dx * xh;
+    }
+  });
+  run.phase([&](int tid) {
+    const float mean = red[R_ST], rstd = red[R_ST + 1];
+    const float m1 = sum16(red + R_S1) * (1.0f / N), m2 = sum16(red + R_S2) * (1.0f / N);
+    for (int i = tid; i < N; i += NT) {
+      const int c = i / H;
+      float xh;
+      const float dx = ln_dn(bx[i], by[i], mean, rstd, gamma[c], beta[c], xh) * gamma[c];
+      float r = rstd * (dx - m1 - xh * m2);
+      if (add) r += add[i];
+      by[i] = r;
+    }
+  });
+}
+
+// Adjoint of ln_bwd_row (disc.hip: k_ln_bwd_bwd has the algebra): q in `by`, the upstream of pass 2 (abar) in `dy`, u in
+// `bx`.  Leaves at (adjoint of abar) in `by` and stores at / udir / pn.
+template <class R, int C, int H, class GP>
+FR_DEV void ln_bwd_bwd_row(R& run, const float* bx, float* by, const float* dy, float* red, const float* gamma, const float* beta,
+                           GP at_g, GP udir_g, GP pn_g) {
+  constexpr int N = C * H;
+  constexpr float IN = 1.0f / N;
+  auto elem = [&](int i, float mean, float rstd, float& xh, float& sl, float& p) {
+    const int c = i / H;
+    xh = (bx[i] - mean) * rstd;
+    const float nn = xh * gamma[c] + beta[c];
+    sl = nn >= 0.f ? 1.0f : LEAK_F;
+    p = dy[i] * sl * gamma[c];
+  };
+  run.reduce2(red + R_S1, red + R_S2, [&](int tid, float& sp, float& spx) {
+    const float mean = red[R_ST], rstd = red[R_ST + 1];
+    for (int i = tid; i < N; i += NT) {
+      float xh, sl, p;
+      elem(i, mean, rstd, xh, sl, p);
+      sp += p;
+      spx += p * xh;
+    }
+  });
+  run.reduce2(red + R_S3, red + R_S4, [&](int tid, float& sq, float& sqx) {
+    const float mean = red[R_ST], rstd = red[R_ST + 1];
+    for (int i = tid; i < N; i += NT) {
+      const float xh = (bx[i] - mean) * rstd;
+      sq += by[i];
+      sqx += by[i] * xh;
+    }
+  });
+  // (the four means are read from red[R_S1..R_S4]; the next pair of sums goes to red[80..112))
+  run.reduce2(red + 80, red + 96, [&](int tid, float& sx, float& ss) {
+    const float mean = red[R_ST], rstd = red[R_ST + 1];
+    const float sp = sum16(red + R_S1) * IN, spx = sum16(red + R_S2) * IN, sqx = sum16(red + R_S4) * IN;
+    for (int i = tid; i < N; i += NT) {
+      float xh, sl, p;
+      elem(i, mean, rstd, xh, sl, p);
+      const float qq = by[i];
+      const float ub = rstd * (p - sp - xh * spx);
+      const float xt = -rstd * (spx * qq + sqx * p);
+      sx += xt;
+      ss += qq * ub + xt * xh;
+    }
+  });
+  run.phase([&](int tid) {
+    const float mean = red[R_ST], rstd = red[R_ST + 1];
+    const float spx = sum16(red + R_S2) * IN, sq = sum16(red + R_S3) * IN, sqx = sum16(red + R_S4) * IN;
+    const float sx = sum16(red + 80) * IN, ss = sum16(red + 96) * IN;
+    for (int i = tid; i < N; i += NT) {
+      const int c = i / H;
+      float xh, sl, p;
+      elem(i, mean, rstd, xh, sl, p);
+      const float qq = by[i];
+      const float xt = -rstd * (spx * qq + sqx * p);
+      const float pt = rstd * (qq - sq - xh * sqx);
+      const float atv = pt * gamma[c] * sl;
+      by[i] = atv;
+      at_g[i] = atv;
+      udir_g[i] = rstd * (xt - sx - xh * ss);
+      pn_g[i] = pt * dy[i] * sl;
+    }
+  });
+}
+
+template <int MODE, class R>
+FR_DEV void critic_front_row(R& run, float* lds, const FrontArgs& a, int r) {
+  float* bx = lds + L_BUFX;
+  float* by = lds + L_BUFY;
+  float* part = lds + L_PART;
+  float* red = lds + L_RED;
+  const float* ch = lds + L_CH;
+  auto P = fr_g(a.P);
+  const size_t row = (size_t)(a.rows0 + r);       // row of the B-row tensors
+  const size_t rr = (size_t)r;                     // row of the per-range tensors
+  if constexpr (MODE == FP_FWD) {
+    auto xf = fr_g(a.rows) + row * HIN;
+    run.phase([&](int tid) { halo_copy<1, HIN, E0F::HP, E0F::PAD>(tid, xf, bx); });
+    run.phase([&](int tid) { sconv_part<E0F>(tid, bx, P + FR_UNIFORM(a.w0), part); });
+    reduce_sum<R, E0F::KS, E0F::NOUT, E0F::HO>(run, part, ch + CH_B, by, red);
+    var_sum<R, E0F::NOUT>(run, by, red, fr_g(a.u0) + row * N0);
+    run.phase([&](int tid) {
+      ln_apply<C0, H0, E1F::HP, E1F::PAD>(tid, by, red, ch + CH_G, ch + CH_BT, bx, fr_g(a.st0) + 2 * row, (FR_G(float))nullptr);
+    });
+    run.phase([&](int tid) { sconv_part<E1F>(tid, bx, P + FR_UNIFORM(a.w1), part); });
+    reduce_sum<R, E1F::KS, E1F::NOUT, E1F::HO>(run, part, ch + CH_B + C0, by, red);
+    var_sum<R, E1F::NOUT>(run, by, red, fr_g(a.u1) + row * N1);
+    run.phase([&](int tid) {
+      ln_apply<C1, H1, H1, 0>(tid, by, red, ch + CH_G + C0, ch + CH_BT + C0, bx, fr_g(a.st1) + 2 * row, fr_g(a.ain2) + row * N1);
+    });
+  } else if constexpr (MODE == FP_IGRAD || MODE == FP_BWD) {
+    constexpr bool IG = MODE == FP_IGRAD;
+    // ---- layer 1: LayerNorm backward of the upstream handed down by the 115-tap layer
+    auto up1 = IG ? fr_g((const float*)a.abar1) + rr * N1 : fr_g(a.da1) + row * N1;
+    auto u1r = fr_g((const float*)a.u1) + row * N1;
+    auto st1r = fr_g((const float*)a.st1) + 2 * row;
+    const bool inj = !IG && a.add1 && (int)row >= a.add_row0;   // uniform
+    run.phase([&](int tid) {
+      for (int i = tid; i < N1; i += NT) {
+        by[i] = up1[i];
+        bx[i] = u1r[i];
+      }
+      if (tid == 0) {
+        red[R_ST] = st1r[0];
+        red[R_ST + 1] = st1r[1];
+      }
+    });
+    {
+      auto ad = inj ? fr_g(a.add1) + (row - a.add_row0) * N1 : (FR_G(const float))nullptr;
+      ln_bwd_row<R, C1, H1>(run, bx, by, red, ch + CH_G + C0, ch + CH_BT + C0, ad);
+    }
+    run.phase([&](int tid) {
+      flush(tid, by, IG ? fr_g(a.ubar1) + rr * N1 : fr_g(a.du1) + row * N1, N1);
+      halo_copy<C1, H1, E1G::HP, E1G::HL>(tid, by, bx);
+    });
+    // ---- layer 1's input gradient, then layer 0's LayerNorm backward
+    run.phase([&](int tid) { tconv_part<E1G>(tid, bx, fr_g(a.w1t), part); });
+    run.phase([&](int tid) {
+      reduce_load<E1G::KS, E1G::NOUT>(tid, part, by, fr_g((const float*)a.u0) + row * N0, bx, fr_g((const float*)a.st0) + 2 * row, red);
+    });
+    {
+      auto ad = (inj && a.add0) ? fr_g(a.add0) + (row - a.add_row0) * N0 : (FR_G(const float))nullptr;
+      auto mid = IG ? fr_g(a.abar0) + rr * N0 : fr_g(a.da0) + row * N0;      // gradient at layer 0's activated output
+      run.phase([&](int tid) { flush(tid, by, mid, N0); });
+      ln_bwd_row<R, C0, H0>(run, bx, by, red, ch + CH_G, ch + CH_BT, ad);
+    }
+    if constexpr (!IG) {
+      run.phase([&](int tid) { flush(tid, by, fr_g(a.du0) + row * N0, N0); });
+    } else {
+      // ---- layer 0's input gradient: g[i] = sum_o sum_{t = (i + 2) mod 3, +3, +6} W0[t][o] ubar0[o][(i + 2 - t) / 3], then the penalty
+      run.reduce(red + R_S1, [&](int tid) {
+        flush(tid, by, fr_g(a.ubar0) + rr * N0, N0);
+        float gi = 0.f;
+        if (tid < HIN) {
+          const int t0 = (tid + 2) % 3;
+          for (int t = t0; t < 7; t += 3) {
+            const int j = (tid + 2 - t) / 3;
+            if (tid + 2 - t < 0 || j >= H0) continue;
+            for (int o = 0; o < C0; ++o) gi += ch[CH_W0 + t * C0 + o] * by[o * H0 + j];
+          }
+          bx[tid] = gi;
+          a.g[rr * HIN + tid] = gi;
+        }
+        return gi * gi;
+      });
+      run.phase([&](int tid) {
+        if (a.coef == 0.f) return;       // uniform: no penalty (generator step)
+        const float nrm = sqrtf(sum16(red + R_S1));
+        const float k = a.coef * (nrm - 1.0f) / nrm;
+        if (tid < HIN) a.gt[rr * HIN + tid] = k * bx[tid];
+        if (tid == 0) a.gp_f[rr] = (nrm - 1.0f) * (nrm - 1.0f);
+      });
+    }
+  } else {   // FP_ADJ
+    // ---- layer 0: q0 = conv0(gt) (no bias), adjoint of its LayerNorm backward
+    auto gtr = fr_g((const float*)a.gt) + rr * HIN;
+    run.phase([&](int tid) { halo_copy<1, HIN, E0F::HP, E0F::PAD>(tid, gtr, bx); });
+    run.phase([&](int tid) { sconv_part<E0F>(tid, bx, P + FR_UNIFORM(a.w0), part); });
+    float* dy = part + E1F::KS * E1F::NOUT;      // the pass-2 upstream of the layer, behind the largest partial-sum area used here
+    static_assert(E1F::KS * E1F::NOUT + N0 <= PART && E0F::KS == 1, "LDS areas of the adjoint pass");
+    {
+      auto u0r = fr_g((const float*)a.u0) + row * N0;
+      auto ab = fr_g((const float*)a.abar0) + rr * N0;
+      auto st0r = fr_g((const float*)a.st0) + 2 * row;
+      run.phase([&](int tid) {
+        for (int i = tid; i < N0; i += NT) {
+          by[i] = part[i];      // (one K slice: the partial sums are the result)
+          bx[i] = u0r[i];
+        }
+        if (tid == 0) {
+          red[R_ST] = st0r[0];
+          red[R_ST + 1] = st0r[1];
+        }
+      });
+      run.phase([&](int tid) {
+        for (int i = tid; i < N0; i += NT) dy[i] = ab[i];
+      });
+    }
+    ln_bwd_bwd_row<R, C0, H0>(run, bx, by, dy, red, ch + CH_G, ch + CH_BT, fr_g(a.at0) + rr * N0, fr_g(a.udir0) + rr * N0,
+                              fr_g(a.pn0) + rr * N0);
+    // ---- layer 1: q1 = conv1(at0), adjoint of its LayerNorm backward
+    run.phase([&](int tid) { halo_copy<C0, H0, E1F::HP, E1F::PAD>(tid, by, bx); });
+    run.phase([&](int tid) { sconv_part<E1F>(tid, bx, P + FR_UNIFORM(a.w1), part); });
+    {
+      auto u1r = fr_g((const float*)a.u1) + row * N1;
+      auto ab = fr_g((const float*)a.abar1) + rr * N1;
+      auto st1r = fr_g((const float*)a.st1) + 2 * row;
+      run.phase([&](int tid) {
+        for (int i = tid; i < N1; i += NT) {
+          float q = 0.f;
+          FR_UNROLL
+          for (int k = 0; k < E1F::KS; ++k) q += part[k * E1F::NOUT + i];
+          by[i] = q;
+          bx[i] = u1r[i];
+          dy[i] = ab[i];
+        }
+        if (tid == 0) {
+          red[R_ST] = st1r[0];
+          red[R_ST + 1] = st1r[1];
+        }
+      });
+    }
+    ln_bwd_bwd_row<R, C1, H1>(run, bx, by, dy, red, ch + CH_G + C0, ch + CH_BT + C0, fr_g(a.at1) + rr * N1, fr_g(a.udir1) + rr * N1,
+                              fr_g(a.pn1) + rr * N1);
+  }
+}
+
+// per-channel vectors and layer 0's kernel into LDS, once per workgroup
+template <class R>
+FR_DEV void critic_front_prologue(R& run, float* lds, const FrontArgs& a) {
+  float* ch = lds + L_CH;
+  auto P = fr_g(a.P);
+  run.phase([&](int tid) {
+    if (tid < C0) {
+      ch[CH_B + tid] = P[a.b0 + tid];
+      ch[CH_G + tid] = P[a.g0 + tid];
+      ch[CH_BT + tid] = P[a.bt0 + tid];
+    } else if (tid < C0 + C1) {
+      ch[CH_B + tid] = P[a.b1 + tid - C0];
+      ch[CH_G + tid] = P[a.g1 + tid - C0];
+      ch[CH_BT + tid] = P[a.bt1 + tid - C0];
+    } else if (tid >= 64 && tid < 64 + 7 * C0) {
+      ch[CH_W0 + tid - 64] = P[a.w0 + tid - 64];
+    }
+  });
 }
 
 }  // namespace front
