@@ -203,6 +203,37 @@ def test_large_batch_dense_layer_agrees_with_the_conv_kernels(monkeypatch):
     assert float((tgt1 - tgt2).abs().max()) <= 1e-4 * float((tgt2 - x).abs().max())
 
 
+@pytest.mark.parametrize('F', [5, 16, 300])
+def test_front_kernels_agree_with_the_per_layer_kernels(monkeypatch, F):
+    """The two thin conv layers on the per-row kernels + job-list weight gradient of csrc/disc_frame.h (default for the
+    VCC2016 layer table) against the same layers on the per-layer kernels (VAENPVC_DISC_FRONT=0, read when the critic is
+    created): critic step (losses, every gradient tensor) and generator target, up to fp32 summation order.  F = 300:
+    more rows (900) than workgroups, frame chunks in the job list."""
+    from hipvae.critic import Critic
+    arch = vawgan_arch()
+    cr, _ = make_critic(arch, 9)
+    monkeypatch.setenv('VAENPVC_DISC_FRONT', '0')
+    c2 = Critic(arch)
+    monkeypatch.delenv('VAENPVC_DISC_FRONT')
+    c2.params.copy_(cr.params)
+    g = torch.Generator().manual_seed(F)
+    dev = cr.device
+    x = torch.tanh(torch.randn(F, 513, generator=g)).to(dev)
+    xh = torch.tanh(0.7 * torch.randn(F, 513, generator=g) + 0.2).to(dev)
+    t = torch.rand(F, generator=g).to(dev)
+    g1, g2 = (torch.empty(cr.n_params, device=dev) for _ in range(2))
+    l_a = cr.critic_fwd_bwd(x, xh, t, 10.0, g1).clone()
+    l_b = c2.critic_fwd_bwd(x, xh, t, 10.0, g2).clone()
+    assert torch.allclose(l_a, l_b, rtol=1e-5, atol=1e-6)
+    for k, (off, shp) in cr.layout.items():
+        n = int(np.prod(shp))
+        a, b = g1[off:off + n], g2[off:off + n]
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-6), k
+    tgt1, _ = cr.generator_target(x, xh, 50.0)
+    tgt2, _ = c2.generator_target(x, xh, 50.0)
+    assert float((tgt1 - tgt2).abs().max()) <= 1e-5 * float((tgt2 - x).abs().max())
+
+
 def test_critic_step_is_deterministic_and_linear_in_lambda():
     """Repeatable (see assert_repeatable), and grad(lambda) is affine in lambda: g(20) - g(10) == g(10) - g(0)."""
     arch = vawgan_arch()

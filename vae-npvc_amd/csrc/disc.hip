@@ -1001,8 +1001,9 @@ void forward(const vaenpvc_disc& m, const float* P, int64_t B, const DWs& w, hip
 }
 
 // pass 2: g = d(sum_f d_f)/d(rows) for R rows starting at row r0; keeps abar_l / ubar_l
-// (coef != 0: the front kernel also leaves the penalty and its adjoint gt -- the work of k_gp)
-void input_gradient(const vaenpvc_disc& m, const float* P, int64_t r0, int64_t R, const DWs& w, hipStream_t s, float coef = 0.f) {
+// (penalty: the front kernel also leaves the penalty and its adjoint gt = coef (|g| - 1) g / |g| -- the work of k_gp)
+void input_gradient(const vaenpvc_disc& m, const float* P, int64_t r0, int64_t R, const DWs& w, hipStream_t s, bool penalty = false,
+                    float coef = 0.f) {
   const int L = m.n_layers;
   {
     const int nb_d = (int)((R * m.flat + 255) / 256);
@@ -1014,6 +1015,7 @@ void input_gradient(const vaenpvc_disc& m, const float* P, int64_t r0, int64_t R
     if (m.front && i == 1) {   // layers 1 and 0 (+ the penalty): one launch
       front::FrontArgs fa = front_args(m, P, w, r0, R);
       fa.coef = coef;
+      fa.penalty = penalty ? 1 : 0;
       launch_front<front::FP_IGRAD>(fa, s);
       break;
     }
@@ -1186,7 +1188,7 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
   expand_dense(m, P, w, s);
   forward(m, P, B, w, s);
   // pass 2 (rows xi) and the penalty
-  input_gradient(m, P, 2 * F, F, w, s, m.front ? 2.0f * lambda / (float)F : 0.f);
+  input_gradient(m, P, 2 * F, F, w, s, m.front, 2.0f * lambda / (float)F);
   if (!m.front) hipLaunchKernelGGL(k_gp, dim3((unsigned)F), dim3(256), 0, s, w.g, w.gt, w.gp_f, m.H, 2.0f * lambda / (float)F);
   hipLaunchKernelGGL(k_losses, dim3(1), dim3(256), 0, s, w.d, w.gp_f, F, d_loss2);
   // pass 3, bottom-up over rows xi

@@ -176,7 +176,8 @@ struct FrontArgs {
   float* g;               // IGRAD: out [.][513]
   float* gt;              // IGRAD: out (coef != 0); ADJ: in
   float* gp_f;            // IGRAD: out
-  float coef;             // 2 lambda / F, or 0: no penalty (generator step)
+  float coef;             // 2 lambda / F
+  int penalty;            // IGRAD: 1 = also leave gt and gp_f (critic step), 0 = only g (generator step)
   float *at0, *udir0, *pn0, *at1, *udir1, *pn1;     // ADJ: out
   // pass 4 tensors (B rows)
   const float* da1;       // BWD: in (from the 115-tap layer's input gradient)
@@ -361,7 +362,7 @@ FR_DEV void critic_front_row(R& run, float* lds, const FrontArgs& a, int r) {
         return gi * gi;
       });
       run.phase([&](int tid) {
-        if (a.coef == 0.f) return;       // uniform: no penalty (generator step)
+        if (!a.penalty) return;          // uniform: generator step
         const float nrm = sqrtf(sum16(red + R_S1));
         const float k = a.coef * (nrm - 1.0f) / nrm;
         if (tid < HIN) a.gt[rr * HIN + tid] = k * bx[tid];
