@@ -776,11 +776,14 @@ __global__ void __launch_bounds__(frame::NT) k_critic_front(front::FrontArgs a) 
 }
 template <int MODE>
 static void launch_front(const front::FrontArgs& a, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
+  // (the attribute is a property of the function ON A DEVICE: one flag per device, the critic has no context object to keep it in)
+  static bool attr[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_critic_front<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               frame::L_TOTAL * 4);
-    attr = true;
+    if (dev >= 0 && dev < 64) attr[dev] = true;
   }
   hipLaunchKernelGGL(k_critic_front<MODE>, dim3((unsigned)std::min(a.nrows, 1024)), dim3(frame::NT), frame::L_TOTAL * 4, s, a);
 }
