@@ -96,8 +96,9 @@ static inline dim3 grid1(int64_t n, int bs = 256) { return dim3((unsigned)((n + 
 // (w1t != nullptr: the launch also leaves layer 1's kernel as [t][o][c] for the input-gradient tile of disc_frame.h)
 __global__ void k_rows(const float* __restrict__ x, const float* __restrict__ xh, const float* __restrict__ t,
                        float* __restrict__ rows, int64_t F, int H, const float* __restrict__ W1 = nullptr,
-                       float* __restrict__ w1t = nullptr) {
+                       float* __restrict__ w1t = nullptr, float* __restrict__ zero = nullptr, int64_t nzero = 0) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < nzero) zero[idx] = 0.f;      // (the critic step's gradient buffer: no separate fill launch)
   if (w1t && idx < 7 * 16 * 32) {
     const int c = (int)idx % 16, o = ((int)idx / 16) % 32, tt = (int)idx / 512;
     w1t[idx] = W1[(tt * 16 + c) * 32 + o];
@@ -890,7 +891,7 @@ int64_t carve(const vaenpvc_disc& m, int64_t F, bool critic, float* base, DWs* w
       if (m.l[i].dense) {
         const int64_t K = m.l[i].kin(), N = m.l[i].n();
         t.Wd[i] = take(K * N);
-        t.ain[i] = take(B * K);
+        t.ain[i] = take((B + (critic ? F : 0)) * K);   // (critic: + the F rows of pass 3's operand, see the aliases below)
         mmax = std::max(mmax, (int64_t)MM_MAX_SPLIT * B * std::max(K, N));
         wmax = std::max(wmax, K * N);
       }
@@ -907,7 +908,14 @@ int64_t carve(const vaenpvc_disc& m, int64_t F, bool critic, float* base, DWs* w
     t.gt = take(F * m.H);
     t.gp_f = take(F);
     for (int i = 0; i < m.n_layers; ++i) t.da[i] = take(B * m.l[i].n());
-    for (int i = 0; i < m.n_layers; ++i) t.du[i] = take(B * m.l[i].n());
+    for (int i = 0; i < m.n_layers; ++i) t.du[i] = take((B + (m.l[i].dense ? F : 0)) * m.l[i].n());
+    // A dense-like layer's weight gradient is ONE GEMM over the rows of pass 4 and pass 3 stacked: the operands of pass 3
+    // (adjoint of the layer's input, ubar of the layer) live directly behind those of pass 4 (activated input, du)
+    for (int i = 1; i < m.n_layers; ++i)
+      if (m.l[i].dense) {
+        t.at[i - 1] = t.ain[i] + B * m.l[i].kin();
+        t.ubar[i] = t.du[i] + B * m.l[i].n();
+      }
     for (int p = 0; p < 2; ++p)
       for (int i = 0; i < m.n_layers; ++i) {
         const int64_t nw = (int64_t)m.l[i].k * m.l[i].cin * m.l[i].cout;
@@ -943,11 +951,13 @@ void dense_fwd(const float* in, const float* Wd, const float* bias, float* out, 
   hipLaunchKernelGGL(k_mm_reduce, grid1(rows * N), dim3(256), 0, s, part, p.splits, rows * N, out, bias, N, l.hout);
 }
 // din[rows][K] = dout[rows][N] Wd^T
-void dense_dgrad(const float* dout, const float* Wd, float* din, int64_t rows, const DiscL& l, float* part, hipStream_t s) {
+// (reduce = false: the split-K parts stay in `part` -- the consumer sums them on load, disc_frame.h; returns their number)
+int dense_dgrad(const float* dout, const float* Wd, float* din, int64_t rows, const DiscL& l, float* part, hipStream_t s, bool reduce = true) {
   const int K = l.kin(), N = l.n();
   const MmPlan p = mm_plan((int)rows, K, N);
   mm_launch<true, false>(dout, N, 1, Wd, 1, N, part, (int)rows, K, N, p, s);
-  hipLaunchKernelGGL(k_mm_reduce, grid1(rows * K), dim3(256), 0, s, part, p.splits, rows * (int64_t)K, din, (const float*)nullptr, K, 1);
+  if (reduce) hipLaunchKernelGGL(k_mm_reduce, grid1(rows * K), dim3(256), 0, s, part, p.splits, rows * (int64_t)K, din, (const float*)nullptr, K, 1);
+  return p.splits;
 }
 // dW += fold(in^T dout)
 void dense_wgrad(const float* in, const float* dout, float* dWd, float* dW, int64_t rows, const DiscL& l, hipStream_t s) {
@@ -1013,10 +1023,14 @@ void input_gradient(const vaenpvc_disc& m, const float* P, int64_t r0, int64_t R
     hipLaunchKernelGGL(k_dense_bwd, dim3((unsigned)nb_d), dim3(256), 0, s, P + m.wd_off, w.abar[L - 1], (const float*)nullptr, kNoAct,
                        1, (float*)nullptr, (float*)nullptr, R, m.flat, R, 1.0f, 1.0f, 1.0f, nb_d);
   }
+  int up_parts = 0;
   for (int i = L - 1; i >= 0; --i) {
     const DiscL& l = m.l[i];
     if (m.front && i == 1) {   // layers 1 and 0 (+ the penalty): one launch
       front::FrontArgs fa = front_args(m, P, w, r0, R);
+      fa.up = w.mmpart;
+      fa.up_parts = up_parts;
+      fa.up_stride = (long long)R * m.l[1].n();
       fa.coef = coef;
       fa.penalty = penalty ? 1 : 0;
       launch_front<front::FP_IGRAD>(fa, s);
@@ -1024,7 +1038,11 @@ void input_gradient(const vaenpvc_disc& m, const float* P, int64_t r0, int64_t R
     }
     hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)R), dim3(256), 0, s, w.abar[i], w.u[i] + r0 * l.n(), w.st[i] + 2 * r0,
                        P + l.gamma_off, P + l.beta_off, (const float*)nullptr, (int64_t)0, w.ubar[i], l.cout, l.hout);
-    if (l.dense) dense_dgrad(w.ubar[i], w.Wd[i], w.abar[i - 1], R, l, w.mmpart, s);
+    if (l.dense) {
+      const bool onload = m.front && i == 2;   // the front kernel sums the parts while it loads them
+      const int np = dense_dgrad(w.ubar[i], w.Wd[i], w.abar[i - 1], R, l, w.mmpart, s, !onload);
+      if (onload) up_parts = np;
+    }
     else conv_bwd_data(w.ubar[i], P + l.w_off, i == 0 ? w.g : w.abar[i - 1], R, l, s);
   }
 }
@@ -1180,14 +1198,13 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
   carve(m, F, true, (float*)d_ws, &w);
   // (a kernel, not hipMemsetAsync: the step is replayed from hipGraphs by hipvae/adversarial.py, and a fill node next to
   //  other fill nodes in one graph was observed to misbehave on replay)
-  hipLaunchKernelGGL(k_zero, grid1(m.n_params), dim3(256), 0, s, Gd, m.n_params);
   PartSums sums;
   sums.count = 0;
   ChanSums csums;   // per-channel reductions of both passes, one launch at the end
   csums.count = 0;
   // pass 1
-  hipLaunchKernelGGL(k_rows, grid1(std::max<int64_t>(F * m.H, m.front ? 3584 : 0)), dim3(256), 0, s, d_x, d_xh, d_t, w.rows, F, m.H,
-                     m.front ? P + m.l[1].w_off : nullptr, w.w1t);
+  hipLaunchKernelGGL(k_rows, grid1(std::max<int64_t>(F * m.H, m.n_params)), dim3(256), 0, s, d_x, d_xh, d_t, w.rows, F, m.H,
+                     m.front ? P + m.l[1].w_off : nullptr, w.w1t, Gd, m.n_params);
   expand_dense(m, P, w, s);
   forward(m, P, B, w, s);
   // pass 2 (rows xi) and the penalty
@@ -1200,8 +1217,7 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
     const DiscL& l = m.l[i];
     const float* src = i == 0 ? w.gt : w.at[i - 1];  // adjoint of abar_{i-1} (of g for the first layer)
     if (l.dense) {
-      dense_fwd(src, w.Wd[i], nullptr, w.q[i], F, l, w.mmpart, s);
-      dense_wgrad(src, w.ubar[i], w.dWd, Gd + l.w_off, F, l, s);
+      dense_fwd(src, w.Wd[i], nullptr, w.q[i], F, l, w.mmpart, s);   // (its weight gradient: with pass 4's, stacked rows)
     } else {
       conv_fwd(src, kNoAct, P + l.w_off, nullptr, w.q[i], F, l, s);
       if (!(m.front && i < 2)) conv_bwd_w(src, kNoAct, w.ubar[i], Gd + l.w_off, F, l, w.part[0][i], &sums, s);
@@ -1221,10 +1237,14 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
   }
   ParamGrads pgs;   // LayerNorm parameter gradients of all layers: one launch at the end
   pgs.count = 0;
+  int up4_parts = 0;
   for (int i = L - 1; i >= 0; --i) {
     const DiscL& l = m.l[i];
     if (m.front && i == 1) {   // layers 1 and 0 of pass 4: LayerNorm backward (+ udir on the rows xi), input gradient
       front::FrontArgs fa = front_args(m, P, w, 0, B);
+      fa.up = w.mmpart;
+      fa.up_parts = up4_parts;
+      fa.up_stride = (long long)B * m.l[1].n();
       fa.add1 = w.udir[1];
       fa.add0 = w.udir[0];
       fa.add_row0 = (int)(2 * F);
@@ -1238,11 +1258,15 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
     hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)B), dim3(256), 0, s, w.da[i], w.u[i], w.st[i], P + l.gamma_off,
                        P + l.beta_off, w.udir[i], 2 * F, w.du[i], l.cout, l.hout);   // udir on the rows xi
     Act ai = i == 0 ? kNoAct : act_of(m.l[i - 1], P, w.st[i - 1]);
-    if (l.dense) dense_wgrad(w.ain[i], w.du[i], w.dWd, Gd + l.w_off, B, l, s);   // (ain: the activated input kept by pass 1)
+    if (l.dense) dense_wgrad(w.ain[i], w.du[i], w.dWd, Gd + l.w_off, B + F, l, s);   // (ain: the activated input kept by pass 1; + pass 3's rows)
     else if (!fr) conv_bwd_w(i == 0 ? w.rows : w.u[i - 1], ai, w.du[i], Gd + l.w_off, B, l, w.part[1][i], &sums, s);
     if (!fr) csums.e[csums.count++] = ChanSum{w.du[i], Gd + l.b_off, B, l.cout, l.hout};   // conv bias
     if (i > 0) {
-      if (l.dense) dense_dgrad(w.du[i], w.Wd[i], w.da[i - 1], B, l, w.mmpart, s);
+      if (l.dense) {
+        const bool onload = m.front && i == 2;
+        const int np = dense_dgrad(w.du[i], w.Wd[i], w.da[i - 1], B, l, w.mmpart, s, !onload);
+        if (onload) up4_parts = np;
+      }
       else conv_bwd_data(w.du[i], P + l.w_off, w.da[i - 1], B, l, s);
     }
   }

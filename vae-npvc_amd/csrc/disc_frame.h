@@ -180,8 +180,13 @@ struct FrontArgs {
   int penalty;            // IGRAD: 1 = also leave gt and gp_f (critic step), 0 = only g (generator step)
   float *at0, *udir0, *pn0, *at1, *udir1, *pn1;     // ADJ: out
   // pass 4 tensors (B rows)
-  const float* da1;       // BWD: in (from the 115-tap layer's input gradient)
+  float* da1;             // BWD: in (from the 115-tap layer's input gradient); out when it arrives as split-K parts
   float *du1, *da0, *du0; // BWD: out
+  // IGRAD / BWD: the upstream of layer 1 as the `up_parts` split-K partial results of the 115-tap layer's input-gradient GEMM
+  // ([part][GEMM row][1824], part stride up_stride floats): summed on load and stored to abar1 / da1 (0: already summed there)
+  const float* up;
+  long long up_stride;
+  int up_parts;
   const float *add1, *add0;   // BWD: the injected adjoints udir1 / udir0 (row r - add_row0 of them), rows >= add_row0 only
   int add_row0;
 };
@@ -309,10 +314,29 @@ FR_DEV void critic_front_row(R& run, float* lds, const FrontArgs& a, int r) {
   } else if constexpr (MODE == FP_IGRAD || MODE == FP_BWD) {
     constexpr bool IG = MODE == FP_IGRAD;
     // ---- layer 1: LayerNorm backward of the upstream handed down by the 115-tap layer
-    auto up1 = IG ? fr_g((const float*)a.abar1) + rr * N1 : fr_g(a.da1) + row * N1;
+    auto up1 = IG ? fr_g((const float*)a.abar1) + rr * N1 : fr_g((const float*)a.da1) + row * N1;
     auto u1r = fr_g((const float*)a.u1) + row * N1;
     auto st1r = fr_g((const float*)a.st1) + 2 * row;
     const bool inj = !IG && a.add1 && (int)row >= a.add_row0;   // uniform
+    if (a.up_parts > 0) {   // uniform: sum the GEMM's split-K parts on load (z ascending, as k_mm_reduce), keep the sum for the later passes
+      auto pp = fr_g(a.up) + (IG ? rr : row) * N1;
+      auto keep = IG ? fr_g(a.abar1) + rr * N1 : fr_g(a.da1) + row * N1;
+      const int np = FR_UNIFORM(a.up_parts);
+      const size_t ps = (size_t)a.up_stride;
+      run.phase([&](int tid) {
+        for (int i = tid; i < N1; i += NT) {
+          float v = 0.f;
+          for (int z = 0; z < np; ++z) v += pp[z * ps + i];
+          by[i] = v;
+          keep[i] = v;
+          bx[i] = u1r[i];
+        }
+        if (tid == 0) {
+          red[R_ST] = st1r[0];
+          red[R_ST + 1] = st1r[1];
+        }
+      });
+    } else
     run.phase([&](int tid) {
       for (int i = tid; i < N1; i += NT) {
         by[i] = up1[i];
