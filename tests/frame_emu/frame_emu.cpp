@@ -6,7 +6,10 @@
 #define FRAME_EMU 1
 #include "../../vae-npvc_amd/csrc/gfx950_frame.h"
 #include "../../vae-npvc_amd/csrc/gfx950_frame_wgrad.h"
+#include "../../vae-npvc_amd/csrc/disc_frame.h"
 
+#include <cstring>
+#include <type_traits>
 #include <vector>
 
 using namespace vaenpvc::frame;
@@ -230,3 +233,68 @@ int frame_emu_run(const float* P, const int* poff, const float* x, const float* 
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ critic front path
+// The five kernels of csrc/disc_frame.h on the host, chained the way vaenpvc_disc_critic_fwd_bwd chains them around the
+// 115-tap layer -- which is cut out here: its input gradients (abar1 for pass 2 on the rows xi, da1 for pass 4 on all rows)
+// are INPUTS.  tests/test_frame_emu.py differentiates the same two-layer block with float64 autograd.
+extern "C" int critic_front_emu(const float* P, const int* off8 /* w0 b0 g0 bt0 w1 b1 g1 bt1 */, const float* rows, int F, const float* abar1,
+                                const float* da1, float coef,
+                                float* u0, float* st0, float* u1, float* st1, float* ain2, float* g, float* gp_f, float* at1,
+                                float* grads /* dW0[112] dW1[3584] db0[16] db1[32] dg0[16] dbt0[16] dg1[32] dbt1[32] */) {
+  using namespace vaenpvc::disc::front;
+  const int B = 3 * F;
+  std::vector<float> lds(L_TOTAL, 0.f), w1t(7 * 16 * 32), ubar1((size_t)F * N1), abar0((size_t)F * N0), ubar0((size_t)F * N0),
+      gt((size_t)F * HIN), at0((size_t)F * N0), udir0((size_t)F * N0), pn0((size_t)F * N0), udir1((size_t)F * N1), pn1((size_t)F * N1),
+      du1((size_t)B * N1), da0((size_t)B * N0), du0((size_t)B * N0), ab1(abar1, abar1 + (size_t)F * N1), d1(da1, da1 + (size_t)B * N1);
+  for (int i = 0; i < 7 * 16 * 32; ++i) {
+    const int c = i % 16, o = (i / 16) % 32, t = i / 512;
+    w1t[i] = P[off8[4] + (t * 16 + c) * 32 + o];
+  }
+  FrontArgs a;
+  memset(&a, 0, sizeof a);
+  a.P = P;
+  a.w0 = off8[0]; a.b0 = off8[1]; a.g0 = off8[2]; a.bt0 = off8[3];
+  a.w1 = off8[4]; a.b1 = off8[5]; a.g1 = off8[6]; a.bt1 = off8[7];
+  a.w1t = w1t.data();
+  a.rows = rows;
+  a.u0 = u0; a.st0 = st0; a.u1 = u1; a.st1 = st1; a.ain2 = ain2;
+  a.abar1 = ab1.data(); a.ubar1 = ubar1.data(); a.abar0 = abar0.data(); a.ubar0 = ubar0.data();
+  a.g = g; a.gt = gt.data(); a.gp_f = gp_f;
+  a.at0 = at0.data(); a.udir0 = udir0.data(); a.pn0 = pn0.data(); a.at1 = at1; a.udir1 = udir1.data(); a.pn1 = pn1.data();
+  a.da1 = d1.data(); a.du1 = du1.data(); a.da0 = da0.data(); a.du0 = du0.data();
+  EmuRunner run;
+  auto pass = [&](auto mode, int rows0, int nrows) {
+    a.rows0 = rows0;
+    a.nrows = nrows;
+    critic_front_prologue(run, lds.data(), a);
+    for (int r = 0; r < nrows; ++r) critic_front_row<decltype(mode)::value>(run, lds.data(), a, r);
+  };
+  pass(std::integral_constant<int, FP_FWD>(), 0, B);
+  a.coef = coef;
+  a.penalty = 1;
+  pass(std::integral_constant<int, FP_IGRAD>(), 2 * F, F);
+  pass(std::integral_constant<int, FP_ADJ>(), 2 * F, F);
+  a.add1 = udir1.data();
+  a.add0 = udir0.data();
+  a.add_row0 = 2 * F;
+  pass(std::integral_constant<int, FP_BWD>(), 0, B);
+  // job list
+  float* dW0 = grads;
+  float* dW1 = dW0 + 112;
+  float* db0 = dW1 + 3584;
+  float* db1 = db0 + 16;
+  float* dg0 = db1 + 32;
+  float* dbt0 = dg0 + 16;
+  float* dg1 = dbt0 + 16;
+  float* dbt1 = dg1 + 32;
+  for (int i = 0; i < 112 + 3584 + 48 + 96; ++i) grads[i] = 0.f;
+  CwArgs ca{rows, gt.data(), u0, st0, u1, st1, P + off8[2], P + off8[3], P + off8[6], P + off8[7], at0.data(), ubar0.data(), ubar1.data(),
+            du0.data(), du1.data(), da0.data(), d1.data(), pn0.data(), pn1.data(), dW0, dW1, db0, db1, dg0, dbt0, dg1, dbt1, F, B};
+  const CwPlan pl = make_cwplan(F, B);
+  std::vector<float> wl(WG_LDS, 0.f);
+  EmuWRunner wrun;
+  for (int b = 0; b < pl.start[CW_SEGS]; ++b) critic_front_wgrad_block(wrun, wl.data(), ca, pl, b);
+  return 0;
+}
+

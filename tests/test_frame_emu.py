@@ -7,6 +7,7 @@ halo, the tap algebra of the strided / transposed convs in both directions, the 
 (Not a product path: nothing under vae-npvc_amd/ loads this library.)
 """
 import ctypes as C
+import json
 import os
 import subprocess
 
@@ -25,8 +26,8 @@ TOL = 2e-5          # fp32 FMA chains against float64, relative to the tensor's 
 def emu():
     so = os.path.join(EMU_DIR, 'libframe_emu.so')
     src = os.path.join(EMU_DIR, 'frame_emu.cpp')
-    hdr = os.path.join(ROOT, 'vae-npvc_amd', 'csrc', 'gfx950_frame.h')
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(ROOT, 'vae-npvc_amd', 'csrc', h) for h in ('gfx950_frame.h', 'gfx950_frame_wgrad.h', 'disc_frame.h')]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-o', so, src])
     lib = C.CDLL(so)
     lib.frame_emu_run.restype = C.c_int
@@ -214,4 +215,82 @@ def test_one_launch_weight_gradient_matches_autograd(emu, arch, F, seed):
         e = rel(got, want)
         if not e < 5e-5:
             bad[name] = e
+    assert not bad, bad
+
+
+# ---------------------------------------------------------------------------------------------- critic front path
+def test_critic_front_kernels_against_float64_autograd(emu):
+    """csrc/disc_frame.h (the VAWGAN critic's two thin conv layers: per-row pass kernels + the job-list weight gradient)
+    emulated on the host and chained as vaenpvc_disc_critic_fwd_bwd chains them, with the 115-tap layer cut out: its input
+    gradients are random inputs (c2 for pass 2 on the rows xi, c4 for pass 4 on all rows).  With a1 = block(rows) the two
+    conv + LayerNorm + lrelu layers, the chain computes the gradient of
+        L = sum_rows <c4, a1>  +  lambda * mean_f (|g_f| - 1)^2 ,   g = d(sum_{xi rows} <c2, a1>) / d(rows xi)
+    with respect to the layers' eight parameter tensors, and  at1 = dL/dc2  (what the chain hands back up to the 115-tap
+    layer in pass 3).  Float64 double-backward autograd of the same expression is the reference."""
+    import torch
+    from oracle import vawgan_oracle as V
+    arch = json.load(open(os.path.join(ROOT, 'vae-npvc_amd', 'architecture-vawgan-vcc2016.json')))
+    F, B, lam = 3, 9, 10.0
+    rng = np.random.RandomState(5)
+    D = V.disc_init_params(arch, 3)
+    names = ['Discriminator/Conv2d-%d/%s' % (i, k) for i in range(2) for k in ('kernel', 'bias', 'layernorm.scale', 'layernorm.offset')]
+    flat, off = [], {}
+    for n in names:
+        off[n] = sum(len(v) for v in flat)
+        flat.append(np.asarray(D[n], np.float64).reshape(-1))
+    P = np.concatenate(flat).astype(np.float32)
+    rows = np.tanh(rng.randn(B, 513)).astype(np.float32)
+    c2 = (0.05 * rng.randn(F, 32 * 57)).astype(np.float32)
+    c4 = (0.05 * rng.randn(B, 32 * 57)).astype(np.float32)
+    # ---- float64 reference
+    Dt = {n: torch.tensor(np.asarray(D[n], np.float64), requires_grad=True) for n in names}
+    g0 = V.disc_geometry(arch)[:2]
+
+    def block(x):
+        cur = x.reshape(x.shape[0], 1, -1, 1)
+        outs = []
+        for i, l in enumerate(g0):
+            p = 'Discriminator/Conv2d-%d/' % i
+            a = O.torch_conv_same(cur, Dt[p + 'kernel'], Dt[p + 'bias'], l['s'])
+            outs.append(a)
+            cur = O.torch_lrelu(O.torch_layernorm(a, Dt[p + 'layernorm.offset'], Dt[p + 'layernorm.scale']))
+        return cur.reshape(x.shape[0], -1), outs
+    xt = torch.tensor(rows.astype(np.float64))
+    xi = xt[2 * F:].clone().requires_grad_(True)
+    c2t = torch.tensor(c2.astype(np.float64), requires_grad=True)
+    c4t = torch.tensor(c4.astype(np.float64))
+    a1_all, pre = block(xt)
+    a1_xi, _ = block(xi)
+    g, = torch.autograd.grad((c2t * a1_xi).sum(), xi, create_graph=True)
+    nrm = torch.sqrt((g ** 2).sum(-1))
+    L = (c4t * a1_all).sum() + lam * ((nrm - 1.0) ** 2).mean()
+    ref = torch.autograd.grad(L, [Dt[n] for n in names] + [c2t])
+    # ---- emulated kernels
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    off8 = np.array([off[names[0]], off[names[1]], off[names[2]], off[names[3]], off[names[4]], off[names[5]], off[names[6]], off[names[7]]],
+                    np.int32)
+    u0, st0 = np.zeros((B, 16 * 171), np.float32), np.zeros((B, 2), np.float32)
+    u1, st1 = np.zeros((B, 32 * 57), np.float32), np.zeros((B, 2), np.float32)
+    ain2, gg, gpf = np.zeros((B, 32 * 57), np.float32), np.zeros((F, 513), np.float32), np.zeros(F, np.float32)
+    at1 = np.zeros((F, 32 * 57), np.float32)
+    grads = np.zeros(112 + 3584 + 16 + 32 + 16 + 16 + 32 + 32, np.float32)
+    emu.critic_front_emu.restype = C.c_int
+    rc = emu.critic_front_emu(fp(P), off8.ctypes.data_as(C.POINTER(C.c_int)), fp(rows), F, fp(c2), fp(c4), C.c_float(2.0 * lam / F),
+                              fp(u0), fp(st0), fp(u1), fp(st1), fp(ain2), fp(gg), fp(gpf), fp(at1), fp(grads))
+    assert rc == 0
+    errs = {}
+    errs['u0'] = rel(u0, pre[0].detach().numpy().reshape(B, -1))
+    errs['u1'] = rel(u1, pre[1].detach().numpy().reshape(B, -1))
+    errs['a1'] = rel(ain2, a1_all.detach().numpy())
+    errs['g'] = rel(gg, g.detach().numpy())
+    errs['gp_f'] = rel(gpf, ((nrm - 1.0) ** 2).detach().numpy())
+    errs['at1'] = rel(at1, ref[8].numpy())
+    pos = 0
+    # order of the grads buffer: dW0 dW1 db0 db1 dgamma0 dbeta0 dgamma1 dbeta1
+    for key, n in (('kernel0', 112), ('kernel1', 3584), ('bias0', 16), ('bias1', 32), ('scale0', 16), ('offset0', 16), ('scale1', 32),
+                   ('offset1', 32)):
+        idx = {'kernel0': 0, 'bias0': 1, 'scale0': 2, 'offset0': 3, 'kernel1': 4, 'bias1': 5, 'scale1': 6, 'offset1': 7}[key]
+        errs['d ' + key] = rel(grads[pos:pos + n], ref[idx].numpy().reshape(-1))
+        pos += n
+    bad = {k: v for k, v in errs.items() if not v < 5e-5}
     assert not bad, bad

@@ -14,13 +14,17 @@
 // Reference: trainer/vae.py:117-145 (WGAN-GP critic update), util/layers.py:47-66 (the conv block); DESIGN.md section 9 for
 // the pass structure (1 forward, 2 input gradient at xi, 3 adjoint of pass 2, 4 ordinary backward).
 #pragma once
+#ifdef FRAME_EMU      // host emulation (tests/frame_emu/frame_emu.cpp): runners and headers come from there
+#include "gfx950_frame.h"
+#include "gfx950_frame_wgrad.h"
+#else
 #include "gfx950_frame_dev.h"
+#endif
 
 namespace vaenpvc {
 namespace disc {
 namespace front {
 using namespace frame;
-using tuned::WRunner;
 
 constexpr int C0 = 16, H0 = 171, N0 = C0 * H0, C1 = 32, H1 = 57, N1 = C1 * H1, HIN = 513;
 
