@@ -456,7 +456,12 @@ def main(argv=None):
         for Fl, nst in ((256, 200), (16, 200)):
             dt2, _ = timed(Fl, nst, 10)
             lit = {'frames_per_s': world * Fl * nst / dt2, 'ms_per_step': dt2 / nst * 1e3, 'launch': 'eager',
-                   'frames_per_step_per_gpu': Fl, 'global_frames_per_step': Fl * world}
+                   'frames_per_step_per_gpu': Fl, 'global_frames_per_step': Fl * world,
+                   # these batch sizes run the frame kernels (fp32 vector arithmetic, one workgroup per frame: DESIGN.md section 11):
+                   # priced against the packed-fp32 VECTOR peak (= the exact-fp32 MFMA figure, 157.3 TFLOP/s) and the HBM model
+                   'path': 'frame kernels: 6 launches per step' if Fl <= 512 else 'layered kernels',
+                   'fraction_of_fp32_vector_peak': Fl * nst / dt2 * FLOP_PER_FRAME_TRAIN / FP32_PEAK,
+                   'fraction_of_hbm_model_B': (Fl * nst / dt2 * BYTES_PER_FRAME_TRAIN + nst / dt2 * BYTES_PER_STEP_PARAMS) / HBM_PEAK}
             # same step captured in a hipGraph (one launch per step instead of one per kernel); with N > 1 the
             # (unbucketed) gradient all-reduce is captured with it
             try:
