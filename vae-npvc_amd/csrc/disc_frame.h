@@ -329,8 +329,12 @@ FR_DEV void critic_front_row(R& run, float* lds, const FrontArgs& a, int r) {
       const size_t ps = (size_t)a.up_stride;
       run.phase([&](int tid) {
         for (int i = tid; i < N1; i += NT) {
+          float t[8];      // (MM_MAX_SPLIT parts at most, all requested before the first add: z ascending as k_mm_reduce)
+          FR_UNROLL
+          for (int z = 0; z < 8; ++z) t[z] = z < np ? pp[z * ps + i] : 0.f;
           float v = 0.f;
-          for (int z = 0; z < np; ++z) v += pp[z * ps + i];
+          FR_UNROLL
+          for (int z = 0; z < 8; ++z) v += t[z];
           by[i] = v;
           keep[i] = v;
           bx[i] = u1r[i];
