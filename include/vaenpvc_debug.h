@@ -37,7 +37,8 @@ extern "C" {
  * carries one frame through a whole pass; selected up to 512 frames per call, VAENPVC_FRAME_MAX); a train step uses them
  * for both passes or for neither.  Bit 20 of the backward mask (default set): cleared = behind the frame kernels, the
  * weight gradients come from the layered kernels on two streams instead of the one-launch job list
- * (gfx950_frame_wgrad.h).  Bit 19 of the backward mask (default set): cleared = encoder layer 0's LayerNorm backward
+ * (gfx950_frame_wgrad.h).  Bit 18 of the backward mask (default set): cleared = a small-batch train step keeps the 1025-tap
+ * layer inside the two frame kernels instead of the two eight-workgroups-per-frame launches between them.  Bit 19 of the backward mask (default set): cleared = encoder layer 0's LayerNorm backward
  * and weight gradient as two passes instead of the fused kernel (k_enc0_bwd_wave, from 1024 frames on). */
 int vaenpvc_set_tuned_masks(vaenpvc_ctx* ctx, uint32_t fwd_mask, uint32_t bwd_mask);
 

@@ -119,7 +119,8 @@ void frame_emu_pack(const float* P, const int* poff, float* pk) {
   for (int i = 0; i < Pk::total; ++i) pk[i] = pack_src(P, o, i);
 }
 
-// mode: FM_* bits of the forward pass; do_bwd: also run the backward pass
+// mode: FM_* bits of the forward pass; do_bwd: 0 forward only, 1 + backward pass, 2 + weight gradients; + 4: the train step
+// with the 1025-tap layer split out (toep_split_fwd / toep_split_bwd between the frame kernels, as the product runs it)
 int frame_emu_run(const float* P, const int* poff, const float* x, const float* target, const long long* y, const float* eps,
                   const float* z_in, int ny, int F, int mode, int do_bwd, float* ws, const long long* t) {
   POff o = make_off(poff);
@@ -168,9 +169,34 @@ int frame_emu_run(const float* P, const int* poff, const float* x, const float* 
       yb += (size_t)F * nd[i];
     }
   }
+  const bool split = (do_bwd & 4) != 0;
+  do_bwd &= 3;
+  if (split) a.mode |= FM_NOD3;
   frame_prologue(run, lds.data(), P, o);
   for (int f = 0; f < F; ++f)
     frame_fwd(run, lds.data(), a, f, [&](int ff, int d) { return eps ? eps[(size_t)ff * 128 + d] : 0.f; });
+  std::vector<float> d_y2;
+  if (split) {
+    EmuWRunner sr;
+    std::vector<float> sl(TS_FWD_LDS > TS_BWD_LDS ? TS_FWD_LDS : TS_BWD_LDS, 0.f), nll8((size_t)F * 8, 0.f);
+    const float* w3t = a.pk + Pk::w3t;
+    for (int f = 0; f < F; ++f)
+      for (int og = 0; og < 8; ++og)
+        toep_split_fwd(sr, sl.data(), a.dec_y + (size_t)f * 4104, w3t, P[o.db[3]], a.target + (size_t)f * 513, og, a.xh + (size_t)f * 513,
+                       nll8.data() + (size_t)f * 8);
+    for (int f = 0; f < F; ++f) {
+      float t = 0.f;
+      for (int k = 0; k < 8; ++k) t += nll8[(size_t)f * 8 + k];
+      a.nll_f[f] = t;
+    }
+    if (do_bwd) {
+      d_y2.resize((size_t)F * 4104);
+      for (int f = 0; f < F; ++f)
+        for (int c = 0; c < 8; ++c)
+          toep_split_bwd(sr, sl.data(), a.xh + (size_t)f * 513, a.target + (size_t)f * 513, w3t, c, a.invF, a.d_xh + (size_t)f * 513,
+                         d_y2.data() + (size_t)f * 4104);
+    }
+  }
   if (!do_bwd) return 0;
   BwdArgs b{};
   b.P = P;
@@ -199,6 +225,7 @@ int frame_emu_run(const float* P, const int* poff, const float* x, const float* 
   b.d_z_mu = ws + t[T_D_Z_MU];
   b.d_z_lv = ws + t[T_D_Z_LV];
   b.lnp = ws + t[T_LNP];
+  b.d_y2 = split ? d_y2.data() : nullptr;
   for (int f = 0; f < F; ++f) frame_bwd(run, lds.data(), b, f);
   if (do_bwd < 2) return 0;
   // ---- every parameter gradient: the job list of the one-launch kernel, block by block

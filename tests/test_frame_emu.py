@@ -76,7 +76,7 @@ def fptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def run_emu(lib, arch, P, x, y, eps, mode=31, bwd=True, target=None, z_in=None, wgrad=False):
+def run_emu(lib, arch, P, x, y, eps, mode=31, bwd=True, target=None, z_in=None, wgrad=False, split=False):
     F = x.shape[0]
     po, _, _ = poff_table(arch)
     flat = O.flatten_params(P)
@@ -89,7 +89,7 @@ def run_emu(lib, arch, P, x, y, eps, mode=31, bwd=True, target=None, z_in=None, 
     eps = None if eps is None else np.ascontiguousarray(eps, np.float32)
     rc = lib.frame_emu_run(fptr(flat), fptr(po), fptr(x), fptr(target) if target is not None else None, fptr(y),
                            fptr(eps) if eps is not None else None, fptr(z_in) if z_in is not None else None,
-                           int(arch['y_dim']), F, mode, (2 if wgrad else 1) if bwd else 0, fptr(ws), fptr(toff))
+                           int(arch['y_dim']), F, mode, ((2 if wgrad else 1) if bwd else 0) + (4 if split else 0), fptr(ws), fptr(toff))
     assert rc == 0
 
     def t(i, shape):
@@ -101,11 +101,14 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def test_forward_pass_matches_the_oracle(emu, arch):
+@pytest.mark.parametrize('split', [False, True])
+def test_forward_pass_matches_the_oracle(emu, arch, split):
+    """split: the 1025-tap layer and the log-density from the eight-workgroups-per-frame bodies (toep_split_fwd), as in a
+    train step; otherwise inside the frame kernel (encode / decode / loss entry points)"""
     F, seed = 3, 4
     P = O.init_params(arch, seed)
     x, y, eps = O.make_inputs(arch, F, seed)
-    t, ws, toff = run_emu(emu, arch, P, x, y, eps, bwd=False)
+    t, ws, toff = run_emu(emu, arch, P, x, y, eps, bwd=False, split=split)
     R = O.np_forward(arch, P, x, y, eps)
     g = O.geometry(arch)
     errs = {}
@@ -126,8 +129,9 @@ def test_forward_pass_matches_the_oracle(emu, arch):
     kl, nll = t(22, (F,)), t(23, (F,))
     errs['D_KL'] = abs(kl.mean() - R['D_KL']) / abs(R['D_KL'])
     errs['logP'] = abs(nll.mean() - R['logP']) / abs(R['logP'])
-    dxh = (R['xh'] - x.astype(np.float64)) / (1 + 1e-6) / F
-    errs['d_xh'] = rel(t(24, dxh.shape), dxh)
+    if not split:      # (the split step leaves d(xh) to its backward half)
+        dxh = (R['xh'] - x.astype(np.float64)) / (1 + 1e-6) / F
+        errs['d_xh'] = rel(t(24, dxh.shape), dxh)
     bad = {k: v for k, v in errs.items() if not v < TOL}
     assert not bad, bad
 
@@ -166,11 +170,12 @@ def oracle_intermediate_grads(arch, P_np, x, y, eps):
     return {k: v.grad.numpy().reshape(v.shape[0], -1) for k, v in keep.items()}, {k: v.grad.numpy() for k, v in P.items()}
 
 
-def test_backward_pass_matches_autograd(emu, arch):
+@pytest.mark.parametrize('split', [False, True])
+def test_backward_pass_matches_autograd(emu, arch, split):
     F, seed = 3, 9
     P = O.init_params(arch, seed)
     x, y, eps = O.make_inputs(arch, F, seed)
-    t, ws, toff = run_emu(emu, arch, P, x, y, eps)
+    t, ws, toff = run_emu(emu, arch, P, x, y, eps, split=split)
     G, GP = oracle_intermediate_grads(arch, P, x, y, eps)
     errs = {}
     errs['d_xh'] = rel(t(24, (F, 513)), G['xh'])
@@ -202,7 +207,7 @@ def test_one_launch_weight_gradient_matches_autograd(emu, arch, F, seed):
     (F = 37: more frames than the smaller jobs have frame chunks, ragged chunks; F = 66: the two-slice form of the 1025-tap job)"""
     P = O.init_params(arch, seed)
     x, y, eps = O.make_inputs(arch, F, seed)
-    t, ws, toff = run_emu(emu, arch, P, x, y, eps, wgrad=True)
+    t, ws, toff = run_emu(emu, arch, P, x, y, eps, wgrad=True, split=(F != 37))
     _, GP = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64)
     T_G = emu.frame_emu_tensor_count() - 2
     g = ws[toff[T_G]:toff[T_G] + 939162].astype(np.float64)

@@ -31,6 +31,15 @@ def test_frame_passes_with_the_layered_weight_gradients():
     assert not fails, '\n'.join(fails)
 
 
+def test_frame_step_with_the_tap_layer_inside_the_frame_kernels():
+    """bit 18 of the backward mask cleared: the 1025-tap layer, the log-density and d(xh) inside the two frame kernels (the
+    form the encode / decode / loss entry points always use) instead of the eight-workgroups-per-frame launches between them
+    -- the A/B partner of the default train step, kept correct"""
+    eng = make_engine('vcc', 'auto', masks=(0xffffffff, 0xffffffff & ~(1 << 18)), frame=True)
+    fails = compare_everything(eng, 16, 3, 'frame F16 unsplit ')
+    assert not fails, '\n'.join(fails)
+
+
 def test_frame_path_is_what_runs_by_default_and_can_be_switched_off():
     """default masks select the frame kernels at 16 frames; clearing bit 21 selects the layered ones; both meet the
     oracle and each other (A/B on one engine)"""

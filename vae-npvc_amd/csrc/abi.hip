@@ -347,7 +347,7 @@ static int train_impl(vaenpvc_ctx* ctx, const float* d_params, const float* d_x,
   const float* eps_bwd = key ? w.eps : d_eps;   // (the seeded sampler stored its draw in the workspace)
   ctx->rt.bucket_next = 0;
   if (frame) {
-    tuned::backward_frame(ctx->m, d_params, d_x, d_target, d_y, eps_bwd, F, w, d_grads, s, /*g_zeroed=*/true);
+    tuned::backward_frame(ctx->m, d_params, d_x, d_target, d_y, eps_bwd, F, w, d_grads, s, /*g_zeroed=*/true, d_loss3);
   } else if (use_tuned(ctx)) {
     tuned::backward(ctx->m, d_params, d_x, d_y, eps_bwd, F, w, d_grads, s);
   } else {

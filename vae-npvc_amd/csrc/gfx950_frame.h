@@ -717,6 +717,157 @@ FR_DEV void halo_copy(int tid, PT a, float* FR_RESTRICT out) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ the 1025-tap layer, split out
+// In a train step the layer is 40 % of each frame kernel's arithmetic and runs on ONE compute unit per frame there.  The
+// two functions below are the bodies of 256-thread workgroups, EIGHT per frame, launched between the frame kernels
+// (forward: a group of 65 outputs each; input gradient: a channel each): the same rotating nine-register window, a
+// fraction of the length per thread.
+constexpr int TS_T = 256;                       // threads per workgroup
+constexpr int TS_NO = 65, TS_NG = 8;            // forward: outputs per workgroup (8 x 65 >= 513), computed as 8 groups of 9
+constexpr int TS_IL = 129;                      // ... reduction positions per thread (4 quarters)
+constexpr int TS_TW = 585;                      // ... taps a workgroup's outputs can meet (584), row pitch
+constexpr int TS_FWD_LDS = TP_C * TP_H + TP_C * TS_TW + 32 * 72;
+// xh[h] = b3 + sum_c sum_i y[c][i] w[c][h - i + 512] for h in [65 og, 65 og + 65) (conv_transpose, stride 1, SAME: output h meets
+// input i through tap h - i + 512; model/vae.py:96-103); log-density terms of those outputs
+template <class R>
+FR_DEV void toep_split_fwd(R& run, float* lds, const float* y2 /*[8][513]*/, const float* w3t /*[8][1028]*/, float b3,
+                           const float* target /*[513]*/, int og, float* xh /*[513]*/, float* nll8 /*this frame's 8 partial sums*/) {
+  float* ys = lds;                       // [8][513]
+  float* ww = ys + TP_C * TP_H;          // [8][585]: ww[c][k] = w[c][tlo + k], zero outside the kernel
+  float* pp = ww + TP_C * TS_TW;         // [32][72] partial sums, then [72] outputs
+  const int tlo = TS_NO * og;        // taps h - i + 512 of h in [65 og, 65 og + 72), i in [0, 513): [65 og, 65 og + 583]
+  run.phase([&](int tid) {
+    for (int i0 = tid; i0 < TP_C * TP_H; i0 += 8 * TS_T) {
+      float v[8];
+      FR_UNROLL
+      for (int u = 0; u < 8; ++u) v[u] = i0 + u * TS_T < TP_C * TP_H ? y2[i0 + u * TS_T] : 0.f;
+      FR_UNROLL
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * TS_T < TP_C * TP_H) ys[i0 + u * TS_T] = v[u];
+    }
+    for (int i0 = tid; i0 < TP_C * TS_TW; i0 += 8 * TS_T) {
+      float v[8];
+      FR_UNROLL
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * TS_T, c = i / TS_TW, t = tlo + i % TS_TW;
+        v[u] = (i < TP_C * TS_TW && t >= 0 && t < TP_K) ? w3t[c * TP_W + t] : 0.f;
+      }
+      FR_UNROLL
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * TS_T < TP_C * TS_TW) ww[i0 + u * TS_T] = v[u];
+    }
+  });
+  run.phase([&](int tid) {
+    const int g9 = tid % TS_NG, c = (tid / TS_NG) % TP_C, iq = tid / (TS_NG * TP_C);
+    const float* yc = ys + c * TP_H;
+    const float* wc = ww + c * TS_TW + 9 * g9 + 512;     // tap of output r at position i: wc[r - i]  (local index 9 g9 + r - i + 512 in [0, 583])
+    const int ib = iq * TS_IL, ie = imin_(TP_H, ib + TS_IL);
+    float acc[TP_R], win[TP_R];
+    FR_UNROLL
+    for (int r = 0; r < TP_R; ++r) acc[r] = 0.f;
+    FR_UNROLL
+    for (int r = 1; r < TP_R; ++r) win[r] = wc[r - ib];
+    int i = ib;
+    for (; i + TP_R <= ie; i += TP_R) {
+      FR_UNROLL
+      for (int s = 0; s < TP_R; ++s) {
+        // rotating window: the tap output 0 meets at this position enters slot (9 - s) % 9; output r meets the tap that
+        // entered r steps ago, slot (r + 9 - s) % 9
+        win[(TP_R - s) % TP_R] = wc[-(i + s)];
+        const float v = yc[i + s];
+        FR_UNROLL
+        for (int r = 0; r < TP_R; ++r) acc[r] += win[(r + TP_R - s) % TP_R] * v;
+      }
+    }
+    for (; i < ie; ++i) {      // tail (< 9 positions): plain reads
+      const float v = yc[i];
+      FR_UNROLL
+      for (int r = 0; r < TP_R; ++r) acc[r] += wc[r - i] * v;
+    }
+    FR_UNROLL
+    for (int r = 0; r < TP_R; ++r) pp[(c * 4 + iq) * 72 + g9 * TP_R + r] = acc[r];
+  });
+  run.phase([&](int tid) {
+    if (tid < 72) {
+      float s = b3;
+      for (int k = 0; k < 32; ++k) s += pp[k * 72 + tid];
+      const int h = TS_NO * og + tid;
+      float t = 0.f;
+      if (tid < TS_NO && h < TP_H) {
+        xh[h] = s;
+        const float d = target[h] - s;
+        t = -0.5f * (LOG_2PI_F + (d * d) / (1.0f + EPSILON_F));
+      }
+      pp[32 * 72 - 72 + tid] = t;      // (row 31 of the partial sums is free once every thread has read it: next phase)
+    }
+  });
+  run.phase([&](int tid) {
+    if (tid == 0) {
+      float t = 0.f;
+      for (int k = 0; k < 72; ++k) t += pp[31 * 72 + k];
+      nll8[og] = t;
+    }
+  });
+}
+
+constexpr int TS_HL = 129;                      // input gradient: reduction positions per thread (4 quarters)
+constexpr int TS_BWD_LDS = 528 + 1040 + 4 * TP_H;
+// d_y2[c][i] = sum_h g[h] w[c][h - i + 512] with g = d(xh) = (xh - target) / ((1 + 1e-6) F)  (model/vae.py:128;
+// util/layers.py:159-167); the workgroup of channel 0 also stores g
+template <class R>
+FR_DEV void toep_split_bwd(R& run, float* lds, const float* xh /*[513]*/, const float* target /*[513]*/, const float* w3t /*[8][1028]*/,
+                           int c, float invF, float* d_xh /*[513]*/, float* d_y2 /*[8][513] of the frame*/) {
+  float* gs = lds;               // [513]
+  float* wr = gs + 528;          // [1025] + zeros
+  float* pp = wr + 1040;         // [4][513]
+  run.phase([&](int tid) {
+    for (int h = tid; h < TP_H; h += TS_T) {
+      const float g = -(target[h] - xh[h]) / (1.0f + EPSILON_F) * invF;
+      gs[h] = g;
+      if (c == 0) d_xh[h] = g;
+    }
+    for (int i0 = tid; i0 < 1040; i0 += 5 * TS_T) {
+      float v[5];
+      FR_UNROLL
+      for (int u = 0; u < 5; ++u) v[u] = i0 + u * TS_T < TP_K ? w3t[c * TP_W + i0 + u * TS_T] : 0.f;
+      FR_UNROLL
+      for (int u = 0; u < 5; ++u)
+        if (i0 + u * TS_T < 1040) wr[i0 + u * TS_T] = v[u];
+    }
+  });
+  run.phase([&](int tid) {
+    if (tid >= TP_G * 4) return;
+    const int gi = tid % TP_G, hq = tid / TP_G;
+    const int hb = hq * TS_HL, he = imin_(TP_H, hb + TS_HL);
+    const float* wc = wr + 512 - 9 * gi;                  // tap of output r at position h: wc[h - r]  (index in [0, 1024])
+    float acc[TP_R], win[TP_R];
+    FR_UNROLL
+    for (int r = 0; r < TP_R; ++r) acc[r] = 0.f;
+    FR_UNROLL
+    for (int r = 1; r < TP_R; ++r) win[r] = wc[hb - r];
+    int h = hb;
+    for (; h + TP_R <= he; h += TP_R) {
+      FR_UNROLL
+      for (int s = 0; s < TP_R; ++s) {
+        win[(TP_R - s) % TP_R] = wc[h + s];
+        const float v = gs[h + s];
+        FR_UNROLL
+        for (int r = 0; r < TP_R; ++r) acc[r] += win[(r + TP_R - s) % TP_R] * v;
+      }
+    }
+    for (; h < he; ++h) {
+      const float v = gs[h];
+      FR_UNROLL
+      for (int r = 0; r < TP_R; ++r) acc[r] += wc[h - r] * v;
+    }
+    FR_UNROLL
+    for (int r = 0; r < TP_R; ++r) pp[hq * TP_H + 9 * gi + r] = acc[r];
+  });
+  run.phase([&](int tid) {
+    for (int i = tid; i < TP_H; i += TS_T) d_y2[c * TP_H + i] = (pp[i] + pp[TP_H + i]) + (pp[2 * TP_H + i] + pp[3 * TP_H + i]);
+  });
+}
+
 // ------------------------------------------------------------------------------------------------ forward pass
 struct FwdArgs {
   const float* P;         // flat parameters
@@ -744,6 +895,8 @@ struct FwdArgs {
 };
 static_assert(sizeof(FwdArgs) <= ARGS_FLOATS * 4, "argument block larger than its LDS slot");
 constexpr int FM_ENC = 1, FM_SAMPLE = 2, FM_DEC = 4, FM_LOSS = 8, FM_GRAD = 16;
+constexpr int FM_NOD3 = 32;   // the pass stops behind decoder layer 2 (its activated output in dec_y): the 1025-tap layer, the log-density
+                              // and d(xh) come from the split launches below (toep_split_fwd / toep_split_bwd)
 
 // optional global output pointer + offset (null stays null)
 template <class T>
@@ -880,6 +1033,12 @@ FR_STAGE void frame_fwd_dec(R& run, float* lds_, const FwdArgs& a_, int f_) {
   run.phase([&](int tid) { tconv_part<D2F>(tid, bx, pk + Pk::d2f, part); });
   reduce_sum<R, D2F::KS, D2F::NOUT, D2F::HOUT>(run, part, ch + LNP_DEC2, by, red);
   var_sum<R, D2F::NOUT>(run, by, red, fr_g(a.dec_a[2]) + (size_t)f * D2F::NOUT);
+  if (a.mode & FM_NOD3) {     // uniform
+    run.phase([&](int tid) {
+      ln_apply<8, 513, 513, 0>(tid, by, red, ch + LNP_C + LNP_DEC2, ch + 2 * LNP_C + LNP_DEC2, bx, fr_g(a.dec_st[2]) + 2 * (size_t)f, ygp(a.dec_y, (size_t)f * 4104));
+    });
+    return;
+  }
   run.phase([&](int tid) {
     // taps of the last layer, one contiguous row per channel (loads first: they must not queue behind the stores below)
     for (int i = tid; i < TP_C * TP_W; i += NT) part[i] = pk[Pk::w3t + i];
@@ -960,6 +1119,8 @@ struct BwdArgs {
   float *d_z, *d_z_mu, *d_z_lv;
   float* d_enc_a[5];
   float* lnp;             // [F][3][LNP_C]
+  const float* d_y2;      // non-null: the gradient at decoder layer 2's activated output [F][8][513] comes from toep_split_bwd
+                          // (which also wrote d_xh); the pass then starts at that layer's LayerNorm backward
 };
 static_assert(sizeof(BwdArgs) <= ARGS_FLOATS * 4, "argument block larger than its LDS slot");
 
@@ -1058,6 +1219,21 @@ FR_STAGE void frame_bwd_dec(R& run, float* lds_, const BwdArgs& a_, int f_) {
   auto P = fr_g(a.P);
   const POff& o = a.off;
   auto lnp_f = fr_g(a.lnp) + (size_t)f * 3 * LNP_C;
+  if (a.d_y2) {   // uniform: split step
+    auto dy = fr_g(a.d_y2) + (size_t)f * 4104;
+    auto ag = fr_g(a.dec_a[2]) + (size_t)f * 4104;
+    auto sg = fr_g(a.dec_st[2]) + 2 * (size_t)f;
+    run.phase([&](int tid) {
+      for (int i = tid; i < 4104; i += NT) {
+        by[i] = dy[i];
+        bx[i] = ag[i];
+      }
+      if (tid == 0) {
+        red[R_ST] = sg[0];
+        red[R_ST + 1] = sg[1];
+      }
+    });
+  } else {
   // ---- d(xh) of G = -logP + D_KL (model/vae.py:128; util/layers.py:159-167): (xh - x) / ((1 + 1e-6) F)
   run.phase([&](int tid) {
     for (int p = tid; p < TP_H; p += NT) {
@@ -1071,6 +1247,7 @@ FR_STAGE void frame_bwd_dec(R& run, float* lds_, const BwdArgs& a_, int f_) {
   // ---- d3 input gradient, LayerNorm backward of decoder layer 2
   run.phase([&](int tid) { toep_dgrad_part(tid, vec, part, part + TP_C * TP_W); });
   run.phase([&](int tid) { reduce_load<2, 4104>(tid, part + TP_C * TP_W, by, fr_g(a.dec_a[2]) + (size_t)f * 4104, bx, fr_g(a.dec_st[2]) + 2 * (size_t)f, red); });
+  }
   ln_bwd<R, 8, 513>(run, bx, by, part, red, ch + LNP_C + LNP_DEC2, ch + 2 * LNP_C + LNP_DEC2, lnp_f + LNP_DEC2);
   run.phase([&](int tid) {
     flush(tid, by, fr_g(a.d_dec_a[2]) + (size_t)f * 4104, 4104);

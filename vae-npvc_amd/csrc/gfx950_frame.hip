@@ -103,6 +103,60 @@ __global__ void __launch_bounds__(256) k_frame_loss(const float* __restrict__ kl
   }
 }
 
+// The 1025-tap layer of a train step, eight workgroups per frame (gfx950_frame.h: toep_split_fwd / toep_split_bwd), between
+// the two frame kernels.  The second one also finishes the losses: per-frame log-density from the eight partial sums, and
+// (workgroup 0) the batch means in the fixed order of k_frame_loss.
+__global__ void __launch_bounds__(TS_T) k_frame_toep_fwd(const float* __restrict__ dec_y, const float* __restrict__ pk,
+                                                         const float* __restrict__ P, int b3_off, const float* __restrict__ target,
+                                                         float* __restrict__ xh, float* __restrict__ nll8) {
+  extern __shared__ __attribute__((aligned(16))) float ts_lds[];
+  WRunner run;
+  const int f = blockIdx.x >> 3, og = blockIdx.x & 7;
+  toep_split_fwd(run, ts_lds, dec_y + (size_t)f * 4104, pk + Pk::w3t, P[b3_off], target + (size_t)f * TP_H, og, xh + (size_t)f * TP_H,
+                 nll8 + (size_t)f * 8);
+}
+__global__ void __launch_bounds__(TS_T) k_frame_toep_bwd(const float* __restrict__ xh, const float* __restrict__ target,
+                                                         const float* __restrict__ pk, float invF, float* __restrict__ d_xh,
+                                                         float* __restrict__ d_y2, const float* __restrict__ kl_f,
+                                                         const float* __restrict__ nll8, float* __restrict__ nll_f, int F,
+                                                         float* __restrict__ loss3) {
+  extern __shared__ __attribute__((aligned(16))) float ts_lds[];
+  WRunner run;
+  const int f = blockIdx.x >> 3, c = blockIdx.x & 7;
+  toep_split_bwd(run, ts_lds, xh + (size_t)f * TP_H, target + (size_t)f * TP_H, pk + Pk::w3t, c, invF, d_xh + (size_t)f * TP_H,
+                 d_y2 + (size_t)f * 4104);
+  auto nll_of = [&](int i) {
+    float t = 0.f;
+    for (int k = 0; k < 8; ++k) t += nll8[(size_t)i * 8 + k];
+    return t;
+  };
+  if (!nll8) return;                   // uniform: backward pass against another target (the losses came from elsewhere)
+  if (c == 0 && threadIdx.x == 0) nll_f[f] = nll_of(f);
+  if (blockIdx.x == 0 && loss3) {      // uniform
+    float* sa = ts_lds;
+    float* sb = ts_lds + TS_T;
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < F; i += TS_T) {
+      a += kl_f[i];
+      b += nll_of(i);
+    }
+    sa[threadIdx.x] = a;
+    sb[threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float x = 0.f, y = 0.f;
+      for (int i = 0; i < TS_T; ++i) {
+        x += sa[i];
+        y += sb[i];
+      }
+      const float kl = x / (float)F, lp = y / (float)F;
+      loss3[0] = -lp + kl;
+      loss3[1] = kl;
+      loss3[2] = lp;
+    }
+  }
+}
+
 // gradients of the LayerNorm offsets / scales and the conv biases of the 8 normalised layers: sums over frames of the
 // per-frame channel sums the backward pass left (fixed order: bitwise repeatable)
 struct LnpDst {
@@ -182,6 +236,16 @@ void frame_pack(const Model& m, const float* P, const Ws& w, float* G, float* ze
   hipLaunchKernelGGL(k_frame_pack, dim3((Pk::total + 255) / 256), dim3(256), 0, s, P, poff_of(m), w.frame_pk, G, G ? (int)m.n_params : 0, zero2, nzero2);
 }
 
+// Train steps run the 1025-tap layer outside the frame kernels (bit 18 of the backward mask, default set): needs the
+// activated output of decoder layer 2 and the scratch both halves share
+// (up to FRAME_SPLIT_MAX frames: the frame kernels leave compute units idle there; at 256 frames every unit holds a frame
+//  and the 2 x 2048 extra workgroups cost more than the frame kernels save: 0.362 -> 0.378 ms, against 0.253 -> 0.229 ms at
+//  16 frames and 0.273 -> 0.254 at 64; VAENPVC_FRAME_SPLIT_MAX overrides)
+bool frame_split_on(const Ws& w, int64_t F) {
+  static const int64_t fmax = getenv("VAENPVC_FRAME_SPLIT_MAX") ? atoll(getenv("VAENPVC_FRAME_SPLIT_MAX")) : 128;
+  return ((rt().bwd_mask >> 18) & 1u) && F <= fmax && w.dec_y && w.dy_tmp && w.frame_lnp && w.d_xh;
+}
+
 // mode: FM_* bits.  x may be null for decode-only, z_in null unless decode-only.
 void frame_forward(const Model& m, const float* P, const float* x, const float* target, const int64_t* y, const float* eps,
                    const PhiloxKey* key, const float* z_in, int64_t F, const Ws& w, float* xh_out, int mode, float* loss3,
@@ -231,6 +295,10 @@ void frame_forward(const Model& m, const float* P, const float* x, const float* 
     }
   }
   if (!a.d_xh) a.mode &= ~FM_GRAD;
+  // train step: the pass stops behind decoder layer 2; xh and the log-density come from k_frame_toep_fwd below, d(xh) and
+  // the batch means from k_frame_toep_bwd (frame_backward)
+  const bool split = (a.mode & FM_GRAD) && (a.mode & FM_LOSS) && frame_split_on(w, F);
+  if (split) a.mode |= FM_NOD3;
   PhiloxKey k = key ? *key : PhiloxKey{0, 0, 0, 0, nullptr};
   if (long long* pb = prof_buf()) {
     rt().ensure_lds(reinterpret_cast<const void*>(&k_frame_fwd<true>), L_TOTAL * 4);
@@ -239,12 +307,17 @@ void frame_forward(const Model& m, const float* P, const float* x, const float* 
     rt().ensure_lds(reinterpret_cast<const void*>(&k_frame_fwd<false>), L_TOTAL * 4);
     VAENPVC_TIMED("frame_fwd", s, hipLaunchKernelGGL(k_frame_fwd<false>, dim3((unsigned)frame_grid((int)F)), dim3(NT), L_TOTAL * 4, s, a, k, key ? 1 : 0, (long long*)nullptr));
   }
+  if (split) {
+    VAENPVC_TIMED("frame_toep_fwd", s, hipLaunchKernelGGL(k_frame_toep_fwd, dim3((unsigned)F * 8), dim3(TS_T), TS_FWD_LDS * 4, s, w.dec_y, w.frame_pk, P,
+                                                          (int)m.dec[3].b_off, a.target, a.xh, w.frame_lnp));
+    return;      // (the losses: k_frame_toep_bwd)
+  }
   if (loss3 && (mode & FM_LOSS) && (mode & FM_SAMPLE))
     hipLaunchKernelGGL(k_frame_loss, dim3(1), dim3(256), 0, s, w.kl_f, w.nll_f, (int)F, loss3);
 }
 
 void frame_backward(const Model& m, const float* P, const float* target, const float* eps, int64_t F, const Ws& w, float* G,
-                    hipStream_t s, bool lnp_sums) {
+                    hipStream_t s, bool lnp_sums, float* loss3) {
   BwdArgs a;
   memset(&a, 0, sizeof a);
   a.P = P;
@@ -273,6 +346,15 @@ void frame_backward(const Model& m, const float* P, const float* target, const f
   a.d_z_mu = w.d_z_mu;
   a.d_z_lv = w.d_z_lv;
   a.lnp = w.frame_lnp;
+  if (frame_split_on(w, F)) {
+    // d(xh) and the gradient at decoder layer 2's activated output, eight workgroups per frame; with `loss3` (the step's own
+    // forward pass came just before) also the per-frame log-density and the batch means from the partial sums that pass left
+    // at the head of the frame_lnp region (the backward kernel overwrites it afterwards)
+    VAENPVC_TIMED("frame_toep_bwd", s, hipLaunchKernelGGL(k_frame_toep_bwd, dim3((unsigned)F * 8), dim3(TS_T), TS_BWD_LDS * 4, s, w.xh, target, w.frame_pk,
+                                                          a.invF, w.d_xh, w.dy_tmp, w.kl_f, loss3 ? w.frame_lnp : (const float*)nullptr, w.nll_f,
+                                                          (int)F, loss3));
+    a.d_y2 = w.dy_tmp;
+  }
   if (long long* pb = prof_buf()) {
     rt().ensure_lds(reinterpret_cast<const void*>(&k_frame_bwd<true>), L_TOTAL * 4);
     hipLaunchKernelGGL(k_frame_bwd<true>, dim3((unsigned)frame_grid((int)F)), dim3(NT), L_TOTAL * 4, s, a, pb + 512);

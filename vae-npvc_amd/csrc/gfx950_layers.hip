@@ -1209,7 +1209,7 @@ float* frame_zero_region(const Ws& w, int* count) {
   return w.scratch + Pk::merge_s;
 }
 void backward_frame(const Model& m, const float* P, const float* x, const float* target, const int64_t* y, const float* eps,
-                    int64_t F64, const Ws& w, float* G, hipStream_t s, bool g_zeroed) {
+                    int64_t F64, const Ws& w, float* G, hipStream_t s, bool g_zeroed, float* loss3) {
   const int F = (int)F64;
   if (!g_zeroed) {
     (void)hipMemsetAsync(G, 0, (size_t)m.n_params * 4, s);
@@ -1218,7 +1218,7 @@ void backward_frame(const Model& m, const float* P, const float* x, const float*
   // bit 20 of the backward mask (default set): every parameter gradient in ONE launch (gfx950_frame_wgrad.h); cleared = the
   // layered weight-gradient kernels below on two streams (A/B, parity tests)
   const bool one_launch = bwd_on(20) && w.frame_y != nullptr;
-  frame_backward(m, P, target ? target : x, eps, F, w, G, s, !one_launch);
+  frame_backward(m, P, target ? target : x, eps, F, w, G, s, !one_launch, loss3);
   if (one_launch) {
     frame_wgrad(m, P, x, y, F, w, G, s);
     Runtime& r0 = rt();

@@ -121,14 +121,17 @@ void frame_forward(const Model& m, const float* P, const float* x, const float* 
                    hipStream_t s);
 // input-gradient chain + LayerNorm parameter / conv-bias gradients (the weight gradients are the caller's)
 // (lnp_sums: also launch the reduction of the LayerNorm parameter / conv-bias sums; false when frame_wgrad follows)
+// (loss3: where the batch means go when the step's forward pass left them to the backward half -- the split train step,
+//  gfx950_frame.hip: frame_split_on; null: nobody wants them)
 void frame_backward(const Model& m, const float* P, const float* target, const float* eps, int64_t F, const Ws& w, float* G,
-                    hipStream_t s, bool lnp_sums);
+                    hipStream_t s, bool lnp_sums, float* loss3 = nullptr);
+bool frame_split_on(const Ws& w, int64_t F);
 // every parameter gradient in one launch (gfx950_frame_wgrad.h); G must have been zero-filled
 void frame_wgrad(const Model& m, const float* P, const float* x, const int64_t* y, int64_t F, const Ws& w, float* G, hipStream_t s);
 // the whole backward pass of a small batch: frame_backward + every weight gradient (gfx950_layers.hip)
 // (g_zeroed: the gradient buffer and frame_zero_region were zero-filled by this step's frame_pack)
 void backward_frame(const Model& m, const float* P, const float* x, const float* target, const int64_t* y, const float* eps,
-                    int64_t F, const Ws& w, float* G, hipStream_t s, bool g_zeroed);
+                    int64_t F, const Ws& w, float* G, hipStream_t s, bool g_zeroed, float* loss3 = nullptr);
 }  // namespace tuned
 
 }  // namespace vaenpvc
