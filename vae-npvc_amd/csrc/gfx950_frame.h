@@ -8,9 +8,12 @@
 //   k_frame_fwd   x -> e0..e4 -> heads -> sampler + KL -> merge -> d0..d3 -> xh, log-density  (model/vae.py:72-137)
 //   k_frame_bwd   d(xh) -> ... -> d(pre-LN output of encoder layer 0): the input-gradient chain with every LayerNorm
 //                 backward in place (autodiff of the above, trainer/vae.py:24)
-//   k_frame_wgrad every weight / bias / LayerNorm-parameter gradient in ONE launch, each element by one thread
-//                 (no atomics, no zero-fill of the gradient buffer)
-//   k_frame_pack  aligned / transposed weight copies the first two read with 16-byte loads (weights change every step)
+//   k_frame_wgrad every weight / bias / LayerNorm-parameter gradient in ONE launch: a job list of tiles over frame chunks
+//                 (gfx950_frame_wgrad.h), tiles meet in LDS and leave as coalesced fp32 atomics into the zeroed buffer
+//   k_frame_pack  aligned / transposed weight copies the first two read with 16-byte loads (weights change every step);
+//                 the step's zero fills ride along
+//   k_frame_toep_fwd / _bwd  (train steps up to 128 frames) the 1025-tap layer as eight 256-thread workgroups per frame
+//                 between the two frame kernels, which then stop / start at decoder layer 2 (toep_split_* below)
 // Arithmetic: plain fp32 FMAs on the vector ALUs (exact-fp32 class, like the fp32 matrix-core kernels they replace at
 // these sizes).  At one frame per CU the pass is bound by streaming the 3.76 MB of weights through one CU's L2 port
 // (~50 B/clk) and by LDS operand reads, not by FLOPs: the matrix cores would buy nothing here.

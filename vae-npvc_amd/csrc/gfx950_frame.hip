@@ -2,7 +2,10 @@
 //   frame_pack   aligned / transposed weight copies (+ optional zero fill of the gradient buffer), once per step
 //   frame_fwd    encoder -> heads -> sampler -> merge -> decoder -> log-density of every frame, then the batch means
 //   frame_bwd    input-gradient chain of every frame with the LayerNorm backward in place
-//   frame_lnp    per-frame channel sums -> gradients of the LayerNorm parameters and conv biases
+//   frame_wgrad  every parameter gradient, one job-list launch (gfx950_frame_wgrad.h)
+//   frame_lnp    per-frame channel sums -> gradients of the LayerNorm parameters and conv biases (only behind the LAYERED
+//                weight gradients, backward-mask bit 20 cleared: the job list has its own segment for them)
+//   toep_fwd / toep_bwd  train steps up to 128 frames: the 1025-tap layer between the two frame kernels (frame_split_on)
 // Reference: model/vae.py:72-137 (forward), trainer/vae.py:24 (autodiff).
 #include "gfx950_frame.h"
 #include "gfx950_frame_wgrad.h"
