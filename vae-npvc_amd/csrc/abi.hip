@@ -391,7 +391,7 @@ int vaenpvc_train_bwd_target(vaenpvc_ctx* ctx, const float* d_params, const floa
   if (use_tuned(ctx) && tuned::frame_fwd_on(F) && tuned::frame_bwd_on(F)) {
     int nz2 = 0;
     float* z2 = tuned::frame_zero_region(w, &nz2);
-    tuned::frame_pack(ctx->m, d_params, w, d_grads, z2, nz2, s);      // (the forward pass ran in an earlier call: cheap to redo)
+    tuned::frame_pack(ctx->m, d_params, w, d_grads, z2, nz2, s, /*zero_only=*/true);   // (the packed weights of the preceding train step are still in the workspace: parameters may not change in between, include/vaenpvc.h)
     tuned::backward_frame(ctx->m, d_params, d_x, d_target, d_y, d_eps, F, w, d_grads, s, /*g_zeroed=*/true);
   } else if (use_tuned(ctx)) {
     tuned::backward(ctx->m, d_params, d_x, d_y, d_eps, F, w, d_grads, s);

@@ -49,6 +49,19 @@ struct Act {  // LN-on-load descriptor; st == nullptr -> identity
   const float* beta;
 };
 static const Act kNoAct{nullptr, nullptr, nullptr};
+// The gradient at the LAST conv layer's activated output is never a tensor: the dense unit d = w . a + c hands down
+// coef(row) * w[k] (coef: rows [0, F0) c0, [F0, 2 F0) c1, the rest c2; row = row0 + the kernel's local row).  The kernels
+// that would read it as `dy` take this descriptor instead when their dy pointer is null.
+struct VDy {
+  const float* w;
+  float c0, c1, c2;
+  int64_t F0, row0;
+  __device__ __forceinline__ float at(int64_t f, int i) const {
+    const int64_t r = row0 + f;
+    return (r < F0 ? c0 : (r < 2 * F0 ? c1 : c2)) * w[i];
+  }
+};
+static const VDy kNoVDy{nullptr, 0.f, 0.f, 0.f, 0, 0};
 
 __device__ __forceinline__ float lnact(float v, const Act& a, int64_t f, int c) {
   if (a.st == nullptr) return v;
@@ -231,10 +244,15 @@ __global__ void __launch_bounds__(256) k_conv_fwd(const float* __restrict__ in, 
 }
 
 // d[f] = c + sum_k act(u)[f,k] w[k]     (flatten is C-major = memory order)
+// (dw != nullptr, critic step: also the dense unit's own gradient dw[k] += coef(f) act(u)[f,k], dc += coef(f), coef as in VDy;
+//  fp32 atomics into the zeroed gradient buffer -- the separate pass over act(u) this replaces cost a launch)
 __global__ void k_dense_fwd(const float* __restrict__ u, Act ai, int hlast, const float* __restrict__ w,
-                            const float* __restrict__ c, float* __restrict__ d, int flat, float* __restrict__ st_new) {
+                            const float* __restrict__ c, float* __restrict__ d, int flat, float* __restrict__ st_new,
+                            float* __restrict__ dw = nullptr, float* __restrict__ dc = nullptr, int64_t F0 = 0, float c0 = 0.f,
+                            float c1 = 0.f, float c2 = 0.f) {
   __shared__ float sm[16];
   int64_t f = blockIdx.x;
+  const float coef = f < F0 ? c0 : (f < 2 * F0 ? c1 : c2);
   float mean = 0.f, rstd = 0.f;
   if (st_new) {   // statistics of the last conv layer, taken here (see k_conv_fwd)
     float a = 0.f;
@@ -262,44 +280,23 @@ __global__ void k_dense_fwd(const float* __restrict__ u, Act ai, int hlast, cons
       v = lnact(u[f * flat + k], ai, f, ch_of(k, hlast));
     }
     s += v * w[k];
+    if (dw && coef != 0.f) atomicAdd(dw + k, coef * v);
   }
   s = block_sum(s, sm);
-  if (threadIdx.x == 0) d[f] = s + c[0];
+  if (threadIdx.x == 0) {
+    d[f] = s + c[0];
+    // dc = sum_f coef(f): one thread, closed form (the +-1/F terms cancel exactly; per-row atomics left a rounding residue)
+    if (dc && f == 0) dc[0] += (float)F0 * c0 + (float)F0 * c1 + (float)((int64_t)gridDim.x - 2 * F0) * c2;
+  }
 }
 
 // ------------------------------------------------------------------------------------------ backward
-// dense unit backward, one launch.  coef(f): rows [0,F0) get c0, [F0,2F0) c1, the rest c2.
-//   blocks [0, nb_d)  : upstream of the last conv layer   da[f,k] = coef(f) w[k]
-//   blocks [nb_d, ..) : dw[k] += sum_f coef(f) act(u)[f,k] ; dc += sum_f coef(f)   (one thread per k; thread `flat` does the
-//                       bias); skipped when dw == nullptr
-__global__ void k_dense_bwd(const float* __restrict__ w, float* __restrict__ da, const float* __restrict__ u, Act ai, int hlast,
-                            float* __restrict__ dw, float* __restrict__ dc, int64_t B, int flat, int64_t F0, float c0, float c1,
-                            float c2, int nb_d) {
-  if ((int)blockIdx.x < nb_d) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * flat) return;
-    int64_t f = idx / flat;
-    float c = f < F0 ? c0 : (f < 2 * F0 ? c1 : c2);
-    da[idx] = c * w[idx % flat];
-    return;
-  }
-  int k = ((int)blockIdx.x - nb_d) * blockDim.x + threadIdx.x;
-  if (k > flat) return;
-  float s = 0.f;
-  for (int64_t f = 0; f < B; ++f) {
-    float c = f < F0 ? c0 : (f < 2 * F0 ? c1 : c2);
-    s += k < flat ? c * lnact(u[f * flat + k], ai, f, k / hlast) : c;
-  }
-  if (k < flat) dw[k] += s;
-  else dc[0] += s;
-}
-
 // LayerNorm + lrelu backward (autodiff of util/layers.py:32-44,149); one block per frame.
 //   n = gamma xhat + beta ; p = dy lrelu'(n) gamma ; du = rstd (p - mean p - xhat mean(p xhat)) (+ add, a tensor whose
 //   row 0 belongs to frame add_row0)
 __global__ void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ u, const float* __restrict__ st,
                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                         const float* __restrict__ add, int64_t add_row0, float* __restrict__ du, int C, int H) {
+                         const float* __restrict__ add, int64_t add_row0, float* __restrict__ du, int C, int H, VDy vd = kNoVDy) {
   __shared__ float sm[16];
   int64_t f = blockIdx.x;
   int n = C * H;
@@ -310,7 +307,7 @@ __global__ void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__
     int c = i / H;
     float xh = (u[f * n + i] - mean) * rstd;
     float nn = xh * gamma[c] + beta[c];
-    float p = dy[f * n + i] * (nn >= 0.f ? 1.0f : LEAK) * gamma[c];
+    float p = (dy ? dy[f * n + i] : vd.at(f, i)) * (nn >= 0.f ? 1.0f : LEAK) * gamma[c];
     s1 += p;
     s2 += p * xh;
   }
@@ -320,7 +317,7 @@ __global__ void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__
     int c = i / H;
     float xh = (u[f * n + i] - mean) * rstd;
     float nn = xh * gamma[c] + beta[c];
-    float p = dy[f * n + i] * (nn >= 0.f ? 1.0f : LEAK) * gamma[c];
+    float p = (dy ? dy[f * n + i] : vd.at(f, i)) * (nn >= 0.f ? 1.0f : LEAK) * gamma[c];
     float r = rstd * (p - s1 - xh * s2);
     du[f * n + i] = add ? r + add[f * n + i] : r;
   }
@@ -336,7 +333,7 @@ __global__ void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__
 __global__ void k_ln_bwd_bwd(const float* __restrict__ q, const float* __restrict__ dy, const float* __restrict__ u,
                              const float* __restrict__ st, const float* __restrict__ gamma,
                              const float* __restrict__ beta, float* __restrict__ at, float* __restrict__ udir,
-                             float* __restrict__ pn, int C, int H) {
+                             float* __restrict__ pn, int C, int H, VDy vd = kNoVDy) {
   __shared__ float sm[16];
   int64_t f = blockIdx.x;
   int n = C * H;
@@ -346,7 +343,7 @@ __global__ void k_ln_bwd_bwd(const float* __restrict__ q, const float* __restric
     int c = i / H;
     float xh = (u[f * n + i] - mean) * rstd;
     float nn = xh * gamma[c] + beta[c];
-    float p = dy[f * n + i] * (nn >= 0.f ? 1.0f : LEAK) * gamma[c];
+    float p = (dy ? dy[f * n + i] : vd.at(f, i)) * (nn >= 0.f ? 1.0f : LEAK) * gamma[c];
     float qq = q[f * n + i];
     sp += p;
     spx += p * xh;
@@ -362,7 +359,7 @@ __global__ void k_ln_bwd_bwd(const float* __restrict__ q, const float* __restric
     int c = i / H;
     float xh = (u[f * n + i] - mean) * rstd;
     float nn = xh * gamma[c] + beta[c];
-    float p = dy[f * n + i] * (nn >= 0.f ? 1.0f : LEAK) * gamma[c];
+    float p = (dy ? dy[f * n + i] : vd.at(f, i)) * (nn >= 0.f ? 1.0f : LEAK) * gamma[c];
     float qq = q[f * n + i];
     float ub = rstd * (p - sp - xh * spx);
     float xt = -rstd * (spx * qq + sqx * p);
@@ -376,7 +373,7 @@ __global__ void k_ln_bwd_bwd(const float* __restrict__ q, const float* __restric
     float xh = (u[f * n + i] - mean) * rstd;
     float nn = xh * gamma[c] + beta[c];
     float sl = nn >= 0.f ? 1.0f : LEAK;
-    float dyv = dy[f * n + i];
+    float dyv = dy ? dy[f * n + i] : vd.at(f, i);
     float p = dyv * sl * gamma[c];
     float qq = q[f * n + i];
     float xt = -rstd * (spx * qq + sqx * p);
@@ -389,10 +386,11 @@ __global__ void k_ln_bwd_bwd(const float* __restrict__ q, const float* __restric
 
 // dgamma[c] += sum_{f,h} dn xhat ; dbeta[c] += sum_{f,h} dn ; one block per (layer, channel): blockIdx.y = layer entry
 struct ParamGrad {
-  const float *dy, *u, *st, *gamma, *beta;
+  const float *dy, *u, *st, *gamma, *beta;      // (dy null: vd)
   float *dgamma, *dbeta;
   int64_t B;
   int C, H;
+  VDy vd;
 };
 struct ParamGrads {
   ParamGrad e[VAENPVC_MAX_LAYERS];
@@ -410,7 +408,7 @@ __global__ void k_ln_param_grad(ParamGrads pg) {
     int64_t e = (f * p.C + c) * p.H + (int)(i % p.H);
     float xh = (p.u[e] - p.st[2 * f]) * p.st[2 * f + 1];
     float nn = xh * g + b;
-    float dn = p.dy[e] * (nn >= 0.f ? 1.0f : LEAK);
+    float dn = (p.dy ? p.dy[e] : p.vd.at(f, c * p.H + (int)(i % p.H))) * (nn >= 0.f ? 1.0f : LEAK);
     sg += dn * xh;
     sb += dn;
   }
@@ -991,7 +989,9 @@ front::FrontArgs front_args(const vaenpvc_disc& m, const float* P, const DWs& w,
   return a;
 }
 
-void forward(const vaenpvc_disc& m, const float* P, int64_t B, const DWs& w, hipStream_t s) {
+// (dw / dc non-null, critic step: the dense unit's own gradient rides in its forward kernel, coefficients -1/F | +1/F | 0)
+void forward(const vaenpvc_disc& m, const float* P, int64_t B, const DWs& w, hipStream_t s, float* dw = nullptr, float* dc = nullptr,
+             int64_t F0 = 0, float c0 = 0.f, float c1 = 0.f) {
   if (m.front) launch_front<front::FP_FWD>(front_args(m, P, w, 0, B), s);   // layers 0-1: outputs, statistics, the 115-tap layer's input
   for (int i = 0; i < m.n_layers; ++i) {
     const DiscL& l = m.l[i];
@@ -1010,7 +1010,7 @@ void forward(const vaenpvc_disc& m, const float* P, int64_t B, const DWs& w, hip
   const DiscL& last = m.l[m.n_layers - 1];
   hipLaunchKernelGGL(k_dense_fwd, dim3((unsigned)B), dim3(256), 0, s, w.u[m.n_layers - 1],
                      act_of(last, P, w.st[m.n_layers - 1]), last.hout, P + m.wd_off, P + m.bd_off, w.d, m.flat,
-                     w.st[m.n_layers - 1]);
+                     w.st[m.n_layers - 1], dw, dc, F0, c0, c1, 0.0f);
 }
 
 // pass 2: g = d(sum_f d_f)/d(rows) for R rows starting at row r0; keeps abar_l / ubar_l
@@ -1018,11 +1018,7 @@ void forward(const vaenpvc_disc& m, const float* P, int64_t B, const DWs& w, hip
 void input_gradient(const vaenpvc_disc& m, const float* P, int64_t r0, int64_t R, const DWs& w, hipStream_t s, bool penalty = false,
                     float coef = 0.f) {
   const int L = m.n_layers;
-  {
-    const int nb_d = (int)((R * m.flat + 255) / 256);
-    hipLaunchKernelGGL(k_dense_bwd, dim3((unsigned)nb_d), dim3(256), 0, s, P + m.wd_off, w.abar[L - 1], (const float*)nullptr, kNoAct,
-                       1, (float*)nullptr, (float*)nullptr, R, m.flat, R, 1.0f, 1.0f, 1.0f, nb_d);
-  }
+  const VDy ones{P + m.wd_off, 1.0f, 1.0f, 1.0f, R, 0};     // upstream of the last conv layer: w itself (d(sum_f d_f) / d(act))
   int up_parts = 0;
   for (int i = L - 1; i >= 0; --i) {
     const DiscL& l = m.l[i];
@@ -1036,8 +1032,9 @@ void input_gradient(const vaenpvc_disc& m, const float* P, int64_t r0, int64_t R
       launch_front<front::FP_IGRAD>(fa, s);
       break;
     }
-    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)R), dim3(256), 0, s, w.abar[i], w.u[i] + r0 * l.n(), w.st[i] + 2 * r0,
-                       P + l.gamma_off, P + l.beta_off, (const float*)nullptr, (int64_t)0, w.ubar[i], l.cout, l.hout);
+    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)R), dim3(256), 0, s, i == L - 1 ? (const float*)nullptr : w.abar[i], w.u[i] + r0 * l.n(),
+                       w.st[i] + 2 * r0, P + l.gamma_off, P + l.beta_off, (const float*)nullptr, (int64_t)0, w.ubar[i], l.cout, l.hout,
+                       i == L - 1 ? ones : kNoVDy);
     if (l.dense) {
       const bool onload = m.front && i == 2;   // the front kernel sums the parts while it loads them
       const int np = dense_dgrad(w.ubar[i], w.Wd[i], w.abar[i - 1], R, l, w.mmpart, s, !onload);
@@ -1205,8 +1202,9 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
   // pass 1
   hipLaunchKernelGGL(k_rows, grid1(std::max<int64_t>(F * m.H, m.n_params)), dim3(256), 0, s, d_x, d_xh, d_t, w.rows, F, m.H,
                      m.front ? P + m.l[1].w_off : nullptr, w.w1t, Gd, m.n_params);
+  const float cr = -1.0f / (float)F, cf = 1.0f / (float)F;     // pass-4 upstream of d: -1/F (x), +1/F (xh), 0 (xi)
   expand_dense(m, P, w, s);
-  forward(m, P, B, w, s);
+  forward(m, P, B, w, s, Gd + m.wd_off, Gd + m.bd_off, F, cr, cf);
   // pass 2 (rows xi) and the penalty
   input_gradient(m, P, 2 * F, F, w, s, m.front, 2.0f * lambda / (float)F);
   if (!m.front) hipLaunchKernelGGL(k_gp, dim3((unsigned)F), dim3(256), 0, s, w.g, w.gt, w.gp_f, m.H, 2.0f * lambda / (float)F);
@@ -1222,19 +1220,14 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
       conv_fwd(src, kNoAct, P + l.w_off, nullptr, w.q[i], F, l, s);
       if (!(m.front && i < 2)) conv_bwd_w(src, kNoAct, w.ubar[i], Gd + l.w_off, F, l, w.part[0][i], &sums, s);
     }
-    hipLaunchKernelGGL(k_ln_bwd_bwd, dim3((unsigned)F), dim3(256), 0, s, w.q[i], w.abar[i], w.u[i] + 2 * F * l.n(),
-                       w.st[i] + 4 * F, P + l.gamma_off, P + l.beta_off, w.at[i], w.udir[i], w.pn[i], l.cout, l.hout);
+    hipLaunchKernelGGL(k_ln_bwd_bwd, dim3((unsigned)F), dim3(256), 0, s, w.q[i], i == L - 1 ? (const float*)nullptr : w.abar[i],
+                       w.u[i] + 2 * F * l.n(), w.st[i] + 4 * F, P + l.gamma_off, P + l.beta_off, w.at[i], w.udir[i], w.pn[i], l.cout, l.hout,
+                       i == L - 1 ? VDy{P + m.wd_off, 1.0f, 1.0f, 1.0f, F, 0} : kNoVDy);
     if (!(m.front && i < 2)) csums.e[csums.count++] = ChanSum{w.pn[i], Gd + l.gamma_off, F, l.cout, l.hout};   // adjoint of gamma
   }
   csums.e[csums.count++] = ChanSum{w.at[L - 1], Gd + m.wd_off, F, m.flat, 1};   // abar_top = w
-  // pass 4, all rows: upstream -1/F (x), +1/F (xh), 0 (xi)
-  const float cr = -1.0f / (float)F, cf = 1.0f / (float)F;
-  const DiscL& last = m.l[L - 1];
-  {
-    const int nb_d = (int)((B * m.flat + 255) / 256), nb_w = (m.flat + 1 + 255) / 256;
-    hipLaunchKernelGGL(k_dense_bwd, dim3((unsigned)(nb_d + nb_w)), dim3(256), 0, s, P + m.wd_off, w.da[L - 1], w.u[L - 1],
-                       act_of(last, P, w.st[L - 1]), last.hout, Gd + m.wd_off, Gd + m.bd_off, B, m.flat, F, cr, cf, 0.0f, nb_d);
-  }
+  // pass 4, all rows: upstream -1/F (x), +1/F (xh), 0 (xi) -- virtual at the last conv layer (VDy)
+  const VDy top{P + m.wd_off, cr, cf, 0.0f, F, 0};
   ParamGrads pgs;   // LayerNorm parameter gradients of all layers: one launch at the end
   pgs.count = 0;
   int up4_parts = 0;
@@ -1253,10 +1246,11 @@ int vaenpvc_disc_critic_fwd_bwd(const vaenpvc_disc* d, const float* d_dparams, c
     }
     const bool fr = false;
     if (!fr)
-    pgs.e[pgs.count++] = ParamGrad{w.da[i], w.u[i], w.st[i], P + l.gamma_off, P + l.beta_off, Gd + l.gamma_off, Gd + l.beta_off, B,
-                                   l.cout, l.hout};
-    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)B), dim3(256), 0, s, w.da[i], w.u[i], w.st[i], P + l.gamma_off,
-                       P + l.beta_off, w.udir[i], 2 * F, w.du[i], l.cout, l.hout);   // udir on the rows xi
+    pgs.e[pgs.count++] = ParamGrad{i == L - 1 ? (const float*)nullptr : w.da[i], w.u[i], w.st[i], P + l.gamma_off, P + l.beta_off,
+                                   Gd + l.gamma_off, Gd + l.beta_off, B, l.cout, l.hout, i == L - 1 ? top : kNoVDy};
+    hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)B), dim3(256), 0, s, i == L - 1 ? (const float*)nullptr : w.da[i], w.u[i], w.st[i],
+                       P + l.gamma_off, P + l.beta_off, w.udir[i], 2 * F, w.du[i], l.cout, l.hout,
+                       i == L - 1 ? top : kNoVDy);   // udir on the rows xi
     Act ai = i == 0 ? kNoAct : act_of(m.l[i - 1], P, w.st[i - 1]);
     if (l.dense) dense_wgrad(w.ain[i], w.du[i], w.dWd, Gd + l.w_off, B + F, l, s);   // (ain: the activated input kept by pass 1; + pass 3's rows)
     else if (!fr) conv_bwd_w(i == 0 ? w.rows : w.u[i - 1], ai, w.du[i], Gd + l.w_off, B, l, w.part[1][i], &sums, s);

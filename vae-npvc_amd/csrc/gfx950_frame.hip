@@ -40,7 +40,8 @@ static long long* prof_buf() {
 __global__ void __launch_bounds__(256) k_frame_pack(const float* __restrict__ P, POff off, float* __restrict__ pk,
                                                     float* __restrict__ zero, int nzero, float* __restrict__ zero2, int nzero2) {
   const int stride = gridDim.x * blockDim.x;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Pk::total; i += stride) pk[i] = pack_src(P, off, i);
+  if (pk)      // (null: only the zero fills -- a backward pass on weights packed by an earlier call)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Pk::total; i += stride) pk[i] = pack_src(P, off, i);
   // the step's zero fills ride along (gradient buffer, per-speaker sums of the merge backward): no memset launches
   if (zero)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += stride) zero[i] = 0.f;
@@ -234,9 +235,11 @@ bool frame_bwd_on(int64_t F) {
   return r.frame_max > 0 && F <= r.frame_max && ((r.bwd_mask >> 21) & 1u);
 }
 
-void frame_pack(const Model& m, const float* P, const Ws& w, float* G, float* zero2, int nzero2, hipStream_t s) {
+void frame_pack(const Model& m, const float* P, const Ws& w, float* G, float* zero2, int nzero2, hipStream_t s, bool zero_only) {
   // one packed element per thread: a thread that walks several elements pays an L2 round trip for each
-  hipLaunchKernelGGL(k_frame_pack, dim3((Pk::total + 255) / 256), dim3(256), 0, s, P, poff_of(m), w.frame_pk, G, G ? (int)m.n_params : 0, zero2, nzero2);
+  const int n = zero_only ? (int)m.n_params : Pk::total;
+  hipLaunchKernelGGL(k_frame_pack, dim3((n + 255) / 256), dim3(256), 0, s, P, poff_of(m), zero_only ? (float*)nullptr : w.frame_pk, G,
+                     G ? (int)m.n_params : 0, zero2, nzero2);
 }
 
 // Train steps run the 1025-tap layer outside the frame kernels (bit 18 of the backward mask, default set): needs the

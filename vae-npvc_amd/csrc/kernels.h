@@ -113,7 +113,7 @@ int64_t frame_lnp_floats(int64_t F);
 bool frame_fwd_on(int64_t F);
 bool frame_bwd_on(int64_t F);
 // packed weight copies; G_zero / zero2 (nullable): buffers zero-filled by the same launch
-void frame_pack(const Model& m, const float* P, const Ws& w, float* G_zero, float* zero2, int nzero2, hipStream_t s);
+void frame_pack(const Model& m, const float* P, const Ws& w, float* G_zero, float* zero2, int nzero2, hipStream_t s, bool zero_only = false);
 // scratch region the small-batch backward wants zeroed before it runs (per-speaker sums of the merge backward)
 float* frame_zero_region(const Ws& w, int* count);
 void frame_forward(const Model& m, const float* P, const float* x, const float* target, const int64_t* y, const float* eps,
