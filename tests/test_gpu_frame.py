@@ -183,3 +183,37 @@ def test_another_speaker_count_runs_on_the_generic_kernels():
         n = int(np.prod(shape))
         check('ny12 grad ' + name, grads[off:off + n].reshape(shape), G[name], TOL_GRAD, fails)
     assert not fails, '\n'.join(fails)
+
+
+def test_three_hundred_steps_on_both_paths_stay_together():
+    """300 Adam steps on one fixed 16-frame batch with the frame kernels and with the layered kernels (mask bit 21), same
+    seeds: finite, falling, and the two loss trajectories within 3 % of each other at every tenth of the run.  (Not tighter:
+    Adam turns 1e-6 differences of tiny gradient entries into lr-sized parameter differences, the two fp32 paths drift apart
+    chaotically while the loss falls from 770 to 470 -- measured gap 1 %; a race in the phase kernels or in the atomics of
+    the weight-gradient launch shows as NaNs or a run that stops falling.  scripts/soak_small_batch.py is the long form.)"""
+    from hipvae import Engine
+    from hipvae.dp import Stepper
+    g = torch.Generator().manual_seed(0)
+    F, N = 16, 300
+    traj = {}
+    for name, mask in (('frame', 0xffffffff), ('layered', 0xffffffff & ~(1 << 21))):
+        eng = Engine(ARCHS['vcc'])
+        eng.init_params(0)
+        eng.set_tuned_masks(mask, mask)
+        dev = eng.device
+        if name == 'frame':
+            x = torch.tanh(torch.randn(F, 513, generator=g)).to(dev)
+            y = torch.randint(0, 10, (F,), generator=g).to(dev)
+            eps = torch.randn(F, 128, generator=g).to(dev)
+        st = Stepper(eng, 1e-4, 0.5, 0.999)
+        out = []
+        for i in range(N):
+            l3 = st.step(x, y, eps)
+            if i % 30 == 0 or i == N - 1:
+                out.append(l3.clone())
+        traj[name] = torch.stack(out).cpu()
+    a, b = traj['frame'], traj['layered']
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert a[-1, 0] < 0.8 * a[0, 0]
+    gap = ((a - b).abs() / b.abs().clamp_min(1.0)).max().item()
+    assert gap < 3e-2, gap
