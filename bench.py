@@ -299,7 +299,9 @@ def main(argv=None):
             ms, n = eng.timer_read()
             eng.timer_select(None)
             if n:
-                kern = (ms / n, n)
+                # duration of the SITE per step: a site may be several launches (the 1025-tap weight gradient is one launch per
+                # q tile since round 3); `n` = launches counted
+                kern = (ms / steps, n, steps)
         return max_over_ranks(dt), kern
 
     F = args.frames
@@ -390,7 +392,7 @@ def main(argv=None):
         return k
 
     def roofline_of(prec_name, npl, kern):
-        avg_ms, n = kern
+        avg_ms, n, nsteps = kern
         ach = DEC3_FLOP_PER_FRAME * F / (avg_ms * 1e-3) / 1e12
         # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (separate
         # --pmc runs of this same command, FETCH_SIZE/WRITE_SIZE in KiB; see profiles/README.md)
@@ -406,7 +408,8 @@ def main(argv=None):
         peak = (BF16_PEAK / PRODUCTS[npl] if bf16 else FP32_PEAK) / 1e12
         return {'bound': 'mfma', 'kernel': args.timer_tag, 'precision': prec_name, 'achieved': ach, 'peak': peak,
                 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
-                'avg_kernel_ms': avg_ms, 'launches': n,
+                'avg_kernel_ms': avg_ms, 'launches': n, 'launches_per_step': n / nsteps,
+                'avg_kernel_ms_note': 'duration of the kernel site per step = sum of its launches (the 1025-tap weight gradient: one launch per q tile)',
                 'algorithmic_flops_per_launch': DEC3_FLOP_PER_FRAME * F,
                 'peak_basis': ('dense bf16 MFMA peak / %d (%d-term operand split: %d bf16 products per fp32 product)'
                                % (PRODUCTS[npl], npl, PRODUCTS[npl]) if bf16
