@@ -7,7 +7,7 @@ ROOT=$(cd $(dirname $0)/.. && pwd)
 OUT=$ROOT/variants/$NAME
 mkdir -p $OUT
 cd $ROOT/vae-npvc_amd/csrc
-for f in abi.hip runtime.hip generic_kernels.hip misc_kernels.hip disc.hip gfx950_layers.hip; do
+for f in abi.hip runtime.hip generic_kernels.hip misc_kernels.hip disc.hip gfx950_*.hip; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $FLAGS -c $f -o $OUT/${f%.hip}.o &
 done
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -x hip -c model.cpp -o $OUT/model.o &

@@ -28,6 +28,41 @@ __device__ __forceinline__ f32x16 zero16() {
   for (int i = 0; i < 16; ++i) z[i] = 0.f;
   return z;
 }
+// Streaming accesses: tensors of hundreds of MB that are touched once per kernel gain nothing from the caches; the
+// nontemporal forms of the loads and stores (measured on the LayerNorm backward passes alone: 7.73 -> 7.64 ms per step)
+// keep them from evicting what IS reused.  One switch per kernel group so that each can be A/B-built
+// (scripts/build_variant.sh NAME "-DVAENPVC_NT_x=0", scripts/ab_libs.sh): A = LayerNorm backward passes (AS: their store), E = encoder layer 0's
+// kernels (measured: +80 us, off), B = plane producers (measured: +35 us per step, the consumer finds freshly written planes in the Infinity Cache
+// otherwise -- off), T = result stores of the 1025-tap layer's input gradient (-15 us).  Tried and removed: the fused conv kernels' result
+// stores as nontemporal 4-byte stores (+310 us), their staging loads (no difference).
+#ifndef VAENPVC_NT_A
+#define VAENPVC_NT_A 1
+#endif
+#ifndef VAENPVC_NT_B
+#define VAENPVC_NT_B 0
+#endif
+#ifndef VAENPVC_NT_E
+#define VAENPVC_NT_E 0
+#endif
+#ifndef VAENPVC_NT_AS
+#define VAENPVC_NT_AS 1
+#endif
+#ifndef VAENPVC_NT_T
+#define VAENPVC_NT_T 1
+#endif
+// 16 bytes at 4-byte alignment (rows of 513 floats): the nontemporal builtins take vector types, not structs
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+template <int ON, class T>
+__device__ __forceinline__ T ld_nt(const T* p) {
+  if constexpr (ON) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <int ON, class T>
+__device__ __forceinline__ void st_nt(T* p, T v) {
+  if constexpr (ON) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 // row of accumulator register `reg` for this lane inside a 32x32 tile
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 

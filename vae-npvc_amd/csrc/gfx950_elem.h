@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) k_enc0_fwd_wave(const float* __restrict__
       if (j < HO) {
 #pragma unroll
         for (int o = 0; o < CO; ++o) {
-          af[o * HO + j] = v[k][o];
+          st_nt<VAENPVC_NT_E>(af + o * HO + j, v[k][o]);
           const float d = v[k][o] - mean;
           q += d * d;
         }
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256, 2) k_enc0_bwd_wave(const float* __restric
     for (int k = 0; k < 3; ++k) {
       const int j = lane + 64 * k;
 #pragma unroll
-      for (int o = 0; o < CO; ++o) dn[k][o] = j < HO ? df[o * HO + j] : 0.f;
+      for (int o = 0; o < CO; ++o) dn[k][o] = j < HO ? ld_nt<VAENPVC_NT_E>(df + o * HO + j) : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -444,8 +444,8 @@ __global__ void __launch_bounds__(256) k_ln_bwd_fused(const float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       int i = tid + 256 * k;
-      dn[k] = i < N ? pd[i] : 0.f;
-      xh[k] = i < N ? pa[i] : mean;
+      dn[k] = i < N ? ld_nt<VAENPVC_NT_A>(pd + i) : 0.f;
+      xh[k] = i < N ? ld_nt<VAENPVC_NT_A>(pa + i) : mean;
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(256) k_ln_bwd_fused(const float* __restrict__ 
       int i = tid + 256 * k;
       float d = rstd * (dn[k] * g[k] - s1 - xh[k] * s2);
       if (i < N) {
-        po[i] = d;
+        st_nt<VAENPVC_NT_A && VAENPVC_NT_AS>(po + i, d);
         su[k] += dn[k] * xh[k];
         sw[k] += dn[k];
         sd[k] += d;

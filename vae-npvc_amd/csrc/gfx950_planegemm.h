@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) k_split_planes(SplitArgs a) {
     u32x4 pk[NPL];
     pack8<NPL>(v, pk);
 #pragma unroll
-    for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(a.dst + ((int64_t)p * a.rows + r) * a.Kp + k0) = pk[p];
+    for (int p = 0; p < NPL; ++p) st_nt<VAENPVC_NT_B>(reinterpret_cast<u32x4*>(a.dst + ((int64_t)p * a.rows + r) * a.Kp + k0), pk[p]);
   }
 }
 

@@ -434,6 +434,9 @@ __global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(cons
 #pragma unroll
               for (int nb = 0; nb < 4; ++nb) atomicAdd(o + nb, acc[mb][nb][reg] + bb);
             } else {  // rows are only 4-byte aligned (513 bins): packed 16-byte store
+              if constexpr (VAENPVC_NT_T && !FWD)
+                st_nt<1>(reinterpret_cast<f32x4_a4*>(o), f32x4_a4{acc[mb][0][reg] + bb, acc[mb][1][reg] + bb, acc[mb][2][reg] + bb, acc[mb][3][reg] + bb});
+              else
               *reinterpret_cast<packed4*>(o) = packed4{acc[mb][0][reg] + bb, acc[mb][1][reg] + bb, acc[mb][2][reg] + bb, acc[mb][3][reg] + bb};
             }
           }
@@ -530,7 +533,7 @@ __global__ void __launch_bounds__(256) k_ln_stats_act_planes(const float* __rest
     u32x4 pkv[NPL];
     pack8<NPL>(o, pkv);
 #pragma unroll
-    for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(ypf + (p * TB_C + c) * TB_KP + 8 * lane) = pkv[p];
+    for (int p = 0; p < NPL; ++p) st_nt<VAENPVC_NT_B>(reinterpret_cast<u32x4*>(ypf + (p * TB_C + c) * TB_KP + 8 * lane), pkv[p]);
   }
   if (lane < TB_C) {  // bin 512 of channel `lane`, and the zero padding 513..527 of its plane rows
     const int c = lane;

@@ -63,8 +63,8 @@ __global__ void __launch_bounds__(256) k_cl_produce(CpArgs a) {
     for (int i = 0; i < PER; ++i) {
       const int idx = lane + 64 * i;
       if constexpr (V4) {
-        const float4 t = idx < NV ? reinterpret_cast<const float4*>(sf)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-        v[i][0] = t.x, v[i][1] = t.y, v[i][2] = t.z, v[i][3] = t.w;
+        const f32x4 t = idx < NV ? ld_nt<VAENPVC_NT_B>(reinterpret_cast<const f32x4*>(sf) + idx) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[i][0] = t[0], v[i][1] = t[1], v[i][2] = t[2], v[i][3] = t[3];
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[i][j] = 4 * idx + j < N ? sf[4 * idx + j] : 0.f;
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) k_cl_produce(CpArgs a) {
       u32x4 pk[NPL];
       pack8<NPL>(v8, pk);
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(df + p * a.plane + (int64_t)it * 8) = pk[p];
+      for (int p = 0; p < NPL; ++p) st_nt<VAENPVC_NT_B>(reinterpret_cast<u32x4*>(df + p * a.plane + (int64_t)it * 8), pk[p]);
     }
     __builtin_amdgcn_wave_barrier();
   }
