@@ -31,18 +31,15 @@ __device__ __forceinline__ f32x16 zero16() {
 // Streaming accesses: tensors of hundreds of MB that are touched once per kernel gain nothing from the caches; the
 // nontemporal forms of the loads and stores (measured on the LayerNorm backward passes alone: 7.73 -> 7.64 ms per step)
 // keep them from evicting what IS reused.  One switch per kernel group so that each can be A/B-built
-// (scripts/build_variant.sh NAME "-DVAENPVC_NT_x=0", scripts/ab_libs.sh): A = LayerNorm backward passes (AS: their store), E = encoder layer 0's
-// kernels (measured: +80 us, off), B = plane producers (measured: +35 us per step, the consumer finds freshly written planes in the Infinity Cache
+// (scripts/build_variant.sh NAME "-DVAENPVC_NT_x=0", scripts/ab_libs.sh): A = LayerNorm backward passes (AS: their store), B = plane producers (measured: +35 us per step, the consumer finds freshly written planes in the Infinity Cache
 // otherwise -- off), T = result stores of the 1025-tap layer's input gradient (-15 us).  Tried and removed: the fused conv kernels' result
-// stores as nontemporal 4-byte stores (+310 us), their staging loads (no difference).
+// stores as nontemporal 4-byte stores (+310 us), their staging loads (no difference), encoder layer 0's store (+60 us) and
+// its backward kernel's loads (no difference), the loads of the statistics + plane pass of decoder layer 2 (no difference).
 #ifndef VAENPVC_NT_A
 #define VAENPVC_NT_A 1
 #endif
 #ifndef VAENPVC_NT_B
 #define VAENPVC_NT_B 0
-#endif
-#ifndef VAENPVC_NT_E
-#define VAENPVC_NT_E 0
 #endif
 #ifndef VAENPVC_NT_AS
 #define VAENPVC_NT_AS 1

@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) k_enc0_fwd_wave(const float* __restrict__
       if (j < HO) {
 #pragma unroll
         for (int o = 0; o < CO; ++o) {
-          st_nt<VAENPVC_NT_E>(af + o * HO + j, v[k][o]);
+          af[o * HO + j] = v[k][o];
           const float d = v[k][o] - mean;
           q += d * d;
         }
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256, 2) k_enc0_bwd_wave(const float* __restric
     for (int k = 0; k < 3; ++k) {
       const int j = lane + 64 * k;
 #pragma unroll
-      for (int o = 0; o < CO; ++o) dn[k][o] = j < HO ? ld_nt<VAENPVC_NT_E>(df + o * HO + j) : 0.f;
+      for (int o = 0; o < CO; ++o) dn[k][o] = j < HO ? df[o * HO + j] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
