@@ -34,7 +34,8 @@ __device__ __forceinline__ f32x16 zero16() {
 // (scripts/build_variant.sh NAME "-DVAENPVC_NT_x=0", scripts/ab_libs.sh): A = LayerNorm backward passes (AS: their store), B = plane producers (measured: +35 us per step, the consumer finds freshly written planes in the Infinity Cache
 // otherwise -- off), T = result stores of the 1025-tap layer's input gradient (-15 us).  Tried and removed: the fused conv kernels' result
 // stores as nontemporal 4-byte stores (+310 us), their staging loads (no difference), encoder layer 0's store (+60 us) and
-// its backward kernel's loads (no difference), the loads of the statistics + plane pass of decoder layer 2 (no difference).
+// its backward kernel's loads (no difference), the loads of the statistics + plane pass of decoder layer 2 (no difference),
+// the result stores of the plane GEMMs (+60 us) and of the view GEMMs (+370 us).
 #ifndef VAENPVC_NT_A
 #define VAENPVC_NT_A 1
 #endif
