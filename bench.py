@@ -462,7 +462,8 @@ def main(argv=None):
                    'frames_per_step_per_gpu': Fl, 'global_frames_per_step': Fl * world,
                    # these batch sizes run the frame kernels (fp32 vector arithmetic, one workgroup per frame: DESIGN.md section 11):
                    # priced against the packed-fp32 VECTOR peak (= the exact-fp32 MFMA figure, 157.3 TFLOP/s) and the HBM model
-                   'path': 'frame kernels: 6 launches per step' if Fl <= 512 else 'layered kernels',
+                   'path': ('frame kernels: 7 launches per step (the 1025-tap layer as two launches of its own)' if Fl <= 128 else
+                            'frame kernels: 6 launches per step' if Fl <= 512 else 'layered kernels'),
                    'fraction_of_fp32_vector_peak': Fl * nst / dt2 * FLOP_PER_FRAME_TRAIN / FP32_PEAK,
                    'fraction_of_hbm_model_B': (Fl * nst / dt2 * BYTES_PER_FRAME_TRAIN + nst / dt2 * BYTES_PER_STEP_PARAMS) / HBM_PEAK}
             # same step captured in a hipGraph (one launch per step instead of one per kernel); with N > 1 the
@@ -483,6 +484,30 @@ def main(argv=None):
                 lit['hipgraph'] = {'frames_per_s': world * Fl * nst / dtg, 'ms_per_step': dtg / nst * 1e3}
             except Exception as ex:       # noqa: BLE001  (capture support differs between RCCL builds)
                 lit['hipgraph'] = {'error': str(ex)[:200]}
+            # the trainer's own hot loop (trainer/vae.py:94-99: shuffle_batch dequeue -> sess.run(opt['g'])): the same step fed by
+            # the frame store's dequeue (host-side index draw + one gather / normalise kernel on resident records) instead of
+            # a resident batch
+            try:
+                import numpy as np
+                from analyzer import FrameStore, Tanhize
+                rng = np.random.default_rng(5 + rank)
+                recs = rng.standard_normal((20000, 1029)).astype(np.float32)
+                recs[:, :513] = rng.uniform(-12, -3, (20000, 513))
+                recs[:, -1] = rng.integers(0, arch['y_dim'], 20000)
+                store = FrameStore(recs, Fl, Tanhize(xmax=np.full(513, -3, np.float32), xmin=np.full(513, -12, np.float32)),
+                                   seed=11, rank=0, world=1, device=dev, capacity=256, min_after_dequeue=128, y_dim=arch['y_dim'])
+                for _ in range(10):
+                    st.step(*store.next_batch())
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(nst):
+                    st.step(*store.next_batch())
+                barrier()
+                dtl = max_over_ranks(time.perf_counter() - t0)
+                lit['with_dequeue'] = {'ms_per_step': dtl / nst * 1e3, 'frames_per_s': world * Fl * nst / dtl}
+                del store
+            except Exception as ex:       # noqa: BLE001
+                lit['with_dequeue'] = {'error': str(ex)[:200]}
             lits['F%d' % Fl] = lit
         out['config']['literal_batches'] = lits
         out['config']['literal_batch256'] = lits['F256']
