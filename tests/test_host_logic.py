@@ -325,3 +325,48 @@ def test_bounded_shuffler_state_roundtrip():
     assert not np.array_equal(fresh.next(16), want[0])    # (and it is not simply the start of the stream again)
     with pytest.raises(ValueError):
         BoundedShuffler([50, 70], capacity=64, min_after_dequeue=32).load_state_dict(sd)
+
+
+def test_index_ahead_same_stream_and_restore():
+    """Drawing the index stream a block of batches ahead hands out the SAME batches as one draw per iteration (both ranks'
+    slices), and a checkpoint taken in the middle of a block continues exactly where it stopped."""
+    import io
+    import torch
+    from analyzer import BoundedShuffler, IndexAhead
+
+    def mk(seed):
+        return BoundedShuffler([50, 70, 30], capacity=64, min_after_dequeue=32, seed=seed)
+
+    def draw(ia, n):
+        out = []
+        for _ in range(n):
+            blk = ia.next_block_if_due()
+            if blk is not None:
+                cur = blk
+            out.append(cur[ia.take()].copy())
+        return out, cur
+
+    plain = mk(5)
+    want = [plain.next(16) for _ in range(100)]
+    for lo, hi in ((0, 8), (8, 16)):
+        ia = IndexAhead(mk(5), 16, lo, hi)
+        got, cur = draw(ia, 45)                        # 45: in the middle of the second block of 32
+        assert all(np.array_equal(w[lo:hi], g) for w, g in zip(want, got))
+        buf = io.BytesIO()
+        torch.save({'source': ia.state_dict()}, buf)
+        buf.seek(0)
+        sd = torch.load(buf, map_location='cpu')['source']
+        assert sd['consumed'] == 45 - IndexAhead.AHEAD
+        ib = IndexAhead(mk(999), 16, lo, hi)
+        ib.load_state_dict(sd)
+        assert np.array_equal(ib._block, cur)          # the block in flight is drawn again, identically
+        rest = [ib._block[ib.take()].copy() for _ in range(IndexAhead.AHEAD - sd['consumed'])]
+        more, _ = draw(ib, 100 - 45 - len(rest))
+        assert all(np.array_equal(w[lo:hi], g) for w, g in zip(want[45:], rest + more))
+    # a state saved before the first draw, and an old checkpoint without the `consumed` field
+    ia = IndexAhead(mk(5), 16, 0, 16)
+    assert ia.state_dict()['consumed'] == 0
+    ib = IndexAhead(mk(1), 16, 0, 16)
+    ib.load_state_dict({'shuffler': mk(5).state_dict()})
+    got, _ = draw(ib, 3)
+    assert all(np.array_equal(w, g) for w, g in zip(want, got))
