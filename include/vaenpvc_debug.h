@@ -39,7 +39,10 @@ extern "C" {
  * weight gradients come from the layered kernels on two streams instead of the one-launch job list
  * (gfx950_frame_wgrad.h).  Bit 18 of the backward mask (default set): cleared = a small-batch train step keeps the 1025-tap
  * layer inside the two frame kernels instead of the two eight-workgroups-per-frame launches between them.  Bit 19 of the backward mask (default set): cleared = encoder layer 0's LayerNorm backward
- * and weight gradient as two passes instead of the fused kernel (k_enc0_bwd_wave, from 1024 frames on). */
+ * and weight gradient as two passes instead of the fused kernel (k_enc0_bwd_wave, from 1024 frames on).  Bit 17 of the
+ * backward mask (default set): cleared = the 1025-tap layer's weight gradient on the eight-wave kernel (64 x 64 wave tiles,
+ * k_toep_wgrad_bf16_k32) at every batch size instead of the four-wave kernel (128 x 128 wave tiles, operands by LDS-DMA:
+ * k_toep_wgrad_bf16_w4) from 4 096 frames on. */
 int vaenpvc_set_tuned_masks(vaenpvc_ctx* ctx, uint32_t fwd_mask, uint32_t bwd_mask);
 
 /* Measurement hook (no reference counterpart): brackets every launch of ONE tagged

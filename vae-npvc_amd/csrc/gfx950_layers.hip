@@ -865,6 +865,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       for_planes([&](auto npl) {
         constexpr int NPL = decltype(npl)::value;
         if constexpr (NPL <= 2) {
+          if (rt().toep_wgrad_w4 && bwd_on(17) && F >= 4096) {   // 128 x 128 wave tiles, operands by LDS-DMA: 8 x 4 x zc4 workgroups
+            const int zc4 = (int)cmax(1, cmin_(2 * rt().toep_zc, cdiv(F, 512)));
+            const int fch4 = rup(cdiv((int)F, zc4), W4_KF);
+            rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_wgrad_bf16_w4<NPL>), w4_lds(NPL));
+            VAENPVC_TIMED("dec3_wgrad", s2, hipLaunchKernelGGL(k_toep_wgrad_bf16_w4<NPL>, dim3(8 * 4 * (unsigned)cdiv((int)F, fch4)), dim3(256),
+                                                              w4_lds(NPL), s2, reinterpret_cast<const unsigned short*>(w.toep_yp), gp,
+                                                              G + m.dec[3].w_off, (int)F, fch4));
+            return;
+          }
           if (!rt().toep_wgrad_k16) {   // 32-frame chunks: two k-steps per barrier
             const int fch32 = rup(cdiv((int)F, zc), W2_KF);
             rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_wgrad_bf16_k32<NPL>), w2_lds(NPL));

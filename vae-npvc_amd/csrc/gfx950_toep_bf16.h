@@ -1003,5 +1003,288 @@ __global__ void __launch_bounds__(512, 2) k_toep_wgrad_bf16_k32(const unsigned s
   }
 }
 
+
+// ---- the weight gradient with 128 x 128 WAVE tiles: four waves (one per SIMD, 2 x 2) on a 256 (i) x 256 (q) tile.
+// k_toep_wgrad_bf16_k32 reads 9 KB of fragments from LDS per 12 MFMAs and wave and writes the staged chunk through
+// registers: ~125 bytes of LDS traffic per CU and clock at the MFMA rate, i.e. it is bound by the LDS (128 B/clk), not
+// by the matrix pipe.  Here a wave reads 18 KB per 51 MFMAs (65 B/clk per CU at the MFMA rate) and nothing passes
+// through staging registers:
+//   * operands arrive by LDS-DMA (global_load_lds_dwordx4, lane-linear 1-KiB blocks = two frames of 256 bins), into a
+//     ring of four 16-frame stages; a stage is requested four iterations before it is multiplied and waited for with a
+//     COUNTED vmcnt (the two newest requests may still be in flight), one bare s_barrier per stage;
+//   * rows are unpadded (512 B); the 16-byte piece index is XOR-ed with (frame & 3) << 2 on the way in (each lane picks
+//     its global piece) and on the way out, which puts the four frames of a transpose read into different 64-byte bank
+//     quarters;
+//   * the fragments of stage t + 1 are read between the MFMAs of stage t (two register sets, sched_group_barrier);
+//   * the q = 512 column is a matrix-VECTOR product: it runs on the vector ALU in the shadow of the MFMAs (12
+//     v_dot2_f32_bf16 per stage and wave on the y fragments the wave holds anyway, d(xh)[.][512] broadcast from the lane
+//     that read it), one fp32 register instead of a 17th accumulator tile (16 tiles = all 256 AGPRs).  The two q tiles
+//     of an i range split its eight row tiles between them, so all workgroups carry the same work (in k32 the odd q
+//     tiles carry 12.5 % more and the others wait for them at the end of the launch).  The wave's row tiles are rotated
+//     so that its strip tile is fragment slot 0 (the fragment addresses are per-lane registers anyway).
+#ifndef VAENPVC_W4_ABL
+#define VAENPVC_W4_ABL 0   // developer ablation of the main loop (wrong results): 1 no requests, 2 no fragment reads, 4 no wait / barrier, 8 no strip
+#endif
+constexpr int W4_KF = 16;                 // frames per stage = one MFMA k-step
+constexpr int W4_RS = 512;                // bytes per LDS row (256 bins)
+constexpr int W4_APL = W4_KF * W4_RS;     // bytes per plane, operand and stage
+constexpr int W4_E = 4096;                // strip: bins 512..575 of both planes (only 512 is used), one 1-KiB block per wave
+constexpr int W4_NS = 4;                  // ring slots
+constexpr int w4_stage(int npl) { return npl * 2 * W4_APL + W4_E; }   // 36 864 bytes at NPL = 2
+constexpr int w4_lds(int npl) { return W4_NS * w4_stage(npl); }       // 147 456
+template <int N>
+struct IntC {
+  static constexpr int value = N;
+};
+
+// LDS-DMA: every lane passes its own global address, the wave ONE LDS byte address (in M0); lane l's 16 bytes land at
+// base + 16 l (scripts/microbench/ldsdma.hip); completion is counted by vmcnt.  Written as inline assembly: behind the
+// builtin the compiler orders every later LDS read after the transfer with s_waitcnt vmcnt(0), which would undo the ring.
+__device__ __forceinline__ void lds_dma16(const unsigned char* g, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_wave_base), "v"(g) : "memory");
+}
+__device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// The requests run up to five stages (80 frames) past the last frame of the batch without clamping: the plane buffers are
+// sized for three planes (model.cpp), this kernel runs with at most two, so the addresses stay inside the buffers; rows of
+// frames >= F are cleared in LDS before they are multiplied (clear_tail), later stages are never multiplied.
+template <int NPL>
+__global__ void __launch_bounds__(256) k_toep_wgrad_bf16_w4(const unsigned short* __restrict__ yp,  // [F][NPL][8][528]
+                                                            const unsigned short* __restrict__ gp,  // [F][NPL][528]
+                                                            float* __restrict__ dW,                 // [1025][8] atomicAdd
+                                                            int F, int fchunk) {
+  static_assert(NPL <= 2, "ring of four stages, slack of the plane buffers: two planes");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using PR = Prod<NPL>;
+  constexpr int STAGE = w4_stage(NPL), BOFF = NPL * W4_APL, EOFF = 2 * NPL * W4_APL;
+  constexpr int NB = 2 * NPL;            // 1-KiB blocks per wave, operand and stage
+  constexpr int NDMA = 2 * NB + 1;       // DMA instructions per wave and stage
+  constexpr int NT8 = 9 * NPL;           // fragment reads (2 x ds_read_b64_tr_b16 each) per wave and stage
+  constexpr int NM = 16 * PR::N;         // MFMAs per wave and stage
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  // XCD = channel (workgroup b runs on XCD b % 8): a channel's y planes pass through ONE L2
+  const int c = blockIdx.x & 7, tl = (blockIdx.x >> 3) & 3, zc = blockIdx.x >> 5;
+  const int it = tl >> 1, qt = tl & 1, i0 = it * 256, q0 = qt * 256;
+  const int fb = zc * fchunk, fe = min(F, fb + fchunk);
+  if (fb >= fe) return;
+  const int nst = (fe - fb + W4_KF - 1) / W4_KF;
+  const int eri = 2 * qt + wc;           // this wave's strip row tile; fragment slot ri holds row tile (ri + eri) & 3
+
+  // ---- DMA: block k of this wave = (plane, frame pair) of the stage; lane -> (frame 2 fp + (lane >> 5), LDS piece lane & 31);
+  //      the piece fetched is (lane & 31) ^ ((frame & 3) << 2).  Strip block of wave w: frames 4 w ..+3, both planes, bins
+  //      512..575: lane -> (plane lane >> 5, frame (lane >> 3) & 3, piece lane & 7)
+  constexpr size_t YF = (size_t)NPL * TB_C * TB_KP * 2, GF = (size_t)NPL * TB_KP * 2;   // bytes per frame
+  const unsigned char* Y8 = reinterpret_cast<const unsigned char*>(yp);
+  const unsigned char* G8 = reinterpret_cast<const unsigned char*>(gp);
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned char* src[NDMA];        // per-lane addresses of stage 0, advanced by a scalar per stage
+  unsigned dst[NDMA];                    // wave-uniform LDS offsets inside a stage
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const int bid = wave * NB + k, pl = bid >> 3, fp = bid & 7, fr = 2 * fp + lh;
+    const int gpc = l31 ^ ((fr & 3) << 2);
+    src[2 * k] = Y8 + (size_t)(fb + fr) * YF + ((size_t)pl * TB_C + c) * (TB_KP * 2) + i0 * 2 + gpc * 16;
+    src[2 * k + 1] = G8 + (size_t)(fb + fr) * GF + (size_t)pl * (TB_KP * 2) + q0 * 2 + gpc * 16;
+    dst[2 * k] = pl * W4_APL + fp * 1024;
+    dst[2 * k + 1] = BOFF + pl * W4_APL + fp * 1024;
+  }
+  {
+    const int pl = min(lh, NPL - 1), fr = 4 * wave + ((lane >> 3) & 3);
+    src[2 * NB] = G8 + (size_t)(fb + fr) * GF + (size_t)pl * (TB_KP * 2) + (64 + (lane & 7)) * 16;
+    dst[2 * NB] = EOFF + wave * 1024;
+  }
+  // request g of stage s into ring slot `slot`
+  auto dma = [&](int g, int s, int slot) __attribute__((always_inline)) {
+    const size_t off = (size_t)s * (W4_KF * ((g & 1) || g == 2 * NB ? GF : YF));
+    lds_dma16(src[g] + off, lds0 + slot * STAGE + dst[g]);
+  };
+  // rows of frames >= F (nv valid rows) of a landed stage are cleared: y planes, d(xh) planes and the strip
+  auto clear_tail = [&](int slot, int nv) __attribute__((always_inline)) {
+    unsigned char* sb = smem + slot * STAGE;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int i = tid; i < 2 * NPL * W4_KF * 32; i += 256)   // [operand][plane][row][32 pieces]
+      if (((i >> 5) & (W4_KF - 1)) >= nv) *reinterpret_cast<u32x4*>(sb + i * 16) = z;
+    for (int i = tid; i < W4_E / 16; i += 256)              // [wave][plane][row & 3][8 pieces]
+      if (4 * (i >> 6) + ((i >> 3) & 3) >= nv) *reinterpret_cast<u32x4*>(sb + EOFF + i * 16) = z;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  const int last_nv = (fe - fb) - (nst - 1) * W4_KF;   // valid frames of the last stage (16: nothing to clear)
+
+  // ---- fragment addresses (transpose reads): lane -> frame row ((l & 15) >> 2) + 8 lh (second read: + 4), bins 4 (l & 3) + 16 ((l >> 4) & 1) ..+3
+  const int trow = ((lane & 15) >> 2) + 8 * lh, tcol = 4 * (lane & 3) + 16 * ((lane >> 4) & 1), s3 = trow & 3;
+  int a_off[4], b_off[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rt = (r + eri) & 3;
+    a_off[r] = trow * W4_RS + (16 * wr + ((rt ^ s3) << 2) + (tcol >> 3)) * 16 + (tcol & 7) * 2;
+    b_off[r] = BOFF + trow * W4_RS + (16 * wc + ((r ^ s3) << 2) + (tcol >> 3)) * 16 + (tcol & 7) * 2;
+  }
+  const int e_off = EOFF + (trow >> 2) * 1024 + (trow & 3) * 128 + (tcol & 15) * 2;   // (+ 512 per plane, + 1024 for frames + 4)
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj) acc[ri][cj] = zero16();
+  float acce = 0.f;   // row l31 of the strip tile, frames 8 lh .. 8 lh + 7 of every stage
+  const int bsrc = 4 * (lane & 32);   // ds_bpermute source: the lane of this half that holds bin 512
+  u32x4 fa[2][4][NPL], fq[2][4][NPL], fx[2][NPL];
+  unsigned bx[NPL][4];
+  // fragment read j of a stage: y row tiles, d(xh) column tiles, strip
+  auto rd = [&](int set, int slot, int j) __attribute__((always_inline)) {
+    const unsigned char* sb = smem + slot * STAGE;
+    if (j < 4 * NPL)
+      fa[set][j / NPL][j % NPL] = tr_read8(sb + (j % NPL) * W4_APL + a_off[j / NPL], 4 * W4_RS);
+    else if (j < 8 * NPL)
+      fq[set][(j - 4 * NPL) / NPL][j % NPL] = tr_read8(sb + (j % NPL) * W4_APL + b_off[(j - 4 * NPL) / NPL], 4 * W4_RS);
+    else if (j < NT8)
+      fx[set][j - 8 * NPL] = tr_read8(sb + (j - 8 * NPL) * 512 + e_off, 1024);
+  };
+  // MFMA m of a stage: product t = m >> 4 outermost (consecutive MFMAs touch different accumulators)
+  auto mm = [&](int set, int m) __attribute__((always_inline)) {
+    const int t = m >> 4, ri = (m >> 2) & 3, cj = m & 3;
+    acc[ri][cj] = mfma_bf16(fa[set][ri][PR::A[t]], fq[set][cj][PR::B[t]], acc[ri][cj]);
+  };
+  // strip: lane (l31, lh) of a B fragment holds bin l31, frames 8 lh ..+7 -- bin 512 is lane 32 lh: broadcast early in
+  // the stage (cross-lane reads have LDS latency), multiplied on the vector ALU at its end
+  auto bcast = [&](int set, int j) __attribute__((always_inline)) {
+    if (j < 4 * NPL) bx[j >> 2][j & 3] = (unsigned)__builtin_amdgcn_ds_bpermute(bsrc, (int)fx[set][j >> 2][j & 3]);
+  };
+
+  // ---- prologue: stages 0 .. 3 requested, 0 and 1 landed
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int g = 0; g < NDMA; ++g) dma(g, s, s);
+  wait_vmcnt<2 * NDMA>();
+  __builtin_amdgcn_s_barrier();
+  if (last_nv < W4_KF && nst <= 2) clear_tail(nst - 1, last_nv);
+#pragma unroll
+  for (int j = 0; j < NT8; ++j) rd(0, 0, j);
+
+  // iteration t (slot S = t & 3, fragment set S & 1): the fragments of stage t are in registers, so its slot is free:
+  // stage t + 4 is requested into it; stage t is multiplied while the fragments of stage t + 1 are read; at the end
+  // stage t + 2 must have landed (t + 3 and t + 4 may be in flight: a stage has three iterations to arrive).  A wave
+  // issues in order and one wave runs per SIMD: whatever stands between two MFMAs must fit the 32 cycles of the first, so
+  // the requests are spread over the stage, ONE between two pairs of MFMAs (with two fragment reads and a broadcast)
+  auto body = [&](auto S_, int t) __attribute__((always_inline)) {
+    constexpr int S = decltype(S_)::value;
+#pragma unroll
+    for (int g = 0; g < NDMA; ++g) {
+      if (!(VAENPVC_W4_ABL & 2)) {
+        rd((S + 1) & 1, (S + 1) & 3, 2 * g);
+        rd((S + 1) & 1, (S + 1) & 3, 2 * g + 1);
+      }
+      mm(S & 1, 2 * g);
+      mm(S & 1, 2 * g + 1);
+      if (!(VAENPVC_W4_ABL & 8)) bcast(S & 1, g);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(VAENPVC_W4_ABL & 1)) dma(g, t + 4, S);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    static_assert(2 * NDMA >= NT8 && 2 * NDMA <= NM && NDMA >= 4 * NPL, "groups cover the reads and the broadcasts");
+#pragma unroll
+    for (int m = 2 * NDMA; m < NM; ++m) mm(S & 1, m);
+    if (!(VAENPVC_W4_ABL & 8)) {
+#pragma unroll
+      for (int tp = 0; tp < PR::N; ++tp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acce = dot2_bf16(fa[S & 1][0][PR::A[tp]][r], bx[PR::B[tp]][r], acce);
+      asm volatile("" : "+v"(acce));   // keeps the dot products in this stage (they would be sunk past the barrier otherwise)
+      WG_INTERLEAVE(4 * PR::N, 0x002, 1);   // one dot product behind each of the next MFMAs
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(VAENPVC_W4_ABL & 4)) {
+      wait_vmcnt<2 * NDMA>();
+      __builtin_amdgcn_s_barrier();
+    }
+    if (last_nv < W4_KF && t + 2 == nst - 1) clear_tail((S + 2) & 3, last_nv);   // uniform, once per launch at most
+  };
+  int t = 0;
+  for (; t + 4 <= nst; t += 4) {
+    body(IntC<0>{}, t);
+    body(IntC<1>{}, t + 1);
+    body(IntC<2>{}, t + 2);
+    body(IntC<3>{}, t + 3);
+  }
+  if (t < nst) {
+    body(IntC<0>{}, t);
+    if (t + 1 < nst) {
+      body(IntC<1>{}, t + 1);
+      if (t + 2 < nst) body(IntC<2>{}, t + 2);
+    }
+  }
+  wait_vmcnt<0>();   // requests past the last stage are still writing into the ring
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: the 511 diagonals of the 256 x 256 tile, WITHOUT LDS atomics (a wave-level ds_add_f32 takes ~150 cycles:
+  //      the 256 per lane of the straightforward reduction cost 80 us of a 400 us launch).  (1) In registers: the 16 tiles
+  //      of a wave lie on 7 tile diagonals (column tile - row tile); tiles of one tile diagonal are added element-wise.
+  //      (2) The 7 sums go to LDS as 32 x 32 blocks (row pitch 33 floats).  (3) Thread D adds up diagonal D of the tile
+  //      from the (at most two) blocks of every wave that cross it and issues the ONE global atomic of that diagonal.
+  constexpr int BLK = 32 * 33;
+  float* blk = reinterpret_cast<float*>(smem);   // [wave][7][32][33]: 118 272 bytes of the (now idle) ring
+  {
+    f32x16 R[7];
+    auto reduce = [&](auto E_) __attribute__((always_inline)) {
+      constexpr int E = decltype(E_)::value;
+#pragma unroll
+      for (int d = 0; d < 7; ++d) {
+        bool first = true;
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+          for (int cj = 0; cj < 4; ++cj)
+            if (cj - ((ri + E) & 3) + 3 == d) {
+              R[d] = first ? acc[ri][cj] : R[d] + acc[ri][cj];
+              first = false;
+            }
+      }
+    };
+    if (eri == 0) reduce(IntC<0>{});
+    else if (eri == 1) reduce(IntC<1>{});
+    else if (eri == 2) reduce(IntC<2>{});
+    else reduce(IntC<3>{});
+#pragma unroll
+    for (int d = 0; d < 7; ++d)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) blk[(wave * 7 + d) * BLK + acc_row(reg, lane) * 33 + l31] = R[d][reg];
+  }
+  __syncthreads();
+  for (int D = tid; D < 511; D += 256) {
+    const int e = D - 255;   // column - row inside the workgroup tile
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int x = e - 128 * ((w & 1) - (w >> 1));   // = 32 td + bd inside wave w's tile, |td| <= 3, |bd| <= 31
+      const int td1 = (x + 512) / 32 - 16;            // floor(x / 32)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int td = td1 + k, bd = x - 32 * td;
+        if (td >= -3 && td <= 3 && bd >= -31 && bd <= 31) {
+          const float* bp = blk + (w * 7 + td + 3) * BLK + bd;
+          const int r0 = bd < 0 ? -bd : 0, r1 = bd > 0 ? 32 - bd : 32;
+          for (int r = r0; r < r1; ++r) v += bp[r * 34];
+        }
+      }
+    }
+    atomicAdd(dW + (q0 - i0 + e + 512) * TB_C + c, v);
+  }
+  {   // the q = 512 column: t = 1024 - i; the two halves of the wave hold the two frame octets of row l31
+    const float tot = acce + __shfl_xor(acce, 32);
+    if (lh == 0) atomicAdd(dW + (1024 - (i0 + 128 * wr + 32 * eri + l31)) * TB_C + c, tot);
+  }
+}
+
 }  // namespace tuned
 }  // namespace vaenpvc

@@ -41,6 +41,7 @@ struct Runtime {
   int toep_zc = 4;              // VAENPVC_TOEP_ZC: frame chunks of the Toeplitz weight gradient, 64 workgroups each (4: one workgroup per CU, one prologue / epilogue per CU)
   bool toep_f32 = false;        // VAENPVC_TOEP=f32: exact-fp32 MFMA kernels for the 1025-tap layer
   bool toep_wgrad_f32 = false;  // VAENPVC_TOEP_WGRAD_F32
+  bool toep_wgrad_w4 = true;    // VAENPVC_TOEP_WGRAD_W4=0: the eight-wave kernel (64 x 64 wave tiles) at every batch size
   bool toep_wgrad_k16 = false;  // VAENPVC_TOEP_WGRAD_K16: 16-frame chunks in the bf16 weight gradient (A/B measurements)
   bool side_enabled = true;     // VAENPVC_SIDE_STREAM=0 disables the internal weight-gradient stream
   int frame_max = 512;          // VAENPVC_FRAME_MAX: largest batch on the whole-frame-per-workgroup kernels (gfx950_frame.h); 0 = never.

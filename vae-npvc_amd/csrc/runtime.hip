@@ -36,6 +36,7 @@ void Runtime::read_env() {
   if (const char* e = getenv("VAENPVC_FRAME_MAX")) frame_max = atoi(e) < 0 ? 0 : (atoi(e) > 1024 ? 1024 : atoi(e));
   tn_k16 = getenv("VAENPVC_TN_K16") != nullptr;
   toep_wgrad_k16 = getenv("VAENPVC_TOEP_WGRAD_K16") != nullptr;
+  if (const char* e = getenv("VAENPVC_TOEP_WGRAD_W4")) toep_wgrad_w4 = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_CV_SITES")) cv_sites_env = (long)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_FCR_SITES")) fcr_sites_env = (long)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_FW_SITES")) fw_sites_env = (long)strtoul(e, nullptr, 0);
