@@ -1135,10 +1135,8 @@ __global__ void __launch_bounds__(256) k_toep_wgrad_bf16_w4(const unsigned short
   for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
     for (int cj = 0; cj < 4; ++cj) acc[ri][cj] = zero16();
-  float acce = 0.f;   // row l31 of the strip tile, frames 8 lh .. 8 lh + 7 of every stage
-  const int bsrc = 4 * (lane & 32);   // ds_bpermute source: the lane of this half that holds bin 512
+  float accl = 0.f, acch = 0.f;   // row l31 of the strip tile times frames 0..7 / 8..15 of every stage (lanes of half lh keep the one that matches their fragment)
   u32x4 fa[2][4][NPL], fq[2][4][NPL], fx[2][NPL];
-  unsigned bx[NPL][4];
   // fragment read j of a stage: y row tiles, d(xh) column tiles, strip
   auto rd = [&](int set, int slot, int j) __attribute__((always_inline)) {
     const unsigned char* sb = smem + slot * STAGE;
@@ -1154,12 +1152,6 @@ __global__ void __launch_bounds__(256) k_toep_wgrad_bf16_w4(const unsigned short
     const int t = m >> 4, ri = (m >> 2) & 3, cj = m & 3;
     acc[ri][cj] = mfma_bf16(fa[set][ri][PR::A[t]], fq[set][cj][PR::B[t]], acc[ri][cj]);
   };
-  // strip: lane (l31, lh) of a B fragment holds bin l31, frames 8 lh ..+7 -- bin 512 is lane 32 lh: broadcast early in
-  // the stage (cross-lane reads have LDS latency), multiplied on the vector ALU at its end
-  auto bcast = [&](int set, int j) __attribute__((always_inline)) {
-    if (j < 4 * NPL) bx[j >> 2][j & 3] = (unsigned)__builtin_amdgcn_ds_bpermute(bsrc, (int)fx[set][j >> 2][j & 3]);
-  };
-
   // ---- prologue: stages 0 .. 3 requested, 0 and 1 landed
 #pragma unroll
   for (int s = 0; s < 4; ++s)
@@ -1178,29 +1170,37 @@ __global__ void __launch_bounds__(256) k_toep_wgrad_bf16_w4(const unsigned short
   // the requests are spread over the stage, ONE between two pairs of MFMAs (with two fragment reads and a broadcast)
   auto body = [&](auto S_, int t) __attribute__((always_inline)) {
     constexpr int S = decltype(S_)::value;
+    // slots: every MFMA is followed by ONE small piece of other work -- a fragment read (two ds_read_b64_tr_b16), or a
+    // request (address add, M0, transfer)
 #pragma unroll
     for (int g = 0; g < NDMA; ++g) {
-      if (!(VAENPVC_W4_ABL & 2)) {
-        rd((S + 1) & 1, (S + 1) & 3, 2 * g);
-        rd((S + 1) & 1, (S + 1) & 3, 2 * g + 1);
-      }
-      mm(S & 1, 2 * g);
-      mm(S & 1, 2 * g + 1);
-      if (!(VAENPVC_W4_ABL & 8)) bcast(S & 1, g);
+      mm(S & 1, 3 * g);
+      if (!(VAENPVC_W4_ABL & 2)) rd((S + 1) & 1, (S + 1) & 3, 2 * g);
       __builtin_amdgcn_sched_barrier(0);
+      mm(S & 1, 3 * g + 1);
+      if (!(VAENPVC_W4_ABL & 2)) rd((S + 1) & 1, (S + 1) & 3, 2 * g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(S & 1, 3 * g + 2);
       if (!(VAENPVC_W4_ABL & 1)) dma(g, t + 4, S);
       __builtin_amdgcn_sched_barrier(0);
     }
-    static_assert(2 * NDMA >= NT8 && 2 * NDMA <= NM && NDMA >= 4 * NPL, "groups cover the reads and the broadcasts");
+    static_assert(2 * NDMA >= NT8 && 3 * NDMA <= NM, "slots cover the reads");
 #pragma unroll
-    for (int m = 2 * NDMA; m < NM; ++m) mm(S & 1, m);
+    for (int m = 3 * NDMA; m < NM; ++m) mm(S & 1, m);
     if (!(VAENPVC_W4_ABL & 8)) {
+      // strip: lane (l31, lh) of a B fragment holds bin l31, frames 8 lh ..+7 -- bin 512 sits in lanes 0 and 32.  Both go
+      // to scalar registers (no LDS cross-lane traffic); every lane multiplies with both, the half is chosen at the end
 #pragma unroll
       for (int tp = 0; tp < PR::N; ++tp)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acce = dot2_bf16(fa[S & 1][0][PR::A[tp]][r], bx[PR::B[tp]][r], acce);
-      asm volatile("" : "+v"(acce));   // keeps the dot products in this stage (they would be sunk past the barrier otherwise)
-      WG_INTERLEAVE(4 * PR::N, 0x002, 1);   // one dot product behind each of the next MFMAs
+        for (int r = 0; r < 4; ++r) {
+          const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)fx[S & 1][PR::B[tp]][r], 0);
+          const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)fx[S & 1][PR::B[tp]][r], 32);
+          accl = dot2_bf16(fa[S & 1][0][PR::A[tp]][r], lo, accl);
+          acch = dot2_bf16(fa[S & 1][0][PR::A[tp]][r], hi, acch);
+        }
+      asm volatile("" : "+v"(accl), "+v"(acch));   // keeps the dot products in this stage (they would be sunk past the barrier otherwise)
+      WG_INTERLEAVE(NM - 3 * NDMA - 1, 0x002, 2);  // two vector instructions behind each of the remaining MFMAs
     }
     __builtin_amdgcn_sched_barrier(0);
     if (!(VAENPVC_W4_ABL & 4)) {
@@ -1281,6 +1281,7 @@ __global__ void __launch_bounds__(256) k_toep_wgrad_bf16_w4(const unsigned short
     atomicAdd(dW + (q0 - i0 + e + 512) * TB_C + c, v);
   }
   {   // the q = 512 column: t = 1024 - i; the two halves of the wave hold the two frame octets of row l31
+    const float acce = lh ? acch : accl;
     const float tot = acce + __shfl_xor(acce, 32);
     if (lh == 0) atomicAdd(dW + (1024 - (i0 + 128 * wr + 32 * eri + l31)) * TB_C + c, tot);
   }
