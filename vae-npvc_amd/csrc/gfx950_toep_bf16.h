@@ -1070,8 +1070,17 @@ __global__ void __launch_bounds__(256) k_toep_wgrad_bf16_w4(const unsigned short
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  // XCD = channel (workgroup b runs on XCD b % 8): a channel's y planes pass through ONE L2
+#ifndef VAENPVC_W4_XCD
+#define VAENPVC_W4_XCD 1
+#endif
+  // XCD-aware order (workgroup b runs on XCD b % 8).  XCD = frame chunk: the 32 workgroups of a chunk (8 channels x 4 tiles)
+  // walk the same frames in step, so a chunk's y planes AND its d(xh) planes pass through one L2, once (with XCD = channel
+  // every XCD fetched all of d(xh): 1.96 x the algorithmic bytes)
+#if VAENPVC_W4_XCD
+  const int zc = blockIdx.x % (gridDim.x >> 5), rest = blockIdx.x / (gridDim.x >> 5), tl = rest & 3, c = rest >> 2;
+#else
   const int c = blockIdx.x & 7, tl = (blockIdx.x >> 3) & 3, zc = blockIdx.x >> 5;
+#endif
   const int it = tl >> 1, qt = tl & 1, i0 = it * 256, q0 = qt * 256;
   const int fb = zc * fchunk, fe = min(F, fb + fchunk);
   if (fb >= fe) return;
