@@ -42,7 +42,8 @@ extern "C" {
  * and weight gradient as two passes instead of the fused kernel (k_enc0_bwd_wave, from 1024 frames on).  Bit 17 of the
  * backward mask (default set): cleared = the 1025-tap layer's weight gradient on the eight-wave kernel (64 x 64 wave tiles,
  * k_toep_wgrad_bf16_k32) at every batch size instead of the four-wave kernel (128 x 128 wave tiles, operands by LDS-DMA:
- * k_toep_wgrad_bf16_w4) from 4 096 frames on. */
+ * k_toep_wgrad_bf16_w4) from 4 096 frames on; bit 16 likewise for the dense-shaped weight gradients with many tiles per row
+ * chunk (encoder layer 4: k_gemm_tn4 instead of k_gemm_tn). */
 int vaenpvc_set_tuned_masks(vaenpvc_ctx* ctx, uint32_t fwd_mask, uint32_t bwd_mask);
 
 /* Measurement hook (no reference counterpart): brackets every launch of ONE tagged

@@ -672,30 +672,28 @@ def test_hipgraph_replay_matches_eager():
 
 
 @pytest.mark.parametrize('F', [4096, 4099, 5000, 8209])
-def test_tap_layer_weight_gradient_four_wave_kernel(F):
-    """The 1025-tap layer's weight gradient from 4 096 frames on runs on four waves with 128 x 128 wave tiles, operands by
-    LDS-DMA into a ring of 16-frame stages (k_toep_wgrad_bf16_w4); bit 17 of the backward mask cleared selects the
-    eight-wave kernel, which tests/…[8192, 32768] fixtures and the small sizes pin against the float64 oracle.  Ragged
-    frame counts exercise the cleared tail stage and the clamped requests past the last frame; the two kernels add the same
-    products in another order (bar: 2e-5 of the largest entry; the oracle fixtures hold the default at 8 192 / 32 768)."""
+@pytest.mark.parametrize('bit,entries,what', [(17, 1025 * 8, 'tap layer'), (16, 7 * 128 * 256, 'encoder layer 4')])
+def test_weight_gradient_four_wave_kernels(F, bit, entries, what):
+    """From 4 096 frames on the weight gradients of the 1025-tap layer and of encoder layer 4 run on four waves with
+    128 x 128 wave tiles, operands by LDS-DMA into a ring of 16-row stages (k_toep_wgrad_bf16_w4, k_gemm_tn4); bits 17 / 16 of
+    the backward mask cleared select the eight-wave kernels, which the small sizes pin against the float64 oracle (the
+    8 192 / 32 768-frame fixtures hold the default, i.e. the four-wave kernels).  Ragged frame counts exercise the cleared
+    tail stage and the requests past the last frame; the two kernels add the same products in another order (bar: 2e-5 of
+    the largest entry)."""
     from hipvae import Engine
     arch = ARCHS['vcc']
     eng = Engine(arch)
     P = O.init_params(arch, 3)
     x, y, eps = O.make_inputs(arch, F, 3)
-    eng.timer_select('dec3_wgrad')
     l_a, g_a = run_train(eng, P, x, y, eps)
-    eng.timer_select(None)
-    eng.set_tuned_masks(0xffffffff, 0xffffffff & ~(1 << 17))
+    eng.set_tuned_masks(0xffffffff, 0xffffffff & ~(1 << bit))
     l_b, g_b = run_train(eng, P, x, y, eps)
     assert np.isfinite(g_a).all() and np.isfinite(g_b).all()
-    # the layer's kernel [1025, 1, 1, 8] is the only tensor with 8 200 entries
-    (name, (off, shape)), = [(k, v) for k, v in eng.layout.items() if int(np.prod(v[1])) == 1025 * 8]
-    w_a, w_b = g_a[off:off + 8200].reshape(1025, 8), g_b[off:off + 8200].reshape(1025, 8)
+    (name, (off, shape)), = [(k, v) for k, v in eng.layout.items() if int(np.prod(v[1])) == entries]
+    w_a, w_b = g_a[off:off + entries], g_b[off:off + entries]
     worst = np.abs(w_a - w_b).max() / np.abs(w_b).max()
-    t, c = np.unravel_index(np.abs(w_a - w_b).argmax(), w_a.shape)
-    report('F%d tap-layer weight gradient, four-wave vs eight-wave kernel' % F, worst, 2e-5)
-    assert worst < 2e-5, '%s: %.3g of max at tap %d channel %d' % (name, worst, t, c)
+    report('F%d %s weight gradient, four-wave vs eight-wave kernel' % (F, what), worst, 2e-5)
+    assert worst < 2e-5, '%s: %.3g of max at flat entry %d' % (name, worst, int(np.abs(w_a - w_b).argmax()))
     rest = np.abs(g_a - g_b)
-    rest[off:off + 8200] = 0
+    rest[off:off + entries] = 0
     assert rest.max() < 1e-5 * np.abs(g_b).max() and rel_err(l_a, l_b) < 1e-6     # nothing else changed (atomic summation order aside)

@@ -278,6 +278,7 @@ static TnpArgs tnp_args(const float* Ap, int lda, const float* Bp, int ldb, int 
   // XCD-aware tile order: measured -15 % where a row chunk has many tiles sharing both operands (layer 4: 7 x 3), +5..10 %
   // on the one-dimensional tilings (merge 1 x 7, heads 6 x 1)
   a.xcd = rt().tn_xcd >= 0 ? rt().tn_xcd : (cdiv(M, 128) > 1 && cdiv(N, 256) > 1 ? 1 : 0);
+  a.tn4 = 0;
   return a;
 }
 // layers whose TF kernel tensor IS the packed operand (no copy)
@@ -999,6 +1000,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
         VAENPVC_TIMED("merge_dsplit", s, launch_split<NPL>(sa, s));
         ready();
         TnpArgs t = tnp_args(w.pl_z, 128, w.pl_dh, 1600, 128, 1539, F, G + m.wz_off, 1539);
+        t.tn4 = bwd_on(16);
         VAENPVC_TIMED("merge_wgrad", s2, (launch_gemm_tn<NPL, TN_EPI_PLAIN>(t, 512, s2)));
       });
     } else {
@@ -1054,6 +1056,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       TnpArgs t = tnp_args(w.pl_y4, 768, w.pl_dz, 256, 768, 256, F, G + m.wmu_off, 128);
       t.C2 = G + m.wlv_off;
       t.split = 128;
+      t.tn4 = bwd_on(16);
       VAENPVC_TIMED("heads_wgrad", s2, (launch_gemm_tn<NPL, TN_EPI_PLAIN>(t, 512, s2)));
       NtArgs a = nt_args(w.pl_dz, F, 256, w.scratch + Pk::pg_headsb, 768, 768, w.dy_tmp, 768);
       VAENPVC_TIMED("heads_dgrad", s, launch_gemm_nt<NPL>(a, s));
@@ -1101,6 +1104,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       VAENPVC_TIMED("enc4_dsplit", s, launch_split<NPL>(split_args(w.d_enc_a[4], 768, 768, F, us(w.pl_da4)), s));
       ready();
       TnpArgs t = tnp_args(w.pl_y3, 896, w.pl_da4, 768, 896, 768, F, G + l.w_off, 0);
+      t.tn4 = bwd_on(16);
       VAENPVC_TIMED("enc4_wgrad", s2, (launch_gemm_tn<NPL, TN_EPI_ENC4>(t, 512, s2)));
       NtArgs a = nt_args(w.pl_da4, F, 768, w.scratch + Pk::pg_enc4b, 896, 896, w.dy_tmp, 896);
       VAENPVC_TIMED("enc4_dgrad", s, launch_gemm_nt<NPL>(a, s));

@@ -440,6 +440,7 @@ struct TnpArgs {
   RowView av, bv;
   int lda, ldb;   // readable elements per row (loads are clamped to the row: ragged last column tile)
   int xcd;               // 1: XCD-aware tile order (the tiles of a row chunk on one XCD)
+  int tn4;               // 1: the four-wave kernel may be used (bit 16 of the backward mask)
   int M, N, F, fchunk;   // F = number of reduction rows
   float* C;   // PLAIN: C[m*ldc + n] (n < split) ; ENC4: the TF kernel tensor [7][128][256] ; TRANS: C[n*ldc + m]
   float* C2;  // PLAIN: columns n >= split at n - split
@@ -627,6 +628,11 @@ template <int NPL, int EPI, int TI, int TJ>
 inline void launch_gemm_tn32(TnpArgs a, int target_wgs, hipStream_t s);
 template <int NPL, int EPI, int TI = 2, int TJ = 2>
 inline void launch_gemm_tn(TnpArgs a, int target_wgs, hipStream_t s) {
+  if constexpr (NPL <= 2 && EPI != TN_EPI_TRANS && TI == 2 && TJ == 2) {
+    // the four-wave kernel where a row chunk has many 256 x 256 tiles (encoder layer 4: 4 x 3) and the rows are plain
+    if (a.tn4 && a.F >= 4096 && a.av.R >= a.F && a.bv.R >= a.F && cdiv(a.M, 256) * cdiv(a.N, 256) >= rt().tn_w4_tiles)
+      return launch_gemm_tn4<NPL, EPI>(a, s);
+  }
   if constexpr (NPL <= 2) {
     // measured (32 768 frames): one plane -27 % over six sites; two planes -17..24 % on the sites with few tiles per row
     // chunk (merge, heads, encoder layer 3), equal on decoder layer 0, +10 % on encoder layer 4 (21 tiles: stays here)
@@ -859,6 +865,167 @@ inline void launch_gemm_tn32(TnpArgs a, int target_wgs, hipStream_t s) {
   a.fchunk = rup(cdiv(a.F, zc), TP32_KF);
   dim3 grid((unsigned)(tiles * cdiv(a.F, a.fchunk)));
   hipLaunchKernelGGL((k_gemm_tn32<NPL, EPI, TI, TJ>), grid, dim3(512), T::LDS, s, a);
+}
+
+// ---------------------------------------------------------------- C += A^T B on four waves (plain row views, up to two planes)
+// The schedule of k_toep_wgrad_bf16_w4 (gfx950_toep_bf16.h) on a 256 x 256 tile: one wave per SIMD with a 128 x 128 wave
+// tile (16 accumulator tiles = all 256 AGPRs; a fragment byte read from LDS feeds twice the MFMAs of the 64 x 64 wave
+// tiles above), operands by LDS-DMA into a ring of four 16-row stages (rows unpadded, 16-byte pieces XOR-swizzled with
+// the row so that the transpose reads stay conflict-free; requested four iterations ahead, counted vmcnt, one bare
+// barrier per stage), one piece of side work -- a fragment read or a request -- behind every MFMA.  Rows are PLAIN
+// (R = INT_MAX): a stage is a scalar step in both operands.  The requests run up to five stages past the last row without
+// clamping: the plane buffers are sized for three planes (model.cpp), this kernel runs with at most two; rows >= F are
+// cleared in LDS before they are multiplied.  Workgroup order: XCD = row chunk (all tiles of a chunk share one L2).
+constexpr int tn4_stage(int npl) { return npl * 2 * W4_APL; }
+constexpr int tn4_lds(int npl) { return W4_NS * tn4_stage(npl); }   // 131 072 bytes at two planes
+template <int NPL, int EPI>
+__global__ void __launch_bounds__(256) k_gemm_tn4(TnpArgs a) {
+  static_assert(NPL <= 2 && EPI != TN_EPI_TRANS, "two planes; plain and folded epilogues");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using PR = Prod<NPL>;
+  constexpr int STAGE = tn4_stage(NPL), BOFF = NPL * W4_APL;
+  constexpr int NB = 2 * NPL, NDMA = 2 * NB, NT8 = 8 * NPL, NM = 16 * PR::N;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ntm = cdiv(a.M, 256), ntt = ntm * cdiv(a.N, 256), nzc = gridDim.x / ntt;
+  const int zc = blockIdx.x % nzc, tl = blockIdx.x / nzc;
+  const int m0 = (tl % ntm) * 256, n0 = (tl / ntm) * 256;
+  const int fb = zc * a.fchunk, fe = min(a.F, fb + a.fchunk);
+  if (fb >= fe) return;
+  const int nst = (fe - fb + W4_KF - 1) / W4_KF;
+
+  // ---- DMA: block k of this wave = (plane, row pair) of the stage; lane -> (row 2 fp + (lane >> 5), LDS piece lane & 31);
+  //      the piece fetched is (lane & 31) ^ ((row & 3) << 2), clamped to the row (ragged last column tile: finite data,
+  //      masked in the epilogue)
+  const unsigned char* A8 = reinterpret_cast<const unsigned char*>(a.A);
+  const unsigned char* B8 = reinterpret_cast<const unsigned char*>(a.B);
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem;
+  const size_t arow = (size_t)a.lda * 2, brow = (size_t)a.ldb * 2;   // bytes per row
+  const unsigned char* src[NDMA];
+  unsigned dst[NDMA];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const int bid = wave * NB + k, pl = bid >> 3, fp = bid & 7, fr = 2 * fp + lh;
+    const int gpc = l31 ^ ((fr & 3) << 2);
+    src[2 * k] = A8 + (size_t)pl * a.a_plane * 2 + (size_t)(fb + fr) * arow + cmin_(m0 * 2 + gpc * 16, a.lda * 2 - 16);
+    src[2 * k + 1] = B8 + (size_t)pl * a.b_plane * 2 + (size_t)(fb + fr) * brow + cmin_(n0 * 2 + gpc * 16, a.ldb * 2 - 16);
+    dst[2 * k] = pl * W4_APL + fp * 1024;
+    dst[2 * k + 1] = BOFF + pl * W4_APL + fp * 1024;
+  }
+  auto dma = [&](int g, int s, int slot) __attribute__((always_inline)) {
+    const size_t off = (size_t)s * (W4_KF * ((g & 1) ? brow : arow));
+    lds_dma16(src[g] + off, lds0 + slot * STAGE + dst[g]);
+  };
+  auto clear_tail = [&](int slot, int nv) __attribute__((always_inline)) {
+    unsigned char* sb = smem + slot * STAGE;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int i = tid; i < 2 * NPL * W4_KF * 32; i += 256)   // [operand][plane][row][32 pieces]
+      if (((i >> 5) & (W4_KF - 1)) >= nv) *reinterpret_cast<u32x4*>(sb + i * 16) = z;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  const int last_nv = (fe - fb) - (nst - 1) * W4_KF;
+
+  const int trow = ((lane & 15) >> 2) + 8 * lh, tcol = 4 * (lane & 3) + 16 * ((lane >> 4) & 1), s3 = trow & 3;
+  int a_off[4], b_off[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    a_off[r] = trow * W4_RS + (16 * wr + ((r ^ s3) << 2) + (tcol >> 3)) * 16 + (tcol & 7) * 2;
+    b_off[r] = BOFF + trow * W4_RS + (16 * wc + ((r ^ s3) << 2) + (tcol >> 3)) * 16 + (tcol & 7) * 2;
+  }
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj) acc[ri][cj] = zero16();
+  u32x4 fa[2][4][NPL], fq[2][4][NPL];
+  auto rd = [&](int set, int slot, int j) __attribute__((always_inline)) {
+    const unsigned char* sb = smem + slot * STAGE;
+    if (j < 4 * NPL)
+      fa[set][j / NPL][j % NPL] = tr_read8(sb + (j % NPL) * W4_APL + a_off[j / NPL], 4 * W4_RS);
+    else if (j < NT8)
+      fq[set][(j - 4 * NPL) / NPL][j % NPL] = tr_read8(sb + (j % NPL) * W4_APL + b_off[(j - 4 * NPL) / NPL], 4 * W4_RS);
+  };
+  auto mm = [&](int set, int m) __attribute__((always_inline)) {
+    const int t = m >> 4, ri = (m >> 2) & 3, cj = m & 3;
+    acc[ri][cj] = mfma_bf16(fa[set][ri][PR::A[t]], fq[set][cj][PR::B[t]], acc[ri][cj]);
+  };
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int g = 0; g < NDMA; ++g) dma(g, s, s);
+  wait_vmcnt<2 * NDMA>();
+  __builtin_amdgcn_s_barrier();
+  if (last_nv < W4_KF && nst <= 2) clear_tail(nst - 1, last_nv);
+#pragma unroll
+  for (int j = 0; j < NT8; ++j) rd(0, 0, j);
+  auto body = [&](auto S_, int t) __attribute__((always_inline)) {
+    constexpr int S = decltype(S_)::value;
+#pragma unroll
+    for (int g = 0; g < NDMA; ++g) {
+      mm(S & 1, 3 * g);
+      rd((S + 1) & 1, (S + 1) & 3, 2 * g);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(S & 1, 3 * g + 1);
+      rd((S + 1) & 1, (S + 1) & 3, 2 * g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(S & 1, 3 * g + 2);
+      dma(g, t + 4, S);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    static_assert(2 * NDMA >= NT8 && 3 * NDMA <= NM, "slots cover the reads");
+#pragma unroll
+    for (int m = 3 * NDMA; m < NM; ++m) mm(S & 1, m);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vmcnt<2 * NDMA>();
+    __builtin_amdgcn_s_barrier();
+    if (last_nv < W4_KF && t + 2 == nst - 1) clear_tail((S + 2) & 3, last_nv);
+  };
+  int t = 0;
+  for (; t + 4 <= nst; t += 4) {
+    body(IntC<0>{}, t);
+    body(IntC<1>{}, t + 1);
+    body(IntC<2>{}, t + 2);
+    body(IntC<3>{}, t + 3);
+  }
+  if (t < nst) {
+    body(IntC<0>{}, t);
+    if (t + 1 < nst) {
+      body(IntC<1>{}, t + 1);
+      if (t + 2 < nst) body(IntC<2>{}, t + 2);
+    }
+  }
+  wait_vmcnt<0>();   // requests past the last stage are still in flight (nothing below touches LDS, but the kernel must not end under them)
+  // ---- epilogue: acc[ri][cj][reg] = C[m0 + 128 wr + 32 ri + acc_row(reg)][n0 + 128 wc + 32 cj + l31]
+#pragma unroll
+  for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj) {
+      const int nn = n0 + 128 * wc + 32 * cj + l31;
+      if (nn >= a.N) continue;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + 128 * wr + 32 * ri + acc_row(reg, lane);
+        if (m >= a.M) continue;
+        const float v = acc[ri][cj][reg];
+        if constexpr (EPI == TN_EPI_ENC4) {
+          const int c = m / 7, h = m - 7 * c, o = nn / 3, j3 = nn - 3 * o, tt = h - 3 * j3 + 3;
+          if (tt >= 0 && tt < 7) atomicAdd(a.C + ((tt * 128 + c) * 256 + o), v);
+        } else {
+          if (a.C2 && nn >= a.split) atomicAdd(a.C2 + (int64_t)m * a.ldc + (nn - a.split), v);
+          else atomicAdd(a.C + (int64_t)m * a.ldc + nn, v);
+        }
+      }
+    }
+}
+template <int NPL, int EPI>
+inline void launch_gemm_tn4(TnpArgs a, hipStream_t s) {
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_tn4<NPL, EPI>), tn4_lds(NPL));
+  const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
+  const int zc = cmax(1, cmin_(cdiv(a.F, 64), 256 / tiles));   // one workgroup per CU
+  a.fchunk = rup(cdiv(a.F, zc), W4_KF);
+  hipLaunchKernelGGL((k_gemm_tn4<NPL, EPI>), dim3((unsigned)(tiles * cdiv(a.F, a.fchunk))), dim3(256), tn4_lds(NPL), s, a);
 }
 
 // =====================================================================================================

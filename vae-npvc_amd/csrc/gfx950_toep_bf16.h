@@ -1031,7 +1031,8 @@ constexpr int W4_APL = W4_KF * W4_RS;     // bytes per plane, operand and stage
 constexpr int W4_E = 4096;                // strip: bins 512..575 of both planes (only 512 is used), one 1-KiB block per wave
 constexpr int W4_NS = 4;                  // ring slots
 constexpr int w4_stage(int npl) { return npl * 2 * W4_APL + W4_E; }   // 36 864 bytes at NPL = 2
-constexpr int w4_lds(int npl) { return W4_NS * w4_stage(npl); }       // 147 456
+constexpr int W4_EPI_LDS = 4 * 7 * 32 * 33 * 4;                       // the epilogue's blocks: 118 272 bytes
+constexpr int w4_lds(int npl) { return W4_NS * w4_stage(npl) > W4_EPI_LDS ? W4_NS * w4_stage(npl) : W4_EPI_LDS; }   // 147 456 at two planes
 template <int N>
 struct IntC {
   static constexpr int value = N;

@@ -37,6 +37,7 @@ struct Runtime {
   unsigned cv_sites() const { return cv_sites_env >= 0 ? (unsigned)cv_sites_env : planes == 1 ? CV_SITES_BF16 : planes == 2 ? CV_SITES_X2 : CV_SITES_X3; }
   static constexpr unsigned CV_SITES_BF16 = 0xe2ceu, CV_SITES_X2 = 0xc244u, CV_SITES_X3 = 0x4u;  // by measurement
   bool tn_k16 = false;          // VAENPVC_TN_K16: the 16-row two-workgroup A^T B kernel instead of the pipelined 32-row one (A/B)
+  int tn_w4_tiles = 8;          // VAENPVC_TN_W4_TILES: the four-wave A^T B kernel from this many 256 x 256 tiles per row chunk on (0: every plain site, 99: never)
   int tn_xcd = -1;              // VAENPVC_TN_XCD=0|1: tile order of the C += A^T B plane GEMM (experiments; -1 = per site)
   int toep_zc = 4;              // VAENPVC_TOEP_ZC: frame chunks of the Toeplitz weight gradient, 64 workgroups each (4: one workgroup per CU, one prologue / epilogue per CU)
   bool toep_f32 = false;        // VAENPVC_TOEP=f32: exact-fp32 MFMA kernels for the 1025-tap layer
