@@ -1,6 +1,6 @@
 """Developer: duration of the 1025-tap weight gradient (site dec3_wgrad) at several batch sizes with the same grid (256
 workgroups from 4 096 frames on): the difference between two sizes is pure main-loop time, the rest prologue + epilogue.
-usage: python scripts/w4_scaling.py [frames ...]"""
+usage: python scripts/w4_scaling.py [frames ...]   (W4_TAG=enc4_wgrad selects another site)"""
 import json
 import os
 import sys
@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, 'vae-npvc_amd'))
 import torch
 from hipvae import Engine
 
+TAG = os.environ.get('W4_TAG', 'dec3_wgrad')
 arch = json.load(open(os.path.join(ROOT, 'vae-npvc_amd', 'architecture-vae-vcc2016.json')))
 eng = Engine(arch)
 eng.init_params(0)
@@ -22,9 +23,9 @@ for F in sizes:
     grads = torch.zeros(eng.n_params, device='cuda')
     for _ in range(3):
         eng.train_fwd_bwd(x, y, eps, grads)
-    eng.timer_select('dec3_wgrad')
+    eng.timer_select(TAG)
     for _ in range(10):
         eng.train_fwd_bwd(x, y, eps, grads)
     ms, k = eng.timer_read()
     eng.timer_select(None)
-    print('frames %6d  dec3_wgrad %.1f us  (%d launches)' % (F, ms / max(k, 1) * 1e3, k))
+    print('frames %6d  %s %.1f us  (%d launches)' % (F, TAG, ms / max(k, 1) * 1e3, k))

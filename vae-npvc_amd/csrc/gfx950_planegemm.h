@@ -877,7 +877,7 @@ inline void launch_gemm_tn32(TnpArgs a, int target_wgs, hipStream_t s) {
 // clamping: the plane buffers are sized for three planes (model.cpp), this kernel runs with at most two; rows >= F are
 // cleared in LDS before they are multiplied.  Workgroup order: XCD = row chunk (all tiles of a chunk share one L2).
 constexpr int tn4_stage(int npl) { return npl * 2 * W4_APL; }
-constexpr int tn4_lds(int npl) { return W4_NS * tn4_stage(npl); }   // 131 072 bytes at two planes
+constexpr int tn4_lds(int npl) { return W4_NS * tn4_stage(npl) > 131072 ? W4_NS * tn4_stage(npl) : 131072; }   // ring (131 072 bytes at two planes) / the folded epilogue's four 32-KB tiles
 template <int NPL, int EPI>
 __global__ void __launch_bounds__(256) k_gemm_tn4(TnpArgs a) {
   static_assert(NPL <= 2 && EPI != TN_EPI_TRANS, "two planes; plain and folded epilogues");
@@ -996,8 +996,53 @@ __global__ void __launch_bounds__(256) k_gemm_tn4(TnpArgs a) {
       if (t + 2 < nst) body(IntC<2>{}, t + 2);
     }
   }
-  wait_vmcnt<0>();   // requests past the last stage are still in flight (nothing below touches LDS, but the kernel must not end under them)
+  wait_vmcnt<0>();   // requests past the last stage are still writing into the ring
   // ---- epilogue: acc[ri][cj][reg] = C[m0 + 128 wr + 32 ri + acc_row(reg)][n0 + 128 wc + 32 cj + l31]
+  if constexpr (EPI == TN_EPI_ENC4) {
+    // m = (c, h) = 7 c + h, n = (o, j3) = 3 o + j3 -> dW[t][c][o], t = h - 3 j3 + 3: up to three entries of the tile fold onto one
+    // output, and along n the outputs of a tap lie three apart.  One atomic per tile entry (16.5 M per launch, five partly
+    // filled lines per wave instruction) cost 80 us at the end of the launch, when every workgroup arrives together.  Here
+    // a wave parks 64 rows of its tile in LDS (its 32 KB of the idle ring), folds them -- lanes along o: stride-3 reads,
+    // conflict-free -- and issues one atomic per (t, c, o) it holds a part of: half as many, on 2-3 full lines per instruction.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float* tile = reinterpret_cast<float*>(smem) + wave * (64 * 128);
+    const int nw0 = n0 + 128 * wc, o_lo = nw0 / 3, n_o = cmin_(nw0 + 127, a.N - 1) / 3 - o_lo + 1;   // (at most 44 <= 64 lanes)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int mw0 = m0 + 128 * wr + 64 * half;
+      wave_lds_sync();   // (the previous half has been read)
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) tile[(32 * r2 + acc_row(reg, lane)) * 128 + 32 * cj + l31] = acc[2 * half + r2][cj][reg];
+      wave_lds_sync();
+      if (mw0 < a.M && nw0 < a.N) {
+        const int c_lo = mw0 / 7, c_hi = cmin_(mw0 + 63, a.M - 1) / 7;
+        const int o = o_lo + lane;
+        for (int c = c_lo; c <= c_hi; ++c)
+#pragma unroll
+          for (int tt = 0; tt < 7; ++tt) {
+            float v = 0.f;
+            bool any = false;
+#pragma unroll
+            for (int j3 = 0; j3 < 3; ++j3) {
+              const int h = tt - 3 + 3 * j3;
+              if (h < 0 || h >= 7) continue;
+              const int m = 7 * c + h - mw0, n = 3 * o + j3 - nw0;     // uniform m
+              if (m >= 0 && m < 64 && 7 * c + h < a.M && lane < n_o && n >= 0 && n < 128 && 3 * o + j3 < a.N) {
+                v += tile[m * 128 + n];
+                any = true;
+              }
+            }
+            if (any) atomicAdd(a.C + ((tt * 128 + c) * 256 + o), v);
+          }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
