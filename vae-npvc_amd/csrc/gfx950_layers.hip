@@ -894,7 +894,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     }
     int ech = cmax(1, cmin_(cdiv(F, 64), 128));
     int efc = rup(cdiv(F, ech), 64);
-    hipLaunchKernelGGL(k_toep_wgrad_row512, dim3((unsigned)cdiv(F, efc), 3), dim3(256), 0, s2, w.dec_y, w.d_xh, G + m.dec[3].w_off, F, efc);
+    VAENPVC_TIMED("dec3_row512", s2, hipLaunchKernelGGL(k_toep_wgrad_row512, dim3((unsigned)cdiv(F, efc), 3), dim3(256), 0, s2, w.dec_y, w.d_xh,
+                                                       G + m.dec[3].w_off, F, efc));
     if (!toep_planes)  // (k_dxh_post computed it)
       hipLaunchKernelGGL(k_sum_all_atomic, dim3((unsigned)cmin_(1024, cdiv(F * 513, 1024))), dim3(256), 0, s2, w.d_xh,
                          (int64_t)F * 513, G + m.dec[3].b_off);

@@ -245,6 +245,9 @@ inline void launch_tngemm(const TnArgs& a, bool toep, int kchunks, hipStream_t s
 // 8 y2 values of 64 frames sit in 8 registers (lane <-> frame) and are broadcast with v_readlane, so a
 // frame costs one coalesced load and 8 FMAs.  Few, long chunks: the result is 513 x 8 atomics per
 // workgroup onto the same 4104 addresses (with 512 chunks those atomics WERE the kernel's run time).
+#ifndef TW512_U
+#define TW512_U 16
+#endif
 __global__ void __launch_bounds__(256) k_toep_wgrad_row512(const float* __restrict__ y2, const float* __restrict__ dxh,
                                                            float* __restrict__ dW, int F, int fchunk) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -259,12 +262,13 @@ __global__ void __launch_bounds__(256) k_toep_wgrad_row512(const float* __restri
     float yv[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) yv[c] = lane < nf ? y2[(int64_t)(f0 + lane) * 4104 + c * 513 + 512] : 0.f;
-    for (int j = 0; j < nf; j += 4) {
-      float d[4];
+    // (sixteen rows of d(xh) in flight per thread: with four the kernel was a chain of 16 round trips per 64 frames)
+    for (int j = 0; j < nf; j += TW512_U) {
+      float d[TW512_U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) d[u] = (tok && j + u < nf) ? dxh[(int64_t)(f0 + j + u) * 513 + t] : 0.f;
+      for (int u = 0; u < TW512_U; ++u) d[u] = (tok && j + u < nf) ? dxh[(int64_t)(f0 + j + u) * 513 + t] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < TW512_U; ++u)
 #pragma unroll
         for (int c = 0; c < 8; ++c)
           acc[c] += d[u] * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yv[c]), (j + u) & 63));
