@@ -343,22 +343,31 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[set][i][PR::A[t]], fb[set][j][PR::B[t]], acc[i][j]);
   };
+#ifndef VAENPVC_NT_ABL
+#define VAENPVC_NT_ABL 0   // developer ablation (wrong results): 1 no global loads after the first chunk, 2 no MFMAs, 4 no result stores, 8 no LDS traffic
+#endif
   const int nch = a.Kp / NT_BK;
   gload(0);
   for (int kc = 0; kc < nch; ++kc) {
-    lstore();  // chunk kc (prefetched)
+    if (!(VAENPVC_NT_ABL & 8)) lstore();  // chunk kc (prefetched)
     __syncthreads();
-    if (kc + 1 < nch) gload(kc + 1);
+    if (kc + 1 < nch && !(VAENPVC_NT_ABL & 1)) gload(kc + 1);
     __builtin_amdgcn_sched_barrier(0);
-    loadF(0, 0);
+    if (!(VAENPVC_NT_ABL & 8) || kc == 0) loadF(0, 0);
 #pragma unroll
     for (int ks = 0; ks < NT_BK / 16; ++ks) {
-      if (ks + 1 < NT_BK / 16) loadF((ks + 1) & 1, ks + 1);
+      if (ks + 1 < NT_BK / 16 && (!(VAENPVC_NT_ABL & 8) || kc == 0)) loadF((ks + 1) & 1, ks + 1);
       __builtin_amdgcn_sched_barrier(0);
-      mm(ks & 1);
+      if (!(VAENPVC_NT_ABL & 2)) mm(ks & 1);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();  // chunk consumed
+  }
+  if (VAENPVC_NT_ABL & 4) {
+    float sacc = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (sacc == 12345.678f) a.C[0] = sacc;
+    return;
   }
   // the speaker table rows of this tile (T[k][n0 .. n0+127], k < nrb <= NT_MAXRB) and the tile's 128 speaker ids go
   // through the (now free) LDS: the epilogue then reads LDS instead of issuing 2 x 64 dependent global loads per lane
