@@ -1,6 +1,17 @@
-"""Soak check of the small-batch path: N Adam steps on one fixed 16-frame batch with the frame kernels (default) and with
-the layered kernels (mask bit 21 cleared), same seeds: the two loss trajectories must stay together (a race in the phase
-kernels or in the atomics would show as a drift), losses finite and falling.  usage: python scripts/soak_small_batch.py [steps]"""
+"""Soak + noise floor of the small-batch path (NOT part of the pytest gate: two fp32 trajectories of a chaotic optimiser
+are compared, which is a measurement, not a parity test -- the gate holds tests/test_gpu_frame.py::
+test_twenty_adam_steps_follow_the_float64_trajectory instead).
+
+N Adam steps on one fixed 16-frame batch, R runs each of
+  frame     the frame kernels (default up to 512 frames; weight gradients accumulated with fp32 atomics)
+  layered   the layered kernels (mask bit 21 cleared; split-K weight gradients, fp32 atomics as well)
+same seeds.  Reported per tenth of the run: the largest relative gap of the loss triple
+  frame vs frame   (run i vs run 0: the floor set by atomic ordering alone)
+  layered vs layered
+  frame vs layered (what the round-3 test asserted < 3 %)
+plus per-step gradient parity of the two paths on IDENTICAL parameters every N/10 steps (non-chaotic: a race shows here).
+A race in the phase kernels / the atomic tail would show as frame-vs-layered leaving the envelope of the two floors, as NaNs,
+or as a gradient gap above the 2e-4 bar.  usage: python scripts/soak_small_batch.py [steps] [runs] [out.txt]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'vae-npvc_amd'))
@@ -8,29 +19,82 @@ import torch
 from hipvae import Engine
 from hipvae.dp import Stepper
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+OUT = sys.argv[3] if len(sys.argv) > 3 else None
 arch = json.load(open(os.path.join(ROOT, 'vae-npvc_amd', 'architecture-vae-vcc2016.json')))
 g = torch.Generator().manual_seed(0)
 F = 16
 x = torch.tanh(torch.randn(F, 513, generator=g)).cuda()
 y = torch.randint(0, 10, (F,), generator=g).cuda()
 eps = torch.randn(F, 128, generator=g).cuda()
-traj = {}
-for name, mask in (('frame', 0xffffffff), ('layered', 0xffffffff & ~(1 << 21))):
+MASK = {'frame': 0xffffffff, 'layered': 0xffffffff & ~(1 << 21)}
+lines = []
+
+
+def say(s):
+    print(s, flush=True)
+    lines.append(s)
+
+
+def run(name):
     eng = Engine(arch)
     eng.init_params(0)
-    eng.set_tuned_masks(mask, mask)
+    eng.set_tuned_masks(MASK[name], MASK[name])
     st = Stepper(eng, 1e-4, 0.5, 0.999)
     out = []
     for i in range(N):
         l3 = st.step(x, y, eps)
         if i % (N // 10) == 0 or i == N - 1:
-            out.append([float(v) for v in l3.cpu()])
-    traj[name] = out
-    print(name, ' '.join('%.3f' % o[0] for o in out))
-a, b = torch.tensor(traj['frame']), torch.tensor(traj['layered'])
-assert torch.isfinite(a).all() and torch.isfinite(b).all()
-rel = ((a - b).abs() / b.abs().clamp_min(1.0)).max().item()
-print('largest relative gap between the trajectories: %.2e' % rel)
-assert a[-1, 0] < a[0, 0] and rel < 2e-2
-print('soak ok')
+            out.append(l3.clone())
+    return torch.stack(out).cpu().double()
+
+
+def gap(a, b):
+    return ((a - b).abs() / b.abs().clamp_min(1.0)).max(dim=1).values
+
+
+traj = {k: [run(k) for _ in range(R)] for k in MASK}
+say('device %s, %d steps, %d runs per path, batch %d' % (torch.cuda.get_device_name(0), N, R, F))
+say('G of run 0 per tenth: frame   ' + ' '.join('%.2f' % v for v in traj['frame'][0][:, 0]))
+say('G of run 0 per tenth: layered ' + ' '.join('%.2f' % v for v in traj['layered'][0][:, 0]))
+worst = {}
+for tag, A, B in (('frame vs frame', traj['frame'][1:], [traj['frame'][0]] * (R - 1)),
+                  ('layered vs layered', traj['layered'][1:], [traj['layered'][0]] * (R - 1)),
+                  ('frame vs layered', traj['frame'], traj['layered'])):
+    gs = torch.stack([gap(a, b) for a, b in zip(A, B)])          # [runs, tenths]
+    worst[tag] = gs.max().item()
+    say('%-20s max over runs per tenth: %s   | overall max %.2e, median of run maxima %.2e'
+        % (tag, ' '.join('%.1e' % v for v in gs.max(dim=0).values), gs.max().item(), gs.max(dim=1).values.median().item()))
+
+# non-chaotic check: both paths evaluate the SAME parameters along one trajectory
+eng = Engine(arch)
+eng.init_params(0)
+st = Stepper(eng, 1e-4, 0.5, 0.999)
+gmax = 0.0
+for i in range(N):
+    if i % (N // 10) == 0:
+        gs = {}
+        p = eng.params.clone()
+        for k in MASK:
+            eng.set_tuned_masks(MASK[k], MASK[k])
+            eng.train_fwd_bwd(x, y, eps, st.grads)
+            torch.cuda.synchronize()
+            gs[k] = st.grads[:eng.n_params].clone()
+        assert torch.equal(p, eng.params)
+        e = ((gs['frame'] - gs['layered']).abs().max() / gs['layered'].abs().max()).item()
+        gmax = max(gmax, e)
+        say('step %4d: gradient of the two paths on identical parameters: max-norm gap %.2e' % (i, e))
+        eng.set_tuned_masks(MASK['frame'], MASK['frame'])
+    st.step(x, y, eps)
+for k in traj:
+    for t in traj[k]:
+        assert torch.isfinite(t).all() and t[-1, 0] < t[0, 0]
+floor = max(worst['frame vs frame'], worst['layered vs layered'])
+say('noise floor (same path twice) %.2e; frame vs layered %.2e; gradient gap on identical parameters %.2e'
+    % (floor, worst['frame vs layered'], gmax))
+assert gmax < 2e-4, 'per-step gradient parity of the two paths broken: that is not chaos'
+say('soak ok')
+if OUT:
+    with open(OUT, 'w') as fp:
+        fp.write('\n'.join(lines) + '\n')

@@ -185,35 +185,57 @@ def test_another_speaker_count_runs_on_the_generic_kernels():
     assert not fails, '\n'.join(fails)
 
 
-def test_three_hundred_steps_on_both_paths_stay_together():
-    """300 Adam steps on one fixed 16-frame batch with the frame kernels and with the layered kernels (mask bit 21), same
-    seeds: finite, falling, and the two loss trajectories within 3 % of each other at every tenth of the run.  (Not tighter:
-    Adam turns 1e-6 differences of tiny gradient entries into lr-sized parameter differences, the two fp32 paths drift apart
-    chaotically while the loss falls from 770 to 470 -- measured gap 1 %; a race in the phase kernels or in the atomics of
-    the weight-gradient launch shows as NaNs or a run that stops falling.  scripts/soak_small_batch.py is the long form.)"""
+TRAJ_STEPS = 20
+TRAJ_LOSS_TOL = 1e-3      # per-step loss triple against the float64 trajectory (measured: see profiles/r04_soak_noise_floor.txt)
+TRAJ_DELTA_TOL = 3e-2     # L2 norm of (parameter move - float64 parameter move) over the L2 norm of the float64 move
+
+
+def oracle_adam_trajectory(arch, F, seed, steps):
+    """float64 restatement of trainer/vae.py:16-28 on ONE fixed batch: loss triple before every step and the parameters
+    after the last one"""
+    from collections import OrderedDict
+    P = OrderedDict((k, w.astype(np.float64)) for k, w in O.init_params(arch, seed).items())
+    x, y, eps = O.make_inputs(arch, F, seed)
+    m = {k: np.zeros_like(v) for k, v in P.items()}
+    v = {k: np.zeros_like(w) for k, w in P.items()}
+    P0 = OrderedDict((k, w.copy()) for k, w in P.items())
+    losses = []
+    for t in range(1, steps + 1):
+        L, G = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64)
+        losses.append([float(L['G']), float(L['D_KL']), float(L['logP'])])
+        for k in P:
+            P[k], m[k], v[k] = O.tf_adam_step(P[k], G[k], m[k], v[k], t)
+    return P0, P, (x, y, eps), np.array(losses)
+
+
+@pytest.mark.parametrize('path', ['frame', 'layered'])
+def test_twenty_adam_steps_follow_the_float64_trajectory(path):
+    """20 Adam steps on one fixed 16-frame batch, on the frame kernels and on the layered kernels (mask bit 21 cleared), each
+    against the float64 ORACLE trajectory (not against each other: two fp32 paths drift apart chaotically over hundreds of
+    steps, which says nothing about either; scripts/soak_small_batch.py measures that drift and its noise floor): the loss
+    triple of every step within 1e-3, the loss falling, and the parameter move after 20 steps within 3 % (L2) of the
+    oracle's move.  A race in the phase kernels or in the atomics of the weight-gradient launch breaks the per-step bar."""
     from hipvae import Engine
     from hipvae.dp import Stepper
-    g = torch.Generator().manual_seed(0)
-    F, N = 16, 300
-    traj = {}
-    for name, mask in (('frame', 0xffffffff), ('layered', 0xffffffff & ~(1 << 21))):
-        eng = Engine(ARCHS['vcc'])
-        eng.init_params(0)
-        eng.set_tuned_masks(mask, mask)
-        dev = eng.device
-        if name == 'frame':
-            x = torch.tanh(torch.randn(F, 513, generator=g)).to(dev)
-            y = torch.randint(0, 10, (F,), generator=g).to(dev)
-            eps = torch.randn(F, 128, generator=g).to(dev)
-        st = Stepper(eng, 1e-4, 0.5, 0.999)
-        out = []
-        for i in range(N):
-            l3 = st.step(x, y, eps)
-            if i % 30 == 0 or i == N - 1:
-                out.append(l3.clone())
-        traj[name] = torch.stack(out).cpu()
-    a, b = traj['frame'], traj['layered']
-    assert torch.isfinite(a).all() and torch.isfinite(b).all()
-    assert a[-1, 0] < 0.8 * a[0, 0]
-    gap = ((a - b).abs() / b.abs().clamp_min(1.0)).max().item()
-    assert gap < 3e-2, gap
+    arch = ARCHS['vcc']
+    F, seed = 16, 3
+    P0, P1, (x, y, eps), want = oracle_adam_trajectory(arch, F, seed, TRAJ_STEPS)
+    eng = Engine(arch)
+    mask = 0xffffffff if path == 'frame' else 0xffffffff & ~(1 << 21)
+    eng.set_tuned_masks(mask, mask)
+    eng.load_flat(O.flatten_params(P0))
+    xt, yt, et = (torch.tensor(a, device=eng.device) for a in (x, y, eps))
+    st = Stepper(eng, 1e-4, 0.5, 0.999)
+    got = torch.stack([st.step(xt, yt, et).clone() for _ in range(TRAJ_STEPS)]).cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    e_loss = (np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max()
+    report('trajectory %s loss3 (20 steps)' % path, e_loss, TRAJ_LOSS_TOL)
+    assert e_loss < TRAJ_LOSS_TOL, (path, e_loss)
+    assert got[-1, 0] < 0.9 * got[0, 0]
+    flat64 = lambda P: np.concatenate([np.asarray(w, np.float64).ravel() for w in P.values()])
+    p0 = flat64(P0)
+    d_want = flat64(P1) - p0
+    d_got = eng.params.cpu().numpy().astype(np.float64) - p0
+    e_delta = np.linalg.norm(d_got - d_want) / np.linalg.norm(d_want)
+    report('trajectory %s parameter move (20 steps, L2)' % path, e_delta, TRAJ_DELTA_TOL)
+    assert e_delta < TRAJ_DELTA_TOL, (path, e_delta)
