@@ -1,6 +1,6 @@
 """Soak + noise floor of the small-batch path (NOT part of the pytest gate: two fp32 trajectories of a chaotic optimiser
 are compared, which is a measurement, not a parity test -- the gate holds tests/test_gpu_frame.py::
-test_twenty_adam_steps_follow_the_float64_trajectory instead).
+test_twenty_adam_steps_follow_the_float64_oracle instead).
 
 N Adam steps on one fixed 16-frame batch, R runs each of
   frame     the frame kernels (default up to 512 frames; weight gradients accumulated with fp32 atomics)
@@ -67,6 +67,22 @@ for tag, A, B in (('frame vs frame', traj['frame'][1:], [traj['frame'][0]] * (R 
     say('%-20s max over runs per tenth: %s   | overall max %.2e, median of run maxima %.2e'
         % (tag, ' '.join('%.1e' % v for v in gs.max(dim=0).values), gs.max().item(), gs.max(dim=1).values.median().item()))
 
+
+
+def branches(eng):
+    """side of the lrelu kink every LayerNorm output of the last train forward took (from the workspace tensors)"""
+    from hipvae import lib as L
+    out = []
+    for net, shapes, pre in (('enc', ((16, 171), (32, 57), (64, 19), (128, 7), (256, 3)), 'Encoder/Conv2d-%d/layernorm'),
+                             ('dec', ((32, 57), (16, 171), (8, 513)), 'Generator/ConvT-LN%d')):
+        for i, (c, h) in enumerate(shapes):
+            a = eng.ws_region(F, L.MODE_TRAIN, '%s_a%d' % (net, i)).view(F, c, h).double()
+            s2 = eng.ws_region(F, L.MODE_TRAIN, '%s_st%d' % (net, i)).view(F, 2).double()
+            gam, bet = (eng.params[eng.layout[(pre % i) + k][0]:][:c].double().view(1, c, 1) for k in ('.scale', '.offset'))
+            out.append((((a - s2[:, :1, None]) * s2[:, 1:, None] * gam + bet) >= 0).flatten())
+    return torch.cat(out)
+
+
 # non-chaotic check: both paths evaluate the SAME parameters along one trajectory
 eng = Engine(arch)
 eng.init_params(0)
@@ -81,17 +97,21 @@ for i in range(N):
             eng.train_fwd_bwd(x, y, eps, st.grads)
             torch.cuda.synchronize()
             gs[k] = st.grads[:eng.n_params].clone()
+            gs[k + ' branches'] = branches(eng)
         assert torch.equal(p, eng.params)
         e = ((gs['frame'] - gs['layered']).abs().max() / gs['layered'].abs().max()).item()
-        gmax = max(gmax, e)
-        say('step %4d: gradient of the two paths on identical parameters: max-norm gap %.2e' % (i, e))
+        flips = int((gs['frame branches'] != gs['layered branches']).sum())
+        if flips == 0:       # a unit on different sides of the lrelu kink is a finite jump of that frame's gradient, not an error
+            gmax = max(gmax, e)
+        say('step %4d: gradient of the two paths on identical parameters: max-norm gap %.2e, lrelu units on different sides: %d'
+            % (i, e, flips))
         eng.set_tuned_masks(MASK['frame'], MASK['frame'])
     st.step(x, y, eps)
 for k in traj:
     for t in traj[k]:
         assert torch.isfinite(t).all() and t[-1, 0] < t[0, 0]
 floor = max(worst['frame vs frame'], worst['layered vs layered'])
-say('noise floor (same path twice) %.2e; frame vs layered %.2e; gradient gap on identical parameters %.2e'
+say('noise floor (same path twice) %.2e; frame vs layered %.2e; gradient gap on identical parameters (steps without kink flips) %.2e'
     % (floor, worst['frame vs layered'], gmax))
 assert gmax < 2e-4, 'per-step gradient parity of the two paths broken: that is not chaos'
 say('soak ok')

@@ -186,8 +186,11 @@ def test_another_speaker_count_runs_on_the_generic_kernels():
 
 
 TRAJ_STEPS = 20
-TRAJ_LOSS_TOL = 1e-3      # per-step loss triple against the float64 trajectory (measured: see profiles/r04_soak_noise_floor.txt)
-TRAJ_DELTA_TOL = 3e-2     # L2 norm of (parameter move - float64 parameter move) over the L2 norm of the float64 move
+TRAJ_DRIFT_TOL = 1e-2     # loss of step t against the float64 RUN: second order in the parameter deviation, which Adam's
+                          # sign-like update makes first order in the rounding error of small gradient entries -- measured
+                          # 1e-6 (frame kernels, 3e-7 gradient error), 1.5e-3 (the bitwise-repeatable generic kernels, 3e-6),
+                          # 1.7e-3 (layered kernels): profiles/r04_soak_noise_floor.txt.  NOT a parity bar.
+TRAJ_REPEAT_TOL = 1e-5    # 30 evaluations on identical parameters (atomic ordering: measured 2.5e-7 / 4.9e-7); a race shows here
 
 
 def oracle_adam_trajectory(arch, F, seed, steps):
@@ -209,14 +212,21 @@ def oracle_adam_trajectory(arch, F, seed, steps):
 
 
 @pytest.mark.parametrize('path', ['frame', 'layered'])
-def test_twenty_adam_steps_follow_the_float64_trajectory(path):
+def test_twenty_adam_steps_follow_the_float64_oracle(path):
     """20 Adam steps on one fixed 16-frame batch, on the frame kernels and on the layered kernels (mask bit 21 cleared), each
-    against the float64 ORACLE trajectory (not against each other: two fp32 paths drift apart chaotically over hundreds of
-    steps, which says nothing about either; scripts/soak_small_batch.py measures that drift and its noise floor): the loss
-    triple of every step within 1e-3, the loss falling, and the parameter move after 20 steps within 3 % (L2) of the
-    oracle's move.  A race in the phase kernels or in the atomics of the weight-gradient launch breaks the per-step bar."""
+    against the float64 ORACLE -- never against each other: two fp32 trajectories of this optimiser drift apart chaotically
+    (the same path run twice differs by up to 3 % in the loss after 300 steps from atomic ordering alone;
+    scripts/soak_small_batch.py measures that floor, profiles/r04_soak_noise_floor.txt holds it).  What is asserted is what
+    is NOT chaotic:
+      * one evaluation repeated 30 times on identical parameters stays within 1e-5 (a race in the phase kernels or in the
+        atomic tail of the weight-gradient launch shows here);
+      * at EVERY step the loss triple (1e-4) and all 44 gradient tensors (2e-4 of the tensor's largest entry, kink units
+        pinned to the GPU's branch) meet float64 evaluated at the GPU's own parameters of that step -- this catches state
+        that goes stale between steps (packed weights, tables), which no single-step test can;
+      * the run is finite, falls, and its loss stays within 1e-2 of the float64 run (a sanity bound, see TRAJ_DRIFT_TOL)."""
     from hipvae import Engine
     from hipvae.dp import Stepper
+    from test_gpu_parity import gpu_branches
     arch = ARCHS['vcc']
     F, seed = 16, 3
     P0, P1, (x, y, eps), want = oracle_adam_trajectory(arch, F, seed, TRAJ_STEPS)
@@ -226,16 +236,41 @@ def test_twenty_adam_steps_follow_the_float64_trajectory(path):
     eng.load_flat(O.flatten_params(P0))
     xt, yt, et = (torch.tensor(a, device=eng.device) for a in (x, y, eps))
     st = Stepper(eng, 1e-4, 0.5, 0.999)
-    got = torch.stack([st.step(xt, yt, et).clone() for _ in range(TRAJ_STEPS)]).cpu().numpy().astype(np.float64)
-    assert np.isfinite(got).all()
-    e_loss = (np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max()
-    report('trajectory %s loss3 (20 steps)' % path, e_loss, TRAJ_LOSS_TOL)
-    assert e_loss < TRAJ_LOSS_TOL, (path, e_loss)
-    assert got[-1, 0] < 0.9 * got[0, 0]
-    flat64 = lambda P: np.concatenate([np.asarray(w, np.float64).ravel() for w in P.values()])
-    p0 = flat64(P0)
-    d_want = flat64(P1) - p0
-    d_got = eng.params.cpu().numpy().astype(np.float64) - p0
-    e_delta = np.linalg.norm(d_got - d_want) / np.linalg.norm(d_want)
-    report('trajectory %s parameter move (20 steps, L2)' % path, e_delta, TRAJ_DELTA_TOL)
-    assert e_delta < TRAJ_DELTA_TOL, (path, e_delta)
+    gs = []
+    for _ in range(30):
+        eng.train_fwd_bwd(xt, yt, et, st.grads)
+        gs.append(st.grads.clone())
+    gs = torch.stack(gs)
+    rep = ((gs - gs[0]).abs().max() / gs[0].abs().max()).item()
+    report('trajectory %s repeatability of one evaluation (30 calls)' % path, rep, TRAJ_REPEAT_TOL)
+    assert rep <= TRAJ_REPEAT_TOL, (path, rep)
+    fails, got = [], []
+    e_grad = e_loss = 0.0
+    for t in range(TRAJ_STEPS):
+        P = O.unflatten_params(arch, eng.params.cpu().numpy())
+        l3 = st.step(xt, yt, et).clone().cpu().numpy().astype(np.float64)
+        got.append(l3)
+        g = st.grads.cpu().numpy()
+        L, G = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64, kink=gpu_branches(eng, arch, P, F))
+        e_loss = max(e_loss, rel_err(l3, np.array([L['G'], L['D_KL'], L['logP']])))
+        for name, (off, shape) in eng.layout.items():
+            n = int(np.prod(shape))
+            if n == 1:
+                # the last layer's bias: ONE entry, the sum of the residuals over the batch, which training drives through
+                # zero -- it has no scale of its own; measured on the scale of the neighbouring layer's bias gradient
+                scale = max(abs(float(G[name].ravel()[0])), np.abs(G['Generator/conv2d_transpose_2/bias']).max())
+                e = abs(float(g[off]) - float(G[name].ravel()[0])) / scale
+            else:
+                e = rel_err(g[off:off + n].reshape(shape), G[name])
+            e_grad = max(e_grad, e)
+            if not e <= TOL_GRAD:
+                fails.append('step %d grad %s: %.3e' % (t, name, e))
+    report('trajectory %s per-step loss3 at the GPU parameters (20 steps)' % path, e_loss, TOL_ACT)
+    report('trajectory %s per-step worst gradient tensor (20 steps)' % path, e_grad, TOL_GRAD)
+    got = np.array(got)
+    drift = (np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max()
+    report('trajectory %s loss drift against the float64 run (20 steps)' % path, drift, TRAJ_DRIFT_TOL)
+    assert not fails, '\n'.join(fails)
+    assert e_loss <= TOL_ACT, (path, e_loss)
+    assert np.isfinite(got).all() and got[-1, 0] < 0.9 * got[0, 0]
+    assert drift <= TRAJ_DRIFT_TOL, (path, drift)
