@@ -230,7 +230,10 @@ def test_twenty_adam_steps_follow_the_float64_oracle(path):
     arch = ARCHS['vcc']
     F, seed = 16, 3
     P0, P1, (x, y, eps), want = oracle_adam_trajectory(arch, F, seed, TRAJ_STEPS)
-    eng = Engine(arch)
+    # (the layered kernels with 3-term operands = fp32-exact, like the frame kernels: what is tested here is state carried
+    #  between steps, not operand precision -- with the default 2-term operands the bias gradients, sums that cancel to
+    #  ~0 as training proceeds, leave the per-tensor bar after ~15 steps: 3.6e-4 of the tensor's largest entry, measured)
+    eng = Engine(arch, precision=None if path == 'frame' else 'bf16x3')
     mask = 0xffffffff if path == 'frame' else 0xffffffff & ~(1 << 21)
     eng.set_tuned_masks(mask, mask)
     eng.load_flat(O.flatten_params(P0))
@@ -256,9 +259,10 @@ def test_twenty_adam_steps_follow_the_float64_oracle(path):
         for name, (off, shape) in eng.layout.items():
             n = int(np.prod(shape))
             if n == 1:
-                # the last layer's bias: ONE entry, the sum of the residuals over the batch, which training drives through
-                # zero -- it has no scale of its own; measured on the scale of the neighbouring layer's bias gradient
-                scale = max(abs(float(G[name].ravel()[0])), np.abs(G['Generator/conv2d_transpose_2/bias']).max())
+                # the last layer's bias: ONE entry, the sum of the F x 513 residuals (xh - x) / ((1 + 1e-6) F), which training
+                # drives through zero -- a sum with cancellation has no scale of its own; its error bound is (relative error
+                # of a term) x (sum of the terms' magnitudes), so that sum is the scale it is measured on
+                scale = np.abs((L['xh'] - x) / ((1 + 1e-6) * F)).sum()
                 e = abs(float(g[off]) - float(G[name].ravel()[0])) / scale
             else:
                 e = rel_err(g[off:off + n].reshape(shape), G[name])

@@ -440,6 +440,26 @@ def test_fused_thin_conv_layers_against_oracle(F, seed, precision):
     assert not fails, '\n'.join(fails)
 
 
+FUSED_BWD = (0xffffffff, 0xffffbfff)    # bit 14 of the backward mask cleared: the one-kernel backward step of the thin decoder layers at any batch size
+
+
+@pytest.mark.parametrize('layers', ['3', '1', '2'])
+@pytest.mark.parametrize('F,seed', [(37, 5), (130, 9), (1, 7), (257, 12)])
+def test_fused_layer_backward_against_oracle(F, seed, layers, monkeypatch):
+    """Decoder layers 2 and 1: LayerNorm + lrelu backward, input gradient, weight gradient and the layer's d gamma / d beta /
+    d bias in ONE kernel per layer (csrc/gfx950_fbwd.h: the gradient at the pre-LN output exists only as bf16 terms in LDS)
+    against the float64 oracle; both layers, and each alone next to the three-kernel form of the other (the hand-over
+    buffers differ); batch sizes with a ragged last 2-frame group.  (By default from 1024 frames on.)"""
+    monkeypatch.setenv('VAENPVC_FB_LAYERS', layers)
+    eng = make_engine('vcc', 'auto', FUSED_BWD)
+    eng.timer_select('dec2_bwd' if layers != '2' else 'dec1_bwd')
+    fails = compare_everything(eng, F, seed, 'fused-bwd layers=%s F%d ' % (layers, F))
+    _, n = eng.timer_read()
+    eng.timer_select(None)
+    assert n == 1, 'the fused backward kernel did not run'
+    assert not fails, '\n'.join(fails)
+
+
 @pytest.mark.parametrize('precision', ['bf16x2', 'bf16'])
 def test_default_selection_at_a_ragged_large_batch(precision):
     """The DEFAULT kernel selection just above its thresholds, at a batch size that is a multiple of nothing the kernels

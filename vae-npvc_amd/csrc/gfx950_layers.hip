@@ -26,6 +26,7 @@
 #include "gfx950_fconv.h"
 #include "gfx950_fwgrad.h"
 #include "gfx950_fconv_r.h"
+#include "gfx950_fbwd.h"
 #include "kernels.h"
 
 namespace vaenpvc {
@@ -234,6 +235,13 @@ static inline bool fw_bwd(int wsite, int64_t F) {
   if (!((rt().bwd_mask >> 24) & 1u)) return true;
   return ((rt().fw_sites() >> wsite) & 1u) && F >= FCONV_MIN_FRAMES;
 }
+// whole backward step of a thin decoder layer in one kernel (gfx950_fbwd.h): bit 15 of the backward mask (default set) and
+// the context's layer set from FCONV_MIN_FRAMES frames on; bit 14 cleared = at any batch size (parity tests)
+static inline bool fb_bwd(int layer, int64_t F) {
+  if ((rt().dense_planes ? rt().dense_planes : rt().planes) > 2 || !((rt().bwd_mask >> 15) & 1u)) return false;
+  if (!((rt().fb_layers() >> layer) & 1u)) return false;
+  return F >= FCONV_MIN_FRAMES || !((rt().bwd_mask >> 14) & 1u);
+}
 static inline bool fc_any(int64_t F) {
   for (int i = 0; i < CV_COUNT; ++i)
     if (fc_fwd(i, F) || fc_bwd(i, F) || fcr_fwd(i, F) || fcr_bwd(i, F)) return true;
@@ -391,9 +399,10 @@ static void prep(const Model& m, const float* P, const Ws& w, int64_t F, hipStre
       pack_job(PackRepeat3{P + m.enc[4].b_off}, S + Pk::pg_bias4, 768));
   // weight planes of the conv view-GEMM sites.  TF layouts: conv [T][Cin][Cout], conv_transpose [T][Cout][Cin];
   // (s_t, s_o, s_c) = strides of (tap, GEMM output channel, contracted channel)
-  if (cg_fwd(F) || cg_bwd(F) || fc_any(F)) {
+  if (cg_fwd(F) || cg_bwd(F) || fc_any(F) || fb_bwd(FB_D2, F) || fb_bwd(FB_D1, F)) {
     // only the sites some kernel of this step reads (count 0 = job skipped)
     auto used = [&](int site, bool fwd_dir) {
+      if (!fwd_dir && ((site == CV_D2G && fb_bwd(FB_D2, F)) || (site == CV_D1G && fb_bwd(FB_D1, F)))) return true;   // gfx950_fbwd.h
       return fwd_dir ? (cv_fwd(site, F) || fc_fwd(site, F) || fcr_fwd(site, F)) : (cv_bwd(site, F) || fc_bwd(site, F) || fcr_bwd(site, F));
     };
     auto job = [&](int site, bool fwd_dir, const ConvL& l, int s_o, int s_c) {
@@ -924,13 +933,39 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL((k_toep_dgrad<1, 4>), dim3((unsigned)cdiv(F, 32), 8), dim3(256), TD_LDS, s, w.d_xh,
                                                         w.scratch + Pk::wc, w.dy_tmp, F));
     }
-    launch_ln_bwd<LnbCfg<8, 513>>(w.dy_tmp, w.dec_a[2], w.dec_st[2], P + l2.gamma_off, P + l2.beta_off, w.d_dec_a[2],
-                                     G + l2.gamma_off, G + l2.beta_off, G + l2.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
-    dec_bias_done[2] = true;
+    // (with the whole backward step of layer 2 in one kernel, gfx950_fbwd.h, its LayerNorm backward runs there)
+    if (!(bwd_on(9) && fb_bwd(FB_D2, F))) {
+      launch_ln_bwd<LnbCfg<8, 513>>(w.dy_tmp, w.dec_a[2], w.dec_st[2], P + l2.gamma_off, P + l2.beta_off, w.d_dec_a[2],
+                                       G + l2.gamma_off, G + l2.beta_off, G + l2.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+      dec_bias_done[2] = true;
+    }
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 3);
+  // one kernel per thin decoder layer: LayerNorm backward + input gradient + weight gradient + the layer's parameter sums
+  auto fused_bwd = [&](int layer, int i, const float* dy, float* dx, const char* tag) {
+    const ConvL &l = m.dec[i], &pl = m.dec[i - 1];
+    for_dense_planes([&](auto npl) {
+      constexpr int NPL = decltype(npl)::value;
+      FbArgs fa{dy, w.dec_a[i], w.dec_st[i], P + l.gamma_off, P + l.beta_off, w.dec_a[i - 1], w.dec_st[i - 1], P + pl.gamma_off,
+                P + pl.beta_off, reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvw + cv_woff(fb_gsite(layer))), dx,
+                G + l.w_off, G + l.gamma_off, G + l.beta_off, G + l.b_off, F};
+      VAENPVC_TIMED(tag, s, fbwd<NPL>(layer, fa, s));
+    });
+  };
+  // where the gradient at the activated output of the layer being processed lives (the fused kernels ping-pong between
+  // dy_tmp and the buffer of the pre-LN gradient they no longer write)
+  const float* dy_cur = w.dy_tmp;
 
   // ---- d2
-  if (bwd_on(9)) {
+  if (bwd_on(9) && bwd_on(10) && fb_bwd(FB_D2, F)) {
+    const ConvL& pl = m.dec[1];
+    fused_bwd(FB_D2, 2, w.dy_tmp, w.d_dec_a[2], "dec2_bwd");
+    dy_cur = w.d_dec_a[2];
+    if (!(bwd_on(8) && fb_bwd(FB_D1, F))) {
+      launch_ln_bwd<LnbCfg<16, 171>>(dy_cur, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[1],
+                                        G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+      dec_bias_done[1] = true;
+    }
+  } else if (bwd_on(9)) {
     const ConvL &l = m.dec[2], &pl = m.dec[1];
     WgArgs a{w.d_dec_a[2], nullptr, nullptr, nullptr, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off,
              G + l.w_off, F, 0};
@@ -947,13 +982,22 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     else
     VAENPVC_TIMED("dec2_dgrad", s, launch_convgemm<GD2>(conv_args(w.d_dec_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::gd2,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GD2>(F), s));
-    launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[1],
-                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
-    dec_bias_done[1] = true;
+    if (!(bwd_on(8) && fb_bwd(FB_D1, F))) {   // (layer 1's fused backward kernel does it otherwise)
+      launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[1],
+                                        G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+      dec_bias_done[1] = true;
+    }
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 2);
 
   // ---- d1
-  if (bwd_on(8)) {
+  if (bwd_on(8) && bwd_on(9) && fb_bwd(FB_D1, F)) {
+    const ConvL& pl = m.dec[0];
+    float* dy0 = dy_cur == w.dy_tmp ? w.d_dec_a[1] : w.dy_tmp;
+    fused_bwd(FB_D1, 1, dy_cur, dy0, "dec1_bwd");
+    launch_ln_bwd<LnbCfg<32, 57>>(dy0, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[0],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+    dec_bias_done[0] = true;
+  } else if (bwd_on(8)) {
     const ConvL &l = m.dec[1], &pl = m.dec[0];
     WgArgs a{w.d_dec_a[1], nullptr, nullptr, nullptr, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off,
              G + l.w_off, F, 0};
