@@ -51,6 +51,38 @@ DEC3_FLOP_PER_FRAME = 2.0 * 8 * 513 * 513
 BF16_PEAK = 2500e12
 PRODUCTS = {3: 6, 2: 3, 1: 1}           # bf16 MFMA products per fp32 product for 3 / 2 / 1 operand terms
 PREC_NAME = {3: 'bf16x3', 2: 'bf16x2', 1: 'bf16'}
+# Kernel GROUPS of the layered train step (roofline.sites): every tagged launch site of csrc/gfx950_layers.hip belongs to one;
+# each group is timed in its own short pass (HIP events around every launch of the group, weight-gradient stream serialised).
+#   bound 'mfma': algorithmic FLOP per frame = 3 (forward, input gradient, weight gradient) x 2 x effective MACs of the group's
+#                 layers, priced against the bf16 matrix-core peak / products of the operand split;
+#   bound 'hbm' : bytes per frame that the group's kernels read + write ONCE through their own interfaces (fp32 tensors),
+#                 priced against 8 TB/s.  (The separate LayerNorm-backward passes exist only because layers are materialised:
+#                 their bytes are moved bytes, not algorithmic ones -- stated in the entry.)
+_E = dict(x=513, e0=2736, e1=1824, e2=1216, e3=896, e4=768, d0=1824, d1=2736, d2=4104)
+SITE_GROUPS = {
+    'tap_layer (1025-tap conv_transpose: forward, input gradient, weight gradient)': dict(
+        tags='dec3_fwd dec3_dgrad dec3_wgrad dec3_row512 dec3_bias dxh_post', bound='mfma', mac=2105352),
+    'dense_shaped (encoder layer 4, heads, sampler, merge: GEMMs + their plane producers)': dict(
+        tags=('enc4_split enc4_fwd stats_enc4 heads_split heads_fwd reparam merge_split merge_fwd loss merge_dsplit merge_wgrad merge_segsum '
+              'merge_small merge_dgrad reparam_bwd heads_dsplit heads_wgrad heads_dgrad enc4_dsplit enc4_wgrad enc4_dgrad stats_enc3'),
+        bound='mfma', mac=688128 + 196608 + 196992),
+    'mid_conv (encoder layers 2-3, decoder layer 0)': dict(
+        tags=('enc2_split enc2_fwd stats_enc2 enc3_split enc3_fwd dec0_split dec0_fwd stats_dec0 dec0_gsplit dec0_asplit dec0_wgrad dec0_dgrad '
+              'enc3_gsplit enc3_asplit enc3_wgrad enc3_dgrad enc2_gsplit enc2_asplit enc2_wgrad enc2_dgrad'),
+        bound='mfma', mac=272384 + 401408 + 427680),
+    'thin_conv (encoder layers 0-1, decoder layers 1-2: fused conv kernels, fused layer-backward kernels)': dict(
+        tags=('enc0_fwd enc1_split enc1_fwd stats_enc1 dec1_split dec1_fwd stats_dec1 dec2_split dec2_fwd dec2_stats_planes dec2_bwd dec1_bwd '
+              'dec2_gsplit dec2_asplit dec2_wgrad dec2_dgrad dec1_gsplit dec1_asplit dec1_wgrad dec1_dgrad enc1_gsplit enc1_asplit enc1_wgrad '
+              'enc1_dgrad enc0_wgrad enc0_bwd enc0_reduce lnb_dec2 lnb_dec1 lnb_enc0'),
+        bound='hbm',
+        bytes=4 * ((_E['x'] + _E['e0']) + (_E['e0'] + _E['e1']) + (_E['d0'] + _E['d1']) + (_E['d1'] + _E['d2']) + (_E['d2'] + 4224)
+                   + (2 * _E['d2'] + 2 * _E['d1']) + (2 * _E['d1'] + 2 * _E['d0']) + (_E['e1'] + _E['e0']) + (_E['e1'] + _E['e0'])
+                   + (_E['e0'] + _E['x']))),
+    'layernorm_backward (separate LayerNorm + lrelu backward passes: decoder layer 0, encoder layers 1-4)': dict(
+        tags='lnb_dec0 lnb_enc4 lnb_enc3 lnb_enc2 lnb_enc1', bound='hbm',
+        bytes=4 * 3 * (_E['d0'] + _E['e4'] + _E['e3'] + _E['e2'] + _E['e1']), moved_not_algorithmic=True),
+    'weight_packing (per-step packed / split copies of the parameters)': dict(tags='prep', bound='hbm', bytes_per_step=10 * 939162 * 4),
+}
 
 
 def parse(argv=None):
@@ -428,6 +460,43 @@ def main(argv=None):
                     sib[tag] = {'avg_kernel_ms': k[0], 'achieved_tflops_fp32_equiv': a2, 'peak': out['roofline']['peak'],
                                 'frac': a2 / out['roofline']['peak']}
             out['roofline']['sibling_kernels'] = sib
+    # ---- roofline.sites: what the step is made of.  One short pass per kernel group (SITE_GROUPS), the five largest by time
+    #      reported with their own bound; `serialised_ms_per_step` = the same step with the weight-gradient stream serialised
+    #      (the sum the groups add up to; `value` is measured with the two streams overlapping)
+    if kern and args.impl == 'auto' and F >= 1024:
+        eng.set_tuned_masks(0xffffffff, 0xbfffffff)
+        try:
+            ser, _ = timed(F, 6, 2)
+            groups = []
+            for name, gdef in SITE_GROUPS.items():
+                _, k = timed(F, 3, 1, ','.join(gdef['tags'].split()))
+                if not k:
+                    continue
+                ms = k[0]
+                ent = {'group': name, 'ms_per_step': ms, 'launches_per_step': k[1] / k[2], 'bound': gdef['bound']}
+                if gdef['bound'] == 'mfma':
+                    ach = 3 * 2.0 * gdef['mac'] * F / (ms * 1e-3) / 1e12
+                    ent.update(achieved=ach, peak=BF16_PEAK / PRODUCTS[planes] / 1e12, unit='TFLOP/s (fp32-equivalent)',
+                               algorithmic_flops_per_step=3 * 2.0 * gdef['mac'] * F)
+                else:
+                    nbytes = gdef.get('bytes_per_step', gdef.get('bytes', 0) * F)
+                    ach = nbytes / (ms * 1e-3) / 1e9
+                    ent.update(achieved=ach, peak=HBM_PEAK / 1e9, unit='GB/s', bytes_per_step=nbytes,
+                               bytes_are=('moved by passes that exist only because layers are materialised (not algorithmic)'
+                                          if gdef.get('moved_not_algorithmic') else 'what the kernels of the group read + write once through their interfaces'))
+                ent['frac'] = ent['achieved'] / ent['peak']
+                groups.append(ent)
+            groups.sort(key=lambda e: -e['ms_per_step'])
+            tot = sum(e['ms_per_step'] for e in groups)
+            out['roofline']['sites'] = groups[:5]
+            out['roofline']['sites_note'] = {
+                'groups_sum_ms': tot, 'groups_beyond_the_five_ms': sum(e['ms_per_step'] for e in groups[5:]),
+                'serialised_ms_per_step': ser / 6 * 1e3, 'untagged_ms': ser / 6 * 1e3 - tot,
+                'ms_per_step': out['ms_per_step'],
+                'measured': 'HIP events around every launch of the group, one pass per group, weight-gradient stream serialised; '
+                            'untagged = Adam, fills, host gaps; ms_per_step is lower than the serialised sum by what the second stream overlaps'}
+        finally:
+            eng.set_tuned_masks(0xffffffff, 0xffffffff)
     # ---- the other precisions beside the default (never instead of it)
     if not args.no_modes and args.impl == 'auto':
         cur = 'bf16x2' if args.precision == 'auto' else args.precision
@@ -452,6 +521,11 @@ def main(argv=None):
         modes['note'] = ('bf16x2 (default): 2-term operand split; bf16x3: 3 terms, fp32-exact; '
                          'bf16: plain bf16 operands on the kernels that run on the bf16 matrix cores (tolerance 3e-2, tests)')
         out['modes'] = modes
+        # the fp32-exact figure beside the headline (the default feeds the matrix cores 16-mantissa-bit operand pairs)
+        if 'bf16x3' in modes:
+            out['reference_precision_value'] = {'value': modes['bf16x3']['frames_per_s'], 'unit': 'frames/s',
+                                                'ms_per_step': modes['bf16x3']['ms_per_step'],
+                                                'precision': 'bf16x3 = 3-term operand split, fp32-exact (measured error vs float64: 2e-6)'}
     if not args.no_literal:
         # the literal batch sizes: 256 frames per GPU (configs[1]; with N = 8 ranks the global batch is configs[2]'s
         # 2048) and 16 (configs[0], the reference's own batch_size)

@@ -35,6 +35,8 @@ class OracleBackend(object):
                offs['Encoder/dense/kernel'], 0]
         ends = [self.n_params] + cut[:-1]
         self.ranges = list(zip(cut, ends))
+        self.one_range = False     # the small-batch frame path: every gradient comes out of ONE launch, so the library hands
+                                   # over ONE range (csrc/gfx950_layers.hip: backward_frame)
         self.cb = None
         self.draws = []
 
@@ -53,7 +55,7 @@ class OracleBackend(object):
             out.copy_(l3)
         flat = torch.tensor(np.concatenate([G[n].ravel() for n in self.names]))
         grads.fill_(float('nan'))           # a range must be complete before its callback fires
-        for b, (lo, hi) in enumerate(self.ranges):
+        for b, (lo, hi) in enumerate([(0, self.n_params)] if self.one_range else self.ranges):
             grads[lo:hi] = flat[lo:hi]
             if self.cb is not None:
                 self.cb(b, lo, hi - lo, None)
@@ -73,6 +75,15 @@ def run(rank, world, F, steps, out, mode):
     st = Stepper(be, 1e-3, 0.5, 0.999, overlap=(mode != 'flat'), seed=3)
     assert st.world == world and st.rank == rank
     st.broadcast_params()
+    be.one_range = mode == 'one_range'
+    ncoll = []
+    if world > 1:      # count the collectives a step issues
+        real_ar = dist.all_reduce
+
+        def counting(*a, **k):
+            ncoll[-1] += 1
+            return real_ar(*a, **k)
+        dist.all_reduce = counting
     if mode == 'seeded':
         # every rank draws its OWN sampler noise: keys differ, and step t uses counter t
         assert st.seed == rank_seed(3, rank, world)
@@ -81,10 +92,15 @@ def run(rank, world, F, steps, out, mode):
         x, y, eps = O.make_inputs(SMALL_ARCH, F, 50 + t)
         x[F // 2:] *= 0.25                # shards with visibly different content (and losses)
         lo, hi = shard_range(F, rank, world)
+        ncoll.append(0)
         if mode == 'seeded':
             l3 = st.step(torch.tensor(x[lo:hi]), torch.tensor(y[lo:hi]))
         else:
             l3 = st.step(torch.tensor(x[lo:hi]), torch.tensor(y[lo:hi]), torch.tensor(eps[lo:hi]))
+    if world > 1:
+        dist.all_reduce = real_ar
+        # one_range / flat: ONE collective per step (gradients + losses in one buffer); bucket: the four ranges
+        assert ncoll == [1 if mode in ('one_range', 'flat') else 4] * steps, ncoll
     gl = st.mean_losses(l3)
     assert torch.allclose(gl, l3)
     if mode == 'seeded':

@@ -32,10 +32,12 @@ def launch(world, F, steps, out, mode='bucket'):
                 p.kill()
 
 
-@pytest.mark.parametrize('world,mode', [(2, 'bucket'), (2, 'flat'), (4, 'bucket')])
+@pytest.mark.parametrize('world,mode', [(2, 'bucket'), (2, 'flat'), (4, 'bucket'), (2, 'one_range')])
 def test_n_rank_equals_one_rank_on_concatenated_batch(tmp_path, world, mode):
     """bucket = the four gradient ranges all-reduced as the backward pass reports them (losses riding in the
-    tail of the first one); flat = one all-reduce of the whole buffer.  Shards carry different content."""
+    tail of the first one); flat = one all-reduce of the whole buffer; one_range = the small-batch frame path, where the
+    library reports the whole buffer as ONE range after its single weight-gradient launch (the worker counts the
+    collectives of every step: 4 / 1 / 1).  Shards carry different content."""
     F, steps = 8, 3
     outn, out1 = str(tmp_path / 'pn.npy'), str(tmp_path / 'p1.npy')
     launch(world, F, steps, outn, mode)

@@ -443,17 +443,20 @@ def test_fused_thin_conv_layers_against_oracle(F, seed, precision):
 FUSED_BWD = (0xffffffff, 0xffffbfff)    # bit 14 of the backward mask cleared: the one-kernel backward step of the thin decoder layers at any batch size
 
 
-@pytest.mark.parametrize('layers', ['3', '1', '2'])
-@pytest.mark.parametrize('F,seed', [(37, 5), (130, 9), (1, 7), (257, 12)])
-def test_fused_layer_backward_against_oracle(F, seed, layers, monkeypatch):
+@pytest.mark.parametrize('layers,dma', [('3', '1'), ('1', '1'), ('2', '1'), ('3', '0')])
+@pytest.mark.parametrize('F,seed', [(37, 5), (130, 9), (1, 7), (257, 12), (300, 13)])
+def test_fused_layer_backward_against_oracle(F, seed, layers, dma, monkeypatch):
     """Decoder layers 2 and 1: LayerNorm + lrelu backward, input gradient, weight gradient and the layer's d gamma / d beta /
     d bias in ONE kernel per layer (csrc/gfx950_fbwd.h: the gradient at the pre-LN output exists only as bf16 terms in LDS)
     against the float64 oracle; both layers, and each alone next to the three-kernel form of the other (the hand-over
-    buffers differ); batch sizes with a ragged last 2-frame group.  (By default from 1024 frames on.)"""
+    buffers differ); in its two forms: dma = 1, one eight-wave workgroup per CU whose next frame arrives by LDS-DMA in
+    landing buffers while the current one is processed (the default), dma = 0, staged through registers; batch sizes
+    below, at and above one frame per CU (256 workgroups).  (By default from 1024 frames on.)"""
     monkeypatch.setenv('VAENPVC_FB_LAYERS', layers)
+    monkeypatch.setenv('VAENPVC_FB_DMA', dma)
     eng = make_engine('vcc', 'auto', FUSED_BWD)
     eng.timer_select('dec2_bwd' if layers != '2' else 'dec1_bwd')
-    fails = compare_everything(eng, F, seed, 'fused-bwd layers=%s F%d ' % (layers, F))
+    fails = compare_everything(eng, F, seed, 'fused-bwd layers=%s dma=%s F%d ' % (layers, dma, F))
     _, n = eng.timer_read()
     eng.timer_select(None)
     assert n == 1, 'the fused backward kernel did not run'
@@ -559,7 +562,9 @@ def test_unfiltered_benchmark_batch_statistics(precision):
           <= UNFILTERED_X2_TENSOR_BAR                                                    [bf16x2, the default];
       (3) over all sampled entries: the share of entries off by more than 2e-4 of their tensor's scale is at most
           the float32 CPU restatement's share + UNFILTERED_SHARE_SLACK [bf16x3] / UNFILTERED_X2_SHARE_BAR [bf16x2];
-      (4) the median error stays at rounding level (<= 2e-5): kinks are rare events, not a shift."""
+      (4) the median error stays at rounding level (<= 2e-5): kinks are rare events, not a shift.
+    (The mechanism itself -- flips counted, pinned, plain bar -- is tested at 2 048 frames by
+    test_kink_flips_explain_the_unfiltered_gradient_excess, where the float64 oracle runs inside the test.)"""
     from hipvae import lib as L
     F, seed = 32768, 23
     arch = ARCHS['vcc']
@@ -604,6 +609,69 @@ def test_unfiltered_benchmark_batch_statistics(precision):
     report(tag + 'median entry error (fp32 CPU restatement: %.1e)' % np.median(errs32), med, 2e-5)
     if med > 2e-5:
         fails.append('median error %.3e' % med)
+    assert not fails, '\n'.join(fails)
+
+
+# lrelu units (LayerNorm outputs) that may land on the other side of the kink than in float64, per evaluated unit: a unit flips
+# when |n| is below the evaluation's own error in n (~1e-6 for fp32-exact operands, ~1e-5 for 16-mantissa-bit operand pairs;
+# n ~ N(0,1): density 0.4 at 0).  Stated bounds, ~4x the expectation:
+KINK_FLIP_RATE_BAR = {'bf16x3': 4e-6, 'bf16x2': 4e-5}
+
+
+@pytest.mark.parametrize('precision', ['bf16x3', 'bf16x2'])
+def test_kink_flips_explain_the_unfiltered_gradient_excess(precision):
+    """An UNFILTERED batch on the large-batch kernels (2 048 plain seeded frames, 38 M lrelu units), float64 oracle run inside
+    the test.  What test_unfiltered_benchmark_batch_statistics bounds statistically at 32 768 frames is tested here as a
+    mechanism: (1) the units whose branch differs between the GPU and float64 are COUNTED per layer and every one of them lies
+    within 1e-4 of the kink in float64 (a flipped unit away from the kink would be an arithmetic error); (2) their rate stays
+    under a stated bound per precision; (3) with exactly the near-kink units pinned to the GPU's branch, every gradient tensor
+    meets the PLAIN 2e-4 bar in both precisions -- so the excess of the unpinned comparison (reported, not asserted) is the
+    flips and nothing else."""
+    F, seed = 2048, 29
+    arch = ARCHS['vcc']
+    eng = make_engine('vcc', 'auto', precision=precision)
+    P = O.init_params(arch, seed)
+    x, y, eps = O.make_inputs(arch, F, seed)
+    l3, g = run_train(eng, P, x, y, eps)
+    assert np.isfinite(g).all()
+    br = gpu_branches(eng, arch, P, F)
+    # float64 pre-LN tensors from the PyTorch restatement (agrees with the NumPy one to 4e-15, tests/test_oracle.py; the NumPy
+    # loops take a minute at this batch size)
+    with torch.no_grad():
+        Pt = O.torch_params(P, torch.float64)
+        xt, et = torch.tensor(x, dtype=torch.float64), torch.tensor(eps, dtype=torch.float64)
+        z_mu, z_lv, eacts = O.torch_encode(arch, Pt, xt)
+        _, dacts = O.torch_decode(arch, Pt, z_mu + et * torch.sqrt(torch.exp(z_lv)), torch.tensor(y))
+    R = {'enc_a%d' % i: a.numpy()[..., 0] for i, (a, _) in enumerate(eacts)}
+    R.update({'dec_a%d' % i: a.numpy()[..., 0] for i, a in enumerate(dacts[1:])})
+    fails, tag = [], 'kink F%d %s ' % (F, precision)
+    flips = units = 0
+    for net, nl, pre in (('enc', 5, 'Encoder/Conv2d-%d/layernorm'), ('dec', 3, 'Generator/ConvT-LN%d')):
+        for i in range(nl):
+            a = R['%s_a%d' % (net, i)]
+            mu, rs = a.mean(axis=(1, 2), keepdims=True), 1 / np.sqrt(a.var(axis=(1, 2), keepdims=True) + 1e-5)
+            n = (a - mu) * rs * np.asarray(P[(pre % i) + '.scale'], np.float64).reshape(1, -1, 1) \
+                + np.asarray(P[(pre % i) + '.offset'], np.float64).reshape(1, -1, 1)
+            fl = (n >= 0) != br['%s%d' % (net, i)]
+            far = float(np.abs(n[fl]).max()) if fl.any() else 0.0
+            report(tag + '%s%d: %d of %d units flipped; largest |n| among them' % (net, i, int(fl.sum()), n.size), far, KINK_TAU)
+            if far >= KINK_TAU:
+                fails.append('%s%d: a unit with |n| = %.2e took the other branch' % (net, i, far))
+            flips += int(fl.sum())
+            units += n.size
+    rate = flips / units
+    report(tag + 'flip rate (%d of %d units)' % (flips, units), rate, KINK_FLIP_RATE_BAR[precision])
+    if rate > KINK_FLIP_RATE_BAR[precision]:
+        fails.append('flip rate %.2e' % rate)
+    _, Gp = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64, kink=br)
+    _, Gr = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64)
+    worst_raw = 0.0
+    for name, (off, shape) in eng.layout.items():
+        n = int(np.prod(shape))
+        got = g[off:off + n].reshape(shape)
+        check(tag + 'pinned grad ' + name, got, Gp[name], TOL_GRAD, fails)
+        worst_raw = max(worst_raw, rel_err(got, Gr[name]))
+    report(tag + 'UNPINNED worst gradient tensor (reported, not a bar)', worst_raw, float('inf'))
     assert not fails, '\n'.join(fails)
 
 

@@ -154,11 +154,17 @@ def test_two_contexts_on_two_host_threads():
     assert engines[0].precision == 2 and engines[1].precision == 3
 
 
-def test_gradient_bucket_callback_ranges_and_order():
-    """vaenpvc_set_bucket_callback: four contiguous ranges, reported back to front, tiling the flat buffer exactly;
-    a range is complete on the stream handed to the callback (checked by copying it there and then)."""
+@pytest.mark.parametrize('path', ['layered', 'frame'])
+def test_gradient_bucket_callback_ranges_and_order(path):
+    """vaenpvc_set_bucket_callback.  Layered kernels (every batch above 512 frames; forced here by clearing mask bit 21): four
+    contiguous ranges, reported back to front as the backward pass finishes them, tiling the flat buffer exactly.  Small-batch
+    frame kernels (the default at this batch size): every gradient comes out of one launch, so ONE range covers the buffer
+    (one all-reduce per step, not four back-to-back ones).  Either way a range is complete on the stream handed to the
+    callback (checked by copying it there and then)."""
     arch = load_arch()
     eng = make_engine()
+    if path == 'layered':
+        eng.set_tuned_masks(0xffffffff & ~(1 << 21), 0xffffffff & ~(1 << 21))
     eng.init_params(1)
     F = 64
     x, y, eps = O.make_inputs(arch, F, 1)
@@ -175,15 +181,19 @@ def test_gradient_bucket_callback_ranges_and_order():
     eng.train_fwd_bwd(xt, yt, et, grads)
     torch.cuda.synchronize()
     eng.set_bucket_callback(None)
-    assert [b for b, _, _ in seen] == [0, 1, 2, 3]
     offs = {n: o for n, (o, _) in eng.layout.items()}
-    want = [(offs['Generator/conv2d_transpose/kernel'], eng.n_params),
-            (offs['Generator/fully_connected/weights'], offs['Generator/conv2d_transpose/kernel']),
-            (offs['Encoder/dense/kernel'], offs['Generator/fully_connected/weights']),
-            (0, offs['Encoder/dense/kernel'])]
+    if path == 'layered':
+        want = [(offs['Generator/conv2d_transpose/kernel'], eng.n_params),
+                (offs['Generator/fully_connected/weights'], offs['Generator/conv2d_transpose/kernel']),
+                (offs['Encoder/dense/kernel'], offs['Generator/fully_connected/weights']),
+                (0, offs['Encoder/dense/kernel'])]
+    else:
+        want = [(0, eng.n_params)]
+    assert [b for b, _, _ in seen] == list(range(len(want)))
     assert [(o, o + c) for _, o, c in seen] == want
     for (_, off, cnt), snap in zip(seen, snaps):
         assert torch.equal(snap, grads[off:off + cnt])
+    assert grads.abs().max().item() > 0
     n0 = len(seen)
     eng.train_fwd_bwd(xt, yt, et, grads)
     assert len(seen) == n0                             # unregistered

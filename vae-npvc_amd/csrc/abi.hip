@@ -298,10 +298,10 @@ static int fwd_all(vaenpvc_ctx* ctx, const float* P, const float* x, const int64
   }
   if (use_tuned(ctx)) tuned::encoder_fwd(ctx->m, P, x, F, w, s);
   else generic::encoder_fwd(ctx->m, P, x, F, w, s);
-  generic::reparam_fwd(ctx->m, eps, key, F, w, s);
+  VAENPVC_TIMED("reparam", s, generic::reparam_fwd(ctx->m, eps, key, F, w, s));
   if (use_tuned(ctx)) tuned::decoder_fwd(ctx->m, P, w.z, y, F, w, w.xh, s, /*weights_packed=*/true);
   else generic::decoder_fwd(ctx->m, P, w.z, y, F, w, w.xh, s);
-  generic::loss_fwd(ctx->m, target ? target : x, F, w, want_grad, loss3, s);   // (the density's data argument)
+  VAENPVC_TIMED("loss", s, generic::loss_fwd(ctx->m, target ? target : x, F, w, want_grad, loss3, s));   // (the density's data argument)
   return 0;
 }
 

@@ -19,8 +19,18 @@ namespace vaenpvc {
 namespace tuned {
 
 // frames per workgroup and 32-row tiles per wave step, per site (0 = site not served by this kernel)
+#ifndef VAENPVC_FC_W2
+#define VAENPVC_FC_W2 0     // bit set of CV_* sites on TWO-wave workgroups with 2-frame groups, four per CU: the same registers and LDS per CU as
+                            // two four-wave workgroups with 4-frame groups, but four independent load -> convert -> GEMM -> store pipelines
+#endif
+constexpr bool fc_w2(int site) { return (VAENPVC_FC_W2 >> site) & 1; }
+#ifndef VAENPVC_FC_OCC3
+#define VAENPVC_FC_OCC3 0x20   // bit set of CV_* sites on 2-frame groups with three workgroups per CU (168 registers) instead of 4-frame groups with two:
+                               // decoder layer 2 forward (the largest frames) 268 -> 244 us; the other thin sites lose 15 - 50 % (same-box A/B, round 4)
+#endif
+constexpr bool fc_occ3(int site) { return (VAENPVC_FC_OCC3 >> site) & 1; }
 constexpr int fc_tf(int site) {
-  return site == CV_E1F || site == CV_D1F || site == CV_D2F || site == CV_E1G || site == CV_D1G ? 4
+  return fc_occ3(site) || fc_w2(site) ? 2 : site == CV_E1F || site == CV_D1F || site == CV_D2F || site == CV_E1G || site == CV_D1G ? 4
          : site == CV_D2G ? 2
          : site == CV_E2G ? 6   // a medium site: weights + frames fill most of the LDS (one workgroup per CU with 2 planes)
                           : 0;
@@ -29,6 +39,9 @@ constexpr int fc_tf(int site) {
 //  against 64 rows: two waves per M tile re-read every B fragment, one workgroup per CU)
 constexpr int fc_nj(int site) { return site == CV_D2G || site == CV_E2G ? 1 : 2; }
 
+#ifndef VAENPVC_FC_ABL
+#define VAENPVC_FC_ABL 0   // developer ablation (wrong results): 1 no global loads, 2 no conversion / LDS stores, 4 no fragment reads / MFMAs, 8 no result stores
+#endif
 template <int NPL, int SITE>
 struct FcCfg {
   static constexpr CvSite V = CVS[SITE];
@@ -38,11 +51,14 @@ struct FcCfg {
   static constexpr int CPL = (CP == 32 || CP == 64 || CP == 128) ? CP + 8 : CP;
   static constexpr int FS = HP * CPL;                  // elements per frame
   static constexpr int TF = fc_tf(SITE), NJ = fc_nj(SITE), SROWS = 32 * NJ;
+  static constexpr int NWV = fc_w2(SITE) ? 2 : 4, NTHR = 64 * NWV;      // waves / threads per workgroup
   static constexpr int XPL = TF * FS + 64;             // elements per plane (+ zero tail: K runs rounded up to 16)
   static constexpr int K = V.NT * CP, KS = cdiv(K, 16);
   static constexpr int MT = cdiv(V.M, 32), WP = V.Kp + 8, WPL = MT * 32 * WP;   // weight rows padded by 16 bytes
   static constexpr int RSTEP = (V.step / CP) * CPL;    // elements between GEMM rows
   static constexpr int LDS = NPL * (XPL + WPL) * 2;
+  static constexpr int OCC = fc_occ3(SITE) && 3 * LDS <= 156 * 1024 ? 3 : 2;   // waves per SIMD the kernel is compiled for
+  static constexpr int WGS_PER_CU = fc_w2(SITE) ? (4 * LDS <= 160 * 1024 ? 4 : 3) : OCC;
   static_assert(TF > 0 && C <= 64 && KS * 16 <= V.Kp, "site not served");
 };
 
@@ -68,7 +84,7 @@ __device__ __forceinline__ int fc_koff(int ks, int lh) {
 
 // LN: 0 plain input, 1 LayerNorm + lrelu with given statistics, 2 ... with statistics computed here
 template <int NPL, int SITE, int LN>
-__global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
+__global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (FcCfg<NPL, SITE>::OCC)) k_fconv(FcArgs a) {
   using T = FcCfg<NPL, SITE>;
   constexpr CvSite V = T::V;
   extern __shared__ __attribute__((aligned(16))) unsigned short fsm[];
@@ -76,18 +92,18 @@ __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
   unsigned short* xs = fsm;                       // [NPL][XPL]
   unsigned short* ws = fsm + NPL * T::XPL;        // [NPL][MT*32][WP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  constexpr int NCH = cdiv(T::H, 64);
+  constexpr int NCH = cdiv(T::H, 64), NWV = T::NWV, NTHR = T::NTHR;
   const int ngroups = cdiv(a.F, T::TF);
   // staging items = (frame of the group, 64-position chunk), dealt round-robin to the four waves; an item's C coalesced
   // 256-byte loads go to registers one step ahead: the loads of group g + 1 fly during the GEMM of group g, the
   // conversion and the 16-byte LDS stores happen at the top of the next iteration
-  constexpr int NIT = T::TF * NCH, IPW = cdiv(NIT, 4);
+  constexpr int NIT = T::TF * NCH, IPW = cdiv(NIT, NWV);
   float v[IPW][T::CP];
   float mean[IPW], rstd[IPW];
   auto fload = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < IPW; ++u) {
-      const int it = wave + 4 * u, fl = it / NCH, k = it - fl * NCH;
+      const int it = wave + NWV * u, fl = it / NCH, k = it - fl * NCH;
       const int f = g * T::TF + fl, h = 64 * k + lane;
       const bool fok = it < NIT && f < a.F;
       const float* sf = a.src + (int64_t)(fok ? f : 0) * (T::C * T::H);
@@ -96,7 +112,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
         rstd[u] = a.st[2 * (fok ? f : 0) + 1];
       }
 #pragma unroll
-      for (int c = 0; c < T::CP; ++c) v[u][c] = (c < T::C && h < T::H && fok) ? sf[c * T::H + h] : 0.f;
+      for (int c = 0; c < T::CP; ++c) v[u][c] = (!(VAENPVC_FC_ABL & 1) && c < T::C && h < T::H && fok) ? sf[c * T::H + h] : 0.f;
     }
   };
   // LayerNorm statistics of the group's frames from the registers (LN == 2): per item partial sums through LDS, two
@@ -105,7 +121,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
     constexpr float INVN = 1.0f / (T::C * T::H);
 #pragma unroll
     for (int u = 0; u < IPW; ++u) {
-      const int it = wave + 4 * u;
+      const int it = wave + NWV * u;
       float sm = 0.f;
 #pragma unroll
       for (int c = 0; c < T::C; ++c) sm += v[u][c];       // (invalid lanes / frames hold zeros)
@@ -115,7 +131,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < IPW; ++u) {
-      const int it = wave + 4 * u, fl = (it < NIT ? it : 0) / NCH, k = it - fl * NCH;
+      const int it = wave + NWV * u, fl = (it < NIT ? it : 0) / NCH, k = it - fl * NCH;
       float sm = 0.f;
 #pragma unroll
       for (int kk = 0; kk < NCH; ++kk) sm += part[0][fl * NCH + kk];
@@ -133,7 +149,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < IPW; ++u) {
-      const int it = wave + 4 * u, fl = (it < NIT ? it : 0) / NCH, k = it - fl * NCH;
+      const int it = wave + NWV * u, fl = (it < NIT ? it : 0) / NCH, k = it - fl * NCH;
       float q = 0.f;
 #pragma unroll
       for (int kk = 0; kk < NCH; ++kk) q += part[1][fl * NCH + kk];
@@ -146,10 +162,11 @@ __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
     }
   };
   auto fstore = [&](int g) __attribute__((always_inline)) {
+    if constexpr ((VAENPVC_FC_ABL & 2) != 0) return;
     if constexpr (LN == 2) fstats(g);
 #pragma unroll
     for (int u = 0; u < IPW; ++u) {
-      const int it = wave + 4 * u, fl = it / NCH, k = it - fl * NCH;
+      const int it = wave + NWV * u, fl = it / NCH, k = it - fl * NCH;
       const int h = 64 * k + lane;
       if (!(it < NIT && g * T::TF + fl < a.F && h < T::H)) continue;
       if constexpr (LN != 0) {
@@ -174,19 +191,19 @@ __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
   // ---- once per workgroup: zero the frame tile (halo rows, channel padding, tail stay zero), copy the weights
   {
     const u32x4 z = {0u, 0u, 0u, 0u};
-    for (int i = tid; i < NPL * T::XPL / 8; i += 256) reinterpret_cast<u32x4*>(xs)[i] = z;
-    constexpr int WROW8 = V.Kp / 8, WPIECES = NPL * T::MT * 32 * WROW8, WPT = cdiv(WPIECES, 256);
+    for (int i = tid; i < NPL * T::XPL / 8; i += NTHR) reinterpret_cast<u32x4*>(xs)[i] = z;
+    constexpr int WROW8 = V.Kp / 8, WPIECES = NPL * T::MT * 32 * WROW8, WPT = cdiv(WPIECES, NTHR);
     u32x4 wr[WPT];
 #pragma unroll
     for (int u = 0; u < WPT; ++u) {
-      int i = tid + 256 * u;
+      int i = tid + NTHR * u;
       i = i < WPIECES ? i : WPIECES - 1;
       const int p = i / (T::MT * 32 * WROW8), r = i - p * (T::MT * 32 * WROW8), m = r / WROW8, c8 = r - m * WROW8;
       wr[u] = *reinterpret_cast<const u32x4*>(a.W + ((size_t)p * V.Mp + m) * V.Kp + c8 * 8);
     }
 #pragma unroll
     for (int u = 0; u < WPT; ++u) {
-      int i = tid + 256 * u;
+      int i = tid + NTHR * u;
       i = i < WPIECES ? i : WPIECES - 1;
       const int p = i / (T::MT * 32 * WROW8), r = i - p * (T::MT * 32 * WROW8), m = r / WROW8, c8 = r - m * WROW8;
       *reinterpret_cast<u32x4*>(ws + p * T::WPL + m * T::WP + c8 * 8) = wr[u];
@@ -201,7 +218,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
     if (g + (int)gridDim.x < ngroups) fload(g + gridDim.x);
     // ---- GEMM rows n = fl * R + q, SROWS per step, steps dealt round-robin to the waves
     const int nrows = nf * V.R, nsteps = cdiv(nrows, T::SROWS);
-    for (int s = wave; s < nsteps; s += 4) {
+    for (int s = wave; s < nsteps; s += NWV) {
       int xoff[T::NJ];
 #pragma unroll
       for (int j = 0; j < T::NJ; ++j) {
@@ -216,7 +233,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
 #pragma unroll
         for (int j = 0; j < T::NJ; ++j) acc[i][j] = zero16();
 #pragma unroll
-      for (int ks = 0; ks < T::KS; ++ks) {
+      for (int ks = 0; ks < ((VAENPVC_FC_ABL & 4) ? 0 : T::KS); ++ks) {
         u32x4 fa[T::MT][NPL], fb[T::NJ][NPL];
         const int ko = fc_koff<T::CP, T::CPL>(ks, lh);
 #pragma unroll
@@ -239,7 +256,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
 #pragma unroll
       for (int j = 0; j < T::NJ; ++j) {
         const int n = s * T::SROWS + j * 32 + l31;
-        if (n >= nrows) continue;
+        if (n >= nrows || ((VAENPVC_FC_ABL & 8) && a.F > 0)) continue;
         const int fl = n / V.R, q = n - fl * V.R;
         float* ob = a.out + (int64_t)(f0 + fl) * (V.OC * V.OH);
         const int pbase = q * V.oq + V.o0;
@@ -293,16 +310,16 @@ __global__ void __launch_bounds__(256, 2) k_fconv(FcArgs a) {
 template <int NPL, int SITE>
 static void launch_fconv(const FcArgs& a, hipStream_t s) {
   using T = FcCfg<NPL, SITE>;
-  const unsigned grid = (unsigned)cmin_(cdiv(a.F, T::TF), T::LDS > 80 * 1024 ? 256 : 512);   // persistent: two workgroups per CU walk the frame groups
+  const unsigned grid = (unsigned)cmin_(cdiv(a.F, T::TF), T::LDS > 80 * 1024 ? 256 : 256 * T::WGS_PER_CU);   // persistent: two (three) workgroups per CU walk the frame groups
   if (a.st_out) {
     rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, 2>), T::LDS);
-    hipLaunchKernelGGL((k_fconv<NPL, SITE, 2>), dim3(grid), dim3(256), T::LDS, s, a);
+    hipLaunchKernelGGL((k_fconv<NPL, SITE, 2>), dim3(grid), dim3(T::NTHR), T::LDS, s, a);
   } else if (a.st) {
     rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, 1>), T::LDS);
-    hipLaunchKernelGGL((k_fconv<NPL, SITE, 1>), dim3(grid), dim3(256), T::LDS, s, a);
+    hipLaunchKernelGGL((k_fconv<NPL, SITE, 1>), dim3(grid), dim3(T::NTHR), T::LDS, s, a);
   } else {
     rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, 0>), T::LDS);
-    hipLaunchKernelGGL((k_fconv<NPL, SITE, 0>), dim3(grid), dim3(256), T::LDS, s, a);
+    hipLaunchKernelGGL((k_fconv<NPL, SITE, 0>), dim3(grid), dim3(T::NTHR), T::LDS, s, a);
   }
 }
 // site dispatch (only the thin sites are instantiated)

@@ -364,7 +364,7 @@ static void prep(const Model& m, const float* P, const Ws& w, int64_t F, hipStre
     if (!dense_planes_used) j.count = 0;
     return j;
   };
-  launch_pack_multi(
+  VAENPVC_TIMED("prep", s, launch_pack_multi(
       s,
       pack_job(PackDense{P + m.wmu_off, P + m.wlv_off, 0, 768, 256, HeadsF::NP, 128, 128}, S + Pk::heads_f, HeadsF::KP * HeadsF::NP),
       pack_job(PackDense{P + m.wmu_off, P + m.wlv_off, 2, 256, 768, HeadsB::NP, 128, 128}, S + Pk::heads_b, HeadsB::KP * HeadsB::NP),
@@ -396,7 +396,7 @@ static void prep(const Model& m, const float* P, const Ws& w, int64_t F, hipStre
       pj(planes_job<NPD>(WMergeB{P + m.wz_off, 1539}, S + Pk::pg_mergeb, 128, 1600)),
       pj(planes_job<NPD>(WEnc4F{P + m.enc[4].w_off}, S + Pk::pg_enc4f, 768, 896)),
       pj(planes_job<NPD>(WEnc4B{P + m.enc[4].w_off}, S + Pk::pg_enc4b, 896, 768)),
-      pack_job(PackRepeat3{P + m.enc[4].b_off}, S + Pk::pg_bias4, 768));
+      pack_job(PackRepeat3{P + m.enc[4].b_off}, S + Pk::pg_bias4, 768)));
   // weight planes of the conv view-GEMM sites.  TF layouts: conv [T][Cin][Cout], conv_transpose [T][Cout][Cin];
   // (s_t, s_o, s_c) = strides of (tap, GEMM output channel, contracted channel)
   if (cg_fwd(F) || cg_bwd(F) || fc_any(F) || fb_bwd(FB_D2, F) || fb_bwd(FB_D1, F)) {
@@ -419,10 +419,10 @@ static void prep(const Model& m, const float* P, const Ws& w, int64_t F, hipStre
       auto pe = fcr_perm_job<NPD>(CV_E2G, P + m.enc[2].w_off, m.enc[2].cin * m.enc[2].cout, m.enc[2].cout, 1, S + Pk::cvwr_e2g);
       if (!fcr_fwd(CV_D0F, F)) pd.count = 0;
       if (!fcr_bwd(CV_E2G, F)) pe.count = 0;
-      if (pd.count || pe.count) launch_pack_multi(s, pd, pe);
+      if (pd.count || pe.count) VAENPVC_TIMED("prep", s, launch_pack_multi(s, pd, pe));
     }
-    launch_pack_multi(s, ef(CV_E1F, 1), ef(CV_E2F, 2), ef(CV_E3F, 3), df(CV_D0F, 0), df(CV_D1F, 1), df(CV_D2F, 2),
-                      eg(CV_E3G, 3), eg(CV_E2G, 2), eg(CV_E1G, 1), dg(CV_D0G, 0), dg(CV_D1G, 1), dg(CV_D2G, 2));
+    VAENPVC_TIMED("prep", s, launch_pack_multi(s, ef(CV_E1F, 1), ef(CV_E2F, 2), ef(CV_E3F, 3), df(CV_D0F, 0), df(CV_D1F, 1), df(CV_D2F, 2),
+                      eg(CV_E3G, 3), eg(CV_E2G, 2), eg(CV_E1G, 1), dg(CV_D0G, 0), dg(CV_D1G, 1), dg(CV_D2G, 2)));
   }
   });
   });
@@ -545,22 +545,22 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
     if (fc_fwd(CV_E1F, F)) fused(CV_E1F, w.enc_a[0], w.enc_st[0], nullptr, &m.enc[0], P + m.enc[1].b_off, w.enc_a[1], "enc1_fwd");
     else if (cv_fwd(CV_E1F, F)) enc_view(CV_E1F, CL_Y0, 1, false, "enc1_split", "enc1_fwd");
     else VAENPVC_TIMED("enc1_fwd", s, launch_convgemm<E1F>(lnp(1), nsplit_for<E1F>(F), s));
-    if (!(have_y1 = enc_stats(1, CV_E2F, CL_Y1, "enc2_split"))) stats<1824>(w.enc_a[1], w.enc_st[1], F, s);
+    if (!(have_y1 = enc_stats(1, CV_E2F, CL_Y1, "enc2_split"))) VAENPVC_TIMED("stats_enc1", s, stats<1824>(w.enc_a[1], w.enc_st[1], F, s));
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 1);
   if (fwd_on(2)) {
     if (fcr_fwd(CV_E2F, F)) fused_r(CV_E2F, w.scratch + Pk::cvw + cv_woff(CV_E2F), w.enc_a[1], w.enc_st[1], &m.enc[1], P + m.enc[2].b_off, w.enc_a[2], "enc2_fwd");
     else if (cv_fwd(CV_E2F, F)) enc_view(CV_E2F, CL_Y1, 2, have_y1, "enc2_split", "enc2_fwd");
     else VAENPVC_TIMED("enc2_fwd", s, launch_convgemm<E2F>(lnp(2), nsplit_for<E2F>(F), s));
-    if (!(have_y2 = enc_stats(2, CV_E3F, CL_Y2, "enc3_split"))) stats<1216>(w.enc_a[2], w.enc_st[2], F, s);
+    if (!(have_y2 = enc_stats(2, CV_E3F, CL_Y2, "enc3_split"))) VAENPVC_TIMED("stats_enc2", s, stats<1216>(w.enc_a[2], w.enc_st[2], F, s));
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 2);
   if (fwd_on(3) && cv_fwd(CV_E3F, F)) {
     enc_view(CV_E3F, CL_Y2, 3, have_y2, "enc3_split", "enc3_fwd");
-    stats_planes<896, 7>(w.enc_a[3], w.enc_st[3], P + m.enc[3].gamma_off, P + m.enc[3].beta_off, w.pl_y3,
-                         fwd_on(4) && pg_fwd(F), F, s);
+    VAENPVC_TIMED("stats_enc3", s, stats_planes<896, 7>(w.enc_a[3], w.enc_st[3], P + m.enc[3].gamma_off, P + m.enc[3].beta_off, w.pl_y3,
+                         fwd_on(4) && pg_fwd(F), F, s));
   } else if (fwd_on(3)) {
     VAENPVC_TIMED("enc3_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<E3Fs>(lnp(3), nsplit_for<E3Fs>(F), s) : launch_convgemm<E3F>(lnp(3), nsplit_for<E3F>(F), s)));
-    stats_planes<896, 7>(w.enc_a[3], w.enc_st[3], P + m.enc[3].gamma_off, P + m.enc[3].beta_off, w.pl_y3,
-                         fwd_on(4) && pg_fwd(F), F, s);
+    VAENPVC_TIMED("stats_enc3", s, stats_planes<896, 7>(w.enc_a[3], w.enc_st[3], P + m.enc[3].gamma_off, P + m.enc[3].beta_off, w.pl_y3,
+                         fwd_on(4) && pg_fwd(F), F, s));
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 3);
   if (fwd_on(4) && pg_fwd(F)) {
     // layer 4 as the dense layer [F, 896] x [896, 768] on the bf16 matrix cores (gfx950_planegemm.h)
@@ -578,12 +578,12 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
       a.bias = w.scratch + Pk::pg_bias4;
       VAENPVC_TIMED("enc4_fwd", s, launch_gemm_nt<NPL>(a, s));
     });
-    stats_planes<768, 3>(w.enc_a[4], w.enc_st[4], P + m.enc[4].gamma_off, P + m.enc[4].beta_off, w.pl_y4,
-                         fwd_on(5) && pg_fwd(F), F, s);
+    VAENPVC_TIMED("stats_enc4", s, stats_planes<768, 3>(w.enc_a[4], w.enc_st[4], P + m.enc[4].gamma_off, P + m.enc[4].beta_off, w.pl_y4,
+                         fwd_on(5) && pg_fwd(F), F, s));
   } else if (fwd_on(4)) {
     VAENPVC_TIMED("enc4_fwd", s, launch_convgemm<E4F>(lnp(4), nsplit_for<E4F>(F), s));
-    stats_planes<768, 3>(w.enc_a[4], w.enc_st[4], P + m.enc[4].gamma_off, P + m.enc[4].beta_off, w.pl_y4,
-                         fwd_on(5) && pg_fwd(F), F, s);
+    VAENPVC_TIMED("stats_enc4", s, stats_planes<768, 3>(w.enc_a[4], w.enc_st[4], P + m.enc[4].gamma_off, P + m.enc[4].beta_off, w.pl_y4,
+                         fwd_on(5) && pg_fwd(F), F, s));
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 4);
   if (fwd_on(5) && pg_fwd(F)) {
     for_dense_planes([&](auto npl) {
@@ -680,27 +680,27 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
                 P + m.dec[0].b_off, w.dec_a[0], F};
       VAENPVC_TIMED("dec0_fwd", s, fconv_r<decltype(npl)::value>(CV_D0F, fa, s));
     });
-    if (!d1_fused && !(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
+    if (!d1_fused && !(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) VAENPVC_TIMED("stats_dec0", s, stats<1824>(w.dec_a[0], w.dec_st[0], F, s));
   } else if (fwd_on(7) && cv_fwd(CV_D0F, F)) {
     dec_view(CV_D0F, CL_H, 0, false, w.h, "dec0_split", "dec0_fwd");
-    if (!d1_fused && !(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
+    if (!d1_fused && !(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) VAENPVC_TIMED("stats_dec0", s, stats<1824>(w.dec_a[0], w.dec_st[0], F, s));
   } else if (fwd_on(7)) {
     VAENPVC_TIMED("dec0_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<D0Fs>(conv_args(w.h, nullptr, nullptr, nullptr, w.scratch + Pk::d0f,
                                                                 P + m.dec[0].b_off, w.dec_a[0], F), nsplit_for<D0Fs>(F), s) : launch_convgemm<D0F>(conv_args(w.h, nullptr, nullptr, nullptr, w.scratch + Pk::d0f,
                                                                 P + m.dec[0].b_off, w.dec_a[0], F), nsplit_for<D0F>(F), s)));
-    if (!d1_fused && !(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) stats<1824>(w.dec_a[0], w.dec_st[0], F, s);
+    if (!d1_fused && !(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) VAENPVC_TIMED("stats_dec0", s, stats<1824>(w.dec_a[0], w.dec_st[0], F, s));
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 0);
   if (fwd_on(8) && fc_fwd(CV_D1F, F)) {
     fused(CV_D1F, w.dec_a[0], nullptr, w.dec_st[0], &m.dec[0], P + m.dec[1].b_off, w.dec_a[1], "dec1_fwd");
-    if (!d2_fused && !(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
+    if (!d2_fused && !(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) VAENPVC_TIMED("stats_dec1", s, stats<2736>(w.dec_a[1], w.dec_st[1], F, s));
   } else if (fwd_on(8) && cv_fwd(CV_D1F, F)) {
     dec_view(CV_D1F, CL_YD0, 1, have_yd0, w.dec_a[0], "dec1_split", "dec1_fwd");
-    if (!d2_fused && !(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
+    if (!d2_fused && !(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) VAENPVC_TIMED("stats_dec1", s, stats<2736>(w.dec_a[1], w.dec_st[1], F, s));
   } else if (fwd_on(8)) {
     VAENPVC_TIMED("dec1_fwd", s, launch_convgemm<D1F>(conv_args(w.dec_a[0], w.dec_st[0], P + m.dec[0].gamma_off,
                                                                 P + m.dec[0].beta_off, w.scratch + Pk::d1f,
                                                                 P + m.dec[1].b_off, w.dec_a[1], F), nsplit_for<D1F>(F), s));
-    if (!d2_fused && !(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) stats<2736>(w.dec_a[1], w.dec_st[1], F, s);
+    if (!d2_fused && !(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) VAENPVC_TIMED("stats_dec1", s, stats<2736>(w.dec_a[1], w.dec_st[1], F, s));
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 1);
   if (fwd_on(9)) {
     if (fc_fwd(CV_D2F, F)) fused(CV_D2F, w.dec_a[1], nullptr, w.dec_st[1], &m.dec[1], P + m.dec[2].b_off, w.dec_a[2], "dec2_fwd");
@@ -711,19 +711,19 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
                                                                 P + m.dec[2].b_off, w.dec_a[2], F), nsplit_for<D2F>(F), s));
     if (toep_bf16_for(F) && fwd_on(10))
       for_planes([&](auto npl) {
-        hipLaunchKernelGGL(k_ln_stats_act_planes<decltype(npl)::value>, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
+        VAENPVC_TIMED("dec2_stats_planes", s, hipLaunchKernelGGL(k_ln_stats_act_planes<decltype(npl)::value>, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
                            P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, reinterpret_cast<unsigned short*>(w.toep_yp),
                            w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, (int)F, toep_wgrad_bf16_for(F) ? 0 : 1,
-                           toep_fwd_groups(F, weights_packed) > 1 ? 1 : 0);
+                           toep_fwd_groups(F, weights_packed) > 1 ? 1 : 0));
       });
     else
-      hipLaunchKernelGGL((k_ln_stats_act<4104, 513>), dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
-                         P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, F);
+      VAENPVC_TIMED("dec2_stats_planes", s, hipLaunchKernelGGL((k_ln_stats_act<4104, 513>), dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
+                         P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, F));
   } else {
     generic::dec_layer_fwd(m, P, F, w, xh_out, s, 2);
     int64_t tot = (int64_t)F * 4104;
-    hipLaunchKernelGGL(k_act_from_stats, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
-                       P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, tot, 4104, 513);
+    VAENPVC_TIMED("dec2_stats_planes", s, hipLaunchKernelGGL(k_act_from_stats, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
+                       P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, tot, 4104, 513));
   }
   if (fwd_on(10)) {
     rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_fwd<4>), TF_LDS);
@@ -801,8 +801,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   const bool toep_planes = bwd_on(10) && toep_bf16_for(F);
   if (toep_planes)
     for_planes([&](auto npl) {
-      hipLaunchKernelGGL(k_dxh_post<decltype(npl)::value>, dim3((unsigned)cmin_(2048, cdiv((int)F, 4))), dim3(256), 0, s, w.d_xh, P + m.dec[3].w_off,
-                         reinterpret_cast<unsigned short*>(w.toep_gp), w.dy_tmp, G + m.dec[3].b_off, (int)F);
+      VAENPVC_TIMED("dxh_post", s, hipLaunchKernelGGL(k_dxh_post<decltype(npl)::value>, dim3((unsigned)cmin_(2048, cdiv((int)F, 4))), dim3(256), 0, s, w.d_xh, P + m.dec[3].w_off,
+                         reinterpret_cast<unsigned short*>(w.toep_gp), w.dy_tmp, G + m.dec[3].b_off, (int)F));
     });
   ready();
   bool dec_bias_done[4] = {false, false, false, false};
@@ -912,8 +912,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("dec3_row512", s2, hipLaunchKernelGGL(k_toep_wgrad_row512, dim3((unsigned)cdiv(F, efc), 3), dim3(256), 0, s2, w.dec_y, w.d_xh,
                                                        G + m.dec[3].w_off, F, efc));
     if (!toep_planes)  // (k_dxh_post computed it)
-      hipLaunchKernelGGL(k_sum_all_atomic, dim3((unsigned)cmin_(1024, cdiv(F * 513, 1024))), dim3(256), 0, s2, w.d_xh,
-                         (int64_t)F * 513, G + m.dec[3].b_off);
+      VAENPVC_TIMED("dec3_bias", s2, hipLaunchKernelGGL(k_sum_all_atomic, dim3((unsigned)cmin_(1024, cdiv(F * 513, 1024))), dim3(256), 0, s2, w.d_xh,
+                         (int64_t)F * 513, G + m.dec[3].b_off));
     rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_dgrad<8, 8>), TD_LDS);
     rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_dgrad<1, 4>), TD_LDS);
     if (toep_bf16_for(F)) {
@@ -935,8 +935,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     }
     // (with the whole backward step of layer 2 in one kernel, gfx950_fbwd.h, its LayerNorm backward runs there)
     if (!(bwd_on(9) && fb_bwd(FB_D2, F))) {
-      launch_ln_bwd<LnbCfg<8, 513>>(w.dy_tmp, w.dec_a[2], w.dec_st[2], P + l2.gamma_off, P + l2.beta_off, w.d_dec_a[2],
-                                       G + l2.gamma_off, G + l2.beta_off, G + l2.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+      VAENPVC_TIMED("lnb_dec2", s, launch_ln_bwd<LnbCfg<8, 513>>(w.dy_tmp, w.dec_a[2], w.dec_st[2], P + l2.gamma_off, P + l2.beta_off, w.d_dec_a[2],
+                                       G + l2.gamma_off, G + l2.beta_off, G + l2.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
       dec_bias_done[2] = true;
     }
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 3);
@@ -961,8 +961,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     fused_bwd(FB_D2, 2, w.dy_tmp, w.d_dec_a[2], "dec2_bwd");
     dy_cur = w.d_dec_a[2];
     if (!(bwd_on(8) && fb_bwd(FB_D1, F))) {
-      launch_ln_bwd<LnbCfg<16, 171>>(dy_cur, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[1],
-                                        G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+      VAENPVC_TIMED("lnb_dec1", s, launch_ln_bwd<LnbCfg<16, 171>>(dy_cur, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[1],
+                                        G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
       dec_bias_done[1] = true;
     }
   } else if (bwd_on(9)) {
@@ -983,8 +983,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("dec2_dgrad", s, launch_convgemm<GD2>(conv_args(w.d_dec_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::gd2,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GD2>(F), s));
     if (!(bwd_on(8) && fb_bwd(FB_D1, F))) {   // (layer 1's fused backward kernel does it otherwise)
-      launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[1],
-                                        G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+      VAENPVC_TIMED("lnb_dec1", s, launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.dec_a[1], w.dec_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[1],
+                                        G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
       dec_bias_done[1] = true;
     }
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 2);
@@ -994,8 +994,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const ConvL& pl = m.dec[0];
     float* dy0 = dy_cur == w.dy_tmp ? w.d_dec_a[1] : w.dy_tmp;
     fused_bwd(FB_D1, 1, dy_cur, dy0, "dec1_bwd");
-    launch_ln_bwd<LnbCfg<32, 57>>(dy0, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[0],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+    VAENPVC_TIMED("lnb_dec0", s, launch_ln_bwd<LnbCfg<32, 57>>(dy0, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[0],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
     dec_bias_done[0] = true;
   } else if (bwd_on(8)) {
     const ConvL &l = m.dec[1], &pl = m.dec[0];
@@ -1014,8 +1014,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     else
     VAENPVC_TIMED("dec1_dgrad", s, launch_convgemm<GD1>(conv_args(w.d_dec_a[1], nullptr, nullptr, nullptr, P + l.w_off, nullptr,
                                                                   w.dy_tmp, F), nsplit_for<GD1>(F), s));
-    launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[0],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+    VAENPVC_TIMED("lnb_dec0", s, launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[0],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
     dec_bias_done[0] = true;
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 1);
 
@@ -1066,8 +1066,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("merge_segsum", s, hipLaunchKernelGGL(k_segsum_atomic<MERGE_NY>, dim3((unsigned)cdiv(1539, 256), (unsigned)cdiv(F, fc)), dim3(256), 0, s,
                                                         w.d_h, y, 1539, F, fc, Sg));
     const int nb_w = cdiv(128 * 1539, 256), nb_e = cdiv(MERGE_NY * 128, 4), nb_b = cdiv(1539, 256);
-    hipLaunchKernelGGL(k_merge_small<MERGE_NY>, dim3((unsigned)(nb_w + nb_e + nb_b)), dim3(256), 0, s, Sg, P + m.emb_off, P + m.wy_off, 128,
-                       1539, G + m.wy_off, G + m.emb_off, G + m.bz_off, G + m.by_off, G + m.bm_off, nb_w, nb_e);
+    VAENPVC_TIMED("merge_small", s, hipLaunchKernelGGL(k_merge_small<MERGE_NY>, dim3((unsigned)(nb_w + nb_e + nb_b)), dim3(256), 0, s, Sg, P + m.emb_off, P + m.wy_off, 128,
+                       1539, G + m.wy_off, G + m.emb_off, G + m.bz_off, G + m.by_off, G + m.bm_off, nb_w, nb_e));
     if (pgm) {
       for_dense_planes([&](auto npl) {
         constexpr int NPL = decltype(npl)::value;
@@ -1088,8 +1088,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   const bool heads_tuned = bwd_on(5);
   if (heads_tuned) {  // sampler + KL backward fused with the two head-bias gradients
     const int rch = cmax(1, cmin_(cdiv(F, 32), 1024)), rfc = cdiv(F, rch);
-    hipLaunchKernelGGL(k_reparam_bwd_colsum, dim3((unsigned)cdiv(F, rfc)), dim3(256), 0, s, w.d_z, w.z_mu, w.z_lv, eps, w.d_z_mu,
-                       w.d_z_lv, G + m.bmu_off, G + m.blv_off, (int)F, rfc, 1.0f / (float)F);
+    VAENPVC_TIMED("reparam_bwd", s, hipLaunchKernelGGL(k_reparam_bwd_colsum, dim3((unsigned)cdiv(F, rfc)), dim3(256), 0, s, w.d_z, w.z_mu, w.z_lv, eps, w.d_z_mu,
+                       w.d_z_lv, G + m.bmu_off, G + m.blv_off, (int)F, rfc, 1.0f / (float)F));
   } else generic::bwd_reparam(m, eps, F, w, s);
 
   // ---- heads
@@ -1112,8 +1112,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       NtArgs a = nt_args(w.pl_dz, F, 256, w.scratch + Pk::pg_headsb, 768, 768, w.dy_tmp, 768);
       VAENPVC_TIMED("heads_dgrad", s, launch_gemm_nt<NPL>(a, s));
     });
-    launch_ln_bwd<LnbCfg<256, 3>>(w.dy_tmp, w.enc_a[4], w.enc_st[4], P + l4.gamma_off, P + l4.beta_off, w.d_enc_a[4],
-                                     G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+    VAENPVC_TIMED("lnb_enc4", s, launch_ln_bwd<LnbCfg<256, 3>>(w.dy_tmp, w.enc_a[4], w.enc_st[4], P + l4.gamma_off, P + l4.beta_off, w.d_enc_a[4],
+                                     G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
     enc_bias_done[4] = true;
   } else if (bwd_on(5)) {
     const ConvL& l4 = m.enc[4];
@@ -1135,8 +1135,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       VAENPVC_TIMED("heads_dgrad", s, launch_densegemm<HeadsBs>(d, s, 4));
     } else
     VAENPVC_TIMED("heads_dgrad", s, launch_densegemm<HeadsB>(d, s));
-    launch_ln_bwd<LnbCfg<256, 3>>(w.dy_tmp, w.enc_a[4], w.enc_st[4], P + l4.gamma_off, P + l4.beta_off, w.d_enc_a[4],
-                                     G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+    VAENPVC_TIMED("lnb_enc4", s, launch_ln_bwd<LnbCfg<256, 3>>(w.dy_tmp, w.enc_a[4], w.enc_st[4], P + l4.gamma_off, P + l4.beta_off, w.d_enc_a[4],
+                                     G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
     enc_bias_done[4] = true;
   } else generic::bwd_heads(m, P, F, w, G, s);
   bucket(m.wmu_off, m.wz_off);  // the two dense heads
@@ -1161,8 +1161,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       VAENPVC_TIMED("enc4_dgrad", s, launch_gemm_nt<NPL>(a, s));
     });
     if (!enc_bias_done[4]) generic::bias_grad(w.d_enc_a[4], G + l.b_off, F, l.cout, l.hout, s);
-    launch_ln_bwd<LnbCfg<128, 7>>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[3],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+    VAENPVC_TIMED("lnb_enc3", s, launch_ln_bwd<LnbCfg<128, 7>>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[3],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
     enc_bias_done[3] = true;
   } else if (bwd_on(4)) {
     const ConvL &l = m.enc[4], &pl = m.enc[3];
@@ -1171,8 +1171,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     if (!enc_bias_done[4]) generic::bias_grad(w.d_enc_a[4], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("enc4_dgrad", s, launch_convgemm<GE4>(conv_args(w.d_enc_a[4], nullptr, nullptr, nullptr, w.scratch + Pk::ge4,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE4>(F), s));
-    launch_ln_bwd<LnbCfg<128, 7>>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[3],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+    VAENPVC_TIMED("lnb_enc3", s, launch_ln_bwd<LnbCfg<128, 7>>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[3],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
     enc_bias_done[3] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 4);
   if (bwd_on(3)) {
@@ -1189,8 +1189,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc3_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<GE3s>(conv_args(w.d_enc_a[3], nullptr, nullptr, nullptr, w.scratch + Pk::ge3,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE3s>(F), s) : launch_convgemm<GE3>(conv_args(w.d_enc_a[3], nullptr, nullptr, nullptr, w.scratch + Pk::ge3,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE3>(F), s)));
-    launch_ln_bwd<LnbCfg<64, 19>>(w.dy_tmp, w.enc_a[2], w.enc_st[2], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[2],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+    VAENPVC_TIMED("lnb_enc2", s, launch_ln_bwd<LnbCfg<64, 19>>(w.dy_tmp, w.enc_a[2], w.enc_st[2], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[2],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
     enc_bias_done[2] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 3);
   if (bwd_on(2)) {
@@ -1210,8 +1210,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc2_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<GE2s>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE2s>(F), s) : launch_convgemm<GE2>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE2>(F), s)));
-    launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.enc_a[1], w.enc_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[1],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+    VAENPVC_TIMED("lnb_enc1", s, launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.enc_a[1], w.enc_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[1],
+                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
     enc_bias_done[1] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 2);
   if (bwd_on(1)) {
@@ -1230,8 +1230,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc1_dgrad", s, launch_convgemm<GE1>(conv_args(w.d_enc_a[1], nullptr, nullptr, nullptr, w.scratch + Pk::ge1,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE1>(F), s));
     if (!enc0_fused)
-    launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.enc_a[0], w.enc_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[0],
-                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq);
+    VAENPVC_TIMED("lnb_enc0", s, launch_ln_bwd<LnbCfg<16, 171>>(w.dy_tmp, w.enc_a[0], w.enc_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[0],
+                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
     enc_bias_done[0] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 1);
   if (enc0_fused) {
@@ -1243,8 +1243,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     rt().ensure_lds(reinterpret_cast<const void*>(&k_enc0_bwd_wave), Enc0BwdCfg::LDS_BYTES);
     VAENPVC_TIMED("enc0_bwd", s, hipLaunchKernelGGL(k_enc0_bwd_wave, dim3((unsigned)nwg), dim3(256), Enc0BwdCfg::LDS_BYTES, s, x, w.dy_tmp,
                                                     w.enc_st[0], P + l.w_off, P + l.b_off, P + l.gamma_off, P + l.beta_off, pw, pc, F));
-    hipLaunchKernelGGL(k_colsum_part, dim3(7 * 16), dim3(256), 0, s, pw, nwg, 7 * 16, G + l.w_off);
-    hipLaunchKernelGGL(k_ln_bwd_reduce, dim3(3 * 16), dim3(256), 0, s, pc, nwg, 16, G + l.gamma_off, G + l.beta_off, G + l.b_off);
+    VAENPVC_TIMED("enc0_reduce", s, hipLaunchKernelGGL(k_colsum_part, dim3(7 * 16), dim3(256), 0, s, pw, nwg, 7 * 16, G + l.w_off));
+    VAENPVC_TIMED("enc0_reduce", s, hipLaunchKernelGGL(k_ln_bwd_reduce, dim3(3 * 16), dim3(256), 0, s, pc, nwg, 16, G + l.gamma_off, G + l.beta_off, G + l.b_off));
   } else if (bwd_on(0)) {
     const ConvL& l = m.enc[0];
     WgArgs a{x, nullptr, nullptr, nullptr, w.d_enc_a[0], nullptr, nullptr, nullptr, G + l.w_off, F, 0};
@@ -1253,7 +1253,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       const int nwg = cmin_(cdiv(F, 128), 256);   // >= 32 frames per wave: the 112 wave reductions at the end stay below 10 % of a wave's work
       VAENPVC_TIMED("enc0_wgrad", s2, hipLaunchKernelGGL(k_enc0_wgrad_wave, dim3((unsigned)nwg), dim3(256), 0, s2, x, w.d_enc_a[0],
                                                         w.scratch + Pk::enc0part, F));
-      hipLaunchKernelGGL(k_colsum_part, dim3(7 * 16), dim3(256), 0, s2, w.scratch + Pk::enc0part, nwg, 7 * 16, G + l.w_off);
+      VAENPVC_TIMED("enc0_reduce", s2, hipLaunchKernelGGL(k_colsum_part, dim3(7 * 16), dim3(256), 0, s2, w.scratch + Pk::enc0part, nwg, 7 * 16, G + l.w_off));
     } else
     VAENPVC_TIMED("enc0_wgrad", s2, launch_convwgrad<WE0>(a, WGS, s2));
     if (!enc_bias_done[0]) generic::bias_grad(w.d_enc_a[0], G + l.b_off, F, l.cout, l.hout, s);
@@ -1286,10 +1286,10 @@ void backward_frame(const Model& m, const float* P, const float* x, const float*
   if (one_launch) {
     frame_wgrad(m, P, x, y, F, w, G, s);
     Runtime& r0 = rt();
-    if (r0.bucket_cb) {
-      const int64_t cut[5] = {m.n_params, m.dec[0].w_off, m.wz_off, m.wmu_off, 0};
-      for (int b = 0; b < 4; ++b) r0.bucket_cb(r0.bucket_user, r0.bucket_next++, cut[b + 1], cut[b] - cut[b + 1], (void*)s);
-    }
+    // every gradient comes out of the one launch above: ONE range = one all-reduce of the whole buffer (four ranges handed
+    // over at the same moment would be four back-to-back collectives with nothing to overlap: three extra latencies on a
+    // 0.3 ms step)
+    if (r0.bucket_cb) r0.bucket_cb(r0.bucket_user, r0.bucket_next++, 0, m.n_params, (void*)s);
     return;
   }
   hipStream_t side = bwd_on(30) ? rt().side_stream() : nullptr;
@@ -1303,9 +1303,9 @@ void backward_frame(const Model& m, const float* P, const float* x, const float*
     VAENPVC_TIMED("dec3_wgrad", s2, launch_tngemm(a, true, kchunks_for(F, 32 * 4), s2));
     int ech = cmax(1, cmin_(cdiv(F, 64), 128));
     int efc = rup(cdiv(F, ech), 64);
-    hipLaunchKernelGGL(k_toep_wgrad_row512, dim3((unsigned)cdiv(F, efc), 3), dim3(256), 0, s2, w.dec_y, w.d_xh, G + m.dec[3].w_off, F, efc);
-    hipLaunchKernelGGL(k_sum_all_atomic, dim3((unsigned)cmin_(1024, cdiv(F * 513, 1024))), dim3(256), 0, s2, w.d_xh,
-                       (int64_t)F * 513, G + m.dec[3].b_off);
+    VAENPVC_TIMED("dec3_row512", s2, hipLaunchKernelGGL(k_toep_wgrad_row512, dim3((unsigned)cdiv(F, efc), 3), dim3(256), 0, s2, w.dec_y, w.d_xh, G + m.dec[3].w_off, F, efc));
+    VAENPVC_TIMED("dec3_bias", s2, hipLaunchKernelGGL(k_sum_all_atomic, dim3((unsigned)cmin_(1024, cdiv(F * 513, 1024))), dim3(256), 0, s2, w.d_xh,
+                       (int64_t)F * 513, G + m.dec[3].b_off));
     for (int i = 2; i >= 0; --i) {
       const ConvL& l = m.dec[i];
       WgArgs a2{w.d_dec_a[i], nullptr, nullptr, nullptr, i ? w.dec_a[i - 1] : w.h, i ? w.dec_st[i - 1] : nullptr,
@@ -1321,14 +1321,14 @@ void backward_frame(const Model& m, const float* P, const float* x, const float*
     VAENPVC_TIMED("merge_wgrad", s, launch_tngemm(a, false, kchunks_for(F, 13), s));
     float* Sg = w.scratch + Pk::merge_s;      // (zeroed by the step's frame_pack launch, or above)
     int ch = cmax(1, cmin_(cdiv(F, 64), 128)), fc = cdiv(F, ch);
-    hipLaunchKernelGGL(k_segsum_atomic<MERGE_NY>, dim3((unsigned)cdiv(1539, 256), (unsigned)cdiv(F, fc)), dim3(256), 0, s, w.d_h, y, 1539, F, fc, Sg);
+    VAENPVC_TIMED("merge_segsum", s, hipLaunchKernelGGL(k_segsum_atomic<MERGE_NY>, dim3((unsigned)cdiv(1539, 256), (unsigned)cdiv(F, fc)), dim3(256), 0, s, w.d_h, y, 1539, F, fc, Sg));
     const int nb_w = cdiv(128 * 1539, 256), nb_e = cdiv(MERGE_NY * 128, 4), nb_b = cdiv(1539, 256);
-    hipLaunchKernelGGL(k_merge_small<MERGE_NY>, dim3((unsigned)(nb_w + nb_e + nb_b)), dim3(256), 0, s, Sg, P + m.emb_off, P + m.wy_off, 128,
-                       1539, G + m.wy_off, G + m.emb_off, G + m.bz_off, G + m.by_off, G + m.bm_off, nb_w, nb_e);
+    VAENPVC_TIMED("merge_small", s, hipLaunchKernelGGL(k_merge_small<MERGE_NY>, dim3((unsigned)(nb_w + nb_e + nb_b)), dim3(256), 0, s, Sg, P + m.emb_off, P + m.wy_off, 128,
+                       1539, G + m.wy_off, G + m.emb_off, G + m.bz_off, G + m.by_off, G + m.bm_off, nb_w, nb_e));
     // (recomputes d(z_mu), d(z_lv) from d(z) exactly as the frame kernel did; what is needed here are the two bias sums)
     const int rch = cmax(1, cmin_(cdiv(F, 32), 1024)), rfc = cdiv(F, rch);
-    hipLaunchKernelGGL(k_reparam_bwd_colsum, dim3((unsigned)cdiv(F, rfc)), dim3(256), 0, s, w.d_z, w.z_mu, w.z_lv, eps, w.d_z_mu,
-                       w.d_z_lv, G + m.bmu_off, G + m.blv_off, (int)F, rfc, 1.0f / (float)F);
+    VAENPVC_TIMED("reparam_bwd", s, hipLaunchKernelGGL(k_reparam_bwd_colsum, dim3((unsigned)cdiv(F, rfc)), dim3(256), 0, s, w.d_z, w.z_mu, w.z_lv, eps, w.d_z_mu,
+                       w.d_z_lv, G + m.bmu_off, G + m.blv_off, (int)F, rfc, 1.0f / (float)F));
     const ConvL& l4 = m.enc[4];
     TnArgs h = tn_args(w.enc_a[4], 768, w.d_z_mu, 128, 768, 128, F, G + m.wmu_off, 128);
     h.st = w.enc_st[4];

@@ -39,12 +39,12 @@ struct Ws {  // resolved workspace pointers (see workspace_layout)
 int abi_error(int code, const char* msg);
 
 // ---- single-kernel event timer (state in the context's Runtime, runtime.h) --------
-#define VAENPVC_TIMED(tag, stream, stmt)              \
+#define VAENPVC_TIMED(tag, stream, ...)               \
   do {                                                \
     ::vaenpvc::Runtime& _rt = ::vaenpvc::rt();        \
     bool _tm = _rt.timer_match(tag);                  \
     if (_tm) _rt.timer_begin(stream);                 \
-    stmt;                                             \
+    __VA_ARGS__;                                      \
     if (_tm) _rt.timer_end(stream);                   \
   } while (0)
 

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstring>
 #include <string>
 #include <unordered_set>
 #include <utility>
@@ -38,6 +39,7 @@ struct Runtime {
   static constexpr unsigned CV_SITES_BF16 = 0xe2ceu, CV_SITES_X2 = 0xc244u, CV_SITES_X3 = 0x4u;  // by measurement
   long fb_layers_env = -1;      // VAENPVC_FB_LAYERS: thin decoder layers whose whole backward step is one kernel (gfx950_fbwd.h; bit = FB_* layer)
   unsigned fb_layers() const { return fb_layers_env >= 0 ? (unsigned)fb_layers_env : 0x3u; }
+  bool fb_dma = false;          // VAENPVC_FB_DMA=0: the register-staged form of those kernels instead of the LDS-DMA one (A/B)
   bool tn_k16 = false;          // VAENPVC_TN_K16: the 16-row two-workgroup A^T B kernel instead of the pipelined 32-row one (A/B)
   int tn_w4_tiles = 8;          // VAENPVC_TN_W4_TILES: the four-wave A^T B kernel from this many 256 x 256 tiles per row chunk on (0: every plain site, 99: never)
   int tn_xcd = -1;              // VAENPVC_TN_XCD=0|1: tile order of the C += A^T B plane GEMM (experiments; -1 = per site)
@@ -75,7 +77,14 @@ struct Runtime {
   // make `to` wait for everything enqueued on `from` so far
   void stream_dep(hipStream_t from, hipStream_t to);
 
-  bool timer_match(const char* t) const { return !tag.empty() && tag == t; }
+  // `tag` is one site name or a comma-separated list of them (a kernel GROUP timed in one pass: bench.py's roofline.sites)
+  bool timer_match(const char* t) const {
+    if (tag.empty()) return false;
+    const size_t n = strlen(t);
+    for (size_t p = tag.find(t); p != std::string::npos; p = tag.find(t, p + 1))
+      if ((p == 0 || tag[p - 1] == ',') && (p + n == tag.size() || tag[p + n] == ',')) return true;
+    return false;
+  }
   void timer_begin(hipStream_t s);
   void timer_end(hipStream_t s);
 };
