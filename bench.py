@@ -71,16 +71,16 @@ SITE_GROUPS = {
               'enc3_gsplit enc3_asplit enc3_wgrad enc3_dgrad enc2_gsplit enc2_asplit enc2_wgrad enc2_dgrad'),
         bound='mfma', mac=272384 + 401408 + 427680),
     'thin_conv (encoder layers 0-1, decoder layers 1-2: fused conv kernels, fused layer-backward kernels)': dict(
-        tags=('enc0_fwd enc1_split enc1_fwd stats_enc1 dec1_split dec1_fwd stats_dec1 dec2_split dec2_fwd dec2_stats_planes dec2_bwd dec1_bwd '
+        tags=('enc0_fwd enc1_split enc1_fwd stats_enc1 dec1_split dec1_fwd stats_dec1 dec2_split dec2_fwd dec2_stats_planes dec2_bwd dec1_bwd enc1_bwd '
               'dec2_gsplit dec2_asplit dec2_wgrad dec2_dgrad dec1_gsplit dec1_asplit dec1_wgrad dec1_dgrad enc1_gsplit enc1_asplit enc1_wgrad '
               'enc1_dgrad enc0_wgrad enc0_bwd enc0_reduce lnb_dec2 lnb_dec1 lnb_enc0'),
         bound='hbm',
         bytes=4 * ((_E['x'] + _E['e0']) + (_E['e0'] + _E['e1']) + (_E['d0'] + _E['d1']) + (_E['d1'] + _E['d2']) + (_E['d2'] + 4224)
-                   + (2 * _E['d2'] + 2 * _E['d1']) + (2 * _E['d1'] + 2 * _E['d0']) + (_E['e1'] + _E['e0']) + (_E['e1'] + _E['e0'])
+                   + (2 * _E['d2'] + 2 * _E['d1']) + (2 * _E['d1'] + 2 * _E['d0']) + (2 * _E['e1'] + 2 * _E['e0'])
                    + (_E['e0'] + _E['x']))),
-    'layernorm_backward (separate LayerNorm + lrelu backward passes: decoder layer 0, encoder layers 1-4)': dict(
+    'layernorm_backward (separate LayerNorm + lrelu backward passes: decoder layer 0, encoder layers 2-4)': dict(
         tags='lnb_dec0 lnb_enc4 lnb_enc3 lnb_enc2 lnb_enc1', bound='hbm',
-        bytes=4 * 3 * (_E['d0'] + _E['e4'] + _E['e3'] + _E['e2'] + _E['e1']), moved_not_algorithmic=True),
+        bytes=4 * 3 * (_E['d0'] + _E['e4'] + _E['e3'] + _E['e2']), moved_not_algorithmic=True),
     'weight_packing (per-step packed / split copies of the parameters)': dict(tags='prep', bound='hbm', bytes_per_step=10 * 939162 * 4),
 }
 

@@ -443,23 +443,21 @@ def test_fused_thin_conv_layers_against_oracle(F, seed, precision):
 FUSED_BWD = (0xffffffff, 0xffffbfff)    # bit 14 of the backward mask cleared: the one-kernel backward step of the thin decoder layers at any batch size
 
 
-@pytest.mark.parametrize('layers,dma', [('3', '1'), ('1', '1'), ('2', '1'), ('3', '0')])
-@pytest.mark.parametrize('F,seed', [(37, 5), (130, 9), (1, 7), (257, 12), (300, 13)])
-def test_fused_layer_backward_against_oracle(F, seed, layers, dma, monkeypatch):
-    """Decoder layers 2 and 1: LayerNorm + lrelu backward, input gradient, weight gradient and the layer's d gamma / d beta /
-    d bias in ONE kernel per layer (csrc/gfx950_fbwd.h: the gradient at the pre-LN output exists only as bf16 terms in LDS)
-    against the float64 oracle; both layers, and each alone next to the three-kernel form of the other (the hand-over
-    buffers differ); in its two forms: dma = 1, one eight-wave workgroup per CU whose next frame arrives by LDS-DMA in
-    landing buffers while the current one is processed (the default), dma = 0, staged through registers; batch sizes
-    below, at and above one frame per CU (256 workgroups).  (By default from 1024 frames on.)"""
+@pytest.mark.parametrize('layers', ['7', '1', '2', '4'])
+@pytest.mark.parametrize('F,seed', [(37, 5), (130, 9), (1, 7), (257, 12), (600, 13)])
+def test_fused_layer_backward_against_oracle(F, seed, layers, monkeypatch):
+    """Decoder layers 2 and 1 and encoder layer 1: LayerNorm + lrelu backward, input gradient, weight gradient and the layer's
+    d gamma / d beta / d bias in ONE kernel per layer (csrc/gfx950_fbwd.h: the gradient at the pre-LN output exists only as bf16
+    terms in LDS; bits of VAENPVC_FB_LAYERS = decoder 2, decoder 1, encoder 1) against the float64 oracle: all three, and each
+    alone next to the three-kernel form of its neighbours (the hand-over buffers differ; encoder layer 0's LayerNorm backward
+    then runs in place); batch sizes below and above one frame per workgroup slot (512).  (By default from 1024 frames on.)"""
     monkeypatch.setenv('VAENPVC_FB_LAYERS', layers)
-    monkeypatch.setenv('VAENPVC_FB_DMA', dma)
     eng = make_engine('vcc', 'auto', FUSED_BWD)
-    eng.timer_select('dec2_bwd' if layers != '2' else 'dec1_bwd')
-    fails = compare_everything(eng, F, seed, 'fused-bwd layers=%s dma=%s F%d ' % (layers, dma, F))
+    eng.timer_select({'7': 'dec2_bwd,dec1_bwd,enc1_bwd', '1': 'dec2_bwd', '2': 'dec1_bwd', '4': 'enc1_bwd'}[layers])
+    fails = compare_everything(eng, F, seed, 'fused-bwd layers=%s F%d ' % (layers, F))
     _, n = eng.timer_read()
     eng.timer_select(None)
-    assert n == 1, 'the fused backward kernel did not run'
+    assert n == (3 if layers == '7' else 1), 'the fused backward kernels did not run'
     assert not fails, '\n'.join(fails)
 
 

@@ -1,72 +1,85 @@
-// gfx950_fbwd.h -- the WHOLE backward step of a thin decoder layer in one kernel (round 4): LayerNorm + lrelu backward,
+// gfx950_fbwd.h -- the WHOLE backward step of a thin conv layer in one kernel (round 4): LayerNorm + lrelu backward,
 // input gradient and weight gradient, the layer's five parameter-gradient tensors.  The layered path ran three kernels
 // per layer (k_ln_bwd_fused -> HBM -> k_fconv input gradient + k_fwgrad weight gradient) and moved the gradient at the
 // layer's pre-LN output three times (one write, two reads); here it never leaves the chip:
-//   1. a workgroup owns TF whole frames.  The gradient at the layer's ACTIVATED output (dy) and the pre-LN output (a) are
-//      read once, coalesced, a lane owning one position and walking the channels in registers (the staging layout of
-//      gfx950_fconv.h).  The LayerNorm backward (autodiff of util/layers.py:32-44,149, written out above k_ln_bwd_fused in
-//      gfx950_elem.h) runs in those registers: two sums per frame through wave reductions + LDS partials, then
+//   1. a workgroup owns one whole frame at a time.  The gradient at the layer's ACTIVATED output (dy) and the pre-LN
+//      output (a) are read once, coalesced, a lane owning one position and walking a group of 8 channels in registers (the
+//      staging layout of gfx950_fconv.h; items = (64-position chunk, channel group) dealt to the four waves).  The
+//      LayerNorm backward (autodiff of util/layers.py:32-44,149, written out above k_ln_bwd_fused in gfx950_elem.h) runs
+//      in those registers: two sums per frame through wave reductions + LDS partials, then
 //      du = rstd (dn gamma - mean(dn gamma) - xhat mean(dn gamma xhat)); the per-channel sums for d gamma / d beta / d bias
-//      are carried per lane to the end of the kernel.
-//   2. du goes, split into NPL bf16 terms, channel-last with the conv's zero rows in front into LDS -- ONE image that is
-//      both the S-type view operand of the input-gradient site (gfx950_viewconv.h: CV_D*G) and the view operand of the
-//      weight-gradient site (CW_D*); the activated input of the layer (lrelu(LN(output of the layer below)), rebuilt on
-//      load) is the weight gradient's plain-row operand.
+//      are carried per lane to the end of the kernel (a wave always owns the same channel group).
+//   2. du goes, split into NPL bf16 terms, channel-last with zero halo rows into LDS -- ONE image that serves both GEMMs:
+//        decoder layer (conv_transpose): the S-type view operand of the input-gradient site (CV_D*G) and the view operand
+//                                        of the weight-gradient site (CW_D*);
+//        encoder layer (conv):           the P-type (phase-stacked) view operand of the input-gradient site (CV_E*G) and
+//                                        the plain-row operand of the weight-gradient site (CW_E*);
+//      the activated input of the layer (lrelu(LN(output of the layer below)), rebuilt on load) is the weight gradient's
+//      other operand (plain rows for a decoder layer, the stride-3 view for an encoder layer).
 //   3. both GEMMs run from LDS on the bf16 matrix cores: the input gradient leaves as canonical fp32 [F][C][H] (it is
 //      the dy of the layer below), the weight-gradient tile stays in the accumulators of the persistent workgroup until
 //      one flush of atomics.
 // HBM traffic per frame: dy + a + input activation + input gradient (decoder layer 2: 54.6 KB against 103.8 KB).
-// Reference: autodiff of model/vae.py:96-102 (conv2d_transpose + Layernorm + lrelu), trainer/vae.py:24.
+// Measured and not kept (round 4, same-box A/Bs): two frames per group or a register prefetch of the
+// next frame beside decoder layer 2's 80 staging registers (474 / 39 registers spilled); ONE eight-wave workgroup per CU
+// whose next frame arrives by LDS-DMA in a second landing buffer while the current one is processed (correct, 724 / 683 us
+// against 552 / 385: the per-frame chain scalar loads -> passes -> three barriers -> dependent LDS reads -> MFMAs is ~5 us
+// of latency, and one workgroup per CU has nothing to hide it with).
+// Reference: autodiff of util/layers.py:47-66 / model/vae.py:96-102 (conv / conv_transpose + Layernorm + lrelu), trainer/vae.py:24.
 #pragma once
 #include "gfx950_fwgrad.h"
 
 namespace vaenpvc {
 namespace tuned {
 
-enum { FB_D2, FB_D1, FB_COUNT };
-constexpr int fb_gsite(int l) { return l == FB_D2 ? CV_D2G : CV_D1G; }
-constexpr int fb_wsite(int l) { return l == FB_D2 ? CW_D2 : CW_D1; }
-
-// frames per group and register prefetch of the next group, per layer.  The staging registers hold a lane's position of
-// every channel of both tensors (dy, a) for all items of the wave: with two frames per group, or with one frame and the
-// next group's loads in flight during the GEMMs, decoder layer 2 does not fit 256 registers (measured: 474 / 39 spilled).
-#ifndef VAENPVC_FB_TF
-#define VAENPVC_FB_TF 1
-#endif
+enum { FB_D2, FB_D1, FB_E1, FB_COUNT };
+constexpr bool fb_enc(int l) { return l == FB_E1; }
+constexpr int fb_gsite(int l) { return l == FB_D2 ? CV_D2G : l == FB_D1 ? CV_D1G : CV_E1G; }
+constexpr int fb_wsite(int l) { return l == FB_D2 ? CW_D2 : l == FB_D1 ? CW_D1 : CW_E1; }
+// channel groups of the LayerNorm-backward items (a lane walks C / groups = 8 channels of its position)
+constexpr int fb_cgr(int l) { return l == FB_D2 ? 1 : l == FB_D1 ? 2 : 4; }
+// register prefetch of the next frame during the GEMMs (fits where a wave stages few values)
 #ifndef VAENPVC_FB_PREFETCH
-#define VAENPVC_FB_PREFETCH 0
+#define VAENPVC_FB_PREFETCH 0x6   // bit = FB_* layer
 #endif
+constexpr bool fb_prefetch(int l) { return (VAENPVC_FB_PREFETCH >> l) & 1; }
+
+constexpr int fb_max(int a, int b) { return a > b ? a : b; }
 template <int NPL, int L>
 struct FbCfg {
+  static constexpr bool ENC = fb_enc(L), PREFETCH = fb_prefetch(L);
   static constexpr CvSite V = CVS[fb_gsite(L)];
   static constexpr CwSite WS = CWS[fb_wsite(L)];
-  static constexpr ClDesc UD = CLD[WS.b], XD = CLD[WS.a];    // U: gradient at this layer's pre-LN output; X: its activated input
-  static constexpr int CU = UD.C, HU = UD.H, CX = XD.C, HX = XD.H, CPX = XD.CP;
-  static constexpr int R = WS.R, R16 = rup(R, 16), TAPS = WS.T, S = 3, PAD = UD.HLO, NU = CU * HU;
-  static constexpr int CPLU = (CU == 32 || CU == 64 || CU == 128) ? CU + 8 : CU;
-  static constexpr int CPLX = (CPX == 32 || CPX == 64 || CPX == 128) ? CPX + 8 : CPX;
-  static constexpr int ROWSU = S * (R16 - 1) + TAPS + 1;
-  static constexpr int FSU = ROWSU * CPLU, FSX = R16 * CPLX;       // elements per frame
-  static constexpr int TF = VAENPVC_FB_TF;
-  static constexpr bool PREFETCH = VAENPVC_FB_PREFETCH != 0;
-  static constexpr int UPL = TF * FSU + 64, XPL = TF * FSX;        // elements per plane
-  // input-gradient site (S-type view of U)
-  static constexpr int KS = cdiv(V.NT * CU, 16), MT = cdiv(V.M, 32), WP = V.Kp + 8, WPL = MT * 32 * WP;
-  static constexpr int RSTEP = (V.step / CU) * CPLU;
-  // weight-gradient tile: rows n = (tap, channel of U), columns m = channel of X
-  static constexpr int N = TAPS * CU, M = WS.M, NT = cdiv(N, 32), MTW = cdiv(M, 32);
+  // G: gradient at this layer's pre-LN output (du); X: its activated input
+  static constexpr ClDesc GD = CLD[ENC ? WS.a : WS.b], XD = CLD[ENC ? WS.b : WS.a];
+  static constexpr int CG = GD.C, HG = GD.H, NG = CG * HG, CX = XD.C, HX = XD.H;
+  static constexpr int R = WS.R, R16 = rup(R, 16), TAPS = WS.T, S = 3;
+  static constexpr int CPLG = (CG == 32 || CG == 64 || CG == 128) ? CG + 8 : CG;
+  static constexpr int CPLX = (CX == 32 || CX == 64 || CX == 128) ? CX + 8 : CX;
+  static constexpr int VIEWROWS = S * (R16 - 1) + TAPS + 1;
+  static constexpr int ROW0G = GD.HLO, ROWSG = ENC ? fb_max(GD.HP, GD.HLO + R16) : VIEWROWS;
+  static constexpr int ROW0X = ENC ? XD.HLO : 0, ROWSX = ENC ? VIEWROWS : R16;
+  static constexpr int GPL = ROWSG * CPLG + 64, XPL = ROWSX * CPLX + 64;   // elements per plane (one frame) + zero tail
+  // input-gradient site (view of G)
+  static constexpr int KS = cdiv(V.NT * CG, 16), MT = cdiv(V.M, 32), WP = V.Kp + 8, WPL = MT * 32 * WP;
+  static constexpr int RSTEP = (V.step / CG) * CPLG;
+  // weight-gradient tile: rows n = (tap, channel of the VIEW operand), columns m = channel of the PLAIN operand
+  static constexpr int CVW = ENC ? CX : CG, CPLV = ENC ? CPLX : CPLG, CPN = ENC ? CG : CX, CPLN = ENC ? CPLG : CPLX;
+  static constexpr int N = TAPS * CVW, M = WS.M, NT = cdiv(N, 32), MTW = cdiv(M, 32);
   static constexpr int KSPLIT = NT <= 2 ? 2 : 1, WN = 4 / KSPLIT, NTW = cdiv(NT, WN);
-  static constexpr int NCHU = cdiv(HU, 64), NITU = TF * NCHU, IPWU = cdiv(NITU, 4);
-  static constexpr int LDS = NPL * (UPL + XPL + WPL) * 2;
-  static_assert(V.x == WS.b && UD.CP == CU && HX == R && V.R == R && V.PH == 0 && V.M == CX && MT == 1, "layer not served");
-  static_assert(KS * 16 <= V.Kp && (S * (R - 1)) * CPLU + KS * 16 <= FSU, "view runs past the frame image");
+  // LayerNorm-backward items
+  static constexpr int CGR = fb_cgr(L), CUG = CG / CGR, NCHG = cdiv(HG, 64), NITG = NCHG * CGR, IPWG = cdiv(NITG, 4);
+  static constexpr int LDS = NPL * (GPL + XPL + WPL) * 2;
+  static_assert(V.x == (ENC ? WS.a : WS.b) && GD.CP == CG && XD.CP == CX && M == CPN && CUG == 8 && 4 % CGR == 0, "layer not served");
+  static_assert(V.OC == CX && V.OH == HX && V.PH == (ENC ? 1 : 0) && (ENC || (V.R == R && MT == 1)), "layer not served");
+  static_assert(KS * 16 <= V.Kp && (V.R - 1) * RSTEP + (KS * 16 / CG + 1) * CPLG <= ROWSG * CPLG + 64, "view runs past the frame image");
 };
 
 struct FbArgs {
-  const float* dy;       // [F][CU][HU] gradient at the layer's activated output
-  const float* a;        // [F][CU][HU] the layer's pre-LN output
+  const float* dy;       // [F][CG][HG] gradient at the layer's activated output
+  const float* a;        // [F][CG][HG] the layer's pre-LN output
   const float* st;       // its LayerNorm statistics (mean, rstd) per frame
-  const float* gamma;    // [CU]
+  const float* gamma;    // [CG]
   const float* beta;
   const float* xa;       // [F][CX][HX] pre-LN output of the layer below
   const float* xst;
@@ -74,8 +87,8 @@ struct FbArgs {
   const float* xbeta;
   const unsigned short* W;   // weight planes of the input-gradient site [NPL][Mp][Kp] (cv_job)
   float* dx;             // [F][CX][HX] out: gradient at the activated output of the layer below
-  float* dW;             // [TAPS * CU][CX], atomicAdd
-  float* dgamma;         // [CU], atomicAdd
+  float* dW;             // [TAPS * CVW][M], atomicAdd (the TF kernel tensor of the layer)
+  float* dgamma;         // [CG], atomicAdd
   float* dbeta;
   float* dbias;
   int F;
@@ -85,60 +98,58 @@ template <int NPL, int L>
 __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
   using T = FbCfg<NPL, L>;
   constexpr CvSite V = T::V;
-  constexpr int CU = T::CU, HU = T::HU, NCHU = T::NCHU, NITU = T::NITU, IPWU = T::IPWU;
+  constexpr int CUG = T::CUG, HG = T::HG, CGR = T::CGR, NITG = T::NITG, IPWG = T::IPWG;
   extern __shared__ __attribute__((aligned(16))) unsigned short bsm[];
-  __shared__ float part[2][FbCfg<NPL, L>::NITU];
-  __shared__ float red[4][3 * FbCfg<NPL, L>::CU];
-  unsigned short* us = bsm;                       // [NPL][UPL]  du, channel-last, PAD zero rows in front
-  unsigned short* xs = bsm + NPL * T::UPL;        // [NPL][XPL]  activated input, plain rows
-  unsigned short* ws = xs + NPL * T::XPL;         // [NPL][32][WP]
+  __shared__ float part[2][FbCfg<NPL, L>::NITG];
+  __shared__ float red[4][3 * FbCfg<NPL, L>::CUG];
+  unsigned short* gs = bsm;                       // [NPL][GPL]  du, channel-last, zero halo rows
+  unsigned short* xs = bsm + NPL * T::GPL;        // [NPL][XPL]  activated input
+  unsigned short* ws = xs + NPL * T::XPL;         // [NPL][MT * 32][WP]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
-  const int ngroups = cdiv(a.F, T::TF);
-  float vd[IPWU][CU], va[IPWU][CU], mean[IPWU], rstd[IPWU];
-  bool uok[IPWU];
-  FwStage<NPL, T::CX, T::CPX, T::CPLX, T::HX, T::TF, T::FSX, 0, T::XPL> sx;
-  float su[CU], sw[CU], sd[CU];
+  const int cg = wave % CGR;                      // this wave's channel group in every item it owns
+  const float* gam = a.gamma + cg * CUG;
+  const float* bet = a.beta + cg * CUG;
+  float vd[IPWG][CUG], va[IPWG][CUG], mean = 0.f, rstd = 1.f;
+  FwStage<NPL, T::CX, T::CX, T::CPLX, T::HX, 1, 0, T::ROW0X, T::XPL> sx;
+  float su[CUG], sw[CUG], sd[CUG];
 #pragma unroll
-  for (int c = 0; c < CU; ++c) su[c] = sw[c] = sd[c] = 0.f;
+  for (int c = 0; c < CUG; ++c) su[c] = sw[c] = sd[c] = 0.f;
 
-  auto uload = [&](int g) __attribute__((always_inline)) {
+  auto uload = [&](int f) __attribute__((always_inline)) {
+    mean = a.st[2 * f];
+    rstd = a.st[2 * f + 1];
 #pragma unroll
-    for (int u = 0; u < IPWU; ++u) {
-      const int it = wave + 4 * u, fl = it / NCHU, k = it - fl * NCHU;
-      const int f = g * T::TF + fl, h = 64 * k + lane;
-      const bool fok = it < NITU && f < a.F;
-      uok[u] = fok;
+    for (int u = 0; u < IPWG; ++u) {
+      const int it = wave + 4 * u, h = 64 * (it / CGR) + lane;
+      const bool ok = it < NITG && h < HG;
       // (addresses clamped into the tensor instead of predicated loads: no branch per load, the loads issue back to back)
-      const int64_t fo = (int64_t)(fok ? f : 0) * T::NU + (h < HU ? h : HU - 1);
-      mean[u] = a.st[2 * (fok ? f : 0)];
-      rstd[u] = a.st[2 * (fok ? f : 0) + 1];
+      const int64_t fo = (int64_t)f * T::NG + cg * CUG * HG + (ok ? h : 0);
       const float* pd = a.dy + fo;
       const float* pa = a.a + fo;
 #pragma unroll
-      for (int c = 0; c < CU; ++c) {
-        vd[u][c] = pd[c * HU];
-        va[u][c] = pa[c * HU];
+      for (int c = 0; c < CUG; ++c) {
+        vd[u][c] = pd[c * HG];
+        va[u][c] = pa[c * HG];
       }
-      const bool ok = fok && h < HU;
 #pragma unroll
-      for (int c = 0; c < CU; ++c) {
+      for (int c = 0; c < CUG; ++c) {
         vd[u][c] = ok ? vd[u][c] : 0.f;
-        va[u][c] = ok ? va[u][c] : mean[u];
+        va[u][c] = ok ? va[u][c] : mean;
       }
     }
   };
   // LayerNorm + lrelu backward, first half: dn = dy lrelu'(n), xhat, and the frame's two sums (partials per item)
   auto upass1 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < IPWU; ++u) {
+    for (int u = 0; u < IPWG; ++u) {
       const int it = wave + 4 * u;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int c = 0; c < CU; ++c) {
-        const float xh = (va[u][c] - mean[u]) * rstd[u];
-        const float nn = xh * a.gamma[c] + a.beta[c];
+      for (int c = 0; c < CUG; ++c) {
+        const float xh = (va[u][c] - mean) * rstd;
+        const float nn = xh * gam[c] + bet[c];
         const float dn = vd[u][c] * (nn >= 0.f ? 1.0f : LEAK);
-        const float dxh = dn * a.gamma[c];
+        const float dxh = dn * gam[c];
         s1 += dxh;
         s2 += dxh * xh;
         vd[u][c] = dn;
@@ -146,62 +157,56 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
       }
       s1 = wave_sum(s1);
       s2 = wave_sum(s2);
-      if (lane == 0 && it < NITU) {
+      if (lane == 0 && it < NITG) {
         part[0][it] = s1;
         part[1][it] = s2;
       }
     }
   };
-  // second half: du, the per-channel sums, and du as bf16 terms into the U image (frames past the batch end: zeros)
+  // second half: du, the per-channel sums, and du as bf16 terms into the G image
   auto upass2 = [&]() __attribute__((always_inline)) {
-    constexpr float INVN = 1.0f / T::NU;
+    constexpr float INVN = 1.0f / T::NG;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int u = 0; u < IPWU; ++u) {
-      const int it = wave + 4 * u, fl = (it < NITU ? it : 0) / NCHU, k = it - fl * NCHU;
-      const int h = 64 * k + lane;
-      float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < NITG; ++k) {
+      s1 += part[0][k];
+      s2 += part[1][k];
+    }
+    s1 *= INVN;
+    s2 *= INVN;
 #pragma unroll
-      for (int kk = 0; kk < NCHU; ++kk) {
-        s1 += part[0][fl * NCHU + kk];
-        s2 += part[1][fl * NCHU + kk];
-      }
-      s1 *= INVN;
-      s2 *= INVN;
-      const bool pos_ok = it < NITU && h < HU, live = pos_ok && uok[u];
+    for (int u = 0; u < IPWG; ++u) {
+      const int it = wave + 4 * u, h = 64 * (it / CGR) + lane;
+      const bool live = it < NITG && h < HG;
+      float v8[8];
 #pragma unroll
-      for (int c = 0; c < CU; ++c) {
-        const float d = rstd[u] * (vd[u][c] * a.gamma[c] - s1 - va[u][c] * s2);
+      for (int c = 0; c < CUG; ++c) {
+        const float d = rstd * (vd[u][c] * gam[c] - s1 - va[u][c] * s2);
         su[c] += live ? vd[u][c] * va[u][c] : 0.f;
         sw[c] += live ? vd[u][c] : 0.f;
         sd[c] += live ? d : 0.f;
-        vd[u][c] = live ? d : 0.f;
+        v8[c] = d;
       }
-      if (!pos_ok) continue;
-      unsigned short* dxp = us + fl * T::FSU + (T::PAD + h) * T::CPLU;
+      if (!live) continue;
+      u32x4 pk[NPL];
+      pack8<NPL>(v8, pk);
+      unsigned short* dxp = gs + (T::ROW0G + h) * T::CPLG + cg * CUG;
 #pragma unroll
-      for (int g8 = 0; g8 < CU / 8; ++g8) {
-        float v8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v8[j] = vd[u][8 * g8 + j];
-        u32x4 pk[NPL];
-        pack8<NPL>(v8, pk);
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(dxp + p * T::UPL + 8 * g8) = pk[p];
-      }
+      for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(dxp + p * T::GPL) = pk[p];
     }
   };
 
-  int g = blockIdx.x;
-  if (T::PREFETCH && g < ngroups) {
-    uload(g);
-    sx.load(a.xa, a.xst, g, a.F, wave, lane);
+  int f = blockIdx.x;
+  if (T::PREFETCH && f < a.F) {
+    uload(f);
+    sx.load(a.xa, a.xst, f, a.F, wave, lane);
   }
-  {  // once per workgroup: zero both images (pad rows, rows past R, tails stay zero), copy the input-gradient weights
+  {  // once per workgroup: zero both images (halo rows, rows past the tensor, tails stay zero), copy the input-gradient weights
     const u32x4 z = {0u, 0u, 0u, 0u};
-    for (int i = tid; i < NPL * (T::UPL + T::XPL) / 8; i += 256) reinterpret_cast<u32x4*>(bsm)[i] = z;
-    constexpr int WROW8 = V.Kp / 8, WPIECES = NPL * 32 * WROW8;
+    for (int i = tid; i < NPL * (T::GPL + T::XPL) / 8; i += 256) reinterpret_cast<u32x4*>(bsm)[i] = z;
+    constexpr int WROW8 = V.Kp / 8, WPIECES = NPL * T::MT * 32 * WROW8;
     for (int i = tid; i < WPIECES; i += 256) {
-      const int p = i / (32 * WROW8), r = i - p * (32 * WROW8), m = r / WROW8, c8 = r - m * WROW8;
+      const int p = i / (T::MT * 32 * WROW8), r = i - p * (T::MT * 32 * WROW8), m = r / WROW8, c8 = r - m * WROW8;
       *reinterpret_cast<u32x4*>(ws + p * T::WPL + m * T::WP + c8 * 8) =
           *reinterpret_cast<const u32x4*>(a.W + ((size_t)p * V.Mp + m) * V.Kp + c8 * 8);
     }
@@ -215,92 +220,125 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
 #pragma unroll
     for (int j = 0; j < T::MTW; ++j) wacc[i][j] = zero16();
   const int trow = ((lane & 15) >> 2) + 8 * lh, tcol = 4 * (lane & 3) + 16 * ((lane >> 4) & 1);
-  int bcol[T::NTW], acol[T::MTW];
+  int vcol[T::NTW], pcol[T::MTW];
 #pragma unroll
   for (int i = 0; i < T::NTW; ++i) {
     int n = 32 * (wn + i * T::WN) + tcol;
     n = n < T::N ? n : 0;
-    bcol[i] = (n / CU) * T::CPLU + n % CU;
+    vcol[i] = (n / T::CVW) * T::CPLV + n % T::CVW;
   }
 #pragma unroll
   for (int j = 0; j < T::MTW; ++j) {
     const int m = 32 * j + tcol;
-    acol[j] = m < T::CPX ? m : 0;
+    pcol[j] = m < T::CPN ? m : 0;
   }
+  const unsigned short* vimg = T::ENC ? xs : gs;      // view operand (rows 3 j + tap), plain operand (row j)
+  const unsigned short* pimg = T::ENC ? gs + T::ROW0G * T::CPLG : xs;
+  constexpr int VPL = T::ENC ? T::XPL : T::GPL, PPL = T::ENC ? T::GPL : T::XPL;
   const int woff = l31 * T::WP + lh * 8;
-  for (; g < ngroups; g += gridDim.x) {
-    const int f0 = g * T::TF, nf = min(T::TF, a.F - f0);
+  for (; f < a.F; f += gridDim.x) {
     if (!T::PREFETCH) {   // (unconditional: the staging registers must be dead across the GEMMs, not loop-carried)
-      uload(g);
-      sx.load(a.xa, a.xst, g, a.F, wave, lane);
+      uload(f);
+      sx.load(a.xa, a.xst, f, a.F, wave, lane);
     }
     upass1();
     sx.store(xs, true, a.xgamma, a.xbeta, wave, lane);
     __syncthreads();   // the partial sums of every item are visible
     upass2();
     __syncthreads();   // both images are complete
-    if (T::PREFETCH && g + (int)gridDim.x < ngroups) {
-      uload(g + gridDim.x);
-      sx.load(a.xa, a.xst, g + gridDim.x, a.F, wave, lane);
+    if (T::PREFETCH && f + (int)gridDim.x < a.F) {
+      uload(f + gridDim.x);
+      sx.load(a.xa, a.xst, f + gridDim.x, a.F, wave, lane);
     }
-    // ---- input gradient: GEMM rows n = fl * R + q (32 per step), steps dealt round-robin to the waves
-    const int nrows = nf * V.R, nsteps = cdiv(nrows, 32);
-    for (int s = wave; s < nsteps; s += 4) {
-      int n = s * 32 + l31;
-      const bool nok = n < nrows;
-      n = nok ? n : 0;
-      const int fl = n / V.R, q = n - fl * V.R;
-      const int xoff = fl * T::FSU + q * T::RSTEP;
-      f32x16 acc = zero16();
+    // ---- input gradient: GEMM rows q (32 per step), steps dealt round-robin to the waves
+    constexpr int NSTEPS = cdiv(V.R, 32);
+    for (int s = wave; s < NSTEPS; s += 4) {
+      int q = s * 32 + l31;
+      const bool nok = q < V.R;
+      q = nok ? q : 0;
+      const int xoff = q * T::RSTEP;
+      f32x16 acc[T::MT];
+#pragma unroll
+      for (int i = 0; i < T::MT; ++i) acc[i] = zero16();
 #pragma unroll
       for (int ks = 0; ks < T::KS; ++ks) {
-        u32x4 fa[NPL], fb[NPL];
-        const int ko = fc_koff<CU, T::CPLU>(ks, lh);
+        u32x4 fa[T::MT][NPL], fb[NPL];
+        const int ko = fc_koff<T::CG, T::CPLG>(ks, lh);
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
-          fa[p] = *reinterpret_cast<const u32x4*>(ws + p * T::WPL + woff + ks * 16);
-          fb[p] = *reinterpret_cast<const u32x4*>(us + p * T::UPL + xoff + ko);
+#pragma unroll
+          for (int i = 0; i < T::MT; ++i) fa[i][p] = *reinterpret_cast<const u32x4*>(ws + p * T::WPL + i * 32 * T::WP + woff + ks * 16);
+          fb[p] = *reinterpret_cast<const u32x4*>(gs + p * T::GPL + xoff + ko);
         }
         using PR = Prod<NPL>;
 #pragma unroll
-        for (int t = 0; t < PR::N; ++t) acc = mfma_bf16(fa[PR::A[t]], fb[PR::B[t]], acc);
+        for (int t = 0; t < PR::N; ++t)
+#pragma unroll
+          for (int i = 0; i < T::MT; ++i) acc[i] = mfma_bf16(fa[i][PR::A[t]], fb[PR::B[t]], acc[i]);
       }
-      if (nok) {
-        float* ob = a.dx + (int64_t)(f0 + fl) * (V.OC * V.OH) + q;
+      if (!nok) continue;
+      float* ob = a.dx + (int64_t)f * (V.OC * V.OH);
+      if constexpr (!T::ENC) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int m = acc_row(reg, lane);
-          if (m < V.M) ob[m * V.OH] = acc[reg];
+          if (m < V.M) ob[m * V.OH + q] = acc[0][reg];
+        }
+      } else {
+        // phase-stacked rows m = phase * mdiv + channel: the three phases of (channel, row q) sit in three registers of the
+        // same lane and are three consecutive positions 3 q + o0 .. + 2 (gfx950_fconv.h): one 12-byte store
+        static_assert(!T::ENC || (V.S == 3 && V.mdiv % 8 == 0 && V.O == V.mdiv), "phase-stacked epilogue");
+        struct __attribute__((packed, aligned(4))) f3 { float x, y, z; };
+        const int pbase = q * V.oq + V.o0;
+        const bool inner = pbase >= 0 && pbase + 2 < V.OH;
+#pragma unroll
+        for (int cs = 0; cs < V.mdiv / 2; ++cs) {
+          const int chb = (cs & 3) + 8 * (cs >> 2), ch = chb + 4 * lh;
+          float ph[3];
+#pragma unroll
+          for (int p3 = 0; p3 < 3; ++p3) {
+            const int mb = p3 * V.mdiv + chb, ti = mb / 32, row = mb % 32, reg = (row & 3) + 4 * (row >> 3);
+            ph[p3] = acc[ti < T::MT ? ti : 0][reg];
+          }
+          float* o = ob + ch * V.OH + pbase;
+          if (inner) {
+            *reinterpret_cast<f3*>(o) = f3{ph[0], ph[1], ph[2]};
+          } else {
+#pragma unroll
+            for (int p3 = 0; p3 < 3; ++p3)
+              if (pbase + p3 >= 0 && pbase + p3 < V.OH) o[p3] = ph[p3];
+          }
         }
       }
     }
-    // ---- weight gradient: k-chunks (frame, 16 rows j) of parity kpar
+    // ---- weight gradient: k-chunks (16 rows j) of parity kpar
     constexpr int CPF = T::R16 / 16;
-    for (int kc = kpar; kc < T::TF * CPF; kc += T::KSPLIT) {
-      const int fl = kc / CPF, j0 = (kc - fl * CPF) * 16 + trow;
-      const unsigned short* pa0 = xs + fl * T::FSX + j0 * T::CPLX;
-      const unsigned short* pb0 = us + fl * T::FSU + (T::S * j0) * T::CPLU;
-      u32x4 fa[T::MTW][NPL], fb[T::NTW][NPL];
+    for (int kc = kpar; kc < CPF; kc += T::KSPLIT) {
+      const int j0 = kc * 16 + trow;
+      const unsigned short* pp0 = pimg + j0 * T::CPLN;
+      const unsigned short* pv0 = vimg + (T::S * j0) * T::CPLV;
+      u32x4 fp[T::MTW][NPL], fv[T::NTW][NPL];
 #pragma unroll
       for (int j = 0; j < T::MTW; ++j)
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) fa[j][p] = tr_read8_2(pa0 + p * T::XPL + acol[j], pa0 + p * T::XPL + acol[j] + 4 * T::CPLX);
+        for (int p = 0; p < NPL; ++p) fp[j][p] = tr_read8_2(pp0 + p * PPL + pcol[j], pp0 + p * PPL + pcol[j] + 4 * T::CPLN);
 #pragma unroll
       for (int i = 0; i < T::NTW; ++i)
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
-          fb[i][p] = tr_read8_2(pb0 + p * T::UPL + bcol[i], pb0 + p * T::UPL + bcol[i] + 4 * T::S * T::CPLU);
+          fv[i][p] = tr_read8_2(pv0 + p * VPL + vcol[i], pv0 + p * VPL + vcol[i] + 4 * T::S * T::CPLV);
       using PR = Prod<NPL>;
+      // (the term pairs of Prod are symmetric in the two operands: view x plain)
 #pragma unroll
       for (int t = 0; t < PR::N; ++t)
 #pragma unroll
         for (int i = 0; i < T::NTW; ++i)
 #pragma unroll
-          for (int j = 0; j < T::MTW; ++j) wacc[i][j] = mfma_bf16(fb[i][PR::B[t]], fa[j][PR::A[t]], wacc[i][j]);
+          for (int j = 0; j < T::MTW; ++j) wacc[i][j] = mfma_bf16(fv[i][PR::B[t]], fp[j][PR::A[t]], wacc[i][j]);
     }
-    __syncthreads();   // all fragment reads of this group are done before the next one overwrites the images
+    __syncthreads();   // all fragment reads of this frame are done before the next one overwrites the images
   }
-  // ---- flush: the weight-gradient tile (rows n = (tap, channel of U), lanes m: consecutive addresses of dW[n][m]) ...
+  // ---- flush: the weight-gradient tile (rows n = (tap, channel of the view operand), lanes m: consecutive addresses of dW[n][m]) ...
 #pragma unroll
   for (int i = 0; i < T::NTW; ++i)
 #pragma unroll
@@ -315,305 +353,31 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
     }
   // ... and the three per-channel sums: d gamma, d beta (LayerNorm parameters), d bias (the conv's)
 #pragma unroll
-  for (int c = 0; c < CU; ++c) {
+  for (int c = 0; c < CUG; ++c) {
     const float u = wave_sum(su[c]), w = wave_sum(sw[c]), d = wave_sum(sd[c]);
     if (lane == 0) {
       red[wave][c] = u;
-      red[wave][CU + c] = w;
-      red[wave][2 * CU + c] = d;
+      red[wave][CUG + c] = w;
+      red[wave][2 * CUG + c] = d;
     }
   }
   __syncthreads();
-  if (tid < 3 * CU) {
-    const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    float* dst = tid < CU ? a.dgamma + tid : tid < 2 * CU ? a.dbeta + (tid - CU) : a.dbias + (tid - 2 * CU);
-    atomicAdd(dst, v);
-  }
-}
-
-// ---------------------------------------------------------------- the same step with LDS-DMA landing buffers
-// k_fbwd above stages through registers: a workgroup's loads, its LayerNorm passes and its GEMMs run one after the other,
-// and what overlaps is what two workgroups per CU happen to interleave (measured 3.2 TB/s of the kernel's own bytes; the
-// register prefetch of the next frame does not fit 256 registers beside two frames or the GEMMs).  Here ONE eight-wave
-// workgroup per CU keeps the memory system busy all the time instead: the three fp32 tensors of the NEXT frame (dy, a,
-// input activation: 43.8 / 29.2 KB) are requested by LDS-DMA (global_load_lds_dwordx4, no registers) into the other of two
-// raw landing buffers before the passes of the current frame start; every wave then reads its positions of the current
-// frame from LDS (lane = position: conflict-free) and the step continues as above -- passes, bf16 images, both GEMMs.
-template <int NPL, int L>
-struct FbdCfg : FbCfg<NPL, L> {
-  using B = FbCfg<NPL, L>;
-  static constexpr int NW = 8;                                      // waves
-  static constexpr int NX = B::CX * B::HX;
-  static constexpr int RAWF = 2 * B::NU + NX;                       // floats per landing buffer: dy | a | xa
-  static constexpr int P1 = B::NU / 4, P2 = NX / 4, PIECES = 2 * P1 + P2;   // 16-byte pieces
-  static constexpr int NDMA = cdiv(PIECES, 64 * NW);                // requests per wave and frame
-  static constexpr int UPL1 = B::FSU + 64, XPL1 = B::FSX;           // one frame per group
-  static constexpr int IMG = NPL * (UPL1 + XPL1 + B::WPL) * 2;      // bytes: U image, X image, weights
-  static constexpr int LDS = 2 * RAWF * 4 + IMG;
-  static constexpr int NCHX = cdiv(B::HX, 64);
-  static constexpr int IPWU = cdiv(B::NCHU, NW), IPWX = cdiv(NCHX, NW);
-  static constexpr int KSPLIT = B::NT <= 2 ? 4 : 2, WN = NW / KSPLIT, NTW = cdiv(B::NT, WN);
-  static_assert(B::NU % 4 == 0 && NX % 4 == 0 && (RAWF * 4) % 16 == 0, "frames are whole 16-byte pieces");
-  static_assert(LDS <= 160 * 1024, "landing buffers + images must fit the LDS");
-};
-
-template <int NPL, int L>
-__global__ void __launch_bounds__(512, 1) k_fbwd_dma(FbArgs a) {
-  using T = FbdCfg<NPL, L>;
-  constexpr CvSite V = T::V;
-  constexpr int CU = T::CU, HU = T::HU, NCHU = T::NCHU, IPWU = T::IPWU, NW = T::NW;
-  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-  __shared__ float part[2][FbCfg<NPL, L>::NCHU];
-  __shared__ float red[FbdCfg<NPL, L>::NW][3 * FbCfg<NPL, L>::CU];
-  float* raw = reinterpret_cast<float*>(dsm);                                          // [2][RAWF]
-  unsigned short* us = reinterpret_cast<unsigned short*>(dsm + 2 * T::RAWF * 4);       // [NPL][UPL1]
-  unsigned short* xs = us + NPL * T::UPL1;                                             // [NPL][XPL1]
-  unsigned short* ws = xs + NPL * T::XPL1;                                             // [NPL][32][WP]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
-  const unsigned raw_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)dsm;
-  float su[CU], sw[CU], sd[CU];
-#pragma unroll
-  for (int c = 0; c < CU; ++c) su[c] = sw[c] = sd[c] = 0.f;
-  // request frame f into landing buffer `slot`: piece p of the frame's 16-byte pieces (dy | a | xa) lands at 16 p
-  auto dma = [&](int f, int slot) __attribute__((always_inline)) {
-    const unsigned char* g0 = reinterpret_cast<const unsigned char*>(a.dy + (int64_t)f * T::NU);
-    const unsigned char* g1 = reinterpret_cast<const unsigned char*>(a.a + (int64_t)f * T::NU);
-    const unsigned char* g2 = reinterpret_cast<const unsigned char*>(a.xa + (int64_t)f * T::NX);
-#pragma unroll
-    for (int k = 0; k < T::NDMA; ++k) {
-      const int pb = (k * NW + wave) * 64, p = pb + lane;
-      if (pb >= T::PIECES) break;                       // (wave-uniform)
-      const unsigned char* src = p < T::P1 ? g0 + 16 * (int64_t)p : p < 2 * T::P1 ? g1 + 16 * (int64_t)(p - T::P1) : g2 + 16 * (int64_t)(p - 2 * T::P1);
-      if (p < T::PIECES) lds_dma16(src, raw_base + (unsigned)(slot * T::RAWF * 4 + pb * 16));
-    }
-  };
-  int f = blockIdx.x;
-  if (f < a.F) dma(f, 0);
-  {  // once per workgroup: zero both images (pad rows, rows past R, tails stay zero), copy the input-gradient weights
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    for (int i = tid; i < NPL * (T::UPL1 + T::XPL1) / 8; i += 64 * NW) reinterpret_cast<u32x4*>(us)[i] = z;
-    constexpr int WROW8 = V.Kp / 8, WPIECES = NPL * 32 * WROW8;
-    for (int i = tid; i < WPIECES; i += 64 * NW) {
-      const int p = i / (32 * WROW8), r = i - p * (32 * WROW8), m = r / WROW8, c8 = r - m * WROW8;
-      *reinterpret_cast<u32x4*>(ws + p * T::WPL + m * T::WP + c8 * 8) =
-          *reinterpret_cast<const u32x4*>(a.W + ((size_t)p * V.Mp + m) * V.Kp + c8 * 8);
-    }
-  }
-  const int wn = wave % T::WN, kpar = wave / T::WN;
-  f32x16 wacc[T::NTW][T::MTW];
-#pragma unroll
-  for (int i = 0; i < T::NTW; ++i)
-#pragma unroll
-    for (int j = 0; j < T::MTW; ++j) wacc[i][j] = zero16();
-  const int trow = ((lane & 15) >> 2) + 8 * lh, tcol = 4 * (lane & 3) + 16 * ((lane >> 4) & 1);
-  int bcol[T::NTW], acol[T::MTW];
-#pragma unroll
-  for (int i = 0; i < T::NTW; ++i) {
-    int n = 32 * (wn + i * T::WN) + tcol;
-    n = n < T::N ? n : 0;
-    bcol[i] = (n / CU) * T::CPLU + n % CU;
-  }
-#pragma unroll
-  for (int j = 0; j < T::MTW; ++j) {
-    const int m = 32 * j + tcol;
-    acol[j] = m < T::CPX ? m : 0;
-  }
-  const int woff = l31 * T::WP + lh * 8;
-  int slot = 0;
-  for (; f < a.F; f += gridDim.x, slot ^= 1) {
-    wait_vmcnt<0>();   // this wave's pieces of frame f have landed (and its result stores of the frame before are done)
-    __syncthreads();   // ... and everybody else's; the images are free (all GEMMs of the frame before are finished)
-    if (f + (int)gridDim.x < a.F) dma(f + gridDim.x, slot ^ 1);
-    const float* rd = raw + slot * T::RAWF;      // dy
-    const float* ra = rd + T::NU;                // a
-    const float* rx = ra + T::NU;                // xa
-    const float mean = a.st[2 * f], rstd = a.st[2 * f + 1];
-    // ---- LayerNorm + lrelu backward, first half (items = 64-position chunks dealt to the waves)
-    float vd[IPWU][CU], va[IPWU][CU];
-#pragma unroll
-    for (int u = 0; u < IPWU; ++u) {
-      const int it = wave + NW * u, h = 64 * it + lane;
-      const bool ok = it < NCHU && h < HU;
-      const int hh = ok ? h : 0;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int c = 0; c < CU; ++c) {
-        const float dyv = ok ? rd[c * HU + hh] : 0.f, av = ok ? ra[c * HU + hh] : mean;
-        const float xh = (av - mean) * rstd;
-        const float nn = xh * a.gamma[c] + a.beta[c];
-        const float dn = dyv * (nn >= 0.f ? 1.0f : LEAK);
-        const float dxh = dn * a.gamma[c];
-        s1 += dxh;
-        s2 += dxh * xh;
-        vd[u][c] = dn;
-        va[u][c] = xh;
-      }
-      s1 = wave_sum(s1);
-      s2 = wave_sum(s2);
-      if (lane == 0 && it < NCHU) {
-        part[0][it] = s1;
-        part[1][it] = s2;
-      }
-    }
-    // ---- the activated input of the layer -> X image (plain rows)
-    {
-      const float xmean = a.xst[2 * f], xrstd = a.xst[2 * f + 1];
-#pragma unroll
-      for (int u = 0; u < T::IPWX; ++u) {
-        const int it = wave + NW * u, h = 64 * it + lane;
-        if (!(it < T::NCHX && h < T::HX)) continue;
-        unsigned short* dxp = xs + h * T::CPLX;
-#pragma unroll
-        for (int g8 = 0; g8 < T::CPX / 8; ++g8) {
-          float v8[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int c = 8 * g8 + j;
-            v8[j] = c < T::CX ? lnact_v(rx[c * T::HX + h], xmean, xrstd, a.xgamma[c], a.xbeta[c]) : 0.f;
-          }
-          u32x4 pk[NPL];
-          pack8<NPL>(v8, pk);
-#pragma unroll
-          for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(dxp + p * T::XPL1 + 8 * g8) = pk[p];
-        }
-      }
-    }
-    __syncthreads();   // the partial sums of every item are visible
-    {
-      constexpr float INVN = 1.0f / T::NU;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < NCHU; ++kk) {
-        s1 += part[0][kk];
-        s2 += part[1][kk];
-      }
-      s1 *= INVN;
-      s2 *= INVN;
-#pragma unroll
-      for (int u = 0; u < IPWU; ++u) {
-        const int it = wave + NW * u, h = 64 * it + lane;
-        const bool live = it < NCHU && h < HU;
-#pragma unroll
-        for (int c = 0; c < CU; ++c) {
-          const float d = rstd * (vd[u][c] * a.gamma[c] - s1 - va[u][c] * s2);
-          su[c] += live ? vd[u][c] * va[u][c] : 0.f;
-          sw[c] += live ? vd[u][c] : 0.f;
-          sd[c] += live ? d : 0.f;
-          vd[u][c] = d;
-        }
-        if (!live) continue;
-        unsigned short* dxp = us + (T::PAD + h) * T::CPLU;
-#pragma unroll
-        for (int g8 = 0; g8 < CU / 8; ++g8) {
-          float v8[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v8[j] = vd[u][8 * g8 + j];
-          u32x4 pk[NPL];
-          pack8<NPL>(v8, pk);
-#pragma unroll
-          for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(dxp + p * T::UPL1 + 8 * g8) = pk[p];
-        }
-      }
-    }
-    __syncthreads();   // both images are complete
-    // ---- input gradient: GEMM rows q (32 per step), steps dealt round-robin to the waves
-    constexpr int NSTEPS = cdiv(V.R, 32);
-    for (int s = wave; s < NSTEPS; s += NW) {
-      int q = s * 32 + l31;
-      const bool nok = q < V.R;
-      q = nok ? q : 0;
-      const int xoff = q * T::RSTEP;
-      f32x16 acc = zero16();
-#pragma unroll
-      for (int ks = 0; ks < T::KS; ++ks) {
-        u32x4 fa[NPL], fb[NPL];
-        const int ko = fc_koff<CU, T::CPLU>(ks, lh);
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) {
-          fa[p] = *reinterpret_cast<const u32x4*>(ws + p * T::WPL + woff + ks * 16);
-          fb[p] = *reinterpret_cast<const u32x4*>(us + p * T::UPL1 + xoff + ko);
-        }
-        using PR = Prod<NPL>;
-#pragma unroll
-        for (int t = 0; t < PR::N; ++t) acc = mfma_bf16(fa[PR::A[t]], fb[PR::B[t]], acc);
-      }
-      if (nok) {
-        float* ob = a.dx + (int64_t)f * (V.OC * V.OH) + q;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int m = acc_row(reg, lane);
-          if (m < V.M) ob[m * V.OH] = acc[reg];
-        }
-      }
-    }
-    // ---- weight gradient: k-chunks (16 rows j) of parity kpar
-    constexpr int CPF = T::R16 / 16;
-    for (int kc = kpar; kc < CPF; kc += T::KSPLIT) {
-      const int j0 = kc * 16 + trow;
-      const unsigned short* pa0 = xs + j0 * T::CPLX;
-      const unsigned short* pb0 = us + (T::S * j0) * T::CPLU;
-      u32x4 fa[T::MTW][NPL], fb[T::NTW][NPL];
-#pragma unroll
-      for (int j = 0; j < T::MTW; ++j)
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) fa[j][p] = tr_read8_2(pa0 + p * T::XPL1 + acol[j], pa0 + p * T::XPL1 + acol[j] + 4 * T::CPLX);
-#pragma unroll
-      for (int i = 0; i < T::NTW; ++i)
-#pragma unroll
-        for (int p = 0; p < NPL; ++p)
-          fb[i][p] = tr_read8_2(pb0 + p * T::UPL1 + bcol[i], pb0 + p * T::UPL1 + bcol[i] + 4 * T::S * T::CPLU);
-      using PR = Prod<NPL>;
-#pragma unroll
-      for (int t = 0; t < PR::N; ++t)
-#pragma unroll
-        for (int i = 0; i < T::NTW; ++i)
-#pragma unroll
-          for (int j = 0; j < T::MTW; ++j) wacc[i][j] = mfma_bf16(fb[i][PR::B[t]], fa[j][PR::A[t]], wacc[i][j]);
-    }
-  }
-  // ---- flush (as k_fbwd)
-#pragma unroll
-  for (int i = 0; i < T::NTW; ++i)
-#pragma unroll
-    for (int j = 0; j < T::MTW; ++j) {
-      const int m = 32 * j + l31;
-      if (m >= T::M) continue;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int n = 32 * (wn + i * T::WN) + acc_row(reg, lane);
-        if (n < T::N && wn + i * T::WN < T::NT) atomicAdd(a.dW + n * T::M + m, wacc[i][j][reg]);
-      }
-    }
-#pragma unroll
-  for (int c = 0; c < CU; ++c) {
-    const float u = wave_sum(su[c]), w = wave_sum(sw[c]), d = wave_sum(sd[c]);
-    if (lane == 0) {
-      red[wave][c] = u;
-      red[wave][CU + c] = w;
-      red[wave][2 * CU + c] = d;
-    }
-  }
-  __syncthreads();
-  if (tid < 3 * CU) {
+  if (tid < 3 * T::CG) {
+    const int which = tid / T::CG, c = tid - which * T::CG, cgi = c / CUG, cc = c - cgi * CUG;
     float v = 0.f;
 #pragma unroll
-    for (int w8 = 0; w8 < NW; ++w8) v += red[w8][tid];
-    float* dst = tid < CU ? a.dgamma + tid : tid < 2 * CU ? a.dbeta + (tid - CU) : a.dbias + (tid - 2 * CU);
+    for (int w4 = 0; w4 < 4; ++w4)
+      if (w4 % CGR == cgi) v += red[w4][which * CUG + cc];
+    float* dst = which == 0 ? a.dgamma + c : which == 1 ? a.dbeta + c : a.dbias + c;
     atomicAdd(dst, v);
   }
 }
 
 template <int NPL, int L>
 static void launch_fbwd(const FbArgs& a, hipStream_t s) {
-  if (rt().fb_dma) {   // VAENPVC_FB_DMA=0: the register-staged kernel (A/B)
-    using D = FbdCfg<NPL, L>;
-    rt().ensure_lds(reinterpret_cast<const void*>(&k_fbwd_dma<NPL, L>), D::LDS);
-    hipLaunchKernelGGL((k_fbwd_dma<NPL, L>), dim3((unsigned)cmin_(a.F, 256)), dim3(512), D::LDS, s, a);
-    return;
-  }
   using T = FbCfg<NPL, L>;
   rt().ensure_lds(reinterpret_cast<const void*>(&k_fbwd<NPL, L>), T::LDS);
-  const unsigned grid = (unsigned)cmin_(cdiv(a.F, T::TF), T::LDS > 78 * 1024 ? 256 : 512);
+  const unsigned grid = (unsigned)cmin_(a.F, T::LDS > 78 * 1024 ? 256 : 512);
   hipLaunchKernelGGL((k_fbwd<NPL, L>), dim3(grid), dim3(256), T::LDS, s, a);
 }
 template <int NPL>
@@ -622,6 +386,7 @@ static bool fbwd(int layer, const FbArgs& a, hipStream_t s) {
     switch (layer) {
       case FB_D2: launch_fbwd<NPL, FB_D2>(a, s); return true;
       case FB_D1: launch_fbwd<NPL, FB_D1>(a, s); return true;
+      case FB_E1: launch_fbwd<NPL, FB_E1>(a, s); return true;
     }
   }
   return false;

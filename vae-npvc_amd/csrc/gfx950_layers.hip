@@ -399,10 +399,10 @@ static void prep(const Model& m, const float* P, const Ws& w, int64_t F, hipStre
       pack_job(PackRepeat3{P + m.enc[4].b_off}, S + Pk::pg_bias4, 768)));
   // weight planes of the conv view-GEMM sites.  TF layouts: conv [T][Cin][Cout], conv_transpose [T][Cout][Cin];
   // (s_t, s_o, s_c) = strides of (tap, GEMM output channel, contracted channel)
-  if (cg_fwd(F) || cg_bwd(F) || fc_any(F) || fb_bwd(FB_D2, F) || fb_bwd(FB_D1, F)) {
+  if (cg_fwd(F) || cg_bwd(F) || fc_any(F) || fb_bwd(FB_D2, F) || fb_bwd(FB_D1, F) || fb_bwd(FB_E1, F)) {
     // only the sites some kernel of this step reads (count 0 = job skipped)
     auto used = [&](int site, bool fwd_dir) {
-      if (!fwd_dir && ((site == CV_D2G && fb_bwd(FB_D2, F)) || (site == CV_D1G && fb_bwd(FB_D1, F)))) return true;   // gfx950_fbwd.h
+      if (!fwd_dir && ((site == CV_D2G && fb_bwd(FB_D2, F)) || (site == CV_D1G && fb_bwd(FB_D1, F)) || (site == CV_E1G && fb_bwd(FB_E1, F)))) return true;   // gfx950_fbwd.h
       return fwd_dir ? (cv_fwd(site, F) || fc_fwd(site, F) || fcr_fwd(site, F)) : (cv_bwd(site, F) || fc_bwd(site, F) || fcr_bwd(site, F));
     };
     auto job = [&](int site, bool fwd_dir, const ConvL& l, int s_o, int s_c) {
@@ -942,10 +942,13 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 3);
   // one kernel per thin decoder layer: LayerNorm backward + input gradient + weight gradient + the layer's parameter sums
   auto fused_bwd = [&](int layer, int i, const float* dy, float* dx, const char* tag) {
-    const ConvL &l = m.dec[i], &pl = m.dec[i - 1];
+    const bool enc = fb_enc(layer);
+    const ConvL &l = enc ? m.enc[i] : m.dec[i], &pl = enc ? m.enc[i - 1] : m.dec[i - 1];
+    float* const* act = enc ? w.enc_a : w.dec_a;
+    float* const* sts = enc ? w.enc_st : w.dec_st;
     for_dense_planes([&](auto npl) {
       constexpr int NPL = decltype(npl)::value;
-      FbArgs fa{dy, w.dec_a[i], w.dec_st[i], P + l.gamma_off, P + l.beta_off, w.dec_a[i - 1], w.dec_st[i - 1], P + pl.gamma_off,
+      FbArgs fa{dy, act[i], sts[i], P + l.gamma_off, P + l.beta_off, act[i - 1], sts[i - 1], P + pl.gamma_off,
                 P + pl.beta_off, reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvw + cv_woff(fb_gsite(layer))), dx,
                 G + l.w_off, G + l.gamma_off, G + l.beta_off, G + l.b_off, F};
       VAENPVC_TIMED(tag, s, fbwd<NPL>(layer, fa, s));
@@ -1210,11 +1213,25 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     VAENPVC_TIMED("enc2_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<GE2s>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE2s>(F), s) : launch_convgemm<GE2>(conv_args(w.d_enc_a[2], nullptr, nullptr, nullptr, w.scratch + Pk::ge2,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE2>(F), s)));
-    VAENPVC_TIMED("lnb_enc1", s, launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.enc_a[1], w.enc_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[1],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
-    enc_bias_done[1] = true;
+    if (!(bwd_on(1) && fb_bwd(FB_E1, F))) {   // (layer 1's fused backward kernel does it otherwise, gfx950_fbwd.h)
+      VAENPVC_TIMED("lnb_enc1", s, launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.enc_a[1], w.enc_st[1], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[1],
+                                       G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
+      enc_bias_done[1] = true;
+    }
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 2);
-  if (bwd_on(1)) {
+  // where encoder layer 0's backward finds the gradient at its activated output
+  const float* dy_e0 = w.dy_tmp;
+  if (bwd_on(1) && bwd_on(2) && fb_bwd(FB_E1, F)) {
+    // LayerNorm backward + input gradient + weight gradient + parameter sums of encoder layer 1 in one kernel; its result goes to
+    // the buffer of layer 0's pre-LN gradient (free until layer 0's LayerNorm backward, which may then run in place)
+    const ConvL& pl = m.enc[0];
+    fused_bwd(FB_E1, 1, w.dy_tmp, w.d_enc_a[0], "enc1_bwd");
+    dy_e0 = w.d_enc_a[0];
+    if (!enc0_fused)
+      VAENPVC_TIMED("lnb_enc0", s, launch_ln_bwd<LnbCfg<16, 171>>(dy_e0, w.enc_a[0], w.enc_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[0],
+                                        G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
+    enc_bias_done[0] = true;
+  } else if (bwd_on(1)) {
     const ConvL &l = m.enc[1], &pl = m.enc[0];
     const bool fg = fc_bwd(CV_E1G, F), vg = !fg && cv_bwd(CV_E1G, F), fw = fw_bwd(CW_E1, F), vw = !fw && cw_bwd(CW_E1, F);
     if (vg || vw) gsplit(CL_GE1, w.d_enc_a[1], "enc1_gsplit");
@@ -1241,7 +1258,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     float* pw = w.scratch + Pk::enc0part;
     float* pc = w.scratch + Pk::lnpart;     // (no other LayerNorm partial rows are alive: the layers before flushed theirs)
     rt().ensure_lds(reinterpret_cast<const void*>(&k_enc0_bwd_wave), Enc0BwdCfg::LDS_BYTES);
-    VAENPVC_TIMED("enc0_bwd", s, hipLaunchKernelGGL(k_enc0_bwd_wave, dim3((unsigned)nwg), dim3(256), Enc0BwdCfg::LDS_BYTES, s, x, w.dy_tmp,
+    VAENPVC_TIMED("enc0_bwd", s, hipLaunchKernelGGL(k_enc0_bwd_wave, dim3((unsigned)nwg), dim3(256), Enc0BwdCfg::LDS_BYTES, s, x, dy_e0,
                                                     w.enc_st[0], P + l.w_off, P + l.b_off, P + l.gamma_off, P + l.beta_off, pw, pc, F));
     VAENPVC_TIMED("enc0_reduce", s, hipLaunchKernelGGL(k_colsum_part, dim3(7 * 16), dim3(256), 0, s, pw, nwg, 7 * 16, G + l.w_off));
     VAENPVC_TIMED("enc0_reduce", s, hipLaunchKernelGGL(k_ln_bwd_reduce, dim3(3 * 16), dim3(256), 0, s, pc, nwg, 16, G + l.gamma_off, G + l.beta_off, G + l.b_off));

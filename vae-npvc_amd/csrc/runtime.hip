@@ -42,7 +42,6 @@ void Runtime::read_env() {
   if (const char* e = getenv("VAENPVC_FCR_SITES")) fcr_sites_env = (long)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_FW_SITES")) fw_sites_env = (long)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_FB_LAYERS")) fb_layers_env = (long)strtoul(e, nullptr, 0);
-  if (const char* e = getenv("VAENPVC_FB_DMA")) fb_dma = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_FC_SITES")) fc_sites_env = (long)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_DENSE_PLANES")) {
     int p = atoi(e);
