@@ -7,6 +7,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "runtime.h"
 
 namespace vaenpvc {
@@ -76,10 +78,31 @@ __device__ __forceinline__ float lnact_v(float v, float mean, float rstd, float 
   return fmaxf(n, LEAK * n);
 }
 
+// Sum over the 64 lanes of a wave, result in every lane.  Four DPP adds inside each row of 16 lanes (quad_perm, row
+// mirrors), then the four row sums are read into scalar registers: ~15 instructions of a few cycles each, against six
+// dependent ds_bpermute round trips through the LDS pipeline (~100 cycles each) for the butterfly of __shfl_xor -- the
+// reductions sit on the per-frame latency chain of every kernel that takes LayerNorm statistics or sums.
+#ifndef VAENPVC_WAVE_SUM_DPP
+#define VAENPVC_WAVE_SUM_DPP 1
+#endif
 __device__ __forceinline__ float wave_sum(float v) {
+#if VAENPVC_WAVE_SUM_DPP
+  auto dpp = [](float x, auto ctrl) __attribute__((always_inline)) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror: every lane holds the sum of its row of 16
+  const int iv = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+  return (r0 + r1) + (r2 + r3);
+#else
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
+#endif
 }
 
 // Cooperative, latency-tolerant copy of `total` contiguous floats HBM -> (functor): every
