@@ -6,10 +6,12 @@ sys.path.insert(0, os.path.join(ROOT, 'vae-npvc_amd')); sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from hipvae import Engine  # noqa: E402
 from hipvae.dp import Stepper  # noqa: E402
-TAGS = ('enc0_fwd enc1_split enc1_fwd enc2_split enc2_fwd enc3_split enc3_fwd enc4_split enc4_fwd heads_split heads_fwd merge_split merge_fwd dec0_split dec0_fwd dec1_split dec1_fwd '
-        'dec2_split dec2_fwd dec3_fwd dec3_wgrad dec3_dgrad dec2_gsplit dec2_asplit dec2_wgrad dec2_dgrad dec1_gsplit dec1_asplit dec1_wgrad dec1_dgrad dec0_gsplit dec0_asplit dec0_wgrad dec0_dgrad merge_dsplit '
-        'merge_wgrad merge_segsum merge_dgrad heads_dsplit heads_wgrad heads_dgrad enc4_dsplit enc4_wgrad enc4_dgrad enc3_gsplit enc3_asplit enc3_wgrad '
-        'enc3_dgrad enc2_gsplit enc2_asplit enc2_wgrad enc2_dgrad enc1_gsplit enc1_asplit enc1_wgrad enc1_dgrad enc0_wgrad enc0_bwd').split()
+TAGS = ('prep enc0_fwd enc1_split enc1_fwd stats_enc1 enc2_split enc2_fwd stats_enc2 enc3_split enc3_fwd stats_enc3 enc4_split enc4_fwd stats_enc4 heads_split heads_fwd '
+        'reparam merge_split merge_fwd dec0_split dec0_fwd stats_dec0 dec1_split dec1_fwd stats_dec1 dec2_split dec2_fwd dec2_stats_planes dec3_fwd loss '
+        'dxh_post dec3_wgrad dec3_row512 dec3_bias dec3_dgrad lnb_dec2 dec2_bwd dec2_gsplit dec2_asplit dec2_wgrad dec2_dgrad lnb_dec1 dec1_bwd dec1_gsplit dec1_asplit '
+        'dec1_wgrad dec1_dgrad lnb_dec0 dec0_gsplit dec0_asplit dec0_wgrad dec0_dgrad merge_dsplit merge_wgrad merge_segsum merge_small merge_dgrad reparam_bwd '
+        'heads_dsplit heads_wgrad heads_dgrad lnb_enc4 enc4_dsplit enc4_wgrad enc4_dgrad lnb_enc3 enc3_gsplit enc3_asplit enc3_wgrad enc3_dgrad lnb_enc2 '
+        'enc2_gsplit enc2_asplit enc2_wgrad enc2_dgrad lnb_enc1 enc1_bwd enc1_gsplit enc1_asplit enc1_wgrad enc1_dgrad lnb_enc0 enc0_wgrad enc0_bwd enc0_reduce').split()
 ap = argparse.ArgumentParser()
 ap.add_argument('--frames', type=int, default=32768)
 ap.add_argument('--precision', default='auto')

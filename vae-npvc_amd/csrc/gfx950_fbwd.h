@@ -92,11 +92,16 @@ struct FbArgs {
   float* dbeta;
   float* dbias;
   int F;
+  bool bf16_act = false;   // bf16 activation storage of the decoder tensors (launch_fbwd picks the layer's pattern)
 };
 
-template <int NPL, int L>
+// BFM: bf16 activation storage (precision "bf16"): bit 0 = dy and a, bit 1 = the input activation xa, bit 2 = the result dx
+template <int NPL, int L, int BFM = 0>
 __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
   using T = FbCfg<NPL, L>;
+  constexpr bool BFG = BFM & 1, BFX = (BFM >> 1) & 1, BFO = (BFM >> 2) & 1;
+  constexpr int PG = act_pitch(BFG, T::HG), PO = act_pitch(BFO, T::V.OH);
+  static_assert(BFM == 0 || (NPL == 1 && !T::ENC), "bf16 storage: decoder layers of the bf16 mode");
   constexpr CvSite V = T::V;
   constexpr int CUG = T::CUG, HG = T::HG, CGR = T::CGR, NITG = T::NITG, IPWG = T::IPWG;
   extern __shared__ __attribute__((aligned(16))) unsigned short bsm[];
@@ -110,7 +115,7 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
   const float* gam = a.gamma + cg * CUG;
   const float* bet = a.beta + cg * CUG;
   float vd[IPWG][CUG], va[IPWG][CUG], mean = 0.f, rstd = 1.f;
-  FwStage<NPL, T::CX, T::CX, T::CPLX, T::HX, 1, 0, T::ROW0X, T::XPL> sx;
+  FwStage<NPL, T::CX, T::CX, T::CPLX, T::HX, 1, 0, T::ROW0X, T::XPL, BFX> sx;
   float su[CUG], sw[CUG], sd[CUG];
 #pragma unroll
   for (int c = 0; c < CUG; ++c) su[c] = sw[c] = sd[c] = 0.f;
@@ -123,13 +128,11 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
       const int it = wave + 4 * u, h = 64 * (it / CGR) + lane;
       const bool ok = it < NITG && h < HG;
       // (addresses clamped into the tensor instead of predicated loads: no branch per load, the loads issue back to back)
-      const int64_t fo = (int64_t)f * T::NG + cg * CUG * HG + (ok ? h : 0);
-      const float* pd = a.dy + fo;
-      const float* pa = a.a + fo;
+      const int64_t fo = (int64_t)f * (T::CG * PG) + cg * CUG * PG + (ok ? h : 0);
 #pragma unroll
       for (int c = 0; c < CUG; ++c) {
-        vd[u][c] = pd[c * HG];
-        va[u][c] = pa[c * HG];
+        vd[u][c] = act_ld<BFG>(a.dy, fo + c * PG);
+        va[u][c] = act_ld<BFG>(a.a, fo + c * PG);
       }
 #pragma unroll
       for (int c = 0; c < CUG; ++c) {
@@ -282,7 +285,7 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int m = acc_row(reg, lane);
-          if (m < V.M) ob[m * V.OH + q] = acc[0][reg];
+          if (m < V.M) act_st<BFO>(a.dx, (int64_t)f * (V.OC * PO) + m * PO + q, acc[0][reg]);
         }
       } else {
         // phase-stacked rows m = phase * mdiv + channel: the three phases of (channel, row q) sit in three registers of the
@@ -376,8 +379,16 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
 template <int NPL, int L>
 static void launch_fbwd(const FbArgs& a, hipStream_t s) {
   using T = FbCfg<NPL, L>;
-  rt().ensure_lds(reinterpret_cast<const void*>(&k_fbwd<NPL, L>), T::LDS);
   const unsigned grid = (unsigned)cmin_(a.F, T::LDS > 78 * 1024 ? 256 : 512);
+  if constexpr (NPL == 1 && (L == FB_D2 || L == FB_D1)) {
+    if (a.bf16_act) {   // bf16 activation storage: layer 2 reads and writes bf16 throughout, layer 1 reads (dy, a) as bf16
+      constexpr int BFM = L == FB_D2 ? 7 : 1;
+      rt().ensure_lds(reinterpret_cast<const void*>(&k_fbwd<NPL, L, BFM>), T::LDS);
+      hipLaunchKernelGGL((k_fbwd<NPL, L, BFM>), dim3(grid), dim3(256), T::LDS, s, a);
+      return;
+    }
+  }
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_fbwd<NPL, L>), T::LDS);
   hipLaunchKernelGGL((k_fbwd<NPL, L>), dim3(grid), dim3(256), T::LDS, s, a);
 }
 template <int NPL>

@@ -73,6 +73,7 @@ struct FcArgs {
   const float* bias;    // [O] or nullptr
   float* out;           // [F][OC][OH]
   int F;
+  bool bf_in = false, bf_out = false;   // bf16 activation storage of the input / output tensor (precision "bf16", decoder layers 1 - 2)
 };
 
 template <int CP, int CPL>
@@ -83,7 +84,7 @@ __device__ __forceinline__ int fc_koff(int ks, int lh) {
 }
 
 // LN: 0 plain input, 1 LayerNorm + lrelu with given statistics, 2 ... with statistics computed here
-template <int NPL, int SITE, int LN>
+template <int NPL, int SITE, int LN, bool BIN = false, bool BOUT = false>
 __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (FcCfg<NPL, SITE>::OCC)) k_fconv(FcArgs a) {
   using T = FcCfg<NPL, SITE>;
   constexpr CvSite V = T::V;
@@ -106,13 +107,14 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (FcCfg<NPL, SITE>::O
       const int it = wave + NWV * u, fl = it / NCH, k = it - fl * NCH;
       const int f = g * T::TF + fl, h = 64 * k + lane;
       const bool fok = it < NIT && f < a.F;
-      const float* sf = a.src + (int64_t)(fok ? f : 0) * (T::C * T::H);
+      constexpr int PIN = act_pitch(BIN, T::H);
+      const int64_t sfo = (int64_t)(fok ? f : 0) * (T::C * PIN);
       if constexpr (LN == 1) {
         mean[u] = a.st[2 * (fok ? f : 0)];
         rstd[u] = a.st[2 * (fok ? f : 0) + 1];
       }
 #pragma unroll
-      for (int c = 0; c < T::CP; ++c) v[u][c] = (!(VAENPVC_FC_ABL & 1) && c < T::C && h < T::H && fok) ? sf[c * T::H + h] : 0.f;
+      for (int c = 0; c < T::CP; ++c) v[u][c] = (!(VAENPVC_FC_ABL & 1) && c < T::C && h < T::H && fok) ? act_ld<BIN>(a.src, sfo + c * PIN + h) : 0.f;
     }
   };
   // LayerNorm statistics of the group's frames from the registers (LN == 2): per item partial sums through LDS, two
@@ -280,6 +282,25 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (FcCfg<NPL, SITE>::O
               const int ti = mb / 32, row = mb % 32, reg = (row & 3) + 4 * (row >> 3);
               ph[p3] = acc[ti][j][reg] + (a.bias ? a.bias[ch] : 0.f);
             }
+            if constexpr (BOUT) {
+              // bf16 storage, rows of an even pitch: the three positions leave as one aligned pair + one single
+              constexpr int PO = act_pitch(true, V.OH);
+              unsigned short* o2 = reinterpret_cast<unsigned short*>(a.out) + ((int64_t)(f0 + fl) * V.OC + ch) * PO + pbase;
+              if (inner) {
+                if (pbase & 1) {
+                  o2[0] = (unsigned short)bf16_rn(ph[0]);
+                  *reinterpret_cast<unsigned*>(o2 + 1) = cvt_pk_bf16(ph[1], ph[2]);
+                } else {
+                  *reinterpret_cast<unsigned*>(o2) = cvt_pk_bf16(ph[0], ph[1]);
+                  o2[2] = (unsigned short)bf16_rn(ph[2]);
+                }
+              } else {
+#pragma unroll
+                for (int p3 = 0; p3 < 3; ++p3)
+                  if (pbase + p3 >= 0 && pbase + p3 < V.OH) o2[p3] = (unsigned short)bf16_rn(ph[p3]);
+              }
+              continue;
+            }
             float* o = ob + ch * V.OH + pbase;
             if (inner) {
               *reinterpret_cast<f3*>(o) = f3{ph[0], ph[1], ph[2]};
@@ -311,6 +332,14 @@ template <int NPL, int SITE>
 static void launch_fconv(const FcArgs& a, hipStream_t s) {
   using T = FcCfg<NPL, SITE>;
   const unsigned grid = (unsigned)cmin_(cdiv(a.F, T::TF), T::LDS > 80 * 1024 ? 256 : 256 * T::WGS_PER_CU);   // persistent: two (three) workgroups per CU walk the frame groups
+  if constexpr (NPL == 1 && (SITE == CV_D1F || SITE == CV_D2F)) {
+    if (a.bf_out) {   // bf16 activation storage (the statistics of the input are taken inside: LN = 2)
+      constexpr bool BIN = SITE == CV_D2F;
+      rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, 2, BIN, true>), T::LDS);
+      hipLaunchKernelGGL((k_fconv<NPL, SITE, 2, BIN, true>), dim3(grid), dim3(T::NTHR), T::LDS, s, a);
+      return;
+    }
+  }
   if (a.st_out) {
     rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, 2>), T::LDS);
     hipLaunchKernelGGL((k_fconv<NPL, SITE, 2>), dim3(grid), dim3(T::NTHR), T::LDS, s, a);

@@ -54,7 +54,7 @@ struct FwArgs {
 };
 
 // staging of one operand: items = (frame of the group, 64-position chunk) dealt round-robin to the waves (see k_fconv)
-template <int NPL, int C, int CP, int CPL, int H, int TF, int FS, int ROW0, int PLANE>
+template <int NPL, int C, int CP, int CPL, int H, int TF, int FS, int ROW0, int PLANE, bool BF = false>   // BF: the tensor is stored as bf16 (act_pitch rows)
 struct FwStage {
   static constexpr int NCH = cdiv(H, 64), NIT = TF * NCH, IPW = cdiv(NIT, 4);
   float v[IPW][CP];
@@ -67,7 +67,8 @@ struct FwStage {
       const int f = g * TF + fl, h = 64 * k + lane;
       const bool fok = it < NIT && f < F;
       ok[u] = fok;
-      const float* sf = src + (int64_t)(fok ? f : 0) * (C * H);
+      constexpr int PIN = act_pitch(BF, H);
+      const int64_t sfo = (int64_t)(fok ? f : 0) * (C * PIN);
       mean[u] = 0.f;
       rstd[u] = 1.f;
       if (st) {  // uniform
@@ -75,7 +76,7 @@ struct FwStage {
         rstd[u] = st[2 * (fok ? f : 0) + 1];
       }
 #pragma unroll
-      for (int c = 0; c < CP; ++c) v[u][c] = (c < C && h < H && fok) ? sf[c * H + h] : 0.f;
+      for (int c = 0; c < CP; ++c) v[u][c] = (c < C && h < H && fok) ? act_ld<BF>(src, sfo + c * PIN + h) : 0.f;
     }
   }
   // frames past the batch end hold zeros in the registers and are stored too (stale rows of an earlier group must not survive)

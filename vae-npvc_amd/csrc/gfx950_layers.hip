@@ -242,6 +242,17 @@ static inline bool fb_bwd(int layer, int64_t F) {
   if (!((rt().fb_layers() >> layer) & 1u)) return false;
   return F >= FCONV_MIN_FRAMES || !((rt().bwd_mask >> 14) & 1u);
 }
+static bool toep_bf16_for(int64_t F);
+// bf16 ACTIVATION STORAGE (precision "bf16" only, gfx950_toep_bf16.h: act_pitch): the pre-LN outputs of decoder layers 1 and 2
+// and the gradients at their activated outputs live in HBM as bf16 when every producer and consumer of them is one of the
+// kernels that knows the format -- the default selection from FCONV_MIN_FRAMES frames on (VAENPVC_ACT_BF16=0: fp32 storage)
+static inline bool act_bf16(int64_t F) {
+  Runtime& r = rt();
+  if (!r.act_bf16 || r.planes != 1 || (r.dense_planes && r.dense_planes != 1) || F < FCONV_MIN_FRAMES) return false;
+  const unsigned need = (1u << 8) | (1u << 9) | (1u << 10);
+  if ((r.fwd_mask & need) != need || (r.bwd_mask & need) != need) return false;
+  return fc_fwd(CV_D1F, F) && fc_fwd(CV_D2F, F) && toep_bf16_for(F) && fb_bwd(FB_D2, F) && fb_bwd(FB_D1, F);
+}
 static inline bool fc_any(int64_t F) {
   for (int i = 0; i < CV_COUNT; ++i)
     if (fc_fwd(i, F) || fc_bwd(i, F) || fcr_fwd(i, F) || fcr_bwd(i, F)) return true;
@@ -646,10 +657,14 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     a.nrb = MERGE_NY;
     VAENPVC_TIMED("merge_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_densegemm<MergeFs>(a, s) : launch_densegemm<MergeF>(a, s)));
   } else generic::merge_fwd(m, P, z, y, F, w, s);
-  auto fused = [&](int site, const float* src, const float* st, float* st_out, const ConvL* ln, const float* bias, float* out, const char* tag) {
+  const bool abf = act_bf16(F);    // bf16 storage of dec_a[1], dec_a[2] (and of their gradients in the backward pass)
+  auto fused = [&](int site, const float* src, const float* st, float* st_out, const ConvL* ln, const float* bias, float* out, const char* tag,
+                   bool bf_in = false, bool bf_out = false) {
     for_dense_planes([&](auto npl) {
       FcArgs fa{src, st, st_out, ln ? P + ln->gamma_off : nullptr, ln ? P + ln->beta_off : nullptr,
                 reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvw + cv_woff(site)), bias, out, F};
+      fa.bf_in = bf_in;
+      fa.bf_out = bf_out;
       VAENPVC_TIMED(tag, s, fconv<decltype(npl)::value>(site, fa, s));
     });
   };
@@ -691,7 +706,7 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     if (!d1_fused && !(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) VAENPVC_TIMED("stats_dec0", s, stats<1824>(w.dec_a[0], w.dec_st[0], F, s));
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 0);
   if (fwd_on(8) && fc_fwd(CV_D1F, F)) {
-    fused(CV_D1F, w.dec_a[0], nullptr, w.dec_st[0], &m.dec[0], P + m.dec[1].b_off, w.dec_a[1], "dec1_fwd");
+    fused(CV_D1F, w.dec_a[0], nullptr, w.dec_st[0], &m.dec[0], P + m.dec[1].b_off, w.dec_a[1], "dec1_fwd", false, abf);
     if (!d2_fused && !(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) VAENPVC_TIMED("stats_dec1", s, stats<2736>(w.dec_a[1], w.dec_st[1], F, s));
   } else if (fwd_on(8) && cv_fwd(CV_D1F, F)) {
     dec_view(CV_D1F, CL_YD0, 1, have_yd0, w.dec_a[0], "dec1_split", "dec1_fwd");
@@ -703,7 +718,7 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     if (!d2_fused && !(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) VAENPVC_TIMED("stats_dec1", s, stats<2736>(w.dec_a[1], w.dec_st[1], F, s));
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 1);
   if (fwd_on(9)) {
-    if (fc_fwd(CV_D2F, F)) fused(CV_D2F, w.dec_a[1], nullptr, w.dec_st[1], &m.dec[1], P + m.dec[2].b_off, w.dec_a[2], "dec2_fwd");
+    if (fc_fwd(CV_D2F, F)) fused(CV_D2F, w.dec_a[1], nullptr, w.dec_st[1], &m.dec[1], P + m.dec[2].b_off, w.dec_a[2], "dec2_fwd", abf, abf);
     else if (cv_fwd(CV_D2F, F)) dec_view(CV_D2F, CL_YD1, 2, have_yd1, w.dec_a[1], "dec2_split", "dec2_fwd");
     else
     VAENPVC_TIMED("dec2_fwd", s, launch_convgemm<D2F>(conv_args(w.dec_a[1], w.dec_st[1], P + m.dec[1].gamma_off,
@@ -711,10 +726,17 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
                                                                 P + m.dec[2].b_off, w.dec_a[2], F), nsplit_for<D2F>(F), s));
     if (toep_bf16_for(F) && fwd_on(10))
       for_planes([&](auto npl) {
-        VAENPVC_TIMED("dec2_stats_planes", s, hipLaunchKernelGGL(k_ln_stats_act_planes<decltype(npl)::value>, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
+        constexpr int NPL_ = decltype(npl)::value;
+        auto launch_sap = [&](auto kern) {
+          VAENPVC_TIMED("dec2_stats_planes", s, hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
                            P + m.dec[2].gamma_off, P + m.dec[2].beta_off, w.dec_y, reinterpret_cast<unsigned short*>(w.toep_yp),
                            w.scratch + Pk::wc, P + m.dec[3].b_off, xh_out, (int)F, toep_wgrad_bf16_for(F) ? 0 : 1,
                            toep_fwd_groups(F, weights_packed) > 1 ? 1 : 0));
+        };
+        if constexpr (NPL_ == 1) {
+          if (abf) { launch_sap(k_ln_stats_act_planes<1, true>); return; }
+        }
+        launch_sap(k_ln_stats_act_planes<NPL_, false>);
       });
     else
       VAENPVC_TIMED("dec2_stats_planes", s, hipLaunchKernelGGL((k_ln_stats_act<4104, 513>), dim3((unsigned)cdiv(F, 4)), dim3(256), 0, s, w.dec_a[2], w.dec_st[2],
@@ -781,6 +803,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
               const Ws& w, float* G, hipStream_t s) {
   read_env();
   const int F = (int)F64;
+  const bool abf = act_bf16(F64);   // bf16 storage of dec_a[1], dec_a[2] and of the gradients at their activated outputs
   (void)hipMemsetAsync(G, 0, (size_t)m.n_params * 4, s);
   // (bit 30 of the backward mask cleared = no fork for this call: serialised kernels, used by bench.py to
   //  time single kernels without concurrent neighbours)
@@ -801,8 +824,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   const bool toep_planes = bwd_on(10) && toep_bf16_for(F);
   if (toep_planes)
     for_planes([&](auto npl) {
-      VAENPVC_TIMED("dxh_post", s, hipLaunchKernelGGL(k_dxh_post<decltype(npl)::value>, dim3((unsigned)cmin_(2048, cdiv((int)F, 4))), dim3(256), 0, s, w.d_xh, P + m.dec[3].w_off,
-                         reinterpret_cast<unsigned short*>(w.toep_gp), w.dy_tmp, G + m.dec[3].b_off, (int)F));
+      constexpr int NPL_ = decltype(npl)::value;
+      auto launch_dp = [&](auto kern) {
+        VAENPVC_TIMED("dxh_post", s, hipLaunchKernelGGL(kern, dim3((unsigned)cmin_(2048, cdiv((int)F, 4))), dim3(256), 0, s, w.d_xh, P + m.dec[3].w_off,
+                           reinterpret_cast<unsigned short*>(w.toep_gp), w.dy_tmp, G + m.dec[3].b_off, (int)F));
+      };
+      if constexpr (NPL_ == 1) {
+        if (abf) { launch_dp(k_dxh_post<1, true>); return; }
+      }
+      launch_dp(k_dxh_post<NPL_, false>);
     });
   ready();
   bool dec_bias_done[4] = {false, false, false, false};
@@ -920,10 +950,16 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       unsigned short* gp = reinterpret_cast<unsigned short*>(w.toep_gp);
       for_planes([&](auto npl) {
         constexpr int NPL = decltype(npl)::value;
-        rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_gemm_bf16<false, NPL>), dg_lds(NPL));
-        VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL((k_toep_gemm_bf16<false, NPL>), dim3((unsigned)cdiv(F, DG_M), (unsigned)toep_groups(F)), dim3(256), dg_lds(NPL), s, gp,
-                                                          reinterpret_cast<const unsigned short*>(w.scratch + Pk::wdg), (const float*)nullptr,
-                                                          w.dy_tmp, (int)F));  // (column 512: k_dxh_post)
+        auto launch_dg = [&](auto kern) {
+          rt().ensure_lds(reinterpret_cast<const void*>(kern), dg_lds(NPL));
+          VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(F, DG_M), (unsigned)toep_groups(F)), dim3(256), dg_lds(NPL), s, gp,
+                                                            reinterpret_cast<const unsigned short*>(w.scratch + Pk::wdg), (const float*)nullptr,
+                                                            w.dy_tmp, (int)F));  // (column 512: k_dxh_post)
+        };
+        if constexpr (NPL == 1) {
+          if (abf) { launch_dg(&k_toep_gemm_bf16<false, 1, true>); return; }
+        }
+        launch_dg(&k_toep_gemm_bf16<false, NPL, false>);
       });
     } else
     if (F >= 8192) {
@@ -951,6 +987,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       FbArgs fa{dy, act[i], sts[i], P + l.gamma_off, P + l.beta_off, act[i - 1], sts[i - 1], P + pl.gamma_off,
                 P + pl.beta_off, reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvw + cv_woff(fb_gsite(layer))), dx,
                 G + l.w_off, G + l.gamma_off, G + l.beta_off, G + l.b_off, F};
+      fa.bf16_act = abf && !enc;
       VAENPVC_TIMED(tag, s, fbwd<NPL>(layer, fa, s));
     });
   };

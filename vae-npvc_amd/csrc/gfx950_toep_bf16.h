@@ -40,6 +40,8 @@ __device__ unsigned long long g_tw_prof[8];  // wgrad: waves, gload, loadF, mm, 
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 struct __attribute__((packed, aligned(4))) packed4 {
   float x, y, z, w;
 };  // 16 bytes = 8 bf16 (native vector: stays in registers)
@@ -57,6 +59,23 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ unsigned bf16_rn(float x) { return cvt_pk_bf16(x, 0.f); }   // as 16 bits (upper half zero)
+// bf16 ACTIVATION STORAGE (precision "bf16", round 4): in the bf16 training mode the large tensors of the thin decoder layers
+// (pre-LN outputs of layers 1 and 2, the gradients at their activated outputs) live in HBM as bf16 -- half the bytes of
+// the passes that are bound by them.  Same workspace regions, rows [C][pitch] with the pitch rounded up to an even number
+// of elements so that pairs / quads of neighbouring positions stay 4-byte aligned.  fp32 everywhere else (LayerNorm
+// statistics, accumulation, parameters, Adam).
+__device__ __forceinline__ float bf16_f32(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+constexpr int act_pitch(bool bf, int h) { return bf ? ((h + 1) & ~1) : h; }
+template <bool BF>
+__device__ __forceinline__ float act_ld(const float* base, int64_t i) {
+  if constexpr (BF) return bf16_f32(reinterpret_cast<const unsigned short*>(base)[i]);
+  else return base[i];
+}
+template <bool BF>
+__device__ __forceinline__ void act_st(float* base, int64_t i, float v) {
+  if constexpr (BF) reinterpret_cast<unsigned short*>(base)[i] = (unsigned short)bf16_rn(v);
+  else base[i] = v;
+}
 // (x, y) -> per plane one packed pair (x's term in the low half): 3 instructions per element with two planes
 template <int NPL>
 __device__ __forceinline__ void split_pair(float x, float y, unsigned (&pk)[NPL]) {
@@ -129,7 +148,7 @@ constexpr int TB_WFLOATS = TB_C * tb_wch(3) / 4;              // floats reserved
 //      dY[f][c][512] = sum_p G[f][p] * W[p][c], (3) the bias gradient sum_f sum_p G[f][p] (one atomic per
 //      workgroup).  One wave per frame, lane l owns bins 8l .. 8l+7 (lane 0 also bin 512); waves walk the frames
 //      with a grid stride.
-template <int NPL>
+template <int NPL, bool BOUT = false>   // BOUT: dY is stored as bf16 with rows of 514 (bf16 activation storage)
 __global__ void __launch_bounds__(256) k_dxh_post(const float* __restrict__ G, const float* __restrict__ W,
                                                   unsigned short* __restrict__ dst, float* __restrict__ dY,
                                                   float* __restrict__ dbias, int F) {
@@ -190,7 +209,7 @@ __global__ void __launch_bounds__(256) k_dxh_post(const float* __restrict__ G, c
 #pragma unroll
     for (int c = 0; c < TB_C; ++c) {
       float v = wave_sum(dot[c]);
-      if (lane == 0) dY[((int64_t)f * TB_C + c) * TB_H + 512] = v;
+      if (lane == 0) act_st<BOUT>(dY, ((int64_t)f * TB_C + c) * act_pitch(BOUT, TB_H) + 512, v);
     }
   }
   bsum = wave_sum(bsum);
@@ -240,7 +259,7 @@ constexpr int dg_lds(int npl) { return npl * DG_APL + tb_wch(npl); }  // NPL = 3
 // planes are per channel ([F][3][8][528]) and the accumulators run over all 8 channels.
 // (second launch bound = waves per SIMD.  One plane: two workgroups per CU, -10..13 %; two planes need 344 - 388
 //  registers and spill at 256: measured equal or slower, so they keep one workgroup per CU)
-template <bool FWD, int NPL>
+template <bool FWD, int NPL, bool BOUT = false>   // BOUT (input gradient only): dY stored as bf16, rows of 514
 __global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(const unsigned short* __restrict__ gp,   // A planes
                                                             const unsigned short* __restrict__ wcp,  // packed tap copies
                                                             const float* __restrict__ bias,          // FWD: [1]
@@ -433,6 +452,12 @@ __global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(cons
             if (split_out) {  // uniform: partial sum of this channel group (the plane producer zeroed the row)
 #pragma unroll
               for (int nb = 0; nb < 4; ++nb) atomicAdd(o + nb, acc[mb][nb][reg] + bb);
+            } else if constexpr (BOUT) {  // four bf16: one 8-byte store (rows of 514 elements: 4-byte aligned)
+              static_assert(!BOUT || !FWD, "bf16 output: input gradient only");
+              unsigned short* o2 = reinterpret_cast<unsigned short*>(dY) + ((int64_t)f0 * TB_C + c) * act_pitch(true, TB_H) +
+                                   (4 * lh + r) * (TB_C * act_pitch(true, TB_H)) + 128 * wave + 4 * l31;
+              const u32x2_a4 pk = {cvt_pk_bf16(acc[mb][0][reg], acc[mb][1][reg]), cvt_pk_bf16(acc[mb][2][reg], acc[mb][3][reg])};
+              st_nt<VAENPVC_NT_T>(reinterpret_cast<u32x2_a4*>(o2), pk);
             } else {  // rows are only 4-byte aligned (513 bins): packed 16-byte store
               if constexpr (VAENPVC_NT_T && !FWD)
                 st_nt<1>(reinterpret_cast<f32x4_a4*>(o), f32x4_a4{acc[mb][0][reg] + bb, acc[mb][1][reg] + bb, acc[mb][2][reg] + bb, acc[mb][3][reg] + bb});
@@ -466,7 +491,7 @@ __global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(cons
 //      of the activated frame with the taps W[1024 - i][c] (the GEMM kernel covers p < 512).
 //      One wave per frame; lane l owns bins 8l .. 8l+7 of every channel, lanes 0..7 also bin 512 of
 //      channel l.
-template <int NPL>
+template <int NPL, bool BIN = false>
 __global__ void __launch_bounds__(256) k_ln_stats_act_planes(const float* __restrict__ a, float* __restrict__ st,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ y, unsigned short* __restrict__ yp,
@@ -479,19 +504,30 @@ __global__ void __launch_bounds__(256) k_ln_stats_act_planes(const float* __rest
   const int lane = threadIdx.x & 63;
   const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (f >= F) return;
+  constexpr int PIN = act_pitch(BIN, TB_H);   // row pitch of the input (bf16 storage: 514 elements of 2 bytes)
   const float* af = a + (int64_t)f * (TB_C * TB_H);
+  const unsigned short* ah = reinterpret_cast<const unsigned short*>(a) + (int64_t)f * (TB_C * PIN);
   float v[TB_C][8], vt = 0.f;
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < TB_C; ++c) {
-    packed4 p0 = *reinterpret_cast<const packed4*>(af + c * TB_H + 8 * lane);
-    packed4 p1 = *reinterpret_cast<const packed4*>(af + c * TB_H + 8 * lane + 4);
-    v[c][0] = p0.x; v[c][1] = p0.y; v[c][2] = p0.z; v[c][3] = p0.w;
-    v[c][4] = p1.x; v[c][5] = p1.y; v[c][6] = p1.z; v[c][7] = p1.w;
+    if constexpr (BIN) {   // 8 bf16 = one 16-byte piece (rows are 4-byte aligned: the pitch is even)
+      const u32x4 q = *reinterpret_cast<const u32x4_a4*>(ah + c * PIN + 8 * lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[c][2 * j] = __uint_as_float(q[j] << 16);
+        v[c][2 * j + 1] = __uint_as_float(q[j] & 0xffff0000u);
+      }
+    } else {
+      packed4 p0 = *reinterpret_cast<const packed4*>(af + c * TB_H + 8 * lane);
+      packed4 p1 = *reinterpret_cast<const packed4*>(af + c * TB_H + 8 * lane + 4);
+      v[c][0] = p0.x; v[c][1] = p0.y; v[c][2] = p0.z; v[c][3] = p0.w;
+      v[c][4] = p1.x; v[c][5] = p1.y; v[c][6] = p1.z; v[c][7] = p1.w;
+    }
     s += ((v[c][0] + v[c][1]) + (v[c][2] + v[c][3])) + ((v[c][4] + v[c][5]) + (v[c][6] + v[c][7]));
   }
   if (lane < TB_C) {
-    vt = af[lane * TB_H + 512];
+    vt = BIN ? bf16_f32(ah[lane * PIN + 512]) : af[lane * TB_H + 512];
     s += vt;
   }
   const float mean = wave_sum(s) / (TB_C * TB_H);

@@ -42,6 +42,7 @@ void Runtime::read_env() {
   if (const char* e = getenv("VAENPVC_FCR_SITES")) fcr_sites_env = (long)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_FW_SITES")) fw_sites_env = (long)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_FB_LAYERS")) fb_layers_env = (long)strtoul(e, nullptr, 0);
+  if (const char* e = getenv("VAENPVC_ACT_BF16")) act_bf16 = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_FC_SITES")) fc_sites_env = (long)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_DENSE_PLANES")) {
     int p = atoi(e);
