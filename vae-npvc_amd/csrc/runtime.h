@@ -39,7 +39,9 @@ struct Runtime {
   static constexpr unsigned CV_SITES_BF16 = 0xe2ceu, CV_SITES_X2 = 0xc244u, CV_SITES_X3 = 0x4u;  // by measurement
   long fb_layers_env = -1;      // VAENPVC_FB_LAYERS: thin decoder layers whose whole backward step is one kernel (gfx950_fbwd.h; bit = FB_* layer)
   unsigned fb_layers() const { return fb_layers_env >= 0 ? (unsigned)fb_layers_env : 0x7u; }
-XX
+  bool act_bf16 = false;        // VAENPVC_ACT_BF16=1: bf16 HBM storage of the thin decoder layers' tensors in the bf16 mode (correct, tested;
+                                // measured 5.29 -> 5.41 ms: the kernels that touch them are bound by the number of vector-memory operations in
+                                // flight, not by bytes, and the phase-stacked epilogue needs two stores where fp32 needs one -- off by default)
   bool tn_k16 = false;          // VAENPVC_TN_K16: the 16-row two-workgroup A^T B kernel instead of the pipelined 32-row one (A/B)
   int tn_w4_tiles = 8;          // VAENPVC_TN_W4_TILES: the four-wave A^T B kernel from this many 256 x 256 tiles per row chunk on (0: every plain site, 99: never)
   int tn_xcd = -1;              // VAENPVC_TN_XCD=0|1: tile order of the C += A^T B plane GEMM (experiments; -1 = per site)
