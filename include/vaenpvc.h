@@ -48,6 +48,7 @@ extern "C" {
 #define VAENPVC_E_WORKSPACE (-2) /* workspace too small */
 #define VAENPVC_E_HIP (-3)       /* a HIP runtime call failed */
 #define VAENPVC_E_UNSUPPORTED (-4)
+#define VAENPVC_E_STATE (-5)     /* the call needs state a preceding call of the same context did not leave (vaenpvc_train_bwd_target) */
 
 /* implementation selector (vaenpvc_set_impl) */
 #define VAENPVC_IMPL_AUTO 0 /* tuned gfx950 kernels where the geometry matches, generic otherwise */
@@ -174,7 +175,9 @@ int vaenpvc_train_fwd_bwd_target(vaenpvc_ctx* ctx, const float* d_params, const 
 /* Backward pass only, against d_target, on the activations a preceding vaenpvc_train_fwd_bwd / _target call
  * left in d_ws: same context, parameters, x, y, eps, F and workspace, nothing else run on that workspace in
  * between.  The backward pass reads the forward tensors and writes only gradient regions, so the second gradient
- * of the VAWGAN generator step (l_G after l_E) costs one backward instead of a whole step. */
+ * of the VAWGAN generator step (l_G after l_E) costs one backward instead of a whole step.  The context remembers the
+ * batch size, kernel selection, precision and workspace of its last train step and returns VAENPVC_E_STATE when this call
+ * does not match them (the backward pass would otherwise consume stale or unwritten operands without a sign). */
 int vaenpvc_train_bwd_target(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, const int64_t* d_y,
                              const float* d_eps, const float* d_target, int64_t F, float* d_grads,
                              float* d_loss3, void* d_ws, size_t ws_bytes, void* stream);

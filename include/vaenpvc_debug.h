@@ -43,7 +43,11 @@ extern "C" {
  * backward mask (default set): cleared = the 1025-tap layer's weight gradient on the eight-wave kernel (64 x 64 wave tiles,
  * k_toep_wgrad_bf16_k32) at every batch size instead of the four-wave kernel (128 x 128 wave tiles, operands by LDS-DMA:
  * k_toep_wgrad_bf16_w4) from 4 096 frames on; bit 16 likewise for the dense-shaped weight gradients with many tiles per row
- * chunk (encoder layer 4: k_gemm_tn4 instead of k_gemm_tn). */
+ * chunk (encoder layer 4: k_gemm_tn4 instead of k_gemm_tn).  Bit 15 of the backward mask (default set): cleared = the thin
+ * layers' backward steps (decoder layers 2 and 1, encoder layer 1; environment VAENPVC_FB_LAYERS = bit set of those three) as three
+ * kernels each (LayerNorm backward, input gradient, weight gradient) instead of ONE kernel per layer (csrc/gfx950_fbwd.h, from 1 024
+ * frames on); bit 14 (default set): cleared = those one-kernel steps at any batch size (parity tests).
+ * vaenpvc_timer_select accepts a comma-separated LIST of site tags (a kernel group timed in one pass: bench.py's roofline.sites). */
 int vaenpvc_set_tuned_masks(vaenpvc_ctx* ctx, uint32_t fwd_mask, uint32_t bwd_mask);
 
 /* Measurement hook (no reference counterpart): brackets every launch of ONE tagged

@@ -154,6 +154,31 @@ def test_two_contexts_on_two_host_threads():
     assert engines[0].precision == 2 and engines[1].precision == 3
 
 
+def test_backward_only_call_needs_a_matching_train_step():
+    """vaenpvc_train_bwd_target consumes the activations, packed weights and operand planes the preceding train step of the
+    same context left in the same workspace: without one -- or after one of another batch size or kernel selection -- it
+    must fail with VAENPVC_E_STATE instead of reading stale operands (round-3 advisor finding)."""
+    from hipvae import lib as L
+    arch = load_arch()
+    eng = make_engine()
+    eng.init_params(2)
+    x, y, eps = O.make_inputs(arch, 24, 2)
+    xt, yt, et = (torch.tensor(a, device=eng.device) for a in (x, y, eps))
+    grads = torch.zeros(eng.n_params, device=eng.device)
+    with pytest.raises(L.HipVaeError, match='no matching train step'):
+        eng.train_bwd_target(xt, yt, et, xt, grads)                    # nothing precedes it
+    eng.train_fwd_bwd(xt, yt, et, grads)
+    g1 = grads.clone()
+    eng.train_bwd_target(xt, yt, et, xt, grads)                        # same batch, target = x: the same gradient
+    torch.cuda.synchronize()
+    assert ((grads - g1).abs().max() / g1.abs().max()).item() < 1e-5
+    with pytest.raises(L.HipVaeError, match='no matching train step'):
+        eng.train_bwd_target(xt[:16], yt[:16], et[:16], xt[:16], grads)   # another batch size
+    eng.set_tuned_masks(0xffffffff & ~(1 << 21), 0xffffffff & ~(1 << 21))
+    with pytest.raises(L.HipVaeError, match='no matching train step'):
+        eng.train_bwd_target(xt, yt, et, xt, grads)                    # another kernel family
+
+
 @pytest.mark.parametrize('path', ['layered', 'frame'])
 def test_gradient_bucket_callback_ranges_and_order(path):
     """vaenpvc_set_bucket_callback.  Layered kernels (every batch above 512 frames; forced here by clearing mask bit 21): four

@@ -344,6 +344,15 @@ static int train_impl(vaenpvc_ctx* ctx, const float* d_params, const float* d_x,
   // only the layered forward pass leaves behind)
   const bool frame = use_tuned(ctx) && tuned::frame_fwd_on(F) && tuned::frame_bwd_on(F);
   fwd_all(ctx, d_params, d_x, d_y, d_eps, key, F, w, true, d_loss3, s, d_target, frame, frame ? d_grads : nullptr);
+  {  // what vaenpvc_train_bwd_target may re-use
+    Runtime& r = ctx->rt;
+    r.last_F = F;
+    r.last_path = frame ? 2 : use_tuned(ctx) ? 1 : 0;
+    r.last_planes = r.planes;
+    r.last_fwd_mask = r.fwd_mask;
+    r.last_bwd_mask = r.bwd_mask;
+    r.last_ws = d_ws;
+  }
   const float* eps_bwd = key ? w.eps : d_eps;   // (the seeded sampler stored its draw in the workspace)
   ctx->rt.bucket_next = 0;
   if (frame) {
@@ -386,6 +395,16 @@ int vaenpvc_train_bwd_target(vaenpvc_ctx* ctx, const float* d_params, const floa
   int rc = resolve(ctx, F, VAENPVC_MODE_TRAIN, d_ws, ws_bytes, &w);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  {
+    // the backward pass consumes what the preceding train step of THIS context left in THIS workspace (activations, packed
+    // weights, operand planes): same batch size, same kernel family, same masks and precision -- anything else would read
+    // stale or unwritten operands without a sign (round-3 advisor)
+    const Runtime& r = ctx->rt;
+    const int path = (use_tuned(ctx) && tuned::frame_fwd_on(F) && tuned::frame_bwd_on(F)) ? 2 : use_tuned(ctx) ? 1 : 0;
+    if (r.last_F != F || r.last_path != path || r.last_planes != r.planes || r.last_fwd_mask != r.fwd_mask ||
+        r.last_bwd_mask != r.bwd_mask || r.last_ws != d_ws)
+      return fail(VAENPVC_E_STATE, "train_bwd_target: no matching train step precedes it in this context (batch size, kernel selection, precision or workspace differ)");
+  }
   generic::loss_fwd(ctx->m, d_target, F, w, true, d_loss3, s);   // new d(xh) from the activations already in place
   ctx->rt.bucket_next = 0;
   if (use_tuned(ctx) && tuned::frame_fwd_on(F) && tuned::frame_bwd_on(F)) {

@@ -53,6 +53,12 @@ struct Runtime {
   bool side_enabled = true;     // VAENPVC_SIDE_STREAM=0 disables the internal weight-gradient stream
   int frame_max = 512;          // VAENPVC_FRAME_MAX: largest batch on the whole-frame-per-workgroup kernels (gfx950_frame.h); 0 = never.
                                 // Bit 21 of a mask cleared = the layered kernels for that pass of this context (A/B, parity tests)
+  // ---- what the last train forward of this context left in the workspace (vaenpvc_train_bwd_target re-uses it): batch size, kernel
+  //      family (0 generic, 1 layered, 2 frame kernels), the masks / precision it ran under and the workspace it wrote
+  int64_t last_F = -1;
+  int last_path = -1, last_planes = 0;
+  unsigned last_fwd_mask = 0, last_bwd_mask = 0;
+  const void* last_ws = nullptr;
   // ---- device binding: created lazily on the device that is current at the first launch
   int device = -1;
   hipStream_t s2 = nullptr;

@@ -77,7 +77,11 @@ class VAETrainer(object):
     def _restore_source(self, sd):
         src = getattr(self.loss, 'source', None)
         if src is not None and hasattr(src, 'load_state_dict') and sd.get('source') is not None:
-            src.load_state_dict(sd['source'])
+            if src.load_state_dict(sd['source']) is False and getattr(self.opt.get('g'), 'rank', 0) == 0:
+                # (another global batch size / world size than the checkpoint's: the record stream starts afresh from the seed)
+                import logging
+                logging.warning('checkpoint holds the data-source state of another batch size or world size: '
+                                'the record stream restarts from its seed (parameters, Adam slots and step are restored)')
 
     def restore(self, restore_from, ckpt=None):
         """tf.train.Supervisor restore (trainer/vae.py:77-84 + util/wrapper.py:32-62): parameters, the Adam
