@@ -37,8 +37,11 @@ constexpr int fc_tf(int site) {
 }
 // (encoder layer 2 FORWARD was tried the same way and dropped: 417 us against 255 us on the fp32 engine -- K = 224
 //  against 64 rows: two waves per M tile re-read every B fragment, one workgroup per CU)
-constexpr int fc_nj(int site) { return site == CV_D2G || site == CV_E2G ? 1 : 2; }
+constexpr int fc_nj(int site) { return site == CV_D2G || site == CV_E2G || (site == CV_D2F && fc_occ3(site)) ? 1 : 2; }   // (decoder layer 2 forward at three workgroups per CU: 32-row steps, three 16-register accumulators per wave instead of two 32-register ones)
 
+#ifndef VAENPVC_FC_DEFER
+#define VAENPVC_FC_DEFER 1   // result stores of a group issued at the top of the next iteration (0: at the end of the GEMM phase; A/B)
+#endif
 #ifndef VAENPVC_FC_ABL
 #define VAENPVC_FC_ABL 0   // developer ablation (wrong results): 1 no global loads, 2 no conversion / LDS stores, 4 no fragment reads / MFMAs, 8 no result stores
 #endif
@@ -213,48 +216,37 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (FcCfg<NPL, SITE>::O
   }
   __syncthreads();
   const int woff = l31 * T::WP + lh * 8;
-  for (; g < ngroups; g += gridDim.x) {
-    const int f0 = g * T::TF, nf = min(T::TF, a.F - f0);
-    fstore(g);
-    __syncthreads();   // the group's frames are in LDS
-    if (g + (int)gridDim.x < ngroups) fload(g + gridDim.x);
-    // ---- GEMM rows n = fl * R + q, SROWS per step, steps dealt round-robin to the waves
-    const int nrows = nf * V.R, nsteps = cdiv(nrows, T::SROWS);
-    for (int s = wave; s < nsteps; s += NWV) {
-      int xoff[T::NJ];
+  // The result stores of a group are DEFERRED to the top of the next iteration, behind the wait for that group's prefetched
+  // loads (VAENPVC_FC_DEFER, round 4): loads and stores share one in-order counter, so stores issued at the end of the GEMM
+  // phase had to be acknowledged before the wave could touch the next group's loaded registers -- their whole round trip
+  // was exposed once per group (the ablation without result stores ran 44 - 59 % faster).  Issued behind
+  // that wait they fly during the conversion, the LDS stores, the barrier and the next GEMM instead.  The accumulators of a
+  // wave's steps (NSW of them) stay live across the barrier; nothing else changes.
+  constexpr int NSW = cdiv(cdiv(T::TF * V.R, T::SROWS), NWV);
+  f32x16 acc[NSW][T::MT][T::NJ];
+  // bias of the rows a lane stores, once per kernel (a load inside the epilogue would order every later store behind it)
+  constexpr int NBV = V.PH ? V.mdiv / 2 : T::MT * 16;
+  float bv[NBV];
 #pragma unroll
-      for (int j = 0; j < T::NJ; ++j) {
-        int n = s * T::SROWS + j * 32 + l31;
-        n = n < nrows ? n : 0;                       // rows past the end: duplicates, never stored
-        const int fl = n / V.R, q = n - fl * V.R;
-        xoff[j] = fl * T::FS + q * T::RSTEP;
-      }
-      f32x16 acc[T::MT][T::NJ];
+  for (int k = 0; k < NBV; ++k) {
+    int ch;
+    bool ok;
+    if constexpr (V.PH) {
+      ch = (k & 3) + 8 * (k >> 2) + 4 * lh;
+      ok = true;
+    } else {
+      const int m = (k >> 4) * 32 + acc_row(k & 15, lane);
+      ch = m % V.mdiv;
+      ok = m < V.M && ch < V.O;
+    }
+    bv[k] = (a.bias && ok) ? a.bias[ch] : 0.f;
+  }
+  auto epilogue = [&](int f0, int nf) __attribute__((always_inline)) {
+    const int nrows = nf * V.R;
 #pragma unroll
-      for (int i = 0; i < T::MT; ++i)
-#pragma unroll
-        for (int j = 0; j < T::NJ; ++j) acc[i][j] = zero16();
-#pragma unroll
-      for (int ks = 0; ks < ((VAENPVC_FC_ABL & 4) ? 0 : T::KS); ++ks) {
-        u32x4 fa[T::MT][NPL], fb[T::NJ][NPL];
-        const int ko = fc_koff<T::CP, T::CPL>(ks, lh);
-#pragma unroll
-        for (int i = 0; i < T::MT; ++i)
-#pragma unroll
-          for (int p = 0; p < NPL; ++p) fa[i][p] = *reinterpret_cast<const u32x4*>(ws + p * T::WPL + i * 32 * T::WP + woff + ks * 16);
-#pragma unroll
-        for (int j = 0; j < T::NJ; ++j)
-#pragma unroll
-          for (int p = 0; p < NPL; ++p) fb[j][p] = *reinterpret_cast<const u32x4*>(xs + p * T::XPL + xoff[j] + ko);
-        using PR = Prod<NPL>;
-#pragma unroll
-        for (int t = 0; t < PR::N; ++t)
-#pragma unroll
-          for (int i = 0; i < T::MT; ++i)
-#pragma unroll
-            for (int j = 0; j < T::NJ; ++j) acc[i][j] = mfma_bf16(fa[i][PR::A[t]], fb[j][PR::B[t]], acc[i][j]);
-      }
-      // epilogue: accumulator rows = GEMM rows m (phase * mdiv + channel), lanes = 32 consecutive (frame, position) rows
+    for (int sidx = 0; sidx < NSW; ++sidx) {
+      const int s = wave + NWV * sidx;
+      // accumulator rows = GEMM rows m (phase * mdiv + channel), lanes = 32 consecutive (frame, position) rows
 #pragma unroll
       for (int j = 0; j < T::NJ; ++j) {
         const int n = s * T::SROWS + j * 32 + l31;
@@ -266,7 +258,7 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (FcCfg<NPL, SITE>::O
           // transposed conv: the three output phases of (channel, row q) sit in three registers of the SAME lane
           // (mdiv is a multiple of 8) and are three consecutive positions: one 12-byte store per (lane, channel), 32
           // lanes = 384 contiguous bytes, instead of three 4-byte stores at a 12-byte stride
-          static_assert(V.S == 3 && V.mdiv % 8 == 0 && V.O == V.mdiv, "phase-stacked epilogue");
+          static_assert(!V.PH || (V.S == 3 && V.mdiv % 8 == 0 && V.O == V.mdiv), "phase-stacked epilogue");
           struct __attribute__((packed, aligned(4))) f3 { float x, y, z; };
           const bool inner = pbase >= 0 && pbase + 2 < V.OH;
 #pragma unroll
@@ -276,11 +268,9 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (FcCfg<NPL, SITE>::O
             float ph[3];
 #pragma unroll
             for (int p3 = 0; p3 < 3; ++p3) {
-              constexpr int dummy = 0;
-              (void)dummy;
               const int mb = p3 * V.mdiv + chb;               // row of the lh = 0 lanes; lh = 1: + 4 (same tile, same register)
               const int ti = mb / 32, row = mb % 32, reg = (row & 3) + 4 * (row >> 3);
-              ph[p3] = acc[ti][j][reg] + (a.bias ? a.bias[ch] : 0.f);
+              ph[p3] = acc[sidx][ti][j][reg] + bv[cs];
             }
             if constexpr (BOUT) {
               // bf16 storage, rows of an even pitch: the three positions leave as one aligned pair + one single
@@ -319,13 +309,72 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (FcCfg<NPL, SITE>::O
               if (m >= V.M) continue;
               const int pim = m / V.mdiv, ch = m - pim * V.mdiv;
               const int pos = pbase + pim;
-              if (ch < V.O && pos >= 0 && pos < V.OH) ob[ch * V.OH + pos] = acc[i][j][reg] + (a.bias ? a.bias[ch] : 0.f);
+              if (ch < V.O && pos >= 0 && pos < V.OH) ob[ch * V.OH + pos] = acc[sidx][i][j][reg] + bv[i * 16 + reg];
             }
         }
       }
     }
+  };
+  int pf0 = -1, pnf = 0;   // the group whose results are still in the accumulators
+  for (; g < ngroups; g += gridDim.x) {
+    const int f0 = g * T::TF, nf = min(T::TF, a.F - f0);
+    if (VAENPVC_FC_DEFER && pf0 >= 0) {
+      // the prefetched loads of this group must have landed BEFORE the deferred stores are issued (a wait behind them would
+      // wait for them too): an empty use of every staging register puts the compiler's wait here
+#pragma unroll
+      for (int u = 0; u < IPW; ++u)
+#pragma unroll
+        for (int c = 0; c < T::CP; ++c) asm volatile("" ::"v"(v[u][c]));
+      epilogue(pf0, pnf);
+    }
+    fstore(g);
+    __syncthreads();   // the group's frames are in LDS
+    if (g + (int)gridDim.x < ngroups) fload(g + gridDim.x);
+    // ---- GEMM rows n = fl * R + q, SROWS per step, steps dealt round-robin to the waves
+    const int nrows = nf * V.R, nsteps = cdiv(nrows, T::SROWS);
+#pragma unroll
+    for (int sidx = 0; sidx < NSW; ++sidx) {
+      const int s = wave + NWV * sidx;
+      if (s >= nsteps) break;
+      int xoff[T::NJ];
+#pragma unroll
+      for (int j = 0; j < T::NJ; ++j) {
+        int n = s * T::SROWS + j * 32 + l31;
+        n = n < nrows ? n : 0;                       // rows past the end: duplicates, never stored
+        const int fl = n / V.R, q = n - fl * V.R;
+        xoff[j] = fl * T::FS + q * T::RSTEP;
+      }
+#pragma unroll
+      for (int i = 0; i < T::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < T::NJ; ++j) acc[sidx][i][j] = zero16();
+#pragma unroll
+      for (int ks = 0; ks < ((VAENPVC_FC_ABL & 4) ? 0 : T::KS); ++ks) {
+        u32x4 fa[T::MT][NPL], fb[T::NJ][NPL];
+        const int ko = fc_koff<T::CP, T::CPL>(ks, lh);
+#pragma unroll
+        for (int i = 0; i < T::MT; ++i)
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) fa[i][p] = *reinterpret_cast<const u32x4*>(ws + p * T::WPL + i * 32 * T::WP + woff + ks * 16);
+#pragma unroll
+        for (int j = 0; j < T::NJ; ++j)
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) fb[j][p] = *reinterpret_cast<const u32x4*>(xs + p * T::XPL + xoff[j] + ko);
+        using PR = Prod<NPL>;
+#pragma unroll
+        for (int t = 0; t < PR::N; ++t)
+#pragma unroll
+          for (int i = 0; i < T::MT; ++i)
+#pragma unroll
+            for (int j = 0; j < T::NJ; ++j) acc[sidx][i][j] = mfma_bf16(fa[i][PR::A[t]], fb[j][PR::B[t]], acc[sidx][i][j]);
+      }
+    }
+    if (!VAENPVC_FC_DEFER) epilogue(f0, nf);
+    pf0 = f0;
+    pnf = nf;
     __syncthreads();   // all fragment reads of this group are done before the next one overwrites the tile
   }
+  if (VAENPVC_FC_DEFER && pf0 >= 0) epilogue(pf0, pnf);
 }
 
 template <int NPL, int SITE>

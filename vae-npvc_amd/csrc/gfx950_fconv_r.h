@@ -160,6 +160,14 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
 #pragma unroll
     for (int p = 0; p < NPL; ++p)
       wreg[ks][p] = *reinterpret_cast<const u32x4*>(a.W + ((size_t)p * fcr_mp(SITE) + tile * 32 + l31) * V.Kp + ks * 16 + lh * 8);
+  // bias of the rows this lane stores, once per kernel: a load inside the epilogue orders every later store behind its round
+  // trip (the shared in-order vector-memory counter; gfx950_fconv.h lost 20 - 30 % to exactly that until round 4)
+  float bvr[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int ch = T::PERM ? tile * 8 + (k & 3) + 4 * lh : tile * 32 + acc_row(k, lane);
+    bvr[k] = (a.bias && ch < V.O) ? a.bias[ch] : 0.f;
+  }
   __syncthreads();
   for (; g < ngroups; g += gridDim.x) {
     const int f0 = g * T::TF, nf = min(T::TF, a.F - f0);
@@ -213,7 +221,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
 #pragma unroll
             for (int cs = 0; cs < 4; ++cs) {
               const int ch = tile * 8 + cs + 4 * lh;
-              const float bb = a.bias ? a.bias[ch] : 0.f;
+              const float bb = bvr[cs];
               const float p0 = acc[h][cs] + bb, p1 = acc[h][cs + 4] + bb, p2 = acc[h][cs + 8] + bb;
               float* o = ob + ch * V.OH + pbase;
               if (inner) {
@@ -228,7 +236,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
               const int ch = tile * 32 + acc_row(reg, lane);
-              if (ch < V.O && pbase >= 0 && pbase < V.OH) ob[ch * V.OH + pbase] = acc[h][reg] + (a.bias ? a.bias[ch] : 0.f);
+              if (ch < V.O && pbase >= 0 && pbase < V.OH) ob[ch * V.OH + pbase] = acc[h][reg] + bvr[reg];
             }
           }
         }

@@ -387,12 +387,19 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
     }
     __syncthreads();
   }
-  // epilogue: lanes = 32 consecutive columns of a row -> 128-byte stores
+  // epilogue: lanes = 32 consecutive columns of a row -> 128-byte stores (both bias values first: a load issued between the
+  // stores would order the later ones behind its round trip)
+  float bb2[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + l31;
+    bb2[j] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn * 64 + j * 32 + l31;
     if (n >= a.N) continue;
-    const float bb = a.bias ? a.bias[n] : 0.f;
+    const float bb = bb2[j];
     float* cb = a.C;
     int nn = n;
     if (a.C2 && n >= a.split) {
@@ -1210,7 +1217,17 @@ __global__ void __launch_bounds__(256, 2) k_cgemm(CgArgs a) {
     }
     __syncthreads();
   }
-  // epilogue: accumulator rows = GEMM rows m, lanes = 32 consecutive (frame, position) rows
+  // epilogue: accumulator rows = GEMM rows m, lanes = 32 consecutive (frame, position) rows.  The bias values of the rows a
+  // lane stores are fetched BEFORE the first store (a load between stores orders the later ones behind its round trip)
+  float bvc[MT][16];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int m = m0 + wm * MT * 32 + i * 32 + acc_row(reg, lane);
+      const int ch = m % a.mdiv;
+      bvc[i][reg] = (a.bias && m < a.M && ch < a.C) ? a.bias[ch] : 0.f;
+    }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn * 64 + j * 32 + l31;
@@ -1226,7 +1243,7 @@ __global__ void __launch_bounds__(256, 2) k_cgemm(CgArgs a) {
         if (m >= a.M) continue;
         const int pim = m / a.mdiv, ch = m - pim * a.mdiv;
         const int pos = pbase + pim * a.o0s;
-        if (ch < a.C && pos >= 0 && pos < a.OH) ob[(int64_t)ch * a.om + pos] = acc[i][j][reg] + (a.bias ? a.bias[ch] : 0.f);
+        if (ch < a.C && pos >= 0 && pos < a.OH) ob[(int64_t)ch * a.om + pos] = acc[i][j][reg] + bvc[i][reg];
       }
   }
 }
