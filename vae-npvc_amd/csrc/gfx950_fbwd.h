@@ -38,16 +38,22 @@ constexpr int fb_gsite(int l) { return l == FB_D2 ? CV_D2G : l == FB_D1 ? CV_D1G
 constexpr int fb_wsite(int l) { return l == FB_D2 ? CW_D2 : l == FB_D1 ? CW_D1 : CW_E1; }
 // channel groups of the LayerNorm-backward items (a lane walks C / groups = 8 channels of its position)
 constexpr int fb_cgr(int l) { return l == FB_D2 ? 1 : l == FB_D1 ? 2 : 4; }
-// register prefetch of the next frame during the GEMMs (fits where a wave stages few values)
-#ifndef VAENPVC_FB_PREFETCH
-#define VAENPVC_FB_PREFETCH 0x6   // bit = FB_* layer
+// register prefetch of the next frame during the GEMMs, per layer: 3 = everything (dy, a, the input activation), 2 = the pre-LN
+// tensor a only, 1 = dy only (decoder layer 2: all of it does not fit 256 registers; its halves fit and change nothing: 514 - 526 us
+// with none / dy / a prefetched, same box), 0 = nothing
+#ifndef VAENPVC_FB_PFW
+#define VAENPVC_FB_PFW 0x330   // hex digit l = what layer FB_* l prefetches
 #endif
-constexpr bool fb_prefetch(int l) { return (VAENPVC_FB_PREFETCH >> l) & 1; }
+constexpr int fb_pfw(int l) { return (VAENPVC_FB_PFW >> (4 * l)) & 0xf; }
 
+#ifndef VAENPVC_FB_ABL
+#define VAENPVC_FB_ABL 0   // developer ablation (wrong results): 1 no input-gradient GEMM, 2 no weight-gradient GEMM, 4 no result stores, 8 no global loads
+#endif
 constexpr int fb_max(int a, int b) { return a > b ? a : b; }
 template <int NPL, int L>
 struct FbCfg {
-  static constexpr bool ENC = fb_enc(L), PREFETCH = fb_prefetch(L);
+  static constexpr bool ENC = fb_enc(L);
+  static constexpr int PFW = fb_pfw(L);
   static constexpr CvSite V = CVS[fb_gsite(L)];
   static constexpr CwSite WS = CWS[fb_wsite(L)];
   // G: gradient at this layer's pre-LN output (du); X: its activated input
@@ -120,9 +126,13 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
 #pragma unroll
   for (int c = 0; c < CUG; ++c) su[c] = sw[c] = sd[c] = 0.f;
 
-  auto uload = [&](int f) __attribute__((always_inline)) {
-    mean = a.st[2 * f];
-    rstd = a.st[2 * f + 1];
+  // WHICH: bit 0 = the gradient dy, bit 1 = the pre-LN tensor a (+ the frame's statistics)
+  auto uload = [&](int f, auto which_) __attribute__((always_inline)) {
+    constexpr int WHICH = decltype(which_)::value;
+    if constexpr ((WHICH & 2) != 0) {
+      mean = a.st[2 * f];
+      rstd = a.st[2 * f + 1];
+    }
 #pragma unroll
     for (int u = 0; u < IPWG; ++u) {
       const int it = wave + 4 * u, h = 64 * (it / CGR) + lane;
@@ -131,13 +141,13 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
       const int64_t fo = (int64_t)f * (T::CG * PG) + cg * CUG * PG + (ok ? h : 0);
 #pragma unroll
       for (int c = 0; c < CUG; ++c) {
-        vd[u][c] = act_ld<BFG>(a.dy, fo + c * PG);
-        va[u][c] = act_ld<BFG>(a.a, fo + c * PG);
+        if constexpr ((WHICH & 1) != 0) vd[u][c] = (VAENPVC_FB_ABL & 8) ? 0.5f : act_ld<BFG>(a.dy, fo + c * PG);
+        if constexpr ((WHICH & 2) != 0) va[u][c] = (VAENPVC_FB_ABL & 8) ? 0.25f : act_ld<BFG>(a.a, fo + c * PG);
       }
 #pragma unroll
       for (int c = 0; c < CUG; ++c) {
-        vd[u][c] = ok ? vd[u][c] : 0.f;
-        va[u][c] = ok ? va[u][c] : mean;
+        if constexpr ((WHICH & 1) != 0) vd[u][c] = ok ? vd[u][c] : 0.f;
+        if constexpr ((WHICH & 2) != 0) va[u][c] = ok ? va[u][c] : mean;
       }
     }
   };
@@ -200,9 +210,12 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
   };
 
   int f = blockIdx.x;
-  if (T::PREFETCH && f < a.F) {
-    uload(f);
-    sx.load(a.xa, a.xst, f, a.F, wave, lane);
+  using W3 = std::integral_constant<int, 3>;
+  using WPF = std::integral_constant<int, T::PFW>;          // what is prefetched during the GEMMs ...
+  using WTOP = std::integral_constant<int, 3 & ~T::PFW>;    // ... and what is loaded at the top of the iteration
+  if (T::PFW && f < a.F) {
+    uload(f, WPF{});
+    if (T::PFW == 3) sx.load(a.xa, a.xst, f, a.F, wave, lane);
   }
   {  // once per workgroup: zero both images (halo rows, rows past the tensor, tails stay zero), copy the input-gradient weights
     const u32x4 z = {0u, 0u, 0u, 0u};
@@ -240,8 +253,8 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
   constexpr int VPL = T::ENC ? T::XPL : T::GPL, PPL = T::ENC ? T::GPL : T::XPL;
   const int woff = l31 * T::WP + lh * 8;
   for (; f < a.F; f += gridDim.x) {
-    if (!T::PREFETCH) {   // (unconditional: the staging registers must be dead across the GEMMs, not loop-carried)
-      uload(f);
+    if (T::PFW != 3) {   // (unconditional: these staging registers must be dead across the GEMMs, not loop-carried)
+      if constexpr (T::PFW != 3) uload(f, WTOP{});
       sx.load(a.xa, a.xst, f, a.F, wave, lane);
     }
     upass1();
@@ -249,13 +262,13 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
     __syncthreads();   // the partial sums of every item are visible
     upass2();
     __syncthreads();   // both images are complete
-    if (T::PREFETCH && f + (int)gridDim.x < a.F) {
-      uload(f + gridDim.x);
-      sx.load(a.xa, a.xst, f + gridDim.x, a.F, wave, lane);
+    if (T::PFW && f + (int)gridDim.x < a.F) {
+      uload(f + gridDim.x, WPF{});
+      if (T::PFW == 3) sx.load(a.xa, a.xst, f + gridDim.x, a.F, wave, lane);
     }
     // ---- input gradient: GEMM rows q (32 per step), steps dealt round-robin to the waves
     constexpr int NSTEPS = cdiv(V.R, 32);
-    for (int s = wave; s < NSTEPS; s += 4) {
+    for (int s = wave; s < ((VAENPVC_FB_ABL & 1) ? 0 : NSTEPS); s += 4) {
       int q = s * 32 + l31;
       const bool nok = q < V.R;
       q = nok ? q : 0;
@@ -279,7 +292,7 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
 #pragma unroll
           for (int i = 0; i < T::MT; ++i) acc[i] = mfma_bf16(fa[i][PR::A[t]], fb[PR::B[t]], acc[i]);
       }
-      if (!nok) continue;
+      if (!nok || ((VAENPVC_FB_ABL & 4) && a.F > 0)) continue;
       float* ob = a.dx + (int64_t)f * (V.OC * V.OH);
       if constexpr (!T::ENC) {
 #pragma unroll
@@ -316,7 +329,7 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
     }
     // ---- weight gradient: k-chunks (16 rows j) of parity kpar
     constexpr int CPF = T::R16 / 16;
-    for (int kc = kpar; kc < CPF; kc += T::KSPLIT) {
+    for (int kc = kpar; kc < ((VAENPVC_FB_ABL & 2) ? 0 : CPF); kc += T::KSPLIT) {
       const int j0 = kc * 16 + trow;
       const unsigned short* pp0 = pimg + j0 * T::CPLN;
       const unsigned short* pv0 = vimg + (T::S * j0) * T::CPLV;
