@@ -548,12 +548,22 @@ __global__ void __launch_bounds__(256) k_ln_stats_act_planes(const float* __rest
   float* yf = y + (int64_t)f * (TB_C * TB_H);
   unsigned short* ypf = yp + (int64_t)f * (NPL * TB_C * TB_KP);
   float dot = 0.f;
+  // taps W[1024 - i][c] for i = 8*lane + j  =  Wc[c][8 + 1024 - 8*lane - j]: one ascending block per channel, reversed.  ALL
+  // channels' taps are fetched before the first plane store (a load between the stores would order the later stores behind
+  // its round trip: round 4)
+  packed4 wq[TB_C][2];
+#pragma unroll
+  for (int c = 0; c < TB_C; ++c) {
+    const float* wp = Wc + c * WROWC + 8 + 1017 - 8 * lane;
+    wq[c][0] = *reinterpret_cast<const packed4*>(wp);
+    wq[c][1] = *reinterpret_cast<const packed4*>(wp + 4);
+  }
+  float wlast = 0.f;
+  if (lane < TB_C) wlast = Wc[lane * WROWC + 8 + 512];
 #pragma unroll
   for (int c = 0; c < TB_C; ++c) {
     const float g = gamma[c], b = beta[c];
-    // taps W[1024 - i][c] for i = 8*lane + j  =  Wc[c][8 + 1024 - 8*lane - j]: one ascending block, reversed
-    const float* wp = Wc + c * WROWC + 8 + 1017 - 8 * lane;
-    packed4 w0 = *reinterpret_cast<const packed4*>(wp), w1 = *reinterpret_cast<const packed4*>(wp + 4);
+    const packed4 w0 = wq[c][0], w1 = wq[c][1];
     const float wr[8] = {w1.w, w1.z, w1.y, w1.x, w0.w, w0.z, w0.y, w0.x};
     float o[8];
     unsigned tm[8][NPL];
@@ -575,7 +585,7 @@ __global__ void __launch_bounds__(256) k_ln_stats_act_planes(const float* __rest
     const int c = lane;
     float o = lnact_v(vt, mean, rstd, gamma[c], beta[c]);
     yf[c * TB_H + 512] = o;
-    dot += o * Wc[c * WROWC + 8 + 512];
+    dot += o * wlast;
     unsigned tt[NPL];
     split_n<NPL>(o, tt);
     const u32x4 z = {0u, 0u, 0u, 0u};
