@@ -118,8 +118,15 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
   unsigned short* ws = xs + NPL * T::XPL;         // [NPL][MT * 32][WP]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
   const int cg = wave % CGR;                      // this wave's channel group in every item it owns
-  const float* gam = a.gamma + cg * CUG;
-  const float* bet = a.beta + cg * CUG;
+  // the LayerNorm parameters of this wave's 8 channels, once, as wave-uniform values (scalar registers): read through the
+  // pointers inside the frame loop the compiler re-fetched them with vector loads in every pass -- one exposed memory round
+  // trip per frame in the second pass
+  float gam[CUG], bet[CUG];
+#pragma unroll
+  for (int c = 0; c < CUG; ++c) {
+    gam[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.gamma[cg * CUG + c])));
+    bet[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.beta[cg * CUG + c])));
+  }
   float vd[IPWG][CUG], va[IPWG][CUG], mean = 0.f, rstd = 1.f;
   FwStage<NPL, T::CX, T::CX, T::CPLX, T::HX, 1, 0, T::ROW0X, T::XPL, BFX> sx;
   float su[CUG], sw[CUG], sd[CUG];
