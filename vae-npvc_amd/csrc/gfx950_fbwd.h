@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned short bsm[];
   __shared__ float part[2][FbCfg<NPL, L>::NITG];
   __shared__ float red[4][3 * FbCfg<NPL, L>::CUG];
+  __shared__ float lnx[2][FbCfg<NPL, L>::CX];   // LayerNorm parameters of the input activation (copied once)
   unsigned short* gs = bsm;                       // [NPL][GPL]  du, channel-last, zero halo rows
   unsigned short* xs = bsm + NPL * T::GPL;        // [NPL][XPL]  activated input
   unsigned short* ws = xs + NPL * T::XPL;         // [NPL][MT * 32][WP]
@@ -224,6 +225,10 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
     uload(f, WPF{});
     if (T::PFW == 3) sx.load(a.xa, a.xst, f, a.F, wave, lane);
   }
+  if (tid < T::CX) {
+    lnx[0][tid] = a.xgamma[tid];
+    lnx[1][tid] = a.xbeta[tid];
+  }
   {  // once per workgroup: zero both images (halo rows, rows past the tensor, tails stay zero), copy the input-gradient weights
     const u32x4 z = {0u, 0u, 0u, 0u};
     for (int i = tid; i < NPL * (T::GPL + T::XPL) / 8; i += 256) reinterpret_cast<u32x4*>(bsm)[i] = z;
@@ -265,7 +270,7 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
       sx.load(a.xa, a.xst, f, a.F, wave, lane);
     }
     upass1();
-    sx.store(xs, true, a.xgamma, a.xbeta, wave, lane);
+    sx.store(xs, true, lnx[0], lnx[1], wave, lane);
     __syncthreads();   // the partial sums of every item are visible
     upass2();
     __syncthreads();   // both images are complete

@@ -93,6 +93,9 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (FcCfg<NPL, SITE>::O
   constexpr CvSite V = T::V;
   extern __shared__ __attribute__((aligned(16))) unsigned short fsm[];
   __shared__ float part[2][FcCfg<NPL, SITE>::TF * cdiv(FcCfg<NPL, SITE>::H, 64)];   // per staging item: sum, sum of squared deviations
+  // LayerNorm parameters of the input, copied once: read through the argument pointers inside the group loop they were re-fetched
+  // with vector loads by every group, right behind the result stores (one exposed round trip per group; round 4)
+  __shared__ float lnp[2][FcCfg<NPL, SITE>::CP];
   unsigned short* xs = fsm;                       // [NPL][XPL]
   unsigned short* ws = fsm + NPL * T::XPL;        // [NPL][MT*32][WP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (FcCfg<NPL, SITE>::O
       if (!(it < NIT && g * T::TF + fl < a.F && h < T::H)) continue;
       if constexpr (LN != 0) {
 #pragma unroll
-        for (int c = 0; c < T::C; ++c) v[u][c] = lnact_v(v[u][c], mean[u], rstd[u], a.gamma[c], a.beta[c]);
+        for (int c = 0; c < T::C; ++c) v[u][c] = lnact_v(v[u][c], mean[u], rstd[u], lnp[0][c], lnp[1][c]);
       }
       unsigned short* dx = xs + fl * T::FS + (T::HLO + h) * T::CPL;
 #pragma unroll
@@ -194,6 +197,12 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (FcCfg<NPL, SITE>::O
   int g = blockIdx.x;
   if (g < ngroups) fload(g);
   // ---- once per workgroup: zero the frame tile (halo rows, channel padding, tail stay zero), copy the weights
+  if constexpr (LN != 0) {
+    if (tid < T::C) {
+      lnp[0][tid] = a.gamma[tid];
+      lnp[1][tid] = a.beta[tid];
+    }
+  }
   {
     const u32x4 z = {0u, 0u, 0u, 0u};
     for (int i = tid; i < NPL * T::XPL / 8; i += NTHR) reinterpret_cast<u32x4*>(xs)[i] = z;

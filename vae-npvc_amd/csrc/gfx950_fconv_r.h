@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
   constexpr CvSite V = T::V;
   extern __shared__ __attribute__((aligned(16))) unsigned short rsm[];
   unsigned short* xs = rsm;   // [NPL][XPL]
+  __shared__ float lnp[2][FrCfg<NPL, SITE>::C];   // LayerNorm parameters of the input (a fetch per group through the pointers otherwise)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int ngroups = cdiv(a.F, T::TF);
   // ---- staging registers (one group ahead, as k_fconv)
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
 #pragma unroll
         for (int cc = 0; cc < T::CG; ++cc) {
           const int c = cbase + cc;
-          if (c < T::C) v[u][cc] = lnact_v(v[u][cc], mean[u], rstd[u], a.gamma[c], a.beta[c]);
+          if (c < T::C) v[u][cc] = lnact_v(v[u][cc], mean[u], rstd[u], lnp[0][c], lnp[1][c]);
         }
       }
       unsigned short* dx = xs + fl * T::FS + (T::HLO + h) * T::CPL + cbase;
@@ -147,7 +148,11 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
   };
   int g = blockIdx.x;
   if (g < ngroups) fload(g);
-  // ---- once: zero the frame tile; this wave's weight tile into registers
+  // ---- once: zero the frame tile; this wave's weight tile into registers; the input's LayerNorm parameters into LDS
+  if (a.st && tid < T::C) {
+    lnp[0][tid] = a.gamma[tid];
+    lnp[1][tid] = a.beta[tid];
+  }
   {
     const u32x4 z = {0u, 0u, 0u, 0u};
     for (int i = tid; i < NPL * T::XPL / 8; i += 256) reinterpret_cast<u32x4*>(xs)[i] = z;

@@ -124,6 +124,16 @@ __global__ void __launch_bounds__(256, 2) k_fwgrad(FwArgs a) {
   const int ngroups = cdiv(a.F, T::TF);
   FwStage<NPL, T::CA, T::CPA, T::CPLA, T::HA, T::TF, T::FSA, 0, T::APL> sa;
   FwStage<NPL, T::CB, T::CPB, T::CPLB, T::HB, T::TF, T::FSB, T::PAD, T::BPL> sb;
+  // LayerNorm parameters of the activation operand, copied once (a fetch per group through the argument pointers otherwise)
+  __shared__ float lnpa[2][FwCfg<NPL, WSITE>::CPA], lnpb[2][FwCfg<NPL, WSITE>::CPB];
+  if (a.a_st && tid < T::CA) {
+    lnpa[0][tid] = a.a_gamma[tid];
+    lnpa[1][tid] = a.a_beta[tid];
+  }
+  if (a.b_st && tid < T::CB) {
+    lnpb[0][tid] = a.b_gamma[tid];
+    lnpb[1][tid] = a.b_beta[tid];
+  }
   int g = blockIdx.x;
   if (g < ngroups) {
     sa.load(a.a_src, a.a_st, g, a.F, wave, lane);
@@ -156,8 +166,8 @@ __global__ void __launch_bounds__(256, 2) k_fwgrad(FwArgs a) {
     acol[j] = m < T::CPA ? m : 0;
   }
   for (; g < ngroups; g += gridDim.x) {
-    sa.store(as, a.a_st != nullptr, a.a_gamma, a.a_beta, wave, lane);
-    sb.store(bs, a.b_st != nullptr, a.b_gamma, a.b_beta, wave, lane);
+    sa.store(as, a.a_st != nullptr, lnpa[0], lnpa[1], wave, lane);
+    sb.store(bs, a.b_st != nullptr, lnpb[0], lnpb[1], wave, lane);
     __syncthreads();   // the group's frames are in LDS
     if (g + (int)gridDim.x < ngroups) {
       sa.load(a.a_src, a.a_st, g + gridDim.x, a.F, wave, lane);
