@@ -280,7 +280,10 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
     }
     // ---- input gradient: GEMM rows q (32 per step), steps dealt round-robin to the waves
     constexpr int NSTEPS = cdiv(V.R, 32);
-    for (int s = wave; s < ((VAENPVC_FB_ABL & 1) ? 0 : NSTEPS); s += 4) {
+    // (decoder layer 2, whose weight-gradient k-chunks are split over wave pairs: steps dealt from the LAST wave down, so the waves with
+    //  one chunk more get one step less, 463 -> 452 us; the layers with two steps keep them on the first waves: the other order cost
+    //  them 40 - 60 us, same-box A/B)
+    for (int s = (T::KSPLIT > 1 ? 3 - wave : wave); s < ((VAENPVC_FB_ABL & 1) ? 0 : NSTEPS); s += 4) {
       int q = s * 32 + l31;
       const bool nok = q < V.R;
       q = nok ? q : 0;
