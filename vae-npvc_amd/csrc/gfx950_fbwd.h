@@ -49,11 +49,17 @@ constexpr int fb_pfw(int l) { return (VAENPVC_FB_PFW >> (4 * l)) & 0xf; }
 #ifndef VAENPVC_FB_ABL
 #define VAENPVC_FB_ABL 0   // developer ablation (wrong results): 1 no input-gradient GEMM, 2 no weight-gradient GEMM, 4 no result stores, 8 no global loads
 #endif
+// which wave stages the input-activation items (item i goes to wave (i - rot) & 3): away from the waves that carry the most
+// LayerNorm items and input-gradient steps
+#ifndef VAENPVC_FB_XROT
+#define VAENPVC_FB_XROT 0x313   // hex digit l = rotation of layer FB_* l
+#endif
+constexpr int fb_xrot(int l) { return (VAENPVC_FB_XROT >> (4 * l)) & 3; }
 constexpr int fb_max(int a, int b) { return a > b ? a : b; }
 template <int NPL, int L>
 struct FbCfg {
   static constexpr bool ENC = fb_enc(L);
-  static constexpr int PFW = fb_pfw(L);
+  static constexpr int PFW = fb_pfw(L), XROT = fb_xrot(L);
   static constexpr CvSite V = CVS[fb_gsite(L)];
   static constexpr CwSite WS = CWS[fb_wsite(L)];
   // G: gradient at this layer's pre-LN output (du); X: its activated input
@@ -119,6 +125,7 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
   unsigned short* ws = xs + NPL * T::XPL;         // [NPL][MT * 32][WP]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
   const int cg = wave % CGR;                      // this wave's channel group in every item it owns
+  const int xwave = (wave + T::XROT) & 3;         // its index for the input-activation items
   // the LayerNorm parameters of this wave's 8 channels, once, as wave-uniform values (scalar registers): read through the
   // pointers inside the frame loop the compiler re-fetched them with vector loads in every pass -- one exposed memory round
   // trip per frame in the second pass
@@ -223,7 +230,7 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
   using WTOP = std::integral_constant<int, 3 & ~T::PFW>;    // ... and what is loaded at the top of the iteration
   if (T::PFW && f < a.F) {
     uload(f, WPF{});
-    if (T::PFW == 3) sx.load(a.xa, a.xst, f, a.F, wave, lane);
+    if (T::PFW == 3) sx.load(a.xa, a.xst, f, a.F, xwave, lane);
   }
   if (tid < T::CX) {
     lnx[0][tid] = a.xgamma[tid];
@@ -267,16 +274,16 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
   for (; f < a.F; f += gridDim.x) {
     if (T::PFW != 3) {   // (unconditional: these staging registers must be dead across the GEMMs, not loop-carried)
       if constexpr (T::PFW != 3) uload(f, WTOP{});
-      sx.load(a.xa, a.xst, f, a.F, wave, lane);
+      sx.load(a.xa, a.xst, f, a.F, xwave, lane);
     }
     upass1();
-    sx.store(xs, true, lnx[0], lnx[1], wave, lane);
+    sx.store(xs, true, lnx[0], lnx[1], xwave, lane);
     __syncthreads();   // the partial sums of every item are visible
     upass2();
     __syncthreads();   // both images are complete
     if (T::PFW && f + (int)gridDim.x < a.F) {
       uload(f + gridDim.x, WPF{});
-      if (T::PFW == 3) sx.load(a.xa, a.xst, f + gridDim.x, a.F, wave, lane);
+      if (T::PFW == 3) sx.load(a.xa, a.xst, f + gridDim.x, a.F, xwave, lane);
     }
     // ---- input gradient: GEMM rows q (32 per step), steps dealt round-robin to the waves
     constexpr int NSTEPS = cdiv(V.R, 32);
