@@ -370,3 +370,34 @@ def test_index_ahead_same_stream_and_restore():
     ib.load_state_dict({'shuffler': mk(5).state_dict()})
     got, _ = draw(ib, 3)
     assert all(np.array_equal(w, g) for w, g in zip(want, got))
+
+
+def test_bench_site_groups_cover_every_tagged_launch_site():
+    """bench.py's roofline.sites adds up kernel GROUPS timed through the library's site tags: every tag of every group must be
+    a tag the library really uses (a string literal in csrc/), every tag of scripts/site_times.py must belong to exactly one
+    group, and no tag may sit in two groups -- otherwise a new kernel silently drops out of (or is counted twice in) the sum
+    the bench line reports."""
+    import importlib.util
+    import re
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    groups = {name: g['tags'].split() for name, g in bench.SITE_GROUPS.items()}
+    flat = [t for tags in groups.values() for t in tags]
+    assert len(flat) == len(set(flat)), 'a site tag sits in two groups: %s' % sorted(t for t in set(flat) if flat.count(t) > 1)
+    src = ''
+    csrc = os.path.join(ROOT, 'vae-npvc_amd', 'csrc')
+    for fn in os.listdir(csrc):
+        if fn.endswith(('.hip', '.h')):
+            src += open(os.path.join(csrc, fn)).read()
+    literals = set(re.findall(r'"([a-z0-9_]+)"', src))
+    missing = [t for t in flat if t not in literals]
+    assert not missing, 'tags unknown to the library: %s' % missing
+    st = open(os.path.join(ROOT, 'scripts', 'site_times.py')).read()
+    listed = set(re.search(r"TAGS = \((.*?)\)\.split\(\)", st, re.S).group(1).replace("'", ' ').split())
+    assert listed == set(flat), (sorted(listed - set(flat)), sorted(set(flat) - listed))
+    # ... and every tag the layered path's launch code passes to VAENPVC_TIMED is listed
+    used = set(re.findall(r'VAENPVC_TIMED\("([a-z0-9_]+)"', src))
+    small_batch = {t for t in used if t.startswith('frame_')}       # the small-batch frame kernels (not part of the layered step)
+    assert used - small_batch <= set(flat), sorted(used - small_batch - set(flat))
