@@ -47,7 +47,7 @@ constexpr int fb_cgr(int l) { return l == FB_D2 ? 1 : l == FB_D1 ? 2 : 4; }
 constexpr int fb_pfw(int l) { return (VAENPVC_FB_PFW >> (4 * l)) & 0xf; }
 
 #ifndef VAENPVC_FB_ABL
-#define VAENPVC_FB_ABL 0   // developer ablation (wrong results): 1 no input-gradient GEMM, 2 no weight-gradient GEMM, 4 no result stores, 8 no global loads
+#define VAENPVC_FB_ABL 0   // developer ablation (wrong results): 1 no input-gradient GEMM, 2 no weight-gradient GEMM, 4 no result stores, 8 no global loads, 16 no flush of the weight-gradient tile / channel sums
 #endif
 // which wave stages the input-activation items (item i goes to wave (i - rot) & 3): away from the waves that carry the most
 // LayerNorm items and input-gradient steps
@@ -376,6 +376,7 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
     }
     __syncthreads();   // all fragment reads of this frame are done before the next one overwrites the images
   }
+  if ((VAENPVC_FB_ABL & 16) && a.F > 0) return;
   // ---- flush: the weight-gradient tile (rows n = (tap, channel of the view operand), lanes m: consecutive addresses of dW[n][m]) ...
 #pragma unroll
   for (int i = 0; i < T::NTW; ++i)

@@ -27,6 +27,9 @@
 #include "gfx950_fwgrad.h"
 #include "gfx950_fconv_r.h"
 #include "gfx950_fbwd.h"
+#ifndef VAENPVC_SPLIT_SEGSUM
+#define VAENPVC_SPLIT_SEGSUM 1
+#endif
 #include "kernels.h"
 
 namespace vaenpvc {
@@ -1087,8 +1090,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     if (pgm) {
       for_dense_planes([&](auto npl) {
         constexpr int NPL = decltype(npl)::value;
+        if (VAENPVC_SPLIT_SEGSUM && F >= 64) {   // the planes of d(h) and the per-speaker column sums S in one pass over d(h)
+        // (the chunk partials go to dy_tmp: the decoder's backward pass, its only user on this path, is behind us on this stream)
+        int nch = 0;
+        VAENPVC_TIMED("merge_dsplit", s, (nch = launch_split_segsum<NPL, MERGE_NY>(w.d_h, y, 1539, 1600, F, us(w.pl_dh), w.dy_tmp, s)));
+        VAENPVC_TIMED("merge_segsum", s, launch_sum_parts(w.dy_tmp, nch, MERGE_NY * 1539, w.scratch + Pk::merge_s, s));
+        } else {
         SplitArgs sa = split_args(w.d_h, 1539, 1600, F, us(w.pl_dh));
         VAENPVC_TIMED("merge_dsplit", s, launch_split<NPL>(sa, s));
+        }
         ready();
         TnpArgs t = tnp_args(w.pl_z, 128, w.pl_dh, 1600, 128, 1539, F, G + m.wz_off, 1539);
         t.tn4 = bwd_on(16);
@@ -1101,10 +1111,12 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     }
     // S[k] = per-speaker column sums of d(h); the bias gradients, dWy = E^T S and dE = S Wy^T follow from it
     float* Sg = w.scratch + Pk::merge_s;
-    (void)hipMemsetAsync(Sg, 0, (size_t)MERGE_NY * 1539 * 4, s);
-    int ch = cmax(1, cmin_(cdiv(F, 64), 128)), fc = cdiv(F, ch);
-    VAENPVC_TIMED("merge_segsum", s, hipLaunchKernelGGL(k_segsum_atomic<MERGE_NY>, dim3((unsigned)cdiv(1539, 256), (unsigned)cdiv(F, fc)), dim3(256), 0, s,
-                                                        w.d_h, y, 1539, F, fc, Sg));
+    if (!(pgm && VAENPVC_SPLIT_SEGSUM && F >= 64)) {
+      (void)hipMemsetAsync(Sg, 0, (size_t)MERGE_NY * 1539 * 4, s);
+      int ch = cmax(1, cmin_(cdiv(F, 64), 128)), fc = cdiv(F, ch);
+      VAENPVC_TIMED("merge_segsum", s, hipLaunchKernelGGL(k_segsum_atomic<MERGE_NY>, dim3((unsigned)cdiv(1539, 256), (unsigned)cdiv(F, fc)), dim3(256), 0, s,
+                                                          w.d_h, y, 1539, F, fc, Sg));
+    }
     const int nb_w = cdiv(128 * 1539, 256), nb_e = cdiv(MERGE_NY * 128, 4), nb_b = cdiv(1539, 256);
     VAENPVC_TIMED("merge_small", s, hipLaunchKernelGGL(k_merge_small<MERGE_NY>, dim3((unsigned)(nb_w + nb_e + nb_b)), dim3(256), 0, s, Sg, P + m.emb_off, P + m.wy_off, 128,
                        1539, G + m.wy_off, G + m.emb_off, G + m.bz_off, G + m.by_off, G + m.bm_off, nb_w, nb_e));

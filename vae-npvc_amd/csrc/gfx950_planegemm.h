@@ -159,6 +159,122 @@ inline void launch_split(const SplitArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((k_split_planes<NPL, false>), dim3(blocks), dim3(256), 0, s, a);
 }
 
+// merge backward: the planes of d(h) (what k_split_planes writes) AND the per-speaker column sums S[y_f][n] += d(h)[f][n]
+// (what k_segsum_atomic adds, models/vae.py merge: the bias / embedding gradients derive from S) in ONE pass over d(h).
+// grid (ceil(Kp/512), frame chunks), 4 waves: a lane owns 8 consecutive columns, a wave a quarter of the chunk's frames
+// (the speaker of a frame is wave-uniform: NY x 8 register partials behind a uniform switch); the four waves meet in an LDS
+// image of S's slab, flushed with one atomic per nonzero entry.
+#ifndef VAENPVC_SS_CHUNKS
+#define VAENPVC_SS_CHUNKS 128
+#endif
+#ifndef VAENPVC_SS_FIF
+#define VAENPVC_SS_FIF 4   // frames in flight per wave
+#endif
+template <int NPL, int NY>
+__global__ void __launch_bounds__(256) k_split_segsum(const float* __restrict__ d, const int64_t* __restrict__ y, int N, int Kp, int F,
+                                                      int fchunk, unsigned short* __restrict__ dst, float* __restrict__ parts) {
+  __shared__ float red[NY * 8 * 64];   // [k][j][lane]: conflict-free for the owners, read transposed by the flush
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k0 = blockIdx.x * 512 + lane * 8;
+  const int fq = fchunk >> 2;
+  const int fb = blockIdx.y * fchunk + wave * fq, fe = min(F, fb + fq);
+  float acc[NY][8];
+#pragma unroll
+  for (int k = 0; k < NY; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+  if (k0 < Kp) {
+    const bool full = k0 + 8 <= N;
+    constexpr int FIF = VAENPVC_SS_FIF;
+    for (int f0 = fb; f0 < fe; f0 += FIF) {
+      float v[FIF][8];
+      int yk[FIF];
+#pragma unroll
+      for (int u = 0; u < FIF; ++u) {
+        const int f = f0 + u < fe ? f0 + u : fe - 1;
+        const float* p = d + (int64_t)f * N + k0;
+        if (full) {
+          packed4 p0 = *reinterpret_cast<const packed4*>(p), p1 = *reinterpret_cast<const packed4*>(p + 4);
+          v[u][0] = p0.x; v[u][1] = p0.y; v[u][2] = p0.z; v[u][3] = p0.w; v[u][4] = p1.x; v[u][5] = p1.y; v[u][6] = p1.z; v[u][7] = p1.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[u][j] = k0 + j < N ? p[j] : 0.f;
+        }
+        const int64_t yy = y[f];
+        yk[u] = (int)(yy < 0 ? 0 : (yy >= NY ? NY - 1 : yy));   // ids are clamped (vaenpvc_validate_ids reports them)
+      }
+#pragma unroll
+      for (int u = 0; u < FIF; ++u) {
+        if (f0 + u >= fe) break;
+        const int ku = __builtin_amdgcn_readfirstlane(yk[u]);
+#pragma unroll
+        for (int k = 0; k < NY; ++k)
+          if (ku == k) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[k][j] += v[u][j];
+          }
+        u32x4 pk[NPL];
+        pack8<NPL>(v[u], pk);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+          st_nt<VAENPVC_NT_B>(reinterpret_cast<u32x4*>(dst + ((int64_t)p * F + (f0 + u)) * Kp + k0), pk[p]);
+      }
+    }
+  }
+  // the four waves meet in LDS one after the other (plain read-modify-write: LDS atomics cost ~150 cycles per wave op)
+#pragma unroll 1
+  for (int w4 = 0; w4 < 4; ++w4) {
+    if (wave == w4) {
+#pragma unroll
+      for (int k = 0; k < NY; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float* r = &red[(k * 8 + j) * 64 + lane];
+          *r = w4 == 0 ? acc[k][j] : *r + acc[k][j];
+        }
+    }
+    __syncthreads();
+  }
+  // (plain stores of the chunk's partial image: device-scope atomics on one address serialise at the memory side)
+  float* part = parts + (int64_t)blockIdx.y * NY * N;
+  for (int i = threadIdx.x; i < NY * 512; i += 256) {
+    const int k = i >> 9, c = i & 511, n = blockIdx.x * 512 + c;
+    if (n < N) part[k * N + n] = red[(k * 8 + (c & 7)) * 64 + (c >> 3)];
+  }
+}
+// out[i] = sum over c of part[c][i] (fixed order: repeatable), 64 columns per workgroup, sixteen waves deal the parts (all of a
+// wave's loads in flight together: with four waves the 32-deep load chain per wave cost more than the bytes)
+__global__ void __launch_bounds__(1024) k_sum_parts(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (i < n) {
+#pragma unroll 8
+    for (int c = wave; c < nparts; c += 16) acc += part[(int64_t)c * n + i];
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][lane];
+    out[i] = t;
+  }
+}
+// parts: scratch of (frame chunks) x NY x N floats; returns the number of chunks (<= max(1, min(F/64, VAENPVC_SS_CHUNKS)))
+template <int NPL, int NY>
+inline int launch_split_segsum(const float* d, const int64_t* y, int N, int Kp, int64_t F, unsigned short* dst, float* parts, hipStream_t s) {
+  const int ch = cmax(1, cmin_(cdiv((int)F, 64), VAENPVC_SS_CHUNKS));
+  const int fc = 4 * cdiv(cdiv((int)F, ch), 4);
+  const int nch = cdiv((int)F, fc);
+  hipLaunchKernelGGL((k_split_segsum<NPL, NY>), dim3((unsigned)cdiv(Kp, 512), (unsigned)nch), dim3(256), 0, s, d, y, N, Kp, (int)F, fc, dst, parts);
+  return nch;
+}
+inline void launch_sum_parts(const float* parts, int nch, int n, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, s, parts, nch, n, out);
+}
+
 static inline SplitArgs split_args(const float* src, int K, int Kp, int64_t rows, unsigned short* dst) {
   SplitArgs a;
   a.src = src;
