@@ -27,6 +27,10 @@
 #include "gfx950_fwgrad.h"
 #include "gfx950_fconv_r.h"
 #include "gfx950_fbwd.h"
+#include "gfx950_lnb_planes.h"
+#ifndef VAENPVC_LNB_PLANES
+#define VAENPVC_LNB_PLANES 7   // LayerNorm backward writing its consumers' operand planes itself: 1 encoder layer 4, 2 encoder layer 3, 4 decoder layer 0
+#endif
 #ifndef VAENPVC_SPLIT_SEGSUM
 #define VAENPVC_SPLIT_SEGSUM 1
 #endif
@@ -1032,13 +1036,28 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     }
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 2);
 
+  // LayerNorm backward of decoder layer 0; with the view weight gradient behind it, the channel-last planes that kernel reads
+  // leave the same pass (gfx950_lnb_planes.h) and the split pass over d(a0) goes away
+  const bool gd0_planes = (VAENPVC_LNB_PLANES & 4) && !lnq && F >= 1024 && bwd_on(7) && bwd_on(8) && cw_bwd(CW_D0, F);
+  auto lnb_dec0 = [&](const float* dy0) {
+    const ConvL& pl = m.dec[0];
+    if (gd0_planes)
+      for_dense_planes([&](auto npl) {
+        constexpr int NPL = decltype(npl)::value;
+        VAENPVC_TIMED("lnb_dec0", s, (launch_ln_bwd_planes<LnbCfg<32, 57>, NPL, CL_GD0, true>(dy0, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off,
+                                         w.d_dec_a[0], us(w.cl[CL_GD0]), cl_plane(CL_GD0, F), G + pl.gamma_off, G + pl.beta_off, G + pl.b_off,
+                                         w.scratch + Pk::lnpart, F, LWGS, s)));
+      });
+    else
+      VAENPVC_TIMED("lnb_dec0", s, launch_ln_bwd<LnbCfg<32, 57>>(dy0, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[0],
+                                       G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
+  };
   // ---- d1
   if (bwd_on(8) && bwd_on(9) && fb_bwd(FB_D1, F)) {
     const ConvL& pl = m.dec[0];
     float* dy0 = dy_cur == w.dy_tmp ? w.d_dec_a[1] : w.dy_tmp;
     fused_bwd(FB_D1, 1, dy_cur, dy0, "dec1_bwd");
-    VAENPVC_TIMED("lnb_dec0", s, launch_ln_bwd<LnbCfg<32, 57>>(dy0, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[0],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
+    lnb_dec0(dy0);
     dec_bias_done[0] = true;
   } else if (bwd_on(8)) {
     const ConvL &l = m.dec[1], &pl = m.dec[0];
@@ -1057,8 +1076,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     else
     VAENPVC_TIMED("dec1_dgrad", s, launch_convgemm<GD1>(conv_args(w.d_dec_a[1], nullptr, nullptr, nullptr, P + l.w_off, nullptr,
                                                                   w.dy_tmp, F), nsplit_for<GD1>(F), s));
-    VAENPVC_TIMED("lnb_dec0", s, launch_ln_bwd<LnbCfg<32, 57>>(w.dy_tmp, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off, w.d_dec_a[0],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
+    lnb_dec0(w.dy_tmp);
     dec_bias_done[0] = true;
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 1);
 
@@ -1067,7 +1085,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const ConvL& l = m.dec[0];
     WgArgs a{w.d_dec_a[0], nullptr, nullptr, nullptr, w.h, nullptr, nullptr, nullptr, G + l.w_off, F, 0};
     const bool rg = fcr_bwd(CV_D0G, F), vg = !rg && cv_bwd(CV_D0G, F), vw = cw_bwd(CW_D0, F);
-    if (vg || vw) gsplit(CL_GD0, w.d_dec_a[0], "dec0_gsplit");
+    if ((vg || vw) && !gd0_planes) gsplit(CL_GD0, w.d_dec_a[0], "dec0_gsplit");
     if (vw && !fwd_planes(7, CV_D0F, F)) asplit(CL_H, w.h, nullptr, nullptr, "dec0_asplit");
     ready();
     if (vw) vwgrad(CW_D0, G + l.w_off, "dec0_wgrad");
@@ -1145,6 +1163,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   } else generic::bwd_reparam(m, eps, F, w, s);
 
   // ---- heads
+  const bool da4_planes = (VAENPVC_LNB_PLANES & 1) && !lnq && F >= 1024 && bwd_on(5) && pg_bwd(F) && pg_fwd(F) && fwd_on(5) && bwd_on(4) && fwd_on(4);
+  const bool ge3_planes = (VAENPVC_LNB_PLANES & 2) && !lnq && F >= 1024 && bwd_on(3) && bwd_on(4) && cv_bwd(CV_E3G, F) && cw_bwd(CW_E3, F);
   if (bwd_on(5) && pg_bwd(F) && pg_fwd(F) && fwd_on(5)) {
     const ConvL& l4 = m.enc[4];
     for_dense_planes([&](auto npl) {
@@ -1164,6 +1184,14 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       NtArgs a = nt_args(w.pl_dz, F, 256, w.scratch + Pk::pg_headsb, 768, 768, w.dy_tmp, 768);
       VAENPVC_TIMED("heads_dgrad", s, launch_gemm_nt<NPL>(a, s));
     });
+    if (da4_planes)   // d(a4) leaves as the planes the two dense-shaped GEMMs of layer 4 read; no fp32 copy, no split pass
+      for_dense_planes([&](auto npl) {
+        constexpr int NPL = decltype(npl)::value;
+        VAENPVC_TIMED("lnb_enc4", s, (launch_ln_bwd_planes<LnbCfg<256, 3>, NPL, -1, false>(w.dy_tmp, w.enc_a[4], w.enc_st[4], P + l4.gamma_off, P + l4.beta_off,
+                                         w.d_enc_a[4], us(w.pl_da4), (int64_t)F * 768, G + l4.gamma_off, G + l4.beta_off, G + l4.b_off,
+                                         w.scratch + Pk::lnpart, F, LWGS, s)));
+      });
+    else
     VAENPVC_TIMED("lnb_enc4", s, launch_ln_bwd<LnbCfg<256, 3>>(w.dy_tmp, w.enc_a[4], w.enc_st[4], P + l4.gamma_off, P + l4.beta_off, w.d_enc_a[4],
                                      G + l4.gamma_off, G + l4.beta_off, G + l4.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
     enc_bias_done[4] = true;
@@ -1199,12 +1227,25 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     return WgArgs{w.enc_a[i - 1], w.enc_st[i - 1], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[i], nullptr, nullptr, nullptr,
                   G + l.w_off, F, 0};
   };
+  auto lnb_enc3 = [&]() {   // (with both view GEMMs of layer 3 behind it: straight to their channel-last planes, no fp32 copy)
+    const ConvL& pl = m.enc[3];
+    if (ge3_planes)
+      for_dense_planes([&](auto npl) {
+        constexpr int NPL = decltype(npl)::value;
+        VAENPVC_TIMED("lnb_enc3", s, (launch_ln_bwd_planes<LnbCfg<128, 7>, NPL, CL_GE3, false>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off,
+                                         w.d_enc_a[3], us(w.cl[CL_GE3]), cl_plane(CL_GE3, F), G + pl.gamma_off, G + pl.beta_off, G + pl.b_off,
+                                         w.scratch + Pk::lnpart, F, LWGS, s)));
+      });
+    else
+      VAENPVC_TIMED("lnb_enc3", s, launch_ln_bwd<LnbCfg<128, 7>>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[3],
+                                       G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
+  };
   if (bwd_on(4) && pg_bwd(F) && pg_fwd(F) && fwd_on(4)) {
     // layer 4 as a dense layer: dW from [F,896]^T x [F,768] folded back onto the 7 taps, d(y3) = d(a4) x Wd
     const ConvL &l = m.enc[4], &pl = m.enc[3];
     for_dense_planes([&](auto npl) {
       constexpr int NPL = decltype(npl)::value;
-      VAENPVC_TIMED("enc4_dsplit", s, launch_split<NPL>(split_args(w.d_enc_a[4], 768, 768, F, us(w.pl_da4)), s));
+      if (!da4_planes) VAENPVC_TIMED("enc4_dsplit", s, launch_split<NPL>(split_args(w.d_enc_a[4], 768, 768, F, us(w.pl_da4)), s));
       ready();
       TnpArgs t = tnp_args(w.pl_y3, 896, w.pl_da4, 768, 896, 768, F, G + l.w_off, 0);
       t.tn4 = bwd_on(16);
@@ -1213,8 +1254,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       VAENPVC_TIMED("enc4_dgrad", s, launch_gemm_nt<NPL>(a, s));
     });
     if (!enc_bias_done[4]) generic::bias_grad(w.d_enc_a[4], G + l.b_off, F, l.cout, l.hout, s);
-    VAENPVC_TIMED("lnb_enc3", s, launch_ln_bwd<LnbCfg<128, 7>>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[3],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
+    lnb_enc3();
     enc_bias_done[3] = true;
   } else if (bwd_on(4)) {
     const ConvL &l = m.enc[4], &pl = m.enc[3];
@@ -1223,14 +1263,13 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     if (!enc_bias_done[4]) generic::bias_grad(w.d_enc_a[4], G + l.b_off, F, l.cout, l.hout, s);
     VAENPVC_TIMED("enc4_dgrad", s, launch_convgemm<GE4>(conv_args(w.d_enc_a[4], nullptr, nullptr, nullptr, w.scratch + Pk::ge4,
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE4>(F), s));
-    VAENPVC_TIMED("lnb_enc3", s, launch_ln_bwd<LnbCfg<128, 7>>(w.dy_tmp, w.enc_a[3], w.enc_st[3], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[3],
-                                     G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
+    lnb_enc3();
     enc_bias_done[3] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 4);
   if (bwd_on(3)) {
     const ConvL &l = m.enc[3], &pl = m.enc[2];
     const bool vg = cv_bwd(CV_E3G, F), vw = cw_bwd(CW_E3, F);
-    if (vg || vw) gsplit(CL_GE3, w.d_enc_a[3], "enc3_gsplit");
+    if ((vg || vw) && !ge3_planes) gsplit(CL_GE3, w.d_enc_a[3], "enc3_gsplit");
     if (vw && !fwd_planes(3, CV_E3F, F)) asplit(CL_Y2, w.enc_a[2], w.enc_st[2], &pl, "enc3_asplit");
     ready();
     if (vw) vwgrad(CW_E3, G + l.w_off, "enc3_wgrad");
