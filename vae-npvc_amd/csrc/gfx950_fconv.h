@@ -77,6 +77,10 @@ struct FcArgs {
   float* out;           // [F][OC][OH]
   int F;
   bool bf_in = false, bf_out = false;   // bf16 activation storage of the input / output tensor (precision "bf16", decoder layers 1 - 2)
+  // k_fconv_r, decoder layer 0 forward: non-null = the staged bf16 terms of the input ALSO leave as its channel-last planes
+  // ([NPL][cl_plane], frames of [HP][CP], cl_layout.h) -- the operand the layer's weight-gradient GEMM reads in the backward pass
+  unsigned short* cl_out = nullptr;
+  int64_t cl_plane = 0;
 };
 
 template <int CP, int CPL>

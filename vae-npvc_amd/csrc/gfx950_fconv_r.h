@@ -80,7 +80,7 @@ static PackViewPermJob<NPL> fcr_perm_job(int site, const float* W, int s_t, int 
                               reinterpret_cast<unsigned short*>(dst), mp, v.Kp, mp * v.Kp / 8};
 }
 
-template <int NPL, int SITE, int LN>
+template <int NPL, int SITE, int LN, bool CLO = false>
 __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
   using T = FrCfg<NPL, SITE>;
   constexpr CvSite V = T::V;
@@ -157,6 +157,14 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
     const u32x4 z = {0u, 0u, 0u, 0u};
     for (int i = tid; i < NPL * T::XPL / 8; i += 256) reinterpret_cast<u32x4*>(xs)[i] = z;
   }
+  if constexpr (CLO) {
+    if (blockIdx.x == 0) {   // zero tails behind the planes (as k_cl_produce)
+      const int64_t used = (int64_t)a.F * T::HP * T::CP;
+      for (int64_t i = used + tid; i < a.cl_plane; i += 256)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) a.cl_out[p * a.cl_plane + i] = 0;
+    }
+  }
   const int tile = wave % T::MTR, sub = wave / T::MTR;      // (3 tiles: wave 3 -> tile 0, sub 1: no steps)
   const bool gemm_wave = sub < T::WPT;
   u32x4 wreg[T::KS][NPL];
@@ -178,6 +186,17 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
     const int f0 = g * T::TF, nf = min(T::TF, a.F - f0);
     fstore(g);
     __syncthreads();
+    if constexpr (CLO) {
+      // the staged image (bf16 terms, channel-last, zero halo rows) is exactly the group's frames of the planes: copied out as
+      // consecutive 16-byte pieces (direct stores from the staging registers -- 16 bytes at a 176-byte stride per lane -- cost
+      // as much as the separate split pass they replaced: 217 -> 314 us, same-box)
+      constexpr int G8 = T::CP / 8, PPF = T::HP * G8;
+      for (int i = tid; i < nf * NPL * PPF; i += 256) {
+        const int fl = i / (NPL * PPF), r = i - fl * (NPL * PPF), p = r / PPF, q = r - p * PPF, hp = q / G8, g8 = q - hp * G8;
+        const u32x4 vv = *reinterpret_cast<const u32x4*>(xs + p * T::XPL + fl * T::FS + hp * T::CPL + 8 * g8);
+        st_nt<VAENPVC_NT_B>(reinterpret_cast<u32x4*>(a.cl_out + p * a.cl_plane + (int64_t)(f0 + fl) * (T::HP * T::CP) + (int64_t)q * 8), vv);
+      }
+    }
     if (g + (int)gridDim.x < ngroups) fload(g + gridDim.x);
     // CHN 32-row steps at a time = CHN independent accumulator chains sharing the wave's weight fragments (a single chain
     // leaves the matrix pipe idle for most of an MFMA's latency).  Two planes: the weight tile leaves no registers for
@@ -255,6 +274,13 @@ template <int NPL, int SITE>
 static void launch_fconv_r(const FcArgs& a, hipStream_t s) {
   using T = FrCfg<NPL, SITE>;
   const unsigned grid = (unsigned)cmin_(cdiv(a.F, T::TF), T::LDS > 80 * 1024 ? 256 : 512);
+  if constexpr (SITE == CV_D0F) {
+    if (a.cl_out && !a.st) {
+      rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv_r<NPL, SITE, 0, true>), T::LDS);
+      hipLaunchKernelGGL((k_fconv_r<NPL, SITE, 0, true>), dim3(grid), dim3(256), T::LDS, s, a);
+      return;
+    }
+  }
   if (a.st) {
     rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv_r<NPL, SITE, 1>), T::LDS);
     hipLaunchKernelGGL((k_fconv_r<NPL, SITE, 1>), dim3(grid), dim3(256), T::LDS, s, a);

@@ -270,6 +270,13 @@ static inline bool fwd_planes(int bit, int site, int64_t F) {
   return ((rt().fwd_mask >> bit) & 1u) && cv_fwd(site, F) && !fc_fwd(site, F) && !fcr_fwd(site, F);
 }
 static inline bool cw_bwd(int site, int64_t F) { return cg_bwd(F) && cv_sel(rt().bwd_mask, CV_COUNT + site); }
+#ifndef VAENPVC_D0F_CLOUT
+#define VAENPVC_D0F_CLOUT 1
+#endif
+// decoder layer 0's fused forward kernel also writes the channel-last planes of its input h (operand of the layer's view weight gradient)
+static inline bool d0f_leaves_planes(int64_t F) {
+  return VAENPVC_D0F_CLOUT && F >= 1024 && ((rt().fwd_mask >> 7) & 1u) && fcr_fwd(CV_D0F, F) && ((rt().bwd_mask >> 7) & 1u) && cw_bwd(CW_D0, F);
+}
 static inline unsigned short* us(float* p) { return reinterpret_cast<unsigned short*>(p); }
 static NtArgs nt_args(const float* Ap, int M, int Kp, const float* Bp, int Np, int N, float* C, int ldc) {
   NtArgs a;
@@ -700,6 +707,10 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     for_dense_planes([&](auto npl) {
       FcArgs fa{w.h, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvwr_d0f),
                 P + m.dec[0].b_off, w.dec_a[0], F};
+      if (w.d_h && d0f_leaves_planes(F)) {   // train mode: the planes of h the weight-gradient GEMM of this layer reads leave the staging
+        fa.cl_out = us(w.cl[CL_H]);
+        fa.cl_plane = cl_plane(CL_H, F);
+      }
       VAENPVC_TIMED("dec0_fwd", s, fconv_r<decltype(npl)::value>(CV_D0F, fa, s));
     });
     if (!d1_fused && !(have_yd0 = dec_stats(0, CV_D1F, CL_YD0, "dec1_split"))) VAENPVC_TIMED("stats_dec0", s, stats<1824>(w.dec_a[0], w.dec_st[0], F, s));
@@ -1086,7 +1097,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     WgArgs a{w.d_dec_a[0], nullptr, nullptr, nullptr, w.h, nullptr, nullptr, nullptr, G + l.w_off, F, 0};
     const bool rg = fcr_bwd(CV_D0G, F), vg = !rg && cv_bwd(CV_D0G, F), vw = cw_bwd(CW_D0, F);
     if ((vg || vw) && !gd0_planes) gsplit(CL_GD0, w.d_dec_a[0], "dec0_gsplit");
-    if (vw && !fwd_planes(7, CV_D0F, F)) asplit(CL_H, w.h, nullptr, nullptr, "dec0_asplit");
+    if (vw && !fwd_planes(7, CV_D0F, F) && !d0f_leaves_planes(F)) asplit(CL_H, w.h, nullptr, nullptr, "dec0_asplit");
     ready();
     if (vw) vwgrad(CW_D0, G + l.w_off, "dec0_wgrad");
     else VAENPVC_TIMED("dec0_wgrad", s2, launch_convwgrad<WD0>(a, WGS, s2));
