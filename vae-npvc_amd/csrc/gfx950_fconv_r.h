@@ -124,6 +124,29 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
       const int h = T::POS ? 64 * k + lane : pg_p;
       const int cbase = T::POS ? 0 : pg_g * T::CG;
       const bool live = it < T::NIT && g * T::TF + fl < a.F && h < T::H && (T::POS || pg_g < 3);
+      if constexpr (LN == 2) {
+        // LayerNorm statistics of the input taken HERE (lane = position, one item = one whole frame: the two sums are wave
+        // reductions, no barrier; two-pass in registers as k_ln_stats_fast) and stored for the backward pass: the separate
+        // statistics pass over the tensor goes away
+        static_assert(LN != 2 || (T::POS && T::NCH == 1 && T::CG >= T::C), "statistics in the staging need one item per frame");
+        constexpr float INVN = 1.0f / (T::C * T::H);
+        float sm = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < T::C; ++cc) sm += v[u][cc];        // (invalid lanes / frames hold zeros)
+        mean[u] = wave_sum(sm) * INVN;
+        float q = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < T::C; ++cc) {
+          const float d = v[u][cc] - mean[u];
+          q += d * d;
+        }
+        q = wave_sum(lane < T::H ? q : 0.f);
+        rstd[u] = 1.0f / sqrtf(q * INVN + LN_EPS);
+        if (lane == 0 && it < T::NIT && g * T::TF + fl < a.F) {
+          a.st_out[2 * (g * T::TF + fl)] = mean[u];
+          a.st_out[2 * (g * T::TF + fl) + 1] = rstd[u];
+        }
+      }
       if (!live) continue;
       if constexpr (LN != 0) {
 #pragma unroll
@@ -149,7 +172,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
   int g = blockIdx.x;
   if (g < ngroups) fload(g);
   // ---- once: zero the frame tile; this wave's weight tile into registers; the input's LayerNorm parameters into LDS
-  if (a.st && tid < T::C) {
+  if (LN != 0 && tid < T::C) {
     lnp[0][tid] = a.gamma[tid];
     lnp[1][tid] = a.beta[tid];
   }
@@ -278,6 +301,13 @@ static void launch_fconv_r(const FcArgs& a, hipStream_t s) {
     if (a.cl_out && !a.st) {
       rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv_r<NPL, SITE, 0, true>), T::LDS);
       hipLaunchKernelGGL((k_fconv_r<NPL, SITE, 0, true>), dim3(grid), dim3(256), T::LDS, s, a);
+      return;
+    }
+  }
+  if constexpr (SITE == CV_E2F) {
+    if (a.st_out) {   // (statistics of the input computed in the staging)
+      rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv_r<NPL, SITE, 2>), T::LDS);
+      hipLaunchKernelGGL((k_fconv_r<NPL, SITE, 2>), dim3(grid), dim3(256), T::LDS, s, a);
       return;
     }
   }

@@ -270,6 +270,9 @@ static inline bool fwd_planes(int bit, int site, int64_t F) {
   return ((rt().fwd_mask >> bit) & 1u) && cv_fwd(site, F) && !fc_fwd(site, F) && !fcr_fwd(site, F);
 }
 static inline bool cw_bwd(int site, int64_t F) { return cg_bwd(F) && cv_sel(rt().bwd_mask, CV_COUNT + site); }
+#ifndef VAENPVC_E2F_STATS
+#define VAENPVC_E2F_STATS 1   // encoder layer 2's fused forward kernel computes the LayerNorm statistics of its input itself
+#endif
 #ifndef VAENPVC_D0F_CLOUT
 #define VAENPVC_D0F_CLOUT 1
 #endif
@@ -558,22 +561,26 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
       VAENPVC_TIMED(tag, s, fconv<decltype(npl)::value>(site, fa, s));
     });
   };
-  auto fused_r = [&](int site, const float* wpl, const float* src, const float* st, const ConvL* ln, const float* bias, float* out, const char* tag) {
+  auto fused_r = [&](int site, const float* wpl, const float* src, const float* st, const ConvL* ln, const float* bias, float* out, const char* tag,
+                     float* st_out = nullptr) {
     for_dense_planes([&](auto npl) {
-      FcArgs fa{src, st, nullptr, ln ? P + ln->gamma_off : nullptr, ln ? P + ln->beta_off : nullptr,
+      FcArgs fa{src, st, st_out, ln ? P + ln->gamma_off : nullptr, ln ? P + ln->beta_off : nullptr,
                 reinterpret_cast<const unsigned short*>(wpl), bias, out, F};
       VAENPVC_TIMED(tag, s, fconv_r<decltype(npl)::value>(site, fa, s));
     });
   };
   bool have_y1 = false, have_y2 = false;
+  const bool e2_takes_stats = VAENPVC_E2F_STATS && fwd_on(1) && fwd_on(2) && fcr_fwd(CV_E2F, F);
   if (fwd_on(1)) {
     if (fc_fwd(CV_E1F, F)) fused(CV_E1F, w.enc_a[0], w.enc_st[0], nullptr, &m.enc[0], P + m.enc[1].b_off, w.enc_a[1], "enc1_fwd");
     else if (cv_fwd(CV_E1F, F)) enc_view(CV_E1F, CL_Y0, 1, false, "enc1_split", "enc1_fwd");
     else VAENPVC_TIMED("enc1_fwd", s, launch_convgemm<E1F>(lnp(1), nsplit_for<E1F>(F), s));
-    if (!(have_y1 = enc_stats(1, CV_E2F, CL_Y1, "enc2_split"))) VAENPVC_TIMED("stats_enc1", s, stats<1824>(w.enc_a[1], w.enc_st[1], F, s));
+    if (e2_takes_stats) {}   // (layer 2's fused kernel takes the statistics of its input in its staging)
+    else if (!(have_y1 = enc_stats(1, CV_E2F, CL_Y1, "enc2_split"))) VAENPVC_TIMED("stats_enc1", s, stats<1824>(w.enc_a[1], w.enc_st[1], F, s));
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 1);
   if (fwd_on(2)) {
-    if (fcr_fwd(CV_E2F, F)) fused_r(CV_E2F, w.scratch + Pk::cvw + cv_woff(CV_E2F), w.enc_a[1], w.enc_st[1], &m.enc[1], P + m.enc[2].b_off, w.enc_a[2], "enc2_fwd");
+    if (fcr_fwd(CV_E2F, F)) fused_r(CV_E2F, w.scratch + Pk::cvw + cv_woff(CV_E2F), w.enc_a[1], e2_takes_stats ? nullptr : w.enc_st[1], &m.enc[1], P + m.enc[2].b_off, w.enc_a[2], "enc2_fwd",
+                                    e2_takes_stats ? w.enc_st[1] : nullptr);
     else if (cv_fwd(CV_E2F, F)) enc_view(CV_E2F, CL_Y1, 2, have_y1, "enc2_split", "enc2_fwd");
     else VAENPVC_TIMED("enc2_fwd", s, launch_convgemm<E2F>(lnp(2), nsplit_for<E2F>(F), s));
     if (!(have_y2 = enc_stats(2, CV_E3F, CL_Y2, "enc3_split"))) VAENPVC_TIMED("stats_enc2", s, stats<1216>(w.enc_a[2], w.enc_st[2], F, s));
