@@ -301,7 +301,10 @@ static int fwd_all(vaenpvc_ctx* ctx, const float* P, const float* x, const int64
   VAENPVC_TIMED("reparam", s, generic::reparam_fwd(ctx->m, eps, key, F, w, s));
   if (use_tuned(ctx)) tuned::decoder_fwd(ctx->m, P, w.z, y, F, w, w.xh, s, /*weights_packed=*/true);
   else generic::decoder_fwd(ctx->m, P, w.z, y, F, w, w.xh, s);
-  VAENPVC_TIMED("loss", s, generic::loss_fwd(ctx->m, target ? target : x, F, w, want_grad, loss3, s));   // (the density's data argument)
+  rt().dxh_post_F = -1;
+  const bool fused_loss = want_grad && use_tuned(ctx);
+  VAENPVC_TIMED("loss", s, (fused_loss && tuned::loss_fwd_post(ctx->m, P, target ? target : x, F, w, loss3, s))
+                               ? (void)0 : generic::loss_fwd(ctx->m, target ? target : x, F, w, want_grad, loss3, s));   // (the density's data argument)
   return 0;
 }
 
@@ -405,6 +408,7 @@ int vaenpvc_train_bwd_target(vaenpvc_ctx* ctx, const float* d_params, const floa
         r.last_bwd_mask != r.bwd_mask || r.last_ws != d_ws)
       return fail(VAENPVC_E_STATE, "train_bwd_target: no matching train step precedes it in this context (batch size, kernel selection, precision or workspace differ)");
   }
+  rt().dxh_post_F = -1;
   generic::loss_fwd(ctx->m, d_target, F, w, true, d_loss3, s);   // new d(xh) from the activations already in place
   ctx->rt.bucket_next = 0;
   if (use_tuned(ctx) && tuned::frame_fwd_on(F) && tuned::frame_bwd_on(F)) {

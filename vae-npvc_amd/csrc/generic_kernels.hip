@@ -533,6 +533,9 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
   for (int i = 0; i < m.n_dec; ++i) dec_layer_fwd(m, P, F, w, xh_out, s, i);
 }
 
+void loss_reduce(int64_t F, const Ws& w, float* loss3, hipStream_t s) {
+  hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, s, w.kl_f, w.nll_f, F, loss3);
+}
 void loss_fwd(const Model& m, const float* x, int64_t F, const Ws& w, bool want_grad, float* loss3, hipStream_t s) {
   hipLaunchKernelGGL(k_nll, dim3((unsigned)F), dim3(256), 0, s, x, w.xh, w.nll_f, want_grad ? w.d_xh : nullptr, m.H,
                      1.0f / (float)F);

@@ -273,6 +273,9 @@ static inline bool cw_bwd(int site, int64_t F) { return cg_bwd(F) && cv_sel(rt()
 #ifndef VAENPVC_E2F_STATS
 #define VAENPVC_E2F_STATS 1   // encoder layer 2's fused forward kernel computes the LayerNorm statistics of its input itself
 #endif
+#ifndef VAENPVC_DZ_PLANES
+#define VAENPVC_DZ_PLANES 1   // the sampler backward writes the planes of [dz_mu | dz_lv] itself
+#endif
 #ifndef VAENPVC_D0F_CLOUT
 #define VAENPVC_D0F_CLOUT 1
 #endif
@@ -824,6 +827,23 @@ static TnArgs tn_args(const float* X, int ldx, const float* Y, int ldy, int M, i
 // device, destroyed with it).
 static int kchunks_for(int F, int tiles) { return cmax(1, cmin_(cdiv(F, 64), 512 / tiles)); }  // 2 workgroups (64 KB LDS) per CU
 
+#ifndef VAENPVC_NLL_POST
+#define VAENPVC_NLL_POST 1
+#endif
+static inline int nll_post_blocks(int64_t F) { return cmin_(2048, cdiv((int)F, 4)); }
+bool loss_fwd_post(const Model& m, const float* P, const float* x, int64_t F64, const Ws& w, float* loss3, hipStream_t s) {
+  const int F = (int)F64;
+  if (!VAENPVC_NLL_POST || !w.d_xh || !w.toep_gp || !w.dy_tmp || F < 1024 || frame_bwd_on(F64) || !bwd_on(10) || !toep_bf16_for(F) || act_bf16(F)) return false;
+  for_planes([&](auto npl) {
+    constexpr int NPL = decltype(npl)::value;
+    hipLaunchKernelGGL((k_nll_dxh_post<NPL>), dim3((unsigned)nll_post_blocks(F)), dim3(256), 0, s, x, w.xh, w.nll_f, w.d_xh, P + m.dec[3].w_off,
+                       reinterpret_cast<unsigned short*>(w.toep_gp), w.dy_tmp, w.scratch + Pk::lnpart, F, 1.0f / (float)F);
+  });
+  generic::loss_reduce(F, w, loss3, s);
+  rt().dxh_post_F = F;
+  return true;
+}
+
 void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F64,
               const Ws& w, float* G, hipStream_t s) {
   read_env();
@@ -847,7 +867,11 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   // one pass over d(xh) for the bf16 kernels of the last layer: its three planes (operand of the input-gradient
   // and weight-gradient GEMMs), column 512 of the input gradient, the bias gradient
   const bool toep_planes = bwd_on(10) && toep_bf16_for(F);
-  if (toep_planes)
+  const bool post_done = toep_planes && rt().dxh_post_F == F;   // (the loss kernel of this step did it: loss_fwd_post)
+  rt().dxh_post_F = -1;
+  if (post_done)
+    VAENPVC_TIMED("dxh_post", s, hipLaunchKernelGGL(k_colsum_part, dim3(1), dim3(256), 0, s, w.scratch + Pk::lnpart, nll_post_blocks(F), 1, G + m.dec[3].b_off));
+  else if (toep_planes)
     for_planes([&](auto npl) {
       constexpr int NPL_ = decltype(npl)::value;
       auto launch_dp = [&](auto kern) {
@@ -1174,8 +1198,15 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   bucket(m.wz_off, m.dec[0].w_off);  // the two merge FCs and the three merge biases (the embedding goes last)
 
   const bool heads_tuned = bwd_on(5);
+  const bool dz_planes = VAENPVC_DZ_PLANES && F >= 1024 && bwd_on(5) && pg_bwd(F) && pg_fwd(F) && fwd_on(5);
   if (heads_tuned) {  // sampler + KL backward fused with the two head-bias gradients
     const int rch = cmax(1, cmin_(cdiv(F, 32), 1024)), rfc = cdiv(F, rch);
+    if (dz_planes)   // straight to the planes [dz_mu | dz_lv] of the two head GEMMs
+      for_dense_planes([&](auto npl) {
+        VAENPVC_TIMED("reparam_bwd", s, hipLaunchKernelGGL((k_reparam_bwd_planes<decltype(npl)::value>), dim3((unsigned)cdiv(F, rfc)), dim3(256), 0, s, w.d_z, w.z_mu,
+                           w.z_lv, eps, us(w.pl_dz), G + m.bmu_off, G + m.blv_off, (int)F, rfc, 1.0f / (float)F));
+      });
+    else
     VAENPVC_TIMED("reparam_bwd", s, hipLaunchKernelGGL(k_reparam_bwd_colsum, dim3((unsigned)cdiv(F, rfc)), dim3(256), 0, s, w.d_z, w.z_mu, w.z_lv, eps, w.d_z_mu,
                        w.d_z_lv, G + m.bmu_off, G + m.blv_off, (int)F, rfc, 1.0f / (float)F));
   } else generic::bwd_reparam(m, eps, F, w, s);
@@ -1192,7 +1223,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       sa.ld1 = 128;
       sa.src2 = w.d_z_lv;
       sa.ld2 = 128;
-      VAENPVC_TIMED("heads_dsplit", s, launch_split<NPL>(sa, s));
+      if (!dz_planes) VAENPVC_TIMED("heads_dsplit", s, launch_split<NPL>(sa, s));
       ready();
       TnpArgs t = tnp_args(w.pl_y4, 768, w.pl_dz, 256, 768, 256, F, G + m.wmu_off, 128);
       t.C2 = G + m.wlv_off;

@@ -275,6 +275,60 @@ inline void launch_sum_parts(const float* parts, int nch, int n, float* out, hip
   hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, s, parts, nch, n, out);
 }
 
+// autodiff of the sampler + KL (k_reparam_bwd_colsum, gfx950_elem.h: util/layers.py:152-156,170-183) whose two results leave as the
+// bf16 planes [dz_mu | dz_lv] ([NPL][F][256]) the two head GEMMs read -- no fp32 copies, no split pass -- with four frames in
+// flight per thread; the two head-bias gradients as there (2 x 128 atomics per workgroup).
+template <int NPL>
+__global__ void __launch_bounds__(256) k_reparam_bwd_planes(const float* __restrict__ dz, const float* __restrict__ zmu,
+                                                            const float* __restrict__ zlv, const float* __restrict__ eps,
+                                                            unsigned short* __restrict__ pl, float* __restrict__ gbmu,
+                                                            float* __restrict__ gblv, int F, int fchunk, float invF) {
+  __shared__ float sm[2][128];
+  const int k = threadIdx.x & 127, ph = threadIdx.x >> 7;
+  const int fb = blockIdx.x * fchunk, fe = min(F, fb + fchunk);
+  const int64_t plane = (int64_t)F * 256;
+  float smu = 0.f, slv = 0.f;
+  for (int f0 = fb + ph; f0 < fe; f0 += 8) {
+    float mu[4], lv[4], g[4], e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = f0 + 2 * u < fe ? f0 + 2 * u : fb;
+      const int64_t i = (int64_t)f * 128 + k;
+      mu[u] = zmu[i];
+      lv[u] = zlv[i];
+      g[u] = dz[i];
+      e[u] = eps[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = f0 + 2 * u;
+      if (f >= fe) break;
+      const float v = expf(lv[u]);
+      const float a = g[u] + mu[u] / (1.0f + EPSILON) * invF;
+      const float b = g[u] * (0.5f * e[u] * sqrtf(v)) + 0.5f * (v / (1.0f + EPSILON) - 1.0f) * invF;
+      smu += a;
+      slv += b;
+      unsigned ta[NPL], tb[NPL];
+      split_n<NPL>(a, ta);
+      split_n<NPL>(b, tb);
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        pl[p * plane + (int64_t)f * 256 + k] = (unsigned short)ta[p];
+        pl[p * plane + (int64_t)f * 256 + 128 + k] = (unsigned short)tb[p];
+      }
+    }
+  }
+  if (ph == 1) {
+    sm[0][k] = smu;
+    sm[1][k] = slv;
+  }
+  __syncthreads();
+  if (ph == 0) {
+    atomicAdd(gbmu + k, smu + sm[0][k]);
+    atomicAdd(gblv + k, slv + sm[1][k]);
+  }
+}
+
 static inline SplitArgs split_args(const float* src, int K, int Kp, int64_t rows, unsigned short* dst) {
   SplitArgs a;
   a.src = src;

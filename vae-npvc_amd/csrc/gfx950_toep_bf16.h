@@ -218,6 +218,98 @@ __global__ void __launch_bounds__(256) k_dxh_post(const float* __restrict__ G, c
   if (threadIdx.x == 0) atomicAdd(dbias, (sm[0] + sm[1]) + (sm[2] + sm[3]));
 }
 
+// ---- the loss (util/layers.py:159-167 with log_var = 0, model/vae.py:112-128) AND everything k_dxh_post derives from d(xh), in ONE
+//      pass over x and xh: per-frame log-density, d(xh) = (xh - x) / ((1 + 1e-6) F) as fp32 and as NPL bf16 planes, column 512 of the
+//      last layer's input gradient, the per-workgroup part of its bias gradient (bpart[blockIdx.x]: the gradient buffer is zeroed
+//      when the backward pass starts, which adds the parts then).  Replaces k_nll + k_dxh_post (the second read of d(xh)).
+template <int NPL>
+__global__ void __launch_bounds__(256) k_nll_dxh_post(const float* __restrict__ x, const float* __restrict__ xh, float* __restrict__ nll_f,
+                                                      float* __restrict__ G, const float* __restrict__ W, unsigned short* __restrict__ dst,
+                                                      float* __restrict__ dY, float* __restrict__ bpart, int F, float invF) {
+  __shared__ float sm[4];
+  constexpr float LOG2PI = 1.8378770664093453f;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float wt[8][TB_C];
+  {
+    const float* wp = W + (size_t)lane * 64;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int c = 0; c < TB_C; ++c) wt[j][c] = wp[j * TB_C + c];
+  }
+  float wl[TB_C];  // bin 512 (lane 0)
+#pragma unroll
+  for (int c = 0; c < TB_C; ++c) wl[c] = W[512 * TB_C + c];
+  const float gs = -invF / (1.0f + EPSILON);
+  float bsum = 0.f;
+  for (int f = blockIdx.x * 4 + wv; f < F; f += gridDim.x * 4) {
+    const float* xf = x + (int64_t)f * TB_H;
+    const float* hf = xh + (int64_t)f * TB_H;
+    const packed4 a0 = *reinterpret_cast<const packed4*>(xf + 8 * lane), a1 = *reinterpret_cast<const packed4*>(xf + 8 * lane + 4);
+    const packed4 b0 = *reinterpret_cast<const packed4*>(hf + 8 * lane), b1 = *reinterpret_cast<const packed4*>(hf + 8 * lane + 4);
+    const float dt = lane == 0 ? xf[512] - hf[512] : 0.f;
+    const float d[8] = {a0.x - b0.x, a0.y - b0.y, a0.z - b0.z, a0.w - b0.w, a1.x - b1.x, a1.y - b1.y, a1.z - b1.z, a1.w - b1.w};
+    float nl = lane == 0 ? -0.5f * (LOG2PI + (dt * dt) / (1.0f + EPSILON)) : 0.f;
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      nl += -0.5f * (LOG2PI + (d[j] * d[j]) / (1.0f + EPSILON));
+      g[j] = d[j] * gs;
+    }
+    const float gt = dt * gs;
+    nl = wave_sum(nl);
+    float* gf = G + (int64_t)f * TB_H;
+    *reinterpret_cast<packed4*>(gf + 8 * lane) = packed4{g[0], g[1], g[2], g[3]};
+    *reinterpret_cast<packed4*>(gf + 8 * lane + 4) = packed4{g[4], g[5], g[6], g[7]};
+    if (lane == 0) {
+      gf[512] = gt;
+      nll_f[f] = nl;
+    }
+    unsigned tm[8][NPL];
+    float dot[TB_C];
+#pragma unroll
+    for (int c = 0; c < TB_C; ++c) dot[c] = gt * wl[c];
+    float sfr = gt;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      split_n<NPL>(g[j], tm[j]);
+      sfr += g[j];
+#pragma unroll
+      for (int c = 0; c < TB_C; ++c) dot[c] += g[j] * wt[j][c];
+    }
+    bsum += sfr;
+    unsigned short* dd = dst + (int64_t)f * (NPL * TB_KP);
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+      u32x4 pk;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pk[k] = tm[2 * k][p] | (tm[2 * k + 1][p] << 16);
+      *reinterpret_cast<u32x4*>(dd + p * TB_KP + 8 * lane) = pk;
+    }
+    if (lane == 0) {  // bin 512 and the zero padding 513..527
+      unsigned tt[NPL];
+      split_n<NPL>(gt, tt);
+      const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        u32x4 t = z;
+        t[0] = tt[p];
+        *reinterpret_cast<u32x4*>(dd + p * TB_KP + 512) = t;
+        *reinterpret_cast<u32x4*>(dd + p * TB_KP + 520) = z;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < TB_C; ++c) {
+      const float v = wave_sum(dot[c]);
+      if (lane == 0) dY[((int64_t)f * TB_C + c) * TB_H + 512] = v;
+    }
+  }
+  bsum = wave_sum(bsum);
+  if (lane == 0) sm[wv] = bsum;
+  __syncthreads();
+  if (threadIdx.x == 0) bpart[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
 // ---- shifted bf16 copies of the tap rows: dst[c][plane][s][m] = plane(w[c][m + s]), m < 8*TB_CHUNKS.
 //      REV = false: w[c][u] = W[u][c] (input gradient);  REV = true: w[c][u] = W[1024 - u][c] (forward).
 template <bool REV, int NPL>

@@ -59,6 +59,7 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
                  float* xh_out, hipStream_t s);
 // per-frame log-density, optional d_xh, then {G, D_KL, logP}
 void loss_fwd(const Model& m, const float* x, int64_t F, const Ws& w, bool want_grad, float* loss3, hipStream_t s);
+void loss_reduce(int64_t F, const Ws& w, float* loss3, hipStream_t s);   // batch means of kl_f / nll_f -> {G, D_KL, logP}
 void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F,
               const Ws& w, float* G, hipStream_t s);
 // per-step entry points (the tuned path can fall back to any of them, per layer)
@@ -105,6 +106,10 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
                  float* xh_out, hipStream_t s, bool weights_packed = false);
 void backward(const Model& m, const float* P, const float* x, const int64_t* y, const float* eps, int64_t F,
               const Ws& w, float* G, hipStream_t s);
+// the loss of a train step fused with the first pass of the backward over d(xh) (planes of d(xh), column 512 of the last layer's
+// input gradient, bias-gradient parts): true = done, the backward pass that follows picks the results up (Runtime::dxh_post_F);
+// false = not selected at this batch size / precision / masks, the caller runs generic::loss_fwd
+bool loss_fwd_post(const Model& m, const float* P, const float* x, int64_t F, const Ws& w, float* loss3, hipStream_t s);
 // ---- small-batch path: whole frames per workgroup (gfx950_frame.hip)
 constexpr int FRAME_ENC = 1, FRAME_SAMPLE = 2, FRAME_DEC = 4, FRAME_LOSS = 8, FRAME_GRAD = 16;   // = frame::FM_*
 constexpr int64_t FRAME_CAP = 1024;          // largest batch the workspace reserves its per-frame sums for
