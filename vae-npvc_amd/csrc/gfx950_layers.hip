@@ -1203,8 +1203,10 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     const int rch = cmax(1, cmin_(cdiv(F, 32), 1024)), rfc = cdiv(F, rch);
     if (dz_planes)   // straight to the planes [dz_mu | dz_lv] of the two head GEMMs
       for_dense_planes([&](auto npl) {
+        // (parts in the LayerNorm-backward scratch: every launch that used it so far on this stream has been reduced)
         VAENPVC_TIMED("reparam_bwd", s, hipLaunchKernelGGL((k_reparam_bwd_planes<decltype(npl)::value>), dim3((unsigned)cdiv(F, rfc)), dim3(256), 0, s, w.d_z, w.z_mu,
-                           w.z_lv, eps, us(w.pl_dz), G + m.bmu_off, G + m.blv_off, (int)F, rfc, 1.0f / (float)F));
+                           w.z_lv, eps, us(w.pl_dz), w.scratch + Pk::lnpart, (int)F, rfc, 1.0f / (float)F);
+                      hipLaunchKernelGGL(k_colsum_part2, dim3(256), dim3(256), 0, s, w.scratch + Pk::lnpart, cdiv(F, rfc), G + m.bmu_off, G + m.blv_off));
       });
     else
     VAENPVC_TIMED("reparam_bwd", s, hipLaunchKernelGGL(k_reparam_bwd_colsum, dim3((unsigned)cdiv(F, rfc)), dim3(256), 0, s, w.d_z, w.z_mu, w.z_lv, eps, w.d_z_mu,

@@ -277,12 +277,12 @@ inline void launch_sum_parts(const float* parts, int nch, int n, float* out, hip
 
 // autodiff of the sampler + KL (k_reparam_bwd_colsum, gfx950_elem.h: util/layers.py:152-156,170-183) whose two results leave as the
 // bf16 planes [dz_mu | dz_lv] ([NPL][F][256]) the two head GEMMs read -- no fp32 copies, no split pass -- with four frames in
-// flight per thread; the two head-bias gradients as there (2 x 128 atomics per workgroup).
+// flight per thread; the two head-bias gradients as per-workgroup parts added by k_colsum_part2.
 template <int NPL>
 __global__ void __launch_bounds__(256) k_reparam_bwd_planes(const float* __restrict__ dz, const float* __restrict__ zmu,
                                                             const float* __restrict__ zlv, const float* __restrict__ eps,
-                                                            unsigned short* __restrict__ pl, float* __restrict__ gbmu,
-                                                            float* __restrict__ gblv, int F, int fchunk, float invF) {
+                                                            unsigned short* __restrict__ pl, float* __restrict__ part,
+                                                            int F, int fchunk, float invF) {
   __shared__ float sm[2][128];
   const int k = threadIdx.x & 127, ph = threadIdx.x >> 7;
   const int fb = blockIdx.x * fchunk, fe = min(F, fb + fchunk);
@@ -323,10 +323,23 @@ __global__ void __launch_bounds__(256) k_reparam_bwd_planes(const float* __restr
     sm[1][k] = slv;
   }
   __syncthreads();
+  // (parts, not atomics: a thousand workgroups adding to the same 256 addresses serialise at the memory side -- the chain was the
+  //  kernel's duration)
   if (ph == 0) {
-    atomicAdd(gbmu + k, smu + sm[0][k]);
-    atomicAdd(gblv + k, slv + sm[1][k]);
+    part[(int64_t)blockIdx.x * 256 + k] = smu + sm[0][k];
+    part[(int64_t)blockIdx.x * 256 + 128 + k] = slv + sm[1][k];
   }
+}
+// out1[col] += sum_r part[r][col] (col < 128), out2[col - 128] += ... (col >= 128): one workgroup per column
+__global__ void __launch_bounds__(256) k_colsum_part2(const float* __restrict__ part, int rows, float* __restrict__ out1, float* __restrict__ out2) {
+  __shared__ float sm[4];
+  const int col = blockIdx.x;
+  float s = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 256) s += part[(int64_t)r * 256 + col];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(col < 128 ? out1 + col : out2 + (col - 128), (sm[0] + sm[1]) + (sm[2] + sm[3]));
 }
 
 static inline SplitArgs split_args(const float* src, int K, int Kp, int64_t rows, unsigned short* dst) {
