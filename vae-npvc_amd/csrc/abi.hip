@@ -298,7 +298,8 @@ static int fwd_all(vaenpvc_ctx* ctx, const float* P, const float* x, const int64
   }
   if (use_tuned(ctx)) tuned::encoder_fwd(ctx->m, P, x, F, w, s);
   else generic::encoder_fwd(ctx->m, P, x, F, w, s);
-  VAENPVC_TIMED("reparam", s, generic::reparam_fwd(ctx->m, eps, key, F, w, s));
+  rt().plz_F = -1;
+  VAENPVC_TIMED("reparam", s, (use_tuned(ctx) && tuned::reparam_fwd_planes(ctx->m, eps, key, F, w, s)) ? (void)0 : generic::reparam_fwd(ctx->m, eps, key, F, w, s));
   if (use_tuned(ctx)) tuned::decoder_fwd(ctx->m, P, w.z, y, F, w, w.xh, s, /*weights_packed=*/true);
   else generic::decoder_fwd(ctx->m, P, w.z, y, F, w, w.xh, s);
   rt().dxh_post_F = -1;

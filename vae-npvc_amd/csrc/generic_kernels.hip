@@ -204,7 +204,8 @@ __global__ void k_loss_reduce(const float* __restrict__ kl_f, const float* __res
                               float* __restrict__ loss3) {
   __shared__ float sm[16];
   float a = 0.f, b = 0.f;
-  for (int64_t i = threadIdx.x; i < F; i += blockDim.x) {
+#pragma unroll 8
+  for (int64_t i = threadIdx.x; i < F; i += blockDim.x) {   // (eight pairs of loads in flight: the single block is latency-bound)
     a += kl_f[i];
     b += nll_f[i];
   }

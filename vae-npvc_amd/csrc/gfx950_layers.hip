@@ -663,10 +663,12 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
   read_env();
   const int F = (int)F64;
   if (!weights_packed) prep(m, P, w, F, s);
+  const bool z_planes_done = rt().plz_F == F && z == w.z;   // (this step's sampler kernel wrote them: reparam_fwd_planes)
+  rt().plz_F = -1;
   if (fwd_on(6) && pg_fwd(F)) {
     for_dense_planes([&](auto npl) {
       constexpr int NPL = decltype(npl)::value;
-      VAENPVC_TIMED("merge_split", s, launch_split<NPL>(split_args(z, 128, 128, F, us(w.pl_z)), s));
+      if (!z_planes_done) VAENPVC_TIMED("merge_split", s, launch_split<NPL>(split_args(z, 128, 128, F, us(w.pl_z)), s));
       NtArgs a = nt_args(w.pl_z, F, 128, w.scratch + Pk::pg_mergef, 1664, 1539, w.h, 1539);
       a.rowbias = w.scratch + Pk::merge_tb;   // + T[y_f]: the speaker's row of E Wy + (bz + by + b)
       a.idx = y;
@@ -827,6 +829,21 @@ static TnArgs tn_args(const float* X, int ldx, const float* Y, int ldy, int M, i
 // device, destroyed with it).
 static int kchunks_for(int F, int tiles) { return cmax(1, cmin_(cdiv(F, 64), 512 / tiles)); }  // 2 workgroups (64 KB LDS) per CU
 
+#ifndef VAENPVC_Z_PLANES
+#define VAENPVC_Z_PLANES 1
+#endif
+bool reparam_fwd_planes(const Model& m, const float* eps, const PhiloxKey* key, int64_t F64, const Ws& w, hipStream_t s) {
+  read_env();
+  const int F = (int)F64;
+  if (!VAENPVC_Z_PLANES || m.z != 128 || F < 1024 || !w.pl_z || !fwd_on(6) || !pg_fwd(F)) return false;
+  const PhiloxKey k = key ? *key : PhiloxKey{0, 0, 0, 0, nullptr};
+  for_dense_planes([&](auto npl) {
+    hipLaunchKernelGGL((k_reparam_planes<decltype(npl)::value>), dim3((unsigned)cmin_(2048, cdiv(F, 4))), dim3(256), 0, s, w.z_mu, w.z_lv, eps, w.z, w.kl_f,
+                       us(w.pl_z), F, k, key ? 1 : 0, w.eps);
+  });
+  rt().plz_F = F;
+  return true;
+}
 #ifndef VAENPVC_NLL_POST
 #define VAENPVC_NLL_POST 1
 #endif

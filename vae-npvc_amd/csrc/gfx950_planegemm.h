@@ -19,6 +19,7 @@
 #pragma once
 #include "gfx950_common.h"
 #include "gfx950_toep_bf16.h"  // split_n, Prod, mfma_bf16, u32x4, packed4, tr_read8
+#include "philox.h"
 
 namespace vaenpvc {
 namespace tuned {
@@ -273,6 +274,49 @@ inline int launch_split_segsum(const float* d, const int64_t* y, int N, int Kp, 
 }
 inline void launch_sum_parts(const float* parts, int nch, int n, float* out, hipStream_t s) {
   hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, s, parts, nch, n, out);
+}
+
+// sampler + per-frame KL (generic k_reparam: util/layers.py:152-156,170-183 with mu2 = lv2 = 0) for z = 128, one WAVE per frame (a lane
+// owns two neighbouring elements), writing z as fp32 AND as the bf16 planes the merge GEMM reads ([NPL][F][128]: the split pass
+// over z goes away).  eps: injected draw, or (draw) drawn here with Philox and stored to eps_out for the backward pass.
+template <int NPL>
+__global__ void __launch_bounds__(256) k_reparam_planes(const float* __restrict__ zmu, const float* __restrict__ zlv, const float* __restrict__ eps,
+                                                        float* __restrict__ z, float* __restrict__ kl_f, unsigned short* __restrict__ pl, int F,
+                                                        PhiloxKey key, int draw, float* __restrict__ eps_out) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (draw) key = philox_resolve(key);
+  const int64_t plane = (int64_t)F * 128;
+  for (int f = blockIdx.x * 4 + wv; f < F; f += gridDim.x * 4) {
+    const int64_t i = (int64_t)f * 128 + 2 * lane;
+    const f32x2 mu = *reinterpret_cast<const f32x2*>(zmu + i), lv = *reinterpret_cast<const f32x2*>(zlv + i);
+    f32x2 e = {0.f, 0.f};
+    if (draw) {
+      e[0] = philox_normal(key, (uint64_t)i);
+      e[1] = philox_normal(key, (uint64_t)i + 1);
+      *reinterpret_cast<f32x2*>(eps_out + i) = e;
+    } else if (eps) {
+      struct __attribute__((packed, aligned(4))) p2 { float x, y; };   // (a caller's pointer: only float alignment is promised)
+      const p2 t = *reinterpret_cast<const p2*>(eps + i);
+      e[0] = t.x;
+      e[1] = t.y;
+    }
+    f32x2 zz;
+    float kl = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float v = expf(lv[j]);
+      zz[j] = (draw || eps) ? mu[j] + e[j] * sqrtf(v) : mu[j];
+      kl += 0.5f * ((0.f - lv[j]) + (v + mu[j] * mu[j]) / (1.0f + EPSILON) - 1.0f);
+    }
+    *reinterpret_cast<f32x2*>(z + i) = zz;
+    unsigned pk[NPL];
+    split_pair<NPL>(zz[0], zz[1], pk);
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) *reinterpret_cast<unsigned*>(pl + p * plane + i) = pk[p];
+    kl = wave_sum(kl);
+    if (lane == 0) kl_f[f] = kl;
+  }
 }
 
 // autodiff of the sampler + KL (k_reparam_bwd_colsum, gfx950_elem.h: util/layers.py:152-156,170-183) whose two results leave as the

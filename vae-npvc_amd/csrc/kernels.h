@@ -109,6 +109,9 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
 // the loss of a train step fused with the first pass of the backward over d(xh) (planes of d(xh), column 512 of the last layer's
 // input gradient, bias-gradient parts): true = done, the backward pass that follows picks the results up (Runtime::dxh_post_F);
 // false = not selected at this batch size / precision / masks, the caller runs generic::loss_fwd
+// sampler + KL writing z also as the planes of the merge GEMM (true = done: the decoder_fwd that follows on w.z skips its split pass,
+// Runtime::plz_F; false = not selected, the caller runs generic::reparam_fwd)
+bool reparam_fwd_planes(const Model& m, const float* eps, const PhiloxKey* key, int64_t F, const Ws& w, hipStream_t s);
 bool loss_fwd_post(const Model& m, const float* P, const float* x, int64_t F, const Ws& w, float* loss3, hipStream_t s);
 // ---- small-batch path: whole frames per workgroup (gfx950_frame.hip)
 constexpr int FRAME_ENC = 1, FRAME_SAMPLE = 2, FRAME_DEC = 4, FRAME_LOSS = 8, FRAME_GRAD = 16;   // = frame::FM_*

@@ -59,6 +59,7 @@ struct Runtime {
   int last_path = -1, last_planes = 0;
   unsigned last_fwd_mask = 0, last_bwd_mask = 0;
   const void* last_ws = nullptr;
+  int64_t plz_F = -1;           // batch size whose z planes tuned::reparam_fwd_planes left for the decoder_fwd that follows (-1: none)
   int64_t dxh_post_F = -1;      // batch size whose d(xh) planes / column 512 / bias parts tuned::loss_fwd_post left for the backward pass (-1: none)
   // ---- device binding: created lazily on the device that is current at the first launch
   int device = -1;
