@@ -81,6 +81,9 @@ struct FcArgs {
   // ([NPL][cl_plane], frames of [HP][CP], cl_layout.h) -- the operand the layer's weight-gradient GEMM reads in the backward pass
   unsigned short* cl_out = nullptr;
   int64_t cl_plane = 0;
+  // k_fconv_r, decoder layer 0 input gradient: non-null = the operand is read as its channel-last planes ([NPL][cl_plane], written by
+  // the LayerNorm backward in front, gfx950_lnb_planes.h) instead of as the fp32 tensor `src`: a straight copy into the LDS image
+  const unsigned short* cl_in = nullptr;
 };
 
 template <int CP, int CPL>

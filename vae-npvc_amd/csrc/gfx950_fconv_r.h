@@ -80,7 +80,7 @@ static PackViewPermJob<NPL> fcr_perm_job(int site, const float* W, int s_t, int 
                               reinterpret_cast<unsigned short*>(dst), mp, v.Kp, mp * v.Kp / 8};
 }
 
-template <int NPL, int SITE, int LN, bool CLO = false>
+template <int NPL, int SITE, int LN, bool CLO = false, bool PIN = false>
 __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
   using T = FrCfg<NPL, SITE>;
   constexpr CvSite V = T::V;
@@ -93,7 +93,21 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
   float v[T::IPW][T::CG];
   float mean[T::IPW], rstd[T::IPW];
   const int pg_p = lane % (T::POS ? 64 : T::H), pg_g = T::POS ? 0 : lane / T::H;   // (position, channel third) of this lane
+  // PIN: the group's frames are one contiguous run of 16-byte pieces in every plane (halo rows included, zero there)
+  constexpr int PG8 = T::CP / 8, PPF = T::HP * PG8, PPT = PIN ? cdiv(T::TF * PPF, 256) : 1;
+  u32x4 pv[PIN ? NPL : 1][PPT];
   auto fload = [&](int g) __attribute__((always_inline)) {
+    if constexpr (PIN) {
+      const int last = min(T::TF, a.F - g * T::TF) * PPF - 1;
+      const unsigned short* b = a.cl_in + (int64_t)g * (T::TF * PPF * 8);
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) {
+        const int r = min(tid + 256 * u, last);   // (clamped address, masked at the LDS store: a select here would wait for its load)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) pv[p][u] = *reinterpret_cast<const u32x4*>(b + p * a.cl_plane + r * 8);
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < T::IPW; ++u) {
       const int it = wave + 4 * u, fl = it / T::NCH, k = it - fl * T::NCH;
@@ -118,6 +132,19 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
     }
   };
   auto fstore = [&](int g) __attribute__((always_inline)) {
+    if constexpr (PIN) {
+      const int nok = min(T::TF, a.F - g * T::TF) * PPF;
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) {
+        const int r = tid + 256 * u;
+        if (r >= T::TF * PPF) continue;
+        const int fl = r / PPF, q = r - fl * PPF, hp = q / PG8, g8 = q - hp * PG8;
+        unsigned short* dx = xs + fl * T::FS + hp * T::CPL + 8 * g8;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(dx + p * T::XPL) = r < nok ? pv[p][u] : u32x4{0u, 0u, 0u, 0u};
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < T::IPW; ++u) {
       const int it = wave + 4 * u, fl = it / T::NCH, k = it - fl * T::NCH;
@@ -301,6 +328,13 @@ static void launch_fconv_r(const FcArgs& a, hipStream_t s) {
     if (a.cl_out && !a.st) {
       rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv_r<NPL, SITE, 0, true>), T::LDS);
       hipLaunchKernelGGL((k_fconv_r<NPL, SITE, 0, true>), dim3(grid), dim3(256), T::LDS, s, a);
+      return;
+    }
+  }
+  if constexpr (SITE == CV_D0G) {
+    if (a.cl_in) {   // (operand planes in: straight copy into the LDS image)
+      rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv_r<NPL, SITE, 0, false, true>), T::LDS);
+      hipLaunchKernelGGL((k_fconv_r<NPL, SITE, 0, false, true>), dim3(grid), dim3(256), T::LDS, s, a);
       return;
     }
   }

@@ -29,7 +29,8 @@
 #include "gfx950_fbwd.h"
 #include "gfx950_lnb_planes.h"
 #ifndef VAENPVC_LNB_PLANES
-#define VAENPVC_LNB_PLANES 7   // LayerNorm backward writing its consumers' operand planes itself: 1 encoder layer 4, 2 encoder layer 3, 4 decoder layer 0
+#define VAENPVC_LNB_PLANES 15   // LayerNorm backward writing its consumers' operand planes itself: 1 encoder layer 4, 2 encoder layer 3, 4 decoder layer 0,
+                               // 8 decoder layer 0 without the fp32 copy (its input-gradient kernel reads the planes)
 #endif
 #ifndef VAENPVC_SPLIT_SEGSUM
 #define VAENPVC_SPLIT_SEGSUM 1
@@ -372,6 +373,7 @@ static void for_planes(Fn&& fn) {
   }
 }
 constexpr int dense_planes(int npl) { return npl; }
+static inline int dense_planes_now() { return rt().dense_planes ? rt().dense_planes : dense_planes(rt().planes); }
 template <class Fn>
 static void for_dense_planes(Fn&& fn) {
   const int p = rt().dense_planes ? rt().dense_planes : dense_planes(rt().planes);
@@ -954,9 +956,13 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       }
     });
   };
-  auto rdgrad = [&](int site, const float* wpl, const float* grad, float* out, const char* tag) {   // medium site, register-weight fused kernel
+  auto rdgrad = [&](int site, const float* wpl, const float* grad, float* out, const char* tag, const float* planes_in = nullptr) {   // medium site, register-weight fused kernel
     for_dense_planes([&](auto npl) {
       FcArgs fa{grad, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const unsigned short*>(wpl), nullptr, out, F};
+      if (planes_in) {
+        fa.cl_in = reinterpret_cast<const unsigned short*>(planes_in);
+        fa.cl_plane = cl_plane(CVS[site].x, F);
+      }
       VAENPVC_TIMED(tag, s, fconv_r<decltype(npl)::value>(site, fa, s));
     });
   };
@@ -1098,9 +1104,17 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   // LayerNorm backward of decoder layer 0; with the view weight gradient behind it, the channel-last planes that kernel reads
   // leave the same pass (gfx950_lnb_planes.h) and the split pass over d(a0) goes away
   const bool gd0_planes = (VAENPVC_LNB_PLANES & 4) && !lnq && F >= 1024 && bwd_on(7) && bwd_on(8) && cw_bwd(CW_D0, F);
+  const bool gd0_only_planes = gd0_planes && (VAENPVC_LNB_PLANES & 8) && fcr_bwd(CV_D0G, F) && dense_planes_now() <= 2;
   auto lnb_dec0 = [&](const float* dy0) {
     const ConvL& pl = m.dec[0];
-    if (gd0_planes)
+    if (gd0_only_planes)   // (the input-gradient kernel reads the planes too: no fp32 copy of d(a0) at all)
+      for_dense_planes([&](auto npl) {
+        constexpr int NPL = decltype(npl)::value;
+        VAENPVC_TIMED("lnb_dec0", s, (launch_ln_bwd_planes<LnbCfg<32, 57>, NPL, CL_GD0, false>(dy0, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off,
+                                         w.d_dec_a[0], us(w.cl[CL_GD0]), cl_plane(CL_GD0, F), G + pl.gamma_off, G + pl.beta_off, G + pl.b_off,
+                                         w.scratch + Pk::lnpart, F, LWGS, s)));
+      });
+    else if (gd0_planes)
       for_dense_planes([&](auto npl) {
         constexpr int NPL = decltype(npl)::value;
         VAENPVC_TIMED("lnb_dec0", s, (launch_ln_bwd_planes<LnbCfg<32, 57>, NPL, CL_GD0, true>(dy0, w.dec_a[0], w.dec_st[0], P + pl.gamma_off, P + pl.beta_off,
@@ -1150,7 +1164,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     if (vw) vwgrad(CW_D0, G + l.w_off, "dec0_wgrad");
     else VAENPVC_TIMED("dec0_wgrad", s2, launch_convwgrad<WD0>(a, WGS, s2));
     if (!dec_bias_done[0]) generic::bias_grad(w.d_dec_a[0], G + l.b_off, F, l.cout, l.hout, s);
-    if (rg) rdgrad(CV_D0G, w.scratch + Pk::cvw + cv_woff(CV_D0G), w.d_dec_a[0], w.d_h, "dec0_dgrad");
+    if (rg) rdgrad(CV_D0G, w.scratch + Pk::cvw + cv_woff(CV_D0G), w.d_dec_a[0], w.d_h, "dec0_dgrad", gd0_only_planes ? w.cl[CL_GD0] : nullptr);
     else if (vg) vdgrad(CV_D0G, w.d_h, "dec0_dgrad");
     else
     VAENPVC_TIMED("dec0_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<GD0s>(conv_args(w.d_dec_a[0], nullptr, nullptr, nullptr, w.scratch + Pk::gd0,
