@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun) from the repo root: produces the text summaries that
 # are committed under profiles/ (kernel trace + three separate PMC passes + default bench + per-site table).
-# usage: scripts/profile_all.sh <round-tag> [trace|all]
+# usage: scripts/profile_all.sh <round-tag> [trace|step|all]   (step: only the large-batch train step: trace, PMC passes, site table, default bench)
 set -u
 TAG=${1:-r02}
 WHAT=${2:-all}
@@ -20,6 +20,13 @@ run_pass() {  # name, parser, rocprof args...
   if [ -n "$db" ]; then python $ROOT/scripts/$parser $db 70 > $OUT/${TAG}_$name.txt; else echo "no db for $name" > $OUT/${TAG}_$name.txt; fi
 }
 run_pass kernel_trace_stats rocpd_stats.py --kernel-trace --stats
+if [ "$WHAT" = step ]; then
+  run_pass pmc_sq rocpd_pmc.py --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+  run_pass pmc_fetch_lds rocpd_pmc.py --kernel-trace --pmc FETCH_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD
+  run_pass pmc_write rocpd_pmc.py --kernel-trace --pmc WRITE_SIZE
+  (cd $ROOT && timeout 300 python scripts/site_times.py > $OUT/${TAG}_site_times.txt 2>/dev/null)
+  (cd $ROOT && timeout 900 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err)
+fi
 if [ "$WHAT" = all ]; then
   run_pass pmc_sq rocpd_pmc.py --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
   run_pass pmc_fetch_lds rocpd_pmc.py --kernel-trace --pmc FETCH_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD

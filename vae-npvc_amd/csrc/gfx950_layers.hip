@@ -277,6 +277,9 @@ static inline bool cw_bwd(int site, int64_t F) { return cg_bwd(F) && cv_sel(rt()
 #ifndef VAENPVC_DZ_PLANES
 #define VAENPVC_DZ_PLANES 1   // the sampler backward writes the planes of [dz_mu | dz_lv] itself
 #endif
+#ifndef VAENPVC_TN_DENSE_XCD
+#define VAENPVC_TN_DENSE_XCD 1   // dense-shaped C += A^T B sites: the tiles of a row chunk on one XCD (they share the narrow operand)
+#endif
 #ifndef VAENPVC_D0F_CLOUT
 #define VAENPVC_D0F_CLOUT 1
 #endif
@@ -323,7 +326,7 @@ static TnpArgs tnp_args(const float* Ap, int lda, const float* Bp, int ldb, int 
   a.ldc = ldc;
   // XCD-aware tile order: measured -15 % where a row chunk has many tiles sharing both operands (layer 4: 7 x 3), +5..10 %
   // on the one-dimensional tilings (merge 1 x 7, heads 6 x 1)
-  a.xcd = rt().tn_xcd >= 0 ? rt().tn_xcd : (cdiv(M, 128) > 1 && cdiv(N, 256) > 1 ? 1 : 0);
+  a.xcd = rt().tn_xcd >= 0 ? rt().tn_xcd : (cdiv(M, 128) * cdiv(N, 256) > 1 ? VAENPVC_TN_DENSE_XCD : 0);
   a.tn4 = 0;
   return a;
 }

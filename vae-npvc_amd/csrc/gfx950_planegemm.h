@@ -1119,6 +1119,9 @@ inline void launch_gemm_tn32(TnpArgs a, int target_wgs, hipStream_t s) {
 // (R = INT_MAX): a stage is a scalar step in both operands.  The requests run up to five stages past the last row without
 // clamping: the plane buffers are sized for three planes (model.cpp), this kernel runs with at most two; rows >= F are
 // cleared in LDS before they are multiplied.  Workgroup order: XCD = row chunk (all tiles of a chunk share one L2).
+#ifndef VAENPVC_TN4_XCD
+#define VAENPVC_TN4_XCD 1
+#endif
 constexpr int tn4_stage(int npl) { return npl * 2 * W4_APL; }
 constexpr int tn4_lds(int npl) { return W4_NS * tn4_stage(npl) > 131072 ? W4_NS * tn4_stage(npl) : 131072; }   // ring (131 072 bytes at two planes) / the folded epilogue's four 32-KB tiles
 template <int NPL, int EPI>
@@ -1132,7 +1135,11 @@ __global__ void __launch_bounds__(256) k_gemm_tn4(TnpArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int ntm = cdiv(a.M, 256), ntt = ntm * cdiv(a.N, 256), nzc = gridDim.x / ntt;
-  const int zc = blockIdx.x % nzc, tl = blockIdx.x / nzc;
+  // every XCD walks a contiguous range of (chunk, tile) with the tile as the fast index: the tiles of a frame chunk -- they read the same
+  // rows of A and B -- share one L2 (the old order, chunk = blockIdx % chunks, spread them over all eight whenever the number of chunks
+  // was not a multiple of 8: encoder layer 4's weight gradient fetched 664 MB for 217 MB of operands)
+  const int wgx = VAENPVC_TN4_XCD ? xcd_contiguous(blockIdx.x, gridDim.x) : -1;
+  const int zc = VAENPVC_TN4_XCD ? wgx / ntt : blockIdx.x % nzc, tl = VAENPVC_TN4_XCD ? wgx - zc * ntt : blockIdx.x / nzc;
   const int m0 = (tl % ntm) * 256, n0 = (tl / ntm) * 256;
   const int fb = zc * a.fchunk, fe = min(a.F, fb + a.fchunk);
   if (fb >= fe) return;
