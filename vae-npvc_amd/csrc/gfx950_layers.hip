@@ -832,6 +832,7 @@ static TnArgs tn_args(const float* X, int ldx, const float* Y, int ldy, int M, i
 // kernel tails the chain leaves idle.  VAENPVC_SIDE_STREAM=0 disables the fork.
 // The stream and its event ring belong to the context (Runtime::side_stream, created lazily on the context's
 // device, destroyed with it).
+constexpr int SIDE_STREAM_MAX_FRAMES = 16384;
 static int kchunks_for(int F, int tiles) { return cmax(1, cmin_(cdiv(F, 64), 512 / tiles)); }  // 2 workgroups (64 KB LDS) per CU
 
 #ifndef VAENPVC_Z_PLANES
@@ -874,7 +875,11 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   (void)hipMemsetAsync(G, 0, (size_t)m.n_params * 4, s);
   // (bit 30 of the backward mask cleared = no fork for this call: serialised kernels, used by bench.py to
   //  time single kernels without concurrent neighbours)
-  hipStream_t side = bwd_on(30) ? rt().side_stream() : nullptr;
+  // (with two operand planes the fork LOSES from SIDE_STREAM_MAX_FRAMES frames on: the weight-gradient GEMMs hold a whole CU's LDS for
+  //  100+ us each and the chain's fused kernels (78 - 150 KB of LDS per workgroup) cannot move in beside them.  Measured same-box, step
+  //  with / without the second stream: 1 024 frames 1.07 / 1.16 ms, 4 096: 1.68 / 1.72, 8 192: 2.39 / 2.41, 16 384: 3.69 / 3.69,
+  //  32 768: 6.79 / 6.59; with one plane (bf16 mode) 4.74 / 4.86 and with three 10.37 / 10.81 at 32 768: the fork stays there)
+  hipStream_t side = bwd_on(30) && (F < SIDE_STREAM_MAX_FRAMES || dense_planes_now() != 2 || rt().side_forced) ? rt().side_stream() : nullptr;
   const bool fork = side != nullptr;
   hipStream_t s2 = fork ? side : s;   // weight-gradient stream
   auto ready = [&]() { if (fork) rt().stream_dep(s, s2); };   // "the tensors produced so far on s are ready for s2"

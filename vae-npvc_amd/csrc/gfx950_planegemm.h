@@ -504,6 +504,9 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nwg) {
 constexpr int nt_bk(int npl) { return npl >= 3 ? 32 : VAENPVC_NT_BK2; }
 constexpr int nt_lds(int npl) { return npl * (NT_BM + NT_BN) * (nt_bk(npl) * 2 + 16); }  // 73 728 (2 planes) / 61 440 (3)
 
+#ifndef VAENPVC_NT_CST
+#define VAENPVC_NT_CST 0   // 1: non-temporal result stores (the result streams past the L2 that holds the weight tiles)
+#endif
 #ifndef VAENPVC_NT_WPS
 #define VAENPVC_NT_WPS 2
 #endif
@@ -652,7 +655,7 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int m = m0 + wm * 64 + i * 32 + acc_row(reg, lane);
-        if (m < a.M) cb[(int64_t)m * a.ldc + nn] = acc[i][j][reg] + bb + rbv[reg];
+        if (m < a.M) st_nt<VAENPVC_NT_CST != 0>(cb + (int64_t)m * a.ldc + nn, acc[i][j][reg] + bb + rbv[reg]);
       }
     }
   }

@@ -51,6 +51,7 @@ struct Runtime {
   bool toep_wgrad_w4 = true;    // VAENPVC_TOEP_WGRAD_W4=0: the eight-wave kernel (64 x 64 wave tiles) at every batch size
   bool toep_wgrad_k16 = false;  // VAENPVC_TOEP_WGRAD_K16: 16-frame chunks in the bf16 weight gradient (A/B measurements)
   bool side_enabled = true;     // VAENPVC_SIDE_STREAM=0 disables the internal weight-gradient stream
+  bool side_forced = false;     // VAENPVC_SIDE_STREAM=1: the second stream at every batch size
   int frame_max = 512;          // VAENPVC_FRAME_MAX: largest batch on the whole-frame-per-workgroup kernels (gfx950_frame.h); 0 = never.
                                 // Bit 21 of a mask cleared = the layered kernels for that pass of this context (A/B, parity tests)
   // ---- what the last train forward of this context left in the workspace (vaenpvc_train_bwd_target re-uses it): batch size, kernel

@@ -15,7 +15,8 @@ RtScope::~RtScope() { tl_rt = prev; }
 
 // Developer knobs, read ONCE when the context is created (not process-global state):
 //   VAENPVC_FWD_MASK / VAENPVC_BWD_MASK   initial kernel-selection masks
-//   VAENPVC_SIDE_STREAM=0                 weight gradients on the caller's stream
+//   VAENPVC_SIDE_STREAM=0|1               weight gradients on the caller's stream / on the second stream at every batch size
+//                                         (default: second stream except for two-plane operands from 16 384 frames per call on)
 //   VAENPVC_TOEP=f32                      exact-fp32 MFMA kernels for the 1025-tap layer
 //   VAENPVC_TOEP_WGRAD_F32                exact-fp32 weight gradient of that layer only
 //   VAENPVC_PLANES=1|2|3                  bf16 terms per fp32 operand (vaenpvc_set_precision)
@@ -28,7 +29,10 @@ RtScope::~RtScope() { tl_rt = prev; }
 void Runtime::read_env() {
   if (const char* e = getenv("VAENPVC_FWD_MASK")) fwd_mask = (unsigned)strtoul(e, nullptr, 0);
   if (const char* e = getenv("VAENPVC_BWD_MASK")) bwd_mask = (unsigned)strtoul(e, nullptr, 0);
-  if (const char* e = getenv("VAENPVC_SIDE_STREAM")) side_enabled = e[0] != '0';
+  if (const char* e = getenv("VAENPVC_SIDE_STREAM")) {
+    side_enabled = e[0] != '0';
+    side_forced = side_enabled;   // explicitly on: at every batch size (default: gfx950_layers.hip, SIDE_STREAM_MAX_FRAMES)
+  }
   if (const char* e = getenv("VAENPVC_TOEP")) toep_f32 = !strcmp(e, "f32");
   toep_wgrad_f32 = getenv("VAENPVC_TOEP_WGRAD_F32") != nullptr;
   if (const char* e = getenv("VAENPVC_TOEP_ZC")) toep_zc = atoi(e) > 0 ? atoi(e) : 4;
