@@ -18,7 +18,9 @@
  *     to the caller's stream), so the caller observes plain stream order.  The stream and
  *     its events are created lazily on the device that is current at the context's first
  *     launch and destroyed by vaenpvc_ctx_destroy; VAENPVC_SIDE_STREAM=0 (read at context
- *     creation) or backward-mask bit 30 cleared keeps everything on the caller's stream;
+ *     creation) or backward-mask bit 30 cleared keeps everything on the caller's stream
+ *     (the library itself does so for two-term operands from 16 384 frames per call on,
+ *     where the fork measured slower; VAENPVC_SIDE_STREAM=1 forces the fork everywhere);
  *   - no mutable state outside the context: masks, precision, timer and the helper stream
  *     belong to the `vaenpvc_ctx`; entry points that take a context lock it for the
  *     duration of the call, so different contexts may be driven from different host
