@@ -853,14 +853,15 @@ bool reparam_fwd_planes(const Model& m, const float* eps, const PhiloxKey* key, 
 #ifndef VAENPVC_NLL_POST
 #define VAENPVC_NLL_POST 1
 #endif
-static inline int nll_post_blocks(int64_t F) { return cmin_(2048, cdiv((int)F, 4)); }
+static inline int nll_post_blocks(int64_t F) { return cmin_(1024, cdiv((int)F, 4)); }   // (each leaves a 16 KB part of the last layer's edge term)
 bool loss_fwd_post(const Model& m, const float* P, const float* x, int64_t F64, const Ws& w, float* loss3, hipStream_t s) {
   const int F = (int)F64;
-  if (!VAENPVC_NLL_POST || !w.d_xh || !w.toep_gp || !w.dy_tmp || F < 1024 || frame_bwd_on(F64) || !bwd_on(10) || !toep_bf16_for(F) || act_bf16(F)) return false;
+  if (!VAENPVC_NLL_POST || !w.d_xh || !w.toep_gp || !w.dy_tmp || !w.dec_y || !w.d_dec_a[0] || !fwd_on(9) || !fwd_on(10) || F < 1024 || frame_bwd_on(F64) || !bwd_on(10) || !toep_bf16_for(F) || act_bf16(F)) return false;
   for_planes([&](auto npl) {
     constexpr int NPL = decltype(npl)::value;
     hipLaunchKernelGGL((k_nll_dxh_post<NPL>), dim3((unsigned)nll_post_blocks(F)), dim3(256), 0, s, x, w.xh, w.nll_f, w.d_xh, P + m.dec[3].w_off,
-                       reinterpret_cast<unsigned short*>(w.toep_gp), w.dy_tmp, w.scratch + Pk::lnpart, F, 1.0f / (float)F);
+                       reinterpret_cast<unsigned short*>(w.toep_gp), w.dy_tmp, w.scratch + Pk::lnpart, F, 1.0f / (float)F, w.dec_y,
+                       w.d_dec_a[0]);   // (the edge-term parts wait in d(a0)'s buffer: nothing writes it before the backward pass has added them)
   });
   generic::loss_reduce(F, w, loss3, s);
   rt().dxh_post_F = F;
@@ -896,8 +897,9 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   const bool toep_planes = bwd_on(10) && toep_bf16_for(F);
   const bool post_done = toep_planes && rt().dxh_post_F == F;   // (the loss kernel of this step did it: loss_fwd_post)
   rt().dxh_post_F = -1;
-  if (post_done)
-    VAENPVC_TIMED("dxh_post", s, hipLaunchKernelGGL(k_colsum_part, dim3(1), dim3(256), 0, s, w.scratch + Pk::lnpart, nll_post_blocks(F), 1, G + m.dec[3].b_off));
+  if (post_done)   // bias parts and the parts of the weight gradient's edge term (row 512 of y) -> the gradient
+    VAENPVC_TIMED("dxh_post", s, hipLaunchKernelGGL(k_colsum_part, dim3(1), dim3(256), 0, s, w.scratch + Pk::lnpart, nll_post_blocks(F), 1, G + m.dec[3].b_off);
+                  hipLaunchKernelGGL(k_sum_parts_add, dim3((unsigned)cdiv(513 * 8, 64)), dim3(1024), 0, s, w.d_dec_a[0], nll_post_blocks(F), 513 * 8, G + m.dec[3].w_off));
   else if (toep_planes)
     for_planes([&](auto npl) {
       constexpr int NPL_ = decltype(npl)::value;
@@ -1019,6 +1021,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     }
     int ech = cmax(1, cmin_(cdiv(F, 64), 128));
     int efc = rup(cdiv(F, ech), 64);
+    if (!post_done)   // (else: the loss kernel left the edge term as parts, added with the bias parts above)
     VAENPVC_TIMED("dec3_row512", s2, hipLaunchKernelGGL(k_toep_wgrad_row512, dim3((unsigned)cdiv(F, efc), 3), dim3(256), 0, s2, w.dec_y, w.d_xh,
                                                        G + m.dec[3].w_off, F, efc));
     if (!toep_planes)  // (k_dxh_post computed it)

@@ -225,24 +225,39 @@ __global__ void __launch_bounds__(256) k_dxh_post(const float* __restrict__ G, c
 template <int NPL>
 __global__ void __launch_bounds__(256) k_nll_dxh_post(const float* __restrict__ x, const float* __restrict__ xh, float* __restrict__ nll_f,
                                                       float* __restrict__ G, const float* __restrict__ W, unsigned short* __restrict__ dst,
-                                                      float* __restrict__ dY, float* __restrict__ bpart, int F, float invF) {
+                                                      float* __restrict__ dY, float* __restrict__ bpart, int F, float invF,
+                                                      const float* __restrict__ y2,      // activated output of the layer in front ([F][8][513]: bin 512 is read)
+                                                      float* __restrict__ wpart) {       // [gridDim.x][513 * 8]: this workgroup's part of the edge term
+  //  dW[t][c] += sum_f y2[f][c][512] * d(xh)[f][t], t <= 512, of the last layer's weight gradient (k_toep_wgrad_row512 re-read d(xh) for it)
   __shared__ float sm[4];
+  __shared__ float wsum[65 * 64];   // [j * 8 + c][lane] (+ row 64: bin 512)
   constexpr float LOG2PI = 1.8378770664093453f;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float wt[8][TB_C];
-  {
-    const float* wp = W + (size_t)lane * 64;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-      for (int c = 0; c < TB_C; ++c) wt[j][c] = wp[j * TB_C + c];
+  // taps of this lane's 8 bins, all 8 channels (W[(8l + j)*8 + c]): the same for the four waves -> one LDS copy [j][c / 4][lane][4],
+  // read back as 16-byte pieces per frame (in registers they cost a wave per SIMD: 177 registers with the edge-term accumulators)
+  __shared__ __attribute__((aligned(16))) float wts[16 * 64 * 4];
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int l = i >> 6, jc = i & 63;          // consecutive threads: consecutive floats of W
+    wts[((jc >> 2) * 64 + l) * 4 + (jc & 3)] = W[i];
   }
+  __syncthreads();
   float wl[TB_C];  // bin 512 (lane 0)
 #pragma unroll
   for (int c = 0; c < TB_C; ++c) wl[c] = W[512 * TB_C + c];
   const float gs = -invF / (1.0f + EPSILON);
   float bsum = 0.f;
-  for (int f = blockIdx.x * 4 + wv; f < F; f += gridDim.x * 4) {
+  float wacc[8][TB_C], wtl[TB_C];
+#pragma unroll
+  for (int c = 0; c < TB_C; ++c) {
+    wtl[c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wacc[j][c] = 0.f;
+  }
+  for (int f = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv); f < F; f += gridDim.x * 4) {
+    asm volatile("" ::: "memory");   // (keeps the tap reads below inside the loop: hoisted they are 64 registers again)
+    float yv[TB_C];
+#pragma unroll
+    for (int c = 0; c < TB_C; ++c) yv[c] = y2[(int64_t)f * (TB_C * TB_H) + c * TB_H + 512];   // wave-uniform
     const float* xf = x + (int64_t)f * TB_H;
     const float* hf = xh + (int64_t)f * TB_H;
     const packed4 a0 = *reinterpret_cast<const packed4*>(xf + 8 * lane), a1 = *reinterpret_cast<const packed4*>(xf + 8 * lane + 4);
@@ -274,9 +289,16 @@ __global__ void __launch_bounds__(256) k_nll_dxh_post(const float* __restrict__ 
     for (int j = 0; j < 8; ++j) {
       split_n<NPL>(g[j], tm[j]);
       sfr += g[j];
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wts[((j * 2) * 64 + lane) * 4]), w1 = *reinterpret_cast<const f32x4*>(&wts[((j * 2 + 1) * 64 + lane) * 4]);
+      const float wtj[TB_C] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
 #pragma unroll
-      for (int c = 0; c < TB_C; ++c) dot[c] += g[j] * wt[j][c];
+      for (int c = 0; c < TB_C; ++c) {
+        dot[c] += g[j] * wtj[c];
+        wacc[j][c] += g[j] * yv[c];
+      }
     }
+#pragma unroll
+    for (int c = 0; c < TB_C; ++c) wtl[c] += gt * yv[c];
     bsum += sfr;
     unsigned short* dd = dst + (int64_t)f * (NPL * TB_KP);
 #pragma unroll
@@ -306,8 +328,49 @@ __global__ void __launch_bounds__(256) k_nll_dxh_post(const float* __restrict__ 
   }
   bsum = wave_sum(bsum);
   if (lane == 0) sm[wv] = bsum;
-  __syncthreads();
+  // the four waves' edge-term partials meet in LDS one after the other (plain read-modify-write, conflict-free rows)
+#pragma unroll 1
+  for (int w4 = 0; w4 < 4; ++w4) {
+    if (wv == w4) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int c = 0; c < TB_C; ++c) {
+          float* r = &wsum[(j * TB_C + c) * 64 + lane];
+          *r = w4 == 0 ? wacc[j][c] : *r + wacc[j][c];
+        }
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < TB_C; ++c) wsum[64 * 64 + c] = w4 == 0 ? wtl[c] : wsum[64 * 64 + c] + wtl[c];
+      }
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) bpart[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  float* wp = wpart + (int64_t)blockIdx.x * (513 * TB_C);
+  for (int e = threadIdx.x; e < 513 * TB_C; e += 256) {   // e = t * 8 + c, t = 8 * lane + j
+    const int t = e >> 3, c = e & 7;
+    wp[e] = t < 512 ? wsum[((t & 7) * TB_C + c) * 64 + (t >> 3)] : wsum[64 * 64 + c];
+  }
+}
+// out[i] += sum over parts (atomic: other kernels add to the same gradient): 64 columns per workgroup, sixteen waves deal the parts
+__global__ void __launch_bounds__(1024) k_sum_parts_add(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (i < n) {
+#pragma unroll 8
+    for (int c = wave; c < nparts; c += 16) acc += part[(int64_t)c * n + i];
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][lane];
+    atomicAdd(out + i, t);
+  }
 }
 
 // ---- shifted bf16 copies of the tap rows: dst[c][plane][s][m] = plane(w[c][m + s]), m < 8*TB_CHUNKS.
