@@ -272,6 +272,9 @@ __global__ void __launch_bounds__(256) k_enc0_wgrad_wave(const float* __restrict
 //   phase 2 (lane = channel o = lane & 15, quarter of the positions): dW[t][o] += x[3j + t - 2] * du[o][j] from LDS,
 //            seven accumulators per lane over all frames of the wave.
 // No workgroup barrier inside the frame loop (a wave only touches its own LDS tile).
+#ifndef VAENPVC_ENC0_BLOCKED
+#define VAENPVC_ENC0_BLOCKED 1
+#endif
 struct Enc0BwdCfg {
   static constexpr int H = 513, HO = 171, CO = 16, N = CO * HO, DP = 172, XS = 528, WAVE_FLOATS = CO * DP + XS;
   static constexpr int LDS_BYTES = 4 * WAVE_FLOATS * 4, NW = 7 * CO, NC = 3 * CO, JQ = 43;
@@ -313,6 +316,52 @@ __global__ void __launch_bounds__(256, 2) k_enc0_bwd_wave(const float* __restric
       if (i < H) xs[2 + i] = xf[i];
     }
     float s1 = 0.f, s2 = 0.f;
+#if VAENPVC_ENC0_BLOCKED
+    // The 160 layer parameters are uniform values.  All live at once they do not fit the scalar file: the compiler parked them in
+    // vector-register lanes and fetched them back with v_readlane -- 782 of the frame loop's 2 343 vector instructions.  Walking the
+    // channels in blocks of four through LAUNDERED pointers (the compiler cannot hoist the loads out of the frame loop, so only one
+    // block's 40 parameters are live, as scalar loads from the constant cache) leaves the vector ALUs to the arithmetic.
+    float xt[3][7];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int j = lane + 64 * k;
+#pragma unroll
+      for (int t = 0; t < 7; ++t) xt[k][t] = xs[(j < HO ? 3 * j : 0) + t];
+    }
+#pragma unroll
+    for (int ob = 0; ob < CO; ob += 4) {
+      const float *Wp = W, *bp = bias, *gp = gamma, *btp = beta;
+      asm volatile("" : "+s"(Wp), "+s"(bp), "+s"(gp), "+s"(btp));
+      float Wl[7][4], bl[4], gl[4], bel[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bl[q] = bp[ob + q];
+        gl[q] = gp[ob + q];
+        bel[q] = btp[ob + q];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) Wl[t][q] = Wp[t * CO + ob + q];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int j = lane + 64 * k;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int o = ob + q;
+          float a0 = bl[q];
+#pragma unroll
+          for (int t = 0; t < 7; ++t) a0 += Wl[t][q] * xt[k][t];
+          const float xv = j < HO ? (a0 - mean) * rstd : 0.f;
+          const float nn = xv * gl[q] + bel[q];
+          const float dv = dn[k][o] * (nn >= 0.f ? 1.0f : LEAK);
+          const float dx = dv * gl[q];
+          s1 += dx;
+          s2 += dx * xv;
+          dn[k][o] = dv;
+          xh[k][o] = xv;
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int j = lane + 64 * k;
@@ -336,6 +385,7 @@ __global__ void __launch_bounds__(256, 2) k_enc0_bwd_wave(const float* __restric
         xh[k][o] = xv;
       }
     }
+#endif
     s1 = wave_sum(s1) * (1.0f / N);
     s2 = wave_sum(s2) * (1.0f / N);
 #pragma unroll
