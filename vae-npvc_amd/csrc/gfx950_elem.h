@@ -330,8 +330,10 @@ __global__ void __launch_bounds__(256, 2) k_enc0_bwd_wave(const float* __restric
     }
 #pragma unroll
     for (int ob = 0; ob < CO; ob += 4) {
-      const float *Wp = W, *bp = bias, *gp = gamma, *btp = beta;
-      asm volatile("" : "+s"(Wp), "+s"(bp), "+s"(gp), "+s"(btp));
+      typedef const __attribute__((address_space(4))) float* cptr;   // constant address space: uniform loads become scalar loads
+      unsigned long long w0 = (unsigned long long)W, b0 = (unsigned long long)bias, g0 = (unsigned long long)gamma, t0 = (unsigned long long)beta;
+      asm volatile("" : "+s"(w0), "+s"(b0), "+s"(g0), "+s"(t0));
+      const cptr Wp = (cptr)w0, bp = (cptr)b0, gp = (cptr)g0, btp = (cptr)t0;
       float Wl[7][4], bl[4], gl[4], bel[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
