@@ -176,22 +176,42 @@ __global__ void __launch_bounds__(256) k_enc0_fwd_wave(const float* __restrict__
     const float* xf = x + (int64_t)f * H;
     float v[3][CO];
     float s = 0.f;
+    float xt[3][7];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int j = lane + 64 * k;
-      float xt[7];
 #pragma unroll
       for (int t = 0; t < 7; ++t) {
         const int i = 3 * j + t - 2;
-        xt[t] = (j < HO && i >= 0 && i < H) ? xf[i] : 0.f;
+        xt[k][t] = (j < HO && i >= 0 && i < H) ? xf[i] : 0.f;
+      }
+    }
+    // channel blocks of four with the block's 32 parameters as scalar loads (see k_enc0_bwd_wave: all 128 live at once were parked in
+    // vector-register lanes, 504 v_readlane / v_writelane per frame)
+#pragma unroll
+    for (int ob = 0; ob < CO; ob += 4) {
+      typedef const __attribute__((address_space(4))) float* cptr;
+      unsigned long long w0 = (unsigned long long)W, b0 = (unsigned long long)bias;
+      asm volatile("" : "+s"(w0), "+s"(b0));
+      const cptr Wp = (cptr)w0, bp = (cptr)b0;
+      float Wl[7][4], bl[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bl[q] = bp[ob + q];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) Wl[t][q] = Wp[t * CO + ob + q];
       }
 #pragma unroll
-      for (int o = 0; o < CO; ++o) {
-        float acc = bias[o];
+      for (int k = 0; k < 3; ++k) {
+        const int j = lane + 64 * k;
 #pragma unroll
-        for (int t = 0; t < 7; ++t) acc += W[t * CO + o] * xt[t];
-        v[k][o] = j < HO ? acc : 0.f;
-        s += v[k][o];
+        for (int q = 0; q < 4; ++q) {
+          float acc = bl[q];
+#pragma unroll
+          for (int t = 0; t < 7; ++t) acc += Wl[t][q] * xt[k][t];
+          v[k][ob + q] = j < HO ? acc : 0.f;
+          s += v[k][ob + q];
+        }
       }
     }
     const float mean = wave_sum(s) * (1.0f / N);

@@ -1456,13 +1456,35 @@ __global__ void __launch_bounds__(256, 2) k_cgemm(CgArgs a) {
   }
   // epilogue: accumulator rows = GEMM rows m, lanes = 32 consecutive (frame, position) rows.  The bias values of the rows a
   // lane stores are fetched BEFORE the first store (a load between stores orders the later ones behind its round trip)
+  // (phase, channel) of a row: with mdiv a multiple of 32 the 32 rows of an MFMA tile share their phase -- ONE uniform division per
+  // tile instead of one per accumulator register and lane (a runtime integer division is ~28 vector instructions: the 2 x MT x 16
+  // of them, 3 400 instructions, took longer than the tile's MFMA loop; round 4)
+  const bool m32 = (a.mdiv & 31) == 0;   // uniform
+  int pimI[MT], chbI[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int mb = __builtin_amdgcn_readfirstlane(m0 + wm * MT * 32 + i * 32);
+    pimI[i] = mb / a.mdiv;
+    chbI[i] = mb - pimI[i] * a.mdiv;
+  }
+  auto row_of = [&](int i, int reg, int& pim, int& ch) __attribute__((always_inline)) {
+    if (m32) {
+      pim = pimI[i];
+      ch = chbI[i] + acc_row(reg, lane);
+    } else {
+      const int m = m0 + wm * MT * 32 + i * 32 + acc_row(reg, lane);
+      pim = m / a.mdiv;
+      ch = m - pim * a.mdiv;
+    }
+  };
   float bvc[MT][16];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int m = m0 + wm * MT * 32 + i * 32 + acc_row(reg, lane);
-      const int ch = m % a.mdiv;
+      int pim, ch;
+      row_of(i, reg, pim, ch);
       bvc[i][reg] = (a.bias && m < a.M && ch < a.C) ? a.bias[ch] : 0.f;
     }
 #pragma unroll
@@ -1478,7 +1500,8 @@ __global__ void __launch_bounds__(256, 2) k_cgemm(CgArgs a) {
       for (int reg = 0; reg < 16; ++reg) {
         const int m = m0 + wm * MT * 32 + i * 32 + acc_row(reg, lane);
         if (m >= a.M) continue;
-        const int pim = m / a.mdiv, ch = m - pim * a.mdiv;
+        int pim, ch;
+        row_of(i, reg, pim, ch);
         const int pos = pbase + pim * a.o0s;
         if (ch < a.C && pos >= 0 && pos < a.OH) ob[(int64_t)ch * a.om + pos] = acc[i][j][reg] + bvc[i][reg];
       }
