@@ -80,7 +80,10 @@ SITE_GROUPS = {
                    + (_E['e0'] + _E['x']))),
     'layernorm_backward (separate LayerNorm + lrelu backward passes: decoder layer 0, encoder layers 2-4)': dict(
         tags='lnb_dec0 lnb_enc4 lnb_enc3 lnb_enc2 lnb_enc1', bound='hbm',
-        bytes=4 * 3 * (_E['d0'] + _E['e4'] + _E['e3'] + _E['e2']), moved_not_algorithmic=True),
+        # reads: d(activated output) + pre-LN tensor (fp32); writes: the consumers' operand planes (2 x bf16; channel-last with halo rows for
+        # decoder 0: 63 x 32, encoder 3: 10 x 128; plain rows for encoder 4) or the fp32 gradient (encoder 2)
+        bytes=4 * 2 * (_E['d0'] + _E['e4'] + _E['e3'] + _E['e2']) + 2 * 2 * (63 * 32 + 10 * 128 + _E['e4']) + 4 * _E['e2'],
+        moved_not_algorithmic=True),
     'weight_packing (per-step packed / split copies of the parameters)': dict(tags='prep', bound='hbm', bytes_per_step=10 * 939162 * 4),
 }
 
