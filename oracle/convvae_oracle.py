@@ -326,7 +326,15 @@ def torch_convT_same(x, W, b, s):
     return full[:, :, pad:pad + ho, :] + b.reshape(1, -1, 1, 1)
 
 
-def torch_encode(arch, P, x, kink=None):
+def _tape(tape, name, t):
+    """tape: optional dict; records, under the NAME of an additive parameter (conv / dense bias, LayerNorm offset), the tensor
+    that parameter is broadcast-added into, with its gradient retained (see torch_loss_and_grads(sum_scales=True))"""
+    if tape is not None:
+        t.retain_grad()
+        tape[name] = t
+
+
+def torch_encode(arch, P, x, kink=None, tape=None):
     """kink: optional {'tau': t, 'enc<i>': bool [F,C,H,1], 'dec<i>': ...} branch pins for torch_lrelu"""
     g = geometry(arch)
     F = x.shape[0]
@@ -336,15 +344,19 @@ def torch_encode(arch, P, x, kink=None):
         p = 'Encoder/Conv2d-%d/' % i
         a = torch_conv_same(cur, P[p + 'kernel'], P[p + 'bias'], l['s'])
         n = torch_layernorm(a, P[p + 'layernorm.offset'], P[p + 'layernorm.scale'])
+        _tape(tape, p + 'bias', a)
+        _tape(tape, p + 'layernorm.offset', n)
         cur = torch_lrelu(n) if kink is None else torch_lrelu(n, kink['enc%d' % i], kink['tau'])
         acts.append((a, cur))
     flat = cur.reshape(F, -1)
     z_mu = flat @ P['Encoder/dense/kernel'] + P['Encoder/dense/bias']
     z_lv = flat @ P['Encoder/dense_1/kernel'] + P['Encoder/dense_1/bias']
+    _tape(tape, 'Encoder/dense/bias', z_mu)
+    _tape(tape, 'Encoder/dense_1/bias', z_lv)
     return z_mu, z_lv, acts
 
 
-def torch_decode(arch, P, z, y, kink=None):
+def torch_decode(arch, P, z, y, kink=None, tape=None):
     torch = _torch()
     g = geometry(arch)
     F = z.shape[0]
@@ -352,14 +364,18 @@ def torch_decode(arch, P, z, y, kink=None):
     h = (z @ P['Generator/fully_connected/weights'] + P['Generator/fully_connected/biases']
          + e @ P['Generator/fully_connected_1/weights'] + P['Generator/fully_connected_1/biases']
          + P['Generator/BiasAdd/biases'])
+    for nm in ('Generator/fully_connected/biases', 'Generator/fully_connected_1/biases', 'Generator/BiasAdd/biases'):
+        _tape(tape, nm, h)
     cur = h.reshape(F, g['dec'][0]['cin'], g['dec'][0]['hin'], 1)
     nd = len(g['dec'])
     acts = [h]
     for i, l in enumerate(g['dec']):
         p = 'Generator/conv2d_transpose%s/' % ('' if i == 0 else '_%d' % i)
         a = torch_convT_same(cur, P[p + 'kernel'], P[p + 'bias'], l['s'])
+        _tape(tape, p + 'bias', a)
         if i < nd - 1:
             n = torch_layernorm(a, P['Generator/ConvT-LN%d.offset' % i], P['Generator/ConvT-LN%d.scale' % i])
+            _tape(tape, 'Generator/ConvT-LN%d.offset' % i, n)
             cur = torch_lrelu(n) if kink is None else torch_lrelu(n, kink['dec%d' % i], kink['tau'])
             acts.append(a)
         else:
@@ -367,12 +383,12 @@ def torch_decode(arch, P, z, y, kink=None):
     return cur.reshape(F, -1), acts
 
 
-def torch_loss(arch, P, x, y, eps, kink=None):
+def torch_loss(arch, P, x, y, eps, kink=None, tape=None):
     """model/vae.py:106-137 -> dict(G, D_KL, logP, z_mu, z_lv, xh)."""
     torch = _torch()
-    z_mu, z_lv, _ = torch_encode(arch, P, x, kink)
+    z_mu, z_lv, _ = torch_encode(arch, P, x, kink, tape)
     z = z_mu + eps * torch.sqrt(torch.exp(z_lv))
-    xh, _ = torch_decode(arch, P, z, y, kink)
+    xh, _ = torch_decode(arch, P, z, y, kink, tape)
     kld = 0.5 * ((0.0 - z_lv) + (torch.exp(z_lv) + z_mu ** 2) / (1.0 + EPSILON) - 1.0)
     D_KL = kld.sum(-1).mean()
     lp = -0.5 * (LOG_2PI + (x.reshape(x.shape[0], -1) - xh) ** 2 / (1.0 + EPSILON))
@@ -380,9 +396,16 @@ def torch_loss(arch, P, x, y, eps, kink=None):
     return dict(G=-logP + D_KL, D_KL=D_KL, logP=logP, z_mu=z_mu, z_lv=z_lv, xh=xh, z=z)
 
 
-def torch_loss_and_grads(arch, P_np, x, y, eps, dtype=None, kink=None):
+def torch_loss_and_grads(arch, P_np, x, y, eps, dtype=None, kink=None, sum_scales=False):
     """Returns (losses dict of floats/arrays, OrderedDict name -> grad ndarray).  kink: see torch_encode / torch_lrelu
-    (branch pins as bool ndarrays [F,C,H], plus 'tau')."""
+    (branch pins as bool ndarrays [F,C,H], plus 'tau').
+
+    sum_scales=True returns a third value: for every ADDITIVE parameter b (conv / dense biases, LayerNorm offsets, the three
+    merge biases), whose gradient is the plain sum of the upstream gradient d over the broadcast axes,
+    dG/db[c] = sum_{f,h} d[f,c,h], the array  S[c] = sum_{f,h} |d[f,c,h]|  (same shape as b).  Such a sum cancels towards 0
+    as a fit converges, so it has no scale of its own: the error of ANY finite-precision evaluation of it is bounded by
+    (relative error of a term) x S[c], never by a fraction of |dG/db|.  S is the scale a comparison of these tensors is
+    measured on where the gradient itself has cancelled away (tests/test_gpu_frame.py)."""
     torch = _torch()
     if kink is not None:
         kink = {k: (v if k == 'tau' else torch.as_tensor(np.asarray(v)).reshape(v.shape[0], v.shape[1], v.shape[2], 1))
@@ -392,12 +415,22 @@ def torch_loss_and_grads(arch, P_np, x, y, eps, dtype=None, kink=None):
     xt = torch.tensor(np.asarray(x), dtype=dtype)
     yt = torch.tensor(np.asarray(y), dtype=torch.int64)
     et = torch.tensor(np.asarray(eps), dtype=dtype)
-    L = torch_loss(arch, P, xt, yt, et, kink)
+    tape = {} if sum_scales else None
+    L = torch_loss(arch, P, xt, yt, et, kink, tape)
     L['G'].backward()
     grads = OrderedDict((k, (v.grad if v.grad is not None else torch.zeros_like(v)).numpy().copy())
                         for k, v in P.items())
     out = {k: v.detach().numpy().copy() for k, v in L.items()}
-    return out, grads
+    if not sum_scales:
+        return out, grads
+    scales = OrderedDict()
+    for k, t in tape.items():
+        d = t.grad.abs()
+        if d.dim() == 4:      # [F,C,H,1] -> per channel
+            scales[k] = d.sum(dim=(0, 2, 3)).numpy().reshape(P[k].shape)
+        else:                 # [F,N] -> per column
+            scales[k] = d.sum(dim=0).numpy().reshape(P[k].shape)
+    return out, grads, scales
 
 
 def tf_adam_step(p, g, m, v, t, lr=1e-4, b1=0.5, b2=0.999, eps=1e-8):

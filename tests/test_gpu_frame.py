@@ -211,7 +211,7 @@ def oracle_adam_trajectory(arch, F, seed, steps):
     return P0, P, (x, y, eps), np.array(losses)
 
 
-@pytest.mark.parametrize('path', ['frame', 'layered'])
+@pytest.mark.parametrize('path', ['frame', 'layered', 'layered-bf16x2'])
 def test_twenty_adam_steps_follow_the_float64_oracle(path):
     """20 Adam steps on one fixed 16-frame batch, on the frame kernels and on the layered kernels (mask bit 21 cleared), each
     against the float64 ORACLE -- never against each other: two fp32 trajectories of this optimiser drift apart chaotically
@@ -223,7 +223,14 @@ def test_twenty_adam_steps_follow_the_float64_oracle(path):
       * at EVERY step the loss triple (1e-4) and all 44 gradient tensors (2e-4 of the tensor's largest entry, kink units
         pinned to the GPU's branch) meet float64 evaluated at the GPU's own parameters of that step -- this catches state
         that goes stale between steps (packed weights, tables), which no single-step test can;
-      * the run is finite, falls, and its loss stays within 1e-2 of the float64 run (a sanity bound, see TRAJ_DRIFT_TOL)."""
+      * the run is finite, falls, and its loss stays within 1e-2 of the float64 run (a sanity bound, see TRAJ_DRIFT_TOL).
+    'layered-bf16x2' is the BENCHMARKED precision (2-term operands) on the layered kernels.  Its bars are the same, with one
+    stated difference: the 22 ADDITIVE parameters (conv / dense / merge biases, LayerNorm offsets) are measured on the scale
+    S[c] = sum_{f,h} |d[f,c,h]| of the sum they are (oracle.torch_loss_and_grads(sum_scales=True)), like the one-entry bias of
+    the last layer on every path.  Their gradient sum_{f,h} d[f,c,h] cancels towards 0 as the fit converges while the terms
+    keep their size, so an upstream operand error of ~1e-5 per term is a growing fraction of what is left of the sum
+    (measured: 3.6e-4 of the tensor's largest entry after ~15 steps, 0 kink flips) although it stays ~1e-5 of S.  The error
+    on the tensor's own scale is reported beside it, not asserted."""
     from hipvae import Engine
     from hipvae.dp import Stepper
     from test_gpu_parity import gpu_branches
@@ -233,7 +240,8 @@ def test_twenty_adam_steps_follow_the_float64_oracle(path):
     # (the layered kernels with 3-term operands = fp32-exact, like the frame kernels: what is tested here is state carried
     #  between steps, not operand precision -- with the default 2-term operands the bias gradients, sums that cancel to
     #  ~0 as training proceeds, leave the per-tensor bar after ~15 steps: 3.6e-4 of the tensor's largest entry, measured)
-    eng = Engine(arch, precision=None if path == 'frame' else 'bf16x3')
+    eng = Engine(arch, precision={'frame': None, 'layered': 'bf16x3', 'layered-bf16x2': 'bf16x2'}[path])
+    sum_scaled = path == 'layered-bf16x2'
     mask = 0xffffffff if path == 'frame' else 0xffffffff & ~(1 << 21)
     eng.set_tuned_masks(mask, mask)
     eng.load_flat(O.flatten_params(P0))
@@ -248,13 +256,13 @@ def test_twenty_adam_steps_follow_the_float64_oracle(path):
     report('trajectory %s repeatability of one evaluation (30 calls)' % path, rep, TRAJ_REPEAT_TOL)
     assert rep <= TRAJ_REPEAT_TOL, (path, rep)
     fails, got = [], []
-    e_grad = e_loss = 0.0
+    e_grad = e_loss = e_own = 0.0
     for t in range(TRAJ_STEPS):
         P = O.unflatten_params(arch, eng.params.cpu().numpy())
         l3 = st.step(xt, yt, et).clone().cpu().numpy().astype(np.float64)
         got.append(l3)
         g = st.grads.cpu().numpy()
-        L, G = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64, kink=gpu_branches(eng, arch, P, F))
+        L, G, S = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64, kink=gpu_branches(eng, arch, P, F), sum_scales=True)
         e_loss = max(e_loss, rel_err(l3, np.array([L['G'], L['D_KL'], L['logP']])))
         for name, (off, shape) in eng.layout.items():
             n = int(np.prod(shape))
@@ -263,7 +271,12 @@ def test_twenty_adam_steps_follow_the_float64_oracle(path):
                 # drives through zero -- a sum with cancellation has no scale of its own; its error bound is (relative error
                 # of a term) x (sum of the terms' magnitudes), so that sum is the scale it is measured on
                 scale = np.abs((L['xh'] - x) / ((1 + 1e-6) * F)).sum()
+                assert abs(scale - float(S[name].ravel()[0])) <= 1e-9 * scale     # the same scale, from the autograd tape
                 e = abs(float(g[off]) - float(G[name].ravel()[0])) / scale
+            elif sum_scaled and name in S:
+                d = np.abs(g[off:off + n].reshape(shape) - G[name])
+                e = float(d.max() / S[name].max())
+                e_own = max(e_own, rel_err(g[off:off + n].reshape(shape), G[name]))
             else:
                 e = rel_err(g[off:off + n].reshape(shape), G[name])
             e_grad = max(e_grad, e)
@@ -271,6 +284,8 @@ def test_twenty_adam_steps_follow_the_float64_oracle(path):
                 fails.append('step %d grad %s: %.3e' % (t, name, e))
     report('trajectory %s per-step loss3 at the GPU parameters (20 steps)' % path, e_loss, TOL_ACT)
     report('trajectory %s per-step worst gradient tensor (20 steps)' % path, e_grad, TOL_GRAD)
+    if sum_scaled:
+        report('trajectory %s additive parameters on their OWN largest entry (reported, not a bar)' % path, e_own, float('inf'))
     got = np.array(got)
     drift = (np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max()
     report('trajectory %s loss drift against the float64 run (20 steps)' % path, drift, TRAJ_DRIFT_TOL)

@@ -542,7 +542,7 @@ UNFILTERED_SHARE_SLACK = 2e-4     # share of the ~53 k sampled entries a path ma
 # evaluation of the SAME batch: measured worst tensor 3.1e-4 (the speaker embedding; fp32 CPU restatement 5.5e-5), 9 of
 # 52 850 sampled entries above 2e-4, median 3.2e-6.  Stated, not hidden: the fp32-exact mode (bf16x3) is held to the
 # float32 restatement's own numbers.
-UNFILTERED_X2_TENSOR_BAR = 5e-4
+UNFILTERED_X2_TENSOR_BAR = 3e-4   # round 5: was 5e-4; measured 2.5e-4 (y_emb) on the round-4 gate boxes
 UNFILTERED_X2_SHARE_BAR = 5e-4
 
 
@@ -561,7 +561,11 @@ def test_unfiltered_benchmark_batch_statistics(precision):
       (3) over all sampled entries: the share of entries off by more than 2e-4 of their tensor's scale is at most
           the float32 CPU restatement's share + UNFILTERED_SHARE_SLACK [bf16x3] / UNFILTERED_X2_SHARE_BAR [bf16x2];
       (4) the median error stays at rounding level (<= 2e-5): kinks are rare events, not a shift.
-    (The mechanism itself -- flips counted, pinned, plain bar -- is tested at 2 048 frames by
+      (5) the kink flips themselves are COUNTED at this batch size: the fixture of make_golden_kink_units.py lists the
+          ~50 k of the batch's 607 M lrelu units whose float64 LayerNorm output lies within 1e-4 of the kink (only those can
+          flip: asserted at 2 048 frames by the mechanism test); the GPU's branch at exactly those units is recomputed in
+          float64 from the GPU's own pre-LN values and statistics, and flips / all units <= KINK_FLIP_RATE_BAR.
+    (The mechanism itself -- flips counted over ALL units, pinned, plain bar -- is tested at 2 048 frames by
     test_kink_flips_explain_the_unfiltered_gradient_excess, where the float64 oracle runs inside the test.)"""
     from hipvae import lib as L
     F, seed = 32768, 23
@@ -607,6 +611,32 @@ def test_unfiltered_benchmark_batch_statistics(precision):
     report(tag + 'median entry error (fp32 CPU restatement: %.1e)' % np.median(errs32), med, 2e-5)
     if med > 2e-5:
         fails.append('median error %.3e' % med)
+    # (5) flips among the near-kink units of the fixture
+    ku = np.load(os.path.join(GOLDEN, 'vcc2016_F%d_seed%d_kink_units.npz' % (F, seed)))
+    assert float(ku['tau']) == KINK_TAU
+    g_ = O.geometry(arch)
+    flips = units = near = 0
+    for net, layers, pre in (('enc', g_['enc'], 'Encoder/Conv2d-%d/layernorm'), ('dec', g_['dec'][:-1], 'Generator/ConvT-LN%d')):
+        for i, l in enumerate(layers):
+            k = '%s%d' % (net, i)
+            idx = torch.as_tensor(ku[k + '_idx'].astype(np.int64), device=eng.device)
+            per = l['cout'] * l['hout']
+            a = eng.ws_region(F, L.MODE_TRAIN, '%s_a%d' % (net, i)).view(-1)[idx].cpu().numpy().astype(np.float64)
+            st = eng.ws_region(F, L.MODE_TRAIN, '%s_st%d' % (net, i)).view(F, 2).cpu().numpy().astype(np.float64)
+            fr = ku[k + '_idx'].astype(np.int64) // per
+            ch = (ku[k + '_idx'].astype(np.int64) % per) // l['hout']
+            gam = np.asarray(P[(pre % i) + '.scale'], np.float64).ravel()[ch]
+            bet = np.asarray(P[(pre % i) + '.offset'], np.float64).ravel()[ch]
+            n_gpu = (a - st[fr, 0]) * st[fr, 1] * gam + bet
+            n_ref = ku[k + '_n']
+            # sanity of the index plumbing: the GPU's n is the float64 n up to the evaluation's own error
+            assert np.abs(n_gpu - n_ref).max() < 1e-3, (k, np.abs(n_gpu - n_ref).max())
+            fl = int(((n_gpu >= 0) != (n_ref >= 0)).sum())
+            flips, units, near = flips + fl, units + int(ku[k + '_units']), near + idx.numel()
+    rate = flips / units
+    report(tag + 'kink flips: %d of the %d near-kink units (%d units in all); rate' % (flips, near, units), rate, KINK_FLIP_RATE_BAR[precision])
+    if rate > KINK_FLIP_RATE_BAR[precision]:
+        fails.append('kink flip rate %.2e > %.2e' % (rate, KINK_FLIP_RATE_BAR[precision]))
     assert not fails, '\n'.join(fails)
 
 

@@ -174,6 +174,14 @@ def test_backward_only_call_needs_a_matching_train_step():
     assert ((grads - g1).abs().max() / g1.abs().max()).item() < 1e-5
     with pytest.raises(L.HipVaeError, match='no matching train step'):
         eng.train_bwd_target(xt[:16], yt[:16], et[:16], xt[:16], grads)   # another batch size
+    # a forward-only entry point on the same context may overwrite activations / planes of the train step (round-4 advisor)
+    for fwd_only in (lambda: eng.loss_fwd(xt, yt, et), lambda: eng.encode(xt)):
+        eng.train_fwd_bwd(xt, yt, et, grads)
+        fwd_only()
+        with pytest.raises(L.HipVaeError, match='no matching train step'):
+            eng.train_bwd_target(xt, yt, et, xt, grads)
+    eng.train_fwd_bwd(xt, yt, et, grads)
+    eng.train_bwd_target(xt, yt, et, xt, grads)                        # ... and a fresh train step re-arms it
     eng.set_tuned_masks(0xffffffff & ~(1 << 21), 0xffffffff & ~(1 << 21))
     with pytest.raises(L.HipVaeError, match='no matching train step'):
         eng.train_bwd_target(xt, yt, et, xt, grads)                    # another kernel family

@@ -254,6 +254,7 @@ int vaenpvc_encode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_x
   Ws w;
   int rc = resolve(ctx, F, VAENPVC_MODE_INFER, d_ws, ws_bytes, &w);
   if (rc) return rc;
+  ctx->rt.last_F = -1;   // activations / operand planes of a preceding train step may be overwritten: vaenpvc_train_bwd_target must not re-use them
   hipStream_t s = (hipStream_t)stream;
   if (use_tuned(ctx) && tuned::frame_fwd_on(F)) {
     tuned::frame_pack(ctx->m, d_params, w, nullptr, nullptr, 0, s);
@@ -273,6 +274,7 @@ int vaenpvc_decode_fwd(vaenpvc_ctx* ctx, const float* d_params, const float* d_z
   Ws w;
   int rc = resolve(ctx, F, VAENPVC_MODE_INFER, d_ws, ws_bytes, &w);
   if (rc) return rc;
+  ctx->rt.last_F = -1;   // activations / operand planes of a preceding train step may be overwritten: vaenpvc_train_bwd_target must not re-use them
   hipStream_t s = (hipStream_t)stream;
   if (use_tuned(ctx) && tuned::frame_fwd_on(F)) {
     tuned::frame_pack(ctx->m, d_params, w, nullptr, nullptr, 0, s);
@@ -320,6 +322,7 @@ static int loss_impl(vaenpvc_ctx* ctx, const float* d_params, const float* d_x, 
   Ws w;
   int rc = resolve(ctx, F, VAENPVC_MODE_INFER, d_ws, ws_bytes, &w);
   if (rc) return rc;
+  ctx->rt.last_F = -1;   // activations / operand planes of a preceding train step may be overwritten: vaenpvc_train_bwd_target must not re-use them
   fwd_all(ctx, d_params, d_x, d_y, d_eps, key, F, w, false, d_loss3, (hipStream_t)stream);
   return check_launch("loss_fwd");
 }

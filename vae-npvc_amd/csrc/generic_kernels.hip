@@ -193,7 +193,7 @@ __global__ void k_nll(const float* __restrict__ x, const float* __restrict__ xh,
   for (int i = threadIdx.x; i < H; i += blockDim.x) {
     float d = x[f * H + i] - xh[f * H + i];
     s += -0.5f * (LOG_2PI + (d * d) / (1.0f + EPSILON));
-    if (dxh) dxh[f * H + i] = -d / (1.0f + EPSILON) * invF;
+    if (dxh) dxh[f * H + i] = d * (-invF / (1.0f + EPSILON));   // (the same expression order in every kernel that forms d(xh): fused and unfused loss paths are bitwise A/B partners)
   }
   s = block_sum(s, sm);
   if (threadIdx.x == 0) nll_f[f] = s;

@@ -82,11 +82,18 @@ __device__ __forceinline__ float lnact_v(float v, float mean, float rstd, float 
 // mirrors), then the four row sums are read into scalar registers: ~15 instructions of a few cycles each, against six
 // dependent ds_bpermute round trips through the LDS pipeline (~100 cycles each) for the butterfly of __shfl_xor -- the
 // reductions sit on the per-frame latency chain of every kernel that takes LayerNorm statistics or sums.
+// PRECONDITION: all 64 lanes active (full EXEC), i.e. every call site is wave-uniform.  With bound_ctrl a disabled lane
+// contributes 0 to the DPP steps, but v_readlane of lanes 0 / 16 / 32 / 48 returns the stale register of an inactive lane:
+// a call under a divergent branch returns a wrong sum without a sign.  -DVAENPVC_WAVE_SUM_ASSERT traps on a partial EXEC
+// mask (debug builds); VAENPVC_WAVE_SUM_DPP=0 is the shuffle butterfly, which tolerates divergence.
 #ifndef VAENPVC_WAVE_SUM_DPP
 #define VAENPVC_WAVE_SUM_DPP 1
 #endif
 __device__ __forceinline__ float wave_sum(float v) {
 #if VAENPVC_WAVE_SUM_DPP
+#ifdef VAENPVC_WAVE_SUM_ASSERT
+  if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();
+#endif
   auto dpp = [](float x, auto ctrl) __attribute__((always_inline)) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
   };

@@ -487,10 +487,13 @@ struct LnbCfg {
   static constexpr int LDS_BYTES = 3 * N * 4;
 };
 
+// dy and da are NOT __restrict__: encoder layer 0's pass runs in place (dy == da) behind the fused backward of layer 1
+// (gfx950_layers.hip).  In place is safe by construction -- a thread reads its elements of frame f before the frame's barrier
+// and writes the same elements after it -- and the frame loop's barrier already keeps the next frame's loads behind these stores.
 template <class L>
-__global__ void __launch_bounds__(256) k_ln_bwd_fused(const float* __restrict__ dy, const float* __restrict__ a,
+__global__ void __launch_bounds__(256) k_ln_bwd_fused(const float* dy, const float* __restrict__ a,
                                                       const float* __restrict__ st, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float* __restrict__ da,
+                                                      const float* __restrict__ beta, float* da,
                                                       float* __restrict__ part, int F, int fchunk,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                       float* __restrict__ dbias) {  // non-null: accumulate directly (few workgroups)

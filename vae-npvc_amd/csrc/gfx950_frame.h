@@ -825,7 +825,7 @@ FR_DEV void toep_split_bwd(R& run, float* lds, const float* xh /*[513]*/, const 
   float* pp = wr + 1040;         // [4][513]
   run.phase([&](int tid) {
     for (int h = tid; h < TP_H; h += TS_T) {
-      const float g = -(target[h] - xh[h]) / (1.0f + EPSILON_F) * invF;
+      const float g = (target[h] - xh[h]) * (-invF / (1.0f + EPSILON_F));
       gs[h] = g;
       if (c == 0) d_xh[h] = g;
     }
@@ -1063,7 +1063,7 @@ FR_STAGE void frame_fwd_dec(R& run, float* lds_, const FwdArgs& a_, int f_) {
         const float d = tf[p] - s;
         t += -0.5f * (LOG_2PI_F + (d * d) / (1.0f + EPSILON_F));
         a.xh[(size_t)f * TP_H + p] = s;
-        if (a.mode & FM_GRAD) a.d_xh[(size_t)f * TP_H + p] = -d / (1.0f + EPSILON_F) * a.invF;
+        if (a.mode & FM_GRAD) a.d_xh[(size_t)f * TP_H + p] = d * (-a.invF / (1.0f + EPSILON_F));
       }
       return t;
     });
@@ -1241,7 +1241,7 @@ FR_STAGE void frame_bwd_dec(R& run, float* lds_, const BwdArgs& a_, int f_) {
   run.phase([&](int tid) {
     for (int p = tid; p < TP_H; p += NT) {
       const float d = a.target[(size_t)f * TP_H + p] - a.xh[(size_t)f * TP_H + p];
-      const float g = -d / (1.0f + EPSILON_F) * a.invF;
+      const float g = d * (-a.invF / (1.0f + EPSILON_F));
       vec[p] = g;
       a.d_xh[(size_t)f * TP_H + p] = g;
     }

@@ -182,6 +182,9 @@ struct Pk {
   static constexpr int ge1 = ge2 + GE2::BTOTAL;
   static constexpr int wc = ge1 + GE1::BTOTAL;
   static constexpr int lnpart = wc + TOEP_C * WROW;  // [LWGS][3][C] partial sums of the LN backward
+  // BORROWED between the forward and the backward pass of a train step: the fused loss kernel (loss_fwd_post) parks the last layer's
+  // per-workgroup BIAS parts here; backward() adds them (k_colsum_part) before its first LayerNorm pass re-uses the region.  Valid
+  // while Runtime::dxh_post_F == F; a kernel placed between the loss and the backward pass must not touch it.
   static constexpr int wdg = lnpart + 2048 * 3 * 256;  // bf16 tap copies, input-gradient direction
   static constexpr int wfw = wdg + TB_WFLOATS;  // bf16 tap copies, forward direction (reversed)
   static constexpr int heads_bias = wfw + TB_WFLOATS;  // [b_mu | b_lv]

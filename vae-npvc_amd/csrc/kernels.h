@@ -20,10 +20,13 @@ struct Ws {  // resolved workspace pointers (see workspace_layout)
   float* dec_y;  // lrelu(LN(dec_a[n_dec-2]))
   // train only
   float* d_xh;
-  float* d_dec_a[VAENPVC_MAX_LAYERS];
+  float* d_dec_a[VAENPVC_MAX_LAYERS];   // d_dec_a[0] is BORROWED from the fused loss kernel to the start of the backward pass (loss_fwd_post parks
+                                        // the edge-term parts of the last layer's weight gradient there; k_sum_parts_add consumes them before
+                                        // anything writes d(a0)); valid while Runtime::dxh_post_F == F
   float *d_h, *d_z, *d_e, *d_z_mu, *d_z_lv;
   float* d_enc_a[VAENPVC_MAX_LAYERS];
-  float* dy_tmp;
+  float* dy_tmp;   // gradient hand-over buffer of the layered backward pass; BORROWED the same way: column 512 of the last layer's
+                   // input gradient waits here from the fused loss kernel until dec3_dgrad has written the other 512 columns
   float *pl_y3, *pl_y4, *pl_z, *pl_dz, *pl_dh, *pl_da4;
   float* cl[12];  // channel-last planes of the conv view GEMMs (cl_layout.h: CL_*)
   float* toep_gp;  // bf16 planes of d_xh
