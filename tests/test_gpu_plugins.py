@@ -139,6 +139,36 @@ def test_convert_utterance_matches_oracle(tmp_path):
     assert tuple(nhwc.shape) == (len(x), 513, 1, 1)
 
 
+def test_batched_conversion_equals_per_utterance_conversion(tmp_path):
+    """convert.convert_utterances: several utterances in one launch (frames are independent samples of the frame-wise network)
+    give what one launch per utterance gives, at the conversion bar (1e-4 of the converted spectrum's range; the two runs may
+    use different kernel families -- whole-frame kernels up to 512 frames, layered kernels above)."""
+    import analyzer
+    import convert as conv_cli
+    from model.vae import ConvVAE
+    arch = load_arch()
+    allr, xmin, xmax = make_dataset(str(tmp_path), n_utt=1, seed=9)
+    normalizer = analyzer.Tanhize(xmax=xmax, xmin=xmin)
+    machine = ConvVAE(arch, seed=2)
+    rng = np.random.default_rng(5)
+    lens = [300, 37, 1500, 700, 1]
+    lo, hi = xmin.astype(np.float32), xmax.astype(np.float32)
+    sps = [(lo + (hi - lo) * rng.random((n, 513), dtype=np.float32)).astype(np.float32) for n in lens]
+    trg = analyzer.SPEAKERS.index('TM3')
+    one = [conv_cli.convert_utterance(machine, normalizer, sp, trg).cpu().numpy() for sp in sps]
+    many = [t.cpu().numpy() for t in conv_cli.convert_utterances(machine, normalizer, sps, trg)]
+    assert [m.shape for m in many] == [(n, 513) for n in lens]
+    for a, b in zip(one, many):
+        assert np.abs(a - b).max() <= 1e-4 * np.abs(a).max()
+    # ... and against the float64 oracle at the utterance sizes convert.py actually runs (700 / 1 500 frames)
+    P = O.unflatten_params(arch, machine.engine.params.cpu().numpy())
+    for i in (2, 3):
+        x = O.tanhize_forward(sps[i].astype(np.float64), xmin.astype(np.float64), xmax.astype(np.float64))
+        R = O.np_forward(arch, P, x, np.full(len(x), trg), None)
+        want = O.tanhize_backward(R['xh'], xmin.astype(np.float64), xmax.astype(np.float64))
+        assert np.abs(many[i] - want).max() / np.abs(want).max() < 1e-4
+
+
 def test_convert_cli_end_to_end(tmp_path, monkeypatch):
     """convert.main() on a synthetic tree (convert.py:66-116): checkpoint + architecture lookup, per-utterance device
     path, log-F0 transform, and the arrays handed to the vocoder (analyzer.pw2wav, analyzer.py:160-171) -- WORLD and

@@ -23,6 +23,49 @@ def test_cli_requires_model_and_trainer():
     assert c.src == 'SF1' and c.trg == 'TM3' and c.module == 'model.vae'
 
 
+def test_convert_groups_utterances_and_cuts_the_result_back():
+    """convert.batched / convert.convert_utterances (round 5): consecutive utterances share one device launch up to
+    --batch_frames frames, order preserved, results cut at the file boundaries; 0 = one launch per file (the reference's
+    sess.run per utterance, convert.py:105-116).  A stand-in machine (frame-wise: row -> 2 * row + target id) and an identity
+    normaliser keep this on the CPU."""
+    import torch
+    import convert as conv_cli
+    assert conv_cli.parse_args(['--model', 'ConvVAE']).batch_frames == 16384
+    rng = np.random.default_rng(0)
+    lens = [300, 700, 5000, 20000, 100, 16384, 1]
+    feats = [{'sp': rng.standard_normal((n, 513)).astype(np.float32), 'filename': ('%d' % i).encode()} for i, n in enumerate(lens)]
+    groups = list(conv_cli.batched(iter(feats), 16384))
+    assert [[int(f['filename']) for f in g] for g in groups] == [[0, 1, 2], [3], [4], [5], [6]]
+    assert [[int(f['filename']) for f in g] for g in conv_cli.batched(iter(feats), 0)] == [[i] for i in range(len(lens))]
+    assert list(conv_cli.batched(iter([]), 16384)) == []
+    calls = []
+
+    class Machine(object):
+        def encode(self, x):
+            calls.append(int(x.shape[0]))
+            assert tuple(x.shape[1:]) == (1, 513, 1)
+            return x.reshape(x.shape[0], -1)
+
+        def decode(self, z, y):
+            assert y.dtype == torch.int64 and tuple(y.shape) == (z.shape[0],)
+            return (2 * z + y.to(z.dtype).unsqueeze(1)).reshape(z.shape[0], 513, 1, 1)
+
+    class Ident(object):
+        def forward_process(self, x):
+            return torch.as_tensor(np.asarray(x))
+
+        def backward_process(self, x):
+            return x
+
+    outs = []
+    for g in groups:
+        outs += conv_cli.convert_utterances(Machine(), Ident(), [f['sp'] for f in g], 9)
+    assert calls == [6000, 20000, 100, 16384, 1]
+    for f, o in zip(feats, outs):
+        assert tuple(o.shape) == f['sp'].shape and np.array_equal(o.numpy(), 2 * f['sp'] + 9)
+    assert conv_cli.convert_utterances(Machine(), Ident(), [], 9) == []
+
+
 def test_plugin_lookup_by_name():
     from importlib import import_module
     assert hasattr(import_module('model.vae'), 'ConvVAE')

@@ -510,7 +510,11 @@ constexpr int nt_lds(int npl) { return npl * (NT_BM + NT_BN) * (nt_bk(npl) * 2 +
 #ifndef VAENPVC_NT_WPS
 #define VAENPVC_NT_WPS 2
 #endif
-template <int NPL>
+// PERS (round 5): PERSISTENT workgroups.  The grid is two workgroups per CU; a workgroup walks the tiles of its XCD's contiguous range
+// (workgroup b runs on XCD b % 8: the workgroups resident on one XCD at any time still work on adjacent tiles and share their rows of A
+// in that L2), and the first K chunk of tile i + 1 is requested BEFORE the result stores of tile i are issued: the prologue round trip of
+// a tile (35 us of launch + first loads + epilogue per one-tile workgroup) then runs under the previous tile's stores.
+template <int NPL, bool PERS = false>
 __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT_BK = nt_bk(NPL), NT_RS = NT_BK * 2 + 16, NQ = NT_BK / 16;   // NQ: 16-byte pieces per thread, plane, operand
@@ -519,13 +523,31 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
   unsigned char* sB = smem + NPL * APL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int ntn = cdiv(a.N, NT_BN), tile = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int m0 = (tile / ntn) * NT_BM, n0 = (tile % ntn) * NT_BN;
+  const int ntn = cdiv(a.N, NT_BN);
+  // tiles of this workgroup: one (the launch has a workgroup per tile), or every (gridDim.x / 8)-th tile of the XCD's range
+  int tile, tile_end, tile_step;
+  if constexpr (PERS) {
+    const int ntiles = cdiv(a.M, NT_BM) * ntn, x = blockIdx.x & 7, q = ntiles >> 3, r = ntiles & 7;
+    const int lo = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    tile = lo + (blockIdx.x >> 3);
+    tile_end = lo + q + (x < r ? 1 : 0);
+    tile_step = gridDim.x >> 3;      // (the grid is a multiple of 8)
+  } else {
+    tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    tile_end = tile + 1;
+    tile_step = 1;
+  }
+  if (tile >= tile_end) return;      // (uniform)
+  int m0 = (tile / ntn) * NT_BM, n0 = (tile % ntn) * NT_BN;
   // staging: thread -> (row tid >> 1, half tid & 1 of the row's chunk) of both tiles: NQ pieces of 16 bytes per plane and operand
   const int srow = tid >> 1, shalf = tid & 1;
-  const int arow = m0 + srow < a.M ? m0 + srow : a.M - 1;  // rows past the end: duplicates, never stored
-  const unsigned char* ga = reinterpret_cast<const unsigned char*>(a.A) + ((size_t)arow * a.Kp) * 2 + shalf * NT_BK;
-  const unsigned char* gb = reinterpret_cast<const unsigned char*>(a.B) + ((size_t)(n0 + srow) * a.Kp) * 2 + shalf * NT_BK;
+  const unsigned char *ga, *gb;
+  auto point = [&](int m0_, int n0_) __attribute__((always_inline)) {
+    const int arow = m0_ + srow < a.M ? m0_ + srow : a.M - 1;  // rows past the end: duplicates, never stored
+    ga = reinterpret_cast<const unsigned char*>(a.A) + ((size_t)arow * a.Kp) * 2 + shalf * NT_BK;
+    gb = reinterpret_cast<const unsigned char*>(a.B) + ((size_t)(n0_ + srow) * a.Kp) * 2 + shalf * NT_BK;
+  };
+  point(m0, n0);
   unsigned char* da = sA + srow * NT_RS + shalf * NT_BK;
   unsigned char* db = sB + srow * NT_RS + shalf * NT_BK;
   u32x4 ra[NPL][NQ], rb[NPL][NQ];
@@ -548,10 +570,6 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
       }
   };
   f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
   const int aoff = (wm * 64 + l31) * NT_RS + lh * 16;
   const int boff = (wn * 64 + l31) * NT_RS + lh * 16;
   u32x4 fa[2][2][NPL], fb[2][2][NPL];
@@ -578,6 +596,11 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
 #endif
   const int nch = a.Kp / NT_BK;
   gload(0);
+  for (;;) {   // tiles of this workgroup
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
   for (int kc = 0; kc < nch; ++kc) {
     if (!(VAENPVC_NT_ABL & 8)) lstore();  // chunk kc (prefetched)
     __syncthreads();
@@ -593,10 +616,26 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
     }
     __syncthreads();  // chunk consumed
   }
+  const int tile_next = tile + tile_step;
+  const int m0c = m0, n0c = n0;      // the tile whose results sit in the accumulators
+  // persistent: the next tile's first chunk is requested ahead of this tile's result stores (the staging registers are free) -- but
+  // BEHIND the epilogue's own loads (speaker table, bias): loads return in order, a load issued behind the request would wait for it
+  auto prefetch_next = [&]() __attribute__((always_inline)) {
+    if constexpr (PERS) {
+      if (tile_next < tile_end) {
+        m0 = (tile_next / ntn) * NT_BM;
+        n0 = (tile_next % ntn) * NT_BN;
+        point(m0, n0);
+        gload(0);
+      }
+    }
+  };
   if (VAENPVC_NT_ABL & 4) {
+    prefetch_next();
     float sacc = 0.f;
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
     if (sacc == 12345.678f) a.C[0] = sacc;
+    if (PERS && tile_next < tile_end) { tile = tile_next; continue; }
     return;
   }
   // the speaker table rows of this tile (T[k][n0 .. n0+127], k < nrb <= NT_MAXRB) and the tile's 128 speaker ids go
@@ -607,11 +646,11 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
   const bool rb_lds = a.rowbias && a.nrb <= NT_MAXRB;   // uniform
   if (rb_lds) {
     for (int i = tid; i < a.nrb * 128; i += 256) {
-      const int k = i >> 7, nl = i & 127, n = n0 + nl;
+      const int k = i >> 7, nl = i & 127, n = n0c + nl;
       Ts[i] = n < a.N ? a.rowbias[(int64_t)k * a.ldrb + n] : 0.f;
     }
     if (tid < 128) {
-      const int m = m0 + tid;
+      const int m = m0c + tid;
       int64_t r = a.idx[m < a.M ? m : a.M - 1];
       ys[tid] = (int)(r < 0 ? 0 : (r >= a.nrb ? a.nrb - 1 : r));
     }
@@ -622,12 +661,15 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
   float bb2[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + l31;
+    const int n = n0c + wn * 64 + j * 32 + l31;
     bb2[j] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
   }
+  __builtin_amdgcn_sched_barrier(0);
+  prefetch_next();
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + l31;
+    const int n = n0c + wn * 64 + j * 32 + l31;
     if (n >= a.N) continue;
     const float bb = bb2[j];
     float* cb = a.C;
@@ -644,9 +686,9 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
         rbv[reg] = 0.f;
         if (rb_lds) {  // uniform
           const int ml = wm * 64 + i * 32 + acc_row(reg, lane);
-          rbv[reg] = Ts[ys[ml] * 128 + (n - n0)];
+          rbv[reg] = Ts[ys[ml] * 128 + (n - n0c)];
         } else if (a.rowbias) {  // uniform
-          const int m = m0 + wm * 64 + i * 32 + acc_row(reg, lane);
+          const int m = m0c + wm * 64 + i * 32 + acc_row(reg, lane);
           int64_t r = a.idx[m < a.M ? m : a.M - 1];
           r = r < 0 ? 0 : (r >= a.nrb ? a.nrb - 1 : r);
           rbv[reg] = a.rowbias[r * a.ldrb + n];
@@ -654,18 +696,29 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
       }
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const int m = m0 + wm * 64 + i * 32 + acc_row(reg, lane);
+        const int m = m0c + wm * 64 + i * 32 + acc_row(reg, lane);
         if (m < a.M) st_nt<VAENPVC_NT_CST != 0>(cb + (int64_t)m * a.ldc + nn, acc[i][j][reg] + bb + rbv[reg]);
       }
     }
   }
+  if (!PERS || tile_next >= tile_end) break;
+  tile = tile_next;
+  if (rb_lds) __syncthreads();   // the epilogue's table reads are done before the next tile's chunks overwrite the LDS
+  }  // tiles
 }
 
 template <int NPL>
 inline void launch_gemm_nt(const NtArgs& a, hipStream_t s) {
-  rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_nt<NPL>), nt_lds(NPL));
-  dim3 grid((unsigned)(cdiv(a.M, NT_BM) * cdiv(a.N, NT_BN)));
-  hipLaunchKernelGGL(k_gemm_nt<NPL>, grid, dim3(256), nt_lds(NPL), s, a);
+  const int ntiles = cdiv(a.M, NT_BM) * cdiv(a.N, NT_BN);
+  constexpr int SLOTS = 256 * VAENPVC_NT_WPS;     // resident workgroups of the chip
+  // (one plane: the one-tile kernel fits three workgroups per CU at 138 registers, the persistent one two at 194: not used)
+  if (NPL >= 2 && rt().nt_persist > 0 && ntiles >= rt().nt_persist) {   // (Runtime::nt_persist, env VAENPVC_NT_PERSIST)
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_nt<NPL, true>), nt_lds(NPL));
+    hipLaunchKernelGGL((k_gemm_nt<NPL, true>), dim3(SLOTS), dim3(256), nt_lds(NPL), s, a);
+    return;
+  }
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_nt<NPL, false>), nt_lds(NPL));
+  hipLaunchKernelGGL((k_gemm_nt<NPL, false>), dim3((unsigned)ntiles), dim3(256), nt_lds(NPL), s, a);
 }
 
 // (An LDS-DMA variant of this kernel -- global_load_lds_dwordx4 into a ring of 2-4 unpadded, XOR-swizzled stage
@@ -1524,6 +1577,142 @@ inline void launch_cgemm_auto(const CgArgs& a, hipStream_t s) {
   if (a.M <= 32) launch_cgemm<NPL, 1, 1>(a, s);
   else if (a.M <= 64 || half_tile_tail) launch_cgemm<NPL, 1, 2>(a, s);
   else launch_cgemm<NPL, 2, 2>(a, s);
+}
+
+// ---------------------------------------------------------------- P-type site on a tile that owns whole frames (round 5)
+// Encoder layer 3's input gradient (conv k7 s3 backward: util/layers.py:56-64 autodiff) has M = 3 phases x 64 channels = 192
+// GEMM rows and R = 8 view rows per frame.  On the tiles above it ran as three 64-row tiles per 256 columns: every view row was
+// fetched three times, and the three phases of one (channel, row q) -- three CONSECUTIVE output positions -- left from three
+// different workgroups as 4-byte stores at a 12-byte stride (246 us at 20 % matrix-pipe busy: the worst GEMM of the step).
+// Here a workgroup owns ALL 192 rows of 128 columns = 16 WHOLE frames: a wave holds the 3 phases x 32 channels x 64 columns,
+// the view rows are staged once, and the finished tile is re-ordered through LDS into the canonical [frame][channel][position]
+// fp32 layout -- 16 frames x 4 864 bytes are ONE contiguous run of the output tensor, copied out as 16-byte pieces (19 per
+// thread).  LDS frame pitch 1 224 floats: the 32 lanes of a half-wave (4 frames x 8 rows q, stride 3) hit 32 different banks.
+template <int NPL>
+struct CgPfTile {
+  static constexpr int PH = 3, MDIV = 64, BM = PH * MDIV, BN = 128, ROWS = BM + BN, BK = 32, RS = BK * 2 + 16;
+  static constexpr int R = 8, TF = BN / R, OH = 19, FOUT = MDIV * OH, FPITCH = FOUT + 8;     // floats per output frame / its LDS pitch
+  static constexpr int PIECES = ROWS * (BK * 2 / 16), PPT = cdiv(PIECES, 256);
+  static constexpr int LDS_GEMM = NPL * ROWS * RS, LDS_OUT = TF * FPITCH * 4, LDS = LDS_GEMM > LDS_OUT ? LDS_GEMM : LDS_OUT;
+  static_assert(PIECES % 256 == 0 && (TF * FOUT / 4) % 256 == 0, "staging / copy-out are whole rounds");
+};
+template <int NPL>
+__global__ void __launch_bounds__(256, 2) k_cgemm_pf(CgArgs a) {
+  using T = CgPfTile<NPL>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int PLB = T::ROWS * T::RS, PPR = T::BK * 2 / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int wc = wave >> 1, wn = wave & 1;     // channel half, column half
+  const int n0 = xcd_contiguous(blockIdx.x, gridDim.x) * T::BN;
+  const unsigned char* gp[T::PPT];
+  int gplane2[T::PPT], lofs[T::PPT];
+#pragma unroll
+  for (int i = 0; i < T::PPT; ++i) {
+    const int id = tid + 256 * i, row = id / PPR, pc = id - row * PPR;
+    lofs[i] = row * T::RS + pc * 16;
+    if (row < T::BM) {
+      gp[i] = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)row * a.Kp) * 2 + pc * 16;
+      gplane2[i] = (int)a.w_plane;
+    } else {
+      int r = n0 + row - T::BM;
+      r = r < a.N ? r : a.N - 1;   // rows past the end: duplicates, never stored
+      gp[i] = reinterpret_cast<const unsigned char*>(a.X) + (size_t)view_off(a.xv, r) * 2 + pc * 16;
+      gplane2[i] = (int)a.x_plane;
+    }
+  }
+  u32x4 rg[NPL][T::PPT];
+  auto gload = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int i = 0; i < T::PPT; ++i)
+        rg[p][i] = *reinterpret_cast<const u32x4*>(gp[i] + (size_t)p * (size_t)gplane2[i] * 2 + kc * (T::BK * 2));
+  };
+  auto lstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int i = 0; i < T::PPT; ++i) *reinterpret_cast<u32x4*>(smem + p * PLB + lofs[i]) = rg[p][i];
+  };
+  f32x16 acc[T::PH][2];
+#pragma unroll
+  for (int i = 0; i < T::PH; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+  const int aoff = (wc * 32 + l31) * T::RS + lh * 16;                    // + phase * MDIV rows
+  const int boff = (T::BM + wn * 64 + l31) * T::RS + lh * 16;            // + t * 32 rows
+  u32x4 fa[2][T::PH][NPL], fb[2][2][NPL];
+  auto loadF = [&](int set, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < T::PH; ++t)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) fa[set][t][p] = *reinterpret_cast<const u32x4*>(smem + p * PLB + aoff + t * T::MDIV * T::RS + ks * 32);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) fb[set][t][p] = *reinterpret_cast<const u32x4*>(smem + p * PLB + boff + t * 32 * T::RS + ks * 32);
+  };
+  auto mm = [&](int set) __attribute__((always_inline)) {
+    using PR = Prod<NPL>;
+#pragma unroll
+    for (int t = 0; t < PR::N; ++t)
+#pragma unroll
+      for (int i = 0; i < T::PH; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[set][i][PR::A[t]], fb[set][j][PR::B[t]], acc[i][j]);
+  };
+  const int nch = a.Kp / T::BK;
+  gload(0);
+  for (int kc = 0; kc < nch; ++kc) {
+    lstore();
+    __syncthreads();
+    if (kc + 1 < nch) gload(kc + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    loadF(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < T::BK / 16; ++ks) {
+      if (ks + 1 < T::BK / 16) loadF((ks + 1) & 1, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: the tile through LDS as [frame][channel][position] fp32, then one contiguous run of the output tensor
+  float* ot = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int nl = wn * 64 + j * 32 + l31, fl = nl / T::R, q = nl - fl * T::R;
+#pragma unroll
+    for (int ph = 0; ph < T::PH; ++ph) {
+      const int pos = q * a.oq + a.o0 + ph;
+      if (pos < 0 || pos >= T::OH) continue;
+      float* ob = ot + fl * T::FPITCH + pos;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) ob[(wc * 32 + acc_row(reg, lane)) * T::OH] = acc[ph][j][reg];
+    }
+  }
+  __syncthreads();
+  const int f0 = n0 / T::R, nf = min(T::TF, a.N / T::R - f0);
+  const u32x4* ot4 = reinterpret_cast<const u32x4*>(smem);
+  u32x4* og = reinterpret_cast<u32x4*>(a.out + (int64_t)f0 * T::FOUT);
+  constexpr int P16 = T::FOUT / 4;     // 16-byte pieces per frame
+#pragma unroll
+  for (int i = 0; i < T::TF * P16 / 256; ++i) {
+    const int id = tid + 256 * i, fl = id / P16, pc = id - fl * P16;
+    if (fl < nf) og[(int64_t)fl * P16 + pc] = ot4[fl * (T::FPITCH / 4) + pc];
+  }
+}
+// serves the site? (geometry of CV_E3G; no bias: an input gradient)
+inline bool cgemm_pf_serves(const CgArgs& a) {
+  return a.M == 192 && a.mdiv == 64 && a.C == 64 && a.xv.R == 8 && a.OH == 19 && a.om == 19 && a.ofs == 64 * 19 && a.oq == 3 && a.o0s == 1 &&
+         !a.bias && a.Kp % 32 == 0 && a.N % 8 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+}
+template <int NPL>
+inline void launch_cgemm_pf(const CgArgs& a, hipStream_t s) {
+  using T = CgPfTile<NPL>;
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_cgemm_pf<NPL>), T::LDS);
+  hipLaunchKernelGGL((k_cgemm_pf<NPL>), dim3((unsigned)cdiv(a.N, T::BN)), dim3(256), T::LDS, s, a);
 }
 
 // (the producers of the channel-last planes live in gfx950_viewconv.h: k_cl_produce)

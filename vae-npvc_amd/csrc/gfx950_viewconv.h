@@ -277,6 +277,12 @@ static void cv_gemm(int site, const float* wplanes, const float* xplanes, float*
   a.o0s = 1;
   a.OH = v.OH;
   a.bias = bias;
+  if constexpr (NPL <= 2) {
+    if (rt().cg_pf && cgemm_pf_serves(a)) {   // encoder layer 3's input gradient: the tile that owns whole frames (VAENPVC_CG_PF=0: A/B)
+      launch_cgemm_pf<NPL>(a, s);
+      return;
+    }
+  }
   launch_cgemm_auto<NPL>(a, s);
 }
 

@@ -44,6 +44,11 @@ struct Runtime {
                                 // flight, not by bytes, and the phase-stacked epilogue needs two stores where fp32 needs one -- off by default)
   bool tn_k16 = false;          // VAENPVC_TN_K16: the 16-row two-workgroup A^T B kernel instead of the pipelined 32-row one (A/B)
   int tn_w4_tiles = 8;          // VAENPVC_TN_W4_TILES: the four-wave A^T B kernel from this many 256 x 256 tiles per row chunk on (0: every plain site, 99: never)
+  int nt_persist = 0;           // VAENPVC_NT_PERSIST=<n>: C = A B^T launches with at least n 128 x 128 tiles run on persistent workgroups (two per CU walk the
+                                // tiles, the next tile's first loads ahead of the result stores; 0 = never).  OFF: measured SLOWER (round 5, same box,
+                                // two interleaved rounds): encoder layer 4 forward 173.5 -> 190.7 us, its input gradient 171.4 -> 188.3, merge forward
+                                // 130.9 -> 146.4, heads input gradient 71.2 -> 84.5
+  bool cg_pf = true;            // VAENPVC_CG_PF=0: encoder layer 3's input gradient on the 64 x 256 view-GEMM tiles instead of the frame-owning 192 x 128 tile (A/B)
   int tn_xcd = -1;              // VAENPVC_TN_XCD=0|1: tile order of the C += A^T B plane GEMM (experiments; -1 = per site)
   int toep_zc = 4;              // VAENPVC_TOEP_ZC: frame chunks of the Toeplitz weight gradient, 64 workgroups each (4: one workgroup per CU, one prologue / epilogue per CU)
   bool toep_f32 = false;        // VAENPVC_TOEP=f32: exact-fp32 MFMA kernels for the 1025-tap layer
