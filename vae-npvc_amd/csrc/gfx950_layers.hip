@@ -597,9 +597,25 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
     if (!(have_y2 = enc_stats(2, CV_E3F, CL_Y2, "enc3_split"))) VAENPVC_TIMED("stats_enc2", s, stats<1216>(w.enc_a[2], w.enc_st[2], F, s));
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 2);
   if (fwd_on(3) && cv_fwd(CV_E3F, F)) {
-    enc_view(CV_E3F, CL_Y2, 3, have_y2, "enc3_split", "enc3_fwd");
-    VAENPVC_TIMED("stats_enc3", s, stats_planes<896, 7>(w.enc_a[3], w.enc_st[3], P + m.enc[3].gamma_off, P + m.enc[3].beta_off, w.pl_y3,
-                         fwd_on(4) && pg_fwd(F), F, s));
+    // the frame-owning tile (k_cgemm_sf, round 5): conv + statistics + activated planes of a3 in one kernel
+    bool e3_whole = false;
+    if (rt().cg_sf)
+      for_dense_planes([&](auto npl) {
+        constexpr int NPL = decltype(npl)::value;
+        if constexpr (NPL <= 2) {
+          if (!have_y2)
+            VAENPVC_TIMED("enc3_split", s, cv_split<NPL>(CL_Y2, w.enc_a[2], w.enc_st[2], P + m.enc[2].gamma_off, P + m.enc[2].beta_off, w.cl[CL_Y2], F, s));
+          have_y2 = true;
+          VAENPVC_TIMED("enc3_fwd", s, e3_whole = cv_gemm_stats_planes<NPL>(CV_E3F, w.scratch + Pk::cvw + cv_woff(CV_E3F), w.cl[CL_Y2], w.enc_a[3], P + m.enc[3].b_off,
+                                                                            w.enc_st[3], P + m.enc[3].gamma_off, P + m.enc[3].beta_off,
+                                                                            (fwd_on(4) && pg_fwd(F)) ? w.pl_y3 : nullptr, F, s));
+        }
+      });
+    if (!e3_whole) {
+      enc_view(CV_E3F, CL_Y2, 3, have_y2, "enc3_split", "enc3_fwd");
+      VAENPVC_TIMED("stats_enc3", s, stats_planes<896, 7>(w.enc_a[3], w.enc_st[3], P + m.enc[3].gamma_off, P + m.enc[3].beta_off, w.pl_y3,
+                           fwd_on(4) && pg_fwd(F), F, s));
+    }
   } else if (fwd_on(3)) {
     VAENPVC_TIMED("enc3_fwd", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<E3Fs>(lnp(3), nsplit_for<E3Fs>(F), s) : launch_convgemm<E3F>(lnp(3), nsplit_for<E3F>(F), s)));
     VAENPVC_TIMED("stats_enc3", s, stats_planes<896, 7>(w.enc_a[3], w.enc_st[3], P + m.enc[3].gamma_off, P + m.enc[3].beta_off, w.pl_y3,

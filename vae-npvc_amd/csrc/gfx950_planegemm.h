@@ -1715,6 +1715,208 @@ inline void launch_cgemm_pf(const CgArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((k_cgemm_pf<NPL>), dim3((unsigned)cdiv(a.N, T::BN)), dim3(256), T::LDS, s, a);
 }
 
+// ---------------------------------------------------------------- S-type site on a tile that owns whole frames (round 5)
+// Encoder layer 3 FORWARD (conv k7 s3: util/layers.py:56-64; M = 128 output channels, R = 7 rows per frame, K = 7 x 64).  The
+// 128 x 128 tile takes 126 columns = 18 WHOLE frames (two columns idle), so the workgroup holds complete pre-LN frames a3[f][128][7]:
+//   * the tile goes through LDS in the canonical [frame][channel][position] order (frame pitch 904 floats: the 32 lanes of a
+//     half-wave -- consecutive (frame, row) columns -- fall on different banks) and leaves as 16-byte pieces of ONE contiguous
+//     run of the tensor (the one-tile kernel above stored 28-byte runs, 4 bytes per lane);
+//   * the layer's LayerNorm statistics (util/layers.py:32-44: mean, biased variance, two-pass) are taken from the frame in LDS,
+//     one wave per frame, and the ACTIVATED frame lrelu(LN(a3)) leaves as the bf16 operand planes pl_y3[NPL][F][896] that
+//     encoder layer 4's GEMMs read: the separate pass over the tensor (k_ln_stats_planes<896, 7>: 43 us, 100 MB read) is gone.
+struct CgSfArgs {
+  CgArgs g;                 // the GEMM (W, X, planes, view, Kp, N = F * 7); g.out = a3 [F][128][7], g.bias = conv bias [128]
+  float* st;                // [F][2] LayerNorm statistics of a3 (mean, rstd)
+  const float* gamma;       // [128]
+  const float* beta;
+  unsigned short* planes;   // [NPL][F][896] or nullptr
+  int F;
+};
+template <int NPL>
+struct CgSfTile {
+  static constexpr int BM = 128, BN = 128, ROWS = BM + BN, BK = 64, RS = BK * 2 + 16;
+  static constexpr int R = 7, TF = 18, NCOL = TF * R, OH = 7, FOUT = BM * OH, FPITCH = FOUT + 8;
+  static constexpr int PIECES = ROWS * (BK * 2 / 16), PPT = cdiv(PIECES, 256);
+  static constexpr int LDS_GEMM = NPL * ROWS * RS, LDS_OUT = TF * FPITCH * 4, LDS = LDS_GEMM > LDS_OUT ? LDS_GEMM : LDS_OUT;
+  static constexpr int P8 = FOUT / 8, PPL = cdiv(P8, 64);   // 8-element pieces per frame, per lane
+  static_assert(PIECES % 256 == 0 && FOUT % 8 == 0 && NCOL <= BN, "tile geometry");
+};
+template <int NPL>
+__global__ void __launch_bounds__(256, 2) k_cgemm_sf(CgSfArgs b) {
+  using T = CgSfTile<NPL>;
+  const CgArgs& a = b.g;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int PLB = T::ROWS * T::RS, PPR = T::BK * 2 / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_contiguous(blockIdx.x, gridDim.x), n0 = tile * T::NCOL, f0 = tile * T::TF;
+  const unsigned char* gp[T::PPT];
+  int gplane2[T::PPT], lofs[T::PPT];
+#pragma unroll
+  for (int i = 0; i < T::PPT; ++i) {
+    const int id = tid + 256 * i, row = id / PPR, pc = id - row * PPR;
+    lofs[i] = row * T::RS + pc * 16;
+    if (row < T::BM) {
+      gp[i] = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)row * a.Kp) * 2 + pc * 16;
+      gplane2[i] = (int)a.w_plane;
+    } else {
+      int nl = row - T::BM;
+      nl = nl < T::NCOL ? nl : T::NCOL - 1;    // the two idle columns and rows past the end: duplicates, never stored
+      int r = n0 + nl;
+      r = r < a.N ? r : a.N - 1;
+      gp[i] = reinterpret_cast<const unsigned char*>(a.X) + (size_t)view_off(a.xv, r) * 2 + pc * 16;
+      gplane2[i] = (int)a.x_plane;
+    }
+  }
+  u32x4 rg[NPL][T::PPT];
+  auto gload = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int i = 0; i < T::PPT; ++i)
+        rg[p][i] = *reinterpret_cast<const u32x4*>(gp[i] + (size_t)p * (size_t)gplane2[i] * 2 + kc * (T::BK * 2));
+  };
+  auto lstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int i = 0; i < T::PPT; ++i) *reinterpret_cast<u32x4*>(smem + p * PLB + lofs[i]) = rg[p][i];
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+  const int aoff = (wm * 64 + l31) * T::RS + lh * 16;
+  const int boff = (T::BM + wn * 64 + l31) * T::RS + lh * 16;
+  u32x4 fa[2][2][NPL], fb[2][2][NPL];
+  auto loadF = [&](int set, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        fa[set][t][p] = *reinterpret_cast<const u32x4*>(smem + p * PLB + aoff + t * 32 * T::RS + ks * 32);
+        fb[set][t][p] = *reinterpret_cast<const u32x4*>(smem + p * PLB + boff + t * 32 * T::RS + ks * 32);
+      }
+  };
+  auto mm = [&](int set) __attribute__((always_inline)) {
+    using PR = Prod<NPL>;
+#pragma unroll
+    for (int t = 0; t < PR::N; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[set][i][PR::A[t]], fb[set][j][PR::B[t]], acc[i][j]);
+  };
+  const int nch = a.Kp / T::BK;
+  gload(0);
+  for (int kc = 0; kc < nch; ++kc) {
+    lstore();
+    __syncthreads();
+    if (kc + 1 < nch) gload(kc + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    loadF(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < T::BK / 16; ++ks) {
+      if (ks + 1 < T::BK / 16) loadF((ks + 1) & 1, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  // ---- the tile as [frame][channel][position] fp32 in LDS (raw conv sums; the bias is added in the frame pass)
+  float* ot = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int nl = wn * 64 + j * 32 + l31;
+    if (nl >= T::NCOL) continue;
+    const int fl = nl / T::R, q = nl - fl * T::R;
+    float* ob = ot + fl * T::FPITCH + q;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) ob[(wm * 64 + i * 32 + acc_row(reg, lane)) * T::OH] = acc[i][j][reg];
+  }
+  // per-lane constants of the frame pass: lane owns the 8-element pieces lane, lane + 64 of a frame's 896 = 112 x 8 elements;
+  // element e = (channel e / 7, position e % 7)
+  float gm[T::PPL][8], bt[T::PPL][8], bs[T::PPL][8];
+#pragma unroll
+  for (int u = 0; u < T::PPL; ++u)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int pc = lane + 64 * u, e = (pc < T::P8 ? pc : 0) * 8 + k, ch = e / T::OH;
+      gm[u][k] = b.gamma[ch];
+      bt[u][k] = b.beta[ch];
+      bs[u][k] = a.bias ? a.bias[ch] : 0.f;
+    }
+  __syncthreads();
+  const int nf = min(T::TF, b.F - f0);
+  constexpr float INVN = 1.0f / T::FOUT;
+  for (int fl = wave; fl < nf; fl += 4) {
+    const int f = f0 + fl;
+    float v[T::PPL][8];
+    float sm = 0.f;
+#pragma unroll
+    for (int u = 0; u < T::PPL; ++u) {
+      const int pc = lane + 64 * u;
+      const bool ok = pc < T::P8;
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(ot + fl * T::FPITCH + (ok ? pc : 0) * 8);
+      const f32x4 t1 = *reinterpret_cast<const f32x4*>(ot + fl * T::FPITCH + (ok ? pc : 0) * 8 + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[u][k] = ok ? t0[k] + bs[u][k] : 0.f;
+        v[u][4 + k] = ok ? t1[k] + bs[u][4 + k] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sm += v[u][k];
+    }
+    const float mean = wave_sum(sm) * INVN;
+    float q2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < T::PPL; ++u) {
+      const bool ok = lane + 64 * u < T::P8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float d = v[u][k] - mean;
+        q2 += ok ? d * d : 0.f;
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q2) * INVN + LN_EPS);
+    if (lane == 0) {
+      b.st[2 * f] = mean;
+      b.st[2 * f + 1] = rstd;
+    }
+    float* og = a.out + (int64_t)f * T::FOUT;
+#pragma unroll
+    for (int u = 0; u < T::PPL; ++u) {
+      const int pc = lane + 64 * u;
+      if (pc >= T::P8) continue;
+      *reinterpret_cast<f32x4*>(og + pc * 8) = f32x4{v[u][0], v[u][1], v[u][2], v[u][3]};
+      *reinterpret_cast<f32x4*>(og + pc * 8 + 4) = f32x4{v[u][4], v[u][5], v[u][6], v[u][7]};
+      if (b.planes) {   // uniform
+        float y8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y8[k] = lnact_v(v[u][k], mean, rstd, gm[u][k], bt[u][k]);
+        u32x4 pk[NPL];
+        pack8<NPL>(y8, pk);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(b.planes + ((int64_t)p * b.F + f) * T::FOUT + pc * 8) = pk[p];
+      }
+    }
+  }
+}
+inline bool cgemm_sf_serves(const CgArgs& a) {   // geometry of CV_E3F
+  return a.M == 128 && a.mdiv == 128 && a.C == 128 && a.xv.R == 7 && a.OH == 7 && a.om == 7 && a.ofs == 128 * 7 && a.oq == 1 && a.o0 == 0 &&
+         a.Kp % 64 == 0 && a.N % 7 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+}
+template <int NPL>
+inline void launch_cgemm_sf(const CgSfArgs& b, hipStream_t s) {
+  using T = CgSfTile<NPL>;
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_cgemm_sf<NPL>), T::LDS);
+  hipLaunchKernelGGL((k_cgemm_sf<NPL>), dim3((unsigned)cdiv(b.F, T::TF)), dim3(256), T::LDS, s, b);
+}
+
 // (the producers of the channel-last planes live in gfx950_viewconv.h: k_cl_produce)
 
 }  // namespace tuned

@@ -253,8 +253,33 @@ static void cv_stats_split(int id, const float* src, float* st_out, const float*
   launch_cl_produce<NPL, 2>(id, a, s);
 }
 
+static CgArgs cv_gemm_args(int site, const float* wplanes, const float* xplanes, float* out, const float* bias, int F);
+// encoder layer 3 forward on the tile that owns whole frames: conv + bias, the LayerNorm statistics of the result and (planes != nullptr)
+// its activated bf16 operand planes in one kernel (k_cgemm_sf).  false: geometry not served, nothing launched
+template <int NPL>
+static bool cv_gemm_stats_planes(int site, const float* wplanes, const float* xplanes, float* out, const float* bias, float* st,
+                                 const float* gamma, const float* beta, float* planes, int F, hipStream_t s) {
+  if constexpr (NPL <= 2) {
+    CgSfArgs b{cv_gemm_args(site, wplanes, xplanes, out, bias, F), st, gamma, beta, reinterpret_cast<unsigned short*>(planes), F};
+    if (!cgemm_sf_serves(b.g)) return false;
+    launch_cgemm_sf<NPL>(b, s);
+    return true;
+  }
+  return false;
+}
+
 template <int NPL>
 static void cv_gemm(int site, const float* wplanes, const float* xplanes, float* out, const float* bias, int F, hipStream_t s) {
+  const CgArgs a = cv_gemm_args(site, wplanes, xplanes, out, bias, F);
+  if constexpr (NPL <= 2) {
+    if (rt().cg_pf && cgemm_pf_serves(a)) {   // encoder layer 3's input gradient: the tile that owns whole frames (VAENPVC_CG_PF=0: A/B)
+      launch_cgemm_pf<NPL>(a, s);
+      return;
+    }
+  }
+  launch_cgemm_auto<NPL>(a, s);
+}
+static CgArgs cv_gemm_args(int site, const float* wplanes, const float* xplanes, float* out, const float* bias, int F) {
   const CvSite& v = CVS[site];
   const ClDesc& x = CLD[v.x];
   CgArgs a;
@@ -277,13 +302,7 @@ static void cv_gemm(int site, const float* wplanes, const float* xplanes, float*
   a.o0s = 1;
   a.OH = v.OH;
   a.bias = bias;
-  if constexpr (NPL <= 2) {
-    if (rt().cg_pf && cgemm_pf_serves(a)) {   // encoder layer 3's input gradient: the tile that owns whole frames (VAENPVC_CG_PF=0: A/B)
-      launch_cgemm_pf<NPL>(a, s);
-      return;
-    }
-  }
-  launch_cgemm_auto<NPL>(a, s);
+  return a;
 }
 
 // weight-gradient sites: dW[n*ldc + m] += sum over rows (f, j) of A[(f,j)][m] * B[(f,j)][n]; A = plain rows of tensor `a`
