@@ -1387,6 +1387,18 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     if (vw) vwgrad(CW_E3, G + l.w_off, "enc3_wgrad");
     else VAENPVC_TIMED("enc3_wgrad", s2, launch_convwgrad<WE3>(wg_enc(3), WGS, s2));
     if (!enc_bias_done[3]) generic::bias_grad(w.d_enc_a[3], G + l.b_off, F, l.cout, l.hout, s);
+    // the frame-owning tile with layer 2's LayerNorm backward in its epilogue (round 5): d(a2) straight from the GEMM, no d(y2) in HBM
+    int lnb_rows = 0;
+    if (vg && rt().cg_pf && rt().cg_lnb && !lnq && bwd_on(2))
+      for_dense_planes([&](auto npl) {
+        VAENPVC_TIMED("enc3_dgrad", s, lnb_rows = cv_gemm_lnb<decltype(npl)::value>(CV_E3G, w.scratch + Pk::cvw + cv_woff(CV_E3G), w.cl[CVS[CV_E3G].x], w.d_enc_a[2],
+                                                    w.enc_a[2], w.enc_st[2], P + pl.gamma_off, P + pl.beta_off, w.scratch + Pk::lnpart,
+                                                    (int64_t)2048 * 3 * 256, F, s));
+      });
+    if (lnb_rows > 0) {
+      VAENPVC_TIMED("lnb_enc2", s, hipLaunchKernelGGL(k_ln_bwd_reduce, dim3(3 * 64), dim3(256), 0, s, w.scratch + Pk::lnpart, lnb_rows, 64,
+                                                       G + pl.gamma_off, G + pl.beta_off, G + pl.b_off));
+    } else {
     if (vg) vdgrad(CV_E3G, w.dy_tmp, "enc3_dgrad");
     else
     VAENPVC_TIMED("enc3_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<GE3s>(conv_args(w.d_enc_a[3], nullptr, nullptr, nullptr, w.scratch + Pk::ge3,
@@ -1394,6 +1406,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
                                                                   nullptr, w.dy_tmp, F), nsplit_for<GE3>(F), s)));
     VAENPVC_TIMED("lnb_enc2", s, launch_ln_bwd<LnbCfg<64, 19>>(w.dy_tmp, w.enc_a[2], w.enc_st[2], P + pl.gamma_off, P + pl.beta_off, w.d_enc_a[2],
                                      G + pl.gamma_off, G + pl.beta_off, G + pl.b_off, w.scratch + Pk::lnpart, F, LWGS, s, lnq));
+    }
     enc_bias_done[2] = true;
   } else generic::bwd_enc_layer(m, P, x, F, w, G, s, 3);
   if (bwd_on(2)) {

@@ -1596,8 +1596,21 @@ struct CgPfTile {
   static constexpr int LDS_GEMM = NPL * ROWS * RS, LDS_OUT = TF * FPITCH * 4, LDS = LDS_GEMM > LDS_OUT ? LDS_GEMM : LDS_OUT;
   static_assert(PIECES % 256 == 0 && (TF * FOUT / 4) % 256 == 0, "staging / copy-out are whole rounds");
 };
-template <int NPL>
-__global__ void __launch_bounds__(256, 2) k_cgemm_pf(CgArgs a) {
+// LNB (round 5): the tile's 16 frames ARE the gradient at encoder layer 2's activated output, so the LayerNorm + lrelu backward of that
+// layer (autodiff of util/layers.py:32-44,149; the arithmetic of k_ln_bwd_fused, gfx950_elem.h) runs on the frames in LDS, one wave per frame:
+// a.out receives d(pre-LN output of layer 2) instead of d(activated output), the pre-LN tensor is read here (requested before the tile
+// is re-ordered, so the loads fly under the LDS traffic), and the per-channel sums for d gamma / d beta / d bias leave as one row of
+// `part` per workgroup (second stage: k_ln_bwd_reduce).  The gradient never exists in HBM as d(activated output): one write and one
+// read of the tensor and the separate pass (k_ln_bwd_fused<64, 19>, 85 us) are gone.
+struct CgLnbArgs {
+  const float* a2;      // [F][64][19] pre-LN output of the layer whose LayerNorm is differentiated
+  const float* st;      // [F][2] its statistics
+  const float* gamma;   // [64]
+  const float* beta;
+  float* part;          // [workgroups][3][64]: sum dn xhat | sum dn | sum du
+};
+template <int NPL, bool LNB = false>
+__global__ void __launch_bounds__(256, 2) k_cgemm_pf(CgArgs a, CgLnbArgs lb) {
   using T = CgPfTile<NPL>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int PLB = T::ROWS * T::RS, PPR = T::BK * 2 / 16;
@@ -1680,6 +1693,32 @@ __global__ void __launch_bounds__(256, 2) k_cgemm_pf(CgArgs a) {
   }
   // ---- epilogue: the tile through LDS as [frame][channel][position] fp32, then one contiguous run of the output tensor
   float* ot = reinterpret_cast<float*>(smem);
+  const int f0 = n0 / T::R, nf = min(T::TF, a.N / T::R - f0);
+  constexpr int P16 = T::FOUT / 4;     // 16-byte pieces per frame
+  constexpr int PPL = cdiv(P16, 64), FPW = T::TF / 4;   // LNB: pieces per lane, frames per wave
+  f32x4 av[LNB ? FPW : 1][LNB ? PPL : 1];
+  float gm[LNB ? PPL : 1][4], bt[LNB ? PPL : 1][4], fmean[LNB ? FPW : 1], frstd[LNB ? FPW : 1];
+  if constexpr (LNB) {
+#pragma unroll
+    for (int k = 0; k < FPW; ++k) {
+      const int f = min(f0 + wave + 4 * k, f0 + nf - 1);
+      fmean[k] = lb.st[2 * f];
+      frstd[k] = lb.st[2 * f + 1];
+#pragma unroll
+      for (int u = 0; u < PPL; ++u) {
+        const int pc = min(lane + 64 * u, P16 - 1);
+        av[k][u] = *reinterpret_cast<const f32x4*>(lb.a2 + (int64_t)f * T::FOUT + pc * 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PPL; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ch = (min(lane + 64 * u, P16 - 1) * 4 + k) / T::OH;
+        gm[u][k] = lb.gamma[ch];
+        bt[u][k] = lb.beta[ch];
+      }
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int nl = wn * 64 + j * 32 + l31, fl = nl / T::R, q = nl - fl * T::R;
@@ -1693,10 +1732,76 @@ __global__ void __launch_bounds__(256, 2) k_cgemm_pf(CgArgs a) {
     }
   }
   __syncthreads();
-  const int f0 = n0 / T::R, nf = min(T::TF, a.N / T::R - f0);
+  if constexpr (LNB) {
+    constexpr float INVN = 1.0f / T::FOUT;
+    float su[PPL][4], sw[PPL][4], sd[PPL][4];
+#pragma unroll
+    for (int u = 0; u < PPL; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) su[u][k] = sw[u][k] = sd[u][k] = 0.f;
+#pragma unroll
+    for (int kf = 0; kf < FPW; ++kf) {
+      const int fl = wave + 4 * kf;
+      if (fl >= nf) break;       // (uniform per wave)
+      const float mean = fmean[kf], rstd = frstd[kf];
+      float dn[PPL][4], xh[PPL][4];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int u = 0; u < PPL; ++u) {
+        const int pc = lane + 64 * u;
+        const bool ok = pc < P16;
+        const f32x4 dy = *reinterpret_cast<const f32x4*>(ot + fl * T::FPITCH + (ok ? pc : 0) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          xh[u][k] = (av[kf][u][k] - mean) * rstd;
+          const float nn = xh[u][k] * gm[u][k] + bt[u][k];
+          dn[u][k] = ok ? dy[k] * (nn >= 0.f ? 1.0f : LEAK) : 0.f;
+          const float dx = dn[u][k] * gm[u][k];
+          s1 += dx;
+          s2 += dx * xh[u][k];
+        }
+      }
+      s1 = wave_sum(s1) * INVN;
+      s2 = wave_sum(s2) * INVN;
+      float* og = a.out + (int64_t)(f0 + fl) * T::FOUT;
+#pragma unroll
+      for (int u = 0; u < PPL; ++u) {
+        const int pc = lane + 64 * u;
+        if (pc >= P16) continue;
+        f32x4 d;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          d[k] = rstd * (dn[u][k] * gm[u][k] - s1 - xh[u][k] * s2);
+          su[u][k] += dn[u][k] * xh[u][k];
+          sw[u][k] += dn[u][k];
+          sd[u][k] += d[k];
+        }
+        *reinterpret_cast<f32x4*>(og + pc * 4) = d;
+      }
+    }
+    __syncthreads();    // every wave is done with the tile: the LDS now carries the per-element sums [wave][3][FOUT]
+    float* ps = ot + wave * (3 * T::FOUT);
+#pragma unroll
+    for (int u = 0; u < PPL; ++u) {
+      const int pc = lane + 64 * u;
+      if (pc >= P16) continue;
+      *reinterpret_cast<f32x4*>(ps + pc * 4) = f32x4{su[u][0], su[u][1], su[u][2], su[u][3]};
+      *reinterpret_cast<f32x4*>(ps + T::FOUT + pc * 4) = f32x4{sw[u][0], sw[u][1], sw[u][2], sw[u][3]};
+      *reinterpret_cast<f32x4*>(ps + 2 * T::FOUT + pc * 4) = f32x4{sd[u][0], sd[u][1], sd[u][2], sd[u][3]};
+    }
+    __syncthreads();
+    if (tid < 3 * T::MDIV) {
+      const int which = tid / T::MDIV, c = tid - which * T::MDIV;
+      float v = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4)
+        for (int h = 0; h < T::OH; ++h) v += ot[w4 * (3 * T::FOUT) + which * T::FOUT + c * T::OH + h];
+      lb.part[(int64_t)blockIdx.x * (3 * T::MDIV) + tid] = v;
+    }
+    return;
+  }
   const u32x4* ot4 = reinterpret_cast<const u32x4*>(smem);
   u32x4* og = reinterpret_cast<u32x4*>(a.out + (int64_t)f0 * T::FOUT);
-  constexpr int P16 = T::FOUT / 4;     // 16-byte pieces per frame
 #pragma unroll
   for (int i = 0; i < T::TF * P16 / 256; ++i) {
     const int id = tid + 256 * i, fl = id / P16, pc = id - fl * P16;
@@ -1711,8 +1816,18 @@ inline bool cgemm_pf_serves(const CgArgs& a) {
 template <int NPL>
 inline void launch_cgemm_pf(const CgArgs& a, hipStream_t s) {
   using T = CgPfTile<NPL>;
-  rt().ensure_lds(reinterpret_cast<const void*>(&k_cgemm_pf<NPL>), T::LDS);
-  hipLaunchKernelGGL((k_cgemm_pf<NPL>), dim3((unsigned)cdiv(a.N, T::BN)), dim3(256), T::LDS, s, a);
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_cgemm_pf<NPL, false>), T::LDS);
+  hipLaunchKernelGGL((k_cgemm_pf<NPL, false>), dim3((unsigned)cdiv(a.N, T::BN)), dim3(256), T::LDS, s, a, CgLnbArgs{});
+}
+// ... with the LayerNorm backward of the layer below in its epilogue; returns the number of rows written to lb.part
+template <int NPL>
+inline int launch_cgemm_pf_lnb(const CgArgs& a, const CgLnbArgs& lb, hipStream_t s) {
+  using T = CgPfTile<NPL>;
+  static_assert(4 * 3 * T::FOUT * 4 <= T::LDS, "the per-element sums of four waves fit the tile's LDS");
+  const int nwg = cdiv(a.N, T::BN);
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_cgemm_pf<NPL, true>), T::LDS);
+  hipLaunchKernelGGL((k_cgemm_pf<NPL, true>), dim3((unsigned)nwg), dim3(256), T::LDS, s, a, lb);
+  return nwg;
 }
 
 // ---------------------------------------------------------------- S-type site on a tile that owns whole frames (round 5)

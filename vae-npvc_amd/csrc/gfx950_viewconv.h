@@ -268,6 +268,19 @@ static bool cv_gemm_stats_planes(int site, const float* wplanes, const float* xp
   return false;
 }
 
+// encoder layer 3's input gradient with the LayerNorm + lrelu backward of layer 2 in its epilogue (k_cgemm_pf<LNB>): `out` receives
+// d(pre-LN output of layer 2); returns the rows of `part` written (second stage: k_ln_bwd_reduce with C = 64), 0 = not served
+template <int NPL>
+static int cv_gemm_lnb(int site, const float* wplanes, const float* xplanes, float* out, const float* a2, const float* st, const float* gamma,
+                       const float* beta, float* part, int64_t part_capacity, int F, hipStream_t s) {
+  if constexpr (NPL <= 2) {
+    const CgArgs a = cv_gemm_args(site, wplanes, xplanes, out, nullptr, F);
+    if (!cgemm_pf_serves(a) || (int64_t)cdiv(a.N, CgPfTile<NPL>::BN) * 3 * 64 > part_capacity) return 0;
+    return launch_cgemm_pf_lnb<NPL>(a, CgLnbArgs{a2, st, gamma, beta, part}, s);
+  }
+  return 0;
+}
+
 template <int NPL>
 static void cv_gemm(int site, const float* wplanes, const float* xplanes, float* out, const float* bias, int F, hipStream_t s) {
   const CgArgs a = cv_gemm_args(site, wplanes, xplanes, out, bias, F);
