@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 5, call 5: A-resident merge forward GEMM (k_gemm_nt_ar): parity + A/B
+set -u
+OUT=gpurun_out/r5c5; mkdir -p $OUT
+rm -f gpurun_out/parity_report.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu --timeout 600 -k "a_resident or plane_gemm or benchmarked or unfiltered or properties or ragged" > $OUT/pytest.log 2>&1
+echo "pytest rc=$?" >> $OUT/pytest.log
+cp gpurun_out/parity_report.txt $OUT/ 2>/dev/null
+tail -3 $OUT/pytest.log
+T="merge_fwd,dec0_fwd,reparam"
+for i in 1 2; do
+  VAENPVC_NT_AR=0 python scripts/site_times.py --tags $T > $OUT/ar_off_$i.txt 2>&1
+  python scripts/site_times.py --tags $T > $OUT/ar_on_$i.txt 2>&1
+done
+python scripts/cmp_sites.py $OUT/ar_off_1.txt $OUT/ar_on_1.txt $OUT/ar_off_2.txt $OUT/ar_on_2.txt
+scripts/ab_env.sh 2 "VAENPVC_NT_AR=0" "-" 2>&1 | tee $OUT/ab.txt

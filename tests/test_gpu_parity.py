@@ -408,6 +408,18 @@ def test_plane_gemm_dense_layers_against_oracle(F, seed, precision):
 
 
 BF16_TOL_ACT, BF16_TOL_GRAD = 3e-2, 6e-2   # bf16 MODE (one bf16 term per operand, ~3 significant digits)
+@pytest.mark.parametrize('F,seed', [(128, 3), (384, 4), (1152, 5)])
+def test_a_resident_merge_gemm_against_oracle(F, seed, monkeypatch):
+    """The merge layer's forward GEMM on the A-resident kernel (k_gemm_nt_ar, round 5: one workgroup owns 128 frames, their K run stays
+    in LDS, the 13 column tiles of Wz stream past it; the default from 24 576 frames on) forced at small batches (VAENPVC_NT_AR=2,
+    plane GEMMs at any batch size): every tensor and gradient against the float64 oracle -- h, everything behind it, and the ragged
+    last column tile (1 539 = 12 x 128 + 3)."""
+    monkeypatch.setenv('VAENPVC_NT_AR', '2')
+    eng = make_engine('vcc', 'auto', masks=PLANE_GEMM)
+    fails = compare_everything(eng, F, seed, 'nt_ar F%d ' % F)
+    assert not fails, '\n'.join(fails)
+
+
 VIEW_CONV = (0xebffffff, 0xebffffff)    # ... and bit 26: every conv site on the view GEMMs (csrc/gfx950_viewconv.h)
 
 

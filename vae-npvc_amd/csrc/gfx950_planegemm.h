@@ -707,8 +707,17 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
   }  // tiles
 }
 
+inline bool gemm_nt_ar_serves(const NtArgs& a);
+template <int NPL>
+inline void launch_gemm_nt_ar(const NtArgs& a, hipStream_t s);
 template <int NPL>
 inline void launch_gemm_nt(const NtArgs& a, hipStream_t s) {
+  if constexpr (NPL <= 2) {
+    if (rt().nt_ar && gemm_nt_ar_serves(a) && (rt().nt_ar > 1 || a.M / NT_BM >= 192)) {   // short K, many rows: the A-resident kernel (Runtime::nt_ar)
+      launch_gemm_nt_ar<NPL>(a, s);
+      return;
+    }
+  }
   const int ntiles = cdiv(a.M, NT_BM) * cdiv(a.N, NT_BN);
   constexpr int SLOTS = 256 * VAENPVC_NT_WPS;     // resident workgroups of the chip
   // (one plane: the one-tile kernel fits three workgroups per CU at 138 registers, the persistent one two at 194: not used)
@@ -719,6 +728,165 @@ inline void launch_gemm_nt(const NtArgs& a, hipStream_t s) {
   }
   rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_nt<NPL, false>), nt_lds(NPL));
   hipLaunchKernelGGL((k_gemm_nt<NPL, false>), dim3((unsigned)ntiles), dim3(256), nt_lds(NPL), s, a);
+}
+
+// ---------------------------------------------------------------- C = A B^T with the A tile RESIDENT (short K; round 5)
+// The merge layer's forward GEMM (model/vae.py:51-61: h = z Wz + T[y], M = frames, N = 1539, K = 128) is a STORE stream: 201 MB of
+// results for 16 MB of operands and 17 GFLOP.  On the one-tile kernel above every 128 x 128 tile was its own workgroup: 3 328 prologues
+// (first loads, table, barriers) for two K chunks each, the A rows fetched 13 times -- 131-146 us against ~45 us for the stores alone.
+// Here ONE workgroup per CU owns 128 rows: their whole K run (Kp <= 128) stays in LDS, the column tiles of B stream through a second
+// LDS buffer (next tile requested into registers before the current one is multiplied), and the workgroup writes 128 complete rows of
+// C.  Full tiles issue their 64 result stores per lane UNCONDITIONALLY (M % 128 == 0 is required, the ragged last column tile takes
+// the predicated path): a static store count lets the wait for the prefetched tile be a counted one, so the stores drain under the
+// next tile's staging and MFMAs instead of being acknowledged first (loads and stores share one in-order counter).
+constexpr int NTA_KP = 128, NTA_RS = NTA_KP * 2 + 16;
+constexpr int nta_lds(int npl) { return npl * (NT_BM + NT_BN) * NTA_RS + NT_MAXRB * 128 * 4 + 128 * 4; }   // 148 480 bytes with two planes
+template <int NPL, bool RB>
+__global__ void __launch_bounds__(256, 1) k_gemm_nt_ar(NtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int APL = NT_BM * NTA_RS, BPL = NT_BN * NTA_RS, NQ = NTA_KP * 2 / 16 / 2;   // NQ: 16-byte pieces per thread, plane, operand (two threads per row)
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + NPL * APL;
+  float* Ts = reinterpret_cast<float*>(smem + NPL * (APL + BPL));   // [NT_MAXRB][128]
+  int* ys = reinterpret_cast<int*>(Ts + NT_MAXRB * 128);            // [128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = cdiv(a.N, NT_BN), m0 = blockIdx.x * NT_BM;
+  const int srow = tid >> 1, shalf = tid & 1;
+  constexpr bool rb = RB;                 // a.rowbias != nullptr (nrb <= NT_MAXRB: checked by the launcher); a template parameter: a uniform
+                                          // runtime flag left one branch per result store in the epilogue
+  constexpr int NTB = NT_MAXRB * 128 / 256;   // table floats per thread
+  {  // the A tile, once
+    const unsigned char* ga = reinterpret_cast<const unsigned char*>(a.A) + ((size_t)(m0 + srow) * a.Kp) * 2 + shalf * (NTA_KP);
+    u32x4 ra[NPL][NQ];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) ra[p][q] = *reinterpret_cast<const u32x4*>(ga + (size_t)p * a.a_plane * 2 + q * 16);
+    if (rb && tid < 128) {
+      const int64_t r = a.idx[m0 + tid];
+      ys[tid] = (int)(r < 0 ? 0 : (r >= a.nrb ? a.nrb - 1 : r));
+    }
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) *reinterpret_cast<u32x4*>(sA + p * APL + srow * NTA_RS + shalf * NTA_KP + q * 16) = ra[p][q];
+  }
+  u32x4 rbq[NPL][NQ];
+  float tb[NTB], bb2[2];
+  auto gload = [&](int t) __attribute__((always_inline)) {   // column tile t: its rows of B, its slice of the speaker table, its bias values
+    const int n0 = t * NT_BN;
+    const unsigned char* gb = reinterpret_cast<const unsigned char*>(a.B) + ((size_t)(n0 + srow) * a.Kp) * 2 + shalf * NTA_KP;
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) rbq[p][q] = *reinterpret_cast<const u32x4*>(gb + (size_t)p * a.b_plane * 2 + q * 16);
+    if (rb) {
+#pragma unroll
+      for (int u = 0; u < NTB; ++u) {
+        const int i = tid + 256 * u, k = min(i >> 7, a.nrb - 1), n = min(n0 + (i & 127), a.N - 1);   // (clamped: entries past nrb / N are never read)
+        tb[u] = a.rowbias[(int64_t)k * a.ldrb + n];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = min(n0 + wn * 64 + j * 32 + l31, a.N - 1);
+      bb2[j] = a.bias ? a.bias[n] : 0.f;
+    }
+  };
+  const int aoff = (wm * 64 + l31) * NTA_RS + lh * 16;
+  const int boff = (wn * 64 + l31) * NTA_RS + lh * 16;
+  f32x16 acc[2][2];
+  u32x4 fa[2][2][NPL], fb[2][2][NPL];
+  auto loadF = [&](int set, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        fa[set][t][p] = *reinterpret_cast<const u32x4*>(sA + p * APL + aoff + t * 32 * NTA_RS + ks * 32);
+        fb[set][t][p] = *reinterpret_cast<const u32x4*>(sB + p * BPL + boff + t * 32 * NTA_RS + ks * 32);
+      }
+  };
+  auto mm = [&](int set) __attribute__((always_inline)) {
+    using PR = Prod<NPL>;
+#pragma unroll
+    for (int t = 0; t < PR::N; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[set][i][PR::A[t]], fb[set][j][PR::B[t]], acc[i][j]);
+  };
+  constexpr int NKS = NTA_KP / 16;
+  // One column tile.  The loop over the FULL tiles is straight-line code (the ragged last tile is peeled, the request for the next tile
+  // is unconditional with a clamped index): only then can the wait for the prefetched registers at the top of the next tile be a counted
+  // one that leaves this tile's 64 result stores in flight (a branch anywhere in between makes the compiler wait for everything).
+  auto tile_body = [&](int t, auto full_) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_)::value;
+    const int n0 = t * NT_BN;
+    // the prefetched tile into LDS (the previous tile's fragment / table reads ended at the barrier that closed its iteration)
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) *reinterpret_cast<u32x4*>(sB + p * BPL + srow * NTA_RS + shalf * NTA_KP + q * 16) = rbq[p][q];
+    if constexpr (rb) {
+#pragma unroll
+      for (int u = 0; u < NTB; ++u) Ts[tid + 256 * u] = tb[u];
+    }
+    const float bb[2] = {bb2[0], bb2[1]};
+    __syncthreads();
+    gload(min(t + 1, ntn - 1));     // (the last tile requests itself again: no branch)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+    loadF(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      if (ks + 1 < NKS) loadF((ks + 1) & 1, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // epilogue: lanes = 32 consecutive columns of a row -> 128-byte runs
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nl = wn * 64 + j * 32 + l31, n = n0 + nl;
+      if (!FULL && n >= a.N) continue;
+      float* cb = a.C + n;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int ml = wm * 64 + i * 32 + acc_row(reg, lane);
+          float v = acc[i][j][reg] + bb[j];
+          if constexpr (rb) v += Ts[ys[ml] * 128 + nl];
+          cb[(int64_t)(m0 + ml) * a.ldc] = v;
+        }
+    }
+    __syncthreads();   // fragment and table reads of this tile are done before the next one overwrites them
+  };
+  const int nfull = a.N / NT_BN;
+  gload(0);
+  // (the first tile is peeled as well: the loop is then ENTERED in the state its back edge leaves -- one tile request and 64 stores
+  //  outstanding -- and the wait at its top stays counted; entered straight from gload(0) the compiler merges both states to "wait for all")
+  tile_body(0, std::true_type{});
+  for (int t = 1; t < nfull; ++t) tile_body(t, std::true_type{});
+  if (nfull < ntn) tile_body(nfull, std::false_type{});
+}
+// served: short K resident in LDS, whole 128-row tiles, one output tensor, a table that fits
+inline bool gemm_nt_ar_serves(const NtArgs& a) {
+  return a.Kp == NTA_KP && a.M % NT_BM == 0 && !a.C2 && (!a.rowbias || (a.nrb <= NT_MAXRB && a.idx)) && a.N >= NT_BN;
+}
+template <int NPL>
+inline void launch_gemm_nt_ar(const NtArgs& a, hipStream_t s) {
+  if (a.rowbias) {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_nt_ar<NPL, true>), nta_lds(NPL));
+    hipLaunchKernelGGL((k_gemm_nt_ar<NPL, true>), dim3((unsigned)(a.M / NT_BM)), dim3(256), nta_lds(NPL), s, a);
+  } else {
+    rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_nt_ar<NPL, false>), nta_lds(NPL));
+    hipLaunchKernelGGL((k_gemm_nt_ar<NPL, false>), dim3((unsigned)(a.M / NT_BM)), dim3(256), nta_lds(NPL), s, a);
+  }
 }
 
 // (An LDS-DMA variant of this kernel -- global_load_lds_dwordx4 into a ring of 2-4 unpadded, XOR-swizzled stage
