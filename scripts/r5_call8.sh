@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 5, call 8: bf16 mode with / without the LDS epilogue of C = A B^T (one plane: 2 instead of 3 workgroups per CU); bf16 mode site table
+set -u
+OUT=gpurun_out/r5c8; mkdir -p $OUT
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu --timeout 600 -k "bf16_mode or plane_gemm" > $OUT/pytest.log 2>&1
+echo "pytest rc=$?" >> $OUT/pytest.log
+tail -3 $OUT/pytest.log
+for i in 1 2; do
+  for e in "VAENPVC_NT_LEP=0" "VAENPVC_NT_LEP=1"; do
+    env $e python bench.py --precision bf16 --steps 40 --warmup 10 --no-cpu-baseline --no-literal --no-modes --no-convert 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$e bf16', round(d['ms_per_step'],4))"
+  done
+done 2>&1 | tee $OUT/ab_bf16.txt
+python scripts/site_times.py --precision bf16 > $OUT/sites_bf16.txt 2>&1; tail -1 $OUT/sites_bf16.txt
+python scripts/site_times.py > $OUT/sites.txt 2>&1; tail -1 $OUT/sites.txt

@@ -485,6 +485,7 @@ struct NtArgs {
   const float* rowbias;   // [nrb][ldrb] or nullptr: row idx[m] is added to output row m
   const int64_t* idx;
   int nrb, ldrb;
+  int lep;                // 1: result tile through LDS, 16-byte stores (set by the launcher: Runtime::nt_lep, env VAENPVC_NT_LEP)
 };
 constexpr int NT_BM = 128, NT_BN = 128;
 constexpr int NT_MAXRB = 16;   // row-bias table rows the epilogue keeps in LDS (speakers; VCC2016: 10)
@@ -502,7 +503,13 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nwg) {
 #define VAENPVC_NT_BK2 64
 #endif
 constexpr int nt_bk(int npl) { return npl >= 3 ? 32 : VAENPVC_NT_BK2; }
-constexpr int nt_lds(int npl) { return npl * (NT_BM + NT_BN) * (nt_bk(npl) * 2 + 16); }  // 73 728 (2 planes) / 61 440 (3)
+// the result tile goes through LDS on its way out (round 5, two planes and more): [128][NT_EP_PITCH] floats behind the speaker table
+constexpr int NT_EP_PITCH = NT_BN + 4, NT_EP_OFF = NT_MAXRB * 128 * 4 + 128 * 4, NT_EP_LDS = NT_EP_OFF + NT_BM * NT_EP_PITCH * 4;   // 76 288 bytes
+constexpr bool nt_lep(int npl) { return npl >= 1; }   // (one plane: 36 KB of staging fit three workgroups per CU, the tile leaves two: measured)
+constexpr int nt_lds(int npl) {
+  const int st = npl * (NT_BM + NT_BN) * (nt_bk(npl) * 2 + 16);  // 73 728 (2 planes) / 61 440 (3)
+  return nt_lep(npl) && NT_EP_LDS > st ? NT_EP_LDS : st;
+}
 
 #ifndef VAENPVC_NT_CST
 #define VAENPVC_NT_CST 0   // 1: non-temporal result stores (the result streams past the L2 that holds the weight tiles)
@@ -656,6 +663,53 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
     }
     __syncthreads();
   }
+  // ---- epilogue through LDS (round 5): the 128 x 128 tile is parked as fp32 rows, then every thread stores 16-byte pieces of whole
+  //      512-byte row runs -- 16 store instructions per lane instead of 64 four-byte ones.  The one-tile launches spent a quarter of their
+  //      time issuing those (ablation without result stores: 176 -> 144 us, DESIGN.md section 6: a CU retires ~4 bytes per clock of
+  //      4-byte-per-lane stores).  Bias and the speaker's table row are added on the way out (bias values fetched before the first store).
+  if (nt_lep(NPL) && a.lep && (!a.rowbias || rb_lds) && (!a.C2 || (a.split % NT_BN) == 0)) {   // uniform
+    float* ot = reinterpret_cast<float*>(smem + NT_EP_OFF);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          ot[(wm * 64 + i * 32 + acc_row(reg, lane)) * NT_EP_PITCH + wn * 64 + j * 32 + l31] = acc[i][j][reg];
+    const int pc = tid & 31, r0 = tid >> 5, n = n0c + pc * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bv[k] = a.bias[min(n + k, a.N - 1)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch_next();
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    const bool second = a.C2 && n0c >= a.split;
+    float* cb = (second ? a.C2 : a.C) + (n - (second ? a.split : 0));
+    const bool whole = n + 3 < a.N;
+#pragma unroll
+    for (int i = 0; i < NT_BM / 8; ++i) {
+      const int row = r0 + 8 * i, m = m0c + row;
+      f32x4 v = *reinterpret_cast<const f32x4*>(ot + row * NT_EP_PITCH + pc * 4);
+      v += bv;
+      if (rb_lds) v += *reinterpret_cast<const f32x4*>(Ts + ys[row] * 128 + pc * 4);
+      if (m >= a.M) continue;
+      float* o = cb + (int64_t)m * a.ldc;
+      if (whole) {
+        st_nt<VAENPVC_NT_CST != 0>(reinterpret_cast<f32x4_a4*>(o), f32x4_a4{v[0], v[1], v[2], v[3]});
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (n + k < a.N) o[k] = v[k];
+      }
+    }
+    if (!PERS || tile_next >= tile_end) break;
+    tile = tile_next;
+    __syncthreads();   // the tile and the table are read before the next tile's chunks overwrite the LDS
+    continue;
+  }
   // epilogue: lanes = 32 consecutive columns of a row -> 128-byte stores (both bias values first: a load issued between the
   // stores would order the later ones behind its round trip)
   float bb2[2];
@@ -711,8 +765,10 @@ inline bool gemm_nt_ar_serves(const NtArgs& a);
 template <int NPL>
 inline void launch_gemm_nt_ar(const NtArgs& a, hipStream_t s);
 template <int NPL>
-inline void launch_gemm_nt(const NtArgs& a, hipStream_t s) {
-  if constexpr (NPL <= 2) {
+inline void launch_gemm_nt(const NtArgs& a_, hipStream_t s) {
+  NtArgs a = a_;
+  a.lep = rt().nt_lep ? 1 : 0;
+  if constexpr (NPL == 2) {   // (two planes: the result tile is parked in the B buffer, which one plane does not fill)
     if (rt().nt_ar && gemm_nt_ar_serves(a) && (rt().nt_ar > 1 || a.M / NT_BM >= 192)) {   // short K, many rows: the A-resident kernel (Runtime::nt_ar)
       launch_gemm_nt_ar<NPL>(a, s);
       return;
@@ -741,6 +797,7 @@ inline void launch_gemm_nt(const NtArgs& a, hipStream_t s) {
 // next tile's staging and MFMAs instead of being acknowledged first (loads and stores share one in-order counter).
 constexpr int NTA_KP = 128, NTA_RS = NTA_KP * 2 + 16;
 constexpr int nta_lds(int npl) { return npl * (NT_BM + NT_BN) * NTA_RS + NT_MAXRB * 128 * 4 + 128 * 4; }   // 148 480 bytes with two planes
+static_assert(NT_BM * NT_EP_PITCH * 4 <= 2 * NT_BN * NTA_RS, "the result tile fits the B buffer (two planes)");
 template <int NPL, bool RB>
 __global__ void __launch_bounds__(256, 1) k_gemm_nt_ar(NtArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -773,7 +830,8 @@ __global__ void __launch_bounds__(256, 1) k_gemm_nt_ar(NtArgs a) {
       for (int q = 0; q < NQ; ++q) *reinterpret_cast<u32x4*>(sA + p * APL + srow * NTA_RS + shalf * NTA_KP + q * 16) = ra[p][q];
   }
   u32x4 rbq[NPL][NQ];
-  float tb[NTB], bb2[2];
+  float tb[NTB];
+  f32x4 bv4;
   auto gload = [&](int t) __attribute__((always_inline)) {   // column tile t: its rows of B, its slice of the speaker table, its bias values
     const int n0 = t * NT_BN;
     const unsigned char* gb = reinterpret_cast<const unsigned char*>(a.B) + ((size_t)(n0 + srow) * a.Kp) * 2 + shalf * NTA_KP;
@@ -789,10 +847,7 @@ __global__ void __launch_bounds__(256, 1) k_gemm_nt_ar(NtArgs a) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = min(n0 + wn * 64 + j * 32 + l31, a.N - 1);
-      bb2[j] = a.bias ? a.bias[n] : 0.f;
-    }
+    for (int k = 0; k < 4; ++k) bv4[k] = a.bias ? a.bias[min(n0 + (tid & 31) * 4 + k, a.N - 1)] : 0.f;
   };
   const int aoff = (wm * 64 + l31) * NTA_RS + lh * 16;
   const int boff = (wn * 64 + l31) * NTA_RS + lh * 16;
@@ -832,7 +887,7 @@ __global__ void __launch_bounds__(256, 1) k_gemm_nt_ar(NtArgs a) {
 #pragma unroll
       for (int u = 0; u < NTB; ++u) Ts[tid + 256 * u] = tb[u];
     }
-    const float bb[2] = {bb2[0], bb2[1]};
+    const f32x4 bv = bv4;
     __syncthreads();
     gload(min(t + 1, ntn - 1));     // (the last tile requests itself again: no branch)
     __builtin_amdgcn_sched_barrier(0);
@@ -848,23 +903,35 @@ __global__ void __launch_bounds__(256, 1) k_gemm_nt_ar(NtArgs a) {
       mm(ks & 1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // epilogue: lanes = 32 consecutive columns of a row -> 128-byte runs
+    // epilogue through LDS (as k_gemm_nt): the tile parked as fp32 rows in the B buffer, then 16-byte pieces of whole 512-byte row runs
+    __syncthreads();   // every wave is done with this tile's B fragments
+    float* ot = reinterpret_cast<float*>(sB);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int nl = wn * 64 + j * 32 + l31, n = n0 + nl;
-      if (!FULL && n >= a.N) continue;
-      float* cb = a.C + n;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int ml = wm * 64 + i * 32 + acc_row(reg, lane);
-          float v = acc[i][j][reg] + bb[j];
-          if constexpr (rb) v += Ts[ys[ml] * 128 + nl];
-          cb[(int64_t)(m0 + ml) * a.ldc] = v;
-        }
+        for (int reg = 0; reg < 16; ++reg)
+          ot[(wm * 64 + i * 32 + acc_row(reg, lane)) * NT_EP_PITCH + wn * 64 + j * 32 + l31] = acc[i][j][reg];
+    __syncthreads();
+    const int pc = tid & 31, r0 = tid >> 5, n = n0 + pc * 4;
+    float* cb = a.C + (int64_t)m0 * a.ldc + n;
+#pragma unroll
+    for (int i = 0; i < NT_BM / 8; ++i) {
+      const int row = r0 + 8 * i;
+      f32x4 v = *reinterpret_cast<const f32x4*>(ot + row * NT_EP_PITCH + pc * 4);
+      v += bv;
+      if constexpr (rb) v += *reinterpret_cast<const f32x4*>(Ts + ys[row] * 128 + pc * 4);
+      float* o = cb + (int64_t)row * a.ldc;
+      if (FULL || n + 3 < a.N) {
+        *reinterpret_cast<f32x4_a4*>(o) = f32x4_a4{v[0], v[1], v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (n + k < a.N) o[k] = v[k];
+      }
     }
-    __syncthreads();   // fragment and table reads of this tile are done before the next one overwrites them
+    __syncthreads();   // tile and table reads are done before the next tile overwrites them
   };
   const int nfull = a.N / NT_BN;
   gload(0);

@@ -51,8 +51,11 @@ struct Runtime {
   bool cg_pf = true;            // VAENPVC_CG_PF=0: encoder layer 3's input gradient on the 64 x 256 view-GEMM tiles instead of the frame-owning 192 x 128 tile (A/B)
   bool cg_sf = true;            // VAENPVC_CG_SF=0: encoder layer 3 forward on the one-tile view GEMM + the separate statistics / planes pass (A/B)
   bool cg_lnb = true;           // VAENPVC_CG_LNB=0: encoder layer 2's LayerNorm backward as its own pass behind layer 3's input gradient (A/B)
-  int nt_ar = 1;                // VAENPVC_NT_AR: the merge forward GEMM on the A-resident kernel (k_gemm_nt_ar): 1 = from 192 row tiles on (one workgroup
-                                // per CU), 0 = never (A/B), 2 = whenever the shape is served (parity tests at small batches)
+  int nt_ar = 0;                // VAENPVC_NT_AR: the merge forward GEMM on the A-resident kernel (k_gemm_nt_ar): 1 = from 192 row tiles on (one workgroup
+                                // per CU), 0 = never, 2 = whenever the shape is served (parity tests at small batches).  OFF: measured 102 us against
+                                // 98 us for the one-tile kernel once both store through LDS, and the decoder layer behind it runs 20 us slower
+                                // (279 -> 299 us: the rows of h leave the caches in another order); round 5, three interleaved rounds on one box
+  bool nt_lep = true;           // VAENPVC_NT_LEP=0: C = A B^T results stored straight from the accumulators (4 bytes per lane) instead of through LDS (A/B)
   int tn_xcd = -1;              // VAENPVC_TN_XCD=0|1: tile order of the C += A^T B plane GEMM (experiments; -1 = per site)
   int toep_zc = 4;              // VAENPVC_TOEP_ZC: frame chunks of the Toeplitz weight gradient, 64 workgroups each (4: one workgroup per CU, one prologue / epilogue per CU)
   bool toep_f32 = false;        // VAENPVC_TOEP=f32: exact-fp32 MFMA kernels for the 1025-tap layer
