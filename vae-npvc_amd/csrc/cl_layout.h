@@ -27,6 +27,7 @@ constexpr ClDesc CLD[CL_COUNT] = {
     {16, 171, 16, 2, 175},   // CL_GD1                                       (pad 2 + 2)
     {8, 513, 8, 2, 517},     // CL_GD2
 };
+constexpr int DY2_PITCH = 516;   // floats per row of d(activated output of decoder layer 2) when its rows are padded to 16 bytes (8 x 516 per frame)
 constexpr int CL_TAIL = 64;  // zero elements behind every plane (K runs padded to the chunk size read into them)
 inline int64_t cl_plane(int id, int64_t F) { return F * CLD[id].HP * CLD[id].CP + CL_TAIL; }
 // workspace floats of a tensor: three planes of unsigned short

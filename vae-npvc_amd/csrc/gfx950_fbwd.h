@@ -33,6 +33,7 @@ namespace vaenpvc {
 namespace tuned {
 
 enum { FB_D2, FB_D1, FB_E1, FB_COUNT };
+constexpr int FB_DY2_PITCH = 516;   // padded rows of decoder layer 2's dy (513 bins -> 16-byte aligned rows; cl_layout.h: DY2_PITCH)
 constexpr bool fb_enc(int l) { return l == FB_E1; }
 constexpr int fb_gsite(int l) { return l == FB_D2 ? CV_D2G : l == FB_D1 ? CV_D1G : CV_E1G; }
 constexpr int fb_wsite(int l) { return l == FB_D2 ? CW_D2 : l == FB_D1 ? CW_D1 : CW_E1; }
@@ -105,14 +106,18 @@ struct FbArgs {
   float* dbias;
   int F;
   bool bf16_act = false;   // bf16 activation storage of the decoder tensors (launch_fbwd picks the layer's pattern)
+  int dy_pitch = 0;        // decoder layer 2: floats per row of dy when its producer padded the rows to 16 bytes (516; 0 = the tensor's own rows)
 };
 
 // BFM: bf16 activation storage (precision "bf16"): bit 0 = dy and a, bit 1 = the input activation xa, bit 2 = the result dx
-template <int NPL, int L, int BFM = 0>
+// DYP: floats per row of dy when they differ from the tensor's (the 1025-tap layer's input gradient writes rows of 516 floats so that
+// its 16-byte stores are aligned, gfx950_toep_bf16.h); 0 = rows of the tensor
+template <int NPL, int L, int BFM = 0, int DYP = 0>
 __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
   using T = FbCfg<NPL, L>;
   constexpr bool BFG = BFM & 1, BFX = (BFM >> 1) & 1, BFO = (BFM >> 2) & 1;
-  constexpr int PG = act_pitch(BFG, T::HG), PO = act_pitch(BFO, T::V.OH);
+  constexpr int PG = act_pitch(BFG, T::HG), PO = act_pitch(BFO, T::V.OH), PD = DYP ? DYP : PG;
+  static_assert(DYP == 0 || (BFM == 0 && DYP >= T::HG), "padded rows: fp32 storage");
   static_assert(BFM == 0 || (NPL == 1 && !T::ENC), "bf16 storage: decoder layers of the bf16 mode");
   constexpr CvSite V = T::V;
   constexpr int CUG = T::CUG, HG = T::HG, CGR = T::CGR, NITG = T::NITG, IPWG = T::IPWG;
@@ -154,9 +159,10 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
       const bool ok = it < NITG && h < HG;
       // (addresses clamped into the tensor instead of predicated loads: no branch per load, the loads issue back to back)
       const int64_t fo = (int64_t)f * (T::CG * PG) + cg * CUG * PG + (ok ? h : 0);
+      const int64_t fd = (int64_t)f * (T::CG * PD) + cg * CUG * PD + (ok ? h : 0);
 #pragma unroll
       for (int c = 0; c < CUG; ++c) {
-        if constexpr ((WHICH & 1) != 0) vd[u][c] = (VAENPVC_FB_ABL & 8) ? 0.5f : act_ld<BFG>(a.dy, fo + c * PG);
+        if constexpr ((WHICH & 1) != 0) vd[u][c] = (VAENPVC_FB_ABL & 8) ? 0.5f : act_ld<BFG>(a.dy, fd + c * PD);
         if constexpr ((WHICH & 2) != 0) va[u][c] = (VAENPVC_FB_ABL & 8) ? 0.25f : act_ld<BFG>(a.a, fo + c * PG);
       }
 #pragma unroll
@@ -421,6 +427,13 @@ static void launch_fbwd(const FbArgs& a, hipStream_t s) {
       constexpr int BFM = L == FB_D2 ? 7 : 1;
       rt().ensure_lds(reinterpret_cast<const void*>(&k_fbwd<NPL, L, BFM>), T::LDS);
       hipLaunchKernelGGL((k_fbwd<NPL, L, BFM>), dim3(grid), dim3(256), T::LDS, s, a);
+      return;
+    }
+  }
+  if constexpr (L == FB_D2) {
+    if (a.dy_pitch == FB_DY2_PITCH) {
+      rt().ensure_lds(reinterpret_cast<const void*>(&k_fbwd<NPL, L, 0, FB_DY2_PITCH>), T::LDS);
+      hipLaunchKernelGGL((k_fbwd<NPL, L, 0, FB_DY2_PITCH>), dim3(grid), dim3(256), T::LDS, s, a);
       return;
     }
   }

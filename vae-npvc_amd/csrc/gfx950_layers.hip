@@ -873,6 +873,12 @@ bool reparam_fwd_planes(const Model& m, const float* eps, const PhiloxKey* key, 
 #define VAENPVC_NLL_POST 1
 #endif
 static inline int nll_post_blocks(int64_t F) { return cmin_(1024, cdiv((int)F, 4)); }   // (each leaves a 16 KB part of the last layer's edge term)
+// floats per row of d(activated output of decoder layer 2) in dy_tmp: padded to 16 bytes when its producer is the bf16 Toeplitz input-gradient
+// GEMM and its only consumer the fused backward kernel of decoder layer 2 (VAENPVC_DY2_PAD=0: the tensor's own 513-float rows, A/B)
+static inline int dy2_pitch(int64_t F) {
+  static_assert(FB_DY2_PITCH == DY2_PITCH, "one constant");
+  return (rt().dy2_pad && toep_bf16_for(F) && bwd_on(9) && bwd_on(10) && fb_bwd(FB_D2, F) && !act_bf16(F) && !frame_bwd_on(F)) ? DY2_PITCH : TB_H;
+}
 bool loss_fwd_post(const Model& m, const float* P, const float* x, int64_t F64, const Ws& w, float* loss3, hipStream_t s) {
   const int F = (int)F64;
   if (!VAENPVC_NLL_POST || !w.d_xh || !w.toep_gp || !w.dy_tmp || !w.dec_y || !w.d_dec_a[0] || !fwd_on(9) || !fwd_on(10) || F < 1024 || frame_bwd_on(F64) || !bwd_on(10) || !toep_bf16_for(F) || act_bf16(F)) return false;
@@ -880,7 +886,8 @@ bool loss_fwd_post(const Model& m, const float* P, const float* x, int64_t F64, 
     constexpr int NPL = decltype(npl)::value;
     hipLaunchKernelGGL((k_nll_dxh_post<NPL>), dim3((unsigned)nll_post_blocks(F)), dim3(256), 0, s, x, w.xh, w.nll_f, w.d_xh, P + m.dec[3].w_off,
                        reinterpret_cast<unsigned short*>(w.toep_gp), w.dy_tmp, w.scratch + Pk::lnpart, F, 1.0f / (float)F, w.dec_y,
-                       w.d_dec_a[0]);   // (the edge-term parts wait in d(a0)'s buffer: nothing writes it before the backward pass has added them)
+                       w.d_dec_a[0],    // (the edge-term parts wait in d(a0)'s buffer: nothing writes it before the backward pass has added them)
+                       dy2_pitch(F));
   });
   generic::loss_reduce(F, w, loss3, s);
   rt().dxh_post_F = F;
@@ -924,7 +931,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       constexpr int NPL_ = decltype(npl)::value;
       auto launch_dp = [&](auto kern) {
         VAENPVC_TIMED("dxh_post", s, hipLaunchKernelGGL(kern, dim3((unsigned)cmin_(2048, cdiv((int)F, 4))), dim3(256), 0, s, w.d_xh, P + m.dec[3].w_off,
-                           reinterpret_cast<unsigned short*>(w.toep_gp), w.dy_tmp, G + m.dec[3].b_off, (int)F));
+                           reinterpret_cast<unsigned short*>(w.toep_gp), w.dy_tmp, G + m.dec[3].b_off, (int)F, dy2_pitch(F)));
       };
       if constexpr (NPL_ == 1) {
         if (abf) { launch_dp(k_dxh_post<1, true>); return; }
@@ -1061,7 +1068,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
         if constexpr (NPL == 1) {
           if (abf) { launch_dg(&k_toep_gemm_bf16<false, 1, true>); return; }
         }
-        launch_dg(&k_toep_gemm_bf16<false, NPL, false>);
+        if (dy2_pitch(F) == DY2_PITCH) launch_dg(&k_toep_gemm_bf16<false, NPL, false, DY2_PITCH>);
+        else launch_dg(&k_toep_gemm_bf16<false, NPL, false>);
       });
     } else
     if (F >= 8192) {
@@ -1090,6 +1098,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
                 P + pl.beta_off, reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvw + cv_woff(fb_gsite(layer))), dx,
                 G + l.w_off, G + l.gamma_off, G + l.beta_off, G + l.b_off, F};
       fa.bf16_act = abf && !enc;
+      fa.dy_pitch = (layer == FB_D2 && dy2_pitch(F) == DY2_PITCH) ? DY2_PITCH : 0;
       VAENPVC_TIMED(tag, s, fbwd<NPL>(layer, fa, s));
     });
   };

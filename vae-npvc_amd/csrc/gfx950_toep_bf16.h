@@ -151,7 +151,8 @@ constexpr int TB_WFLOATS = TB_C * tb_wch(3) / 4;              // floats reserved
 template <int NPL, bool BOUT = false>   // BOUT: dY is stored as bf16 with rows of 514 (bf16 activation storage)
 __global__ void __launch_bounds__(256) k_dxh_post(const float* __restrict__ G, const float* __restrict__ W,
                                                   unsigned short* __restrict__ dst, float* __restrict__ dY,
-                                                  float* __restrict__ dbias, int F) {
+                                                  float* __restrict__ dbias, int F,
+                                                  int dyp = TB_H) {   // floats per row of the fp32 dY (516: rows padded to 16 bytes, round 5)
   __shared__ float sm[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // taps of this lane's 8 bins, all 8 channels: W[(8l + j)*8 + c], 64 contiguous floats
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(256) k_dxh_post(const float* __restrict__ G, c
 #pragma unroll
     for (int c = 0; c < TB_C; ++c) {
       float v = wave_sum(dot[c]);
-      if (lane == 0) act_st<BOUT>(dY, ((int64_t)f * TB_C + c) * act_pitch(BOUT, TB_H) + 512, v);
+      if (lane == 0) act_st<BOUT>(dY, ((int64_t)f * TB_C + c) * (BOUT ? act_pitch(true, TB_H) : dyp) + 512, v);
     }
   }
   bsum = wave_sum(bsum);
@@ -227,7 +228,8 @@ __global__ void __launch_bounds__(256) k_nll_dxh_post(const float* __restrict__ 
                                                       float* __restrict__ G, const float* __restrict__ W, unsigned short* __restrict__ dst,
                                                       float* __restrict__ dY, float* __restrict__ bpart, int F, float invF,
                                                       const float* __restrict__ y2,      // activated output of the layer in front ([F][8][513]: bin 512 is read)
-                                                      float* __restrict__ wpart) {       // [gridDim.x][513 * 8]: this workgroup's part of the edge term
+                                                      float* __restrict__ wpart,         // [gridDim.x][513 * 8]: this workgroup's part of the edge term
+                                                      int dyp) {                         // floats per row of dY (513, or 516: rows padded to 16 bytes)
   //  dW[t][c] += sum_f y2[f][c][512] * d(xh)[f][t], t <= 512, of the last layer's weight gradient (k_toep_wgrad_row512 re-read d(xh) for it)
   __shared__ float sm[4];
   __shared__ float wsum[65 * 64];   // [j * 8 + c][lane] (+ row 64: bin 512)
@@ -323,7 +325,7 @@ __global__ void __launch_bounds__(256) k_nll_dxh_post(const float* __restrict__ 
 #pragma unroll
     for (int c = 0; c < TB_C; ++c) {
       const float v = wave_sum(dot[c]);
-      if (lane == 0) dY[((int64_t)f * TB_C + c) * TB_H + 512] = v;
+      if (lane == 0) dY[((int64_t)f * TB_C + c) * dyp + 512] = v;
     }
   }
   bsum = wave_sum(bsum);
@@ -414,7 +416,11 @@ constexpr int dg_lds(int npl) { return npl * DG_APL + tb_wch(npl); }  // NPL = 3
 // planes are per channel ([F][3][8][528]) and the accumulators run over all 8 channels.
 // (second launch bound = waves per SIMD.  One plane: two workgroups per CU, -10..13 %; two planes need 344 - 388
 //  registers and spill at 256: measured equal or slower, so they keep one workgroup per CU)
-template <bool FWD, int NPL, bool BOUT = false>   // BOUT (input gradient only): dY stored as bf16, rows of 514
+// DYP (input gradient only, round 5): floats per row of the fp32 result.  The canonical [F][8][513] rows start at every 4-byte alignment, and
+// 16-byte stores that are not 16-byte aligned retire at about HALF the rate (this kernel with one plane: 538 MB in 230 us = 2.3 TB/s, the
+// merge GEMM's 1 539-float rows the same); with rows of 516 floats every store of this epilogue is aligned.  Only the fused backward
+// kernel of decoder layer 2 reads the result (gfx950_fbwd.h, same pitch).
+template <bool FWD, int NPL, bool BOUT = false, int DYP = TB_H>   // BOUT (input gradient only): dY stored as bf16, rows of 514
 __global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(const unsigned short* __restrict__ gp,   // A planes
                                                             const unsigned short* __restrict__ wcp,  // packed tap copies
                                                             const float* __restrict__ bias,          // FWD: [1]
@@ -592,8 +598,9 @@ __global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(cons
     // epilogue: rows = frames, lanes = 32 consecutive bins -> 128-byte stores; one uniform base
     // per workgroup and channel, 32-bit lane offsets, column tiles through the immediate offset
     {
-      constexpr int ORS = (FWD ? 1 : TB_C) * TB_H;  // floats between consecutive frames of the output
-      float* ob = dY + ((int64_t)f0 * (FWD ? 1 : TB_C) + (FWD ? 0 : c)) * TB_H;
+      constexpr int OP = FWD ? TB_H : DYP;          // floats per output row
+      constexpr int ORS = (FWD ? 1 : TB_C) * OP;    // floats between consecutive frames of the output
+      float* ob = dY + ((int64_t)f0 * (FWD ? 1 : TB_C) + (FWD ? 0 : c)) * OP;
       const int lo = (4 * lh) * ORS + 128 * wave + 4 * l31;
       const bool full = f0 + DG_M <= F;  // uniform
       const float bb = (FWD && c_lo == 0) ? bias[0] : 0.f;

@@ -177,7 +177,8 @@ std::vector<Region> workspace_layout(const Model& m, int64_t F, int mode, int64_
     add("d_z_mu", F * m.z);
     add("d_z_lv", F * m.z);
     for (int i = m.n_enc - 1; i >= 0; --i) add("d_enc_a" + std::to_string(i), F * m.enc[i].cout * m.enc[i].hout);
-    add("dy_tmp", F * maxact);
+    // (VCC2016 geometry: room for the 1025-tap layer's input gradient with rows padded to 16 bytes, [F][8][516]; cl_layout.h)
+    add("dy_tmp", F * (m.is_vcc2016 ? std::max<int64_t>(maxact, 8 * tuned::DY2_PITCH) : maxact));
     if (m.is_vcc2016) {  // planes of [dz_mu | dz_lv], d(h) (1539 -> 1600 columns) and d(pre-LN output of encoder layer 4)
       add("pl_dz", F * 256 * 3 / 2);
       add("pl_dh", F * 1600 * 3 / 2);
