@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 5, call 10: result tile in LDS for the S-type register-weight sites (dec0 dgrad, enc2 fwd): parity + A/B against the variant library
+set -u
+OUT=gpurun_out/r5c10; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu --timeout 600 -k "fused_thin or tuned_step or ragged or benchmarked or all_tuned or view_conv" > $OUT/pytest.log 2>&1
+echo "pytest rc=$?" >> $OUT/pytest.log
+tail -3 $OUT/pytest.log
+T="dec0_dgrad,enc2_fwd,enc3_split,merge_dsplit"
+for i in 1 2; do
+  VAENPVC_LIB=variants/otl0/libvaenpvc_hip.so python scripts/site_times.py --tags $T > $OUT/otl_off_$i.txt 2>&1
+  python scripts/site_times.py --tags $T > $OUT/otl_on_$i.txt 2>&1
+done
+python scripts/cmp_sites.py $OUT/otl_off_1.txt $OUT/otl_on_1.txt $OUT/otl_off_2.txt $OUT/otl_on_2.txt
+scripts/ab_libs.sh 2 otl0 default 2>&1 | tee $OUT/ab.txt

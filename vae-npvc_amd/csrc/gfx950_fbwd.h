@@ -47,6 +47,9 @@ constexpr int fb_cgr(int l) { return l == FB_D2 ? 1 : l == FB_D1 ? 2 : 4; }
 #endif
 constexpr int fb_pfw(int l) { return (VAENPVC_FB_PFW >> (4 * l)) & 0xf; }
 
+#ifndef VAENPVC_FB_OTL
+#define VAENPVC_FB_OTL 1   // 0: input gradient stored straight from the accumulators (A/B)
+#endif
 #ifndef VAENPVC_FB_ABL
 #define VAENPVC_FB_ABL 0   // developer ablation (wrong results): 1 no input-gradient GEMM, 2 no weight-gradient GEMM, 4 no result stores, 8 no global loads, 16 no flush of the weight-gradient tile / channel sums
 #endif
@@ -82,7 +85,12 @@ struct FbCfg {
   static constexpr int KSPLIT = NT <= 2 ? 2 : 1, WN = 4 / KSPLIT, NTW = cdiv(NT, WN);
   // LayerNorm-backward items
   static constexpr int CGR = fb_cgr(L), CUG = CG / CGR, NCHG = cdiv(HG, 64), NITG = NCHG * CGR, IPWG = cdiv(NITG, 4);
-  static constexpr int LDS = NPL * (GPL + XPL + WPL) * 2;
+  // OTL (round 5): the frame's input gradient goes through an LDS tile ([CX][HX] fp32, the canonical order) and leaves as 16-byte ALIGNED
+  // pieces of one contiguous run (a frame is a multiple of 16 bytes although its rows of 171 / 57 floats are not): straight from the
+  // accumulators it left as 4- / 12-byte stores at unaligned row starts
+  static constexpr bool OTL = VAENPVC_FB_OTL != 0;
+  static constexpr int OFR = CX * HX, LDS_IMG = NPL * (GPL + XPL + WPL) * 2, LDS = LDS_IMG + (OTL ? OFR * 4 : 0);
+  static_assert(!OTL || (LDS_IMG % 16 == 0 && OFR % 4 == 0), "result tile: aligned, whole pieces");
   static_assert(V.x == (ENC ? WS.a : WS.b) && GD.CP == CG && XD.CP == CX && M == CPN && CUG == 8 && 4 % CGR == 0, "layer not served");
   static_assert(V.OC == CX && V.OH == HX && V.PH == (ENC ? 1 : 0) && (ENC || (V.R == R && MT == 1)), "layer not served");
   static_assert(KS * 16 <= V.Kp && (V.R - 1) * RSTEP + (KS * 16 / CG + 1) * CPLG <= ROWSG * CPLG + 64, "view runs past the frame image");
@@ -322,6 +330,28 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
       }
       if (!nok || ((VAENPVC_FB_ABL & 4) && a.F > 0)) continue;
       float* ob = a.dx + (int64_t)f * (V.OC * V.OH);
+      if constexpr (T::OTL && BFM == 0) {
+        float* ot = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(bsm) + T::LDS_IMG);
+        if constexpr (!T::ENC) {
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int m = acc_row(reg, lane);
+            if (m < V.M) ot[m * V.OH + q] = acc[0][reg];
+          }
+        } else {
+          const int pbase = q * V.oq + V.o0;
+#pragma unroll
+          for (int cs = 0; cs < V.mdiv / 2; ++cs) {
+            const int chb = (cs & 3) + 8 * (cs >> 2), ch = chb + 4 * lh;
+#pragma unroll
+            for (int p3 = 0; p3 < 3; ++p3) {
+              const int mb = p3 * V.mdiv + chb, ti = mb / 32, row = mb % 32, reg = (row & 3) + 4 * (row >> 3);
+              if (pbase + p3 >= 0 && pbase + p3 < V.OH) ot[ch * V.OH + pbase + p3] = acc[ti < T::MT ? ti : 0][reg];
+            }
+          }
+        }
+        continue;
+      }
       if constexpr (!T::ENC) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -381,6 +411,20 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
           for (int j = 0; j < T::MTW; ++j) wacc[i][j] = mfma_bf16(fv[i][PR::B[t]], fp[j][PR::A[t]], wacc[i][j]);
     }
     __syncthreads();   // all fragment reads of this frame are done before the next one overwrites the images
+    if constexpr (T::OTL && BFM == 0) {
+      // the frame's input gradient: one aligned contiguous run (unconditional stores, the rounds past the end repeat the last piece: a static
+      // store count keeps the wait for the next frame's prefetched registers a counted one).  The tile is rewritten two barriers from here.
+      if (!((VAENPVC_FB_ABL & (1 | 4)) && a.F > 0)) {
+        const f32x4* ot4 = reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(bsm) + T::LDS_IMG);
+        f32x4* og = reinterpret_cast<f32x4*>(a.dx + (int64_t)f * T::OFR);
+        constexpr int N4 = T::OFR / 4;
+#pragma unroll
+        for (int r = 0; r < cdiv(N4, 256); ++r) {
+          const int i = min(tid + 256 * r, N4 - 1);
+          og[i] = ot4[i];
+        }
+      }
+    }
   }
   if ((VAENPVC_FB_ABL & 16) && a.F > 0) return;
   // ---- flush: the weight-gradient tile (rows n = (tap, channel of the view operand), lanes m: consecutive addresses of dW[n][m]) ...

@@ -18,8 +18,17 @@ namespace tuned {
 
 constexpr bool fcr_serves_site(int site) { return site == CV_D0F || site == CV_D0G || site == CV_E2F || site == CV_E2G; }
 // frames per group: 4 where the weight tile takes 136 - 144 registers with two planes (one staging item per wave)
+// OTL (round 5): S-type sites park their result frames in an LDS tile ([TF][OC * OH] fp32, the canonical order) and the workgroup copies the
+// group out as ONE contiguous run of 16-byte pieces.  Straight from the accumulators these sites stored 4 bytes per lane in runs of OH = 19
+// floats (76 bytes: every store instruction touched ~5 partial lines); the same re-ordering took the plane GEMMs' result stores from 64 to 16
+// instructions per lane (gfx950_planegemm.h).  Sites: decoder layer 0 input gradient, encoder layer 2 forward (4 frames per group there:
+// frames + tile stay under 80 KB, two workgroups per CU).
+#ifndef VAENPVC_FCR_OTL
+#define VAENPVC_FCR_OTL 1
+#endif
+constexpr bool fcr_otl(int site, int npl) { return VAENPVC_FCR_OTL && npl == 2 && (site == CV_D0G || site == CV_E2F); }
 constexpr int fcr_tf(int site, int npl) {
-  return site == CV_D0F ? (npl == 1 ? 8 : 4) : site == CV_D0G ? (npl == 1 ? 6 : 4) : site == CV_E2G ? 8 : 6;
+  return site == CV_D0F ? (npl == 1 ? 8 : 4) : site == CV_D0G ? (npl == 1 ? 6 : 4) : site == CV_E2G ? 8 : (fcr_otl(site, npl) ? 4 : 6);
 }
 
 template <int NPL, int SITE>
@@ -37,7 +46,10 @@ struct FrCfg {
   static constexpr int XPL = TF * FS + 64;
   static constexpr int K = V.NT * CP, KS = cdiv(K, 16);
   static constexpr int RSTEP = (V.step / CP) * CPL;
-  static constexpr int LDS = NPL * XPL * 2;
+  static constexpr bool OTL = fcr_otl(SITE, NPL) && !PERM;
+  static constexpr int OFR = V.OC * V.OH;                       // floats per result frame
+  static constexpr int LDS_X = NPL * XPL * 2, LDS = LDS_X + (OTL ? TF * OFR * 4 : 0);
+  static_assert(!OTL || (LDS_X % 16 == 0 && (TF * OFR) % 4 == 0), "result tile: 16-byte aligned, whole groups are whole pieces");
   // staging: lane = position (H >= 32) or lane = (position, channel third) (H < 32)
   static constexpr bool POS = H >= 32;
   static constexpr int NCH = POS ? cdiv(H, 64) : 1;
@@ -306,6 +318,13 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
                 if (pbase + 2 >= 0 && pbase + 2 < V.OH) o[2] = p2;
               }
             }
+          } else if constexpr (T::OTL) {
+            float* ot = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(rsm) + T::LDS_X) + fl * T::OFR + pbase;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const int ch = tile * 32 + acc_row(reg, lane);
+              if (ch < V.O && pbase >= 0 && pbase < V.OH) ot[ch * V.OH] = acc[h][reg] + bvr[reg];
+            }
           } else {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
@@ -317,6 +336,15 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
       }
     }
     __syncthreads();
+    if constexpr (T::OTL) {
+      // the group's result frames: one contiguous run of the output tensor (the next group's results are written behind the barrier that
+      // follows its staging, so these reads need no barrier of their own)
+      const float* ot = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(rsm) + T::LDS_X);
+      float* og = a.out + (int64_t)f0 * T::OFR;
+      const int nfl = nf * T::OFR, n4 = nfl >> 2;
+      for (int i = tid; i < n4; i += 256) reinterpret_cast<f32x4*>(og)[i] = reinterpret_cast<const f32x4*>(ot)[i];
+      if (tid < (nfl & 3)) og[4 * n4 + tid] = ot[4 * n4 + tid];     // (ragged last group)
+    }
   }
 }
 
