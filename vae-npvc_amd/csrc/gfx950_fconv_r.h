@@ -24,9 +24,10 @@ constexpr bool fcr_serves_site(int site) { return site == CV_D0F || site == CV_D
 // instructions per lane (gfx950_planegemm.h).  Sites: decoder layer 0 input gradient, encoder layer 2 forward (4 frames per group there:
 // frames + tile stay under 80 KB, two workgroups per CU).
 #ifndef VAENPVC_FCR_OTL
-#define VAENPVC_FCR_OTL 1
+#define VAENPVC_FCR_OTL 1   // bit 0: the S-type sites (dec0 dgrad 167 -> 155 us, enc2 fwd 119 -> 117), bit 1: decoder layer 0 forward as well (phase-stacked; measured
+                            // SLOWER, 276 -> 291 us: its 12-byte stores are not what bounds it, the tile's LDS traffic and the later store issue cost more)
 #endif
-constexpr bool fcr_otl(int site, int npl) { return VAENPVC_FCR_OTL && npl == 2 && (site == CV_D0G || site == CV_E2F); }
+constexpr bool fcr_otl(int site, int npl) { return VAENPVC_FCR_OTL && npl == 2 && (site == CV_D0G || site == CV_E2F || (site == CV_D0F && (VAENPVC_FCR_OTL & 2))); }
 constexpr int fcr_tf(int site, int npl) {
   return site == CV_D0F ? (npl == 1 ? 8 : 4) : site == CV_D0G ? (npl == 1 ? 6 : 4) : site == CV_E2G ? 8 : (fcr_otl(site, npl) ? 4 : 6);
 }
@@ -46,7 +47,7 @@ struct FrCfg {
   static constexpr int XPL = TF * FS + 64;
   static constexpr int K = V.NT * CP, KS = cdiv(K, 16);
   static constexpr int RSTEP = (V.step / CP) * CPL;
-  static constexpr bool OTL = fcr_otl(SITE, NPL) && !PERM;
+  static constexpr bool OTL = fcr_otl(SITE, NPL);
   static constexpr int OFR = V.OC * V.OH;                       // floats per result frame
   static constexpr int LDS_X = NPL * XPL * 2, LDS = LDS_X + (OTL ? TF * OFR * 4 : 0);
   static_assert(!OTL || (LDS_X % 16 == 0 && (TF * OFR) % 4 == 0), "result tile: 16-byte aligned, whole groups are whole pieces");
@@ -300,7 +301,18 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
           const int fl = nn[h] / V.R, q = nn[h] - fl * V.R;
           float* ob = a.out + (int64_t)(f0 + fl) * (V.OC * V.OH);
           const int pbase = q * V.oq + V.o0;
-          if constexpr (T::PERM) {
+          if constexpr (T::PERM && T::OTL) {
+            float* ot = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(rsm) + T::LDS_X) + fl * T::OFR + pbase;
+#pragma unroll
+            for (int cs = 0; cs < 4; ++cs) {
+              const int ch = tile * 8 + cs + 4 * lh;
+              const float bb = bvr[cs];
+              float* o = ot + ch * V.OH;
+              if (pbase >= 0 && pbase < V.OH) o[0] = acc[h][cs] + bb;
+              if (pbase + 1 >= 0 && pbase + 1 < V.OH) o[1] = acc[h][cs + 4] + bb;
+              if (pbase + 2 >= 0 && pbase + 2 < V.OH) o[2] = acc[h][cs + 8] + bb;
+            }
+          } else if constexpr (T::PERM) {
             // tile row = phase * 8 + channel % 8: registers cs, cs + 4, cs + 8 of this lane are the three phases
             struct __attribute__((packed, aligned(4))) f3 { float x, y, z; };
             const bool inner = pbase >= 0 && pbase + 2 < V.OH;
