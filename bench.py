@@ -679,7 +679,7 @@ def main(argv=None):
         # BASELINE.json configs[3]: the conversion path convert.py:79-89 (encode -> z_mu, decode towards speaker 9 = TM3),
         # forward only, frames resident in HBM; every rank converts its own frames
         conv = {}
-        for Fc, nit in ((1024, 50), (32768, 10)):
+        for Fc, nit in ((300, 50), (1024, 50), (32768, 10)):
             xc, _ = make_batch(Fc, 4321 + rank)
             yc = torch.full((Fc,), 9, dtype=torch.int64, device=dev)
             for _ in range(3):
@@ -695,8 +695,25 @@ def main(argv=None):
                                 'fraction_of_fp32_flops': fps / world * FLOP_PER_FRAME_CONVERT / FP32_PEAK,
                                 'fraction_of_mfma_%s' % PREC_NAME[planes]: fps / world * FLOP_PER_FRAME_CONVERT / (BF16_PEAK / PRODUCTS[planes]),
                                 'fraction_of_hbm_model_B': fps / world * BYTES_PER_FRAME_CONVERT / HBM_PEAK}
+        # the utterance sizes convert.py actually runs (a few hundred to ~2 000 frames per file, convert.py:105-116) are latency-bound as
+        # single launches; convert.py gathers consecutive files into one launch (--batch_frames, default 16 384: convert.convert_utterances).
+        # Measured here: 16 synthetic utterances of 1 024 (resp. 54 of 300) frames converted in ONE encode -> decode call, per utterance
+        for Fu, nu, nit in ((1024, 16, 20), (300, 54, 20)):
+            xc, _ = make_batch(Fu * nu, 4321 + rank)
+            yc = torch.full((Fu * nu,), 9, dtype=torch.int64, device=dev)
+            for _ in range(3):
+                eng.decode(eng.encode(xc), yc)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(nit):
+                torch.split(eng.decode(eng.encode(xc), yc), Fu)      # (the cut back to utterances: views, no copy)
+            barrier()
+            dtc = max_over_ranks(time.perf_counter() - t0) / nit
+            conv['F%d_batched_x%d' % (Fu, nu)] = {'frames_per_utterance': Fu, 'utterances_per_launch': nu, 'ms_per_launch': dtc * 1e3,
+                                                  'ms_per_utterance': dtc * 1e3 / nu, 'frames_per_s': world * Fu * nu / dtc}
         conv['note'] = ('encode (z_mu) + decode, 9.419 MFLOP and 150 384 layer-materialised bytes per frame (SURVEY 8d); '
-                        'the CPU leg of the same path is cpu_baseline.legs.convert_fwd_F1024')
+                        'the CPU leg of the same path is cpu_baseline.legs.convert_fwd_F1024; F300 / F1024 = ONE utterance per launch (the '
+                        'reference\'s sess.run per file), F*_batched_x* = what convert.py does by default')
         out['config']['convert_config4'] = conv
     if not args.no_literal:
         # BASELINE.json configs[4]: the VAWGAN branch (nIterD critic steps + one generator step per iteration, 16 frames per

@@ -84,6 +84,15 @@ struct FcArgs {
   // k_fconv_r, decoder layer 0 input gradient: non-null = the operand is read as its channel-last planes ([NPL][cl_plane], written by
   // the LayerNorm backward in front, gfx950_lnb_planes.h) instead of as the fp32 tensor `src`: a straight copy into the LDS image
   const unsigned short* cl_in = nullptr;
+  // k_fconv_r, encoder layer 2 forward (round 5): non-null = the LayerNorm statistics of the RESULT are taken from the result tile in LDS
+  // (one wave per frame) and stored here, and the activated result lrelu(LN(out)) ALSO leaves as the channel-last planes the next layer's
+  // view GEMM reads ([NPL][cl2_plane], frames of [HP][CP] with zero halo rows, cl_layout.h: CL_Y2): the separate statistics + planes pass
+  // over the tensor (k_cl_produce<LN = 2>, 73 us) goes away
+  float* st2_out = nullptr;
+  const float* gamma2 = nullptr;
+  const float* beta2 = nullptr;
+  unsigned short* cl2_out = nullptr;
+  int64_t cl2_plane = 0;
 };
 
 template <int CP, int CPL>

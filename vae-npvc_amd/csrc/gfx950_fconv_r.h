@@ -93,13 +93,16 @@ static PackViewPermJob<NPL> fcr_perm_job(int site, const float* W, int s_t, int 
                               reinterpret_cast<unsigned short*>(dst), mp, v.Kp, mp * v.Kp / 8};
 }
 
-template <int NPL, int SITE, int LN, bool CLO = false, bool PIN = false>
+// OSP (encoder layer 2 forward with the result tile in LDS): statistics of the result + its activated channel-last planes (FcArgs::st2_out ...)
+template <int NPL, int SITE, int LN, bool CLO = false, bool PIN = false, bool OSP = false>
 __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
   using T = FrCfg<NPL, SITE>;
   constexpr CvSite V = T::V;
+  static_assert(!OSP || (T::OTL && !T::PERM && T::TF == 4 && V.O <= 64), "result statistics: one wave per frame of the LDS tile");
   extern __shared__ __attribute__((aligned(16))) unsigned short rsm[];
   unsigned short* xs = rsm;   // [NPL][XPL]
   __shared__ float lnp[2][FrCfg<NPL, SITE>::C];   // LayerNorm parameters of the input (a fetch per group through the pointers otherwise)
+  __shared__ float lno[2][OSP ? 64 : 1];          // ... of the result (OSP)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int ngroups = cdiv(a.F, T::TF);
   // ---- staging registers (one group ahead, as k_fconv)
@@ -215,6 +218,19 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
   if (LN != 0 && tid < T::C) {
     lnp[0][tid] = a.gamma[tid];
     lnp[1][tid] = a.beta[tid];
+  }
+  if constexpr (OSP) {
+    if (tid < V.O) {
+      lno[0][tid] = a.gamma2[tid];
+      lno[1][tid] = a.beta2[tid];
+    }
+    if (blockIdx.x == 0) {   // zero tails behind the planes (as k_cl_produce)
+      constexpr ClDesc D2 = CLD[CL_Y2];
+      const int64_t used = (int64_t)a.F * D2.HP * D2.CP;
+      for (int64_t i = used + tid; i < a.cl2_plane; i += 256)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) a.cl2_out[p * a.cl2_plane + i] = 0;
+    }
   }
   {
     const u32x4 z = {0u, 0u, 0u, 0u};
@@ -356,6 +372,48 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
       const int nfl = nf * T::OFR, n4 = nfl >> 2;
       for (int i = tid; i < n4; i += 256) reinterpret_cast<f32x4*>(og)[i] = reinterpret_cast<const f32x4*>(ot)[i];
       if (tid < (nfl & 3)) og[4 * n4 + tid] = ot[4 * n4 + tid];     // (ragged last group)
+      if constexpr (OSP) {
+        // LayerNorm statistics of the result frames (two-pass, as k_ln_stats_fast) and their activated channel-last planes: wave = frame
+        constexpr ClDesc D2 = CLD[CL_Y2];
+        static_assert(!OSP || (D2.C == V.OC && D2.H == V.OH && D2.CP == 64), "planes of this site's result");
+        constexpr int NE = T::OFR, EPL = cdiv(NE, 64), G8 = D2.CP / 8, ITEMS = D2.HP * G8;
+        if (wave < nf) {
+          const float* t = ot + wave * NE;
+          const int f = f0 + wave;
+          float sm = 0.f;
+#pragma unroll
+          for (int i = 0; i < EPL; ++i) sm += (lane + 64 * i < NE) ? t[lane + 64 * i] : 0.f;
+          const float mean = wave_sum(sm) * (1.0f / NE);
+          float q = 0.f;
+#pragma unroll
+          for (int i = 0; i < EPL; ++i) {
+            const float d = (lane + 64 * i < NE) ? t[lane + 64 * i] - mean : 0.f;
+            q += d * d;
+          }
+          const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / NE) + LN_EPS);
+          if (lane == 0) {
+            a.st2_out[2 * f] = mean;
+            a.st2_out[2 * f + 1] = rstd;
+          }
+          unsigned short* df = a.cl2_out + (int64_t)f * (D2.HP * D2.CP);
+#pragma unroll
+          for (int r = 0; r < cdiv(ITEMS, 64); ++r) {
+            const int it = lane + 64 * r;
+            if (it >= ITEMS) continue;
+            const int hp = it / G8, cg = it - hp * G8, h = hp - D2.HLO;
+            float v8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int c = cg * 8 + j;
+              v8[j] = (h >= 0 && h < D2.H && c < D2.C) ? lnact_v(t[c * D2.H + (h >= 0 && h < D2.H ? h : 0)], mean, rstd, lno[0][c], lno[1][c]) : 0.f;
+            }
+            u32x4 pk[NPL];
+            pack8<NPL>(v8, pk);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) st_nt<VAENPVC_NT_B>(reinterpret_cast<u32x4*>(df + p * a.cl2_plane + (int64_t)it * 8), pk[p]);
+          }
+        }
+      }
     }
   }
 }
@@ -375,6 +433,13 @@ static void launch_fconv_r(const FcArgs& a, hipStream_t s) {
     if (a.cl_in) {   // (operand planes in: straight copy into the LDS image)
       rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv_r<NPL, SITE, 0, false, true>), T::LDS);
       hipLaunchKernelGGL((k_fconv_r<NPL, SITE, 0, false, true>), dim3(grid), dim3(256), T::LDS, s, a);
+      return;
+    }
+  }
+  if constexpr (SITE == CV_E2F && T::OTL) {
+    if (a.st_out && a.cl2_out) {   // (statistics of the input in the staging; statistics + activated planes of the result from the LDS tile)
+      rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv_r<NPL, SITE, 2, false, false, true>), T::LDS);
+      hipLaunchKernelGGL((k_fconv_r<NPL, SITE, 2, false, false, true>), dim3(grid), dim3(256), T::LDS, s, a);
       return;
     }
   }

@@ -590,11 +590,28 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
     else if (!(have_y1 = enc_stats(1, CV_E2F, CL_Y1, "enc2_split"))) VAENPVC_TIMED("stats_enc1", s, stats<1824>(w.enc_a[1], w.enc_st[1], F, s));
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 1);
   if (fwd_on(2)) {
+    // (round 5) layer 2's fused kernel also leaves the statistics of its RESULT and the activated channel-last planes layer 3's view GEMM reads
+    const bool e2_makes_y2 = rt().e2_osp && e2_takes_stats && dense_planes_now() == 2 && fcr_otl(CV_E2F, 2) && fwd_on(3) && cv_fwd(CV_E3F, F) &&
+                             !fc_fwd(CV_E3F, F) && !fcr_fwd(CV_E3F, F);
+    if (fcr_fwd(CV_E2F, F) && e2_makes_y2) {
+      for_dense_planes([&](auto npl) {
+        FcArgs fa{w.enc_a[1], nullptr, w.enc_st[1], P + m.enc[1].gamma_off, P + m.enc[1].beta_off,
+                  reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvw + cv_woff(CV_E2F)), P + m.enc[2].b_off, w.enc_a[2], F};
+        fa.st2_out = w.enc_st[2];
+        fa.gamma2 = P + m.enc[2].gamma_off;
+        fa.beta2 = P + m.enc[2].beta_off;
+        fa.cl2_out = us(w.cl[CL_Y2]);
+        fa.cl2_plane = cl_plane(CL_Y2, F);
+        VAENPVC_TIMED("enc2_fwd", s, fconv_r<decltype(npl)::value>(CV_E2F, fa, s));
+      });
+      have_y2 = true;
+    } else {
     if (fcr_fwd(CV_E2F, F)) fused_r(CV_E2F, w.scratch + Pk::cvw + cv_woff(CV_E2F), w.enc_a[1], e2_takes_stats ? nullptr : w.enc_st[1], &m.enc[1], P + m.enc[2].b_off, w.enc_a[2], "enc2_fwd",
                                     e2_takes_stats ? w.enc_st[1] : nullptr);
     else if (cv_fwd(CV_E2F, F)) enc_view(CV_E2F, CL_Y1, 2, have_y1, "enc2_split", "enc2_fwd");
     else VAENPVC_TIMED("enc2_fwd", s, launch_convgemm<E2F>(lnp(2), nsplit_for<E2F>(F), s));
     if (!(have_y2 = enc_stats(2, CV_E3F, CL_Y2, "enc3_split"))) VAENPVC_TIMED("stats_enc2", s, stats<1216>(w.enc_a[2], w.enc_st[2], F, s));
+    }
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 2);
   if (fwd_on(3) && cv_fwd(CV_E3F, F)) {
     // the frame-owning tile (k_cgemm_sf, round 5): conv + statistics + activated planes of a3 in one kernel
