@@ -986,7 +986,11 @@ constexpr int TP_KF = 16;
 template <int NPL, int TI, int TJ>
 struct TnTile {
   static constexpr int BM = 64 * TI, BN = 128 * TJ;
-  static constexpr int RSA = BM * 2 + 64, RSB = BN * 2 + 64;
+  // LDS row pitch: the transposing fragment reads take 8 bytes of four consecutive ROWS per lane group, so consecutive rows must fall on
+  // different banks: pitch / 4 = 16 or 48 (mod 64).  + 64 bytes does that for the power-of-two tiles; 96 and 288 columns need no pad
+  static constexpr int tn32_pitch(int w) { return ((w * 2 + 64) / 4) % 32 == 16 ? w * 2 + 64 : w * 2; }
+  static constexpr int RSA = tn32_pitch(BM), RSB = tn32_pitch(BN);
+  static_assert((RSA / 4) % 32 == 16 && (RSB / 4) % 32 == 16 && RSA % 16 == 0 && RSB % 16 == 0, "conflict-free row pitches");
   static constexpr int APL = TP_KF * RSA, BPL = TP_KF * RSB;
   static constexpr int BUF = NPL * (APL + BPL), LDS = 2 * BUF;
   static constexpr int APC = BM / 8, BPC = BN / 8;   // 16-byte pieces per row
@@ -1158,7 +1162,7 @@ __global__ void __launch_bounds__(512, NPL <= 2 ? 4 : 2) k_gemm_tn(TnpArgs a) {
     }
 }
 
-template <int NPL, int EPI, int TI, int TJ>
+template <int NPL, int EPI, int TI, int TJ, int WR, int WC>
 inline void launch_gemm_tn32(TnpArgs a, int target_wgs, hipStream_t s);
 template <int NPL, int EPI, int TI = 2, int TJ = 2>
 inline void launch_gemm_tn(TnpArgs a, int target_wgs, hipStream_t s) {
@@ -1171,7 +1175,7 @@ inline void launch_gemm_tn(TnpArgs a, int target_wgs, hipStream_t s) {
     // measured (32 768 frames): one plane -27 % over six sites; two planes -17..24 % on the sites with few tiles per row
     // chunk (merge, heads, encoder layer 3), equal on decoder layer 0, +10 % on encoder layer 4 (21 tiles: stays here)
     const bool many_tiles = cdiv(a.M, 64 * TI) * cdiv(a.N, 128 * TJ) > 8;
-    if (!rt().tn_k16 && (NPL == 1 || !many_tiles)) return launch_gemm_tn32<NPL, EPI, TI, TJ>(a, target_wgs, s);
+    if (!rt().tn_k16 && (NPL == 1 || !many_tiles)) return launch_gemm_tn32<NPL, EPI, TI, TJ, 2, 4>(a, target_wgs, s);
   }
   using T = TnTile<NPL, TI, TJ>;
   rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_tn<NPL, EPI, TI, TJ>), T::LDS);
@@ -1189,10 +1193,17 @@ inline void launch_gemm_tn(TnpArgs a, int target_wgs, hipStream_t s) {
 // two fragment sets with the transposed reads issued between the MFMAs, the staging registers refilled right after
 // they were written to LDS, one 8-wave workgroup per CU and HALF as many workgroups (half the atomics).
 constexpr int TP32_KF = 32;
-template <int NPL, int TI, int TJ>
+// (round 5) the wave grid is a template parameter: WR x WC waves of TI x TJ MFMA tiles each -- 2 x 4 waves (512 threads) as before, or the
+// 3 x 3 grid of 1 x 3 tiles (576 threads) whose 96 x 288 tile fits decoder layer 0's weight gradient (M = 81, N = 9 taps x 32 = 288):
+// on the 128 x 256 tile that site ran 2 column tiles of which 36 % of the MFMA work was useful (the kernel is MFMA-bound there).
+template <int NPL, int TI, int TJ, int WR = 2, int WC = 4>
 struct Tn32Tile {
-  static constexpr int BM = 64 * TI, BN = 128 * TJ;
-  static constexpr int RSA = BM * 2 + 64, RSB = BN * 2 + 64;
+  static constexpr int BM = 32 * TI * WR, BN = 32 * TJ * WC, NTHR = 64 * WR * WC;
+  // LDS row pitch: the transposing fragment reads take 8 bytes of four consecutive ROWS per lane group, so consecutive rows must fall on
+  // different banks: pitch / 4 = 16 or 48 (mod 64).  + 64 bytes does that for the power-of-two tiles; 96 and 288 columns need no pad
+  static constexpr int tn32_pitch(int w) { return ((w * 2 + 64) / 4) % 32 == 16 ? w * 2 + 64 : w * 2; }
+  static constexpr int RSA = tn32_pitch(BM), RSB = tn32_pitch(BN);
+  static_assert((RSA / 4) % 32 == 16 && (RSB / 4) % 32 == 16 && RSA % 16 == 0 && RSB % 16 == 0, "conflict-free row pitches");
   static constexpr int APL = TP32_KF * RSA, BPL = TP32_KF * RSB;
   static constexpr int BUF = NPL * (APL + BPL), LDS = 2 * BUF;
   static constexpr int APC = BM / 8, BPC = BN / 8;   // 16-byte pieces per row
@@ -1203,14 +1214,15 @@ struct Tn32Tile {
     __builtin_amdgcn_sched_group_barrier((MASK), (CNT), 0);   \
   }
 
-template <int NPL, int EPI, int TI = 2, int TJ = 2>
-__global__ void __launch_bounds__(512, 2) k_gemm_tn32(TnpArgs a) {
+template <int NPL, int EPI, int TI = 2, int TJ = 2, int WR = 2, int WC = 4>
+__global__ void __launch_bounds__((Tn32Tile<NPL, TI, TJ, WR, WC>::NTHR), (WR * WC <= 8 ? 2 : 1)) k_gemm_tn32(TnpArgs a) {
   static_assert(NPL <= 2, "three planes do not fit two 32-row buffers");
-  using T = Tn32Tile<NPL, TI, TJ>;
+  using T = Tn32Tile<NPL, TI, TJ, WR, WC>;
+  static_assert(TP32_KF * T::APC <= T::NTHR && 16 * T::BPC <= T::NTHR, "one staging piece of A, two of B per thread");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BUF = T::BUF;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lh = lane >> 5, l31 = lane & 31;
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = wave / WC, wc = wave % WC;
   const int ntm = cdiv(a.M, T::BM), ntt = ntm * cdiv(a.N, T::BN);
   const int wg = a.xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
   const int zc = wg / ntt, tl = wg - zc * ntt;
@@ -1390,15 +1402,15 @@ __global__ void __launch_bounds__(512, 2) k_gemm_tn32(TnpArgs a) {
     }
 }
 
-template <int NPL, int EPI, int TI, int TJ>
+template <int NPL, int EPI, int TI, int TJ, int WR = 2, int WC = 4>
 inline void launch_gemm_tn32(TnpArgs a, int target_wgs, hipStream_t s) {
-  using T = Tn32Tile<NPL, TI, TJ>;
-  rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_tn32<NPL, EPI, TI, TJ>), T::LDS);
+  using T = Tn32Tile<NPL, TI, TJ, WR, WC>;
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_tn32<NPL, EPI, TI, TJ, WR, WC>), T::LDS);
   const int tiles = cdiv(a.M, T::BM) * cdiv(a.N, T::BN);
   const int zc = cmax(1, cmin_(cdiv(a.F, 128), cdiv(cmax(target_wgs / 2, 1), tiles)));   // one workgroup per CU
   a.fchunk = rup(cdiv(a.F, zc), TP32_KF);
   dim3 grid((unsigned)(tiles * cdiv(a.F, a.fchunk)));
-  hipLaunchKernelGGL((k_gemm_tn32<NPL, EPI, TI, TJ>), grid, dim3(512), T::LDS, s, a);
+  hipLaunchKernelGGL((k_gemm_tn32<NPL, EPI, TI, TJ, WR, WC>), grid, dim3(T::NTHR), T::LDS, s, a);
 }
 
 // ---------------------------------------------------------------- C += A^T B on four waves (plain row views, up to two planes)

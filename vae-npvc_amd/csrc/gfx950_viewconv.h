@@ -353,6 +353,10 @@ static void cv_wgrad(int site, const float* aplanes, const float* bplanes, float
   t.C = dW;
   t.ldc = v.M;
   t.xcd = rt().tn_xcd >= 0 ? rt().tn_xcd : (v.M > 64 ? 1 : 0);   // measured: pays with >= 2 tiles of 128 x 256 per row chunk
+  if constexpr (NPL <= 2) {
+    // decoder layer 0 (M = 81, N = 288): the 96 x 288 tile of the 3 x 3 wave grid instead of two 128 x 256 tiles (VAENPVC_TN_D0FIT=0: A/B)
+    if (site == CW_D0 && rt().tn_d0fit && !rt().tn_k16) return launch_gemm_tn32<NPL, TN_EPI_TRANS, 1, 3, 3, 3>(t, target_wgs, s);
+  }
   if (v.M > 64) launch_gemm_tn<NPL, TN_EPI_TRANS, 2, 2>(t, target_wgs, s);
   else if (t.N > 128) launch_gemm_tn<NPL, TN_EPI_TRANS, 1, 2>(t, target_wgs, s);
   else launch_gemm_tn<NPL, TN_EPI_TRANS, 1, 1>(t, target_wgs, s);
