@@ -27,9 +27,9 @@ constexpr bool fcr_serves_site(int site) { return site == CV_D0F || site == CV_D
 #define VAENPVC_FCR_OTL 1   // bit 0: the S-type sites (dec0 dgrad 167 -> 155 us, enc2 fwd 119 -> 117), bit 1: decoder layer 0 forward as well (phase-stacked; measured
                             // SLOWER, 276 -> 291 us: its 12-byte stores are not what bounds it, the tile's LDS traffic and the later store issue cost more)
 #endif
-constexpr bool fcr_otl(int site, int npl) { return VAENPVC_FCR_OTL && npl == 2 && (site == CV_D0G || site == CV_E2F || (site == CV_D0F && (VAENPVC_FCR_OTL & 2))); }
+constexpr bool fcr_otl(int site, int npl) { return VAENPVC_FCR_OTL && npl <= 2 && (site == CV_D0G || site == CV_E2F || (site == CV_D0F && (VAENPVC_FCR_OTL & 2))); }
 constexpr int fcr_tf(int site, int npl) {
-  return site == CV_D0F ? (npl == 1 ? 8 : 4) : site == CV_D0G ? (npl == 1 ? 6 : 4) : site == CV_E2G ? 8 : (fcr_otl(site, npl) ? 4 : 6);
+  return site == CV_D0F ? (npl == 1 ? 8 : 4) : site == CV_D0G ? (npl == 1 && !fcr_otl(site, npl) ? 6 : 4) : site == CV_E2G ? 8 : (fcr_otl(site, npl) ? 4 : 6);
 }
 
 template <int NPL, int SITE>

@@ -591,7 +591,7 @@ void encoder_fwd(const Model& m, const float* P, const float* x, int64_t F64, co
   } else generic::enc_layer_fwd(m, P, x, F, w, s, 1);
   if (fwd_on(2)) {
     // (round 5) layer 2's fused kernel also leaves the statistics of its RESULT and the activated channel-last planes layer 3's view GEMM reads
-    const bool e2_makes_y2 = rt().e2_osp && e2_takes_stats && dense_planes_now() == 2 && fcr_otl(CV_E2F, 2) && fwd_on(3) && cv_fwd(CV_E3F, F) &&
+    const bool e2_makes_y2 = rt().e2_osp && e2_takes_stats && dense_planes_now() <= 2 && fcr_otl(CV_E2F, 2) && fwd_on(3) && cv_fwd(CV_E3F, F) &&
                              !fc_fwd(CV_E3F, F) && !fcr_fwd(CV_E3F, F);
     if (fcr_fwd(CV_E2F, F) && e2_makes_y2) {
       for_dense_planes([&](auto npl) {

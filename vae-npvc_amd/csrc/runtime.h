@@ -32,7 +32,8 @@ struct Runtime {
   static constexpr unsigned FCR_SITES = 0x28au, FCR_SITES_BF16 = 0x08au;   // CV_E2F (1), CV_D0F (3), CV_E2G (7), CV_D0G (9; view GEMM with one plane)
   long fw_sites_env = -1;       // VAENPVC_FW_SITES: thin weight gradients on the fused kernel (gfx950_fwgrad.h; bit = CW_* site)
   unsigned fw_sites() const { return fw_sites_env >= 0 ? (unsigned)fw_sites_env : planes == 1 ? FW_SITES_BF16 : FW_SITES; }
-  static constexpr unsigned FW_SITES = 0x3fu, FW_SITES_BF16 = 0x3du;   // (bf16 mode: encoder layer 2 keeps the view GEMM, its planes exist anyway)
+  static constexpr unsigned FW_SITES = 0x3fu, FW_SITES_BF16 = 0x3fu;   // (round 5: encoder layer 2 as well -- its view GEMM needed two split passes since the forward kernels no
+                                                                        //  longer leave its planes: 4.32 -> 4.26 ms per step in the bf16 mode, same box)
   unsigned fc_sites() const { return fc_sites_env >= 0 ? (unsigned)fc_sites_env : planes == 1 ? FC_SITES_BF16 : FC_SITES; }
   static constexpr unsigned FC_SITES = 0xdb1u, FC_SITES_BF16 = 0xdb1u;   // by measurement
   unsigned cv_sites() const { return cv_sites_env >= 0 ? (unsigned)cv_sites_env : planes == 1 ? CV_SITES_BF16 : planes == 2 ? CV_SITES_X2 : CV_SITES_X3; }
