@@ -89,7 +89,16 @@ struct FbCfg {
   // pieces of one contiguous run (a frame is a multiple of 16 bytes although its rows of 171 / 57 floats are not): straight from the
   // accumulators it left as 4- / 12-byte stores at unaligned row starts
   static constexpr bool OTL = VAENPVC_FB_OTL != 0;
+  // LNB2 (round 5, decoder layer 1): the LayerNorm + lrelu backward of the layer BELOW (decoder layer 0) runs on the input gradient while it
+  // sits in the LDS tile -- its normalised pre-LN values were in this kernel's registers anyway (they are the activation the weight gradient
+  // multiplies) and are parked in a second fp32 tile; the result leaves as the channel-last operand planes of that layer's gradient GEMMs
+  // (CL_GD0), its per-channel sums as one row of `part0` per workgroup.  The gradient at decoder layer 0's activated output never reaches
+  // HBM and the separate pass (k_ln_bwd_planes<32, 57>: 131 us, 0.5 GB read + 0.26 GB written) is gone.
+  static constexpr bool LNB2_OK = OTL && L == FB_D1 && NPL <= 2;
+  static constexpr ClDesc PD0 = CLD[CL_GD0];
+  static constexpr int P0_CPL = PD0.CP + 8, P0_IMG = PD0.HP * P0_CPL;   // LDS pitch / elements of one plane image
   static constexpr int OFR = CX * HX, LDS_IMG = NPL * (GPL + XPL + WPL) * 2, LDS = LDS_IMG + (OTL ? OFR * 4 : 0);
+  static constexpr int LDS_LNB2 = LDS + OFR * 4 + 2 * NPL * P0_IMG * 2;   // + the normalised values + two parities of plane images
   static_assert(!OTL || (LDS_IMG % 16 == 0 && OFR % 4 == 0), "result tile: aligned, whole pieces");
   static_assert(V.x == (ENC ? WS.a : WS.b) && GD.CP == CG && XD.CP == CX && M == CPN && CUG == 8 && 4 % CGR == 0, "layer not served");
   static_assert(V.OC == CX && V.OH == HX && V.PH == (ENC ? 1 : 0) && (ENC || (V.R == R && MT == 1)), "layer not served");
@@ -115,14 +124,19 @@ struct FbArgs {
   int F;
   bool bf16_act = false;   // bf16 activation storage of the decoder tensors (launch_fbwd picks the layer's pattern)
   int dy_pitch = 0;        // decoder layer 2: floats per row of dy when its producer padded the rows to 16 bytes (516; 0 = the tensor's own rows)
+  // LNB2 (decoder layer 1): non-null = LayerNorm backward of the layer below in the epilogue; dx is then NOT written
+  unsigned short* pl0 = nullptr;   // channel-last planes of d(pre-LN output of the layer below) [NPL][pl0_plane] (cl_layout.h: CL_GD0)
+  int64_t pl0_plane = 0;
+  float* part0 = nullptr;          // [gridDim.x][3][CX]: sum dn xhat | sum dn | sum du per channel of the layer below
 };
 
 // BFM: bf16 activation storage (precision "bf16"): bit 0 = dy and a, bit 1 = the input activation xa, bit 2 = the result dx
 // DYP: floats per row of dy when they differ from the tensor's (the 1025-tap layer's input gradient writes rows of 516 floats so that
 // its 16-byte stores are aligned, gfx950_toep_bf16.h); 0 = rows of the tensor
-template <int NPL, int L, int BFM = 0, int DYP = 0>
+template <int NPL, int L, int BFM = 0, int DYP = 0, bool LNB2 = false>
 __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
   using T = FbCfg<NPL, L>;
+  static_assert(!LNB2 || (T::LNB2_OK && BFM == 0), "LayerNorm backward of the layer below: decoder layer 1, fp32 storage");
   constexpr bool BFG = BFM & 1, BFX = (BFM >> 1) & 1, BFO = (BFM >> 2) & 1;
   constexpr int PG = act_pitch(BFG, T::HG), PO = act_pitch(BFO, T::V.OH), PD = DYP ? DYP : PG;
   static_assert(DYP == 0 || (BFM == 0 && DYP >= T::HG), "padded rows: fp32 storage");
@@ -133,6 +147,10 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
   __shared__ float part[2][FbCfg<NPL, L>::NITG];
   __shared__ float red[4][3 * FbCfg<NPL, L>::CUG];
   __shared__ float lnx[2][FbCfg<NPL, L>::CX];   // LayerNorm parameters of the input activation (copied once)
+  __shared__ float red0[2][4][2];                 // LNB2: the frame's two sums, per parity and wave
+  __shared__ float lnq0[2][LNB2 ? FbCfg<NPL, L>::CX : 1];
+  float* xh0 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(bsm) + T::LDS);              // LNB2: [CX][HX] normalised values of the layer below
+  unsigned short* img0 = reinterpret_cast<unsigned short*>(xh0 + T::OFR);                               // LNB2: [2][NPL][P0_IMG]
   unsigned short* gs = bsm;                       // [NPL][GPL]  du, channel-last, zero halo rows
   unsigned short* xs = bsm + NPL * T::GPL;        // [NPL][XPL]  activated input
   unsigned short* ws = xs + NPL * T::XPL;         // [NPL][MT * 32][WP]
@@ -260,6 +278,37 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
           *reinterpret_cast<const u32x4*>(a.W + ((size_t)p * V.Mp + m) * V.Kp + c8 * 8);
     }
   }
+  // LNB2: a thread owns ONE channel of the layer below (8 threads per channel, positions t8, t8 + 8, ...): its LayerNorm parameters and its
+  // three per-channel sums are scalars per thread
+  const int c0 = tid >> 3, t8 = tid & 7;
+  float g0 = 0.f, b0 = 0.f, su0 = 0.f, sw0 = 0.f, sd0 = 0.f;
+  if constexpr (LNB2) {
+    g0 = a.xgamma[c0];
+    b0 = a.xbeta[c0];
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int i = tid; i < 2 * NPL * T::P0_IMG / 8; i += 256) reinterpret_cast<u32x4*>(img0)[i] = z;   // (halo rows stay zero)
+    if (blockIdx.x == 0) {   // zero tails behind the planes (as k_cl_produce)
+      const int64_t used = (int64_t)a.F * T::PD0.HP * T::PD0.CP;
+      for (int64_t i = used + tid; i < a.pl0_plane; i += 256)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) a.pl0[p * a.pl0_plane + i] = 0;
+    }
+  }
+  // the plane image of frame fp (parity par) -> its [HP][CP] frame of every plane, consecutive threads = consecutive 16-byte pieces
+  auto copy_out0 = [&](int fp, int par) __attribute__((always_inline)) {
+    constexpr int G8 = T::PD0.CP / 8, PPP = T::PD0.HP * G8;
+    const unsigned short* im = img0 + par * NPL * T::P0_IMG;
+    unsigned short* df = a.pl0 + (int64_t)fp * T::PD0.HP * T::PD0.CP;
+#pragma unroll
+    for (int r = 0; r < cdiv(NPL * PPP, 256); ++r) {
+      const int it = min(tid + 256 * r, NPL * PPP - 1);      // (rounds past the end repeat the last piece: unconditional stores)
+      const int p = it / PPP, q = it - p * PPP, hp = q / G8, g8 = q - hp * G8;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(im + p * T::P0_IMG + hp * T::P0_CPL + 8 * g8);
+      *reinterpret_cast<u32x4*>(df + p * a.pl0_plane + (int64_t)q * 8) = v;
+    }
+  };
+  int nfr = 0;      // frames this workgroup has processed (parity of the plane images)
+  int fprev = -1;
   __syncthreads();
   // weight-gradient tiles of this wave (gfx950_fwgrad.h): n tiles wn, wn + WN, ...; k-chunks of parity kpar
   const int wn = wave % T::WN, kpar = wave / T::WN;
@@ -291,7 +340,7 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
       sx.load(a.xa, a.xst, f, a.F, xwave, lane);
     }
     upass1();
-    sx.store(xs, true, lnx[0], lnx[1], xwave, lane);
+    sx.store(xs, true, lnx[0], lnx[1], xwave, lane, LNB2 ? xh0 : nullptr);
     __syncthreads();   // the partial sums of every item are visible
     upass2();
     __syncthreads();   // both images are complete
@@ -411,7 +460,54 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
           for (int j = 0; j < T::MTW; ++j) wacc[i][j] = mfma_bf16(fv[i][PR::B[t]], fp[j][PR::A[t]], wacc[i][j]);
     }
     __syncthreads();   // all fragment reads of this frame are done before the next one overwrites the images
-    if constexpr (T::OTL && BFM == 0) {
+    if constexpr (LNB2) {
+      // ---- LayerNorm + lrelu backward of the layer below on the tile (arithmetic of k_ln_bwd_planes, gfx950_lnb_planes.h)
+      const float* ot = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(bsm) + T::LDS_IMG);
+      const float rstd0 = a.xst[2 * f + 1];
+      constexpr int HX = T::HX, EPT0 = cdiv(HX, 8);
+      float dn[EPT0], xh[EPT0];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < EPT0; ++j) {
+        const int h = t8 + 8 * j;
+        const bool ok = h < HX;
+        const int i = c0 * HX + (ok ? h : 0);
+        xh[j] = xh0[i];
+        const float nn = xh[j] * g0 + b0;
+        dn[j] = ok ? ot[i] * (nn >= 0.f ? 1.0f : LEAK) : 0.f;
+        const float dxv = dn[j] * g0;
+        s1 += dxv;
+        s2 += dxv * xh[j];
+      }
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      const int par = nfr & 1;
+      if (lane == 0) {
+        red0[par][wave][0] = s1;
+        red0[par][wave][1] = s2;
+      }
+      __syncthreads();
+      constexpr float INVN0 = 1.0f / T::OFR;
+      s1 = ((red0[par][0][0] + red0[par][1][0]) + (red0[par][2][0] + red0[par][3][0])) * INVN0;
+      s2 = ((red0[par][0][1] + red0[par][1][1]) + (red0[par][2][1] + red0[par][3][1])) * INVN0;
+      if (fprev >= 0) copy_out0(fprev, par ^ 1);     // the previous frame's image is complete: every thread has passed this frame's barrier
+      unsigned short* im = img0 + par * NPL * T::P0_IMG;
+#pragma unroll
+      for (int j = 0; j < EPT0; ++j) {
+        const int h = t8 + 8 * j;
+        if (h >= HX) continue;
+        const float d = rstd0 * (dn[j] * g0 - s1 - xh[j] * s2);
+        su0 += dn[j] * xh[j];
+        sw0 += dn[j];
+        sd0 += d;
+        unsigned t[NPL];
+        split_n<NPL>(d, t);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) im[p * T::P0_IMG + (T::PD0.HLO + h) * T::P0_CPL + c0] = (unsigned short)t[p];
+      }
+      fprev = f;
+      ++nfr;
+    } else if constexpr (T::OTL && BFM == 0) {
       // the frame's input gradient: one aligned contiguous run (unconditional stores, the rounds past the end repeat the last piece: a static
       // store count keeps the wait for the next frame's prefetched registers a counted one).  The tile is rewritten two barriers from here.
       if (!((VAENPVC_FB_ABL & (1 | 4)) && a.F > 0)) {
@@ -424,6 +520,23 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
           og[i] = ot4[i];
         }
       }
+    }
+  }
+  if constexpr (LNB2) {
+    __syncthreads();
+    if (fprev >= 0) copy_out0(fprev, (nfr - 1) & 1);
+    // the three per-channel sums of the layer below: the 8 threads of a channel are 8 consecutive lanes
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      su0 += __shfl_xor(su0, o);
+      sw0 += __shfl_xor(sw0, o);
+      sd0 += __shfl_xor(sd0, o);
+    }
+    if (t8 == 0) {
+      float* pp = a.part0 + (int64_t)blockIdx.x * (3 * T::CX);
+      pp[c0] = su0;
+      pp[T::CX + c0] = sw0;
+      pp[2 * T::CX + c0] = sd0;
     }
   }
   if ((VAENPVC_FB_ABL & 16) && a.F > 0) return;
@@ -471,6 +584,13 @@ static void launch_fbwd(const FbArgs& a, hipStream_t s) {
       constexpr int BFM = L == FB_D2 ? 7 : 1;
       rt().ensure_lds(reinterpret_cast<const void*>(&k_fbwd<NPL, L, BFM>), T::LDS);
       hipLaunchKernelGGL((k_fbwd<NPL, L, BFM>), dim3(grid), dim3(256), T::LDS, s, a);
+      return;
+    }
+  }
+  if constexpr (T::LNB2_OK) {
+    if (a.pl0) {
+      rt().ensure_lds(reinterpret_cast<const void*>(&k_fbwd<NPL, L, 0, 0, true>), T::LDS_LNB2);
+      hipLaunchKernelGGL((k_fbwd<NPL, L, 0, 0, true>), dim3(grid), dim3(256), T::LDS_LNB2, s, a);
       return;
     }
   }

@@ -80,12 +80,19 @@ struct FwStage {
     }
   }
   // frames past the batch end hold zeros in the registers and are stored too (stale rows of an earlier group must not survive)
-  __device__ __forceinline__ void store(unsigned short* xs, bool ln, const float* gamma, const float* beta, int wave, int lane) {
+  // xh_out (TF == 1 only): the normalised values (v - mean) rstd of the frame also go to an fp32 LDS tile [C][H] -- the LayerNorm backward of
+  // THIS tensor's layer, fused behind the consumer's input gradient (gfx950_fbwd.h: LNB2), needs them and the branch of lrelu
+  __device__ __forceinline__ void store(unsigned short* xs, bool ln, const float* gamma, const float* beta, int wave, int lane,
+                                        float* xh_out = nullptr) {
 #pragma unroll
     for (int u = 0; u < IPW; ++u) {
       const int it = wave + 4 * u, fl = it / NCH, k = it - fl * NCH;
       const int h = 64 * k + lane;
       if (!(it < NIT && h < H)) continue;
+      if (xh_out) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) xh_out[c * H + h] = (v[u][c] - mean[u]) * rstd[u];
+      }
       if (ln && ok[u]) {
 #pragma unroll
         for (int c = 0; c < C; ++c) v[u][c] = lnact_v(v[u][c], mean[u], rstd[u], gamma[c], beta[c]);

@@ -1104,7 +1104,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     }
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 3);
   // one kernel per thin decoder layer: LayerNorm backward + input gradient + weight gradient + the layer's parameter sums
-  auto fused_bwd = [&](int layer, int i, const float* dy, float* dx, const char* tag) {
+  auto fused_bwd = [&](int layer, int i, const float* dy, float* dx, const char* tag, unsigned short* pl0 = nullptr, int64_t pl0_plane = 0,
+                       float* part0 = nullptr) {
     const bool enc = fb_enc(layer);
     const ConvL &l = enc ? m.enc[i] : m.dec[i], &pl = enc ? m.enc[i - 1] : m.dec[i - 1];
     float* const* act = enc ? w.enc_a : w.dec_a;
@@ -1116,6 +1117,9 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
                 G + l.w_off, G + l.gamma_off, G + l.beta_off, G + l.b_off, F};
       fa.bf16_act = abf && !enc;
       fa.dy_pitch = (layer == FB_D2 && dy2_pitch(F) == DY2_PITCH) ? DY2_PITCH : 0;
+      fa.pl0 = pl0;
+      fa.pl0_plane = pl0_plane;
+      fa.part0 = part0;
       VAENPVC_TIMED(tag, s, fbwd<NPL>(layer, fa, s));
     });
   };
@@ -1185,8 +1189,16 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
   if (bwd_on(8) && bwd_on(9) && fb_bwd(FB_D1, F)) {
     const ConvL& pl = m.dec[0];
     float* dy0 = dy_cur == w.dy_tmp ? w.d_dec_a[1] : w.dy_tmp;
-    fused_bwd(FB_D1, 1, dy_cur, dy0, "dec1_bwd");
-    lnb_dec0(dy0);
+    // (round 5) decoder layer 0's LayerNorm backward inside layer 1's kernel: planes of d(a0) straight from the tile, no d(y0) in HBM
+    if (rt().fb_lnb2 && gd0_only_planes && dense_planes_now() <= 2 && !abf) {
+      const int nwg = (int)cmin_((int64_t)F, (int64_t)512);
+      fused_bwd(FB_D1, 1, dy_cur, dy0, "dec1_bwd", us(w.cl[CL_GD0]), cl_plane(CL_GD0, F), w.scratch + Pk::lnpart);
+      VAENPVC_TIMED("lnb_dec0", s, hipLaunchKernelGGL(k_ln_bwd_reduce, dim3(3 * 32), dim3(256), 0, s, w.scratch + Pk::lnpart, nwg, 32,
+                                                       G + pl.gamma_off, G + pl.beta_off, G + pl.b_off));
+    } else {
+      fused_bwd(FB_D1, 1, dy_cur, dy0, "dec1_bwd");
+      lnb_dec0(dy0);
+    }
     dec_bias_done[0] = true;
   } else if (bwd_on(8)) {
     const ConvL &l = m.dec[1], &pl = m.dec[0];

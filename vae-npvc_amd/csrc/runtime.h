@@ -60,6 +60,7 @@ struct Runtime {
   bool dy2_pad = true;          // VAENPVC_DY2_PAD=0: the 1025-tap layer's input gradient in the tensor's own 513-float rows (unaligned 16-byte stores; A/B)
   bool e2_osp = true;           // VAENPVC_E2_OSP=0: statistics + activated planes of encoder layer 2's output in their own pass (A/B)
   bool tn_d0fit = true;         // VAENPVC_TN_D0FIT=0: decoder layer 0's weight gradient on 128 x 256 tiles (36 % of the MFMA work useful) instead of 96 x 288 (A/B)
+  bool fb_lnb2 = true;          // VAENPVC_FB_LNB2=0: decoder layer 0's LayerNorm backward as its own pass behind layer 1's fused backward kernel (A/B)
   int tn_xcd = -1;              // VAENPVC_TN_XCD=0|1: tile order of the C += A^T B plane GEMM (experiments; -1 = per site)
   int toep_zc = 4;              // VAENPVC_TOEP_ZC: frame chunks of the Toeplitz weight gradient, 64 workgroups each (4: one workgroup per CU, one prologue / epilogue per CU)
   bool toep_f32 = false;        // VAENPVC_TOEP=f32: exact-fp32 MFMA kernels for the 1025-tap layer
