@@ -97,17 +97,15 @@ KERNEL_ROWS = [
     dict(name='k_gemm_nt<%d, false>', tags='enc4_fwd heads_fwd merge_fwd merge_dgrad heads_dgrad enc4_dgrad', bound='mfma',
          mac=2 * (688128 + 196608 + 196992),
          what='C = A B^T plane GEMM: forward + input gradient of encoder layer 4 (as a dense layer), heads, merge: six launches per step'),
-    dict(name='k_fbwd<%d, 0, 0, 516>', tags='dec2_bwd', bound='hbm', bytes=4 * (_E['d2'] + _E['d2'] + _E['d1'] + _E['d1']),
+    dict(name='k_fbwd<%d, 0, 0, 516, false>', tags='dec2_bwd', bound='hbm', bytes=4 * (_E['d2'] + _E['d2'] + _E['d1'] + _E['d1']),
          what='whole backward step of decoder layer 2 in one kernel: dy + pre-LN output + input activation read, input gradient written, once'),
-    dict(name='k_fbwd<%d, 1, 0, 0>', tags='dec1_bwd', bound='hbm', bytes=4 * (_E['d1'] + _E['d1'] + _E['d0'] + _E['d0']),
-         what='whole backward step of decoder layer 1'),
-    dict(name='k_fbwd<%d, 2, 0, 0>', tags='enc1_bwd', bound='hbm', bytes=4 * (_E['e1'] + _E['e1'] + _E['e0'] + _E['e0']),
+    dict(name='k_fbwd<%d, 2, 0, 0, false>', tags='enc1_bwd', bound='hbm', bytes=4 * (_E['e1'] + _E['e1'] + _E['e0'] + _E['e0']),
          what='whole backward step of encoder layer 1'),
     dict(name='k_toep_gemm_bf16<false, %d, false, 516>', tags='dec3_dgrad', bound='mfma', mac=8 * 513 * 513, what='1025-tap layer, input gradient'),
     dict(name='k_toep_gemm_bf16<true, %d, false, 513>', tags='dec3_fwd', bound='mfma', mac=8 * 513 * 513, what='1025-tap layer, forward'),
     dict(name='k_toep_wgrad_bf16_w4<%d>', tags='dec3_wgrad', bound='mfma', mac=8 * 513 * 513, what='1025-tap layer, weight gradient'),
-    dict(name='k_gemm_tn32<%d, 2, 2, 2>', tags='enc3_wgrad dec0_wgrad', bound='mfma', mac=401408 + 427680,
-         what='C += A^T B over (frame, position) rows: weight gradients of encoder layer 3 and decoder layer 0'),
+    dict(name='k_fbwd<%d, 1, 0, 0, true>', tags='dec1_bwd', bound='hbm', bytes=4 * (_E['d1'] + _E['d1'] + _E['d0']) + 2 * 2 * 63 * 32,
+         what='whole backward step of decoder layer 1 + the LayerNorm backward of layer 0 (result: its bf16 operand planes)'),
 ]
 # layer-materialised (Model B) bytes per frame of the thin conv group's tensors: outputs of encoder 0-1 and decoder 1-2, each
 # written + read once forward and its gradient written + read once backward, x read twice
