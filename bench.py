@@ -76,14 +76,16 @@ SITE_GROUPS = {
               'enc1_dgrad enc0_wgrad enc0_bwd enc0_reduce lnb_dec2 lnb_dec1 lnb_enc0'),
         bound='hbm',
         bytes=4 * ((_E['x'] + _E['e0']) + (_E['e0'] + _E['e1']) + (_E['d0'] + _E['d1']) + (_E['d1'] + _E['d2']) + (_E['d2'] + 4224)
-                   + (2 * _E['d2'] + 2 * _E['d1']) + (2 * _E['d1'] + 2 * _E['d0']) + (2 * _E['e1'] + 2 * _E['e0'])
-                   + (_E['e0'] + _E['x']))),
-    'layernorm_backward (separate LayerNorm + lrelu backward passes: decoder layer 0, encoder layers 2-4)': dict(
+                   + (2 * _E['d2'] + 2 * _E['d1']) + (2 * _E['d1'] + _E['d0']) + (2 * _E['e1'] + 2 * _E['e0'])
+                   + (_E['e0'] + _E['x']))
+              + 2 * 2 * 63 * 32),   # (decoder layer 1's backward writes layer 0's gradient planes, 2 x bf16 [63][32], instead of the fp32 d(y0))
+    'layernorm_backward (separate LayerNorm + lrelu backward passes: encoder layers 3-4; second-stage reductions of the fused ones)': dict(
         tags='lnb_dec0 lnb_enc4 lnb_enc3 lnb_enc2 lnb_enc1', bound='hbm',
         # reads: d(activated output) + pre-LN tensor (fp32); writes: the consumers' operand planes (2 x bf16; channel-last with halo rows for
         # decoder 0: 63 x 32, encoder 3: 10 x 128; plain rows for encoder 4) or the fp32 gradient (encoder 2)
         # (round 5: encoder layer 2's pass is gone -- it runs in the epilogue of layer 3's input-gradient GEMM; `lnb_enc2` is its 8 us second stage)
-        bytes=4 * 2 * (_E['d0'] + _E['e4'] + _E['e3']) + 2 * 2 * (63 * 32 + 10 * 128 + _E['e4']),
+        # (... and decoder layer 0's inside decoder layer 1's fused backward kernel: `lnb_dec0` is its 7 us second stage)
+        bytes=4 * 2 * (_E['e4'] + _E['e3']) + 2 * 2 * (10 * 128 + _E['e4']),
         moved_not_algorithmic=True),
     'weight_packing (per-step packed / split copies of the parameters)': dict(tags='prep', bound='hbm', bytes_per_step=10 * 939162 * 4),
 }
