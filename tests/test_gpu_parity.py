@@ -420,6 +420,21 @@ def test_a_resident_merge_gemm_against_oracle(F, seed, monkeypatch):
     assert not fails, '\n'.join(fails)
 
 
+def test_decoder_tail_in_the_forward_epilogue(monkeypatch):
+    """k_fconv<TAIL> (round 5; built, measured, OFF by default because it is not faster): decoder layer 2's forward kernel with the work of
+    the pass behind it in its epilogue -- LayerNorm statistics of its result, the 1025-tap layer's operand planes, bin 512 of the activated
+    tensor, output column 512.  Forced with VAENPVC_D2_TAIL=1 at a ragged large batch (odd number of frames: the last group holds one frame):
+    every tensor and gradient against the float64 oracle."""
+    monkeypatch.setenv('VAENPVC_D2_TAIL', '1')
+    eng = make_engine('vcc', 'auto')
+    eng.timer_select('dec2_stats_planes')
+    fails = compare_everything(eng, 1027, 7, 'd2_tail F1027 ')
+    _, n = eng.timer_read()
+    eng.timer_select(None)
+    assert n == 0, 'the separate statistics / planes pass still ran'
+    assert not fails, '\n'.join(fails)
+
+
 VIEW_CONV = (0xebffffff, 0xebffffff)    # ... and bit 26: every conv site on the view GEMMs (csrc/gfx950_viewconv.h)
 
 

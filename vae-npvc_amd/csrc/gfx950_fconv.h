@@ -93,6 +93,12 @@ struct FcArgs {
   const float* beta2 = nullptr;
   unsigned short* cl2_out = nullptr;
   int64_t cl2_plane = 0;
+  // k_fconv, decoder layer 2 forward with the DECODER TAIL in its epilogue (round 5, TAIL): st2_out / gamma2 / beta2 as above, and
+  unsigned short* yp = nullptr;     // the 1025-tap layer's forward operand: planes of lrelu(LN(out)) [F][NPL][8][528] (zero padding 513..527)
+  float* decy = nullptr;            // fp32 [F][8][513]: only bin 512 of every channel is written (read by the loss kernel's edge term)
+  const float* wc = nullptr;        // tap table of the 1025-tap layer [8][1040]: Wc[c][8 + t] (k_ln_stats_act_planes)
+  const float* bias3 = nullptr;     // its bias [1]
+  float* xh = nullptr;              // [F][513]: column 512 of the forward result = dot(activated frame, reversed taps) + bias
 };
 
 template <int CP, int CPL>
@@ -103,11 +109,21 @@ __device__ __forceinline__ int fc_koff(int ks, int lh) {
 }
 
 // LN: 0 plain input, 1 LayerNorm + lrelu with given statistics, 2 ... with statistics computed here
-template <int NPL, int SITE, int LN, bool BIN = false, bool BOUT = false>
-__global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (FcCfg<NPL, SITE>::OCC)) k_fconv(FcArgs a) {
+// TAIL (round 5, decoder layer 2 forward only): the workgroup owns whole result frames, so the work of the separate pass between this layer and
+// the 1025-tap layer (k_ln_stats_act_planes: 240 us, a re-read of the 0.54 GB result) runs on the accumulators in the deferred epilogue:
+// LayerNorm statistics of the result (two-pass: per-wave partials through LDS, two barriers), the activated values as bf16 terms into an LDS
+// image of the frames' operand planes [frame][plane][8][528] (copied out as 16-byte pieces behind a third barrier), bin 512 of the activated
+// tensor as fp32, and output column 512 of the 1025-tap layer (a dot product of the activated frame with the reversed taps).  Two workgroups per
+// CU (the image does not fit beside three), up to 256 registers.
+constexpr int fc_tail_img_bytes(int npl, int tf) { return tf * npl * TB_C * TB_KP * 2; }
+template <int NPL, int SITE, int LN, bool BIN = false, bool BOUT = false, bool TAIL = false>
+__global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (TAIL ? 2 : FcCfg<NPL, SITE>::OCC)) k_fconv(FcArgs a) {
   using T = FcCfg<NPL, SITE>;
   constexpr CvSite V = T::V;
+  static_assert(!TAIL || (SITE == CV_D2F && !BIN && !BOUT && V.PH && V.O == TB_C && V.OH == TB_H && T::NJ == 1 && T::MT == 1 && VAENPVC_FC_DEFER),
+                "decoder tail: decoder layer 2 forward, fp32 storage, deferred epilogue");
   extern __shared__ __attribute__((aligned(16))) unsigned short fsm[];
+  __shared__ float tpart[3][4][FcCfg<NPL, SITE>::TF];   // TAIL: per-wave partials of the frames' sum / centred square sum / dot product
   __shared__ float part[2][FcCfg<NPL, SITE>::TF * cdiv(FcCfg<NPL, SITE>::H, 64)];   // per staging item: sum, sum of squared deviations
   // LayerNorm parameters of the input, copied once: read through the argument pointers inside the group loop they were re-fetched
   // with vector loads by every group, right behind the result stores (one exposed round trip per group; round 4)
@@ -340,6 +356,162 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (FcCfg<NPL, SITE>::O
       }
     }
   };
+  // ---- TAIL epilogue (see above).  Lane: row n = (frame fl, view row q) of each of its NSW steps; 4 channels (cs + 4 lh) x 3 positions.
+  float g2[4], b2[4];
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int cs = 0; cs < 4; ++cs) {
+      g2[cs] = a.gamma2[cs + 4 * lh];
+      b2[cs] = a.beta2[cs + 4 * lh];
+    }
+  }
+  auto epilogue_tail = [&](int f0, int nf) __attribute__((always_inline)) {
+   if constexpr (TAIL) {
+    static_assert(!TAIL || T::TF == 2, "two frames per group");
+    const int nrows = nf * V.R;
+    unsigned short* img = fsm + NPL * (T::XPL + T::WPL);      // [TF][NPL][8][528]
+    // taps of this lane's positions (before any store; rows past the end / positions out of range read tap 0 of a valid address)
+    float wt[NSW][4][3];
+    int fl_[NSW], pb_[NSW];
+    bool ok_[NSW];
+#pragma unroll
+    for (int sidx = 0; sidx < NSW; ++sidx) {
+      const int n = (wave + NWV * sidx) * T::SROWS + l31;
+      ok_[sidx] = n < nrows;
+      const int nn = ok_[sidx] ? n : 0;
+      fl_[sidx] = nn / V.R;
+      pb_[sidx] = (nn - fl_[sidx] * V.R) * V.oq + V.o0;
+#pragma unroll
+      for (int cs = 0; cs < 4; ++cs)
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) {
+          const int pos = min(max(pb_[sidx] + p3, 0), TB_H - 1);
+          wt[sidx][cs][p3] = a.wc[(cs + 4 * lh) * 1040 + 8 + 1024 - pos];
+        }
+    }
+    // values (conv + bias) in place of the accumulators; positions outside the tensor / rows past the group are masked everywhere below
+    // accumulator register of (channel slot cs, phase p3): tile row = phase * mdiv + channel
+#define FC_TAIL_VAL(sidx, cs, p3) acc[sidx][0][0][(((p3) * V.mdiv + (cs)) % 32 & 3) + 4 * ((((p3) * V.mdiv + (cs)) % 32) >> 3)]
+    auto live = [&](int sidx, int p3) __attribute__((always_inline)) {
+      const int pos = pb_[sidx] + p3;
+      return ok_[sidx] && pos >= 0 && pos < TB_H;
+    };
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int sidx = 0; sidx < NSW; ++sidx)
+#pragma unroll
+      for (int cs = 0; cs < 4; ++cs)
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) {
+          FC_TAIL_VAL(sidx, cs, p3) += bv[cs];
+          const float t = live(sidx, p3) ? FC_TAIL_VAL(sidx, cs, p3) : 0.f;
+          s0 += fl_[sidx] == 0 ? t : 0.f;
+          s1 += fl_[sidx] == 1 ? t : 0.f;
+        }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (lane == 0) {
+      tpart[0][wave][0] = s0;
+      tpart[0][wave][1] = s1;
+    }
+    __syncthreads();
+    constexpr float INVN = 1.0f / (TB_C * TB_H);
+    const float mean0 = ((tpart[0][0][0] + tpart[0][1][0]) + (tpart[0][2][0] + tpart[0][3][0])) * INVN;
+    const float mean1 = ((tpart[0][0][1] + tpart[0][1][1]) + (tpart[0][2][1] + tpart[0][3][1])) * INVN;
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int sidx = 0; sidx < NSW; ++sidx)
+#pragma unroll
+      for (int cs = 0; cs < 4; ++cs)
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) {
+          const float d = FC_TAIL_VAL(sidx, cs, p3) - (fl_[sidx] == 0 ? mean0 : mean1);
+          const float t = live(sidx, p3) ? d * d : 0.f;
+          q0 += fl_[sidx] == 0 ? t : 0.f;
+          q1 += fl_[sidx] == 1 ? t : 0.f;
+        }
+    q0 = wave_sum(q0);
+    q1 = wave_sum(q1);
+    if (lane == 0) {
+      tpart[1][wave][0] = q0;
+      tpart[1][wave][1] = q1;
+    }
+    __syncthreads();
+    const float rstd0 = 1.0f / sqrtf(((tpart[1][0][0] + tpart[1][1][0]) + (tpart[1][2][0] + tpart[1][3][0])) * INVN + LN_EPS);
+    const float rstd1 = 1.0f / sqrtf(((tpart[1][0][1] + tpart[1][1][1]) + (tpart[1][2][1] + tpart[1][3][1])) * INVN + LN_EPS);
+    if (tid < nf) {
+      a.st2_out[2 * (f0 + tid)] = tid == 0 ? mean0 : mean1;
+      a.st2_out[2 * (f0 + tid) + 1] = tid == 0 ? rstd0 : rstd1;
+    }
+    // pre-LN result (fp32, as the plain epilogue), activated values -> image / bin 512 / dot product
+    float d0 = 0.f, d1 = 0.f;
+    struct __attribute__((packed, aligned(4))) f3 { float x, y, z; };
+#pragma unroll
+    for (int sidx = 0; sidx < NSW; ++sidx) {
+      if (!ok_[sidx]) continue;
+      const int fl = fl_[sidx], pbase = pb_[sidx];
+      const float mean = fl == 0 ? mean0 : mean1, rstd = fl == 0 ? rstd0 : rstd1;
+      float* ob = a.out + (int64_t)(f0 + fl) * (V.OC * V.OH);
+      const bool inner = pbase >= 0 && pbase + 2 < V.OH;
+      float dsum = 0.f;
+#pragma unroll
+      for (int cs = 0; cs < 4; ++cs) {
+        const int ch = cs + 4 * lh;
+        const float p0 = FC_TAIL_VAL(sidx, cs, 0), p1 = FC_TAIL_VAL(sidx, cs, 1), p2 = FC_TAIL_VAL(sidx, cs, 2);
+        float* o = ob + ch * V.OH + pbase;
+        if (inner) {
+          *reinterpret_cast<f3*>(o) = f3{p0, p1, p2};
+        } else {
+          if (pbase >= 0 && pbase < V.OH) o[0] = p0;
+          if (pbase + 1 >= 0 && pbase + 1 < V.OH) o[1] = p1;
+          if (pbase + 2 >= 0 && pbase + 2 < V.OH) o[2] = p2;
+        }
+        unsigned short* ir = img + (fl * NPL * TB_C + ch) * TB_KP;      // + plane * TB_C * TB_KP
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) {
+          const int pos = pbase + p3;
+          if (pos < 0) continue;
+          unsigned t[NPL];
+          if (pos < TB_H) {
+            const float y = lnact_v(FC_TAIL_VAL(sidx, cs, p3), mean, rstd, g2[cs], b2[cs]);
+            dsum += y * wt[sidx][cs][p3];
+            split_n<NPL>(y, t);
+            if (pos == TB_H - 1) a.decy[(int64_t)(f0 + fl) * (TB_C * TB_H) + ch * TB_H + pos] = y;
+          } else {
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) t[p] = 0u;
+          }
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) ir[p * TB_C * TB_KP + pos] = (unsigned short)t[p];
+        }
+        if (pbase + 2 >= TB_H) {   // the last view row of the frame (positions 511, 512, 513): the zero padding 514 .. 527 of the plane rows
+#pragma unroll
+          for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int z = TB_H + 1; z < TB_KP; z += 2) *reinterpret_cast<unsigned*>(ir + p * TB_C * TB_KP + z) = 0u;
+        }
+      }
+      d0 += fl == 0 ? dsum : 0.f;
+      d1 += fl == 1 ? dsum : 0.f;
+    }
+    d0 = wave_sum(d0);
+    d1 = wave_sum(d1);
+    if (lane == 0) {
+      tpart[2][wave][0] = d0;
+      tpart[2][wave][1] = d1;
+    }
+    __syncthreads();
+    if (tid < nf) a.xh[(int64_t)(f0 + tid) * TB_H + (TB_H - 1)] = ((tpart[2][0][tid] + tpart[2][1][tid]) + (tpart[2][2][tid] + tpart[2][3][tid])) + a.bias3[0];
+    // the image: the frames' planes are one contiguous run of yp
+    {
+      constexpr int PPF = NPL * TB_C * TB_KP / 8;       // 16-byte pieces per frame
+      const u32x4* im4 = reinterpret_cast<const u32x4*>(img);
+      u32x4* og = reinterpret_cast<u32x4*>(a.yp + (int64_t)f0 * (NPL * TB_C * TB_KP));
+      for (int i = tid; i < nf * PPF; i += NTHR) og[i] = im4[i];
+    }
+#undef FC_TAIL_VAL
+   }
+  };
   int pf0 = -1, pnf = 0;   // the group whose results are still in the accumulators
   for (; g < ngroups; g += gridDim.x) {
     const int f0 = g * T::TF, nf = min(T::TF, a.F - f0);
@@ -350,7 +522,8 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (FcCfg<NPL, SITE>::O
       for (int u = 0; u < IPW; ++u)
 #pragma unroll
         for (int c = 0; c < T::CP; ++c) asm volatile("" ::"v"(v[u][c]));
-      epilogue(pf0, pnf);
+      if constexpr (TAIL) epilogue_tail(pf0, pnf);
+      else epilogue(pf0, pnf);
     }
     fstore(g);
     __syncthreads();   // the group's frames are in LDS
@@ -399,7 +572,11 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (FcCfg<NPL, SITE>::O
     pnf = nf;
     __syncthreads();   // all fragment reads of this group are done before the next one overwrites the tile
   }
-  if (VAENPVC_FC_DEFER && pf0 >= 0) epilogue(pf0, pnf);
+  if constexpr (TAIL) {
+    if (pf0 >= 0) epilogue_tail(pf0, pnf);
+  } else {
+    if (VAENPVC_FC_DEFER && pf0 >= 0) epilogue(pf0, pnf);
+  }
 }
 
 template <int NPL, int SITE>
@@ -411,6 +588,15 @@ static void launch_fconv(const FcArgs& a, hipStream_t s) {
       constexpr bool BIN = SITE == CV_D2F;
       rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, 2, BIN, true>), T::LDS);
       hipLaunchKernelGGL((k_fconv<NPL, SITE, 2, BIN, true>), dim3(grid), dim3(T::NTHR), T::LDS, s, a);
+      return;
+    }
+  }
+  if constexpr (SITE == CV_D2F && NPL <= 2 && fc_occ3(SITE)) {
+    if (a.yp && a.st_out) {   // decoder tail in the epilogue: two workgroups per CU (frames + weights + plane image)
+      constexpr int LDS_T = T::LDS + fc_tail_img_bytes(NPL, T::TF);
+      const unsigned gridt = (unsigned)cmin_(cdiv(a.F, T::TF), 512);
+      rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, 2, false, false, true>), LDS_T);
+      hipLaunchKernelGGL((k_fconv<NPL, SITE, 2, false, false, true>), dim3(gridt), dim3(T::NTHR), LDS_T, s, a);
       return;
     }
   }

@@ -789,13 +789,34 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     if (!d2_fused && !(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) VAENPVC_TIMED("stats_dec1", s, stats<2736>(w.dec_a[1], w.dec_st[1], F, s));
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 1);
   if (fwd_on(9)) {
+    // (round 5) the decoder tail in layer 2's epilogue: statistics of its result, the 1025-tap layer's operand planes, bin 512 of the activated
+    // tensor and output column 512 leave the kernel that computed the frames; k_ln_stats_act_planes and its re-read of the tensor are gone
+    const bool d2_tail = rt().d2_tail && fc_fwd(CV_D2F, F) && fwd_on(10) && toep_bf16_for(F) && !abf && dense_planes_now() <= 2 &&
+                         dense_planes_now() == rt().planes && toep_wgrad_bf16_for(F) && toep_fwd_groups(F, weights_packed) == 1 && w.dec_y && w.toep_yp &&
+                         fc_occ3(CV_D2F) && F >= FCONV_MIN_FRAMES;
+    if (d2_tail) {
+      for_dense_planes([&](auto npl) {
+        FcArgs fa{w.dec_a[1], nullptr, w.dec_st[1], P + m.dec[1].gamma_off, P + m.dec[1].beta_off,
+                  reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvw + cv_woff(CV_D2F)), P + m.dec[2].b_off, w.dec_a[2], F};
+        fa.st2_out = w.dec_st[2];
+        fa.gamma2 = P + m.dec[2].gamma_off;
+        fa.beta2 = P + m.dec[2].beta_off;
+        fa.yp = reinterpret_cast<unsigned short*>(w.toep_yp);
+        fa.decy = w.dec_y;
+        fa.wc = w.scratch + Pk::wc;
+        fa.bias3 = P + m.dec[3].b_off;
+        fa.xh = xh_out;
+        VAENPVC_TIMED("dec2_fwd", s, fconv<decltype(npl)::value>(CV_D2F, fa, s));
+      });
+    } else
     if (fc_fwd(CV_D2F, F)) fused(CV_D2F, w.dec_a[1], nullptr, w.dec_st[1], &m.dec[1], P + m.dec[2].b_off, w.dec_a[2], "dec2_fwd", abf, abf);
     else if (cv_fwd(CV_D2F, F)) dec_view(CV_D2F, CL_YD1, 2, have_yd1, w.dec_a[1], "dec2_split", "dec2_fwd");
     else
     VAENPVC_TIMED("dec2_fwd", s, launch_convgemm<D2F>(conv_args(w.dec_a[1], w.dec_st[1], P + m.dec[1].gamma_off,
                                                                 P + m.dec[1].beta_off, w.scratch + Pk::d2f,
                                                                 P + m.dec[2].b_off, w.dec_a[2], F), nsplit_for<D2F>(F), s));
-    if (toep_bf16_for(F) && fwd_on(10))
+    if (d2_tail) {}
+    else if (toep_bf16_for(F) && fwd_on(10))
       for_planes([&](auto npl) {
         constexpr int NPL_ = decltype(npl)::value;
         auto launch_sap = [&](auto kern) {

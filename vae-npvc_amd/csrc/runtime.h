@@ -61,6 +61,11 @@ struct Runtime {
   bool e2_osp = true;           // VAENPVC_E2_OSP=0: statistics + activated planes of encoder layer 2's output in their own pass (A/B)
   bool tn_d0fit = true;         // VAENPVC_TN_D0FIT=0: decoder layer 0's weight gradient on 128 x 256 tiles (36 % of the MFMA work useful) instead of 96 x 288 (A/B)
   bool fb_lnb2 = true;          // VAENPVC_FB_LNB2=0: decoder layer 0's LayerNorm backward as its own pass behind layer 1's fused backward kernel (A/B)
+  bool d2_tail = false;         // VAENPVC_D2_TAIL=1: the pass between decoder layer 2 and the 1025-tap layer (statistics, planes, bin 512, column 512) in the
+                                // epilogue of layer 2's forward kernel (k_fconv<TAIL>).  OFF: built, parity-green, NOT faster -- 457 us against 205 + 240 us for
+                                // the two kernels (round 5, same box): the epilogue's ~1 100 vector instructions and three barriers per 2-frame group are
+                                // serial work in a kernel that then fits two workgroups per CU instead of three (255 registers, 66 KB of LDS), while the
+                                // separate pass streams at 4.6 TB/s with 16 waves per CU
   int tn_xcd = -1;              // VAENPVC_TN_XCD=0|1: tile order of the C += A^T B plane GEMM (experiments; -1 = per site)
   int toep_zc = 4;              // VAENPVC_TOEP_ZC: frame chunks of the Toeplitz weight gradient, 64 workgroups each (4: one workgroup per CU, one prologue / epilogue per CU)
   bool toep_f32 = false;        // VAENPVC_TOEP=f32: exact-fp32 MFMA kernels for the 1025-tap layer

@@ -37,6 +37,7 @@ void Runtime::read_env() {
   toep_wgrad_f32 = getenv("VAENPVC_TOEP_WGRAD_F32") != nullptr;
   if (const char* e = getenv("VAENPVC_TOEP_ZC")) toep_zc = atoi(e) > 0 ? atoi(e) : 4;
   if (const char* e = getenv("VAENPVC_TN_XCD")) tn_xcd = atoi(e);
+  if (const char* e = getenv("VAENPVC_D2_TAIL")) d2_tail = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_FB_LNB2")) fb_lnb2 = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_TN_D0FIT")) tn_d0fit = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_E2_OSP")) e2_osp = atoi(e) != 0;
