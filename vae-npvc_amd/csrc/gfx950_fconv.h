@@ -99,6 +99,7 @@ struct FcArgs {
   const float* wc = nullptr;        // tap table of the 1025-tap layer [8][1040]: Wc[c][8 + t] (k_ln_stats_act_planes)
   const float* bias3 = nullptr;     // its bias [1]
   float* xh = nullptr;              // [F][513]: column 512 of the forward result = dot(activated frame, reversed taps) + bias
+  int zero_xh = 0;                  // 1: bins 0 .. 511 of xh are zeroed (the 1025-tap forward GEMM accumulates channel groups into them at small batches)
 };
 
 template <int CP, int CPL>
@@ -502,6 +503,8 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (TAIL ? 2 : FcCfg<NP
     }
     __syncthreads();
     if (tid < nf) a.xh[(int64_t)(f0 + tid) * TB_H + (TB_H - 1)] = ((tpart[2][0][tid] + tpart[2][1][tid]) + (tpart[2][2][tid] + tpart[2][3][tid])) + a.bias3[0];
+    if (a.zero_xh)   // uniform
+      for (int i = tid; i < nf * (TB_H - 1); i += NTHR) a.xh[(int64_t)(f0 + i / (TB_H - 1)) * TB_H + i % (TB_H - 1)] = 0.f;
     // the image: the frames' planes are one contiguous run of yp
     {
       constexpr int PPF = NPL * TB_C * TB_KP / 8;       // 16-byte pieces per frame

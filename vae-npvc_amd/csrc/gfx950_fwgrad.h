@@ -53,14 +53,43 @@ struct FwArgs {
   int F;
 };
 
+#ifndef VAENPVC_FW_THIRDS
+#define VAENPVC_FW_THIRDS 1   // 0: lane = position for every tensor (A/B)
+#endif
 // staging of one operand: items = (frame of the group, 64-position chunk) dealt round-robin to the waves (see k_fconv)
 template <int NPL, int C, int CP, int CPL, int H, int TF, int FS, int ROW0, int PLANE, bool BF = false>   // BF: the tensor is stored as bf16 (act_pitch rows)
 struct FwStage {
   static constexpr int NCH = cdiv(H, 64), NIT = TF * NCH, IPW = cdiv(NIT, 4);
-  float v[IPW][CP];
+  // THIRDS (round 5): tensors with few positions and many channels (encoder layer 2's gradient: 64 x 19) are staged with lane = (position,
+  // channel third) -- 57 active lanes walking 24 channels -- instead of lane = position: 19 active lanes walking 64 (as gfx950_fconv_r.h)
+  static constexpr bool THIRDS = VAENPVC_FW_THIRDS && H < 32 && 3 * H <= 64 && CP >= 24 && !BF;
+  static constexpr int CG = THIRDS ? rup(cdiv(CP, 3), 8) : CP;
+  float v[IPW][CG];
   float mean[IPW], rstd[IPW];
   bool ok[IPW];   // the item's frame exists (frames past the batch end are stored as zeros)
   __device__ __forceinline__ void load(const float* src, const float* st, int g, int F, int wave, int lane) {
+    if constexpr (THIRDS) {
+      const int p = lane % H, g3 = lane / H;
+#pragma unroll
+      for (int u = 0; u < IPW; ++u) {
+        const int it = wave + 4 * u, f = g * TF + it;
+        const bool fok = it < NIT && f < F;
+        ok[u] = fok;
+        const int64_t sfo = (int64_t)(fok ? f : 0) * (C * H);
+        mean[u] = 0.f;
+        rstd[u] = 1.f;
+        if (st) {  // uniform
+          mean[u] = st[2 * (fok ? f : 0)];
+          rstd[u] = st[2 * (fok ? f : 0) + 1];
+        }
+#pragma unroll
+        for (int cc = 0; cc < CG; ++cc) {
+          const int c = g3 * CG + cc;
+          v[u][cc] = (c < C && g3 < 3 && fok) ? src[sfo + c * H + p] : 0.f;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < IPW; ++u) {
       const int it = wave + 4 * u, fl = it / NCH, k = it - fl * NCH;
@@ -84,6 +113,32 @@ struct FwStage {
   // THIS tensor's layer, fused behind the consumer's input gradient (gfx950_fbwd.h: LNB2), needs them and the branch of lrelu
   __device__ __forceinline__ void store(unsigned short* xs, bool ln, const float* gamma, const float* beta, int wave, int lane,
                                         float* xh_out = nullptr) {
+    if constexpr (THIRDS) {
+      const int p = lane % H, g3 = lane / H, cbase = g3 * CG;
+#pragma unroll
+      for (int u = 0; u < IPW; ++u) {
+        const int it = wave + 4 * u;
+        if (!(it < NIT && g3 < 3)) continue;
+        if (ln && ok[u]) {
+#pragma unroll
+          for (int cc = 0; cc < CG; ++cc)
+            if (cbase + cc < C) v[u][cc] = lnact_v(v[u][cc], mean[u], rstd[u], gamma[cbase + cc], beta[cbase + cc]);
+        }
+        unsigned short* dx = xs + it * FS + (ROW0 + p) * CPL + cbase;
+#pragma unroll
+        for (int g8 = 0; g8 < CG / 8; ++g8) {
+          if (cbase + 8 * g8 >= CPL) continue;   // (the last third's tail beyond the padded row)
+          float v8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v8[j] = v[u][8 * g8 + j];
+          u32x4 pk[NPL];
+          pack8<NPL>(v8, pk);
+#pragma unroll
+          for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x4*>(dx + q * PLANE + 8 * g8) = pk[q];
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < IPW; ++u) {
       const int it = wave + 4 * u, fl = it / NCH, k = it - fl * NCH;

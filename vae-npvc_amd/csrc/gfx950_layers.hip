@@ -792,7 +792,7 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     // (round 5) the decoder tail in layer 2's epilogue: statistics of its result, the 1025-tap layer's operand planes, bin 512 of the activated
     // tensor and output column 512 leave the kernel that computed the frames; k_ln_stats_act_planes and its re-read of the tensor are gone
     const bool d2_tail = rt().d2_tail && fc_fwd(CV_D2F, F) && fwd_on(10) && toep_bf16_for(F) && !abf && dense_planes_now() <= 2 &&
-                         dense_planes_now() == rt().planes && toep_wgrad_bf16_for(F) && toep_fwd_groups(F, weights_packed) == 1 && w.dec_y && w.toep_yp &&
+                         dense_planes_now() == rt().planes && toep_wgrad_bf16_for(F) && w.dec_y && w.toep_yp &&
                          fc_occ3(CV_D2F) && F >= FCONV_MIN_FRAMES;
     if (d2_tail) {
       for_dense_planes([&](auto npl) {
@@ -806,6 +806,7 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
         fa.wc = w.scratch + Pk::wc;
         fa.bias3 = P + m.dec[3].b_off;
         fa.xh = xh_out;
+        fa.zero_xh = toep_fwd_groups(F, weights_packed) > 1 ? 1 : 0;
         VAENPVC_TIMED("dec2_fwd", s, fconv<decltype(npl)::value>(CV_D2F, fa, s));
       });
     } else
