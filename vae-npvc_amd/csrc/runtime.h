@@ -29,7 +29,8 @@ struct Runtime {
   long cv_sites_env = -1, fc_sites_env = -1;   // (VAENPVC_FC_SITES: thin sites on the fused kernel, gfx950_fconv.h)
   long fcr_sites_env = -1;      // VAENPVC_FCR_SITES: medium sites on the register-weight fused kernel (gfx950_fconv_r.h; bit = CV_* site)
   unsigned fcr_sites() const { return fcr_sites_env >= 0 ? (unsigned)fcr_sites_env : planes == 1 ? FCR_SITES_BF16 : FCR_SITES; }
-  static constexpr unsigned FCR_SITES = 0x28au, FCR_SITES_BF16 = 0x08au;   // CV_E2F (1), CV_D0F (3), CV_E2G (7), CV_D0G (9; view GEMM with one plane)
+  static constexpr unsigned FCR_SITES = 0x28au, FCR_SITES_BF16 = 0x28au;   // CV_E2F (1), CV_D0F (3), CV_E2G (7), CV_D0G (9; round 5: with one plane as well -- reading the planes
+                                                                            //  decoder layer 1's fused backward now leaves, the LayerNorm pass in between is gone there too: 4.21 -> 4.02 ms)
   long fw_sites_env = -1;       // VAENPVC_FW_SITES: thin weight gradients on the fused kernel (gfx950_fwgrad.h; bit = CW_* site)
   unsigned fw_sites() const { return fw_sites_env >= 0 ? (unsigned)fw_sites_env : planes == 1 ? FW_SITES_BF16 : FW_SITES; }
   static constexpr unsigned FW_SITES = 0x3fu, FW_SITES_BF16 = 0x3fu;   // (round 5: encoder layer 2 as well -- its view GEMM needed two split passes since the forward kernels no
