@@ -392,7 +392,10 @@ def main(argv=None):
         'step_fraction_of_rooflines': {
             'hbm_model_B': (frames_per_s / world * BYTES_PER_FRAME_TRAIN + steps_per_s * BYTES_PER_STEP_PARAMS) / HBM_PEAK,
             'fp32_flops': frames_per_s / world * FLOP_PER_FRAME_TRAIN / FP32_PEAK,
-            'mfma_%s' % PREC_NAME[planes]: frames_per_s / world * FLOP_PER_FRAME_TRAIN / (BF16_PEAK / PRODUCTS[planes])},
+            'mfma_%s' % PREC_NAME[planes]: frames_per_s / world * FLOP_PER_FRAME_TRAIN / (BF16_PEAK / PRODUCTS[planes]),
+            'note': ('fp32_flops prices the step against the EXACT-fp32 MFMA peak (157.3 TFLOP/s, v_mfma_f32_32x32x2_f32), an instruction this path no longer '
+                     'uses above 1 024 frames: its GEMMs run on the bf16 matrix cores with split operands, so that figure may pass 1; the matrix-core '
+                     'bound of the arithmetic actually executed is mfma_%s' % PREC_NAME[planes])},
     }
     if standin:
         out['data'] = 'CPU stand-in engine (test of the launcher / process-group logic only; not a measurement)'

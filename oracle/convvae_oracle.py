@@ -290,11 +290,13 @@ def torch_params(P, dtype=None, requires_grad=False):
     return out
 
 
-def torch_layernorm(a, offset, scale):
+def torch_layernorm(a, offset, scale, want_xhat=False):
     torch = _torch()
     mu = a.mean(dim=(1, 2, 3), keepdim=True)
     var = ((a - mu) ** 2).mean(dim=(1, 2, 3), keepdim=True)
-    return (a - mu) * torch.rsqrt(var + LN_EPS) * scale.reshape(1, -1, 1, 1) + offset.reshape(1, -1, 1, 1)
+    xhat = (a - mu) * torch.rsqrt(var + LN_EPS)
+    n = xhat * scale.reshape(1, -1, 1, 1) + offset.reshape(1, -1, 1, 1)
+    return (n, xhat) if want_xhat else n
 
 
 def torch_lrelu(x, branch=None, tau=0.0):
@@ -323,15 +325,25 @@ def torch_convT_same(x, W, b, s):
     H, k = x.shape[2], W.shape[0]
     ho, pad = same_pad_convT(H, k, s)
     full = Fn.conv_transpose2d(x, W.permute(3, 2, 0, 1), None, stride=(s, 1))
-    return full[:, :, pad:pad + ho, :] + b.reshape(1, -1, 1, 1)
+    out = full[:, :, pad:pad + ho, :]
+    return out if b is None else out + b.reshape(1, -1, 1, 1)
 
 
-def _tape(tape, name, t):
-    """tape: optional dict; records, under the NAME of an additive parameter (conv / dense bias, LayerNorm offset), the tensor
-    that parameter is broadcast-added into, with its gradient retained (see torch_loss_and_grads(sum_scales=True))"""
+def _tape(tape, name, t, factor=None):
+    """tape: optional dict; records, under the NAME of a parameter whose gradient is a plain sum over the broadcast axes -- an additive
+    parameter (conv / dense bias, LayerNorm offset: gradient = sum of the upstream gradient d) or a LayerNorm scale (gradient = sum of
+    d * xhat: `factor` = xhat) -- the tensor it acts on, with its gradient retained (see torch_loss_and_grads(sum_scales=True))"""
     if tape is not None:
         t.retain_grad()
-        tape[name] = t
+        tape[name] = (t, None if factor is None else factor.detach())
+
+
+def _tape_lin(tape, name, fn, x, out):
+    """... and for a WEIGHT tensor W of a linear layer out = fn(x, W) (+ bias): its gradient is sum over (frame, position) of x * d, so
+    S = fn's weight gradient evaluated on |x| and |d| (the layer is linear in W: autograd of fn(|x|, W) with upstream |d|)"""
+    if tape is not None:
+        out.retain_grad()
+        tape.setdefault('__lin__', []).append((name, fn, x.detach(), out))
 
 
 def torch_encode(arch, P, x, kink=None, tape=None):
@@ -343,9 +355,11 @@ def torch_encode(arch, P, x, kink=None, tape=None):
     for i, l in enumerate(g['enc']):
         p = 'Encoder/Conv2d-%d/' % i
         a = torch_conv_same(cur, P[p + 'kernel'], P[p + 'bias'], l['s'])
-        n = torch_layernorm(a, P[p + 'layernorm.offset'], P[p + 'layernorm.scale'])
+        n, xhat = torch_layernorm(a, P[p + 'layernorm.offset'], P[p + 'layernorm.scale'], want_xhat=True)
         _tape(tape, p + 'bias', a)
+        _tape_lin(tape, p + 'kernel', (lambda xx, W, s_=l['s']: torch_conv_same(xx, W, None, s_)), cur, a)
         _tape(tape, p + 'layernorm.offset', n)
+        _tape(tape, p + 'layernorm.scale', n, xhat)
         cur = torch_lrelu(n) if kink is None else torch_lrelu(n, kink['enc%d' % i], kink['tau'])
         acts.append((a, cur))
     flat = cur.reshape(F, -1)
@@ -353,6 +367,8 @@ def torch_encode(arch, P, x, kink=None, tape=None):
     z_lv = flat @ P['Encoder/dense_1/kernel'] + P['Encoder/dense_1/bias']
     _tape(tape, 'Encoder/dense/bias', z_mu)
     _tape(tape, 'Encoder/dense_1/bias', z_lv)
+    _tape_lin(tape, 'Encoder/dense/kernel', (lambda xx, W: xx @ W), flat, z_mu)
+    _tape_lin(tape, 'Encoder/dense_1/kernel', (lambda xx, W: xx @ W), flat, z_lv)
     return z_mu, z_lv, acts
 
 
@@ -366,6 +382,12 @@ def torch_decode(arch, P, z, y, kink=None, tape=None):
          + P['Generator/BiasAdd/biases'])
     for nm in ('Generator/fully_connected/biases', 'Generator/fully_connected_1/biases', 'Generator/BiasAdd/biases'):
         _tape(tape, nm, h)
+    _tape_lin(tape, 'Generator/fully_connected/weights', (lambda xx, W: xx @ W), z, h)
+    _tape_lin(tape, 'Generator/fully_connected_1/weights', (lambda xx, W: xx @ W), e, h)
+    if tape is not None:   # the embedding table: e = onehot(y) E, linear in E
+        onehot = torch.zeros(F, P['y_embedding/y_emb'].shape[0], dtype=z.dtype)
+        onehot[torch.arange(F), y] = 1.0
+        _tape_lin(tape, 'y_embedding/y_emb', (lambda xx, W: xx @ W), onehot, e)
     cur = h.reshape(F, g['dec'][0]['cin'], g['dec'][0]['hin'], 1)
     nd = len(g['dec'])
     acts = [h]
@@ -373,9 +395,11 @@ def torch_decode(arch, P, z, y, kink=None, tape=None):
         p = 'Generator/conv2d_transpose%s/' % ('' if i == 0 else '_%d' % i)
         a = torch_convT_same(cur, P[p + 'kernel'], P[p + 'bias'], l['s'])
         _tape(tape, p + 'bias', a)
+        _tape_lin(tape, p + 'kernel', (lambda xx, W, s_=l['s']: torch_convT_same(xx, W, None, s_)), cur, a)
         if i < nd - 1:
-            n = torch_layernorm(a, P['Generator/ConvT-LN%d.offset' % i], P['Generator/ConvT-LN%d.scale' % i])
+            n, xhat = torch_layernorm(a, P['Generator/ConvT-LN%d.offset' % i], P['Generator/ConvT-LN%d.scale' % i], want_xhat=True)
             _tape(tape, 'Generator/ConvT-LN%d.offset' % i, n)
+            _tape(tape, 'Generator/ConvT-LN%d.scale' % i, n, xhat)
             cur = torch_lrelu(n) if kink is None else torch_lrelu(n, kink['dec%d' % i], kink['tau'])
             acts.append(a)
         else:
@@ -402,7 +426,10 @@ def torch_loss_and_grads(arch, P_np, x, y, eps, dtype=None, kink=None, sum_scale
 
     sum_scales=True returns a third value: for every ADDITIVE parameter b (conv / dense biases, LayerNorm offsets, the three
     merge biases), whose gradient is the plain sum of the upstream gradient d over the broadcast axes,
-    dG/db[c] = sum_{f,h} d[f,c,h], the array  S[c] = sum_{f,h} |d[f,c,h]|  (same shape as b).  Such a sum cancels towards 0
+    dG/db[c] = sum_{f,h} d[f,c,h], the array  S[c] = sum_{f,h} |d[f,c,h]|  (same shape as b); and for every LayerNorm SCALE g,
+    dG/dg[c] = sum_{f,h} d[f,c,h] xhat[f,c,h], the array  S[c] = sum_{f,h} |d[f,c,h] xhat[f,c,h]|; and for every WEIGHT tensor W of a
+    linear layer (conv / conv_transpose / dense kernels, the two merge matrices, the embedding table), dG/dW = sum_{f,h} x d, the same
+    sum over |x| |d| (the layer's own weight-gradient operator applied to the absolute values).  All 44 trainables have an entry.  Such a sum cancels towards 0
     as a fit converges, so it has no scale of its own: the error of ANY finite-precision evaluation of it is bounded by
     (relative error of a term) x S[c], never by a fraction of |dG/db|.  S is the scale a comparison of these tensors is
     measured on where the gradient itself has cancelled away (tests/test_gpu_frame.py)."""
@@ -424,8 +451,13 @@ def torch_loss_and_grads(arch, P_np, x, y, eps, dtype=None, kink=None, sum_scale
     if not sum_scales:
         return out, grads
     scales = OrderedDict()
-    for k, t in tape.items():
-        d = t.grad.abs()
+    lin = tape.pop('__lin__', [])
+    for name, fn, xin, outt in lin:
+        Wl = P[name].detach().clone().requires_grad_(True)
+        (sw,) = torch.autograd.grad(fn(xin.abs(), Wl), Wl, grad_outputs=outt.grad.abs())
+        scales[name] = sw.numpy().reshape(P[name].shape)
+    for k, (t, factor) in tape.items():
+        d = (t.grad if factor is None else t.grad * factor).abs()
         if d.dim() == 4:      # [F,C,H,1] -> per channel
             scales[k] = d.sum(dim=(0, 2, 3)).numpy().reshape(P[k].shape)
         else:                 # [F,N] -> per column

@@ -221,3 +221,25 @@ def test_lrelu_kink_branch_pin():
     _, G2 = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64, kink=k2)
     d = max(np.abs(G2[n] - G0[n]).max() / np.abs(G0[n]).max() for n in G0)
     assert d > 1e-6, d          # one flipped unit of ~300 moves the gradient visibly
+
+
+def test_sum_of_magnitudes_scales_bound_every_gradient():
+    """oracle.torch_loss_and_grads(sum_scales=True): for each of the 44 trainables the scale S = sum over (frame, position) of |term| of the
+    sum its gradient is.  Pinned here: every tensor has one, of its own shape; S >= |gradient| entry by entry (triangle inequality: a replay
+    function that is not the layer's weight-gradient operator breaks it); the gradients themselves are unchanged by the tape; and for ONE
+    frame with the upstream gradient of one sign the additive parameters of the last layer have S == |gradient|."""
+    import torch
+    arch = load_arch()
+    P = O.init_params(arch, 3)
+    x, y, eps = O.make_inputs(arch, 16, 3)
+    _, G, S = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64, sum_scales=True)
+    _, G0 = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64)
+    assert list(S.keys()).__len__() == 44 and set(S) == set(G)
+    for k in G:
+        assert np.array_equal(G[k], G0[k])
+        assert S[k].shape == G[k].shape and np.all(S[k] >= np.abs(G[k]) * (1 - 1e-9)), k
+    b = 'Generator/conv2d_transpose_3/bias'
+    assert S[b].ravel()[0] > abs(G[b].ravel()[0])            # 16 frames x 513 residuals of both signs: cancellation
+    x1 = np.full((1, 513), 100.0)                            # one frame far above anything the untrained decoder emits: every residual has one sign
+    _, G1, S1 = O.torch_loss_and_grads(arch, P, x1, y[:1], eps[:1], torch.float64, sum_scales=True)
+    assert abs(S1[b].ravel()[0] - abs(G1[b].ravel()[0])) <= 1e-12 * S1[b].ravel()[0]
