@@ -23,6 +23,9 @@ constexpr bool fcr_serves_site(int site) { return site == CV_D0F || site == CV_D
 // floats (76 bytes: every store instruction touched ~5 partial lines); the same re-ordering took the plane GEMMs' result stores from 64 to 16
 // instructions per lane (gfx950_planegemm.h).  Sites: decoder layer 0 input gradient, encoder layer 2 forward (4 frames per group there:
 // frames + tile stay under 80 KB, two workgroups per CU).
+#ifndef VAENPVC_FCR_CLO_ORDER
+#define VAENPVC_FCR_CLO_ORDER 2   // (281 -> 274 us for decoder layer 0 forward; 1: 278)
+#endif
 #ifndef VAENPVC_FCR_OTL
 #define VAENPVC_FCR_OTL 1   // bit 0: the S-type sites (dec0 dgrad 167 -> 155 us, enc2 fwd 119 -> 117), bit 1: decoder layer 0 forward as well (phase-stacked; measured
                             // SLOWER, 276 -> 291 us: its 12-byte stores are not what bounds it, the tile's LDS traffic and the later store issue cost more)
@@ -265,7 +268,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
     const int f0 = g * T::TF, nf = min(T::TF, a.F - f0);
     fstore(g);
     __syncthreads();
-    if constexpr (CLO) {
+    auto clo_copy = [&]() __attribute__((always_inline)) {
       // the staged image (bf16 terms, channel-last, zero halo rows) is exactly the group's frames of the planes: copied out as
       // consecutive 16-byte pieces (direct stores from the staging registers -- 16 bytes at a 176-byte stride per lane -- cost
       // as much as the separate split pass they replaced: 217 -> 314 us, same-box)
@@ -275,8 +278,11 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
         const u32x4 vv = *reinterpret_cast<const u32x4*>(xs + p * T::XPL + fl * T::FS + hp * T::CPL + 8 * g8);
         st_nt<VAENPVC_NT_B>(reinterpret_cast<u32x4*>(a.cl_out + p * a.cl_plane + (int64_t)(f0 + fl) * (T::HP * T::CP) + (int64_t)q * 8), vv);
       }
-    }
+    };
+    // VAENPVC_FCR_CLO_ORDER: 0 = copy-out, then the next group's loads, then the GEMM; 1 = loads first; 2 = copy-out behind the GEMM
+    if constexpr (CLO && VAENPVC_FCR_CLO_ORDER == 0) clo_copy();
     if (g + (int)gridDim.x < ngroups) fload(g + gridDim.x);
+    if constexpr (CLO && VAENPVC_FCR_CLO_ORDER == 1) clo_copy();
     // CHN 32-row steps at a time = CHN independent accumulator chains sharing the wave's weight fragments (a single chain
     // leaves the matrix pipe idle for most of an MFMA's latency).  Two planes: the weight tile leaves no registers for
     // a second chain (it spilled 50 - 118 registers), one chain.
@@ -363,6 +369,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
         }
       }
     }
+    if constexpr (CLO && VAENPVC_FCR_CLO_ORDER == 2) clo_copy();
     __syncthreads();
     if constexpr (T::OTL) {
       // the group's result frames: one contiguous run of the output tensor (the next group's results are written behind the barrier that
