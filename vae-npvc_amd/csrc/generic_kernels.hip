@@ -248,17 +248,22 @@ __global__ void k_convT_bwd_w(const float* __restrict__ in, Act ai, const float*
   int c = (int)(idx % g.cin);
   int o = (int)((idx / g.cin) % g.cout);
   int t = (int)(idx / ((int64_t)g.cin * g.cout));
-  float acc = 0.f;
+  // (round 5) a frame's terms are summed in fp32, the frames in DOUBLE: one thread walks the whole batch, and a sequential fp32 sum of
+  // F x H terms that cancel loses digits with the batch size (the 1025-tap kernel's gradient at 20 000 frames: 4e-3 of its largest entry
+  // against the tuned path and float64; 2e-6 now) -- this path is the correctness baseline on the GPU at every batch size
+  double acc = 0.0;
   for (int64_t f = 0; f < F; ++f) {
     const float* ir = in + (f * g.cin + c) * g.hin;
     const float* dr = dout + (f * g.cout + o) * g.hout;
+    float af = 0.f;
     for (int j = 0; j < g.hin; ++j) {
       int p = g.s * j - g.pad + t;
       if (p < 0 || p >= g.hout) continue;
-      acc += lnact(ir[j], ai, f, c) * dr[p];
+      af += lnact(ir[j], ai, f, c) * dr[p];
     }
+    acc += (double)af;
   }
-  dW[idx] = acc;
+  dW[idx] = (float)acc;
 }
 
 // db[o] = sum_f sum_h d[f,o,h] ; one block per channel
@@ -362,17 +367,19 @@ __global__ void k_conv_bwd_w(const float* __restrict__ in, Act ai, const float* 
   int o = (int)(idx % g.cout);
   int c = (int)((idx / g.cout) % g.cin);
   int t = (int)(idx / ((int64_t)g.cout * g.cin));
-  float acc = 0.f;
+  double acc = 0.0;   // (frames in double: see k_convT_bwd_w)
   for (int64_t f = 0; f < F; ++f) {
     const float* ir = in + (f * g.cin + c) * g.hin;
     const float* dr = da + (f * g.cout + o) * g.hout;
+    float af = 0.f;
     for (int j = 0; j < g.hout; ++j) {
       int i = g.s * j - g.pad + t;
       if (i < 0 || i >= g.hin) continue;
-      acc += lnact(ir[i], ai, f, c) * dr[j];
+      af += lnact(ir[i], ai, f, c) * dr[j];
     }
+    acc += (double)af;
   }
-  dW[idx] = acc;
+  dW[idx] = (float)acc;
 }
 
 // dflat[f,k] = sum_n dzmu[f,n] Wmu[k,n] + dzlv[f,n] Wlv[k,n]
@@ -397,14 +404,14 @@ __global__ void k_heads_bwd_w(const float* __restrict__ a, Act ai, int hlast, co
   if (idx >= (int64_t)flat * z) return;
   int n = (int)(idx % z);
   int k = (int)(idx / z);
-  float a1 = 0.f, a2 = 0.f;
+  double a1 = 0.0, a2 = 0.0;   // (frames in double: see k_convT_bwd_w)
   for (int64_t f = 0; f < F; ++f) {
     float v = lnact(a[f * flat + k], ai, f, k / hlast);
-    a1 += v * dzmu[f * z + n];
-    a2 += v * dzlv[f * z + n];
+    a1 += (double)(v * dzmu[f * z + n]);
+    a2 += (double)(v * dzlv[f * z + n]);
   }
-  dWmu[idx] = a1;
-  dWlv[idx] = a2;
+  dWmu[idx] = (float)a1;
+  dWlv[idx] = (float)a2;
 }
 
 // column sums of a [F, N] matrix written to up to three destinations
@@ -455,14 +462,14 @@ __global__ void k_merge_bwd_w(const float* __restrict__ z, const int64_t* __rest
   if (idx >= (int64_t)zd * M) return;
   int n = (int)(idx % M);
   int k = (int)(idx / M);
-  float a1 = 0.f, a2 = 0.f;
+  double a1 = 0.0, a2 = 0.0;   // (frames in double: see k_convT_bwd_w)
   for (int64_t f = 0; f < F; ++f) {
     float g = dh[f * M + n];
-    a1 += z[f * zd + k] * g;
-    a2 += emb[clamp_id(y[f], ny) * zd + k] * g;
+    a1 += (double)(z[f * zd + k] * g);
+    a2 += (double)(emb[clamp_id(y[f], ny) * zd + k] * g);
   }
-  dWz[idx] = a1;
-  dWy[idx] = a2;
+  dWz[idx] = (float)a1;
+  dWy[idx] = (float)a2;
 }
 
 // dE[spk,k] = sum_{f : y_f == spk} de[f,k]   (tf IndexedSlices gradient, densified)
