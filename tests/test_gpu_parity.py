@@ -420,6 +420,37 @@ def test_a_resident_merge_gemm_against_oracle(F, seed, monkeypatch):
     assert not fails, '\n'.join(fails)
 
 
+RAGGED_LARGE_TENSOR_BAR = 1e-3     # two GPU evaluations of an UNFILTERED batch differ by their lrelu kink flips: measured worst
+                                   # tensor 4.9e-4 (encoder layer 0's 112-entry kernel, downstream of every flip), y_emb 2.7e-4, the large weight
+                                   # tensors <= 1.6e-4; a wrong or missing frame in a ragged tile moves a tensor by far more
+
+
+def test_tuned_and_generic_paths_agree_at_a_ragged_large_batch():
+    """20 011 frames (not a multiple of 16, 18, 64 or 128): the frame-owning GEMM tiles (k_cgemm_pf: 16 frames, k_cgemm_sf: 18), the plane GEMMs'
+    128-row tiles, the fused layer kernels' groups and the 1025-tap kernels' 64-frame tiles all end in a ragged tile at a size the float64
+    fixtures (8 192 / 32 768) do not cover and the in-test oracle cannot reach.  The generic kernels (one thread per output, any geometry; pinned
+    against float64 at small sizes) are the reference: losses and all 44 gradient tensors of the tuned default selection against them."""
+    from hipvae import Engine
+    arch = ARCHS['vcc']
+    F, seed = 20011, 31
+    P = O.init_params(arch, seed)
+    x, y, eps = O.make_inputs(arch, F, seed)
+    res = {}
+    for impl in ('generic', 'auto'):
+        eng = Engine(arch, impl=impl)
+        res[impl] = run_train(eng, P, x, y, eps)
+        layout = eng.layout
+        del eng
+    (l_g, g_g), (l_t, g_t) = res['generic'], res['auto']
+    assert np.isfinite(g_t).all() and np.isfinite(g_g).all()
+    fails, tag = [], 'tuned vs generic F%d ' % F
+    check(tag + 'loss3', l_t, l_g, 1e-5, fails)
+    for name, (off, shape) in layout.items():
+        n = int(np.prod(shape))
+        check(tag + 'grad ' + name, g_t[off:off + n], g_g[off:off + n], RAGGED_LARGE_TENSOR_BAR, fails)
+    assert not fails, '\n'.join(fails)
+
+
 def test_decoder_tail_in_the_forward_epilogue(monkeypatch):
     """k_fconv<TAIL> (round 5; built, measured, OFF by default because it is not faster): decoder layer 2's forward kernel with the work of
     the pass behind it in its epilogue -- LayerNorm statistics of its result, the 1025-tap layer's operand planes, bin 512 of the activated
