@@ -133,8 +133,13 @@ struct FbArgs {
 // BFM: bf16 activation storage (precision "bf16"): bit 0 = dy and a, bit 1 = the input activation xa, bit 2 = the result dx
 // DYP: floats per row of dy when they differ from the tensor's (the 1025-tap layer's input gradient writes rows of 516 floats so that
 // its 16-byte stores are aligned, gfx950_toep_bf16.h); 0 = rows of the tensor
+#ifndef VAENPVC_FB_OCC3
+#define VAENPVC_FB_OCC3 0   // bit l: layer FB_* l compiled for three workgroups per CU (168 registers).  Measured (round 5): decoder layer 2 spills 22 registers
+                            // there and runs 453 -> 488 us; the other two layers do not fit three workgroups in LDS
+#endif
+constexpr int fb_occ(int l, bool lnb2) { return (!lnb2 && ((VAENPVC_FB_OCC3 >> l) & 1)) ? 3 : 2; }
 template <int NPL, int L, int BFM = 0, int DYP = 0, bool LNB2 = false>
-__global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
+__global__ void __launch_bounds__(256, fb_occ(L, LNB2)) k_fbwd(FbArgs a) {
   using T = FbCfg<NPL, L>;
   static_assert(!LNB2 || (T::LNB2_OK && BFM == 0), "LayerNorm backward of the layer below: decoder layer 1, fp32 storage");
   constexpr bool BFG = BFM & 1, BFX = (BFM >> 1) & 1, BFO = (BFM >> 2) & 1;
@@ -578,7 +583,7 @@ __global__ void __launch_bounds__(256, 2) k_fbwd(FbArgs a) {
 template <int NPL, int L>
 static void launch_fbwd(const FbArgs& a, hipStream_t s) {
   using T = FbCfg<NPL, L>;
-  const unsigned grid = (unsigned)cmin_(a.F, T::LDS > 78 * 1024 ? 256 : 512);
+  const unsigned grid = (unsigned)cmin_(a.F, T::LDS > 78 * 1024 ? 256 : (fb_occ(L, false) == 3 && 3 * T::LDS <= 156 * 1024) ? 768 : 512);
   if constexpr (NPL == 1 && (L == FB_D2 || L == FB_D1)) {
     if (a.bf16_act) {   // bf16 activation storage: layer 2 reads and writes bf16 throughout, layer 1 reads (dy, a) as bf16
       constexpr int BFM = L == FB_D2 ? 7 : 1;
