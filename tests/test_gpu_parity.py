@@ -466,6 +466,19 @@ def test_decoder_tail_in_the_forward_epilogue(monkeypatch):
     assert not fails, '\n'.join(fails)
 
 
+@pytest.mark.parametrize('planes_out', ['1', '0'])
+def test_merge_gradient_operand_from_the_layer_above(monkeypatch, planes_out):
+    """Decoder layer 0's input-gradient kernel writes d(h) as the bf16 operand planes of the two merge GEMMs itself (k_fconv_r<..., POUT>,
+    round 5, default from 1 024 frames on) and the per-speaker column sums are taken from those planes (k_segsum_planes); with
+    VAENPVC_D0G_PLANES=0 it stores fp32 d(h) and k_split_segsum makes planes + sums in a pass of its own.  Both at a ragged large batch (the
+    last group of the kernel holds three frames), every tensor and gradient against the float64 oracle -- the three merge biases, dWy and dE are
+    functions of the column sums alone."""
+    monkeypatch.setenv('VAENPVC_D0G_PLANES', planes_out)
+    eng = make_engine('vcc', 'auto')
+    fails = compare_everything(eng, 1027, 11, 'd(h) planes=%s F1027 ' % planes_out)
+    assert not fails, '\n'.join(fails)
+
+
 VIEW_CONV = (0xebffffff, 0xebffffff)    # ... and bit 26: every conv site on the view GEMMs (csrc/gfx950_viewconv.h)
 
 

@@ -100,6 +100,12 @@ struct FcArgs {
   const float* bias3 = nullptr;     // its bias [1]
   float* xh = nullptr;              // [F][513]: column 512 of the forward result = dot(activated frame, reversed taps) + bias
   int zero_xh = 0;                  // 1: bins 0 .. 511 of xh are zeroed (the 1025-tap forward GEMM accumulates channel groups into them at small batches)
+  // k_fconv_r, decoder layer 0 input gradient (round 5, POUT): non-null = the result rows d(h) leave as the bf16 operand planes of the two
+  // merge GEMMs ([NPL][pl_plane], rows of pl_kp elements, columns behind the row's 1539 values zero) INSTEAD of as the fp32 tensor `out`:
+  // the split pass over d(h) (k_split_segsum: 200 MB read, 210 MB written) shrinks to a read-only pass for the per-speaker sums
+  unsigned short* pl_out = nullptr;
+  int64_t pl_plane = 0;
+  int pl_kp = 0;
 };
 
 template <int CP, int CPL>

@@ -52,7 +52,8 @@ struct FrCfg {
   static constexpr int RSTEP = (V.step / CP) * CPL;
   static constexpr bool OTL = fcr_otl(SITE, NPL);
   static constexpr int OFR = V.OC * V.OH;                       // floats per result frame
-  static constexpr int LDS_X = NPL * XPL * 2, LDS = LDS_X + (OTL ? TF * OFR * 4 : 0);
+  static constexpr int OPT4 = rup(OFR, 4);                      // tile row pitch when the rows leave one by one (POUT: 16-byte aligned rows)
+  static constexpr int LDS_X = NPL * XPL * 2, LDS = LDS_X + (OTL ? TF * OPT4 * 4 : 0);
   static_assert(!OTL || (LDS_X % 16 == 0 && (TF * OFR) % 4 == 0), "result tile: 16-byte aligned, whole groups are whole pieces");
   // staging: lane = position (H >= 32) or lane = (position, channel third) (H < 32)
   static constexpr bool POS = H >= 32;
@@ -97,11 +98,14 @@ static PackViewPermJob<NPL> fcr_perm_job(int site, const float* W, int s_t, int 
 }
 
 // OSP (encoder layer 2 forward with the result tile in LDS): statistics of the result + its activated channel-last planes (FcArgs::st2_out ...)
-template <int NPL, int SITE, int LN, bool CLO = false, bool PIN = false, bool OSP = false>
+// POUT (decoder layer 0 input gradient with the result tile in LDS): the result rows leave as bf16 operand planes (FcArgs::pl_out), no fp32 copy
+template <int NPL, int SITE, int LN, bool CLO = false, bool PIN = false, bool OSP = false, bool POUT = false>
 __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
   using T = FrCfg<NPL, SITE>;
   constexpr CvSite V = T::V;
   static_assert(!OSP || (T::OTL && !T::PERM && T::TF == 4 && V.O <= 64), "result statistics: one wave per frame of the LDS tile");
+  static_assert(!POUT || (T::OTL && !T::PERM && !OSP), "operand planes out: from the canonical result tile");
+  constexpr int OPT = POUT ? T::OPT4 : T::OFR;   // floats per frame of the result tile
   extern __shared__ __attribute__((aligned(16))) unsigned short rsm[];
   unsigned short* xs = rsm;   // [NPL][XPL]
   __shared__ float lnp[2][FrCfg<NPL, SITE>::C];   // LayerNorm parameters of the input (a fetch per group through the pointers otherwise)
@@ -324,7 +328,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
           float* ob = a.out + (int64_t)(f0 + fl) * (V.OC * V.OH);
           const int pbase = q * V.oq + V.o0;
           if constexpr (T::PERM && T::OTL) {
-            float* ot = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(rsm) + T::LDS_X) + fl * T::OFR + pbase;
+            float* ot = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(rsm) + T::LDS_X) + fl * OPT + pbase;
 #pragma unroll
             for (int cs = 0; cs < 4; ++cs) {
               const int ch = tile * 8 + cs + 4 * lh;
@@ -353,7 +357,7 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
               }
             }
           } else if constexpr (T::OTL) {
-            float* ot = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(rsm) + T::LDS_X) + fl * T::OFR + pbase;
+            float* ot = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(rsm) + T::LDS_X) + fl * OPT + pbase;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
               const int ch = tile * 32 + acc_row(reg, lane);
@@ -375,10 +379,38 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
       // the group's result frames: one contiguous run of the output tensor (the next group's results are written behind the barrier that
       // follows its staging, so these reads need no barrier of their own)
       const float* ot = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(rsm) + T::LDS_X);
+      if constexpr (POUT) {
+        // a row of the tile = a row of the merge GEMMs' operand: split into its bf16 terms eight values at a time, whole padded rows
+        // (pl_kp elements: the pieces behind the row's OFR values are zero) as consecutive 16-byte pieces of every plane
+        const int p8 = a.pl_kp >> 3;
+        constexpr int FULL = T::OFR >> 3, REM = T::OFR & 7;
+        for (int i = tid; i < nf * p8; i += 256) {
+          const int fl = i / p8, j = i - fl * p8;
+          const float* t = ot + fl * OPT + 8 * j;
+          float v8[8];
+          if (j < FULL) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(t), hi = *reinterpret_cast<const f32x4*>(t + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v8[k] = lo[k];
+              v8[4 + k] = hi[k];
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v8[k] = (j == FULL && k < REM) ? t[k] : 0.f;
+          }
+          u32x4 pk[NPL];
+          pack8<NPL>(v8, pk);
+#pragma unroll
+          for (int p = 0; p < NPL; ++p)
+            st_nt<VAENPVC_NT_B>(reinterpret_cast<u32x4*>(a.pl_out + p * a.pl_plane + (int64_t)(f0 + fl) * a.pl_kp + 8 * j), pk[p]);
+        }
+      } else {
       float* og = a.out + (int64_t)f0 * T::OFR;
       const int nfl = nf * T::OFR, n4 = nfl >> 2;
       for (int i = tid; i < n4; i += 256) reinterpret_cast<f32x4*>(og)[i] = reinterpret_cast<const f32x4*>(ot)[i];
       if (tid < (nfl & 3)) og[4 * n4 + tid] = ot[4 * n4 + tid];     // (ragged last group)
+      }
       if constexpr (OSP) {
         // LayerNorm statistics of the result frames (two-pass, as k_ln_stats_fast) and their activated channel-last planes: wave = frame
         constexpr ClDesc D2 = CLD[CL_Y2];
@@ -433,6 +465,13 @@ static void launch_fconv_r(const FcArgs& a, hipStream_t s) {
     if (a.cl_out && !a.st) {
       rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv_r<NPL, SITE, 0, true>), T::LDS);
       hipLaunchKernelGGL((k_fconv_r<NPL, SITE, 0, true>), dim3(grid), dim3(256), T::LDS, s, a);
+      return;
+    }
+  }
+  if constexpr (SITE == CV_D0G && T::OTL) {
+    if (a.cl_in && a.pl_out) {   // (operand planes in, operand planes of the merge GEMMs out)
+      rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv_r<NPL, SITE, 0, false, true, false, true>), T::LDS);
+      hipLaunchKernelGGL((k_fconv_r<NPL, SITE, 0, false, true, false, true>), dim3(grid), dim3(256), T::LDS, s, a);
       return;
     }
   }

@@ -1031,12 +1031,18 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
       }
     });
   };
-  auto rdgrad = [&](int site, const float* wpl, const float* grad, float* out, const char* tag, const float* planes_in = nullptr) {   // medium site, register-weight fused kernel
+  auto rdgrad = [&](int site, const float* wpl, const float* grad, float* out, const char* tag, const float* planes_in = nullptr,
+                    float* planes_out = nullptr, int out_kp = 0) {   // medium site, register-weight fused kernel
     for_dense_planes([&](auto npl) {
       FcArgs fa{grad, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const unsigned short*>(wpl), nullptr, out, F};
       if (planes_in) {
         fa.cl_in = reinterpret_cast<const unsigned short*>(planes_in);
         fa.cl_plane = cl_plane(CVS[site].x, F);
+      }
+      if (planes_out) {   // (the result as the operand planes [NPL][F][out_kp] of the GEMMs behind it, no fp32 copy)
+        fa.pl_out = us(planes_out);
+        fa.pl_plane = (int64_t)F * out_kp;
+        fa.pl_kp = out_kp;
       }
       VAENPVC_TIMED(tag, s, fconv_r<decltype(npl)::value>(site, fa, s));
     });
@@ -1243,6 +1249,10 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     dec_bias_done[0] = true;
   } else generic::bwd_dec_layer(m, P, F, w, G, s, 1);
 
+  // d(h) straight to the planes of the two merge GEMMs (the input-gradient kernel owns whole frames and has them in LDS): every consumer
+  // of d(h) on this path must be a plane kernel, and the per-speaker sums are then taken from the planes
+  const bool dh_planes = rt().d0g_planes && gd0_only_planes && fcr_otl(CV_D0G, dense_planes_now()) && bwd_on(6) && pg_bwd(F) && pg_fwd(F) && fwd_on(6) &&
+                         VAENPVC_SPLIT_SEGSUM && F >= 64;
   // ---- d0
   if (bwd_on(7)) {
     const ConvL& l = m.dec[0];
@@ -1254,7 +1264,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     if (vw) vwgrad(CW_D0, G + l.w_off, "dec0_wgrad");
     else VAENPVC_TIMED("dec0_wgrad", s2, launch_convwgrad<WD0>(a, WGS, s2));
     if (!dec_bias_done[0]) generic::bias_grad(w.d_dec_a[0], G + l.b_off, F, l.cout, l.hout, s);
-    if (rg) rdgrad(CV_D0G, w.scratch + Pk::cvw + cv_woff(CV_D0G), w.d_dec_a[0], w.d_h, "dec0_dgrad", gd0_only_planes ? w.cl[CL_GD0] : nullptr);
+    if (rg) rdgrad(CV_D0G, w.scratch + Pk::cvw + cv_woff(CV_D0G), w.d_dec_a[0], w.d_h, "dec0_dgrad", gd0_only_planes ? w.cl[CL_GD0] : nullptr,
+                   dh_planes ? w.pl_dh : nullptr, 1600);
     else if (vg) vdgrad(CV_D0G, w.d_h, "dec0_dgrad");
     else
     VAENPVC_TIMED("dec0_dgrad", s, (F < SMALL_BATCH_FRAMES ? launch_convgemm<GD0s>(conv_args(w.d_dec_a[0], nullptr, nullptr, nullptr, w.scratch + Pk::gd0,
@@ -1274,6 +1285,8 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
         if (VAENPVC_SPLIT_SEGSUM && F >= 64) {   // the planes of d(h) and the per-speaker column sums S in one pass over d(h)
         // (the chunk partials go to dy_tmp: the decoder's backward pass, its only user on this path, is behind us on this stream)
         int nch = 0;
+        if (dh_planes) VAENPVC_TIMED("merge_dsplit", s, (nch = launch_segsum_planes<NPL, MERGE_NY>(us(w.pl_dh), (int64_t)F * 1600, y, 1539, 1600, F, w.dy_tmp, s)));
+        else
         VAENPVC_TIMED("merge_dsplit", s, (nch = launch_split_segsum<NPL, MERGE_NY>(w.d_h, y, 1539, 1600, F, us(w.pl_dh), w.dy_tmp, s)));
         VAENPVC_TIMED("merge_segsum", s, launch_sum_parts(w.dy_tmp, nch, MERGE_NY * 1539, w.scratch + Pk::merge_s, s));
         } else {

@@ -272,6 +272,88 @@ inline int launch_split_segsum(const float* d, const int64_t* y, int N, int Kp, 
   hipLaunchKernelGGL((k_split_segsum<NPL, NY>), dim3((unsigned)cdiv(Kp, 512), (unsigned)nch), dim3(256), 0, s, d, y, N, Kp, (int)F, fc, dst, parts);
   return nch;
 }
+// The per-speaker column sums alone, from the bf16 operand PLANES of d(h) (round 5: the input-gradient kernel of decoder layer 0 writes the
+// planes itself, gfx950_fconv_r.h POUT, and no fp32 d(h) exists): value = sum of the element's terms (two planes: the fp32 value to 16 - 17
+// mantissa bits, rounded to nearest -- the sums of 3 000+ such values per speaker move by < 1e-6 of their magnitude scale).  Same grid,
+// ownership and chunk partials as k_split_segsum; read-only, eight frames in flight per wave.
+template <int NPL, int NY>
+__global__ void __launch_bounds__(256) k_segsum_planes(const unsigned short* __restrict__ pl, int64_t plane, const int64_t* __restrict__ y,
+                                                       int N, int Kp, int F, int fchunk, float* __restrict__ parts) {
+  __shared__ float red[NY * 8 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k0 = blockIdx.x * 512 + lane * 8;
+  const int fq = fchunk >> 2;
+  const int fb = blockIdx.y * fchunk + wave * fq, fe = min(F, fb + fq);
+  float acc[NY][8];
+#pragma unroll
+  for (int k = 0; k < NY; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+  if (k0 < N) {
+    constexpr int FIF = 8;
+    for (int f0 = fb; f0 < fe; f0 += FIF) {
+      u32x4 v[FIF][NPL];
+      int yk[FIF];
+#pragma unroll
+      for (int u = 0; u < FIF; ++u) {
+        const int f = f0 + u < fe ? f0 + u : fe - 1;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) v[u][p] = *reinterpret_cast<const u32x4*>(pl + p * plane + (int64_t)f * Kp + k0);
+        const int64_t yy = y[f];
+        yk[u] = (int)(yy < 0 ? 0 : (yy >= NY ? NY - 1 : yy));   // ids are clamped (vaenpvc_validate_ids reports them)
+      }
+#pragma unroll
+      for (int u = 0; u < FIF; ++u) {
+        if (f0 + u >= fe) break;
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float lo = 0.f, hi = 0.f;
+#pragma unroll
+          for (int p = NPL - 1; p >= 0; --p) {   // smallest term first
+            lo += __uint_as_float(v[u][p][q] << 16);
+            hi += __uint_as_float(v[u][p][q] & 0xffff0000u);
+          }
+          x[2 * q] = lo;
+          x[2 * q + 1] = hi;
+        }
+        const int ku = __builtin_amdgcn_readfirstlane(yk[u]);
+#pragma unroll
+        for (int k = 0; k < NY; ++k)
+          if (ku == k) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[k][j] += x[j];
+          }
+      }
+    }
+  }
+#pragma unroll 1
+  for (int w4 = 0; w4 < 4; ++w4) {
+    if (wave == w4) {
+#pragma unroll
+      for (int k = 0; k < NY; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float* r = &red[(k * 8 + j) * 64 + lane];
+          *r = w4 == 0 ? acc[k][j] : *r + acc[k][j];
+        }
+    }
+    __syncthreads();
+  }
+  float* part = parts + (int64_t)blockIdx.y * NY * N;
+  for (int i = threadIdx.x; i < NY * 512; i += 256) {
+    const int k = i >> 9, c = i & 511, n = blockIdx.x * 512 + c;
+    if (n < N) part[k * N + n] = red[(k * 8 + (c & 7)) * 64 + (c >> 3)];
+  }
+}
+template <int NPL, int NY>
+inline int launch_segsum_planes(const unsigned short* pl, int64_t plane, const int64_t* y, int N, int Kp, int64_t F, float* parts, hipStream_t s) {
+  const int ch = cmax(1, cmin_(cdiv((int)F, 64), VAENPVC_SS_CHUNKS));
+  const int fc = 4 * cdiv(cdiv((int)F, ch), 4);
+  const int nch = cdiv((int)F, fc);
+  hipLaunchKernelGGL((k_segsum_planes<NPL, NY>), dim3((unsigned)cdiv(N, 512), (unsigned)nch), dim3(256), 0, s, pl, plane, y, N, Kp, (int)F, fc, parts);
+  return nch;
+}
 inline void launch_sum_parts(const float* parts, int nch, int n, float* out, hipStream_t s) {
   hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, s, parts, nch, n, out);
 }

@@ -62,6 +62,7 @@ struct Runtime {
   bool e2_osp = true;           // VAENPVC_E2_OSP=0: statistics + activated planes of encoder layer 2's output in their own pass (A/B)
   bool tn_d0fit = true;         // VAENPVC_TN_D0FIT=0: decoder layer 0's weight gradient on 128 x 256 tiles (36 % of the MFMA work useful) instead of 96 x 288 (A/B)
   bool fb_lnb2 = true;          // VAENPVC_FB_LNB2=0: decoder layer 0's LayerNorm backward as its own pass behind layer 1's fused backward kernel (A/B)
+  bool d0g_planes = true;       // VAENPVC_D0G_PLANES=0: decoder layer 0's input gradient leaves as fp32 d(h) and a split pass makes the merge GEMMs' planes (A/B)
   bool d2_tail = false;         // VAENPVC_D2_TAIL=1: the pass between decoder layer 2 and the 1025-tap layer (statistics, planes, bin 512, column 512) in the
                                 // epilogue of layer 2's forward kernel (k_fconv<TAIL>).  OFF: built, parity-green, NOT faster -- 457 us against 205 + 240 us for
                                 // the two kernels (round 5, same box): the epilogue's ~1 100 vector instructions and three barriers per 2-frame group are

@@ -39,6 +39,7 @@ void Runtime::read_env() {
   if (const char* e = getenv("VAENPVC_TN_XCD")) tn_xcd = atoi(e);
   if (const char* e = getenv("VAENPVC_D2_TAIL")) d2_tail = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_FB_LNB2")) fb_lnb2 = atoi(e) != 0;
+  if (const char* e = getenv("VAENPVC_D0G_PLANES")) d0g_planes = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_TN_D0FIT")) tn_d0fit = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_E2_OSP")) e2_osp = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_DY2_PAD")) dy2_pad = atoi(e) != 0;
