@@ -154,6 +154,24 @@ def test_frame_step_is_repeatable_and_graph_capturable():
     torch.cuda.synchronize()
     d = (eng.params - p0).abs().max().item()
     assert d > 0 and (eng.params - p_eager).abs().max().item() <= 2e-3 * d + 1e-9
+    # K steps in ONE graph (Stepper.capture(steps=K): a graph launch's fixed cost shared by K steps): 2 replays of a 2-step graph on two
+    # different batches against the same four eager steps
+    x2 = torch.stack([xt, xt.flip(0)])
+    y2 = torch.stack([yt, yt.flip(0)])
+    eng.params.copy_(p0)
+    st3 = Stepper(eng, 1e-4, 0.5, 0.999, seed=5)
+    for i in range(4):
+        st3.step(x2[i & 1], y2[i & 1])
+    p_eager4 = eng.params.clone()
+    eng.params.copy_(p0)
+    st4 = Stepper(eng, 1e-4, 0.5, 0.999, seed=5)
+    st4.capture(x2, y2, steps=2)
+    for _ in range(2):
+        st4.replay()
+    torch.cuda.synchronize()
+    assert st4.step_count == 4
+    d4 = (p_eager4 - p0).abs().max().item()
+    assert d4 > 0 and (eng.params - p_eager4).abs().max().item() <= 2e-3 * d4 + 1e-9
 
 
 def test_another_speaker_count_runs_on_the_generic_kernels():

@@ -166,9 +166,13 @@ class Stepper(object):
         return self._loss_tail.clone() if loss3 is None else loss3.clone()
 
     # ------------------------------------------------------------------ hipGraph replay
-    def capture(self, x, y, eps=None):
+    def capture(self, x, y, eps=None, steps=1):
         """Capture one train step (forward + backward [+ all-reduce] + Adam, ~130 kernel launches) in a
         hipGraph on static copies of (x, y[, eps]); `replay()` then runs a step with one launch.
+        steps = K > 1: K CONSECUTIVE steps in one graph on K static batches (x [K, F, ...], y [K, F][, eps
+        [K, F, z]]): a graph launch has a fixed cost of its own (~10 us on this stack: at 16 / 256 frames a
+        one-step graph replays slower than the eager launches it replaces), K steps share it; `replay()` then
+        advances K steps and returns the losses of the last one.
         Launch overhead dominates below a few thousand frames per step (the reference trains with
         batch 16).  Without eps the sampler draws inside the graph, keyed by the DEVICE step counter, so
         every replay sees fresh noise.  With more than one rank the (single, unbucketed) gradient
@@ -177,17 +181,26 @@ class Stepper(object):
         batches into."""
         be = self.backend
         self._set_cb(False)
+        steps = int(steps)
+        if steps < 1:
+            raise ValueError('steps must be >= 1')
+        if steps > 1 and (x.shape[0] != steps or y.shape[0] != steps or (eps is not None and eps.shape[0] != steps)):
+            raise ValueError('capture(steps=%d): the leading dimension of x, y[, eps] is the step' % steps)
+        self._gsteps = steps
         self._gx, self._gy = x.clone(), y.clone()
         self._ge = eps.clone() if eps is not None else None
         self._d_step = torch.full((1,), self.step_count, dtype=torch.int64, device=be.params.device)
         snap = (be.params.clone(), self.m.clone(), self.v.clone())
 
-        def one_step():
+        def batch(t, i):
+            return t if steps == 1 else t[i]
+
+        def one_step(i=0):
             if self._ge is None:
-                l3 = be.train_fwd_bwd(self._gx, self._gy, None, self.grads, out=self._loss_tail, seed=self.seed,
+                l3 = be.train_fwd_bwd(batch(self._gx, i), batch(self._gy, i), None, self.grads, out=self._loss_tail, seed=self.seed,
                                       offset=0, d_offset=self._d_step)
             else:
-                l3 = be.train_fwd_bwd(self._gx, self._gy, self._ge, self.grads, out=self._loss_tail)
+                l3 = be.train_fwd_bwd(batch(self._gx, i), batch(self._gy, i), batch(self._ge, i), self.grads, out=self._loss_tail)
             if self.collective:
                 dist.all_reduce(self._gbuf, op=dist.ReduceOp.SUM, group=self.group)
             be.adam_step_dev(self.grads, self.m, self.v, self._d_step, self.lr, self.beta1, self.beta2, self.eps,
@@ -202,7 +215,8 @@ class Stepper(object):
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            self._gl3 = one_step()
+            for i in range(steps):
+                self._gl3 = one_step(i)
         be.params.copy_(snap[0])
         self.m.copy_(snap[1])
         self.v.copy_(snap[2])
@@ -210,10 +224,10 @@ class Stepper(object):
         return (self._gx, self._gy, self._ge) if self._ge is not None else (self._gx, self._gy)
 
     def replay(self):
-        """One captured step on the current contents of the static inputs; returns loss3 (with more than one
-        rank: the SUM over ranks -- use mean_losses())."""
+        """The captured step(s) on the current contents of the static inputs; returns loss3 of the last one (with more
+        than one rank: the SUM over ranks -- use mean_losses())."""
         self._graph.replay()
-        self.step_count += 1
+        self.step_count += getattr(self, '_gsteps', 1)
         return self._gl3
 
     def state_dict(self):
