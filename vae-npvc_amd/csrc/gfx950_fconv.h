@@ -568,12 +568,14 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (TAIL ? 2 : FcCfg<NP
 #pragma unroll
           for (int p = 0; p < NPL; ++p) fb[j][p] = *reinterpret_cast<const u32x4*>(xs + p * T::XPL + xoff[j] + ko);
         using PR = Prod<NPL>;
+        mfma_prio<8>(true);
 #pragma unroll
         for (int t = 0; t < PR::N; ++t)
 #pragma unroll
           for (int i = 0; i < T::MT; ++i)
 #pragma unroll
             for (int j = 0; j < T::NJ; ++j) acc[sidx][i][j] = mfma_bf16(fa[i][PR::A[t]], fb[j][PR::B[t]], acc[sidx][i][j]);
+        mfma_prio<8>(false);
       }
     }
     if (!VAENPVC_FC_DEFER) epilogue(f0, nf);

@@ -316,10 +316,12 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
 #pragma unroll
             for (int p = 0; p < NPL; ++p) fb[h][p] = *reinterpret_cast<const u32x4*>(xs + p * T::XPL + xoff[h] + ko);
           using PR = Prod<NPL>;
+          mfma_prio<4>(true);
 #pragma unroll
           for (int t = 0; t < PR::N; ++t)
 #pragma unroll
             for (int h = 0; h < CHN; ++h) acc[h] = mfma_bf16(wreg[ks][PR::A[t]], fb[h][PR::B[t]], acc[h]);
+          mfma_prio<4>(false);
         }
 #pragma unroll
         for (int h = 0; h < CHN; ++h) {

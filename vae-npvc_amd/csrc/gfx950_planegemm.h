@@ -673,12 +673,14 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
   };
   auto mm = [&](int set) __attribute__((always_inline)) {
     using PR = Prod<NPL>;
+    mfma_prio<1>(true);
 #pragma unroll
     for (int t = 0; t < PR::N; ++t)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[set][i][PR::A[t]], fb[set][j][PR::B[t]], acc[i][j]);
+    mfma_prio<1>(false);
   };
 #ifndef VAENPVC_NT_ABL
 #define VAENPVC_NT_ABL 0   // developer ablation (wrong results): 1 no global loads after the first chunk, 2 no MFMAs, 4 no result stores, 8 no LDS traffic
@@ -1812,12 +1814,14 @@ __global__ void __launch_bounds__(256, 2) k_cgemm(CgArgs a) {
   };
   auto mm = [&](int set) __attribute__((always_inline)) {
     using PR = Prod<NPL>;
+    mfma_prio<2>(true);
 #pragma unroll
     for (int t = 0; t < PR::N; ++t)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[set][i][PR::A[t]], fb[set][j][PR::B[t]], acc[i][j]);
+    mfma_prio<2>(false);
   };
   const int nch = a.Kp / T::BK;
   gload(0);
@@ -1996,12 +2000,14 @@ __global__ void __launch_bounds__(256, 2) k_cgemm_pf(CgArgs a, CgLnbArgs lb) {
   };
   auto mm = [&](int set) __attribute__((always_inline)) {
     using PR = Prod<NPL>;
+    mfma_prio<2>(true);
 #pragma unroll
     for (int t = 0; t < PR::N; ++t)
 #pragma unroll
       for (int i = 0; i < T::PH; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[set][i][PR::A[t]], fb[set][j][PR::B[t]], acc[i][j]);
+    mfma_prio<2>(false);
   };
   const int nch = a.Kp / T::BK;
   gload(0);
@@ -2245,12 +2251,14 @@ __global__ void __launch_bounds__(256, 2) k_cgemm_sf(CgSfArgs b) {
   };
   auto mm = [&](int set) __attribute__((always_inline)) {
     using PR = Prod<NPL>;
+    mfma_prio<2>(true);
 #pragma unroll
     for (int t = 0; t < PR::N; ++t)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(fa[set][i][PR::A[t]], fb[set][j][PR::B[t]], acc[i][j]);
+    mfma_prio<2>(false);
   };
   const int nch = a.Kp / T::BK;
   gload(0);

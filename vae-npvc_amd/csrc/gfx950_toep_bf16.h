@@ -50,6 +50,20 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// developer switch (variant libraries): waves raise their scheduling priority while they issue a cluster of MFMAs, so that on a SIMD shared by
+// two waves the one in its matrix phase is not interleaved with the other's address arithmetic.  Bits: 1 k_gemm_nt, 2 k_cgemm*, 4 k_fconv_r,
+// 8 k_fconv.  Measured in round 5: see DESIGN.md section 6.
+#ifndef VAENPVC_MFMA_PRIO
+#define VAENPVC_MFMA_PRIO 0
+#endif
+template <int BIT>
+__device__ __forceinline__ void mfma_prio(bool hi) {
+  if constexpr ((VAENPVC_MFMA_PRIO & BIT) != 0) {
+    if (hi) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+  }
+}
+
 // fp32 -> bf16, round to nearest even: v_cvt_pk_bf16_f32 converts TWO values in one instruction (the integer recipe
 // u += 0x7fff + ((u >> 16) & 1); u >>= 16 costs four; in the conversion-heavy fused kernels the VALU was the limit)
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
