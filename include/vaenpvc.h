@@ -121,7 +121,12 @@ int vaenpvc_param_info(const vaenpvc_ctx* ctx, int index, char* name, int name_c
  * scratch).  `vaenpvc_ws_find` exposes named regions (float offsets into d_ws) so
  * that tests can inspect every intermediate the reference graph would hold:
  *   enc_a<i>, enc_st<i>, z_mu, z_lv, z, eps, h, dec_a<i>, dec_st<i>, xh,
- *   kl_f, nll_f, d_enc_a<i>, d_z_mu, d_z_lv, d_z, d_h, d_dec_a<i>, d_xh        */
+ *   kl_f, nll_f, d_enc_a<i>, d_z_mu, d_z_lv, d_z, d_h, d_dec_a<i>, d_xh
+ * The forward regions are written at every batch size.  The gradient regions are the
+ * hand-over buffers of the backward pass: on the tuned path at >= 1024 frames several
+ * of them are never written because the gradient travels as bf16 operand planes
+ * (d_h, d_z_mu / d_z_lv, d_enc_a3 / d_enc_a4, d_dec_a0; regions pl_*, cl<i>) -- select
+ * the generic path (vaenpvc_set_impl) to inspect every one of them.               */
 int64_t vaenpvc_workspace_bytes(const vaenpvc_ctx* ctx, int64_t F, int mode);
 int vaenpvc_ws_find(const vaenpvc_ctx* ctx, int64_t F, int mode, const char* name,
                     int64_t* offset_floats, int64_t* count_floats);
