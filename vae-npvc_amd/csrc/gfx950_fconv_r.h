@@ -60,7 +60,7 @@ struct FrCfg {
   static constexpr int NCH = POS ? cdiv(H, 64) : 1;
   static constexpr int CG = POS ? CP : rup(cdiv(CP, 3), 8);   // channels a lane collects
   static constexpr int NIT = TF * NCH, IPW = cdiv(NIT, 4);
-  static_assert(KS * 16 <= V.Kp && (POS || (3 * H <= 64 && 3 * CG <= CPL + 8)), "site not served");
+  static_assert(KS * 16 <= V.Kp && (POS || (3 * H <= 64 && 3 * CG <= CPL + 8 && C > 2 * CG)), "site not served");
 };
 
 // weight planes with the rows of FrCfg: plain sites as cv_job; PERM: row = tile * 32 + phase * 8 + (channel % 8)
@@ -146,11 +146,17 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
 #pragma unroll
         for (int c = 0; c < T::CG; ++c) v[u][c] = (c < T::C && h < T::H && fok) ? sf[c * T::H + h] : 0.f;
       } else {
+        // every lane loads UNCONDITIONALLY, base pointer + compile-time offset, from a valid address of a valid frame and the store below
+        // zeroes what is not live: the channel slots past C of the last third are read one third lower (bpB), idle lanes read the first
+        // third.  As predicated loads (`c < C && ... ? sf[..] : 0`) every element became a branch of its own with its own 64-bit offset
+        // register pair, hoisted out of the group loop; in decoder layer 0's forward kernel twelve of those pairs were spilled and each came
+        // back with `s_waitcnt vmcnt(0)` in front of its load -- a full memory round trip per element, eleven per group (round 5)
+        constexpr int CL = T::C - 2 * T::CG;   // valid channel slots of the last third
+        const int g3 = pg_g < 3 ? pg_g : 0;
+        const float* bpA = sf + g3 * (T::CG * T::H) + pg_p;
+        const float* bpB = g3 == 2 ? bpA - T::CG * T::H : bpA;
 #pragma unroll
-        for (int cc = 0; cc < T::CG; ++cc) {
-          const int c = pg_g * T::CG + cc;
-          v[u][cc] = (c < T::C && pg_g < 3 && fok) ? sf[c * T::H + pg_p] : 0.f;
-        }
+        for (int cc = 0; cc < T::CG; ++cc) v[u][cc] = (cc < CL ? bpA : bpB)[cc * T::H];
       }
     }
   };
@@ -204,6 +210,11 @@ __global__ void __launch_bounds__(256, 2) k_fconv_r(FcArgs a) {
           const int c = cbase + cc;
           if (c < T::C) v[u][cc] = lnact_v(v[u][cc], mean[u], rstd[u], lnp[0][c], lnp[1][c]);
         }
+      }
+      if constexpr (!T::POS) {   // (the clamped loads above left copies in the channel slots past C)
+#pragma unroll
+        for (int cc = 0; cc < T::CG; ++cc)
+          if (cbase + cc >= T::C) v[u][cc] = 0.f;
       }
       unsigned short* dx = xs + fl * T::FS + (T::HLO + h) * T::CPL + cbase;
 #pragma unroll
