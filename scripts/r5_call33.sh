@@ -1,0 +1,13 @@
+#!/bin/bash
+# loss kernel with the next frame requested ahead of the stores: parity (loss / d(xh) consumers), then same-box A/B against variants/old
+set -u
+OUT=gpurun_out/r5c33; mkdir -p $OUT
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu --timeout 600 -k "fixture or ragged_large or merge_gradient or decoder_tail or gradients" > $OUT/pytest.log 2>&1
+echo "pytest rc=$?" >> $OUT/pytest.log; tail -3 $OUT/pytest.log
+T="loss,dxh_post,dec3_wgrad,dec3_dgrad,dec2_stats_planes,dec3_fwd"
+for i in 1 2; do
+  VAENPVC_LIB=variants/old/libvaenpvc_hip.so python scripts/site_times.py --tags $T > $OUT/old_$i.txt 2>&1
+  python scripts/site_times.py --tags $T > $OUT/new_$i.txt 2>&1
+done
+python scripts/cmp_sites.py $OUT/old_1.txt $OUT/new_1.txt $OUT/old_2.txt $OUT/new_2.txt
+bash scripts/ab_libs.sh 3 old default | tee $OUT/ab.txt
