@@ -196,11 +196,9 @@ __global__ void __launch_bounds__(256, fb_occ(L, LNB2)) k_fbwd(FbArgs a) {
         if constexpr ((WHICH & 1) != 0) vd[u][c] = (VAENPVC_FB_ABL & 8) ? 0.5f : act_ld<BFG>(a.dy, fd + c * PD);
         if constexpr ((WHICH & 2) != 0) va[u][c] = (VAENPVC_FB_ABL & 8) ? 0.25f : act_ld<BFG>(a.a, fo + c * PG);
       }
-#pragma unroll
-      for (int c = 0; c < CUG; ++c) {
-        if constexpr ((WHICH & 1) != 0) vd[u][c] = ok ? vd[u][c] : 0.f;
-        if constexpr ((WHICH & 2) != 0) va[u][c] = ok ? va[u][c] : mean;
-      }
+      // (no fill of the idle lanes HERE: a select on a register a load is still writing waits for that load -- and, through `mean`, for the
+      //  statistics -- in the middle of the request sequence: `s_waitcnt vmcnt(0)` between the loads of every wave that holds a tail item
+      //  (bin 512: lane 0 alone), once per group.  upass1 masks the idle lanes when it consumes the values.)
     }
   };
   // LayerNorm + lrelu backward, first half: dn = dy lrelu'(n), xhat, and the frame's two sums (partials per item)
@@ -208,12 +206,13 @@ __global__ void __launch_bounds__(256, fb_occ(L, LNB2)) k_fbwd(FbArgs a) {
 #pragma unroll
     for (int u = 0; u < IPWG; ++u) {
       const int it = wave + 4 * u;
+      const bool ok = it < NITG && 64 * (it / CGR) + lane < HG;   // (idle lanes hold the values of a clamped address: xhat = 0, dn = 0 for them)
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int c = 0; c < CUG; ++c) {
-        const float xh = (va[u][c] - mean) * rstd;
+        const float xh = ok ? (va[u][c] - mean) * rstd : 0.f;
         const float nn = xh * gam[c] + bet[c];
-        const float dn = vd[u][c] * (nn >= 0.f ? 1.0f : LEAK);
+        const float dn = ok ? vd[u][c] * (nn >= 0.f ? 1.0f : LEAK) : 0.f;
         const float dxh = dn * gam[c];
         s1 += dxh;
         s2 += dxh * xh;
