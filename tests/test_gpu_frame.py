@@ -208,6 +208,14 @@ TRAJ_DRIFT_TOL = 1e-2     # loss of step t against the float64 RUN: second order
                           # sign-like update makes first order in the rounding error of small gradient entries -- measured
                           # 1e-6 (frame kernels, 3e-7 gradient error), 1.5e-3 (the bitwise-repeatable generic kernels, 3e-6),
                           # 1.7e-3 (layered kernels): profiles/r04_soak_noise_floor.txt.  NOT a parity bar.
+TRAJ_OWN_SCALE_BAR = 2.5e-4   # layered-bf16x2 only: error of a non-additive gradient tensor on its OWN largest entry (see the test)
+
+
+def ADDITIVE(name):
+    """the additive parameters (their gradient is a plain sum of the upstream gradient): biases and LayerNorm offsets"""
+    return (name,) if (name.endswith('bias') or name.endswith('biases') or name.endswith('.offset')) else ()
+
+
 TRAJ_REPEAT_TOL = 1e-5    # 30 evaluations on identical parameters (atomic ordering: measured 2.5e-7 / 4.9e-7); a race shows here
 
 
@@ -279,8 +287,9 @@ def test_twenty_adam_steps_follow_the_float64_oracle(path):
     report('trajectory %s repeatability of one evaluation (30 calls)' % path, rep, TRAJ_REPEAT_TOL)
     assert rep <= TRAJ_REPEAT_TOL, (path, rep)
     fails, got = [], []
-    e_grad = e_loss = e_own = 0.0
+    e_grad = e_loss = e_own = e_tensor = 0.0
     worst = ''
+    own_w = {}      # layered-bf16x2: worst own-scale error of every NON-additive tensor (kernels, dense / merge weights, embedding, LN scales)
     plain = {}      # worst error per tensor measured on its own largest entry (the weight tensors, and everything on the other paths)
     for t in range(TRAJ_STEPS):
         P = O.unflatten_params(arch, eng.params.cpu().numpy())
@@ -299,9 +308,16 @@ def test_twenty_adam_steps_follow_the_float64_oracle(path):
                 assert abs(scale - float(S[name].ravel()[0])) <= 1e-9 * scale     # the same scale, from the autograd tape
                 e = abs(float(g[off]) - float(G[name].ravel()[0])) / scale
             elif sum_scaled and name in S:
+                # ENTRY BY ENTRY (round 6, advisor): |g - G|[i] against S[i], the sum of magnitudes of the terms of THAT entry -- the
+                # bound the docstring derives is per entry; dividing by max(S) let a wrong small-scale channel or tap hide behind
+                # the tensor's largest one.  An entry without terms (a speaker absent from the batch) has S = g = G = 0.
                 d = np.abs(g[off:off + n].reshape(shape) - G[name])
-                e = float(d.max() / S[name].max())
-                e_own = max(e_own, rel_err(g[off:off + n].reshape(shape), G[name]))
+                e = float((d / np.maximum(S[name], 1e-30)).max())
+                e_tensor = max(e_tensor, float(d.max() / S[name].max()))
+                own = rel_err(g[off:off + n].reshape(shape), G[name])
+                e_own = max(e_own, own)
+                if name not in ADDITIVE(name):
+                    own_w[name] = max(own_w.get(name, 0.0), own)
             else:
                 e = rel_err(g[off:off + n].reshape(shape), G[name])
                 plain[name] = max(plain.get(name, 0.0), e)
@@ -312,7 +328,16 @@ def test_twenty_adam_steps_follow_the_float64_oracle(path):
     report('trajectory %s per-step loss3 at the GPU parameters (20 steps)' % path, e_loss, TOL_ACT)
     report('trajectory %s per-step worst gradient tensor (20 steps; %s)' % (path, worst), e_grad, TOL_GRAD)
     if sum_scaled:
+        report('trajectory %s worst tensor as max|g - G| / max(S) (the round-5 form of the bar; reported)' % path, e_tensor, float('inf'))
         report('trajectory %s all 44 tensors on their OWN largest entry (reported, not a bar)' % path, e_own, float('inf'))
+        # round 6: the own-scale error of the non-additive tensors may not drift silently -- measured 0.8e-4 - 1.7e-4 over the
+        # runs of round 5 (LayerNorm scales lead); the additive ones (biases, LayerNorm offsets: pure sums of the upstream
+        # gradient, up to 3.6e-4 on their own scale once the fit has cancelled them) stay on S alone
+        for name, e in sorted(own_w.items(), key=lambda kv: -kv[1])[:3]:
+            report('trajectory %s   own-scale error, non-additive tensors: %s' % (path, name), e, TRAJ_OWN_SCALE_BAR)
+        for name, e in own_w.items():
+            if not e <= TRAJ_OWN_SCALE_BAR:
+                fails.append('own-scale error of %s: %.3e > %.1e' % (name, e, TRAJ_OWN_SCALE_BAR))
     for name, e in sorted(plain.items(), key=lambda kv: -kv[1])[:3]:
         report('trajectory %s   largest plain-bar tensors: %s' % (path, name), e, TOL_GRAD)
     got = np.array(got)

@@ -613,8 +613,9 @@ UNFILTERED_SHARE_SLACK = 2e-4     # share of the ~53 k sampled entries a path ma
 # evaluation of the SAME batch: measured worst tensor 3.1e-4 (the speaker embedding; fp32 CPU restatement 5.5e-5), 9 of
 # 52 850 sampled entries above 2e-4, median 3.2e-6.  Stated, not hidden: the fp32-exact mode (bf16x3) is held to the
 # float32 restatement's own numbers.
-UNFILTERED_X2_TENSOR_BAR = 3e-4   # round 5: was 5e-4; measured 2.5e-4 (y_emb) on the round-4 gate boxes
-UNFILTERED_X2_SHARE_BAR = 5e-4
+UNFILTERED_X2_TENSOR_BAR = 3e-4   # round 5: was 5e-4; measured 2.2e-4 (y_emb; which term carries it: DESIGN.md section 5, measured by
+                                  # test_kink_flips_explain_the_unfiltered_gradient_excess -- the flips, not the operand rounding)
+UNFILTERED_X2_SHARE_BAR = 2.5e-4  # round 6: was 5e-4; measured 1.3e-4
 
 
 @pytest.mark.parametrize('precision', ['bf16x3', 'bf16x2'])
@@ -713,8 +714,11 @@ def test_unfiltered_benchmark_batch_statistics(precision):
 
 # lrelu units (LayerNorm outputs) that may land on the other side of the kink than in float64, per evaluated unit: a unit flips
 # when |n| is below the evaluation's own error in n (~1e-6 for fp32-exact operands, ~1e-5 for 16-mantissa-bit operand pairs;
-# n ~ N(0,1): density 0.4 at 0).  Stated bounds, ~4x the expectation:
-KINK_FLIP_RATE_BAR = {'bf16x3': 4e-6, 'bf16x2': 4e-5}
+# n ~ N(0,1): density 0.4 at 0).  Round 6: the bars sit ~2.5-3x above what was MEASURED at 32 768 frames (78 flips of 5.3e8 units =
+# 1.5e-7 with 3-term operands, 1 302 = 2.5e-6 with the default 2 terms; they were 4e-6 / 4e-5, 16x the measurement).  The 2 048-frame
+# mechanism test counts ~6 / ~95 flips of 3.8e7 units at the same rates: its bar allows for the Poisson spread of such a small count.
+KINK_FLIP_RATE_BAR = {'bf16x3': 5e-7, 'bf16x2': 6e-6}
+KINK_FLIP_RATE_BAR_F2048 = {'bf16x3': 1e-6, 'bf16x2': 8e-6}
 
 
 @pytest.mark.parametrize('precision', ['bf16x3', 'bf16x2'])
@@ -759,8 +763,8 @@ def test_kink_flips_explain_the_unfiltered_gradient_excess(precision):
             flips += int(fl.sum())
             units += n.size
     rate = flips / units
-    report(tag + 'flip rate (%d of %d units)' % (flips, units), rate, KINK_FLIP_RATE_BAR[precision])
-    if rate > KINK_FLIP_RATE_BAR[precision]:
+    report(tag + 'flip rate (%d of %d units)' % (flips, units), rate, KINK_FLIP_RATE_BAR_F2048[precision])
+    if rate > KINK_FLIP_RATE_BAR_F2048[precision]:
         fails.append('flip rate %.2e' % rate)
     _, Gp = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64, kink=br)
     _, Gr = O.torch_loss_and_grads(arch, P, x, y, eps, torch.float64)
@@ -770,6 +774,11 @@ def test_kink_flips_explain_the_unfiltered_gradient_excess(precision):
         got = g[off:off + n].reshape(shape)
         check(tag + 'pinned grad ' + name, got, Gp[name], TOL_GRAD, fails)
         worst_raw = max(worst_raw, rel_err(got, Gr[name]))
+        if name == 'y_embedding/y_emb':
+            # the tensor that leads the unfiltered 32 768-frame comparison (2.2e-4 with 2-term operands): the split of its error into
+            # operand rounding (flips pinned) and kink flips (the rest of the unpinned figure), measured -- DESIGN.md section 5
+            report(tag + 'y_emb: operand rounding alone (flips pinned; reported)', rel_err(got, Gp[name]), float('inf'))
+            report(tag + 'y_emb: with the flips (unpinned; reported)', rel_err(got, Gr[name]), float('inf'))
     report(tag + 'UNPINNED worst gradient tensor (reported, not a bar)', worst_raw, float('inf'))
     assert not fails, '\n'.join(fails)
 

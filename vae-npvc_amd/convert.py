@@ -34,7 +34,10 @@ def parse_args(argv=None):
     p.add_argument('--file_pattern', default='./dataset/vcc2016/bin/Testing Set/{}/*.bin', help='file pattern')
     p.add_argument('--batch_frames', type=int, default=16384,
                    help='(not in the reference) frames gathered from consecutive utterances into one device launch; '
-                        '0 = one launch per utterance, like the reference\'s sess.run per file')
+                        '0 = REFERENCE-PARITY mode: one launch per utterance, like the reference\'s sess.run per file -- an '
+                        'utterance of <= 512 frames then runs on the fp32-exact whole-frame kernels and its output does not '
+                        'depend on its neighbours in the glob order.  The default gathers files onto the large-batch kernels '
+                        '(2-term bf16 operands: within the 1e-4 relative parity bar, not bit-reproducible per file)')
     args = p.parse_args(argv)
     if args.model is None:                                               # convert.py:23-27
         raise ValueError('\n  You MUST specify `model`.'

@@ -579,10 +579,19 @@ __global__ void __launch_bounds__(256, fb_occ(L, LNB2)) k_fbwd(FbArgs a) {
   }
 }
 
+// the grid launch_fbwd uses: also the number of rows of per-workgroup parts the LNB2 form leaves in `part0`, so the
+// reduce kernel behind it must be given THIS number (round-5 advisor: the caller had its own copy of the formula)
+template <int NPL, int L>
+static unsigned fbwd_grid(int64_t F) {
+  using T = FbCfg<NPL, L>;
+  return (unsigned)cmin_((int)F, T::LDS > 78 * 1024 ? 256 : (fb_occ(L, false) == 3 && 3 * T::LDS <= 156 * 1024) ? 768 : 512);
+}
+static unsigned fbwd_grid_d1(int npl, int64_t F) { return npl == 1 ? fbwd_grid<1, FB_D1>(F) : fbwd_grid<2, FB_D1>(F); }
+
 template <int NPL, int L>
 static void launch_fbwd(const FbArgs& a, hipStream_t s) {
   using T = FbCfg<NPL, L>;
-  const unsigned grid = (unsigned)cmin_(a.F, T::LDS > 78 * 1024 ? 256 : (fb_occ(L, false) == 3 && 3 * T::LDS <= 156 * 1024) ? 768 : 512);
+  const unsigned grid = fbwd_grid<NPL, L>(a.F);
   if constexpr (NPL == 1 && (L == FB_D2 || L == FB_D1)) {
     if (a.bf16_act) {   // bf16 activation storage: layer 2 reads and writes bf16 throughout, layer 1 reads (dy, a) as bf16
       constexpr int BFM = L == FB_D2 ? 7 : 1;

@@ -1219,7 +1219,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
     float* dy0 = dy_cur == w.dy_tmp ? w.d_dec_a[1] : w.dy_tmp;
     // (round 5) decoder layer 0's LayerNorm backward inside layer 1's kernel: planes of d(a0) straight from the tile, no d(y0) in HBM
     if (rt().fb_lnb2 && gd0_only_planes && dense_planes_now() <= 2 && !abf) {
-      const int nwg = (int)cmin_((int64_t)F, (int64_t)512);
+      const int nwg = (int)fbwd_grid_d1(dense_planes_now(), F);   // rows of parts = the grid the kernel is launched with
       fused_bwd(FB_D1, 1, dy_cur, dy0, "dec1_bwd", us(w.cl[CL_GD0]), cl_plane(CL_GD0, F), w.scratch + Pk::lnpart);
       VAENPVC_TIMED("lnb_dec0", s, hipLaunchKernelGGL(k_ln_bwd_reduce, dim3(3 * 32), dim3(256), 0, s, w.scratch + Pk::lnpart, nwg, 32,
                                                        G + pl.gamma_off, G + pl.beta_off, G + pl.b_off));

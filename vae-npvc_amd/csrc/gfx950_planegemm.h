@@ -585,9 +585,12 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nwg) {
 #define VAENPVC_NT_BK2 64
 #endif
 constexpr int nt_bk(int npl) { return npl >= 3 ? 32 : VAENPVC_NT_BK2; }
-// the result tile goes through LDS on its way out (round 5, two planes and more): [128][NT_EP_PITCH] floats behind the speaker table
+// the result tile goes through LDS on its way out (round 5, EVERY plane count): [128][NT_EP_PITCH] floats behind the speaker table
 constexpr int NT_EP_PITCH = NT_BN + 4, NT_EP_OFF = NT_MAXRB * 128 * 4 + 128 * 4, NT_EP_LDS = NT_EP_OFF + NT_BM * NT_EP_PITCH * 4;   // 76 288 bytes
-constexpr bool nt_lep(int npl) { return npl >= 1; }   // (one plane: 36 KB of staging fit three workgroups per CU, the tile leaves two: measured)
+// One plane INCLUDED on purpose: its 36 KB of staging alone would fit three workgroups per CU and the 76 KB tile leaves two, and the
+// tile still won the A/B (bf16 mode 4.46 -> 4.39 ms per step with VAENPVC_NT_LEP, DESIGN.md section 6 round 5: these sites are bound by
+// their store instructions, not by the third workgroup).
+constexpr bool nt_lep(int npl) { return npl >= 1; }
 constexpr int nt_lds(int npl) {
   const int st = npl * (NT_BM + NT_BN) * (nt_bk(npl) * 2 + 16);  // 73 728 (2 planes) / 61 440 (3)
   return nt_lep(npl) && NT_EP_LDS > st ? NT_EP_LDS : st;
@@ -860,7 +863,8 @@ inline void launch_gemm_nt(const NtArgs& a_, hipStream_t s) {
   }
   const int ntiles = cdiv(a.M, NT_BM) * cdiv(a.N, NT_BN);
   constexpr int SLOTS = 256 * VAENPVC_NT_WPS;     // resident workgroups of the chip
-  // (one plane: the one-tile kernel fits three workgroups per CU at 138 registers, the persistent one two at 194: not used)
+  // (one plane: the one-tile kernel runs two workgroups per CU -- its LDS result tile, see nt_lep -- at 138 registers; the persistent form
+  //  needs 194 and was only measured with two planes and more: not used)
   if (NPL >= 2 && rt().nt_persist > 0 && ntiles >= rt().nt_persist) {   // (Runtime::nt_persist, env VAENPVC_NT_PERSIST)
     rt().ensure_lds(reinterpret_cast<const void*>(&k_gemm_nt<NPL, true>), nt_lds(NPL));
     hipLaunchKernelGGL((k_gemm_nt<NPL, true>), dim3(SLOTS), dim3(256), nt_lds(NPL), s, a);

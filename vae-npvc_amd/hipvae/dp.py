@@ -186,6 +186,12 @@ class Stepper(object):
             raise ValueError('steps must be >= 1')
         if steps > 1 and (x.shape[0] != steps or y.shape[0] != steps or (eps is not None and eps.shape[0] != steps)):
             raise ValueError('capture(steps=%d): the leading dimension of x, y[, eps] is the step' % steps)
+        if steps == 1 and y.dim() == 2:
+            # a stacked [1, F, ...] input (the K-step calling convention with K = 1): take the one batch, never pass the extra
+            # dimension through -- the library would read F = 1 from it
+            if y.shape[0] != 1 or x.shape[0] != 1 or (eps is not None and eps.shape[0] != 1):
+                raise ValueError('capture(steps=1): x, y[, eps] carry a leading step dimension of %d' % y.shape[0])
+            x, y, eps = x[0], y[0], (eps[0] if eps is not None else None)
         self._gsteps = steps
         self._gx, self._gy = x.clone(), y.clone()
         self._ge = eps.clone() if eps is not None else None
