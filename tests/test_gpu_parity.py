@@ -466,6 +466,39 @@ def test_decoder_tail_in_the_forward_epilogue(monkeypatch):
     assert not fails, '\n'.join(fails)
 
 
+@pytest.mark.parametrize('precision', ['bf16x2'])
+@pytest.mark.parametrize('F,seed', [(37, 7), (257, 12), (1027, 7)])
+def test_layernorm_on_load_in_the_tap_layer_forward(F, seed, precision, monkeypatch):
+    """Round 6: no pass between decoder layer 2 and the 1025-tap layer.  Decoder layer 2's forward kernel leaves the LayerNorm statistics of its
+    result (k_fconv<..., OST>: per-wave (count, sum, centred squares) combined by Chan's formula), the 1025-tap forward kernel stages the fp32
+    tensor itself -- LayerNorm + lrelu + operand split on the way into LDS -- and also emits the weight-gradient kernel's operand planes, output
+    column 512 and bin 512 of the activated tensor (k_toep_gemm_bf16<..., LNA>).  Default from 16 384 frames per step on (one channel group per
+    frame tile); forced here with VAENPVC_D2_LNA=2 at ragged batches (last frame tile with 37 / 1 / 3 frames, last 2-frame group with one frame):
+    every tensor and gradient against the float64 oracle, and the separate pass must not have run.  (Two operand planes and fewer: the kernel
+    keeps two A tiles in LDS, three planes do not fit; the bf16 mode runs it by default in the 32 768-frame fixture test.)"""
+    monkeypatch.setenv('VAENPVC_D2_LNA', '2')
+    eng = make_engine('vcc', 'auto', FUSED_CONV if F < 1024 else (0xffffffff, 0xffffffff), precision=precision)
+    eng.timer_select('dec2_stats_planes')
+    fails = compare_everything(eng, F, seed, 'd2_lna %s F%d ' % (precision, F))
+    _, n = eng.timer_read()
+    eng.timer_select(None)
+    assert n == 0, 'the separate statistics / planes pass still ran'
+    assert not fails, '\n'.join(fails)
+
+
+def test_the_separate_plane_producer_pass_still_serves(monkeypatch):
+    """VAENPVC_D2_LNA=0: the round-5 form (k_ln_stats_act_planes between decoder layer 2 and the 1025-tap layer) stays the A/B partner and the
+    path of the batch sizes with several channel groups per frame tile: same comparison at a ragged large batch."""
+    monkeypatch.setenv('VAENPVC_D2_LNA', '0')
+    eng = make_engine('vcc', 'auto')
+    eng.timer_select('dec2_stats_planes')
+    fails = compare_everything(eng, 1027, 7, 'd2_lna=0 F1027 ')
+    _, n = eng.timer_read()
+    eng.timer_select(None)
+    assert n == 1, 'the separate statistics / planes pass did not run'
+    assert not fails, '\n'.join(fails)
+
+
 @pytest.mark.parametrize('planes_out', ['1', '0'])
 def test_merge_gradient_operand_from_the_layer_above(monkeypatch, planes_out):
     """Decoder layer 0's input-gradient kernel writes d(h) as the bf16 operand planes of the two merge GEMMs itself (k_fconv_r<..., POUT>,
@@ -532,7 +565,22 @@ def test_fused_layer_backward_against_oracle(F, seed, layers, monkeypatch):
     assert not fails, '\n'.join(fails)
 
 
-@pytest.mark.parametrize('precision', ['bf16x2', 'bf16'])
+@pytest.mark.parametrize('F,seed', [(37, 5), (257, 12), (600, 13)])
+def test_fused_layer_backward_three_planes(F, seed, monkeypatch):
+    """Round 6: the one-kernel backward step of the three thin layers with THREE operand planes (precision bf16x3, the fp32-exact mode
+    that bench.py reports as reference_precision_value; until round 5 that mode fell back to the three-kernel form per layer, 2.2 ms
+    of its step).  Same kernels, same bars; the plain 1e-4 / 2e-4 comparison against float64."""
+    monkeypatch.setenv('VAENPVC_FB_LAYERS', '7')
+    eng = make_engine('vcc', 'auto', FUSED_BWD, precision='bf16x3')
+    eng.timer_select('dec2_bwd,dec1_bwd,enc1_bwd')
+    fails = compare_everything(eng, F, seed, 'fused-bwd bf16x3 F%d ' % F)
+    _, n = eng.timer_read()
+    eng.timer_select(None)
+    assert n == 3, 'the fused backward kernels did not run'
+    assert not fails, '\n'.join(fails)
+
+
+@pytest.mark.parametrize('precision', ['bf16x2', 'bf16x3', 'bf16'])
 def test_default_selection_at_a_ragged_large_batch(precision):
     """The DEFAULT kernel selection just above its thresholds, at a batch size that is a multiple of nothing the kernels
     tile by (1027 frames: last frame groups of 3, 1 and 7 frames for the fused kernels' groups of 4, 2 and 8; 128-row

@@ -137,6 +137,9 @@ struct FbArgs {
 #define VAENPVC_FB_OCC3 0   // bit l: layer FB_* l compiled for three workgroups per CU (168 registers).  Measured (round 5): decoder layer 2 spills 22 registers
                             // there and runs 453 -> 488 us; the other two layers do not fit three workgroups in LDS
 #endif
+#ifndef VAENPVC_FB_MAXPL
+#define VAENPVC_FB_MAXPL 3   // operand planes the fused layer-backward kernels serve (round 6: the fp32-exact 3-term mode as well; 2 = rounds 4-5)
+#endif
 constexpr int fb_occ(int l, bool lnb2) { return (!lnb2 && ((VAENPVC_FB_OCC3 >> l) & 1)) ? 3 : 2; }
 template <int NPL, int L, int BFM = 0, int DYP = 0, bool LNB2 = false>
 __global__ void __launch_bounds__(256, fb_occ(L, LNB2)) k_fbwd(FbArgs a) {
@@ -619,7 +622,7 @@ static void launch_fbwd(const FbArgs& a, hipStream_t s) {
 }
 template <int NPL>
 static bool fbwd(int layer, const FbArgs& a, hipStream_t s) {
-  if constexpr (NPL <= 2) {
+  if constexpr (NPL <= VAENPVC_FB_MAXPL) {
     switch (layer) {
       case FB_D2: launch_fbwd<NPL, FB_D2>(a, s); return true;
       case FB_D1: launch_fbwd<NPL, FB_D1>(a, s); return true;

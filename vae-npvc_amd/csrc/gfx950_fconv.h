@@ -123,10 +123,18 @@ __device__ __forceinline__ int fc_koff(int ks, int lh) {
 // tensor as fp32, and output column 512 of the 1025-tap layer (a dot product of the activated frame with the reversed taps).  Two workgroups per
 // CU (the image does not fit beside three), up to 256 registers.
 constexpr int fc_tail_img_bytes(int npl, int tf) { return tf * npl * TB_C * TB_KP * 2; }
-template <int NPL, int SITE, int LN, bool BIN = false, bool BOUT = false, bool TAIL = false>
+// OST (round 6, decoder layer 2 forward only): the LayerNorm statistics of the RESULT (mean, rstd per frame -> st2_out) are taken from the
+// accumulators in the deferred epilogue and NOTHING else of the tail: per wave and frame the triple (count, sum, centred square sum about the
+// wave's own mean) by wave reductions, the four triples of a frame combined behind the barrier the loop has anyway (Chan's formula: two-pass
+// quality without a second barrier).  No LDS image, no third workgroup lost (the TAIL variant's cost): with the statistics known the
+// 1025-tap layer's forward kernel normalises the fp32 tensor while it stages it (k_toep_gemm_bf16<..., LNA>) and the pass in between
+// (k_ln_stats_act_planes: 237 us, a re-read of the 0.54 GB tensor + 0.55 GB of planes written) is gone.
+template <int NPL, int SITE, int LN, bool BIN = false, bool BOUT = false, bool TAIL = false, bool OST = false>
 __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (TAIL ? 2 : FcCfg<NPL, SITE>::OCC)) k_fconv(FcArgs a) {
   using T = FcCfg<NPL, SITE>;
   constexpr CvSite V = T::V;
+  static_assert(!OST || (!TAIL && SITE == CV_D2F && !BOUT && V.PH && V.mdiv == 8 && T::NJ == 1 && T::MT == 1 && T::TF == 2 && T::NWV == 4 && VAENPVC_FC_DEFER),
+                "result statistics: decoder layer 2 forward on 2-frame groups, fp32 output, deferred epilogue");
   static_assert(!TAIL || (SITE == CV_D2F && !BIN && !BOUT && V.PH && V.O == TB_C && V.OH == TB_H && T::NJ == 1 && T::MT == 1 && VAENPVC_FC_DEFER),
                 "decoder tail: decoder layer 2 forward, fp32 storage, deferred epilogue");
   extern __shared__ __attribute__((aligned(16))) unsigned short fsm[];
@@ -521,6 +529,80 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (TAIL ? 2 : FcCfg<NP
 #undef FC_TAIL_VAL
    }
   };
+  // ---- OST: statistics of the group's result frames from the accumulators (+ bias), see the comment above the kernel
+  auto ost_stats = [&](int nf) __attribute__((always_inline)) {
+   if constexpr (OST) {
+    // ONE pass over the accumulators: sums of (x - K) and (x - K)^2 about a pivot K taken from the data (this wave's first value), so the
+    // centred square sum M2 = Q - S^2 / n loses nothing to the frame's mean; counts from ballots (scalar registers).  Few live registers and
+    // few instructions on purpose: the kernel is compiled for three workgroups per CU (168 registers) with the next group's staged loads live
+    // here, and it is bound by memory operations in flight -- serial vector work per group delays the next group's requests (the first,
+    // two-pass version of this: dec2_fwd 204 -> 241 us).
+    const int nrows = nf * V.R;
+    const float K = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[0][0][0][0] + bv[0])));
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    int c0 = 0, c1 = 0;
+#pragma unroll
+    for (int sidx = 0; sidx < NSW; ++sidx) {
+      const int n = (wave + NWV * sidx) * T::SROWS + l31;
+      const int nn = n < nrows ? n : 0;
+      const int fl = nn / V.R;
+      const int pbase = n < nrows ? (nn - fl * V.R) * V.oq + V.o0 : -8;    // rows past the group: every position out of range
+#pragma unroll
+      for (int p3 = 0; p3 < 3; ++p3) {
+        const bool lv = pbase + p3 >= 0 && pbase + p3 < V.OH;
+        float t = 0.f, u = 0.f;
+#pragma unroll
+        for (int cs = 0; cs < 4; ++cs) {
+          const float d = (acc[sidx][0][0][cs + 4 * p3] + bv[cs]) - K;
+          t += d;
+          u = fmaf(d, d, u);
+        }
+        const bool a0 = lv && fl == 0, a1 = lv && fl == 1;
+        s0 += a0 ? t : 0.f;
+        q0 += a0 ? u : 0.f;
+        s1 += a1 ? t : 0.f;
+        q1 += a1 ? u : 0.f;
+        c0 += 4 * __builtin_popcountll(__ballot(a0));
+        c1 += 4 * __builtin_popcountll(__ballot(a1));
+      }
+    }
+    s0 = wave_sum(s0);
+    q0 = wave_sum(q0);
+    s1 = wave_sum(s1);
+    q1 = wave_sum(q1);
+    if (lane == 0) {
+      const float n0 = (float)(c0 > 0 ? c0 : 1), n1 = (float)(c1 > 0 ? c1 : 1);
+      tpart[0][wave][0] = (float)c0;
+      tpart[0][wave][1] = (float)c1;
+      tpart[1][wave][0] = K + s0 / n0;          // the wave's mean
+      tpart[1][wave][1] = K + s1 / n1;
+      tpart[2][wave][0] = q0 - s0 * s0 / n0;    // centred square sum about it
+      tpart[2][wave][1] = q1 - s1 * s1 / n1;
+    }
+   }
+  };
+  // ... combined behind the next barrier by one thread per frame (Chan): n = sum n_w, mean = sum n_w m_w / n, M2 = sum (M2_w + n_w (m_w - mean)^2)
+  auto ost_combine = [&](int f0, int nf) __attribute__((always_inline)) {
+   if constexpr (OST) {
+    if (tid < nf) {
+      float n = 0.f, sm = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) {
+        n += tpart[0][w4][tid];
+        sm += tpart[0][w4][tid] * tpart[1][w4][tid];
+      }
+      const float mean = sm / n;
+      float m2 = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) {
+        const float d = tpart[1][w4][tid] - mean;
+        m2 += tpart[2][w4][tid] + tpart[0][w4][tid] * d * d;
+      }
+      a.st2_out[2 * (f0 + tid)] = mean;
+      a.st2_out[2 * (f0 + tid) + 1] = 1.0f / sqrtf(m2 / n + LN_EPS);
+    }
+   }
+  };
   int pf0 = -1, pnf = 0;   // the group whose results are still in the accumulators
   for (; g < ngroups; g += gridDim.x) {
     const int f0 = g * T::TF, nf = min(T::TF, a.F - f0);
@@ -532,10 +614,14 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (TAIL ? 2 : FcCfg<NP
 #pragma unroll
         for (int c = 0; c < T::CP; ++c) asm volatile("" ::"v"(v[u][c]));
       if constexpr (TAIL) epilogue_tail(pf0, pnf);
-      else epilogue(pf0, pnf);
+      else {
+        ost_stats(pnf);
+        epilogue(pf0, pnf);
+      }
     }
     fstore(g);
     __syncthreads();   // the group's frames are in LDS
+    if (OST && pf0 >= 0) ost_combine(pf0, pnf);   // (the next triples are written behind the barrier at the end of this iteration)
     if (g + (int)gridDim.x < ngroups) fload(g + gridDim.x);
     // ---- GEMM rows n = fl * R + q, SROWS per step, steps dealt round-robin to the waves
     const int nrows = nf * V.R, nsteps = cdiv(nrows, T::SROWS);
@@ -586,7 +672,14 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (TAIL ? 2 : FcCfg<NP
   if constexpr (TAIL) {
     if (pf0 >= 0) epilogue_tail(pf0, pnf);
   } else {
-    if (VAENPVC_FC_DEFER && pf0 >= 0) epilogue(pf0, pnf);
+    if (VAENPVC_FC_DEFER && pf0 >= 0) {
+      ost_stats(pnf);
+      epilogue(pf0, pnf);
+      if constexpr (OST) {
+        __syncthreads();
+        ost_combine(pf0, pnf);
+      }
+    }
   }
 }
 
@@ -608,6 +701,13 @@ static void launch_fconv(const FcArgs& a, hipStream_t s) {
       const unsigned gridt = (unsigned)cmin_(cdiv(a.F, T::TF), 512);
       rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, 2, false, false, true>), LDS_T);
       hipLaunchKernelGGL((k_fconv<NPL, SITE, 2, false, false, true>), dim3(gridt), dim3(T::NTHR), LDS_T, s, a);
+      return;
+    }
+  }
+  if constexpr (SITE == CV_D2F && fc_occ3(SITE)) {
+    if (a.st2_out && !a.yp && a.st_out) {   // statistics of the RESULT from the accumulators (OST; those of the input in the staging: LN = 2)
+      rt().ensure_lds(reinterpret_cast<const void*>(&k_fconv<NPL, SITE, 2, false, false, false, true>), T::LDS);
+      hipLaunchKernelGGL((k_fconv<NPL, SITE, 2, false, false, false, true>), dim3(grid), dim3(T::NTHR), T::LDS, s, a);
       return;
     }
   }

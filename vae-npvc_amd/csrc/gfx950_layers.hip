@@ -22,6 +22,7 @@
 #include "gfx950_toeplitz.h"
 #include "gfx950_toep_bf16.h"
 #include "gfx950_planegemm.h"
+#include "gfx950_ntring.h"
 #include "gfx950_viewconv.h"
 #include "gfx950_fconv.h"
 #include "gfx950_fwgrad.h"
@@ -249,7 +250,7 @@ static inline bool fw_bwd(int wsite, int64_t F) {
 // whole backward step of a thin decoder layer in one kernel (gfx950_fbwd.h): bit 15 of the backward mask (default set) and
 // the context's layer set from FCONV_MIN_FRAMES frames on; bit 14 cleared = at any batch size (parity tests)
 static inline bool fb_bwd(int layer, int64_t F) {
-  if ((rt().dense_planes ? rt().dense_planes : rt().planes) > 2 || !((rt().bwd_mask >> 15) & 1u)) return false;
+  if ((rt().dense_planes ? rt().dense_planes : rt().planes) > VAENPVC_FB_MAXPL || !((rt().bwd_mask >> 15) & 1u)) return false;
   if (!((rt().fb_layers() >> layer) & 1u)) return false;
   return F >= FCONV_MIN_FRAMES || !((rt().bwd_mask >> 14) & 1u);
 }
@@ -788,12 +789,26 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
                                                                 P + m.dec[1].b_off, w.dec_a[1], F), nsplit_for<D1F>(F), s));
     if (!d2_fused && !(have_yd1 = dec_stats(1, CV_D2F, CL_YD1, "dec2_split"))) VAENPVC_TIMED("stats_dec1", s, stats<2736>(w.dec_a[1], w.dec_st[1], F, s));
   } else generic::dec_layer_fwd(m, P, F, w, xh_out, s, 1);
+  // (round 6) no pass between decoder layer 2 and the 1025-tap layer: statistics out of layer 2's epilogue (k_fconv<OST>), LayerNorm + lrelu +
+  // operand split in the 1025-tap forward kernel's staging (k_toep_gemm_bf16<LNA>).  One channel group per frame tile (large batches).
+  const bool d2_lna = rt().d2_lna && rt().planes <= 2 && !rt().d2_tail && fwd_on(9) && fwd_on(10) && fc_fwd(CV_D2F, F) && fc_occ3(CV_D2F) && toep_bf16_for(F) && !abf &&
+                      (rt().d2_lna >= 2 || (F >= FCONV_MIN_FRAMES && toep_fwd_groups(F, weights_packed) == 1)) &&
+                      (!weights_packed || (toep_wgrad_bf16_for(F) && w.dec_y && w.toep_yp));
   if (fwd_on(9)) {
     // (round 5) the decoder tail in layer 2's epilogue: statistics of its result, the 1025-tap layer's operand planes, bin 512 of the activated
     // tensor and output column 512 leave the kernel that computed the frames; k_ln_stats_act_planes and its re-read of the tensor are gone
     const bool d2_tail = rt().d2_tail && fc_fwd(CV_D2F, F) && fwd_on(10) && toep_bf16_for(F) && !abf && dense_planes_now() <= 2 &&
                          dense_planes_now() == rt().planes && toep_wgrad_bf16_for(F) && w.dec_y && w.toep_yp &&
                          fc_occ3(CV_D2F) && F >= FCONV_MIN_FRAMES;
+    if (d2_lna) {
+      // (round 6) layer 2's kernel leaves the statistics of its result; the 1025-tap forward kernel normalises the fp32 tensor in its staging
+      for_dense_planes([&](auto npl) {
+        FcArgs fa{w.dec_a[1], nullptr, w.dec_st[1], P + m.dec[1].gamma_off, P + m.dec[1].beta_off,
+                  reinterpret_cast<const unsigned short*>(w.scratch + Pk::cvw + cv_woff(CV_D2F)), P + m.dec[2].b_off, w.dec_a[2], F};
+        fa.st2_out = w.dec_st[2];
+        VAENPVC_TIMED("dec2_fwd", s, fconv<decltype(npl)::value>(CV_D2F, fa, s));
+      });
+    } else
     if (d2_tail) {
       for_dense_planes([&](auto npl) {
         FcArgs fa{w.dec_a[1], nullptr, w.dec_st[1], P + m.dec[1].gamma_off, P + m.dec[1].beta_off,
@@ -816,7 +831,7 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
     VAENPVC_TIMED("dec2_fwd", s, launch_convgemm<D2F>(conv_args(w.dec_a[1], w.dec_st[1], P + m.dec[1].gamma_off,
                                                                 P + m.dec[1].beta_off, w.scratch + Pk::d2f,
                                                                 P + m.dec[2].b_off, w.dec_a[2], F), nsplit_for<D2F>(F), s));
-    if (d2_tail) {}
+    if (d2_tail || d2_lna) {}
     else if (toep_bf16_for(F) && fwd_on(10))
       for_planes([&](auto npl) {
         constexpr int NPL_ = decltype(npl)::value;
@@ -847,10 +862,26 @@ void decoder_fwd(const Model& m, const float* P, const float* z, const int64_t* 
       for_planes([&](auto npl) {
         constexpr int NPL = decltype(npl)::value;
         rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_gemm_bf16<true, NPL>), dg_lds(NPL));
+        if constexpr (NPL <= 2) if (d2_lna) {   // LayerNorm + lrelu + split of decoder layer 2's fp32 output in the staging (no plane producer pass in front)
+          constexpr int LDS_LNA = dg_lds(NPL) + NPL * DG_APL + DG_LNA_LDS;   // two A tiles: 151 104 bytes with two planes (three would not fit)
+          ToepLna ln;
+          ln.a = w.dec_a[2];
+          ln.st = w.dec_st[2];
+          ln.gamma = P + m.dec[2].gamma_off;
+          ln.beta = P + m.dec[2].beta_off;
+          ln.wc = w.scratch + Pk::wc;
+          ln.yp = weights_packed ? reinterpret_cast<unsigned short*>(w.toep_yp) : nullptr;   // (a train step: the weight gradient reads the planes)
+          ln.decy = weights_packed ? w.dec_y : nullptr;
+          rt().ensure_lds(reinterpret_cast<const void*>(&k_toep_gemm_bf16<true, NPL, false, TB_H, true>), LDS_LNA);
+          VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL((k_toep_gemm_bf16<true, NPL, false, TB_H, true>), dim3((unsigned)cdiv(F, DG_M), 1u), dim3(256),
+                                                          LDS_LNA, s, nullptr, reinterpret_cast<const unsigned short*>(w.scratch + Pk::wfw),
+                                                          P + m.dec[3].b_off, xh_out, (int)F, ln));
+          return;
+        }
         VAENPVC_TIMED("dec3_fwd", s, hipLaunchKernelGGL((k_toep_gemm_bf16<true, NPL>), dim3((unsigned)cdiv(F, DG_M), (unsigned)toep_fwd_groups(F, weights_packed)), dim3(256), dg_lds(NPL), s,
                                                         reinterpret_cast<const unsigned short*>(w.toep_yp),
                                                         reinterpret_cast<const unsigned short*>(w.scratch + Pk::wfw),
-                                                        P + m.dec[3].b_off, xh_out, (int)F));
+                                                        P + m.dec[3].b_off, xh_out, (int)F, ToepLna{}));
       });
     } else
     if (F >= 2048) {
@@ -1108,7 +1139,7 @@ void backward(const Model& m, const float* P, const float* x, const int64_t* y, 
           rt().ensure_lds(reinterpret_cast<const void*>(kern), dg_lds(NPL));
           VAENPVC_TIMED("dec3_dgrad", s, hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(F, DG_M), (unsigned)toep_groups(F)), dim3(256), dg_lds(NPL), s, gp,
                                                             reinterpret_cast<const unsigned short*>(w.scratch + Pk::wdg), (const float*)nullptr,
-                                                            w.dy_tmp, (int)F));  // (column 512: k_dxh_post)
+                                                            w.dy_tmp, (int)F, ToepLna{}));  // (column 512: k_dxh_post)
         };
         if constexpr (NPL == 1) {
           if (abf) { launch_dg(&k_toep_gemm_bf16<false, 1, true>); return; }

@@ -776,6 +776,9 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
     const bool second = a.C2 && n0c >= a.split;
     float* cb = (second ? a.C2 : a.C) + (n - (second ? a.split : 0));
     const bool whole = n + 3 < a.N;
+    // (Round 6, measured and removed: pieces SHIFTED to each row's 16-byte boundary for rows that are not a multiple of 16 bytes -- the merge
+    //  forward's 1 539-float rows -- with thread 31 storing the wrap-around floats singly: every 16-byte store aligned, and SLOWER, 94 -> 150 us:
+    //  the shifted columns cost eight 4-byte LDS reads + a select chain per row where this loop has two 16-byte reads.)
 #pragma unroll
     for (int i = 0; i < NT_BM / 8; ++i) {
       const int row = r0 + 8 * i, m = m0c + row;
@@ -848,6 +851,8 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
   }  // tiles
 }
 
+inline bool gemm_nt_ring_serves(const NtArgs& a);                 // gfx950_ntring.h (round 6)
+inline void launch_gemm_nt_ring(const NtArgs& a, hipStream_t s);
 inline bool gemm_nt_ar_serves(const NtArgs& a);
 template <int NPL>
 inline void launch_gemm_nt_ar(const NtArgs& a, hipStream_t s);
@@ -858,6 +863,13 @@ inline void launch_gemm_nt(const NtArgs& a_, hipStream_t s) {
   if constexpr (NPL == 2) {   // (two planes: the result tile is parked in the B buffer, which one plane does not fill)
     if (rt().nt_ar && gemm_nt_ar_serves(a) && (rt().nt_ar > 1 || a.M / NT_BM >= 192)) {   // short K, many rows: the A-resident kernel (Runtime::nt_ar)
       launch_gemm_nt_ar<NPL>(a, s);
+      return;
+    }
+  }
+  if constexpr (NPL == 2) {
+    // K-long sites on the four-wave ring kernel (Runtime::nt_ring: 1 = from 128 tiles of 256 x 128 on, 2 = whenever served -- parity tests)
+    if (rt().nt_ring && gemm_nt_ring_serves(a) && (rt().nt_ring > 1 || cdiv(a.M, 256) * cdiv(a.N, 128) >= 128)) {
+      launch_gemm_nt_ring(a, s);
       return;
     }
   }

@@ -434,20 +434,182 @@ constexpr int dg_lds(int npl) { return npl * DG_APL + tb_wch(npl); }  // NPL = 3
 // 16-byte stores that are not 16-byte aligned retire at about HALF the rate (this kernel with one plane: 538 MB in 230 us = 2.3 TB/s, the
 // merge GEMM's 1 539-float rows the same); with rows of 516 floats every store of this epilogue is aligned.  Only the fused backward
 // kernel of decoder layer 2 reads the result (gfx950_fbwd.h, same pitch).
-template <bool FWD, int NPL, bool BOUT = false, int DYP = TB_H>   // BOUT (input gradient only): dY stored as bf16, rows of 514
-__global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(const unsigned short* __restrict__ gp,   // A planes
+// LNA (round 6, forward only): the A operand is NOT read as planes.  The kernel stages decoder layer 2's fp32 pre-LN output itself and applies
+// LayerNorm + lrelu (statistics from the layer's own forward kernel, k_fconv<..., OST>) and the split into bf16 terms on the way into LDS --
+// what the separate pass k_ln_stats_act_planes did with a read of the 0.54 GB tensor and a write of 0.55 GB of planes (237 us per step).  Every
+// A element is staged exactly once per launch (a workgroup owns 64 frames x all 512 columns), so nothing is converted twice.  On the way:
+//   * the converted pieces also leave as the operand planes yp[F][NPL][8][528] the weight-gradient kernel reads by LDS-DMA (it cannot convert
+//     on load); nullable: the conversion path has no backward pass;
+//   * output column 512 (a dot product of the activated frame with the reversed taps, the pass computed it) is accumulated per staged piece
+//     against an fp32 LDS copy of the taps and summed per frame in a FIXED order at the end (bitwise repeatable);
+//   * bin 512 of the activated tensor leaves as fp32 (dec_y[f][c][512]: the loss kernel's edge term reads it).
+// Thread map: piece id = tid + 256 i (i < 6), piece = (frame row id / 22, 8 bins id % 22) of the 64 x 176 chunk: consecutive lanes read
+// consecutive 32-byte runs of an fp32 row and write consecutive 16-byte pieces of a plane row.
+#ifndef VAENPVC_LNA_NT
+#define VAENPVC_LNA_NT 1   // the planes yp leave with non-temporal stores: 0.55 GB that the weight-gradient kernel reads a whole forward tail + loss later;
+                           // cached they push x / xh out of the Infinity Cache in front of the loss kernel (measured: loss 88 -> 111 us)
+#endif
+struct ToepLna {
+  const float* a = nullptr;      // [F][8][513] fp32 pre-LN output of decoder layer 2
+  const float* st = nullptr;     // [F][2] its LayerNorm statistics (mean, rstd)
+  const float* gamma = nullptr;  // [8]
+  const float* beta = nullptr;
+  const float* wc = nullptr;     // [8][1040] fp32 taps, wc[c][8 + t] = W[t][c] (k_ln_stats_act_planes' table)
+  unsigned short* yp = nullptr;  // out, nullable: planes of the activated tensor [F][NPL][8][528] (zero padding 513 .. 527)
+  float* decy = nullptr;         // out, nullable: fp32 [F][8][513], only bin 512 of every channel is written
+};
+constexpr int DG_LNA_LDS = TB_C * TB_KP * 4 + 2 * TB_C * 4 + DG_M * (DG_KC / 8) * 4 + DG_M * 4;   // taps + LN parameters + per-piece dot sums + row sums
+template <bool FWD, int NPL, bool BOUT = false, int DYP = TB_H, bool LNA = false>   // BOUT (input gradient only): dY stored as bf16, rows of 514
+__global__ void __launch_bounds__(256, (NPL == 1 && !LNA ? 2 : 1)) k_toep_gemm_bf16(const unsigned short* __restrict__ gp,   // A planes
                                                             const unsigned short* __restrict__ wcp,  // packed tap copies
                                                             const float* __restrict__ bias,          // FWD: [1]
                                                             float* __restrict__ dY,  // dgrad: [F][8][513]; fwd: [F][513]
-                                                            int F) {
+                                                            int F, ToepLna ln) {
+  static_assert(!LNA || (FWD && !BOUT && DYP == TB_H), "LayerNorm on load: the forward direction");
   constexpr int A_PL = (FWD ? TB_C : 1) * TB_KP * 2;  // bytes between planes of a frame
   constexpr int A_FR = NPL * A_PL;                    // bytes per frame
   constexpr int TB_WCH = tb_wch(NPL);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;
-  unsigned char* sW = smem + NPL * DG_APL;
+  // LNA: TWO A tiles -- the chunk being multiplied and the one being converted into (no staging registers for the converted terms, one
+  // barrier per chunk)
+  constexpr int NABUF = LNA ? 2 : 1;
+  unsigned char* sA = smem;             // the tile the MFMAs read (LNA: toggles between the two)
+  unsigned char* sAn = smem + (LNA ? NPL * DG_APL : 0);   // LNA: the tile the conversion writes
+  unsigned char* sW = smem + NABUF * NPL * DG_APL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int f0 = blockIdx.x * DG_M;
+  // ---- LNA staging state
+  constexpr int LN_NPC = 6, LN_PPR = DG_KC / 8, LN_NP = DG_M * LN_PPR;   // pieces per thread / row / chunk (22, 1408)
+  float* wrev = reinterpret_cast<float*>(smem + NABUF * NPL * DG_APL + TB_WCH);   // [8][528]: wrev[c][i] = W[1024 - i][c], zero from bin 513 on
+  float* lnpar = wrev + TB_C * TB_KP;                                     // [2][8] gamma | beta
+  float* pdot = lnpar + 2 * TB_C;                                         // [1408] per-piece dot sums (end of the kernel)
+  float* rdot = pdot + LN_NP;                                             // [64]
+  int ln_aoff[LN_NPC], ln_loff[LN_NPC], ln_yoff[LN_NPC], ln_pc[LN_NPC];
+  bool ln_ok[LN_NPC], ln_st[LN_NPC];
+  float ln_mean[LN_NPC], ln_rstd[LN_NPC], ln_dot[LN_NPC];
+  float ln_A[LN_NPC], ln_B[LN_NPC];   // n = v * A + B for the chunk being converted (A = rstd * gamma_c, B = beta_c - mean * A)
+  float raw[LN_NPC][8];
+  // the last chunk's pieces 20 (bin 512 + padding) and 21 (padding) of a row are written by thread `row` (tid < 64), not by the piece slots
+  float sp_mean = 0.f, sp_rstd = 0.f, sp_a512 = 0.f, sp_dot = 0.f;
+  bool ln_spec[LN_NPC];
+  if constexpr (LNA) {
+#pragma unroll
+    for (int i = 0; i < LN_NPC; ++i) {
+      const int id0 = tid + 256 * i, id = id0 < LN_NP ? id0 : LN_NP - 1, row = id / LN_PPR, pc = id - row * LN_PPR;
+      const int fr = f0 + row < F ? row : F - 1 - f0;     // rows past the batch end: duplicates of its last frame, never stored
+      ln_pc[i] = pc;
+      ln_aoff[i] = fr * (TB_C * TB_H) + pc * 8;
+      ln_loff[i] = row * DG_ROWB + pc * 16;
+      ln_yoff[i] = fr * (NPL * TB_C * TB_KP) + pc * 8;
+      ln_st[i] = id0 < LN_NP;                              // this slot holds a piece of the chunk (i = 5: the first 128 threads)
+      ln_ok[i] = id0 < LN_NP && f0 + row < F;              // ... of a frame of the batch
+      ln_mean[i] = ln.st[2 * (f0 + fr)];
+      ln_rstd[i] = ln.st[2 * (f0 + fr) + 1];
+      ln_dot[i] = 0.f;
+      ln_spec[i] = pc >= 20;
+    }
+    if (tid < DG_M) {
+      const int fr = f0 + tid < F ? tid : F - 1 - f0;
+      sp_mean = ln.st[2 * (f0 + fr)];
+      sp_rstd = ln.st[2 * (f0 + fr) + 1];
+    }
+    for (int i = tid; i < TB_C * TB_KP; i += 256) {
+      const int c = i / TB_KP, b = i - c * TB_KP;
+      wrev[i] = b < TB_H ? ln.wc[c * 1040 + 8 + (TB_T - 1) - b] : 0.f;
+    }
+    if (tid < 2 * TB_C) lnpar[tid] = tid < TB_C ? ln.gamma[tid] : ln.beta[tid - TB_C];
+    // (visible behind the first barrier of the channel loop)
+  }
+  // fp32 pieces of chunk (c, kc) -> raw.  The last chunk's pieces 20 (bins 512 .. 519: only bin 512 exists) and 21 (padding) read bins 505 .. 512
+  // instead: no access leaves the frame's row set; the conversion picks bin 512 out of element 7
+  auto gload_lna = [&](int c, int kc) __attribute__((always_inline)) {
+    if constexpr (LNA) {
+      const float* ab = ln.a + (int64_t)f0 * (TB_C * TB_H) + c * TB_H + kc * DG_KC;
+#pragma unroll
+      for (int i = 0; i < LN_NPC; ++i) {
+        const int back = (kc == DG_NKC - 1 && ln_pc[i] >= 20) ? (ln_pc[i] == 20 ? 7 : 15) : 0;
+        const float* p = ab + ln_aoff[i] - back;
+        const packed4 p0 = *reinterpret_cast<const packed4*>(p), p1 = *reinterpret_cast<const packed4*>(p + 4);
+        raw[i][0] = p0.x; raw[i][1] = p0.y; raw[i][2] = p0.z; raw[i][3] = p0.w;
+        raw[i][4] = p1.x; raw[i][5] = p1.y; raw[i][6] = p1.z; raw[i][7] = p1.w;
+      }
+      if (kc == DG_NKC - 1 && tid < DG_M) {
+        const int fr = f0 + tid < F ? tid : F - 1 - f0;
+        sp_a512 = ln.a[((int64_t)(f0 + fr) * TB_C + c) * TB_H + (TB_H - 1)];
+      }
+    }
+  };
+  // raw (chunk (c, kc)) -> LayerNorm + lrelu -> bf16 terms (lpk); dot products with the reversed taps; yp / bin 512 out.  PAIRWISE: pair q of
+  // piece i is ~25 vector instructions, small enough to issue in the shadow of the MFMAs of ONE (k-step, column tile) step of the chunk in
+  // front -- as one serial block at the top of a chunk the conversion cost 100 us per launch (measured, 328 -> 430 us: a wave issues in order
+  // and one wave runs per SIMD).  `live` = false: the chunk is the redundant wrap-around prefetch behind the last chunk of the launch.
+  u32x4 cpk[NPL];   // the piece being converted (four pairs = four steps), then stored
+  // per chunk, before its first pair: the LayerNorm coefficients of the six piece slots
+  auto convert_begin = [&](float g, float b) __attribute__((always_inline)) {
+    if constexpr (LNA) {
+#pragma unroll
+      for (int i = 0; i < LN_NPC; ++i) {
+        ln_A[i] = ln_rstd[i] * g;
+        ln_B[i] = b - ln_mean[i] * ln_A[i];
+      }
+    }
+  };
+  // pair q of piece slot i of chunk (c, kc): LayerNorm + lrelu (n = v A + B), the pair's term of output column 512, the split; behind the
+  // fourth pair the piece goes to the OTHER A tile in LDS and (live) to yp.  The special pieces of a channel's last chunk (20: bin 512 +
+  // padding, 21: padding) convert what they loaded (bins 505 .. 512) and are neither stored nor summed: convert_special writes them.
+  auto convert_pair = [&](int i, int q, int c, int kc, bool live) __attribute__((always_inline)) {
+    if constexpr (LNA) {
+      const float n0 = fmaf(raw[i][2 * q], ln_A[i], ln_B[i]), n1 = fmaf(raw[i][2 * q + 1], ln_A[i], ln_B[i]);
+      const float o0 = fmaxf(n0, LEAK * n0), o1 = fmaxf(n1, LEAK * n1);
+      const bool reg = !(kc == DG_NKC - 1 && ln_spec[i]);
+      const float* wr = wrev + c * TB_KP + kc * DG_KC + ln_pc[i] * 8 + 2 * q;
+      const float d = o0 * wr[0] + o1 * wr[1];
+      ln_dot[i] += (live && reg) ? d : 0.f;
+      unsigned pk2[NPL];
+      split_pair<NPL>(o0, o1, pk2);
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) cpk[p][q] = pk2[p];
+      if (q == 3) {
+        if (ln_st[i] && reg) {
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(sAn + p * DG_APL + ln_loff[i]) = cpk[p];
+        }
+        if (live && reg && ln.yp && ln_ok[i]) {
+          unsigned short* ypb = ln.yp + (int64_t)f0 * (NPL * TB_C * TB_KP) + c * TB_KP + kc * DG_KC;
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) st_nt<VAENPVC_LNA_NT>(reinterpret_cast<u32x4*>(ypb + p * (TB_C * TB_KP) + ln_yoff[i]), cpk[p]);
+        }
+      }
+    }
+  };
+  // the last chunk of channel c: thread `row` (tid < 64) writes the row's pieces 20 and 21 -- bin 512 of the activated tensor (also to yp /
+  // dec_y, and its term of output column 512) and the zero padding 513 .. 527
+  auto convert_special = [&](int c, bool live) __attribute__((always_inline)) {
+    if constexpr (LNA) {
+      if (tid < DG_M) {
+        const float y = lnact_v(sp_a512, sp_mean, sp_rstd, lnpar[c], lnpar[TB_C + c]);
+        sp_dot += live ? y * wrev[c * TB_KP + (TB_H - 1)] : 0.f;
+        unsigned t[NPL];
+        split_n<NPL>(y, t);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        const bool out = live && f0 + tid < F;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+          u32x4 v = z;
+          v[0] = t[p];
+          *reinterpret_cast<u32x4*>(sAn + p * DG_APL + tid * DG_ROWB + 20 * 16) = v;
+          *reinterpret_cast<u32x4*>(sAn + p * DG_APL + tid * DG_ROWB + 21 * 16) = z;
+          if (out && ln.yp) {
+            unsigned short* yr = ln.yp + ((int64_t)(f0 + tid) * NPL + p) * (TB_C * TB_KP) + c * TB_KP + (TB_H - 1);
+            *reinterpret_cast<u32x4*>(yr) = v;
+            *reinterpret_cast<u32x4*>(yr + 8) = z;
+          }
+        }
+        if (out && ln.decy) ln.decy[((int64_t)(f0 + tid) * TB_C + c) * TB_H + (TB_H - 1)] = y;
+      }
+    }
+  };
+  constexpr int LN_S0 = 44 - 4 * LN_NPC;   // first (k-step, column tile) step of a chunk that carries a conversion pair: the last 24 of its 44 steps
 
   // staging map: thread -> (row = tid >> 2, part = tid & 3) copies the 16-byte pieces part + 4*q
   // (q < 6; a row of a chunk has 22 pieces) of all three planes: every address is a per-thread
@@ -529,7 +691,16 @@ __global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(cons
   // set) was tried and dropped: 128 more live registers and the unrolled chunk loop spill ~100 registers, 340 -> 394 us.
   const int crot = FWD ? 0 : (int)(blockIdx.x % (unsigned)cpg);
   auto chan = [&](int ci) { return c_lo + (ci - c_lo + crot) % cpg; };   // ci = loop position -> channel
-  gload(chan(c_lo), 0);
+  if constexpr (LNA) {
+    gload_lna(chan(c_lo), 0);
+    __syncthreads();   // wrev / lnpar are in LDS
+    convert_begin(lnpar[chan(c_lo)], lnpar[TB_C + chan(c_lo)]);
+#pragma unroll
+    for (int i = 0; i < LN_NPC; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) convert_pair(i, q, chan(c_lo), 0, true);   // the first chunk: once per workgroup, serial
+    unsigned char* t_ = sA; sA = sAn; sAn = t_;   // (visible behind the barrier at the top of the channel loop + the one behind the tap copies)
+  } else gload(chan(c_lo), 0);
   // tap copies of a channel: the global loads are issued one channel ahead, BEFORE the epilogue stores of the channel
   // in front (vector memory completes in order and loads and stores share one counter on this ISA: loads issued behind
   // 64 stores per lane wait for all of them -- measured: the input-gradient epilogue, 538 MB, cost its full 100 us on
@@ -562,20 +733,26 @@ __global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(cons
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = zero16();
     }
+    if constexpr (LNA) __syncthreads();   // the channel's tap copies are in LDS (without LNA the barrier behind the first lstore publishes them)
     TBPROF_T(t1);
 #if VAENPVC_PROF
     pc[0] += t1 - t0;
 #endif
     for (int kc = 0; kc < DG_NKC; ++kc) {
       TBPROF_T(t2);
-      lstore();  // chunk kc (prefetched)
-      __syncthreads();
-      TBPROF_T(t3);
-      {  // prefetch the next chunk (same rows, next bins; wraps to chunk 0 for the next channel)
-        int kn = kc + 1 < DG_NKC ? kc + 1 : 0;
-        int cn = kc + 1 < DG_NKC ? c : (ci + 1 < c_hi ? chan(ci + 1) : c);
-        gload(cn, kn);
+      if constexpr (!LNA) {
+        lstore();  // chunk kc (prefetched)
+        __syncthreads();
       }
+      TBPROF_T(t3);
+      // prefetch the next chunk (same rows, next bins; wraps to chunk 0 for the next channel)
+      const int kn = kc + 1 < DG_NKC ? kc + 1 : 0;
+      const int cn = kc + 1 < DG_NKC ? c : (ci + 1 < c_hi ? chan(ci + 1) : c);
+      const bool nlive = kc + 1 < DG_NKC || ci + 1 < c_hi;   // (false: the wrap-around prefetch behind the last chunk)
+      if constexpr (LNA) {
+        gload_lna(cn, kn);
+        convert_begin(lnpar[cn], lnpar[TB_C + cn]);
+      } else gload(cn, kn);
       __builtin_amdgcn_sched_barrier(0);
       loadA(0, 0);
       loadB(0, kc, 0, 0);
@@ -592,6 +769,17 @@ __global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(cons
           }
           __builtin_amdgcn_sched_barrier(0);
           mm(sa, sb, nb);
+          if constexpr (LNA) {   // one conversion pair of the NEXT chunk in the shadow of this step's MFMAs
+            constexpr int NMM = 2 * Prod<NPL>::N;
+            if (4 * ks + nb >= LN_S0) {
+              convert_pair((4 * ks + nb - LN_S0) >> 2, (4 * ks + nb - LN_S0) & 3, cn, kn, nlive);
+#pragma unroll
+              for (int _m = 0; _m < NMM; ++_m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (NMM >= 12 ? 3 : NMM >= 6 ? 5 : 12), 0);
+              }
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -599,7 +787,11 @@ __global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(cons
       asm volatile("s_nop 0" ::: "memory");
 #endif
       TBPROF_T(t4);
-      __syncthreads();  // chunk consumed
+      if constexpr (LNA) {
+        if (kn == DG_NKC - 1) convert_special(cn, nlive);   // uniform
+      }
+      __syncthreads();  // chunk consumed (LNA: and the next one converted)
+      if constexpr (LNA) { unsigned char* t_ = sA; sA = sAn; sAn = t_; }
 #if VAENPVC_PROF
       TBPROF_T(t5);
       pc[1] += (t3 - t2) + (t5 - t4);
@@ -648,6 +840,19 @@ __global__ void __launch_bounds__(256, (NPL == 1 ? 2 : 1)) k_toep_gemm_bf16(cons
     TBPROF_T(t7);
     pc[3] += t7 - t6;
 #endif
+  }
+  if constexpr (LNA) {
+    // output column 512: the pieces' dot sums of a frame row added in a fixed order (22 pieces x 24 chunks each)
+#pragma unroll
+    for (int i = 0; i < LN_NPC; ++i)
+      if (ln_st[i]) pdot[tid + 256 * i] = ln_dot[i];
+    __syncthreads();
+    if (tid < DG_M && f0 + tid < F) {
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < LN_PPR; ++k) sum += pdot[tid * LN_PPR + k];
+      dY[(int64_t)(f0 + tid) * TB_H + (TB_H - 1)] = (sum + sp_dot) + bias[0];
+    }
   }
 #if VAENPVC_PROF
   {

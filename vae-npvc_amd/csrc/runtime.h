@@ -57,12 +57,16 @@ struct Runtime {
                                 // per CU), 0 = never, 2 = whenever the shape is served (parity tests at small batches).  OFF: measured 102 us against
                                 // 98 us for the one-tile kernel once both store through LDS, and the decoder layer behind it runs 20 us slower
                                 // (279 -> 299 us: the rows of h leave the caches in another order); round 5, three interleaved rounds on one box
+  int nt_ring = 0;              // VAENPVC_NT_RING: C = A B^T sites with K >= 256 on the four-wave LDS-DMA ring kernel (gfx950_ntring.h): 1 = from 128 tiles of
+                                // 256 x 128 on, 2 = whenever the shape is served (parity tests), 0 = never
   bool nt_lep = true;           // VAENPVC_NT_LEP=0: C = A B^T results stored straight from the accumulators (4 bytes per lane) instead of through LDS (A/B)
   bool dy2_pad = true;          // VAENPVC_DY2_PAD=0: the 1025-tap layer's input gradient in the tensor's own 513-float rows (unaligned 16-byte stores; A/B)
   bool e2_osp = true;           // VAENPVC_E2_OSP=0: statistics + activated planes of encoder layer 2's output in their own pass (A/B)
   bool tn_d0fit = true;         // VAENPVC_TN_D0FIT=0: decoder layer 0's weight gradient on 128 x 256 tiles (36 % of the MFMA work useful) instead of 96 x 288 (A/B)
   bool fb_lnb2 = true;          // VAENPVC_FB_LNB2=0: decoder layer 0's LayerNorm backward as its own pass behind layer 1's fused backward kernel (A/B)
   bool d0g_planes = true;       // VAENPVC_D0G_PLANES=0: decoder layer 0's input gradient leaves as fp32 d(h) and a split pass makes the merge GEMMs' planes (A/B)
+  int d2_lna = 1;               // (2: also below 16 384 frames per step, one channel group per frame tile -- parity tests)  VAENPVC_D2_LNA=0: the separate pass between decoder layer 2 and the 1025-tap layer (k_ln_stats_act_planes: statistics, activation,
+                                // operand planes, column 512) instead of statistics in layer 2's epilogue + LayerNorm on load in the 1025-tap forward kernel (A/B)
   bool d2_tail = false;         // VAENPVC_D2_TAIL=1: the pass between decoder layer 2 and the 1025-tap layer (statistics, planes, bin 512, column 512) in the
                                 // epilogue of layer 2's forward kernel (k_fconv<TAIL>).  OFF: built, parity-green, NOT faster -- 457 us against 205 + 240 us for
                                 // the two kernels (round 5, same box): the epilogue's ~1 100 vector instructions and three barriers per 2-frame group are

@@ -38,12 +38,14 @@ void Runtime::read_env() {
   if (const char* e = getenv("VAENPVC_TOEP_ZC")) toep_zc = atoi(e) > 0 ? atoi(e) : 4;
   if (const char* e = getenv("VAENPVC_TN_XCD")) tn_xcd = atoi(e);
   if (const char* e = getenv("VAENPVC_D2_TAIL")) d2_tail = atoi(e) != 0;
+  if (const char* e = getenv("VAENPVC_D2_LNA")) d2_lna = atoi(e);
   if (const char* e = getenv("VAENPVC_FB_LNB2")) fb_lnb2 = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_D0G_PLANES")) d0g_planes = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_TN_D0FIT")) tn_d0fit = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_E2_OSP")) e2_osp = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_DY2_PAD")) dy2_pad = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_NT_LEP")) nt_lep = atoi(e) != 0;
+  if (const char* e = getenv("VAENPVC_NT_RING")) nt_ring = atoi(e);
   if (const char* e = getenv("VAENPVC_NT_AR")) nt_ar = atoi(e);
   if (const char* e = getenv("VAENPVC_CG_LNB")) cg_lnb = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_CG_SF")) cg_sf = atoi(e) != 0;
