@@ -407,6 +407,23 @@ def test_plane_gemm_dense_layers_against_oracle(F, seed, precision):
     assert not fails, '\n'.join(fails)
 
 
+VIEW_CONV_BITS = 0xebffffff            # (= VIEW_CONV below: plane GEMMs + every conv site on the view GEMMs at any batch size)
+
+
+@pytest.mark.parametrize('F,seed', [(1, 7), (37, 5), (130, 9), (257, 12), (1027, 7)])
+def test_ring_gemm_dense_layers_against_oracle(F, seed, monkeypatch):
+    """Round 6: C = A B^T of the K-long dense-shaped sites (encoder layer 4 as a dense layer, forward + input gradient; the heads, forward +
+    input gradient) on the four-wave LDS-DMA ring kernel (csrc/gfx950_ntring.h: 256 x 128 tiles, 128 x 64 wave tiles, per-(operand, plane)
+    64-k slots, three product phases per chunk with all four k-steps of a plane's fragments in registers), forced with VAENPVC_NT_RING=2 at
+    ragged batches (one 256-row tile holding 1 / 37 / 130 rows, two tiles with 1 row in the second, five with 3): every tensor and gradient
+    against the float64 oracle; the kernel must have run (the six C = A B^T sites are then split between it and k_gemm_nt)."""
+    monkeypatch.setenv('VAENPVC_NT_RING', '2')
+    monkeypatch.setenv('VAENPVC_CG_SF_RING', '1')        # encoder layer 3 forward on the same main loop (36 whole frames per tile)
+    eng = make_engine('vcc', 'auto', masks=(PLANE_GEMM[0] & VIEW_CONV_BITS, PLANE_GEMM[1] & VIEW_CONV_BITS), precision='bf16x2')
+    fails = compare_everything(eng, F, seed, 'nt_ring F%d ' % F)
+    assert not fails, '\n'.join(fails)
+
+
 BF16_TOL_ACT, BF16_TOL_GRAD = 3e-2, 6e-2   # bf16 MODE (one bf16 term per operand, ~3 significant digits)
 @pytest.mark.parametrize('F,seed', [(128, 3), (384, 4), (1152, 5)])
 def test_a_resident_merge_gemm_against_oracle(F, seed, monkeypatch):

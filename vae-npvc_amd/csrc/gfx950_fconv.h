@@ -615,8 +615,8 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (TAIL ? 2 : FcCfg<NP
         for (int c = 0; c < T::CP; ++c) asm volatile("" ::"v"(v[u][c]));
       if constexpr (TAIL) epilogue_tail(pf0, pnf);
       else {
+        epilogue(pf0, pnf);   // the stores first: they fly while the statistics are taken from the same accumulators
         ost_stats(pnf);
-        epilogue(pf0, pnf);
       }
     }
     fstore(g);
@@ -673,8 +673,8 @@ __global__ void __launch_bounds__((FcCfg<NPL, SITE>::NTHR), (TAIL ? 2 : FcCfg<NP
     if (pf0 >= 0) epilogue_tail(pf0, pnf);
   } else {
     if (VAENPVC_FC_DEFER && pf0 >= 0) {
-      ost_stats(pnf);
       epilogue(pf0, pnf);
+      ost_stats(pnf);
       if constexpr (OST) {
         __syncthreads();
         ost_combine(pf0, pnf);

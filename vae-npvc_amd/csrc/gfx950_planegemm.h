@@ -853,6 +853,10 @@ __global__ void __launch_bounds__(256, VAENPVC_NT_WPS) k_gemm_nt(NtArgs a) {
 
 inline bool gemm_nt_ring_serves(const NtArgs& a);                 // gfx950_ntring.h (round 6)
 inline void launch_gemm_nt_ring(const NtArgs& a, hipStream_t s);
+struct CgArgs;
+struct CgSfArgs;
+inline bool cgemm_sf_ring_serves(const CgArgs& a);
+inline void launch_cgemm_sf_ring(const CgSfArgs& b, hipStream_t s);
 inline bool gemm_nt_ar_serves(const NtArgs& a);
 template <int NPL>
 inline void launch_gemm_nt_ar(const NtArgs& a, hipStream_t s);

@@ -262,6 +262,12 @@ static bool cv_gemm_stats_planes(int site, const float* wplanes, const float* xp
   if constexpr (NPL <= 2) {
     CgSfArgs b{cv_gemm_args(site, wplanes, xplanes, out, bias, F), st, gamma, beta, reinterpret_cast<unsigned short*>(planes), F};
     if (!cgemm_sf_serves(b.g)) return false;
+    if constexpr (NPL == 2) {
+      if (rt().cg_sf_ring && cgemm_sf_ring_serves(b.g)) {   // the four-wave LDS-DMA ring kernel (gfx950_ntring.h; VAENPVC_CG_SF_RING=0: A/B)
+        launch_cgemm_sf_ring(b, s);
+        return true;
+      }
+    }
     launch_cgemm_sf<NPL>(b, s);
     return true;
   }

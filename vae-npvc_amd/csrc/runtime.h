@@ -57,8 +57,9 @@ struct Runtime {
                                 // per CU), 0 = never, 2 = whenever the shape is served (parity tests at small batches).  OFF: measured 102 us against
                                 // 98 us for the one-tile kernel once both store through LDS, and the decoder layer behind it runs 20 us slower
                                 // (279 -> 299 us: the rows of h leave the caches in another order); round 5, three interleaved rounds on one box
-  int nt_ring = 0;              // VAENPVC_NT_RING: C = A B^T sites with K >= 256 on the four-wave LDS-DMA ring kernel (gfx950_ntring.h): 1 = from 128 tiles of
+  int nt_ring = 1;              // VAENPVC_NT_RING: C = A B^T sites with K >= 256 on the four-wave LDS-DMA ring kernel (gfx950_ntring.h): 1 = from 128 tiles of
                                 // 256 x 128 on, 2 = whenever the shape is served (parity tests), 0 = never
+  bool cg_sf_ring = false;      // VAENPVC_CG_SF_RING=1: encoder layer 3 forward on the ring kernel's main loop (k_cgemm_sf_ring: 36 whole frames per tile)
   bool nt_lep = true;           // VAENPVC_NT_LEP=0: C = A B^T results stored straight from the accumulators (4 bytes per lane) instead of through LDS (A/B)
   bool dy2_pad = true;          // VAENPVC_DY2_PAD=0: the 1025-tap layer's input gradient in the tensor's own 513-float rows (unaligned 16-byte stores; A/B)
   bool e2_osp = true;           // VAENPVC_E2_OSP=0: statistics + activated planes of encoder layer 2's output in their own pass (A/B)
