@@ -96,15 +96,17 @@ SITE_GROUPS = {
 # bench.py times every row (HIP events around each launch, weight-gradient stream serialised) and reports the row with the largest
 # time per step as the top-level `roofline` -- the dominant kernel is measured, not chosen.
 KERNEL_ROWS = [
-    dict(name='k_gemm_nt<%d, false>', tags='enc4_fwd heads_fwd merge_fwd merge_dgrad heads_dgrad enc4_dgrad', bound='mfma',
-         mac=2 * (688128 + 196608 + 196992),
-         what='C = A B^T plane GEMM: forward + input gradient of encoder layer 4 (as a dense layer), heads, merge: six launches per step'),
+    dict(name='k_gemm_nt_ring', tags='enc4_fwd heads_fwd enc4_dgrad', bound='mfma', mac=2 * 688128 + 196608,
+         what='C = A B^T on the four-wave LDS-DMA ring kernel (round 6): encoder layer 4 as a dense layer, forward + input gradient, and the heads forward'),
+    dict(name='k_gemm_nt<%d, false>', tags='merge_fwd merge_dgrad heads_dgrad', bound='mfma', mac=2 * 196992 + 196608,
+         what='C = A B^T plane GEMM on the two-barrier 128 x 128 loop: merge forward (a store stream, K = 128), merge and heads input gradients'),
     dict(name='k_fbwd<%d, 0, 0, 516, false>', tags='dec2_bwd', bound='hbm', bytes=4 * (_E['d2'] + _E['d2'] + _E['d1'] + _E['d1']),
          what='whole backward step of decoder layer 2 in one kernel: dy + pre-LN output + input activation read, input gradient written, once'),
     dict(name='k_fbwd<%d, 2, 0, 0, false>', tags='enc1_bwd', bound='hbm', bytes=4 * (_E['e1'] + _E['e1'] + _E['e0'] + _E['e0']),
          what='whole backward step of encoder layer 1'),
-    dict(name='k_toep_gemm_bf16<false, %d, false, 516>', tags='dec3_dgrad', bound='mfma', mac=8 * 513 * 513, what='1025-tap layer, input gradient'),
-    dict(name='k_toep_gemm_bf16<true, %d, false, 513>', tags='dec3_fwd', bound='mfma', mac=8 * 513 * 513, what='1025-tap layer, forward'),
+    dict(name='k_toep_gemm_bf16<false, %d, false, 516, false>', tags='dec3_dgrad', bound='mfma', mac=8 * 513 * 513, what='1025-tap layer, input gradient'),
+    dict(name='k_toep_gemm_bf16<true, %d, false, 513, true>', tags='dec3_fwd', bound='mfma', mac=8 * 513 * 513,
+         what='1025-tap layer, forward, with LayerNorm + lrelu + operand split of its input in the staging (round 6: no producer pass in front)'),
     dict(name='k_toep_wgrad_bf16_w4<%d>', tags='dec3_wgrad', bound='mfma', mac=8 * 513 * 513, what='1025-tap layer, weight gradient'),
     dict(name='k_fbwd<%d, 1, 0, 0, true>', tags='dec1_bwd', bound='hbm', bytes=4 * (_E['d1'] + _E['d1'] + _E['d0']) + 2 * 2 * 63 * 32,
          what='whole backward step of decoder layer 1 + the LayerNorm backward of layer 0 (result: its bf16 operand planes)'),
@@ -566,7 +568,7 @@ def main(argv=None):
                 if not k:
                     continue
                 ms = k[0]
-                name = 'void ' + r['name'] % planes
+                name = 'void ' + (r['name'] % planes if '%d' in r['name'] else r['name'])
                 ent = {'kernel': name, 'sites': r['tags'].split(), 'what': r['what'], 'ms_per_step': ms, 'launches_per_step': k[1] / k[2],
                        'avg_launch_ms': ms * k[2] / k[1], 'bound': r['bound'], 'precision': prec_name}
                 if r['bound'] == 'mfma':
@@ -579,7 +581,7 @@ def main(argv=None):
                     ent.update(achieved=nb / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s', algorithmic_bytes_per_step=nb,
                                peak_basis='HBM3E 8 TB/s')
                 ent['frac'] = ent['achieved'] / ent['peak']
-                tj = tjall.get('row/%s/%s' % (name, prec_name))
+                tj = tjall.get('row/%s/%s' % (name, prec_name)) or tjall.get('row/%s/%s' % (name[5:], prec_name))
                 ent['traffic'] = tj['hbm_bytes_per_step'] if (tj and tj.get('frames') == F) else None
                 ent['traffic_measured_in_run'] = False
                 rows.append(ent)

@@ -263,7 +263,7 @@ static bool cv_gemm_stats_planes(int site, const float* wplanes, const float* xp
     CgSfArgs b{cv_gemm_args(site, wplanes, xplanes, out, bias, F), st, gamma, beta, reinterpret_cast<unsigned short*>(planes), F};
     if (!cgemm_sf_serves(b.g)) return false;
     if constexpr (NPL == 2) {
-      if (rt().cg_sf_ring && cgemm_sf_ring_serves(b.g)) {   // the four-wave LDS-DMA ring kernel (gfx950_ntring.h; VAENPVC_CG_SF_RING=0: A/B)
+      if (rt().cg_sf_ring && (rt().cg_sf_ring > 1 || F >= 36 * 256) && cgemm_sf_ring_serves(b.g)) {   // the four-wave LDS-DMA ring kernel (gfx950_ntring.h; VAENPVC_CG_SF_RING=0: A/B)
         launch_cgemm_sf_ring(b, s);
         return true;
       }

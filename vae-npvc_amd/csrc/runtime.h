@@ -59,7 +59,8 @@ struct Runtime {
                                 // (279 -> 299 us: the rows of h leave the caches in another order); round 5, three interleaved rounds on one box
   int nt_ring = 1;              // VAENPVC_NT_RING: C = A B^T sites with K >= 256 on the four-wave LDS-DMA ring kernel (gfx950_ntring.h): 1 = from 128 tiles of
                                 // 256 x 128 on, 2 = whenever the shape is served (parity tests), 0 = never
-  bool cg_sf_ring = false;      // VAENPVC_CG_SF_RING=1: encoder layer 3 forward on the ring kernel's main loop (k_cgemm_sf_ring: 36 whole frames per tile)
+  int cg_sf_ring = 1;           // (2: at any batch size -- parity tests; 1: from 9 216 frames on = one 36-frame tile per CU)  VAENPVC_CG_SF_RING=0: encoder layer 3 forward on k_cgemm_sf (two-barrier loop, 18 frames per tile) instead of the ring kernel's main loop
+                                // (k_cgemm_sf_ring, 36 whole frames per tile: 166 -> 155 us, round 6; A/B)
   bool nt_lep = true;           // VAENPVC_NT_LEP=0: C = A B^T results stored straight from the accumulators (4 bytes per lane) instead of through LDS (A/B)
   bool dy2_pad = true;          // VAENPVC_DY2_PAD=0: the 1025-tap layer's input gradient in the tensor's own 513-float rows (unaligned 16-byte stores; A/B)
   bool e2_osp = true;           // VAENPVC_E2_OSP=0: statistics + activated planes of encoder layer 2's output in their own pass (A/B)
