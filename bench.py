@@ -96,10 +96,11 @@ SITE_GROUPS = {
 # bench.py times every row (HIP events around each launch, weight-gradient stream serialised) and reports the row with the largest
 # time per step as the top-level `roofline` -- the dominant kernel is measured, not chosen.
 KERNEL_ROWS = [
-    dict(name='k_gemm_nt_ring', tags='enc4_fwd heads_fwd enc4_dgrad', bound='mfma', mac=2 * 688128 + 196608,
-         what='C = A B^T on the four-wave LDS-DMA ring kernel (round 6): encoder layer 4 as a dense layer, forward + input gradient, and the heads forward'),
-    dict(name='k_gemm_nt<%d, false>', tags='merge_fwd merge_dgrad heads_dgrad', bound='mfma', mac=2 * 196992 + 196608,
-         what='C = A B^T plane GEMM on the two-barrier 128 x 128 loop: merge forward (a store stream, K = 128), merge and heads input gradients'),
+    dict(name='k_gemm_nt_ring', tags='enc4_fwd heads_fwd enc4_dgrad heads_dgrad merge_dgrad', bound='mfma', mac=2 * 688128 + 2 * 196608 + 196992,
+         what='C = A B^T on the four-wave LDS-DMA ring kernel (round 6): encoder layer 4 as a dense layer and the heads, forward + input gradient, '
+              'and the merge input gradient: five launches per step'),
+    dict(name='k_gemm_nt<%d, false>', tags='merge_fwd', bound='mfma', mac=196992,
+         what='C = A B^T plane GEMM on the two-barrier 128 x 128 loop: the merge forward (K = 128, speaker table in the epilogue: a store stream)'),
     dict(name='k_fbwd<%d, 0, 0, 516, false>', tags='dec2_bwd', bound='hbm', bytes=4 * (_E['d2'] + _E['d2'] + _E['d1'] + _E['d1']),
          what='whole backward step of decoder layer 2 in one kernel: dy + pre-LN output + input activation read, input gradient written, once'),
     dict(name='k_fbwd<%d, 2, 0, 0, false>', tags='enc1_bwd', bound='hbm', bytes=4 * (_E['e1'] + _E['e1'] + _E['e0'] + _E['e0']),

@@ -53,7 +53,7 @@ if [ -n "$TAGS" ]; then
 fi
 for i in $(seq $SR); do
   for a in "$@"; do
-    env $(arm_env "$a") python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-literal --no-modes --no-convert $BMODE 2>/dev/null \
+    env $(arm_env "$a") python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-literal --no-modes --no-convert --no-traffic $BMODE 2>/dev/null \
       | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('step[$a]', round(d['ms_per_step'],4))"
   done
 done

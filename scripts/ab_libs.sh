@@ -5,7 +5,7 @@ R=$1; shift
 for i in $(seq $R); do
   for n in "$@"; do
     if [ "$n" = default ]; then L=""; else L="variants/$n/libvaenpvc_hip.so"; fi
-    VAENPVC_LIB=$L python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-literal --no-modes --no-convert 2>/dev/null \
+    VAENPVC_LIB=$L python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-literal --no-modes --no-convert --no-traffic 2>/dev/null \
       | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$n', round(d['ms_per_step'],4))"
   done
 done

@@ -11,7 +11,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 # the weight-gradient stream is serialised (VAENPVC_SIDE_STREAM=0) so that a kernel's duration is not inflated
 # by kernels running next to it
-CMD="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-literal --no-modes --no-convert"
+CMD="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-literal --no-modes --no-convert --no-traffic"
 run_pass() {  # name, parser, rocprof args...
   local name=$1 parser=$2; shift 2
   rm -rf /tmp/rp_$name
@@ -33,9 +33,9 @@ if [ "$WHAT" = all ]; then
   run_pass pmc_write rocpd_pmc.py --kernel-trace --pmc WRITE_SIZE
   (cd $ROOT && timeout 300 python scripts/site_times.py > $OUT/${TAG}_site_times.txt 2>/dev/null)
   (cd $ROOT && timeout 300 python scripts/site_times.py --frames 256 > $OUT/${TAG}_site_times_F256.txt 2>/dev/null)
-  (cd /tmp && VAENPVC_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rp_f256 -- python $ROOT/bench.py --frames 256 --steps 100 --warmup 10 --no-cpu-baseline --no-literal --no-modes --no-convert > $OUT/f256.log 2>&1)
+  (cd /tmp && VAENPVC_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rp_f256 -- python $ROOT/bench.py --frames 256 --steps 100 --warmup 10 --no-cpu-baseline --no-literal --no-modes --no-convert --no-traffic > $OUT/f256.log 2>&1)
   db=$(find /tmp/rp_f256 -name '*.db' | head -1); [ -n "$db" ] && python $ROOT/scripts/rocpd_stats.py $db 70 > $OUT/${TAG}_kernel_trace_stats_F256.txt
-  (cd /tmp && VAENPVC_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rp_f16 -- python $ROOT/bench.py --frames 16 --steps 100 --warmup 10 --no-cpu-baseline --no-literal --no-modes --no-convert > $OUT/f16.log 2>&1)
+  (cd /tmp && VAENPVC_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rp_f16 -- python $ROOT/bench.py --frames 16 --steps 100 --warmup 10 --no-cpu-baseline --no-literal --no-modes --no-convert --no-traffic > $OUT/f16.log 2>&1)
   db=$(find /tmp/rp_f16 -name '*.db' | head -1); [ -n "$db" ] && python $ROOT/scripts/rocpd_stats.py $db 70 > $OUT/${TAG}_kernel_trace_stats_F16.txt
   # VAWGAN branch (config 5): wall times and kernel trace at 16 and 256 frames
   for VF in 16 256; do

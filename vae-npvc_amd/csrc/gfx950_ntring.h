@@ -288,6 +288,20 @@ __global__ void __launch_bounds__(256) k_cgemm_sf_ring(CgSfArgs b) {
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) boffs[j] = (unsigned)(8 * (wave + 4 * j) + (lane >> 3)) * (unsigned)(a.Kp * 2) + dpc * 16;
+  // (fetched BEFORE the K loop: 48 per-lane loads right behind it were an exposed round trip per tile)
+  // per-lane constants of the frame pass: lane owns the 8-element pieces lane, lane + 64 of a frame's 896 = 112 x 8 elements;
+  // element e = (channel e / 7, position e % 7)
+  constexpr int P8 = SFR_FOUT / 8, PPL = cdiv(P8, 64);
+  float gm[PPL][8], bt[PPL][8], bs[PPL][8];
+#pragma unroll
+  for (int u = 0; u < PPL; ++u)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int pc = lane + 64 * u, e = (pc < P8 ? pc : 0) * 8 + k, ch = e / SFR_R;
+      gm[u][k] = b.gamma[ch];
+      bt[u][k] = b.beta[ch];
+      bs[u][k] = a.bias ? a.bias[ch] : 0.f;
+    }
   f32x16 acc[4][2];
   nr_mainloop<4, 2>(smem, reinterpret_cast<const unsigned char*>(a.X), reinterpret_cast<const unsigned char*>(a.W), (size_t)a.x_plane * 2,
                     (size_t)a.w_plane * 2, aoffs, boffs, a.Kp / NR_BK, acc);
@@ -303,71 +317,78 @@ __global__ void __launch_bounds__(256) k_cgemm_sf_ring(CgSfArgs b) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) ot[fl * SFR_FPITCH + (64 * wn + 32 * u + l31) * SFR_R + q] = acc[t][u][reg];
     }
-  // per-lane constants of the frame pass: lane owns the 8-element pieces lane, lane + 64 of a frame's 896 = 112 x 8 elements;
-  // element e = (channel e / 7, position e % 7)
-  constexpr int P8 = SFR_FOUT / 8, PPL = cdiv(P8, 64);
-  float gm[PPL][8], bt[PPL][8], bs[PPL][8];
-#pragma unroll
-  for (int u = 0; u < PPL; ++u)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int pc = lane + 64 * u, e = (pc < P8 ? pc : 0) * 8 + k, ch = e / SFR_R;
-      gm[u][k] = b.gamma[ch];
-      bt[u][k] = b.beta[ch];
-      bs[u][k] = a.bias ? a.bias[ch] : 0.f;
-    }
   __syncthreads();
   const int nf = min(SFR_TF, b.F - f0);
   constexpr float INVN = 1.0f / SFR_FOUT;
-  for (int fl = wave; fl < nf; fl += 4) {
-    const int f = f0 + fl;
-    float v[PPL][8];
-    float sm = 0.f;
+  // THREE frames of a wave at a time (frames wave, wave + 4, wave + 8 of every dozen): a frame is a dependent chain LDS read -> sum -> wave
+  // reduction -> centred squares -> wave reduction -> stores (~2.5 us), and with one wave per SIMD nothing else hides it -- nine frames in a row
+  // were most of this kernel's time (7 K chunks per tile: 10 us of MFMAs against ~25 us of frame pass).  The fragment registers are dead here.
+  constexpr int NB3 = 3;
+  for (int fb = wave; fb < SFR_TF; fb += 4 * NB3) {
+    if (fb >= nf) break;                              // (uniform per wave)
+    float v[NB3][PPL][8], mean[NB3], rstd[NB3];
+    float sm[NB3], q2[NB3];
 #pragma unroll
-    for (int u = 0; u < PPL; ++u) {
-      const int pc = lane + 64 * u;
-      const bool ok = pc < P8;
-      const f32x4 t0 = *reinterpret_cast<const f32x4*>(ot + fl * SFR_FPITCH + (ok ? pc : 0) * 8);
-      const f32x4 t1 = *reinterpret_cast<const f32x4*>(ot + fl * SFR_FPITCH + (ok ? pc : 0) * 8 + 4);
+    for (int r = 0; r < NB3; ++r) {
+      const int fl = min(fb + 4 * r, SFR_TF - 1);     // (frames past the tile's last: a duplicate, never stored)
+      sm[r] = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        v[u][k] = ok ? t0[k] + bs[u][k] : 0.f;
-        v[u][4 + k] = ok ? t1[k] + bs[u][4 + k] : 0.f;
-      }
+      for (int u = 0; u < PPL; ++u) {
+        const int pc = lane + 64 * u;
+        const bool ok = pc < P8;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(ot + fl * SFR_FPITCH + (ok ? pc : 0) * 8);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(ot + fl * SFR_FPITCH + (ok ? pc : 0) * 8 + 4);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) sm += v[u][k];
-    }
-    const float mean = wave_sum(sm) * INVN;
-    float q2 = 0.f;
+        for (int k = 0; k < 4; ++k) {
+          v[r][u][k] = ok ? t0[k] + bs[u][k] : 0.f;
+          v[r][u][4 + k] = ok ? t1[k] + bs[u][4 + k] : 0.f;
+        }
 #pragma unroll
-    for (int u = 0; u < PPL; ++u) {
-      const bool ok = lane + 64 * u < P8;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float d = v[u][k] - mean;
-        q2 += ok ? d * d : 0.f;
+        for (int k = 0; k < 8; ++k) sm[r] += v[r][u][k];
       }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(q2) * INVN + LN_EPS);
-    if (lane == 0) {
-      b.st[2 * f] = mean;
-      b.st[2 * f + 1] = rstd;
+#pragma unroll
+    for (int r = 0; r < NB3; ++r) mean[r] = wave_sum(sm[r]) * INVN;
+#pragma unroll
+    for (int r = 0; r < NB3; ++r) {
+      q2[r] = 0.f;
+#pragma unroll
+      for (int u = 0; u < PPL; ++u) {
+        const bool ok = lane + 64 * u < P8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float d = v[r][u][k] - mean[r];
+          q2[r] += ok ? d * d : 0.f;
+        }
+      }
     }
-    float* og = a.out + (int64_t)f * SFR_FOUT;
 #pragma unroll
-    for (int u = 0; u < PPL; ++u) {
-      const int pc = lane + 64 * u;
-      if (pc >= P8) continue;
-      *reinterpret_cast<f32x4*>(og + pc * 8) = f32x4{v[u][0], v[u][1], v[u][2], v[u][3]};
-      *reinterpret_cast<f32x4*>(og + pc * 8 + 4) = f32x4{v[u][4], v[u][5], v[u][6], v[u][7]};
-      if (b.planes) {   // uniform
-        float y8[8];
+    for (int r = 0; r < NB3; ++r) rstd[r] = 1.0f / sqrtf(wave_sum(q2[r]) * INVN + LN_EPS);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) y8[k] = lnact_v(v[u][k], mean, rstd, gm[u][k], bt[u][k]);
-        u32x4 pk[2];
-        pack8<2>(y8, pk);
+    for (int r = 0; r < NB3; ++r) {
+      const int fl = fb + 4 * r;
+      if (fl >= nf) continue;                         // (uniform per wave)
+      const int f = f0 + fl;
+      if (lane == 0) {
+        b.st[2 * f] = mean[r];
+        b.st[2 * f + 1] = rstd[r];
+      }
+      float* og = a.out + (int64_t)f * SFR_FOUT;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(b.planes + ((int64_t)p * b.F + f) * SFR_FOUT + pc * 8) = pk[p];
+      for (int u = 0; u < PPL; ++u) {
+        const int pc = lane + 64 * u;
+        if (pc >= P8) continue;
+        *reinterpret_cast<f32x4*>(og + pc * 8) = f32x4{v[r][u][0], v[r][u][1], v[r][u][2], v[r][u][3]};
+        *reinterpret_cast<f32x4*>(og + pc * 8 + 4) = f32x4{v[r][u][4], v[r][u][5], v[r][u][6], v[r][u][7]};
+        if (b.planes) {   // uniform
+          float y8[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) y8[k] = lnact_v(v[r][u][k], mean[r], rstd[r], gm[u][k], bt[u][k]);
+          u32x4 pk[2];
+          pack8<2>(y8, pk);
+#pragma unroll
+          for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(b.planes + ((int64_t)p * b.F + f) * SFR_FOUT + pc * 8) = pk[p];
+        }
       }
     }
   }
