@@ -2,8 +2,9 @@
 // per CU, ONE wave per SIMD with a (32 TM) x (32 TN) wave tile, operands by LDS-DMA (global_load_lds_dwordx4, inline assembly, counted
 // vmcnt) into a ring of per-(operand, plane) K chunks, one bare s_barrier per PHASE, one piece of side work (a fragment read or a request)
 // behind each MFMA.  Users:
-//   k_gemm_nt_ring   (TM, TN = 4, 2: 256 x 128 tiles) the K-long dense-shaped sites of k_gemm_nt: encoder layer 4 as a dense layer, forward +
-//                    input gradient, and the heads' forward GEMM (model/vae.py:79-82, util/layers.py:56-64);
+//   k_gemm_nt_ring   (TM, TN = 4, 2: 256 x 128 tiles) every two-plane C = A B^T launch with K >= 256, no speaker table and >= 128 tiles: encoder
+//                    layer 4 as a dense layer and the heads, forward + input gradient, and the merge input gradient (model/vae.py:51-61,79-82,
+//                    util/layers.py:56-64); the gains are at the K-long sites (K = 768 / 896), K = 256 and the one-column-tile merge site run equal;
 //   k_cgemm_sf_ring  (4, 2) encoder layer 3 forward as a view GEMM whose 252-row tile owns 36 WHOLE frames, with the layer's LayerNorm
 //                    statistics and activated operand planes in its epilogue (the successor of k_cgemm_sf; util/layers.py:47-66).
 //
