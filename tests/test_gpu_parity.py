@@ -418,7 +418,8 @@ def test_ring_gemm_dense_layers_against_oracle(F, seed, monkeypatch):
     ragged batches (one 256-row tile holding 1 / 37 / 130 rows, two tiles with 1 row in the second, five with 3): every tensor and gradient
     against the float64 oracle; the kernel must have run (the six C = A B^T sites are then split between it and k_gemm_nt)."""
     monkeypatch.setenv('VAENPVC_NT_RING', '2')
-    monkeypatch.setenv('VAENPVC_CG_SF_RING', '2')        # encoder layer 3 forward on the same main loop (36 whole frames per tile)
+    monkeypatch.setenv('VAENPVC_CG_SF_RING', '2')
+    monkeypatch.setenv('VAENPVC_CG_PF_RING', '2')        # ... and its input gradient + layer 2's LayerNorm backward on the (3, 3) instance (24 frames per tile)        # encoder layer 3 forward on the same main loop (36 whole frames per tile)
     eng = make_engine('vcc', 'auto', masks=(PLANE_GEMM[0] & VIEW_CONV_BITS, PLANE_GEMM[1] & VIEW_CONV_BITS), precision='bf16x2')
     fails = compare_everything(eng, F, seed, 'nt_ring F%d ' % F)
     assert not fails, '\n'.join(fails)

@@ -399,5 +399,152 @@ inline void launch_cgemm_sf_ring(const CgSfArgs& b, hipStream_t s) {
   hipLaunchKernelGGL(k_cgemm_sf_ring, dim3((unsigned)cdiv(b.F, SFR_TF)), dim3(256), SFR_LDS, s, b);
 }
 
+// ---------------------------------------------------------------- encoder layer 3 input gradient + LayerNorm backward of layer 2 (successor of k_cgemm_pf<LNB>)
+// The P-type view GEMM of CV_E3G (gfx950_viewconv.h: 3 output phases x 64 channels = 192 weight rows, K = 3 taps x 128 = 384 = 6 chunks, 8 view rows per
+// frame) on the (3, 3) instance of the main loop: the ring's ROWS = the view rows of 24 WHOLE frames (192), its COLUMNS = the 192 stacked weight rows,
+// wave tiles of 96 x 96.  Epilogue as k_cgemm_pf<LNB>: the tile re-ordered through LDS into [frame][channel][position] (pitch 1 224 floats), then the
+// LayerNorm + lrelu backward of encoder layer 2 (autodiff of util/layers.py:32-44,149) on the frames in LDS, one wave per frame: a.out receives d(pre-LN
+// output of layer 2), the per-channel sums leave as one row of `part` per workgroup.
+constexpr int PFR_TF = 24, PFR_R = 8, PFR_C = 64, PFR_OH = 19, PFR_FOUT = PFR_C * PFR_OH, PFR_FPITCH = PFR_FOUT + 8;
+constexpr int PFR_EP_LDS = PFR_TF * PFR_FPITCH * 4;    // 117 504
+constexpr int PFR_LDS = NrCfg<3, 3>::RING > PFR_EP_LDS ? NrCfg<3, 3>::RING : PFR_EP_LDS;
+static_assert(4 * 3 * PFR_FOUT * 4 <= PFR_LDS, "the per-element sums of four waves fit the LDS");
+inline bool cgemm_pf_ring_serves(const CgArgs& a) {
+  return a.M == 192 && a.mdiv == 64 && a.C == 64 && a.xv.R == 8 && a.OH == 19 && a.om == 19 && a.ofs == 64 * 19 && a.oq == 3 && a.o0s == 1 && !a.bias &&
+         a.Kp % NR_BK == 0 && a.Kp >= 4 * NR_BK && a.N % 8 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && (a.xv.step % 8) == 0 &&
+         (a.xv.fs % 8) == 0 && (a.xv.x0 % 8) == 0;
+}
+__global__ void __launch_bounds__(256) k_cgemm_pf_ring(CgArgs a, CgLnbArgs lb) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_contiguous(blockIdx.x, gridDim.x), f0 = tile * PFR_TF, n0 = f0 * PFR_R;
+  const int nf = min(PFR_TF, a.N / PFR_R - f0);
+  const int dpc = nr_dma_piece(wave, lane);
+  unsigned aoffs[6], boffs[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    int r = n0 + 8 * (wave + 4 * j) + (lane >> 3);
+    r = r < a.N ? r : a.N - 1;                        // rows past the end: duplicates, never stored
+    aoffs[j] = (unsigned)(view_off(a.xv, r) * 2) + dpc * 16;
+    boffs[j] = (unsigned)(8 * (wave + 4 * j) + (lane >> 3)) * (unsigned)(a.Kp * 2) + dpc * 16;
+  }
+  f32x16 acc[3][3];
+  nr_mainloop<3, 3>(smem, reinterpret_cast<const unsigned char*>(a.X), reinterpret_cast<const unsigned char*>(a.W), (size_t)a.x_plane * 2,
+                    (size_t)a.w_plane * 2, aoffs, boffs, a.Kp / NR_BK, acc);
+  // ---- LayerNorm operands of this wave's frames (fl = wave + 4 k): requested before the tile is re-ordered, so the loads fly under the LDS traffic
+  float* ot = reinterpret_cast<float*>(smem);
+  constexpr int P16 = PFR_FOUT / 4, PPL = cdiv(P16, 64), FPW = PFR_TF / 4;   // 16-byte pieces per frame / per lane; frames per wave
+  f32x4 av[FPW][PPL];
+  float gm[PPL][4], bt[PPL][4], fmean[FPW], frstd[FPW];
+#pragma unroll
+  for (int k = 0; k < FPW; ++k) {
+    const int f = min(f0 + wave + 4 * k, f0 + nf - 1);
+    fmean[k] = lb.st[2 * f];
+    frstd[k] = lb.st[2 * f + 1];
+#pragma unroll
+    for (int u = 0; u < PPL; ++u) {
+      const int pc = min(lane + 64 * u, P16 - 1);
+      av[k][u] = *reinterpret_cast<const f32x4*>(lb.a2 + (int64_t)f * PFR_FOUT + pc * 4);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PPL; ++u)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ch = (min(lane + 64 * u, P16 - 1) * 4 + k) / PFR_OH;
+      gm[u][k] = lb.gamma[ch];
+      bt[u][k] = lb.beta[ch];
+    }
+  // ---- the tile as [frame][channel][position] fp32: ring row = (frame fl, view row q), ring column = phase * 64 + channel, position = 3 q + o0 + phase
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int rl = 96 * wm + 32 * t + acc_row(reg, lane);
+      const int fl = rl / PFR_R, q = rl - fl * PFR_R;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int col = 96 * wn + 32 * u + l31, ph = col >> 6, ch = col & 63;
+        const int pos = q * a.oq + a.o0 + ph;
+        if (pos >= 0 && pos < PFR_OH) ot[fl * PFR_FPITCH + ch * PFR_OH + pos] = acc[t][u][reg];
+      }
+    }
+  __syncthreads();
+  constexpr float INVN = 1.0f / PFR_FOUT;
+  float su[PPL][4], sw[PPL][4], sd[PPL][4];
+#pragma unroll
+  for (int u = 0; u < PPL; ++u)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) su[u][k] = sw[u][k] = sd[u][k] = 0.f;
+#pragma unroll
+  for (int kf = 0; kf < FPW; ++kf) {
+    const int fl = wave + 4 * kf;
+    if (fl >= nf) break;       // (uniform per wave)
+    const float mean = fmean[kf], rstd = frstd[kf];
+    float dn[PPL][4], xh[PPL][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < PPL; ++u) {
+      const int pc = lane + 64 * u;
+      const bool ok = pc < P16;
+      const f32x4 dy = *reinterpret_cast<const f32x4*>(ot + fl * PFR_FPITCH + (ok ? pc : 0) * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        xh[u][k] = (av[kf][u][k] - mean) * rstd;
+        const float nn = xh[u][k] * gm[u][k] + bt[u][k];
+        dn[u][k] = ok ? dy[k] * (nn >= 0.f ? 1.0f : LEAK) : 0.f;
+        const float dx = dn[u][k] * gm[u][k];
+        s1 += dx;
+        s2 += dx * xh[u][k];
+      }
+    }
+    s1 = wave_sum(s1) * INVN;
+    s2 = wave_sum(s2) * INVN;
+    float* og = a.out + (int64_t)(f0 + fl) * PFR_FOUT;
+#pragma unroll
+    for (int u = 0; u < PPL; ++u) {
+      const int pc = lane + 64 * u;
+      if (pc >= P16) continue;
+      f32x4 d;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        d[k] = rstd * (dn[u][k] * gm[u][k] - s1 - xh[u][k] * s2);
+        su[u][k] += dn[u][k] * xh[u][k];
+        sw[u][k] += dn[u][k];
+        sd[u][k] += d[k];
+      }
+      *reinterpret_cast<f32x4*>(og + pc * 4) = d;
+    }
+  }
+  __syncthreads();    // every wave is done with the tile: the LDS now carries the per-element sums [wave][3][FOUT]
+  float* ps = ot + wave * (3 * PFR_FOUT);
+#pragma unroll
+  for (int u = 0; u < PPL; ++u) {
+    const int pc = lane + 64 * u;
+    if (pc >= P16) continue;
+    *reinterpret_cast<f32x4*>(ps + pc * 4) = f32x4{su[u][0], su[u][1], su[u][2], su[u][3]};
+    *reinterpret_cast<f32x4*>(ps + PFR_FOUT + pc * 4) = f32x4{sw[u][0], sw[u][1], sw[u][2], sw[u][3]};
+    *reinterpret_cast<f32x4*>(ps + 2 * PFR_FOUT + pc * 4) = f32x4{sd[u][0], sd[u][1], sd[u][2], sd[u][3]};
+  }
+  __syncthreads();
+  if (tid < 3 * PFR_C) {
+    const int which = tid / PFR_C, c = tid - which * PFR_C;
+    float v = 0.f;
+#pragma unroll
+    for (int w4 = 0; w4 < 4; ++w4)
+      for (int h = 0; h < PFR_OH; ++h) v += ot[w4 * (3 * PFR_FOUT) + which * PFR_FOUT + c * PFR_OH + h];
+    lb.part[(int64_t)blockIdx.x * (3 * PFR_C) + tid] = v;
+  }
+}
+// returns the number of rows written to lb.part
+inline int launch_cgemm_pf_ring_lnb(const CgArgs& a, const CgLnbArgs& lb, hipStream_t s) {
+  const int nwg = cdiv(a.N / PFR_R, PFR_TF);
+  rt().ensure_lds(reinterpret_cast<const void*>(&k_cgemm_pf_ring), PFR_LDS);
+  hipLaunchKernelGGL(k_cgemm_pf_ring, dim3((unsigned)nwg), dim3(256), PFR_LDS, s, a, lb);
+  return nwg;
+}
+
 }  // namespace tuned
 }  // namespace vaenpvc

@@ -857,6 +857,9 @@ struct CgArgs;
 struct CgSfArgs;
 inline bool cgemm_sf_ring_serves(const CgArgs& a);
 inline void launch_cgemm_sf_ring(const CgSfArgs& b, hipStream_t s);
+struct CgLnbArgs;
+inline bool cgemm_pf_ring_serves(const CgArgs& a);
+inline int launch_cgemm_pf_ring_lnb(const CgArgs& a, const CgLnbArgs& lb, hipStream_t s);
 inline bool gemm_nt_ar_serves(const NtArgs& a);
 template <int NPL>
 inline void launch_gemm_nt_ar(const NtArgs& a, hipStream_t s);

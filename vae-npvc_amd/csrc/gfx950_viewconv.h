@@ -282,6 +282,11 @@ static int cv_gemm_lnb(int site, const float* wplanes, const float* xplanes, flo
   if constexpr (NPL <= 2) {
     const CgArgs a = cv_gemm_args(site, wplanes, xplanes, out, nullptr, F);
     if (!cgemm_pf_serves(a) || (int64_t)cdiv(a.N, CgPfTile<NPL>::BN) * 3 * 64 > part_capacity) return 0;
+    if constexpr (NPL == 2) {
+      // the (3, 3) ring kernel, 24 whole frames per tile (gfx950_ntring.h; VAENPVC_CG_PF_RING: 1 = from 6 144 frames on, 2 = always, 0 = never)
+      if (rt().cg_pf_ring && (rt().cg_pf_ring > 1 || F >= 24 * 256) && cgemm_pf_ring_serves(a))
+        return launch_cgemm_pf_ring_lnb(a, CgLnbArgs{a2, st, gamma, beta, part}, s);
+    }
     return launch_cgemm_pf_lnb<NPL>(a, CgLnbArgs{a2, st, gamma, beta, part}, s);
   }
   return 0;

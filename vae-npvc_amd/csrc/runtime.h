@@ -61,6 +61,7 @@ struct Runtime {
                                 // 256 x 128 on, 2 = whenever the shape is served (parity tests), 0 = never
   int cg_sf_ring = 1;           // (2: at any batch size -- parity tests; 1: from 9 216 frames on = one 36-frame tile per CU)  VAENPVC_CG_SF_RING=0: encoder layer 3 forward on k_cgemm_sf (two-barrier loop, 18 frames per tile) instead of the ring kernel's main loop
                                 // (k_cgemm_sf_ring, 36 whole frames per tile: 166 -> 155 us, round 6; A/B)
+  int cg_pf_ring = 0;           // VAENPVC_CG_PF_RING: encoder layer 3's input gradient (+ layer 2's LayerNorm backward) on the (3, 3) ring kernel, 24 whole frames per tile
   bool nt_lep = true;           // VAENPVC_NT_LEP=0: C = A B^T results stored straight from the accumulators (4 bytes per lane) instead of through LDS (A/B)
   bool dy2_pad = true;          // VAENPVC_DY2_PAD=0: the 1025-tap layer's input gradient in the tensor's own 513-float rows (unaligned 16-byte stores; A/B)
   bool e2_osp = true;           // VAENPVC_E2_OSP=0: statistics + activated planes of encoder layer 2's output in their own pass (A/B)

@@ -47,6 +47,7 @@ void Runtime::read_env() {
   if (const char* e = getenv("VAENPVC_NT_LEP")) nt_lep = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_NT_RING")) nt_ring = atoi(e);
   if (const char* e = getenv("VAENPVC_CG_SF_RING")) cg_sf_ring = atoi(e);
+  if (const char* e = getenv("VAENPVC_CG_PF_RING")) cg_pf_ring = atoi(e);
   if (const char* e = getenv("VAENPVC_NT_AR")) nt_ar = atoi(e);
   if (const char* e = getenv("VAENPVC_CG_LNB")) cg_lnb = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_CG_SF")) cg_sf = atoi(e) != 0;
