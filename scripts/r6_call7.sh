@@ -1,4 +1,5 @@
 #!/bin/bash
+# (variant libraries: for v in 1 2 4 8; do scripts/build_variant.sh nrabl$v "-DVAENPVC_NR_ABL=$v"; done)
 # ring GEMM: main-loop ablations (variant libraries -DVAENPVC_NR_ABL=n) and PMC counters of the new loop against the old one
 set -u
 OUT=$(pwd)/gpurun_out/r6c7; mkdir -p $OUT
