@@ -522,18 +522,18 @@ __global__ void __launch_bounds__(256, (NPL == 1 && !LNA ? 2 : 1)) k_toep_gemm_b
   }
   // fp32 pieces of chunk (c, kc) -> raw.  The last chunk's pieces 20 (bins 512 .. 519: only bin 512 exists) and 21 (padding) read bins 505 .. 512
   // instead: no access leaves the frame's row set; the conversion picks bin 512 out of element 7
-  auto gload_lna = [&](int c, int kc) __attribute__((always_inline)) {
+  auto gload_lna = [&](int c, int kc, int i0 = 0, int i1 = LN_NPC) __attribute__((always_inline)) {   // piece slots [i0, i1)
     if constexpr (LNA) {
       const float* ab = ln.a + (int64_t)f0 * (TB_C * TB_H) + c * TB_H + kc * DG_KC;
 #pragma unroll
-      for (int i = 0; i < LN_NPC; ++i) {
+      for (int i = i0; i < i1; ++i) {
         const int back = (kc == DG_NKC - 1 && ln_pc[i] >= 20) ? (ln_pc[i] == 20 ? 7 : 15) : 0;
         const float* p = ab + ln_aoff[i] - back;
         const packed4 p0 = *reinterpret_cast<const packed4*>(p), p1 = *reinterpret_cast<const packed4*>(p + 4);
         raw[i][0] = p0.x; raw[i][1] = p0.y; raw[i][2] = p0.z; raw[i][3] = p0.w;
         raw[i][4] = p1.x; raw[i][5] = p1.y; raw[i][6] = p1.z; raw[i][7] = p1.w;
       }
-      if (kc == DG_NKC - 1 && tid < DG_M) {
+      if (i1 == LN_NPC && kc == DG_NKC - 1 && tid < DG_M) {   // (with the second half of a channel's last chunk: one chunk before convert_special uses it)
         const int fr = f0 + tid < F ? tid : F - 1 - f0;
         sp_a512 = ln.a[((int64_t)(f0 + fr) * TB_C + c) * TB_H + (TB_H - 1)];
       }
@@ -609,7 +609,14 @@ __global__ void __launch_bounds__(256, (NPL == 1 && !LNA ? 2 : 1)) k_toep_gemm_b
       }
     }
   };
-  constexpr int LN_S0 = 44 - 4 * LN_NPC;   // first (k-step, column tile) step of a chunk that carries a conversion pair: the last 24 of its 44 steps
+  // Conversion schedule (round 6, last version): the 24 pairs of the NEXT chunk are spread over ALL 44 (k-step, column tile) steps of the chunk being
+  // multiplied -- pair p at step floor(44 p / 24) -- so a step carries ~10 vector instructions beside its 6 MFMAs instead of ~18 in the last 24
+  // steps (a wave hides ~5 other instructions per MFMA; the fragment reads already use 1 - 2).  The fp32 pieces arrive in two halves on ONE set
+  // of staging registers: piece slots 0 - 2 (converted in steps 0 - 20) are refilled at step 22 with the chunk AFTER next, slots 3 - 5 (converted
+  // in steps 22 - 42) at step 0 with the next chunk: every load has half a chunk (~2 us) to land.
+  constexpr int LN_NP2 = 4 * LN_NPC;   // pairs per chunk
+  auto ln_pair_at = [](int step) constexpr { for (int p = 0; p < 24; ++p) if ((44 * p) / 24 == step) return p; return -1; };
+  static_assert(LN_NP2 == 24, "schedule written for six piece slots");
 
   // staging map: thread -> (row = tid >> 2, part = tid & 3) copies the 16-byte pieces part + 4*q
   // (q < 6; a row of a chunk has 22 pieces) of all three planes: every address is a per-thread
@@ -700,6 +707,7 @@ __global__ void __launch_bounds__(256, (NPL == 1 && !LNA ? 2 : 1)) k_toep_gemm_b
 #pragma unroll
       for (int q = 0; q < 4; ++q) convert_pair(i, q, chan(c_lo), 0, true);   // the first chunk: once per workgroup, serial
     unsigned char* t_ = sA; sA = sAn; sAn = t_;   // (visible behind the barrier at the top of the channel loop + the one behind the tap copies)
+    gload_lna(chan(c_lo), 1 < DG_NKC ? 1 : 0, 0, LN_NPC / 2);   // first half of the second chunk (steady state: requested at step 22 of the chunk in front)
   } else gload(chan(c_lo), 0);
   // tap copies of a channel: the global loads are issued one channel ahead, BEFORE the epilogue stores of the channel
   // in front (vector memory completes in order and loads and stores share one counter on this ISA: loads issued behind
@@ -749,8 +757,11 @@ __global__ void __launch_bounds__(256, (NPL == 1 && !LNA ? 2 : 1)) k_toep_gemm_b
       const int kn = kc + 1 < DG_NKC ? kc + 1 : 0;
       const int cn = kc + 1 < DG_NKC ? c : (ci + 1 < c_hi ? chan(ci + 1) : c);
       const bool nlive = kc + 1 < DG_NKC || ci + 1 < c_hi;   // (false: the wrap-around prefetch behind the last chunk)
+      // ... and the chunk after next (LNA: its first half is requested in the middle of this chunk)
+      const int kn2 = kn + 1 < DG_NKC ? kn + 1 : 0;
+      const int cn2 = kn + 1 < DG_NKC ? cn : ((kc + 1 < DG_NKC ? ci : ci + 1) + 1 < c_hi ? chan((kc + 1 < DG_NKC ? ci : ci + 1) + 1) : cn);
       if constexpr (LNA) {
-        gload_lna(cn, kn);
+        gload_lna(cn, kn, LN_NPC / 2, LN_NPC);      // second half of the next chunk
         convert_begin(lnpar[cn], lnpar[TB_C + cn]);
       } else gload(cn, kn);
       __builtin_amdgcn_sched_barrier(0);
@@ -771,12 +782,14 @@ __global__ void __launch_bounds__(256, (NPL == 1 && !LNA ? 2 : 1)) k_toep_gemm_b
           mm(sa, sb, nb);
           if constexpr (LNA) {   // one conversion pair of the NEXT chunk in the shadow of this step's MFMAs
             constexpr int NMM = 2 * Prod<NPL>::N;
-            if (4 * ks + nb >= LN_S0) {
-              convert_pair((4 * ks + nb - LN_S0) >> 2, (4 * ks + nb - LN_S0) & 3, cn, kn, nlive);
+            const int pr = ln_pair_at(4 * ks + nb);
+            if (4 * ks + nb == 22) gload_lna(cn2, kn2, 0, LN_NPC / 2);   // slots 0 - 2 are converted: first half of the chunk after next
+            if (pr >= 0) {
+              convert_pair(pr >> 2, pr & 3, cn, kn, nlive);
 #pragma unroll
               for (int _m = 0; _m < NMM; ++_m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, (NMM >= 12 ? 3 : NMM >= 6 ? 5 : 12), 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (NMM >= 12 ? 2 : NMM >= 6 ? 4 : 12), 0);
               }
             }
           }
