@@ -870,7 +870,7 @@ __global__ void __launch_bounds__(256, (NPL == 1 && !LNA ? 2 : 1)) k_toep_gemm_b
 #if VAENPVC_PROF
   {
     TBPROF_T(k1);
-    if ((threadIdx.x & 63) == 0) {
+    if (!FWD && (threadIdx.x & 63) == 0) {   // (the input gradient only: the forward instances would add into the same sums)
       atomicAdd(g_tb_prof + 0, 1ull);
       for (int i = 0; i < 4; ++i) atomicAdd(g_tb_prof + 1 + i, (unsigned long long)pc[i]);
       atomicAdd(g_tb_prof + 5, (unsigned long long)(k1 - k0));
