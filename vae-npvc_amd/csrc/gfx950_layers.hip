@@ -954,7 +954,9 @@ bool loss_fwd_post(const Model& m, const float* P, const float* x, int64_t F64, 
   if (!VAENPVC_NLL_POST || !w.d_xh || !w.toep_gp || !w.dy_tmp || !w.dec_y || !w.d_dec_a[0] || !fwd_on(9) || !fwd_on(10) || F < 1024 || frame_bwd_on(F64) || !bwd_on(10) || !toep_bf16_for(F) || act_bf16(F)) return false;
   for_planes([&](auto npl) {
     constexpr int NPL = decltype(npl)::value;
-    hipLaunchKernelGGL((k_nll_dxh_post<NPL>), dim3((unsigned)nll_post_blocks(F)), dim3(256), 0, s, x, w.xh, w.nll_f, w.d_xh, P + m.dec[3].w_off,
+    // (d(xh) as fp32 has no reader when the weight-gradient GEMM takes the planes too: 67 MB per step not written)
+    hipLaunchKernelGGL((k_nll_dxh_post<NPL>), dim3((unsigned)nll_post_blocks(F)), dim3(256), 0, s, x, w.xh, w.nll_f,
+                       rt().dxh_skip && toep_wgrad_bf16_for(F) ? nullptr : w.d_xh, P + m.dec[3].w_off,
                        reinterpret_cast<unsigned short*>(w.toep_gp), w.dy_tmp, w.scratch + Pk::lnpart, F, 1.0f / (float)F, w.dec_y,
                        w.d_dec_a[0],    // (the edge-term parts wait in d(a0)'s buffer: nothing writes it before the backward pass has added them)
                        dy2_pitch(F));

@@ -289,13 +289,13 @@ __global__ void __launch_bounds__(256) k_nll_dxh_post(const float* __restrict__ 
     }
     const float gt = dt * gs;
     nl = wave_sum(nl);
-    float* gf = G + (int64_t)f * TB_H;
-    *reinterpret_cast<packed4*>(gf + 8 * lane) = packed4{g[0], g[1], g[2], g[3]};
-    *reinterpret_cast<packed4*>(gf + 8 * lane + 4) = packed4{g[4], g[5], g[6], g[7]};
-    if (lane == 0) {
-      gf[512] = gt;
-      nll_f[f] = nl;
+    if (G) {   // (uniform; nullptr: only the planes below are read downstream)
+      float* gf = G + (int64_t)f * TB_H;
+      *reinterpret_cast<packed4*>(gf + 8 * lane) = packed4{g[0], g[1], g[2], g[3]};
+      *reinterpret_cast<packed4*>(gf + 8 * lane + 4) = packed4{g[4], g[5], g[6], g[7]};
+      if (lane == 0) gf[512] = gt;
     }
+    if (lane == 0) nll_f[f] = nl;
     unsigned tm[8][NPL];
     float dot[TB_C];
 #pragma unroll

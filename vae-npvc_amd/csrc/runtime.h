@@ -63,6 +63,7 @@ struct Runtime {
                                 // (k_cgemm_sf_ring, 36 whole frames per tile: 166 -> 155 us, round 6; A/B)
   int cg_pf_ring = 0;           // VAENPVC_CG_PF_RING: encoder layer 3's input gradient (+ layer 2's LayerNorm backward) on the (3, 3) ring kernel, 24 whole frames per tile
   bool nt_lep = true;           // VAENPVC_NT_LEP=0: C = A B^T results stored straight from the accumulators (4 bytes per lane) instead of through LDS (A/B)
+  bool dxh_skip = true;         // VAENPVC_DXH_SKIP=0: the loss kernel also stores d(xh) as fp32 (nothing reads it when both last-layer GEMMs take its bf16 planes; A/B)
   bool dy2_pad = true;          // VAENPVC_DY2_PAD=0: the 1025-tap layer's input gradient in the tensor's own 513-float rows (unaligned 16-byte stores; A/B)
   bool e2_osp = true;           // VAENPVC_E2_OSP=0: statistics + activated planes of encoder layer 2's output in their own pass (A/B)
   bool tn_d0fit = true;         // VAENPVC_TN_D0FIT=0: decoder layer 0's weight gradient on 128 x 256 tiles (36 % of the MFMA work useful) instead of 96 x 288 (A/B)

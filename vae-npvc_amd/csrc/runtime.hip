@@ -44,6 +44,7 @@ void Runtime::read_env() {
   if (const char* e = getenv("VAENPVC_TN_D0FIT")) tn_d0fit = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_E2_OSP")) e2_osp = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_DY2_PAD")) dy2_pad = atoi(e) != 0;
+  if (const char* e = getenv("VAENPVC_DXH_SKIP")) dxh_skip = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_NT_LEP")) nt_lep = atoi(e) != 0;
   if (const char* e = getenv("VAENPVC_NT_RING")) nt_ring = atoi(e);
   if (const char* e = getenv("VAENPVC_CG_SF_RING")) cg_sf_ring = atoi(e);
