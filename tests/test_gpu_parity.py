@@ -517,6 +517,28 @@ def test_the_separate_plane_producer_pass_still_serves(monkeypatch):
     assert not fails, '\n'.join(fails)
 
 
+@pytest.mark.parametrize('skip', ['1', '0'])
+def test_loss_kernel_with_and_without_the_fp32_copy_of_its_gradient(monkeypatch, skip):
+    """Round 6: from 1 024 frames on the loss kernel (k_nll_dxh_post) hands d(xh) to both GEMMs of the 1025-tap layer as bf16 planes; its fp32
+    copy in the workspace tensor `d_xh` has no reader then and is no longer stored (VAENPVC_DXH_SKIP=1, default).  Both settings at a ragged
+    large batch: every tensor and gradient against the float64 oracle; with 0 the tensor holds -(x - xh) / ((1 + 1e-6) F) (model/vae.py:120-125,
+    util/layers.py:159-167), with 1 it is left untouched."""
+    from hipvae import lib as L
+    monkeypatch.setenv('VAENPVC_DXH_SKIP', skip)
+    eng = make_engine('vcc', 'auto')
+    F, seed = 1027, 7
+    eng.ws_region(F, L.MODE_TRAIN, 'd_xh').fill_(123.0)
+    fails = compare_everything(eng, F, seed, 'dxh_skip=%s F%d ' % (skip, F))
+    P, x, y, eps, R = oracle_case(F, seed)
+    d = eng.ws_region(F, L.MODE_TRAIN, 'd_xh').cpu().numpy().reshape(F, 513)
+    if skip == '0':
+        want = -(np.asarray(x, np.float64).reshape(F, 513) - R['xh'].reshape(F, 513)) / ((1.0 + 1e-6) * F)
+        check('dxh_skip=0 d_xh', d, want, TOL_ACT, fails)
+    elif not (d == 123.0).all():
+        fails.append('dxh_skip=1: the fp32 copy of d(xh) was written')
+    assert not fails, '\n'.join(fails)
+
+
 @pytest.mark.parametrize('planes_out', ['1', '0'])
 def test_merge_gradient_operand_from_the_layer_above(monkeypatch, planes_out):
     """Decoder layer 0's input-gradient kernel writes d(h) as the bf16 operand planes of the two merge GEMMs itself (k_fconv_r<..., POUT>,
